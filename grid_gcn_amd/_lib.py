@@ -1,0 +1,76 @@
+"""ctypes binding of libgridgcn_hip.so (the C ABI of include/gridgcn.h).
+
+There is NO fallback: if the library is missing or fails to load, every operator raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgridgcn_hip.so")
+
+EXPORTS = [
+    "gridgcn_strerror", "gridgcn_abi_version",
+    "gridgcn_gridify_workspace_bytes", "gridgcn_gridify",
+    "gridgcn_gridify_knn_workspace_bytes", "gridgcn_gridify_knn",
+    "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
+    "gridgcn_ball_knn", "gridgcn_knn",
+    "gridgcn_batch_take", "gridgcn_batch_take_backward",
+]
+
+
+class GridParams(ctypes.Structure):
+    """struct gridgcn_grid_params (include/gridgcn.h) == GridifyParam (gridify-inl.h:58-87)."""
+    _fields_ = [("max_p_grid", ctypes.c_int32), ("max_o_grid", ctypes.c_int32),
+                ("kernel_size", ctypes.c_int32), ("stride", ctypes.c_int32),
+                ("loc", ctypes.c_int32), ("coord_shift", ctypes.c_float * 3),
+                ("voxel_size", ctypes.c_float * 3), ("grid_size", ctypes.c_int32 * 3),
+                ("seed", ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises RuntimeError (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libgridgcn_hip.so is not built (%s). Run `python -m grid_gcn_amd.build` "
+            "(needs hipcc). grid_gcn_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError("cannot load %s: %s (grid_gcn_amd has no CPU fallback)" % (LIB_PATH, e))
+    vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    pp = ctypes.POINTER(GridParams)
+    lib.gridgcn_strerror.restype = ctypes.c_char_p
+    lib.gridgcn_strerror.argtypes = [ci]
+    lib.gridgcn_abi_version.restype = ci
+    for name in ("gridgcn_gridify_workspace_bytes", "gridgcn_gridify_knn_workspace_bytes",
+                 "gridgcn_gridify_up_workspace_bytes"):
+        f = getattr(lib, name)
+        f.restype = ci
+        f.argtypes = [ci, ci, pp, ctypes.POINTER(cs)]
+    for name in ("gridgcn_gridify", "gridgcn_gridify_knn"):
+        f = getattr(lib, name)
+        f.restype = ci
+        f.argtypes = [vp, vp, ci, ci, pp, vp, vp, vp, vp, vp, vp, cs, vp]
+    lib.gridgcn_gridify_up.restype = ci
+    lib.gridgcn_gridify_up.argtypes = [vp, vp, vp, vp, ci, ci, pp, vp, vp, vp, cs, vp]
+    lib.gridgcn_ball_knn.restype = ci
+    lib.gridgcn_ball_knn.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp]
+    lib.gridgcn_knn.restype = ci
+    lib.gridgcn_knn.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_batch_take.restype = ci
+    lib.gridgcn_batch_take.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_batch_take_backward.restype = ci
+    lib.gridgcn_batch_take_backward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, load().gridgcn_strerror(rc).decode()))

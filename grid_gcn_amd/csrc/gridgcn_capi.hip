@@ -1,0 +1,180 @@
+// gridgcn_capi.hip -- the extern "C" boundary declared in include/gridgcn.h.
+// Argument checking mirrors the reference's CHECK_EQs (gridify-inl.h:174-182,
+// ball_k_nn.cc:34-42) and adds the limits this implementation relies on.
+#include "../../include/gridgcn.h"
+#include "gridgcn_index.h"
+
+int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
+                            const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
+                            float *centmsk, const int *centnum, hipStream_t st);
+int gg_launch_query_knn(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
+                        const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
+                        float *centmsk, const int *centnum, hipStream_t st);
+int gg_launch_query_up(const float *updata, const int *up_np, int B, int Nd, const GGGrid &gp,
+                       char *wsbase, const GGIndexWs &w, int *nebidx, float *nebmsk,
+                       hipStream_t st);
+int gg_ball_knn(const float *, const float *, const int *, const int *, int, int, int, int, float,
+                int *, hipStream_t);
+int gg_knn(const float *, const float *, const int *, const int *, int, int, int, int, int *,
+           hipStream_t);
+int gg_batch_take(const float *, const int *, int, int, int, int, float *, hipStream_t);
+int gg_batch_take_backward(const float *, const int *, int, int, int, int, float *, hipStream_t);
+
+static int fill_grid(const gridgcn_grid_params *p, int B, int N, bool up, GGGrid *gp)
+{
+    if (!p || B < 1 || N < 1) return GRIDGCN_EINVAL;
+    if (p->max_p_grid < 1 || p->max_p_grid > GG_PMAX) return GRIDGCN_EINVAL;
+    if (p->max_o_grid < 1) return GRIDGCN_EINVAL;
+    if (p->kernel_size < 1 || p->kernel_size > GG_KMAX || (p->kernel_size & 1) == 0)
+        return GRIDGCN_EINVAL;
+    long long G = 1;
+    for (int j = 0; j < 3; j++) {
+        if (p->grid_size[j] < 1 || !(p->voxel_size[j] > 0.0f)) return GRIDGCN_EINVAL;
+        G *= p->grid_size[j];
+        if (G >= (1ll << 24)) return GRIDGCN_EINVAL;  // the reference indexes voxels in fp32
+        gp->shift[j] = p->coord_shift[j];
+        gp->vs[j] = p->voxel_size[j];
+        gp->g[j] = p->grid_size[j];
+    }
+    const long long k3 = (long long)p->kernel_size * p->kernel_size * p->kernel_size;
+    if ((long long)B * G >= (1ll << 31) || (long long)B * N >= (1ll << 31)) return GRIDGCN_EINVAL;
+    if ((long long)B * p->max_o_grid * p->max_p_grid >= (1ll << 31)) return GRIDGCN_EINVAL;
+    if (up && (long long)B * N * k3 >= (1ll << 31)) return GRIDGCN_EINVAL;  // int threadindex
+    gp->G = (int)G;
+    gp->gxy = p->grid_size[0] * p->grid_size[1];
+    gp->P = p->max_p_grid;
+    gp->O = p->max_o_grid;
+    gp->k = p->kernel_size;
+    gp->k3 = (int)k3;
+    gp->loc = p->loc;
+    gp->seed = p->seed;
+    return GRIDGCN_OK;
+}
+
+extern "C" {
+
+const char *gridgcn_strerror(int code)
+{
+    switch (code) {
+    case GRIDGCN_OK: return "ok";
+    case GRIDGCN_EINVAL: return "invalid argument (shape/attribute outside the supported domain)";
+    case GRIDGCN_EWORKSPACE: return "workspace missing or too small";
+    case GRIDGCN_ELAUNCH: return "HIP launch failed";
+    default: return "unknown error";
+    }
+}
+
+int gridgcn_abi_version(void) { return 1; }
+
+int gridgcn_gridify_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes)
+{
+    GGGrid gp;
+    int rc = fill_grid(p, B, N, false, &gp);
+    if (rc || !bytes) return rc ? rc : GRIDGCN_EINVAL;
+    *bytes = gg_index_workspace_bytes(B, N, gp, true, nullptr);
+    return GRIDGCN_OK;
+}
+
+static int gridify_common(bool knn, const float *data, const int32_t *np, int B, int N,
+                          const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk,
+                          float *cent, float *centmsk, int32_t *centnum, void *ws,
+                          size_t ws_bytes, void *stream)
+{
+    GGGrid gp;
+    int rc = fill_grid(p, B, N, false, &gp);
+    if (rc) return rc;
+    if (!data || !np || !nebidx || !nebmsk || !cent || !centmsk || !centnum) return GRIDGCN_EINVAL;
+    GGIndexWs w;
+    size_t need = gg_index_workspace_bytes(B, N, gp, true, &w);
+    if (!ws || ws_bytes < need) return GRIDGCN_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    rc = gg_index_build(data, np, B, N, gp, true, centnum, (char *)ws, w, st);
+    if (rc) return rc;
+    if (knn)
+        return gg_launch_query_knn(data, B, N, gp, (char *)ws, w, nebidx, nebmsk, cent, centmsk,
+                                   centnum, st);
+    return gg_launch_query_gridify(data, B, N, gp, (char *)ws, w, nebidx, nebmsk, cent, centmsk,
+                                   centnum, st);
+}
+
+int gridgcn_gridify(const float *data, const int32_t *np, int B, int N,
+                    const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk, float *cent,
+                    float *centmsk, int32_t *centnum, void *ws, size_t ws_bytes, void *stream)
+{
+    return gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
+                          ws_bytes, stream);
+}
+
+int gridgcn_gridify_knn_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes)
+{
+    return gridgcn_gridify_workspace_bytes(B, N, p, bytes);
+}
+
+int gridgcn_gridify_knn(const float *data, const int32_t *np, int B, int N,
+                        const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk, float *cent,
+                        float *centmsk, int32_t *centnum, void *ws, size_t ws_bytes, void *stream)
+{
+    return gridify_common(true, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
+                          ws_bytes, stream);
+}
+
+int gridgcn_gridify_up_workspace_bytes(int B, int Nd, const gridgcn_grid_params *p, size_t *bytes)
+{
+    GGGrid gp;
+    int rc = fill_grid(p, B, Nd, true, &gp);
+    if (rc || !bytes) return rc ? rc : GRIDGCN_EINVAL;
+    *bytes = gg_index_workspace_bytes(B, Nd, gp, false, nullptr);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_gridify_up(const float *downdata, const float *updata, const int32_t *down_np,
+                       const int32_t *up_np, int B, int Nd, const gridgcn_grid_params *p,
+                       int32_t *nebidx, float *nebmsk, void *ws, size_t ws_bytes, void *stream)
+{
+    GGGrid gp;
+    int rc = fill_grid(p, B, Nd, true, &gp);
+    if (rc) return rc;
+    if (!downdata || !updata || !down_np || !up_np || !nebidx || !nebmsk) return GRIDGCN_EINVAL;
+    GGIndexWs w;
+    size_t need = gg_index_workspace_bytes(B, Nd, gp, false, &w);
+    if (!ws || ws_bytes < need) return GRIDGCN_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    rc = gg_index_build(downdata, down_np, B, Nd, gp, false, nullptr, (char *)ws, w, st);
+    if (rc) return rc;
+    return gg_launch_query_up(updata, up_np, B, Nd, gp, (char *)ws, w, nebidx, nebmsk, st);
+}
+
+int gridgcn_ball_knn(const float *unknown, const float *known, const int32_t *downnum,
+                     const int32_t *upnum, int B, int n, int m, int k, float radius, int32_t *idx,
+                     void *stream)
+{
+    if (!unknown || !known || !downnum || !upnum || !idx) return GRIDGCN_EINVAL;
+    if (B < 1 || n < 1 || m < 1 || k < 1 || k > 6) return GRIDGCN_EINVAL;  // best[6]
+    return gg_ball_knn(unknown, known, downnum, upnum, B, n, m, k, radius, idx,
+                       (hipStream_t)stream);
+}
+
+int gridgcn_knn(const float *unknown, const float *known, const int32_t *downnum,
+                const int32_t *upnum, int B, int n, int m, int k, int32_t *idx, void *stream)
+{
+    if (!unknown || !known || !downnum || !upnum || !idx) return GRIDGCN_EINVAL;
+    if (B < 1 || n < 1 || m < 1 || k < 1 || k > 64) return GRIDGCN_EINVAL;
+    return gg_knn(unknown, known, downnum, upnum, B, n, m, k, idx, (hipStream_t)stream);
+}
+
+int gridgcn_batch_take(const float *data, const int32_t *index, int B, int N, int C, int M,
+                       float *out, void *stream)
+{
+    if (!data || !index || !out || B < 1 || N < 1 || C < 1 || M < 1) return GRIDGCN_EINVAL;
+    return gg_batch_take(data, index, B, N, C, M, out, (hipStream_t)stream);
+}
+
+int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int B, int N, int C,
+                                int M, float *grad_data, void *stream)
+{
+    if (!grad_out || !index || !grad_data || B < 1 || N < 1 || C < 1 || M < 1)
+        return GRIDGCN_EINVAL;
+    return gg_batch_take_backward(grad_out, index, B, N, C, M, grad_data, (hipStream_t)stream);
+}
+
+}  // extern "C"

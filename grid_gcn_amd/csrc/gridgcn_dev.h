@@ -1,0 +1,88 @@
+// gridgcn_dev.h -- device helpers shared by the gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GG_WAVE 64
+#define GG_PMAX 128   // max_p_grid limit (reference: best[128] gridifyknn.cu:257; LDS slot arrays)
+#define GG_KMAX 7     // kernel_size limit (classification/configs/configs.yaml:49 uses 7)
+#define GG_K3MAX (GG_KMAX * GG_KMAX * GG_KMAX)
+
+struct GGGrid {
+    float shift[3];
+    float vs[3];
+    int g[3];
+    int G;     // g0*g1*g2
+    int gxy;   // g0*g1
+    int P, O, k, k3, loc;
+    unsigned long long seed;
+};
+
+// cuRAND XORWOW curand_init(seed,0,0) + first curand_uniform (gridify.cu:149-150).
+// Restated integer-for-integer; rocRAND's XORWOW uses different scramble constants.
+__device__ __forceinline__ float gg_xorwow_uniform(unsigned long long seed)
+{
+    unsigned s0 = ((unsigned)seed) ^ 0xaad26b49u;
+    unsigned s1 = ((unsigned)(seed >> 32)) ^ 0xf7dcefddu;
+    unsigned t0 = 1099087573u * s0;
+    unsigned t1 = 2591861531u * s1;
+    unsigned d = 6615241u + t1 + t0;
+    unsigned v0 = 123456789u + t0;
+    unsigned v4 = 5783321u + t0;
+    unsigned t = v0 ^ (v0 >> 2);
+    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
+    d += 362437u;
+    unsigned x = v4 + d;
+    // x*2^-32 is exact, so mul+add rounds once, like the FMA nvcc would emit.
+    return __fadd_rn(__fmul_rn((float)x, 2.3283064e-10f), 1.1641532e-10f);
+}
+
+// "ceilf(curand_uniform(&state) * n) - 1"  (gridify.cu:150,183,261; gridify_up.cu:163)
+__device__ __forceinline__ int gg_reservoir_pick(unsigned long long seed, int n)
+{
+    float u = gg_xorwow_uniform(seed);
+    return (int)(ceilf(__fmul_rn(u, (float)n)) - 1.0f);
+}
+
+// voxel of a point (gridify.cu:134-143); -1 = dropped.  add then divide, IEEE, no contraction.
+__device__ __forceinline__ int gg_voxel_of(float x, float y, float z, const GGGrid &gp, int *c3)
+{
+    float q0 = __fdiv_rn(__fadd_rn(x, gp.shift[0]), gp.vs[0]);
+    float q1 = __fdiv_rn(__fadd_rn(y, gp.shift[1]), gp.vs[1]);
+    float q2 = __fdiv_rn(__fadd_rn(z, gp.shift[2]), gp.vs[2]);
+    float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+    bool ok = (f0 >= 0.0f) && (f0 < (float)gp.g[0]) && (f1 >= 0.0f) && (f1 < (float)gp.g[1]) &&
+              (f2 >= 0.0f) && (f2 < (float)gp.g[2]);
+    if (!ok) return -1;
+    int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+    if (c3) { c3[0] = c0; c3[1] = c1; c3[2] = c2; }
+    return c2 * gp.gxy + c1 * gp.g[0] + c0;
+}
+
+__device__ __forceinline__ int gg_lane() { return (int)(threadIdx.x & 63); }
+
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ int gg_wave_incl_scan(int v)
+{
+    int lane = gg_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int gg_wave_sum(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ long long gg_wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}

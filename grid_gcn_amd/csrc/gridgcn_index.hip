@@ -1,0 +1,300 @@
+// gridgcn_index.hip -- voxel index build shared by Gridify / GridifyKNN / GridifyUp (gfx950).
+//
+// Replaces gridify_kernel_build_index (gridifyop/gridify.cu:102-191, gridifyknn.cu:115-204,
+// gridify_up.cu:102-170).  The reference appends points to a dense [B*G, P] bucket table with
+// atomics in arrival order (non-deterministic, 262-524 MB of scratch per call).  Here the result
+// of the canonical schedule S0 (threads in ascending index) is computed order-independently:
+//
+//   K1 voxelize : voxel id per point, per-voxel population (atomic add: a commutative count)
+//   K2 scan     : exclusive scan of the populations -> compact segment offsets
+//   K3 scatter  : point ids into their voxel's segment in arrival order (order irrelevant)
+//   K4 rank     : rank n of a point inside its voxel = #{ids in the segment smaller than mine};
+//                 sorted[off+n] = id; reservoir of S0 resolved as "largest n wins" == atomicMax
+//                 on the point id (ids ascend with n); voxel leaders (n == 0) flagged
+//   K5 centres  : t = number of leaders before mine (block prefix + in-block scan) = the order of
+//                 first appearance of the voxel; centre reservoir again "largest t wins"
+//
+// Every atomic used is commutative/idempotent on the final value, so the output is bit-identical
+// from run to run and equal to schedule S0 of the reference.
+#include "gridgcn_index.h"
+
+// ------------------------------------------------------------------------------------------
+// K1: one thread per point, coalesced float4 loads.  grid (ceil(N/256), B).
+__global__ __launch_bounds__(256) void gg_k_voxelize(const float4 *__restrict__ data,
+                                                     const int *__restrict__ np, int N, GGGrid gp,
+                                                     int *__restrict__ vox, int *__restrict__ arr,
+                                                     int *__restrict__ cnt,
+                                                     unsigned long long *__restrict__ wsum,
+                                                     int *__restrict__ nonint)
+{
+    const int b = blockIdx.y;
+    const int ip = blockIdx.x * 256 + threadIdx.x;
+    const int nvalid = np[b];
+    int v = -1;
+    long long aw = 0;
+    bool bad = false;
+    if (ip < N && ip < nvalid) {
+        float4 p = data[(size_t)b * N + ip];
+        v = gg_voxel_of(p.x, p.y, p.z, gp, nullptr);
+        if (v >= 0) {
+            float w = p.w;
+            bad = !(truncf(w) == w) || !(fabsf(w) < 8388608.0f);
+            aw = bad ? 0 : (long long)fabsf(w);
+        }
+    }
+    if (ip < N) {
+        vox[(size_t)b * N + ip] = v;
+        if (v >= 0) arr[(size_t)b * N + ip] = atomicAdd(&cnt[(size_t)b * gp.G + v], 1);
+    }
+    // per-cloud "weights are small integers" statistic: selects the exact integer path of the
+    // query kernels (total_weight, gridify.cu:258,268)
+    long long s = gg_wave_sum_ll(aw);
+    bool anybad = __any(bad);
+    if (gg_lane() == 0) {
+        if (s) atomicAdd(&wsum[b], (unsigned long long)s);
+        if (anybad) atomicOr(&nonint[b], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: exclusive scan over the B*G populations.  2048 elements per block.
+#define GG_SCAN_CHUNK 2048
+__global__ __launch_bounds__(256) void gg_k_scan_partials(const int *__restrict__ cnt, int n,
+                                                          int *__restrict__ part)
+{
+    __shared__ int sw[4];
+    int base = blockIdx.x * GG_SCAN_CHUNK + threadIdx.x * 8;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += (base + j < n) ? cnt[base + j] : 0;
+    s = gg_wave_sum(s);
+    if (gg_lane() == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+__global__ __launch_bounds__(256) void gg_k_scan_apply(const int *__restrict__ cnt, int n,
+                                                       const int *__restrict__ part,
+                                                       int *__restrict__ off)
+{
+    __shared__ int sw[4];
+    __shared__ int sbase;
+    // prefix of the preceding blocks' partial sums
+    int acc = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += part[j];
+    acc = gg_wave_sum(acc);
+    if (gg_lane() == 0) sw[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sbase = sw[0] + sw[1] + sw[2] + sw[3];
+    __syncthreads();
+    int base = blockIdx.x * GG_SCAN_CHUNK + threadIdx.x * 8;
+    int v[8];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        v[j] = (base + j < n) ? cnt[base + j] : 0;
+        s += v[j];
+    }
+    int incl = gg_wave_incl_scan(s);
+    int wtot = __shfl(incl, 63, 64);
+    __syncthreads();
+    if (gg_lane() == 0) sw[threadIdx.x >> 6] = wtot;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += sw[w];
+    int run = sbase + wbase + incl - s;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (base + j < n) off[base + j] = run;
+        run += v[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: arrival-order scatter into the voxel segment; also resets the reservoir slots.
+__global__ __launch_bounds__(256) void gg_k_scatter(int N, int G, const int *__restrict__ vox,
+                                                    const int *__restrict__ arr,
+                                                    const int *__restrict__ off,
+                                                    int *__restrict__ seg, int *__restrict__ bkt)
+{
+    const int b = blockIdx.y;
+    const int ip = blockIdx.x * 256 + threadIdx.x;
+    if (ip >= N) return;
+    size_t i = (size_t)b * N + ip;
+    int v = vox[i];
+    if (bkt) bkt[i] = -1;
+    if (v >= 0) seg[off[(size_t)b * G + v] + arr[i]] = ip;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: rank inside the voxel, sorted segment, bucket reservoir (gridify.cu:145-154), leaders.
+// grid (ceil(N/1024), B), block 1024.  WITH_CENTRES=false for GridifyUp (no buckets/leaders).
+template <bool WITH_CENTRES>
+__global__ __launch_bounds__(1024) void gg_k_rank(int N, GGGrid gp, const int *__restrict__ vox,
+                                                  const int *__restrict__ cnt,
+                                                  const int *__restrict__ off,
+                                                  const int *__restrict__ seg,
+                                                  int *__restrict__ sorted, int *__restrict__ bkt,
+                                                  unsigned char *__restrict__ lead,
+                                                  int *__restrict__ blkcnt)
+{
+    __shared__ int swc[16];
+    const int b = blockIdx.y;
+    const int ip = blockIdx.x * 1024 + threadIdx.x;
+    const size_t i = (size_t)b * N + ip;
+    int v = (ip < N) ? vox[i] : -1;
+    int is_lead = 0;
+    if (v >= 0) {
+        size_t vb = (size_t)b * gp.G + v;
+        int c = cnt[vb];
+        int o = off[vb];
+        int n = 0;
+        int j = 0;
+        for (; j + 4 <= c; j += 4) {
+            int a0 = seg[o + j], a1 = seg[o + j + 1], a2 = seg[o + j + 2], a3 = seg[o + j + 3];
+            n += (a0 < ip) + (a1 < ip) + (a2 < ip) + (a3 < ip);
+        }
+        for (; j < c; j++) n += (seg[o + j] < ip);
+        sorted[o + n] = ip;
+        if (WITH_CENTRES) {
+            if (c > gp.P) {
+                // S0: item n < P sits in slot n; item n >= P overwrites slot r(n) if r(n) < P
+                // (gridify.cu:146-153).  Last writer = largest n = largest point id.
+                int s = n;
+                if (n >= gp.P)
+                    s = gg_reservoir_pick((unsigned long long)(long long)(int)i + gp.seed, n + 1);
+                if (s < gp.P) atomicMax(&bkt[o + s], ip);
+            }
+            is_lead = (n == 0);
+        }
+    }
+    if (WITH_CENTRES) {
+        if (ip < N) lead[i] = (unsigned char)is_lead;
+        unsigned long long m = __ballot(is_lead);
+        if (gg_lane() == 0) swc[threadIdx.x >> 6] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) t += swc[w];
+            blkcnt[(size_t)b * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
+template __global__ void gg_k_rank<true>(int, GGGrid, const int *, const int *, const int *,
+                                         const int *, int *, int *, unsigned char *, int *);
+template __global__ void gg_k_rank<false>(int, GGGrid, const int *, const int *, const int *,
+                                          const int *, int *, int *, unsigned char *, int *);
+
+// ------------------------------------------------------------------------------------------
+// K5: centre slots = RVS reservoir over voxels in order of first appearance (gridify.cu:165-189).
+// slotfirst1[b,O] holds (first point id of the chosen voxel) + 1, 0 = empty.
+__global__ __launch_bounds__(1024) void gg_k_centres(int N, GGGrid gp,
+                                                     const unsigned char *__restrict__ lead,
+                                                     const int *__restrict__ blkcnt,
+                                                     int *__restrict__ slotfirst1,
+                                                     int *__restrict__ centnum)
+{
+    __shared__ int swc[16];
+    __shared__ int sred[16];
+    const int b = blockIdx.y;
+    const int nblk = gridDim.x;
+    const int ip = blockIdx.x * 1024 + threadIdx.x;
+    const size_t i = (size_t)b * N + ip;
+    // leaders in the preceding blocks of this cloud (and, for block 0, in the whole cloud)
+    int before = 0, all = 0;
+    for (int j = threadIdx.x; j < nblk; j += 1024) {
+        int c = blkcnt[(size_t)b * nblk + j];
+        all += c;
+        if (j < (int)blockIdx.x) before += c;
+    }
+    before = gg_wave_sum(before);
+    all = gg_wave_sum(all);
+    if (gg_lane() == 0) { swc[threadIdx.x >> 6] = before; sred[threadIdx.x >> 6] = all; }
+    __syncthreads();
+    int t0 = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { t0 += swc[w]; total += sred[w]; }
+    __syncthreads();
+    int flag = (ip < N) ? (int)lead[i] : 0;
+    unsigned long long m = __ballot(flag);
+    int pre = __popcll(m & ((1ull << gg_lane()) - 1ull));
+    if (gg_lane() == 0) swc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += swc[w];
+    if (flag) {
+        int t = t0 + wbase + pre;
+        int s = t;
+        if (t >= gp.O)
+            s = gg_reservoir_pick((unsigned long long)(long long)(int)i + 2ull * gp.seed, t + 1);
+        if (s < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + s], ip + 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) centnum[b] = total < gp.O ? total : gp.O;
+}
+
+// ------------------------------------------------------------------------------------------
+size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres, GGIndexWs *ws)
+{
+    const size_t BG = (size_t)B * gp.G, BN = (size_t)B * N;
+    const int nblk = (N + 1023) / 1024;
+    const int nscan = (int)((BG + GG_SCAN_CHUNK - 1) / GG_SCAN_CHUNK);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    GGIndexWs w;
+    // ---- zero-filled region (one hipMemsetAsync) ----
+    w.o_cnt = take(BG * 4);
+    w.o_slotfirst1 = take(with_centres ? (size_t)B * gp.O * 4 : 0);
+    w.o_blkcnt = take(with_centres ? (size_t)B * nblk * 4 : 0);
+    w.o_wsum = take((size_t)B * 8);
+    w.o_nonint = take((size_t)B * 4);
+    w.zero_bytes = o;
+    // ---- written before read ----
+    w.o_off = take(BG * 4);
+    w.o_part = take((size_t)nscan * 4);
+    w.o_vox = take(BN * 4);
+    w.o_arr = take(BN * 4);
+    w.o_seg = take(BN * 4);
+    w.o_sorted = take(BN * 4);
+    w.o_bkt = take(with_centres ? BN * 4 : 0);
+    w.o_lead = take(with_centres ? BN : 0);
+    w.total = o;
+    w.nblk = nblk;
+    w.nscan = nscan;
+    if (ws) *ws = w;
+    return o;
+}
+
+int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid &gp,
+                   bool with_centres, int *centnum, char *wsbase, const GGIndexWs &w,
+                   hipStream_t st)
+{
+    int *cnt = (int *)(wsbase + w.o_cnt), *off = (int *)(wsbase + w.o_off);
+    int *part = (int *)(wsbase + w.o_part), *vox = (int *)(wsbase + w.o_vox);
+    int *arr = (int *)(wsbase + w.o_arr), *seg = (int *)(wsbase + w.o_seg);
+    int *sorted = (int *)(wsbase + w.o_sorted);
+    int *bkt = with_centres ? (int *)(wsbase + w.o_bkt) : nullptr;
+    unsigned char *lead = with_centres ? (unsigned char *)(wsbase + w.o_lead) : nullptr;
+    int *slotfirst1 = (int *)(wsbase + w.o_slotfirst1), *blkcnt = (int *)(wsbase + w.o_blkcnt);
+    unsigned long long *wsum = (unsigned long long *)(wsbase + w.o_wsum);
+    int *nonint = (int *)(wsbase + w.o_nonint);
+    const int BG = B * gp.G;
+
+    if (hipMemsetAsync(wsbase, 0, w.zero_bytes, st) != hipSuccess) return 3;
+    dim3 g256((N + 255) / 256, B), g1024(w.nblk, B);
+    gg_k_voxelize<<<g256, 256, 0, st>>>((const float4 *)data, np, N, gp, vox, arr, cnt, wsum,
+                                        nonint);
+    gg_k_scan_partials<<<w.nscan, 256, 0, st>>>(cnt, BG, part);
+    gg_k_scan_apply<<<w.nscan, 256, 0, st>>>(cnt, BG, part, off);
+    gg_k_scatter<<<g256, 256, 0, st>>>(N, gp.G, vox, arr, off, seg, bkt);
+    if (with_centres) {
+        gg_k_rank<true><<<g1024, 1024, 0, st>>>(N, gp, vox, cnt, off, seg, sorted, bkt, lead,
+                                                blkcnt);
+        gg_k_centres<<<g1024, 1024, 0, st>>>(N, gp, lead, blkcnt, slotfirst1, centnum);
+    } else {
+        gg_k_rank<false><<<g1024, 1024, 0, st>>>(N, gp, vox, cnt, off, seg, sorted, nullptr,
+                                                 nullptr, nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

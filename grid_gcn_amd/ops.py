@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference operator interface, on top of the C ABI (include/gridgcn.h).
+
+Names, argument order, attribute names and output order are those of the MXNet symbols the
+reference registers from gridifyop/additional.so:
+
+    mx.sym.Gridify(data, actual_numpoints, max_o_grid, max_p_grid, kernel_size, stride,
+                   coord_shift, voxel_size, grid_size, loc)
+        -> nebidx, nebidxmsk, cent, centmsk, actual_centnum       gridify-inl.h:146-152
+    mx.sym.GridifyKNN(...)      same signature                    gridifyknn-inl.h
+    mx.sym.GridifyUp(downdata, updata, down_actual_numpoints, up_actual_numpoints,
+                     max_p_grid, max_o_grid, kernel_size, coord_shift, voxel_size, grid_size)
+        -> nebidx, nebidxmsk                                      gridify_up-inl.h:137-143
+    mx.sym.contrib.BallKNN(unknown, known, downnum, upnum, k=3, radius=0.1) -> idx
+                                                                  ball_k_nn.cc:14-66
+    mx.sym.contrib.KNN(unknown, known, downnum, upnum, k=3) -> idx           k_nn.cc:14-66
+    batch_take_g(data, index, shape)                              utils/ops.py:78-93
+
+The only addition is `seed` (the reference seeds cuRAND from gettimeofday().tv_usec,
+gridify.cu:377-379; seed=0 is the fast_apprxmt fixed-seed mode).
+
+Tensors are torch CUDA(HIP) tensors; PyTorch is used for device memory and the current stream
+only.  Errors (ndim, dtype, contiguity, device, attribute range) raise RuntimeError, the analogue
+of the MXNetError raised by the reference's CHECK_EQ (gridify-inl.h:174-182).  There is no CPU
+path: the reference has none either for the grid ops (gridify.cc:28-39 LOG(FATAL)).
+All index ops are non-differentiable (gridify-inl.h:227-231, ball_k_nn.cc:60).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _chk(t, name, ndim, dtype, last=None):
+    _require(isinstance(t, torch.Tensor), "%s must be a torch.Tensor" % name)
+    _require(t.is_cuda, "%s must live on the GPU (no CPU path: gridify.cc:28-39)" % name)
+    _require(t.dim() == ndim, "%s should be a %dD tensor" % (name, ndim))
+    _require(t.dtype == dtype, "%s must be %s" % (name, dtype))
+    _require(t.is_contiguous(), "%s must be contiguous" % name)
+    if last is not None:
+        _require(t.shape[-1] == last, "last dim of %s should be %d" % (name, last))
+
+
+def _num(t, name, B):
+    """actual_numpoints-style input: int32 [B,1] (or [B])."""
+    _require(isinstance(t, torch.Tensor) and t.is_cuda, "%s must be a GPU tensor" % name)
+    _require(t.dtype == torch.int32, "%s must be int32" % name)
+    _require(t.numel() == B and t.is_contiguous(), "%s should be a [B,1] tensor" % name)
+    return t
+
+
+def _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size,
+            seed):
+    p = _lib.GridParams()
+    p.max_p_grid, p.max_o_grid, p.kernel_size = int(max_p_grid), int(max_o_grid), int(kernel_size)
+    p.stride, p.loc = int(stride), int(loc)
+    _require(len(coord_shift) == 3 and len(voxel_size) == 3 and len(grid_size) == 3,
+             "coord_shift / voxel_size / grid_size must have 3 entries")
+    for j in range(3):
+        p.coord_shift[j] = float(coord_shift[j])
+        p.voxel_size[j] = float(voxel_size[j])
+        p.grid_size[j] = int(grid_size[j])
+    p.seed = int(seed) & (2 ** 64 - 1)
+    return p
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _workspace(nbytes, device):
+    # torch caching allocator: no hipMalloc in steady state, stream-ordered reuse
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def _gridify_like(fn_name, data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, stride,
+                  loc, coord_shift, voxel_size, grid_size, seed):
+    lib = _lib.load()
+    _chk(data, "data", 3, torch.float32, 4)
+    B, N, _ = data.shape
+    _num(actual_numpoints, "actual_numpoints", B)
+    _require(actual_numpoints.device == data.device, "inputs must be on the same device")
+    p = _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size,
+                grid_size, seed)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(getattr(lib, fn_name + "_workspace_bytes")(B, N, ctypes.byref(p),
+                                                          ctypes.byref(nbytes)), fn_name)
+    dev = data.device
+    O, P = int(max_o_grid), int(max_p_grid)
+    with torch.cuda.device(dev):
+        ws = _workspace(nbytes.value, dev)
+        nebidx = torch.empty((B, O, P), dtype=torch.int32, device=dev)
+        nebidxmsk = torch.empty((B, O, P), dtype=torch.float32, device=dev)
+        cent = torch.empty((B, O, 4), dtype=torch.float32, device=dev)
+        centmsk = torch.empty((B, O), dtype=torch.float32, device=dev)
+        actual_centnum = torch.empty((B, 1), dtype=torch.int32, device=dev)
+        rc = getattr(lib, fn_name)(_ptr(data), _ptr(actual_numpoints), B, N, ctypes.byref(p),
+                                   _ptr(nebidx), _ptr(nebidxmsk), _ptr(cent), _ptr(centmsk),
+                                   _ptr(actual_centnum), _ptr(ws), nbytes.value, _stream(data))
+    _lib.check(rc, fn_name)
+    return nebidx, nebidxmsk, cent, centmsk, actual_centnum
+
+
+@torch.no_grad()
+def Gridify(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
+            coord_shift, voxel_size, grid_size, seed=0):
+    """Coverage-aware grid query with random voxel sampling (RVS).
+
+    data [B,N,4] f32 (x,y,z,w), actual_numpoints [B,1] i32 ->
+    nebidx [B,O,P] i32, nebidxmsk [B,O,P] f32, cent [B,O,4] f32, centmsk [B,O] f32,
+    actual_centnum [B,1] i32.  Reference: GridifyForward<gpu>, gridify.cu:294-413.
+    """
+    return _gridify_like("gridgcn_gridify", data, actual_numpoints, max_p_grid, max_o_grid,
+                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed)
+
+
+@torch.no_grad()
+def GridifyKNN(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
+               coord_shift, voxel_size, grid_size, seed=0):
+    """As Gridify, neighbours = exact top-P by distance to the voxel centre
+    (GridifyKNNForward<gpu>, gridifyknn.cu:337-455)."""
+    return _gridify_like("gridgcn_gridify_knn", data, actual_numpoints, max_p_grid, max_o_grid,
+                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed)
+
+
+@torch.no_grad()
+def GridifyUp(downdata, updata, down_actual_numpoints, up_actual_numpoints, *, max_p_grid,
+              max_o_grid, kernel_size, coord_shift, voxel_size, grid_size, seed=0):
+    """downdata [B,Nd,4], updata [B,max_o_grid,4] -> nebidx [B,O,P] i32, nebidxmsk [B,O,P] f32.
+    Reference: GridifyUpForward<gpu>, gridify_up.cu:229-323."""
+    lib = _lib.load()
+    _chk(downdata, "downdata", 3, torch.float32, 4)
+    _chk(updata, "updata", 3, torch.float32, 4)
+    B, Nd, _ = downdata.shape
+    O, P = int(max_o_grid), int(max_p_grid)
+    _require(updata.shape[0] == B and updata.shape[1] == O,
+             "updata must be [B, max_o_grid, 4] (it is indexed with stride max_o_grid, "
+             "gridify_up.cu:196)")
+    _num(down_actual_numpoints, "down_actual_numpoints", B)
+    _num(up_actual_numpoints, "up_actual_numpoints", B)
+    p = _params(max_p_grid, max_o_grid, kernel_size, 1, 0, coord_shift, voxel_size, grid_size, seed)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.gridgcn_gridify_up_workspace_bytes(B, Nd, ctypes.byref(p), ctypes.byref(nbytes)),
+               "gridgcn_gridify_up")
+    dev = downdata.device
+    with torch.cuda.device(dev):
+        ws = _workspace(nbytes.value, dev)
+        nebidx = torch.empty((B, O, P), dtype=torch.int32, device=dev)
+        nebidxmsk = torch.empty((B, O, P), dtype=torch.float32, device=dev)
+        rc = lib.gridgcn_gridify_up(_ptr(downdata), _ptr(updata), _ptr(down_actual_numpoints),
+                                    _ptr(up_actual_numpoints), B, Nd, ctypes.byref(p),
+                                    _ptr(nebidx), _ptr(nebidxmsk), _ptr(ws), nbytes.value,
+                                    _stream(downdata))
+    _lib.check(rc, "gridgcn_gridify_up")
+    return nebidx, nebidxmsk
+
+
+def _knn_common(ball, unknown, known, downnum, upnum, k, radius, out):
+    lib = _lib.load()
+    _chk(unknown, "unknown", 3, torch.float32, 3)   # ball_k_nn.cc:36-42
+    _chk(known, "known", 3, torch.float32, 3)
+    B, n, _ = unknown.shape
+    _require(known.shape[0] == B, "unknown and known must have the same batch size")
+    m = known.shape[1]
+    _num(downnum, "downnum", B)
+    _num(upnum, "upnum", B)
+    dev = unknown.device
+    if out is None:
+        # the reference leaves rows >= upnum[b] untouched (undefined memory); zero them here
+        out = torch.zeros((B, n, int(k)), dtype=torch.int32, device=dev)
+    else:
+        _chk(out, "out", 3, torch.int32, int(k))
+    with torch.cuda.device(dev):
+        if ball:
+            rc = lib.gridgcn_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n,
+                                      m, int(k), ctypes.c_float(radius), _ptr(out),
+                                      _stream(unknown))
+        else:
+            rc = lib.gridgcn_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m,
+                                 int(k), _ptr(out), _stream(unknown))
+    _lib.check(rc, "gridgcn_ball_knn" if ball else "gridgcn_knn")
+    return out
+
+
+@torch.no_grad()
+def BallKNN(unknown, known, downnum, upnum, *, k=3, radius=0.1, out=None):
+    """unknown [B,n,3], known [B,m,3], downnum/upnum [B,1] i32 -> idx [B,n,k] i32 (-1 = none).
+    Reference: _contrib_BallKNN, ball_k_nn-inl.h:43-116 (k <= 6)."""
+    return _knn_common(True, unknown, known, downnum, upnum, k, radius, out)
+
+
+@torch.no_grad()
+def KNN(unknown, known, downnum, upnum, *, k=3, out=None):
+    """Reference: _contrib_KNN, k_nn-inl.h:40-113."""
+    return _knn_common(False, unknown, known, downnum, upnum, k, 0.0, out)
+
+
+class _BatchTake(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, index):
+        lib = _lib.load()
+        B, N, C = data.shape
+        M = index.numel() // B
+        out = torch.empty(tuple(index.shape) + (C,), dtype=torch.float32, device=data.device)
+        with torch.cuda.device(data.device):
+            rc = lib.gridgcn_batch_take(_ptr(data), _ptr(index), B, N, C, M, _ptr(out),
+                                        _stream(data))
+        _lib.check(rc, "gridgcn_batch_take")
+        ctx.save_for_backward(index)
+        ctx.dims = (B, N, C, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        (index,) = ctx.saved_tensors
+        B, N, C, M = ctx.dims
+        grad_out = grad_out.contiguous()
+        gdata = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            rc = lib.gridgcn_batch_take_backward(_ptr(grad_out), _ptr(index), B, N, C, M,
+                                                 _ptr(gdata), _stream(grad_out))
+        _lib.check(rc, "gridgcn_batch_take_backward")
+        return gdata, None
+
+
+def batch_take_g(data, index, shape=None, scope=""):
+    """Per-cloud gather: data [B,N,C] f32, index [B,...] i32 -> [B,...,C]
+    (utils/ops.py:78-93; flat take with mode='clip').  `shape`/`scope` are accepted for
+    signature compatibility and ignored (they only size the MXNet symbol)."""
+    _chk(data, "data", 3, torch.float32)
+    _require(isinstance(index, torch.Tensor) and index.is_cuda and index.dtype == torch.int32
+             and index.is_contiguous() and index.shape[0] == data.shape[0],
+             "index must be a contiguous int32 GPU tensor [B,...]")
+    return _BatchTake.apply(data, index)

@@ -1,0 +1,125 @@
+/*
+ * gridgcn.h -- C ABI of libgridgcn_hip.so: the MI355X (gfx950) implementation of the
+ * Grid-GCN index operators (Coverage-Aware Grid Query family) and of the GridConv
+ * neighbour gather.
+ *
+ * The reference has no C ABI: its operators are registered into MXNet's C++ operator
+ * registry by static initialisers of gridifyop/additional.so
+ *   MXNET_REGISTER_OP_PROPERTY(Gridify, GridifyProp)        gridify.cc:63-67
+ *   MXNET_REGISTER_OP_PROPERTY(GridifyUp, GridifyUpProp)    gridify_up.cc:62-68
+ *   MXNET_REGISTER_OP_PROPERTY(GridifyKNN, GridifyKNNProp)  gridifyknn.cc:63-67
+ *   NNVM_REGISTER_OP(_contrib_BallKNN)                      ball_k_nn.cc:14
+ *   NNVM_REGISTER_OP(_contrib_KNN)                          k_nn.cc:14
+ * and each ends in a host function taking raw device pointers:
+ *   GridifyForward<gpu>     gridify.cu:294-413
+ *   GridifyUpForward<gpu>   gridify_up.cu:228-323
+ *   GridifyKNNForward<gpu>  gridifyknn.cu:336-455
+ *   BallKNNForward<gpu>     ball_k_nn-inl.h:96-116
+ *   KNNForward<gpu>         k_nn-inl.h:94-113
+ * The entry points below are drop-ins for exactly those host functions: same tensors, same
+ * layouts (row-major, contiguous), same dtypes, same attribute meaning.  INTEGRATION.md
+ * shows the MXNet-side Forward() stub a maintainer would write on top of them.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), contiguous, 16-byte aligned for float4 rows;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it:
+ *     no allocation, no host synchronisation, no default-stream use (capturable in a hipGraph);
+ *   - scratch comes from the caller: query the size with *_workspace_bytes, pass any buffer of
+ *     at least that size (256-byte aligned); it can be reused by later calls on the same stream;
+ *   - return value: 0 = ok, otherwise a GRIDGCN_E* code; gridgcn_strerror() explains;
+ *     no C++ exception ever crosses this boundary;
+ *   - outputs are fully written by the call (the reference pre-fills them in
+ *     GridifyOp::Forward, gridify-inl.h:117-121; that fill is folded into the kernels).
+ */
+#ifndef GRIDGCN_H_
+#define GRIDGCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIDGCN_OK 0
+#define GRIDGCN_EINVAL 1      /* bad argument (shape/attribute out of the supported domain) */
+#define GRIDGCN_EWORKSPACE 2  /* workspace too small / null */
+#define GRIDGCN_ELAUNCH 3     /* hipGetLastError() != hipSuccess after a launch */
+
+/* Attributes of Gridify / GridifyKNN / GridifyUp = GridifyParam (gridify-inl.h:58-87) and
+ * GridifyUpParam (gridify_up-inl.h:58-81).  `seed` replaces the reference's
+ * gettimeofday().tv_usec (gridify.cu:377-379); seed 0 == the fast_apprxmt fixed-seed build. */
+typedef struct gridgcn_grid_params {
+    int32_t max_p_grid;     /* P: neighbours kept per centre / per voxel bucket (<= 128)        */
+    int32_t max_o_grid;     /* O: centres per cloud (GridifyUp: number of up points M)          */
+    int32_t kernel_size;    /* k: odd, <= 7; neighbourhood is k^3 voxels                         */
+    int32_t stride;         /* accepted and ignored, as in the reference kernels                */
+    int32_t loc;            /* 1: centre xyz = weighted mean of the centre voxel's points       */
+    float coord_shift[3];
+    float voxel_size[3];
+    int32_t grid_size[3];   /* gx*gy*gz < 2^24 and B*gx*gy*gz < 2^31                             */
+    uint64_t seed;
+} gridgcn_grid_params;
+
+const char *gridgcn_strerror(int code);
+/* library/ABI version, bumped on any signature change */
+int gridgcn_abi_version(void);
+
+/* ---- Gridify : replaces GridifyForward<gpu>, gridify.cu:294-413 -------------------------------
+ * in : data[B,N,4] f32 (x,y,z,w)   actual_numpoints[B] i32
+ * out: nebidx[B,O,P] i32  nebidxmsk[B,O,P] f32  cent[B,O,4] f32  centmsk[B,O] f32
+ *      actual_centnum[B] i32                                   (shapes: gridify-inl.h:190-195) */
+int gridgcn_gridify_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes);
+int gridgcn_gridify(const float *data, const int32_t *actual_numpoints, int B, int N,
+                    const gridgcn_grid_params *p,
+                    int32_t *nebidx, float *nebidxmsk, float *cent, float *centmsk,
+                    int32_t *actual_centnum,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- GridifyKNN : replaces GridifyKNNForward<gpu>, gridifyknn.cu:336-455 ----------------------
+ * same tensors as Gridify; neighbours = exact top-P by distance to the voxel centre over
+ * Chebyshev shells (gridifyknn.cu:231-332). */
+int gridgcn_gridify_knn_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes);
+int gridgcn_gridify_knn(const float *data, const int32_t *actual_numpoints, int B, int N,
+                        const gridgcn_grid_params *p,
+                        int32_t *nebidx, float *nebidxmsk, float *cent, float *centmsk,
+                        int32_t *actual_centnum,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- GridifyUp : replaces GridifyUpForward<gpu>, gridify_up.cu:228-323 ------------------------
+ * in : downdata[B,Nd,4] f32  updata[B,O,4] f32  down_actual_numpoints[B] i32
+ *      up_actual_numpoints[B] i32            (O = max_o_grid: updata is indexed with stride O,
+ *                                             gridify_up.cu:196)
+ * out: nebidx[B,O,P] i32  nebidxmsk[B,O,P] f32                (gridify_up-inl.h:183-184) */
+int gridgcn_gridify_up_workspace_bytes(int B, int Nd, const gridgcn_grid_params *p, size_t *bytes);
+int gridgcn_gridify_up(const float *downdata, const float *updata,
+                       const int32_t *down_actual_numpoints, const int32_t *up_actual_numpoints,
+                       int B, int Nd, const gridgcn_grid_params *p,
+                       int32_t *nebidx, float *nebidxmsk,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- BallKNN / KNN : replace BallKNNForward<gpu> (ball_k_nn-inl.h:96-116) and
+ *      KNNForward<gpu> (k_nn-inl.h:94-113) ------------------------------------------------------
+ * in : unknown[B,n,3] f32  known[B,m,3] f32  downnum[B] i32  upnum[B] i32
+ * out: idx[B,n,k] i32; -1 = no neighbour; rows >= upnum[b] are NOT written (as the reference).
+ * BallKNN: k <= 6 (best[6], ball_k_nn-inl.h:63).  KNN: k <= 64 here. */
+int gridgcn_ball_knn(const float *unknown, const float *known, const int32_t *downnum,
+                     const int32_t *upnum, int B, int n, int m, int k, float radius,
+                     int32_t *idx, void *stream);
+int gridgcn_knn(const float *unknown, const float *known, const int32_t *downnum,
+                const int32_t *upnum, int B, int n, int m, int k,
+                int32_t *idx, void *stream);
+
+/* ---- batch_take : replaces the MXNet graph of utils/ops.py:78-93 (batch_take_g) ---------------
+ * out[b, j, :] = data[clip(index[b, j] + b*N, 0, B*N-1), :]    (mx.sym.take default mode='clip')
+ * data[B,N,C] f32, index[B,M] i32, out[B,M,C] f32.  Backward = scatter-add of grad_out into
+ * grad_data (must be zero-filled by the caller). */
+int gridgcn_batch_take(const float *data, const int32_t *index, int B, int N, int C, int M,
+                       float *out, void *stream);
+int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int B, int N, int C,
+                                int M, float *grad_data, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDGCN_H_ */

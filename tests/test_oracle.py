@@ -1,0 +1,142 @@
+"""CPU tests of the oracle: golden fixtures, the independent restatement, and the
+schedule-independent invariants of SURVEY App. A.7 (true for every legal run of the reference)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+import cases
+import pyref
+from golden import make_golden
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def check_against_golden(name, outs):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    assert int(g["n"]) == len(outs)
+    for j, a in enumerate(outs):
+        a = np.ascontiguousarray(a)
+        assert tuple(g["shape%d" % j]) == a.shape, (name, j)
+        head = a.reshape(-1)[:make_golden.HEAD]
+        np.testing.assert_array_equal(head, g["head%d" % j], err_msg="%s out%d head" % (name, j))
+        sha = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), np.uint8)
+        assert np.array_equal(sha, g["sha%d" % j]), "%s out%d sha256" % (name, j)
+
+
+@pytest.mark.parametrize("name,build,run", make_golden.all_cases(),
+                         ids=[c[0] for c in make_golden.all_cases()])
+def test_oracle_matches_golden(name, build, run):
+    args, kw = build()
+    check_against_golden(name, run(args, kw))
+
+
+def test_xorwow_restatements_agree():
+    for s in [0, 1, 2, 12345, 2 ** 31 - 1, 2 ** 32, 2 ** 33 + 7, 2 ** 64 - 5]:
+        assert np.float32(orc.xorwow_uniform(s)) == pyref.xorwow_uniform(s)
+    u = [orc.xorwow_uniform(s) for s in range(20000)]
+    assert 0.0 < min(u) and max(u) <= 1.0
+    assert abs(np.mean(u) - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("seed", [0, 7, 123456])
+def test_oracle_equals_order_independent_form_gridify(seed):
+    """S0 (sequential simulation) == "largest index wins" formulation used by the kernels."""
+    rng = np.random.default_rng(seed)
+    data = np.concatenate([rng.uniform(-1.1, 1.1, (2, 500, 3)).astype(np.float32),
+                           np.ones((2, 500, 1), np.float32)], 2)
+    npn = np.array([[500], [333]], np.int32)
+    kw = dict(max_p_grid=6, max_o_grid=9, kernel_size=3, stride=1, loc=1, coord_shift=[1, 1, 1],
+              voxel_size=[0.5] * 3, grid_size=[4] * 3, seed=seed)
+    a = orc.gridify(data, npn, **kw)
+    b = pyref.gridify(data, npn, **kw)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_oracle_equals_order_independent_form_up():
+    rng = np.random.default_rng(3)
+    down = np.concatenate([rng.uniform(-1.1, 1.1, (2, 300, 3)).astype(np.float32),
+                           np.ones((2, 300, 1), np.float32)], 2)
+    up = np.concatenate([rng.uniform(-1.1, 1.1, (2, 200, 3)).astype(np.float32),
+                         np.ones((2, 200, 1), np.float32)], 2)
+    kw = dict(max_p_grid=3, max_o_grid=200, kernel_size=3, coord_shift=[1, 1, 1],
+              voxel_size=[0.5] * 3, grid_size=[4] * 3, seed=11)
+    a = orc.gridify_up(down, up, [[300], [250]], [[200], [120]], **kw)
+    b = pyref.gridify_up(down, up, [[300], [250]], [[200], [120]], **kw)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+# ---- App. A.7 invariants -----------------------------------------------------------------
+def _voxels(data, npn, kw):
+    B, N, _ = data.shape
+    out = []
+    for b in range(B):
+        vs = np.full(N, -1, np.int64)
+        for i in range(min(int(npn[b, 0]), N)):
+            vs[i], _ = pyref.voxel_of(data[b, i], kw["coord_shift"], kw["voxel_size"],
+                                      kw["grid_size"])
+        out.append(vs)
+    return out
+
+
+@pytest.mark.parametrize("case", ["gridify_mn40_L0_b1", "gridify_oob", "gridify_seeded_1",
+                                  "gridify_ragged"])
+def test_gridify_invariants(case):
+    build = dict(cases.gridify_cases(orc.gridify))[case]
+    (data, npn), kw = build()
+    idx, msk, cent, cmsk, cn = orc.gridify(data, npn, **kw)
+    P, O, k = kw["max_p_grid"], kw["max_o_grid"], kw["kernel_size"]
+    gx, gy, gz = kw["grid_size"]
+    vox = _voxels(data, npn, kw)
+    for b in range(data.shape[0]):
+        occ = np.unique(vox[b][vox[b] >= 0])
+        assert cn[b, 0] == min(len(occ), O)                                  # A.7-2
+        assert cmsk[b].sum() == cn[b, 0] and np.all(cmsk[b, :cn[b, 0]] == 1)
+        for o in range(cn[b, 0]):
+            m = int(msk[b, o].sum())
+            assert m >= 1 and np.all(msk[b, o, :m] == 1) and np.all(msk[b, o, m:] == 0)
+            assert np.all(idx[b, o, m:] == idx[b, o, 0])                      # pad rule (F10)
+            ids = idx[b, o, :m]
+            assert np.all((ids >= 0) & (ids < npn[b, 0]))                     # A.7-6
+            assert np.all(vox[b][ids] >= 0)
+            # all neighbours lie within Chebyshev distance (k-1)/2 of ONE voxel
+            vv = vox[b][ids]
+            z, y, x = vv // (gx * gy), (vv // gx) % gy, vv % gx
+            assert z.max() - z.min() <= k - 1 and y.max() - y.min() <= k - 1 \
+                and x.max() - x.min() <= k - 1
+            if kw["loc"] == 1:                                                # A.7-5
+                # cent xyz is the mean of some occupied voxel's points
+                c = cent[b, o, :3]
+                v, _ = pyref.voxel_of(c, kw["coord_shift"], kw["voxel_size"], kw["grid_size"])
+                assert v in occ
+            assert cent[b, o, 3] == np.float32(np.sum(np.trunc(data[b, ids, 3])))  # A.7-3
+        assert np.all(idx[b, cn[b, 0]:] == 0) and np.all(cent[b, cn[b, 0]:] == 1)
+
+
+def test_ball_knn_invariants():
+    (un, kn, dn, upn), kw = dict(cases.knn_cases())["ball_knn_1024_256"]()
+    idx = orc.ball_knn(un, kn, dn, upn, **kw)
+    r2 = np.float32(kw["radius"]) * np.float32(kw["radius"])
+    for b in range(2):
+        for i in range(0, int(upn[b, 0]), 37):
+            d = ((un[b, i] - kn[b, :dn[b, 0]]) ** 2).astype(np.float32)
+            d = (d[:, 0] + d[:, 1]) + d[:, 2]
+            order = np.lexsort((np.arange(len(d)), d))
+            want = [j for j in order if d[j] <= r2][:kw["k"]]
+            want = want + [-1] * (kw["k"] - len(want))
+            assert list(idx[b, i]) == want                                    # A.7-7
+        assert np.all(idx[b, int(upn[b, 0]):] == 0)   # untouched rows (zeros from the binding)
+
+
+def test_batch_take_clip():
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((2, 10, 4)).astype(np.float32)
+    index = np.array([[[0, 9, -1]], [[-1, 3, 12]]], np.int32)   # -1 + b*N clips / crosses clouds
+    out = orc.batch_take(data, index)
+    flat = data.reshape(20, 4)
+    want = flat[np.clip(index + np.array([0, 10])[:, None, None], 0, 19)]
+    np.testing.assert_array_equal(out, want)
