@@ -20,6 +20,12 @@ int gg_knn(const float *, const float *, const int *, const int *, int, int, int
 int gg_batch_take(const float *, const int *, int, int, int, int, float *, hipStream_t);
 int gg_batch_take_backward(const float *, const int *, int, int, int, int, float *, hipStream_t);
 
+static int ensure_init()
+{
+    static int rc = gg_index_init();  // thread-safe one-time init (C++11 static)
+    return rc;
+}
+
 static int fill_grid(const gridgcn_grid_params *p, int B, int N, bool up, GGGrid *gp)
 {
     if (!p || B < 1 || N < 1) return GRIDGCN_EINVAL;
@@ -88,6 +94,7 @@ static int gridify_common(bool knn, const float *data, const int32_t *np, int B,
     size_t need = gg_index_workspace_bytes(B, N, gp, true, &w);
     if (!ws || ws_bytes < need) return GRIDGCN_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (ensure_init()) return GRIDGCN_ELAUNCH;
     rc = gg_index_build(data, np, B, N, gp, true, centnum, (char *)ws, w, st);
     if (rc) return rc;
     if (knn)
@@ -139,6 +146,7 @@ int gridgcn_gridify_up(const float *downdata, const float *updata, const int32_t
     size_t need = gg_index_workspace_bytes(B, Nd, gp, false, &w);
     if (!ws || ws_bytes < need) return GRIDGCN_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (ensure_init()) return GRIDGCN_ELAUNCH;
     rc = gg_index_build(downdata, down_np, B, Nd, gp, false, nullptr, (char *)ws, w, st);
     if (rc) return rc;
     return gg_launch_query_up(updata, up_np, B, Nd, gp, (char *)ws, w, nebidx, nebmsk, st);

@@ -5,8 +5,9 @@
 // atomics in arrival order (non-deterministic, 262-524 MB of scratch per call).  Here the result
 // of the canonical schedule S0 (threads in ascending index) is computed order-independently:
 //
-//   K1 voxelize : voxel id per point, per-voxel population (atomic add: a commutative count)
-//   K2 scan     : exclusive scan of the populations -> compact segment offsets
+//   K1 voxelize : voxel id per point (coalesced float4 stream, no atomics)
+//   K2 slabs    : LDS-staged voxel slabs: per-voxel population + arrival slot via LDS atomics,
+//                 LDS scan + one bump allocation per slab -> compact segment offsets
 //   K3 scatter  : point ids into their voxel's segment in arrival order (order irrelevant)
 //   K4 rank     : rank n of a point inside its voxel = #{ids in the segment smaller than mine};
 //                 sorted[off+n] = id; reservoir of S0 resolved as "largest n wins" == atomicMax
@@ -14,21 +15,23 @@
 //   K5 centres  : t = number of leaders before mine (block prefix + in-block scan) = the order of
 //                 first appearance of the voxel; centre reservoir again "largest t wins"
 //
-// Every atomic used is commutative/idempotent on the final value, so the output is bit-identical
-// from run to run and equal to schedule S0 of the reference.
+// Every atomic used is commutative/idempotent on the final value (arrival slots and segment
+// placement only permute scratch), so the output is bit-identical from run to run and equal to
+// schedule S0 of the reference.
 #include "gridgcn_index.h"
 
 // ------------------------------------------------------------------------------------------
-// K1: one thread per point, coalesced float4 loads.  grid (ceil(N/256), B).
-__global__ __launch_bounds__(256) void gg_k_voxelize(const float4 *__restrict__ data,
-                                                     const int *__restrict__ np, int N, GGGrid gp,
-                                                     int *__restrict__ vox, int *__restrict__ arr,
-                                                     int *__restrict__ cnt,
-                                                     unsigned long long *__restrict__ wsum,
-                                                     int *__restrict__ nonint)
+// K1: one thread per point, coalesced float4 loads, NO atomics.  grid (ceil(N/1024), B).
+// Also reduces the per-block weight statistic that selects the exact-integer total_weight path.
+__global__ __launch_bounds__(1024) void gg_k_voxelize(const float4 *__restrict__ data,
+                                                      const int *__restrict__ np, int N, GGGrid gp,
+                                                      int *__restrict__ vox,
+                                                      unsigned long long *__restrict__ wsum_blk)
 {
+    __shared__ long long sw[16];
+    __shared__ int sbad[16];
     const int b = blockIdx.y;
-    const int ip = blockIdx.x * 256 + threadIdx.x;
+    const int ip = blockIdx.x * 1024 + threadIdx.x;
     const int nvalid = np[b];
     int v = -1;
     long long aw = 0;
@@ -42,71 +45,87 @@ __global__ __launch_bounds__(256) void gg_k_voxelize(const float4 *__restrict__ 
             aw = bad ? 0 : (long long)fabsf(w);
         }
     }
-    if (ip < N) {
-        vox[(size_t)b * N + ip] = v;
-        if (v >= 0) arr[(size_t)b * N + ip] = atomicAdd(&cnt[(size_t)b * gp.G + v], 1);
-    }
-    // per-cloud "weights are small integers" statistic: selects the exact integer path of the
-    // query kernels (total_weight, gridify.cu:258,268)
+    if (ip < N) vox[(size_t)b * N + ip] = v;
     long long s = gg_wave_sum_ll(aw);
     bool anybad = __any(bad);
-    if (gg_lane() == 0) {
-        if (s) atomicAdd(&wsum[b], (unsigned long long)s);
-        if (anybad) atomicOr(&nonint[b], 1);
+    if (gg_lane() == 0) { sw[threadIdx.x >> 6] = s; sbad[threadIdx.x >> 6] = anybad ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        int nb = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { t += sw[w]; nb |= sbad[w]; }
+        // bit 63 = "some weight is not a small integer"
+        wsum_blk[(size_t)b * gridDim.x + blockIdx.x] =
+            (unsigned long long)t | (nb ? (1ull << 63) : 0ull);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: exclusive scan over the B*G populations.  2048 elements per block.
-#define GG_SCAN_CHUNK 2048
-__global__ __launch_bounds__(256) void gg_k_scan_partials(const int *__restrict__ cnt, int n,
-                                                          int *__restrict__ part)
+// K2: LDS-staged voxel slabs.  grid (nslab, B), block 1024, dynamic LDS = S ints.
+// A workgroup owns the contiguous voxel range [s*S, (s+1)*S) of one cloud.  It streams the
+// cloud's voxel ids (4 B per point, L2 resident) and counts its own voxels with LDS atomics:
+// the returned value is the arrival slot of the point inside its voxel.  (Global returning
+// atomics run memory-side on MI355X at only ~5 G/s -- measured 140 us for 655k points; LDS
+// atomics make this kernel a pure L2 stream.)  Then: LDS exclusive scan of the slab's
+// populations, one bump allocation per slab for its compact segment range, coalesced stores of
+// cnt[] and off[] -- so no dense memset and no global scan pass either.
+__global__ __launch_bounds__(1024) void gg_k_slab_count(const int *__restrict__ vox, int N, int G,
+                                                        int S, int *__restrict__ arr,
+                                                        int *__restrict__ cnt,
+                                                        int *__restrict__ off,
+                                                        int *__restrict__ cursor)
 {
-    __shared__ int sw[4];
-    int base = blockIdx.x * GG_SCAN_CHUNK + threadIdx.x * 8;
-    int s = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) s += (base + j < n) ? cnt[base + j] : 0;
-    s = gg_wave_sum(s);
-    if (gg_lane() == 0) sw[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
-}
-
-__global__ __launch_bounds__(256) void gg_k_scan_apply(const int *__restrict__ cnt, int n,
-                                                       const int *__restrict__ part,
-                                                       int *__restrict__ off)
-{
-    __shared__ int sw[4];
+    extern __shared__ __attribute__((aligned(16))) int lcnt[];
+    __shared__ int swc[16];
     __shared__ int sbase;
-    // prefix of the preceding blocks' partial sums
-    int acc = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) acc += part[j];
-    acc = gg_wave_sum(acc);
-    if (gg_lane() == 0) sw[threadIdx.x >> 6] = acc;
+    const int b = blockIdx.y;
+    const int v0 = blockIdx.x * S;
+    const int v1 = (v0 + S < G) ? v0 + S : G;
+    const int ns = v1 - v0;
+    for (int j = threadIdx.x; j < ns; j += 1024) lcnt[j] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) sbase = sw[0] + sw[1] + sw[2] + sw[3];
-    __syncthreads();
-    int base = blockIdx.x * GG_SCAN_CHUNK + threadIdx.x * 8;
-    int v[8];
-    int s = 0;
+    const int *vb = vox + (size_t)b * N;
+    int *ab = arr + (size_t)b * N;
+    const int N4 = ((((size_t)b * N) & 3) == 0) ? (N >> 2) : 0;  // int4 path needs 16 B alignment
+    for (int q = threadIdx.x; q < N4; q += 1024) {
+        int4 v4 = ((const int4 *)vb)[q];
+        int vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        v[j] = (base + j < n) ? cnt[base + j] : 0;
-        s += v[j];
+        for (int j = 0; j < 4; j++) {
+            int v = vv[j];
+            if (v >= v0 && v < v1) ab[q * 4 + j] = atomicAdd(&lcnt[v - v0], 1);
+        }
     }
+    for (int i = N4 * 4 + threadIdx.x; i < N; i += 1024) {
+        int v = vb[i];
+        if (v >= v0 && v < v1) ab[i] = atomicAdd(&lcnt[v - v0], 1);
+    }
+    __syncthreads();
+    // exclusive scan of lcnt[0..ns): each thread owns a contiguous run of `per` entries
+    const int per = (ns + 1023) / 1024;
+    const int j0 = threadIdx.x * per;
+    int s = 0;
+    for (int j = j0; j < j0 + per && j < ns; j++) s += lcnt[j];
     int incl = gg_wave_incl_scan(s);
-    int wtot = __shfl(incl, 63, 64);
+    if (gg_lane() == 63) swc[threadIdx.x >> 6] = incl;
     __syncthreads();
-    if (gg_lane() == 0) sw[threadIdx.x >> 6] = wtot;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += sw[w];
-    int run = sbase + wbase + incl - s;
+    int wbase = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (base + j < n) off[base + j] = run;
-        run += v[j];
+    for (int w = 0; w < 16; w++) {
+        int t = swc[w];
+        if (w < (int)(threadIdx.x >> 6)) wbase += t;
+        total += t;
+    }
+    if (threadIdx.x == 0) sbase = b * N + (total ? atomicAdd(&cursor[b], total) : 0);
+    __syncthreads();
+    int run = sbase + wbase + incl - s;
+    size_t gb = (size_t)b * G + v0;
+    for (int j = j0; j < j0 + per && j < ns; j++) {
+        int c = lcnt[j];
+        cnt[gb + j] = c;
+        off[gb + j] = run;
+        run += c;
     }
 }
 
@@ -193,8 +212,10 @@ template __global__ void gg_k_rank<false>(int, GGGrid, const int *, const int *,
 __global__ __launch_bounds__(1024) void gg_k_centres(int N, GGGrid gp,
                                                      const unsigned char *__restrict__ lead,
                                                      const int *__restrict__ blkcnt,
+                                                     const unsigned long long *__restrict__ wsum_blk,
                                                      int *__restrict__ slotfirst1,
-                                                     int *__restrict__ centnum)
+                                                     int *__restrict__ centnum,
+                                                     int *__restrict__ exact)
 {
     __shared__ int swc[16];
     __shared__ int sred[16];
@@ -231,7 +252,18 @@ __global__ __launch_bounds__(1024) void gg_k_centres(int N, GGGrid gp,
             s = gg_reservoir_pick((unsigned long long)(long long)(int)i + 2ull * gp.seed, t + 1);
         if (s < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + s], ip + 1);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) centnum[b] = total < gp.O ? total : gp.O;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        centnum[b] = total < gp.O ? total : gp.O;
+        // weights of the cloud are integers and sum(|w|) < 2^23: every partial sum of S0's
+        // total_weight accumulation is exact, so it may be evaluated in any order
+        unsigned long long ws = 0, bad = 0;
+        for (int j = 0; j < nblk; j++) {
+            unsigned long long x = wsum_blk[(size_t)b * nblk + j];
+            bad |= x >> 63;
+            ws += x & ~(1ull << 63);
+        }
+        exact[b] = (!bad && ws < (1ull << 23)) ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -239,20 +271,26 @@ size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centre
 {
     const size_t BG = (size_t)B * gp.G, BN = (size_t)B * N;
     const int nblk = (N + 1023) / 1024;
-    const int nscan = (int)((BG + GG_SCAN_CHUNK - 1) / GG_SCAN_CHUNK);
+    // slabs: enough workgroups to fill 256 CUs twice, each slab <= 32768 voxels (128 KB of LDS)
+    int nslab = (512 + B - 1) / B;
+    const int min_slab = (gp.G + 32767) / 32768;
+    if (nslab < min_slab) nslab = min_slab;
+    if (nslab > gp.G) nslab = gp.G;
+    const int S = (gp.G + nslab - 1) / nslab;
+    nslab = (gp.G + S - 1) / S;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     GGIndexWs w;
     // ---- zero-filled region (one hipMemsetAsync) ----
-    w.o_cnt = take(BG * 4);
     w.o_slotfirst1 = take(with_centres ? (size_t)B * gp.O * 4 : 0);
-    w.o_blkcnt = take(with_centres ? (size_t)B * nblk * 4 : 0);
-    w.o_wsum = take((size_t)B * 8);
-    w.o_nonint = take((size_t)B * 4);
+    w.o_cursor = take((size_t)B * 4);
     w.zero_bytes = o;
     // ---- written before read ----
+    w.o_cnt = take(BG * 4);
     w.o_off = take(BG * 4);
-    w.o_part = take((size_t)nscan * 4);
+    w.o_blkcnt = take(with_centres ? (size_t)B * nblk * 4 : 0);
+    w.o_wsum = take((size_t)B * nblk * 8);
+    w.o_exact = take((size_t)B * 4);
     w.o_vox = take(BN * 4);
     w.o_arr = take(BN * 4);
     w.o_seg = take(BN * 4);
@@ -261,7 +299,8 @@ size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centre
     w.o_lead = take(with_centres ? BN : 0);
     w.total = o;
     w.nblk = nblk;
-    w.nscan = nscan;
+    w.nslab = nslab;
+    w.S = S;
     if (ws) *ws = w;
     return o;
 }
@@ -271,30 +310,37 @@ int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid 
                    hipStream_t st)
 {
     int *cnt = (int *)(wsbase + w.o_cnt), *off = (int *)(wsbase + w.o_off);
-    int *part = (int *)(wsbase + w.o_part), *vox = (int *)(wsbase + w.o_vox);
+    int *vox = (int *)(wsbase + w.o_vox);
     int *arr = (int *)(wsbase + w.o_arr), *seg = (int *)(wsbase + w.o_seg);
     int *sorted = (int *)(wsbase + w.o_sorted);
     int *bkt = with_centres ? (int *)(wsbase + w.o_bkt) : nullptr;
     unsigned char *lead = with_centres ? (unsigned char *)(wsbase + w.o_lead) : nullptr;
     int *slotfirst1 = (int *)(wsbase + w.o_slotfirst1), *blkcnt = (int *)(wsbase + w.o_blkcnt);
     unsigned long long *wsum = (unsigned long long *)(wsbase + w.o_wsum);
-    int *nonint = (int *)(wsbase + w.o_nonint);
-    const int BG = B * gp.G;
+    int *exact = (int *)(wsbase + w.o_exact);
+    int *cursor = (int *)(wsbase + w.o_cursor);
 
     if (hipMemsetAsync(wsbase, 0, w.zero_bytes, st) != hipSuccess) return 3;
-    dim3 g256((N + 255) / 256, B), g1024(w.nblk, B);
-    gg_k_voxelize<<<g256, 256, 0, st>>>((const float4 *)data, np, N, gp, vox, arr, cnt, wsum,
-                                        nonint);
-    gg_k_scan_partials<<<w.nscan, 256, 0, st>>>(cnt, BG, part);
-    gg_k_scan_apply<<<w.nscan, 256, 0, st>>>(cnt, BG, part, off);
+    dim3 g256((N + 255) / 256, B), g1024(w.nblk, B), gslab(w.nslab, B);
+    gg_k_voxelize<<<g1024, 1024, 0, st>>>((const float4 *)data, np, N, gp, vox, wsum);
+    gg_k_slab_count<<<gslab, 1024, (size_t)w.S * 4, st>>>(vox, N, gp.G, w.S, arr, cnt, off,
+                                                          cursor);
     gg_k_scatter<<<g256, 256, 0, st>>>(N, gp.G, vox, arr, off, seg, bkt);
     if (with_centres) {
         gg_k_rank<true><<<g1024, 1024, 0, st>>>(N, gp, vox, cnt, off, seg, sorted, bkt, lead,
                                                 blkcnt);
-        gg_k_centres<<<g1024, 1024, 0, st>>>(N, gp, lead, blkcnt, slotfirst1, centnum);
+        gg_k_centres<<<g1024, 1024, 0, st>>>(N, gp, lead, blkcnt, wsum, slotfirst1, centnum,
+                                             exact);
     } else {
         gg_k_rank<false><<<g1024, 1024, 0, st>>>(N, gp, vox, cnt, off, seg, sorted, nullptr,
                                                  nullptr, nullptr);
     }
     return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_index_init() {
+    // slabs may use up to 128 KB of dynamic LDS (default limit is 64 KB)
+    return hipFuncSetAttribute((const void *)gg_k_slab_count,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) == hipSuccess
+               ? 0 : 3;
 }

@@ -10,8 +10,7 @@
 #include "gridgcn_index.h"
 
 struct GGQueryPtrs {
-    const int *cnt, *off, *vox, *sorted, *bkt, *slotfirst1, *centnum, *nonint;
-    const unsigned long long *wsum;
+    const int *cnt, *off, *vox, *sorted, *bkt, *slotfirst1, *centnum, *exact;
 };
 
 // item g0 (0-based, flat over the neighbour table) -> point id
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(64) void gg_k_query_gridify(const float4 *__restric
     }
     __syncthreads();
 
-    const bool exact = (q.nonint[b] == 0) && (q.wsum[b] < (1ull << 23));
+    const bool exact = q.exact[b] != 0;
     const unsigned seedbase = (unsigned)index * (unsigned)P * (unsigned)k3;  // int wrap (:260)
     float total;
     if (exact) {
@@ -311,8 +310,7 @@ int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, c
     q.bkt = (const int *)(wsbase + w.o_bkt);
     q.slotfirst1 = (const int *)(wsbase + w.o_slotfirst1);
     q.centnum = centnum;
-    q.nonint = (const int *)(wsbase + w.o_nonint);
-    q.wsum = (const unsigned long long *)(wsbase + w.o_wsum);
+    q.exact = (const int *)(wsbase + w.o_exact);
     gg_k_query_gridify<<<B * gp.O, 64, 0, st>>>((const float4 *)data, N, gp, q, nebidx, nebmsk,
                                                 (float4 *)cent, centmsk);
     return hipGetLastError() == hipSuccess ? 0 : 3;

@@ -13,8 +13,7 @@
 #define GG_KNN_CAP 2048  // candidates staged per LDS tile
 
 struct GGKnnPtrs {
-    const int *cnt, *off, *vox, *sorted, *bkt, *slotfirst1, *centnum, *nonint;
-    const unsigned long long *wsum;
+    const int *cnt, *off, *vox, *sorted, *bkt, *slotfirst1, *centnum, *exact;
 };
 
 __global__ __launch_bounds__(64) void gg_k_query_knn(const float4 *__restrict__ data, int N,
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(64) void gg_k_query_knn(const float4 *__restrict__ 
         s_w[s] = cloud[id].w;
     }
     __syncthreads();
-    const bool exact = (q.nonint[b] == 0) && (q.wsum[b] < (1ull << 23));
+    const bool exact = q.exact[b] != 0;
     float total;
     if (exact) {
         long long acc = 0;
@@ -206,8 +205,7 @@ int gg_launch_query_knn(const float *data, int B, int N, const GGGrid &gp, char 
     q.bkt = (const int *)(wsbase + w.o_bkt);
     q.slotfirst1 = (const int *)(wsbase + w.o_slotfirst1);
     q.centnum = centnum;
-    q.nonint = (const int *)(wsbase + w.o_nonint);
-    q.wsum = (const unsigned long long *)(wsbase + w.o_wsum);
+    q.exact = (const int *)(wsbase + w.o_exact);
     gg_k_query_knn<<<B * gp.O, 64, 0, st>>>((const float4 *)data, N, gp, q, nebidx, nebmsk,
                                             (float4 *)cent, centmsk);
     return hipGetLastError() == hipSuccess ? 0 : 3;
