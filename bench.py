@@ -1,0 +1,165 @@
+"""bench.py -- BASELINE.json metric on MI355X: point-clouds/s fwd+bwd of the ScanNet 81920-pt
+segmentation network (configs[3]: batch 8 per GPU, data parallel), plus ms per CAGQ layer
+(= one Gridify call) with its HBM roofline, and the CPU baseline timed beside it.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad, forward (3 Gridify + 3 BallKNN + 6 gathers + 6 GridConv layers + head),
+loss, backward, one flat RCCL all-reduce of the gradients (N > 1), Adam update.  Inputs are
+synthetic clouds already resident in HBM (no dataset offline); weights are Xavier random.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from grid_gcn_amd import dp, model, ops, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def cpu_baseline(cfg, points, kind):
+    """Reference-side number: the S0 oracle (C, scalar) for the index ops + PyTorch CPU for
+    gather/GridConv, fwd+bwd of ONE cloud of the same workload (bounded sample)."""
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(0)
+    m = model.GGCNSeg(cfg, index_ops=OracleIndexOps)
+    m.train()
+    data, npn = synth.make_batch(1, points, kind)
+    x = torch.from_numpy(data[..., :3].copy())
+    n = torch.from_numpy(npn)
+    lab = torch.randint(0, cfg["num_classes"], (1, points))
+    t0 = time.time()
+    loss = model.seg_loss(m(x, n), lab)
+    loss.backward()
+    dt = time.time() - t0
+    # the CAGQ layer alone on the CPU (oracle, 1 core)
+    from oracle import oracle as orc
+    kw = synth.gridify_kwargs(cfg["grid"], 0)
+    t1 = time.time()
+    orc.gridify(data, npn, **kw)
+    dt_g = time.time() - t1
+    return {"value": 1.0 / dt, "unit": "point-clouds/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "1 cloud x %d pts, fwd+bwd: S0 oracle (C, 1 thread) for Gridify/BallKNN + "
+                      "PyTorch-CPU (%d threads) for gather/GridConv" % (points, torch.get_num_threads()),
+            "ms_per_cagq_layer_1core": dt_g * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=81920)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    cfg = model.SEG_81920 if a.points > 8192 else model.SEG_8192
+    if a.points not in (8192, 81920):       # off-config sizes keep the layer tables
+        cfg = dict(cfg)
+    kind = "planes"
+    torch.manual_seed(0)
+    net = model.GGCNSeg(cfg).to(dev)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    sync = dp.FlatGradAllReduce(net)
+    sync.broadcast_parameters()
+    B = a.batch
+    data, npn = synth.make_batch(B, a.points, kind, first_id=rank * B)   # a different shard per rank
+    x = torch.from_numpy(data[..., :3].copy()).to(dev)
+    n = torch.from_numpy(npn).to(dev)
+    lab = torch.randint(0, cfg["num_classes"], (B, a.points), device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.seg_loss(net(x, n), lab)
+        loss.backward()
+        sync()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item()
+
+    out = {
+        "metric": "point-clouds/sec fwd+bwd (ScanNet 81920-pt)", "value": world * B * a.steps / dt,
+        "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: ScanNet %d-pt segmentation, batch %d per GPU, "
+                               "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (a.points, B),
+                   "global_batch": world * B, "points_per_cloud": a.points,
+                   "parallelism": "dp%d" % world,
+                   "gridconv_mlp": "torch-rocm ops (rocBLAS/MIOpen); index ops + gather: HIP"},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- ms per CAGQ layer: Gridify of down layer 0 on the same batch, HIP events on the
+        #      stream the kernels are launched on (torch's current stream) ----
+        kw = synth.gridify_kwargs(cfg["grid"], 0)
+        d4 = torch.from_numpy(data).to(dev)
+        for _ in range(5):
+            ops.Gridify(d4, n, **kw)
+        torch.cuda.synchronize()
+        iters = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.Gridify(d4, n, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        alg = B * synth.gridify_algorithmic_bytes(a.points, kw["max_o_grid"], kw["max_p_grid"])
+        ach = alg / (ms * 1e-3) / 1e9
+        out["ms_per_cagq_layer"] = ms
+        out["roofline"] = {"bound": "hbm", "kernel": "gridgcn_gridify (memset + 6 launches, "
+                           "down layer 0)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": alg}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.points, kind)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""GridConv layer (`sub_g_update`) and its primitives, restated for PyTorch-ROCm.
+
+Follows segmentation/models/gcn_module_g_att.py:172-287 (sub_g_update), :120-170
+(verts_pair_func), :45-79 (aggregation_func), :24-43 (update_func) and the 1x1-conv primitives of
+utils/ops.py:141-158,236-260 (Convolution(1x1, bias) -> BatchNorm(eps=1e-3, momentum=bn_decay,
+fix_gamma=False) -> ReLU).  Tensors are edge-major / channels-last ([B,O,P,C]); a 1x1 conv on
+NCHW is the same contraction as a Linear on the last axis, BatchNorm statistics run over every
+other axis exactly as MXNet's axis=1 BatchNorm on [B,C,O,P].
+
+Two execution paths with identical semantics:
+  * "torch": every op is a stock PyTorch op (rocBLAS/MIOpen underneath) -- the fp32 reference
+    the fused HIP kernels are checked against;
+  * "fused": gather + geo features + per-edge MLPs + attention product + max over P inside the
+    hand-written gfx950 kernels of csrc/gridgcn_conv.hip (inference-mode BatchNorm).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_EPS = 1e-3  # MXNet BatchNorm default eps
+
+
+class ConvBNReLU(nn.Module):
+    """conv1d/conv2d(kernel 1) + BatchNorm + ReLU of utils/ops.py:141-158 on channels-last input."""
+
+    def __init__(self, cin, cout, bn_decay=0.9, use_bn=True, use_relu=True):
+        super().__init__()
+        self.lin = nn.Linear(cin, cout, bias=True)
+        nn.init.xavier_uniform_(self.lin.weight)      # mx.init.Xavier (base_solver.py:62)
+        nn.init.zeros_(self.lin.bias)
+        # MXNet momentum m: running = m*running + (1-m)*batch ; torch uses (1-m)
+        self.bn = nn.BatchNorm1d(cout, eps=BN_EPS, momentum=1.0 - bn_decay) if use_bn else None
+        self.use_relu = use_relu
+
+    def forward(self, x):
+        y = self.lin(x)
+        if self.bn is not None:
+            shp = y.shape
+            y = self.bn(y.reshape(-1, shp[-1])).reshape(shp)
+        return F.relu(y) if self.use_relu else y
+
+    def folded(self):
+        """(W^T [cin,cout], bias [cout]) with inference-mode BatchNorm folded in."""
+        w = self.lin.weight.detach().t().contiguous()
+        b = self.lin.bias.detach().clone()
+        if self.bn is not None:
+            s = self.bn.weight.detach() / torch.sqrt(self.bn.running_var + self.bn.eps)
+            w = w * s[None, :]
+            b = (b - self.bn.running_mean) * s + self.bn.bias.detach()
+        return w.contiguous(), b.contiguous()
+
+
+def mlp(cin, dims, bn_decay=0.9):
+    """mlp2d_c / mlp1d_c (utils/ops.py:236-260)."""
+    layers = []
+    for d in dims:
+        layers.append(ConvBNReLU(cin, d, bn_decay))
+        cin = d
+    return nn.Sequential(*layers)
+
+
+def geo_features(neighbors, centers_xyz):
+    """geo_vec, geo_dist and the attfdim=10 attention input (gcn_module_g_att.py:190-194, 217-218).
+    neighbors [B,O,P,4+C], centers_xyz [B,O,3]."""
+    nbr_xyz = neighbors[..., 0:3]
+    cexp = centers_xyz[:, :, None, :].expand_as(nbr_xyz)
+    geo_vec = nbr_xyz - cexp
+    geo_dist = torch.sqrt(torch.sum(geo_vec * geo_vec, dim=-1, keepdim=True))
+    att_vec = torch.cat([geo_dist, geo_vec, cexp, nbr_xyz], dim=-1)
+    return geo_vec, geo_dist, att_vec
+
+
+class SubGUpdate(nn.Module):
+    """sub_g_update for aggtype='gcn', pool 'max_pooling', attfdim=10 (the shipped seg configs).
+
+    in_feats   : C of the gathered features (0 -> first layer, neighbours carry xyz,w only)
+    localfdim  : 0 or 3 (3: geo_vec is concatenated to the features, gcn_module_g_att.py:249-250)
+    pt_mlp     : per-edge feature MLP dims
+    center_in  : channels of center_ori_feats (None: down layer)
+    center_dim / out_dim : centre MLP and update MLP dims (up layers)
+    """
+
+    def __init__(self, in_feats, pt_mlp, localfdim=0, relu=True, center_in=None, center_dim=(),
+                 out_dim=(), bn_decay=0.9):
+        super().__init__()
+        self.has_feats = in_feats > 0
+        self.localfdim = localfdim
+        self.relu = relu
+        cin = 3 if not self.has_feats else in_feats + (3 if localfdim != 0 else 0)
+        self.cin = cin
+        C = pt_mlp[-1]
+        self.pt_mlp = mlp(cin, pt_mlp, bn_decay)
+        self.att1 = mlp(10, [C // 4], bn_decay)          # update_att_mlp2d_frst (:141)
+        self.att2 = mlp(C // 4, [C], bn_decay)           # update_att_mlp2d_scnd (:152)
+        self.center_mlp = mlp(center_in, list(center_dim), bn_decay) if center_in else None
+        agg_c = C + (center_dim[-1] if (center_in and len(center_dim)) else (center_in or 0))
+        self.update_mlp = mlp(agg_c, list(out_dim), bn_decay) if len(out_dim) else None
+        self.out_channels = out_dim[-1] if len(out_dim) else agg_c
+
+    def edge_inputs(self, neighbors, centers_xyz):
+        geo_vec, _, att_vec = geo_features(neighbors, centers_xyz)
+        if not self.has_feats:
+            nf = geo_vec                                                   # :242-243
+        elif self.localfdim != 0:
+            nf = torch.cat([geo_vec, neighbors[..., 4:]], dim=-1)          # :249-250
+        else:
+            nf = neighbors[..., 4:]
+        return nf, att_vec
+
+    def forward(self, centers_xyz, neighbors, center_masks=None, center_ori_feats=None):
+        """centers_xyz [B,O,3], neighbors [B,O,P,4+C] (already gathered), center_masks [B,O]|None,
+        center_ori_feats [B,O,Cc]|None  ->  [B,O,out_channels]."""
+        nf, att_vec = self.edge_inputs(neighbors, centers_xyz)
+        pair = self.att2(self.att1(att_vec)) * self.pt_mlp(nf)             # :135-167
+        agg = pair.max(dim=2).values                                       # :57-59 (unmasked, F10)
+        return self.finish(agg, center_masks, center_ori_feats)
+
+    def finish(self, agg, center_masks, center_ori_feats):
+        if center_ori_feats is not None:
+            cf = self.center_mlp(center_ori_feats) if self.center_mlp is not None else center_ori_feats
+            agg = torch.cat([cf, agg], dim=-1)                             # up_center_inte=concat
+        if self.relu:
+            agg = F.relu(agg)                                              # update_func :31-32
+        if self.update_mlp is not None:
+            agg = self.update_mlp(agg)
+        if center_masks is not None:
+            agg = agg * center_masks[..., None]                            # :284-285
+        return agg

@@ -1,0 +1,109 @@
+"""Callers of the index operators: the ScanNet segmentation network `get_symbol_seg_ggcn`
+(segmentation/models/ggcn_models_g.py:110-237), restated so that the HIP operators are exercised
+with the reference's dataflow (layer chaining data_loc <- cent, actual_centnum threaded through,
+data_layer = concat(cent, feats), up path BallKNN | GridifyUp -> gather -> sub_g_update).
+
+Shape contract = segmentation/configs/configs.yaml:71-111 (8192-pt) and :144-189 (81920-pt).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, synth
+from .gridconv import ConvBNReLU, SubGUpdate
+
+SEG_8192 = dict(
+    grid=synth.SEG_SCANNET_8192, inputDim=[0, 64, 128], pt_ele_dim=[[32, 32, 64], [64, 64, 128],
+                                                                   [128, 128, 256]],
+    localfdim=0, relu=True, up_inputDim=[256, 128, 128], up_center_dim=[[128]] * 3,
+    up_pt_ele_dim=[[128]] * 3, up_gcn_outDim=[[128]] * 3, up_neigh_fetch=True, num_classes=21,
+    bn_decay=0.9, dropout=0.5)
+SEG_81920 = dict(SEG_8192, grid=synth.SEG_SCANNET_81920, localfdim=3, relu=False)
+
+
+class HipIndexOps:
+    """Default index provider: the gfx950 kernels behind the C ABI (grid_gcn_amd.ops)."""
+    Gridify = staticmethod(ops.Gridify)
+    GridifyUp = staticmethod(ops.GridifyUp)
+    BallKNN = staticmethod(ops.BallKNN)
+    batch_take_g = staticmethod(ops.batch_take_g)
+
+
+class GGCNSeg(nn.Module):
+    def __init__(self, cfg=SEG_8192, index_ops=HipIndexOps, seed=0):
+        super().__init__()
+        self.cfg = cfg
+        self.ix = index_ops
+        self.seed = seed
+        g = cfg["grid"]
+        nd = len(g["down"])
+        self.down = nn.ModuleList()
+        feat_c = [0]                                   # channels (without the 4 loc dims) per level
+        for i in range(nd):
+            layer = SubGUpdate(cfg["inputDim"][i], cfg["pt_ele_dim"][i], cfg["localfdim"],
+                               cfg["relu"], bn_decay=cfg["bn_decay"])
+            self.down.append(layer)
+            feat_c.append(layer.out_channels)
+        self.up = nn.ModuleList()
+        last_c = feat_c[-1]
+        for i in range(len(g["up"])):
+            this_c = 4 + feat_c[nd - 1 - i]            # f_this_layer carries xyz,w too (:212)
+            layer = SubGUpdate(last_c, cfg["up_pt_ele_dim"][i], cfg["localfdim"], cfg["relu"],
+                               center_in=this_c, center_dim=cfg["up_center_dim"][i],
+                               out_dim=cfg["up_gcn_outDim"][i], bn_decay=cfg["bn_decay"])
+            self.up.append(layer)
+            last_c = layer.out_channels
+        # get_seg_head (:30-43)
+        self.fc1 = ConvBNReLU(last_c, 128, cfg["bn_decay"])
+        self.fc2 = nn.Linear(128, cfg["num_classes"])
+        nn.init.xavier_uniform_(self.fc2.weight)
+        nn.init.zeros_(self.fc2.bias)
+
+    def forward(self, data_xyz, actual_centnum):
+        """data_xyz [B,N,3] f32, actual_centnum [B,1] i32 -> logits [B,N,num_classes]."""
+        cfg, g, ix = self.cfg, self.cfg["grid"], self.ix
+        B, N, _ = data_xyz.shape
+        data = torch.cat([data_xyz, torch.ones_like(data_xyz[..., :1])], dim=2)     # :137
+        locs = [data]                 # centers_reverse_lst: [B,n,4] per level
+        feats = [data]                # center_locnfeat_alllayers: [B,n,4+C]
+        masks, nums = [], [actual_centnum]
+        data_loc, data_layer = data, data
+        for i, layer in enumerate(self.down):
+            kw = synth.gridify_kwargs(g, i, self.seed)
+            nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
+                data_loc.detach().contiguous(), nums[-1], **kw)                     # :154-159
+            data_loc = cent
+            neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)            # :172-173
+            cf = layer(cent[..., 0:3], neighbors, centmsk)                          # :185
+            data_layer = torch.cat([cent, cf], dim=2)                               # :186
+            locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
+        f_last = feats[-1]
+        nup = len(self.up)
+        for i, layer in enumerate(self.up):
+            down, upl = locs[-i - 1], locs[-i - 2]
+            downnum, upnum = nums[-i - 1], nums[-i - 2]
+            U = g["up"][i]
+            if cfg["up_neigh_fetch"]:
+                radius = U["voxel_size"][0] * U["kernel_size"] * 1.7 / 2            # :204
+                nebidx = ix.BallKNN(upl[..., 0:3].detach().contiguous(),
+                                    down[..., 0:3].detach().contiguous(), downnum, upnum,
+                                    k=U["max_p_grid"], radius=radius)               # :85
+            else:
+                nebidx, _ = ix.GridifyUp(down.detach().contiguous(), upl.detach().contiguous(),
+                                         downnum, upnum,
+                                         **synth.gridify_up_kwargs(g, i, self.seed))  # :206-210
+            f_this = feats[-i - 2]
+            neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)                # :217-218
+            cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
+            cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)    # :229
+            f_last = torch.cat([upl, cf], dim=2)                                    # :231
+        net = self.fc1(cf)
+        net = F.dropout(net, self.cfg["dropout"], self.training)
+        return self.fc2(net)
+
+
+def seg_loss(logits, label):
+    """SoftmaxOutput(use_ignore=True, ignore_label=0, normalization='valid')
+    (segmentation/models/ggcn_models_g.py:41): mean cross-entropy over labels != 0."""
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), label.reshape(-1).long(),
+                           ignore_index=0, reduction="mean")
