@@ -15,6 +15,7 @@ EXPORTS = [
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
+    "gridgcn_gridconv_forward",
 ]
 
 
@@ -25,6 +26,12 @@ class GridParams(ctypes.Structure):
                 ("loc", ctypes.c_int32), ("coord_shift", ctypes.c_float * 3),
                 ("voxel_size", ctypes.c_float * 3), ("grid_size", ctypes.c_int32 * 3),
                 ("seed", ctypes.c_uint64)]
+
+
+class ConvLayer(ctypes.Structure):
+    """struct gridgcn_conv_layer (include/gridgcn.h)."""
+    _fields_ = [("W", ctypes.c_void_p), ("b", ctypes.c_void_p), ("K", ctypes.c_int32),
+                ("ldw", ctypes.c_int32), ("cout", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 _lib = None
@@ -67,6 +74,10 @@ def load():
     lib.gridgcn_batch_take.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
     lib.gridgcn_batch_take_backward.restype = ci
     lib.gridgcn_batch_take_backward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_gridconv_forward.restype = ci
+    lib.gridgcn_gridconv_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci,
+                                             ctypes.POINTER(ConvLayer), ctypes.POINTER(ConvLayer),
+                                             vp, vp]
     _lib = lib
     return lib
 

@@ -3,6 +3,7 @@
 // ball_k_nn.cc:34-42) and adds the limits this implementation relies on.
 #include "../../include/gridgcn.h"
 #include "gridgcn_index.h"
+#include "gridgcn_conv.h"
 
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
@@ -183,6 +184,49 @@ int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int
     if (!grad_out || !index || !grad_data || B < 1 || N < 1 || C < 1 || M < 1)
         return GRIDGCN_EINVAL;
     return gg_batch_take_backward(grad_out, index, B, N, C, M, grad_data, (hipStream_t)stream);
+}
+
+int gridgcn_gridconv_forward(const float *src, const int32_t *nebidx, const float *cent,
+                             int cent_stride, int B, int Nsrc, int Cs, int O, int P,
+                             int has_feats, int localfdim, int npt, const gridgcn_conv_layer *pt,
+                             const gridgcn_conv_layer *att, float *out, void *stream)
+{
+    if (!src || !nebidx || !cent || !pt || !att || !out) return GRIDGCN_EINVAL;
+    if (B < 1 || Nsrc < 1 || O < 1 || P < 1 || P > 128 || Cs < 4 || npt < 1 || npt > 4)
+        return GRIDGCN_EINVAL;
+    if (has_feats && Cs == 4) return GRIDGCN_EINVAL;
+    GGConvParams p;
+    p.src = src; p.nebidx = nebidx; p.cent = cent; p.out = out; p.cent_stride = cent_stride;
+    p.B = B; p.Nsrc = Nsrc; p.Cs = Cs; p.O = O; p.P = P;
+    p.has_feats = has_feats; p.localfdim = localfdim; p.npt = npt;
+    int cin = (has_feats ? Cs - 4 : 0) + ((!has_feats || localfdim != 0) ? 3 : 0);
+    int amax = cin + (cin & 1);
+    auto conv = [](const gridgcn_conv_layer &s, GGConvLayer *d) -> bool {
+        if (!s.W || !s.b || s.K < 2 || (s.K & 1)) return false;
+        if (s.ldw != 32 && s.ldw != 64 && s.ldw != 128 && s.ldw != 256) return false;
+        if (s.cout < 1 || s.cout > s.ldw) return false;
+        d->W = s.W; d->b = s.b; d->K = s.K; d->ldw = s.ldw; d->cout_real = s.cout; d->pad_ = 0;
+        return true;
+    };
+    int kin = amax;
+    for (int l = 0; l < npt; l++) {
+        if (!conv(pt[l], &p.pt[l]) || p.pt[l].K != kin) return GRIDGCN_EINVAL;
+        if (l < npt - 1) {
+            if (p.pt[l].ldw > amax) amax = p.pt[l].ldw;
+            kin = p.pt[l].cout_real + (p.pt[l].cout_real & 1);
+        }
+    }
+    for (int l = npt; l < 4; l++) p.pt[l] = p.pt[0];
+    if (!conv(att[0], &p.att[0]) || !conv(att[1], &p.att[1])) return GRIDGCN_EINVAL;
+    if (p.att[0].K != 10 || p.att[1].K != p.att[0].cout_real + (p.att[0].cout_real & 1))
+        return GRIDGCN_EINVAL;
+    if (p.att[1].ldw != p.pt[npt - 1].ldw || p.att[1].cout_real != p.pt[npt - 1].cout_real)
+        return GRIDGCN_EINVAL;
+    int tmax = p.att[0].ldw > 10 ? p.att[0].ldw : 10;
+    p.lda = amax | 1;          // odd row strides: conflict-free ds_read_b32 down a column
+    p.ldt = tmax | 1;
+    int rc = gg_gridconv_forward(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
 }  // extern "C"

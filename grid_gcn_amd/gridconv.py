@@ -115,6 +115,28 @@ class SubGUpdate(nn.Module):
         agg = pair.max(dim=2).values                                       # :57-59 (unmasked, F10)
         return self.finish(agg, center_masks, center_ori_feats)
 
+    def packed_layers(self):
+        """BatchNorm-folded, padded weights for the fused kernel (cached; eval mode only)."""
+        from . import ops
+        key = tuple(p._version for p in self.parameters()) + tuple(
+            b._version for b in self.buffers())
+        if getattr(self, "_packed_key", None) != key:
+            self._packed = ([ops.pack_conv_layer(*l.folded()) for l in self.pt_mlp],
+                            [ops.pack_conv_layer(*self.att1[0].folded()),
+                             ops.pack_conv_layer(*self.att2[0].folded())])
+            self._packed_key = key
+        return self._packed
+
+    def forward_fused(self, cent, src, nebidx, center_masks=None, center_ori_feats=None):
+        """Inference path through the hand-written gfx950 kernel (csrc/gridgcn_conv.hip):
+        src [B,Nsrc,4+C] (NOT gathered), nebidx [B,O,P], cent [B,O,>=3]."""
+        from . import ops
+        assert not self.training, "the fused kernel folds BatchNorm: eval() mode only"
+        pt, att = self.packed_layers()
+        agg = ops.gridconv_forward(src.contiguous(), nebidx, cent.contiguous(), pt, att,
+                                   has_feats=self.has_feats, localfdim=self.localfdim)
+        return self.finish(agg, center_masks, center_ori_feats)
+
     def finish(self, agg, center_masks, center_ori_feats):
         if center_ori_feats is not None:
             cf = self.center_mlp(center_ori_feats) if self.center_mlp is not None else center_ori_feats

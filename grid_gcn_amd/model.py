@@ -59,6 +59,11 @@ class GGCNSeg(nn.Module):
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
 
+    fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
+
+    def use_fused(self):
+        return self.fused and (not self.training) and self.ix is HipIndexOps
+
     def forward(self, data_xyz, actual_centnum):
         """data_xyz [B,N,3] f32, actual_centnum [B,1] i32 -> logits [B,N,num_classes]."""
         cfg, g, ix = self.cfg, self.cfg["grid"], self.ix
@@ -73,8 +78,11 @@ class GGCNSeg(nn.Module):
             nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
                 data_loc.detach().contiguous(), nums[-1], **kw)                     # :154-159
             data_loc = cent
-            neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)            # :172-173
-            cf = layer(cent[..., 0:3], neighbors, centmsk)                          # :185
+            if self.use_fused():
+                cf = layer.forward_fused(cent, data_layer, nebidx, centmsk)
+            else:
+                neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)        # :172-173
+                cf = layer(cent[..., 0:3], neighbors, centmsk)                      # :185
             data_layer = torch.cat([cent, cf], dim=2)                               # :186
             locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
         f_last = feats[-1]
@@ -93,9 +101,12 @@ class GGCNSeg(nn.Module):
                                          downnum, upnum,
                                          **synth.gridify_up_kwargs(g, i, self.seed))  # :206-210
             f_this = feats[-i - 2]
-            neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)                # :217-218
             cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
-            cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)    # :229
+            if self.use_fused():
+                cf = layer.forward_fused(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
+            else:
+                neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
+                cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
             f_last = torch.cat([upl, cf], dim=2)                                    # :231
         net = self.fc1(cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)

@@ -242,3 +242,51 @@ def batch_take_g(data, index, shape=None, scope=""):
              and index.is_contiguous() and index.shape[0] == data.shape[0],
              "index must be a contiguous int32 GPU tensor [B,...]")
     return _BatchTake.apply(data, index)
+
+
+# ---- fused GridConv edge pipeline (inference-mode BatchNorm) -----------------------------------
+def pack_conv_layer(w, b):
+    """(W^T [cin,cout], bias [cout]) with BatchNorm folded -> padded device tensors for
+    gridgcn_gridconv_forward: W [K][ldw] k-major (K = cin rounded up to even, ldw = cout rounded up
+    to 32/64/128/256, zero padded) and b [ldw]."""
+    cin, cout = w.shape
+    K = cin + (cin & 1)
+    ldw = next((x for x in (32, 64, 128, 256) if x >= cout), None)
+    _require(ldw is not None, "GridConv layer wider than 256 channels is not supported")
+    W = torch.zeros((K, ldw), dtype=torch.float32, device=w.device)
+    W[:cin, :cout] = w
+    B = torch.zeros((ldw,), dtype=torch.float32, device=w.device)
+    B[:cout] = b
+    return (W.contiguous(), B.contiguous(), K, ldw, cout)
+
+
+@torch.no_grad()
+def gridconv_forward(src, nebidx, cent, pt_layers, att_layers, *, has_feats, localfdim):
+    """Fused gather -> geo features -> pt-MLP (x) att-MLP -> max over P.
+
+    src [B,Nsrc,4+C] f32, nebidx [B,O,P] i32, cent [B,O,>=3] f32 (xyz first),
+    pt_layers / att_layers: lists of pack_conv_layer() tuples (att: exactly two).
+    Returns [B,O,C_out] f32 = max_p relu(att2) * relu(pt_last)
+    (segmentation/models/gcn_module_g_att.py:135-167, 57-59)."""
+    lib = _lib.load()
+    _chk(src, "src", 3, torch.float32)
+    _chk(nebidx, "nebidx", 3, torch.int32)
+    _chk(cent, "cent", 3, torch.float32)
+    B, Nsrc, Cs = src.shape
+    _, O, P = nebidx.shape
+    _require(cent.shape[0] == B and cent.shape[1] == O and cent.shape[2] >= 3, "cent must be [B,O,>=3]")
+    _require(len(att_layers) == 2 and 1 <= len(pt_layers) <= 4, "need 1..4 pt layers, 2 att layers")
+
+    def arr(layers):
+        a = (_lib.ConvLayer * len(layers))()
+        for j, (W, b, K, ldw, cout) in enumerate(layers):
+            a[j].W, a[j].b, a[j].K, a[j].ldw, a[j].cout = W.data_ptr(), b.data_ptr(), K, ldw, cout
+        return a
+    pt, att = arr(pt_layers), arr(att_layers)
+    out = torch.empty((B, O, pt_layers[-1][4]), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = lib.gridgcn_gridconv_forward(_ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B,
+                                          Nsrc, Cs, O, P, int(bool(has_feats)), int(localfdim),
+                                          len(pt_layers), pt, att, _ptr(out), _stream(src))
+    _lib.check(rc, "gridgcn_gridconv_forward")
+    return out

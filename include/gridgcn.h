@@ -119,6 +119,31 @@ int gridgcn_batch_take(const float *data, const int32_t *index, int B, int N, in
 int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int B, int N, int C,
                                 int M, float *grad_data, void *stream);
 
+/* ---- GridConv edge pipeline (inference-mode BatchNorm) ----------------------------------------
+ * Replaces, for one sub_g_update call (segmentation/models/gcn_module_g_att.py:172-287, aggtype
+ * 'gcn', attfdim 10, pool max), the operators between the index op and update_func:
+ *   batch_take_g (utils/ops.py:78-93) -> geo_vec/geo_dist/att_vec (:190-194,217-218) ->
+ *   [concat geo_vec if localfdim != 0] (:242-250) -> pt-MLP (:135) -> att-MLP (:141,152) ->
+ *   product (:167) -> max over P (:57-59).
+ * src[B,Nsrc,Cs] f32 (x,y,z,w,features; Cs = 4 + C_in), nebidx[B,O,P] i32 (take mode 'clip'),
+ * cent: xyz of centre ci at cent + ci*cent_stride floats, out[B,O,C] f32.
+ * Each 1x1 conv is given as W[K][ldw] (k-major, BatchNorm folded, zero padded: K = cin rounded up
+ * to even, ldw = cout rounded up to 32/64/128/256) and b[ldw].  pt: npt layers (1..4),
+ * att: exactly 2 layers (10 -> C/4 -> C).  Layer structs live in HOST memory, W/b on the device. */
+typedef struct gridgcn_conv_layer {
+    const float *W;
+    const float *b;
+    int32_t K;
+    int32_t ldw;
+    int32_t cout;
+    int32_t reserved;
+} gridgcn_conv_layer;
+
+int gridgcn_gridconv_forward(const float *src, const int32_t *nebidx, const float *cent,
+                             int cent_stride, int B, int Nsrc, int Cs, int O, int P,
+                             int has_feats, int localfdim, int npt, const gridgcn_conv_layer *pt,
+                             const gridgcn_conv_layer *att, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
