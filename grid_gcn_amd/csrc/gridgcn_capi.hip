@@ -199,10 +199,12 @@ int gridgcn_gridconv_forward(const float *src, const int32_t *nebidx, const floa
     p.src = src; p.nebidx = nebidx; p.cent = cent; p.out = out; p.cent_stride = cent_stride;
     p.B = B; p.Nsrc = Nsrc; p.Cs = Cs; p.O = O; p.P = P;
     p.has_feats = has_feats; p.localfdim = localfdim; p.npt = npt;
-    int cin = (has_feats ? Cs - 4 : 0) + ((!has_feats || localfdim != 0) ? 3 : 0);
-    int amax = cin + (cin & 1);
+    // LDS row of the first pt layer = the gathered source row with columns 0..3 replaced by
+    // (geo_vec, 0): K0 = Cs rounded up to a multiple of 4 (the packer zero-fills unused rows)
+    auto r4 = [](int x) { return (x + 3) & ~3; };
+    int amax = r4(Cs);
     auto conv = [](const gridgcn_conv_layer &s, GGConvLayer *d) -> bool {
-        if (!s.W || !s.b || s.K < 2 || (s.K & 1)) return false;
+        if (!s.W || !s.b || s.K < 4 || (s.K & 3)) return false;
         if (s.ldw != 32 && s.ldw != 64 && s.ldw != 128 && s.ldw != 256) return false;
         if (s.cout < 1 || s.cout > s.ldw) return false;
         d->W = s.W; d->b = s.b; d->K = s.K; d->ldw = s.ldw; d->cout_real = s.cout; d->pad_ = 0;
@@ -212,17 +214,18 @@ int gridgcn_gridconv_forward(const float *src, const int32_t *nebidx, const floa
     for (int l = 0; l < npt; l++) {
         if (!conv(pt[l], &p.pt[l]) || p.pt[l].K != kin) return GRIDGCN_EINVAL;
         if (l < npt - 1) {
+            if (p.pt[l].ldw > 128) return GRIDGCN_EINVAL;   // in-place layers: <= 128 wide
             if (p.pt[l].ldw > amax) amax = p.pt[l].ldw;
-            kin = p.pt[l].cout_real + (p.pt[l].cout_real & 1);
+            kin = r4(p.pt[l].cout_real);
         }
     }
     for (int l = npt; l < 4; l++) p.pt[l] = p.pt[0];
     if (!conv(att[0], &p.att[0]) || !conv(att[1], &p.att[1])) return GRIDGCN_EINVAL;
-    if (p.att[0].K != 10 || p.att[1].K != p.att[0].cout_real + (p.att[0].cout_real & 1))
+    if (p.att[0].K != 12 || p.att[0].ldw > 128 || p.att[1].K != r4(p.att[0].cout_real))
         return GRIDGCN_EINVAL;
     if (p.att[1].ldw != p.pt[npt - 1].ldw || p.att[1].cout_real != p.pt[npt - 1].cout_real)
         return GRIDGCN_EINVAL;
-    int tmax = p.att[0].ldw > 10 ? p.att[0].ldw : 10;
+    int tmax = p.att[0].ldw > 12 ? p.att[0].ldw : 12;
     p.lda = amax | 1;          // odd row strides: conflict-free ds_read_b32 down a column
     p.ldt = tmax | 1;
     int rc = gg_gridconv_forward(p, (hipStream_t)stream);

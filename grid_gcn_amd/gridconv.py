@@ -121,9 +121,23 @@ class SubGUpdate(nn.Module):
         key = tuple(p._version for p in self.parameters()) + tuple(
             b._version for b in self.buffers())
         if getattr(self, "_packed_key", None) != key:
-            self._packed = ([ops.pack_conv_layer(*l.folded()) for l in self.pt_mlp],
-                            [ops.pack_conv_layer(*self.att1[0].folded()),
-                             ops.pack_conv_layer(*self.att2[0].folded())])
+            # LDS row of the first pt layer = the gathered source row (x,y,z,w,features) with
+            # columns 0..3 overwritten by (geo_vec, 0): map the layer's input channels onto it
+            nfeat = self.cin - (3 if (not self.has_feats or self.localfdim != 0) else 0)
+            if not self.has_feats:
+                rows = [0, 1, 2]
+            elif self.localfdim != 0:
+                rows = [0, 1, 2] + [4 + j for j in range(nfeat)]
+            else:
+                rows = [4 + j for j in range(nfeat)]
+            k0 = (4 + (nfeat if self.has_feats else 0) + 3) & ~3
+            pt = []
+            for i, l in enumerate(self.pt_mlp):
+                w, b = l.folded()
+                pt.append(ops.pack_conv_layer(w, b, rows, k0) if i == 0
+                          else ops.pack_conv_layer(w, b))
+            self._packed = (pt, [ops.pack_conv_layer(*self.att1[0].folded(), K=12),
+                                 ops.pack_conv_layer(*self.att2[0].folded())])
             self._packed_key = key
         return self._packed
 

@@ -245,19 +245,32 @@ def batch_take_g(data, index, shape=None, scope=""):
 
 
 # ---- fused GridConv edge pipeline (inference-mode BatchNorm) -----------------------------------
-def pack_conv_layer(w, b):
-    """(W^T [cin,cout], bias [cout]) with BatchNorm folded -> padded device tensors for
-    gridgcn_gridconv_forward: W [K][ldw] k-major (K = cin rounded up to even, ldw = cout rounded up
-    to 32/64/128/256, zero padded) and b [ldw]."""
+def pack_conv_layer(w, b, rows=None, K=None):
+    """(W^T [cin,cout], bias [cout]) with BatchNorm folded -> device tensors in the layout
+    gridgcn_gridconv_forward reads (include/gridgcn.h):
+
+      * K    = contraction length, a multiple of 4.  `rows[i]` = LDS column fed by input channel
+               i (default: identity); unused rows are zero.
+      * ldw  = cout rounded up to 32/64/128/256, zero padded.
+      * W is packed per group of up to 128 columns as [group][K][32 lanes][NT] (NT = columns of the
+        group / 32) so that a lane fetches the NT weights of one k with a single vector load.
+    """
     cin, cout = w.shape
-    K = cin + (cin & 1)
+    if rows is None:
+        rows = list(range(cin))
+    if K is None:
+        K = (max(rows) + 1 + 3) & ~3
     ldw = next((x for x in (32, 64, 128, 256) if x >= cout), None)
     _require(ldw is not None, "GridConv layer wider than 256 channels is not supported")
     W = torch.zeros((K, ldw), dtype=torch.float32, device=w.device)
-    W[:cin, :cout] = w
+    W[torch.as_tensor(rows, device=w.device), :cout] = w
+    gw = min(ldw, 128)
+    nt = gw // 32
+    # [K, ldw] -> [groups, K, 32, nt]:  packed[g, k, j, t] = W[k, g*gw + t*32 + j]
+    Wp = W.reshape(K, ldw // gw, nt, 32).permute(1, 0, 3, 2).contiguous()
     B = torch.zeros((ldw,), dtype=torch.float32, device=w.device)
     B[:cout] = b
-    return (W.contiguous(), B.contiguous(), K, ldw, cout)
+    return (Wp, B.contiguous(), K, ldw, cout)
 
 
 @torch.no_grad()

@@ -127,9 +127,15 @@ int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int
  *   product (:167) -> max over P (:57-59).
  * src[B,Nsrc,Cs] f32 (x,y,z,w,features; Cs = 4 + C_in), nebidx[B,O,P] i32 (take mode 'clip'),
  * cent: xyz of centre ci at cent + ci*cent_stride floats, out[B,O,C] f32.
- * Each 1x1 conv is given as W[K][ldw] (k-major, BatchNorm folded, zero padded: K = cin rounded up
- * to even, ldw = cout rounded up to 32/64/128/256) and b[ldw].  pt: npt layers (1..4),
- * att: exactly 2 layers (10 -> C/4 -> C).  Layer structs live in HOST memory, W/b on the device. */
+ * Each 1x1 conv is given BatchNorm-folded and zero padded: contraction length K (multiple of 4),
+ * width ldw = cout rounded up to 32/64/128/256, bias b[ldw], and W packed per group of up to 128
+ * output columns as [group][K][32][NT] (NT = group columns / 32; element (k, j, t) is the weight
+ * of input row k and output column group*128 + t*32 + j).  Input rows of the first pt layer are
+ * the columns of the gathered source row with columns 0..3 replaced by (geo_vec, 0), i.e.
+ * K = round4(Cs); of the first att layer the 10 att_vec channels (K = 12); of every other layer
+ * the previous layer's outputs (K = round4(cout_prev)).  pt: npt layers (1..4), intermediate
+ * widths <= 128; att: exactly 2 layers (10 -> C/4 -> C).  Layer structs live in HOST memory,
+ * W/b on the device.  grid_gcn_amd.ops.pack_conv_layer builds this layout. */
 typedef struct gridgcn_conv_layer {
     const float *W;
     const float *b;
