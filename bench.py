@@ -149,10 +149,58 @@ def main():
         alg = B * synth.gridify_algorithmic_bytes(a.points, kw["max_o_grid"], kw["max_p_grid"])
         ach = alg / (ms * 1e-3) / 1e9
         out["ms_per_cagq_layer"] = ms
-        out["roofline"] = {"bound": "hbm", "kernel": "gridgcn_gridify (memset + 6 launches, "
-                           "down layer 0)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "algorithmic_bytes_per_launch": alg}
+        out["roofline_cagq"] = {"bound": "hbm", "kernel": "gridgcn_gridify (memset + 6 launches, "
+                                "down layer 0)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "traffic": 134e6,  # FETCH+WRITE_SIZE, profiles/r1_pmc_index.txt
+                                "algorithmic_bytes_per_launch": alg}
+        # ---- inference forward through the fused GridConv kernels (the reference's own speed
+        #      recipe times inference: train_gpu_speed_profiling.py:105-118) + the dominant
+        #      hand-written kernel of the path: gg_k_gridconv of up layer 2 (fp32 MFMA bound) ----
+        net.eval()
+        with torch.no_grad():
+            net.jobs = []
+            net(x, n)
+            jobs, net.jobs = net.jobs, None
+            for _ in range(2):
+                net(x, n)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                net(x, n)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_inf = e0.elapsed_time(e1) / 10
+            name, layer, cent_, src_, idx_ = max(jobs, key=lambda j: j[4].numel() * j[1].cin)
+            pt, att = layer.packed_layers()
+            src_ = src_.contiguous()
+            call = lambda: ops.gridconv_forward(src_, idx_, cent_, pt, att,  # noqa: E731
+                                                has_feats=layer.has_feats,
+                                                localfdim=layer.localfdim)
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_k = e0.elapsed_time(e1) / 20
+        macs = sum(l.lin.in_features * l.lin.out_features
+                   for seq in (layer.pt_mlp, layer.att1, layer.att2) for l in seq)
+        flops = 2.0 * idx_.numel() * macs
+        tf = flops / (ms_k * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gg_k_gridconv (GridConv %s: gather + "
+                           "per-edge MLPs + att product + max, one launch)" % name,
+                           "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                           "traffic": None, "algorithmic_flops_per_launch": flops,
+                           "ms_per_launch": ms_k, "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
+                           "note": "inference-mode BatchNorm; the timed training step above runs "
+                                   "the same contractions through rocBLAS (fused training kernels "
+                                   "pending)"}
+        out["inference"] = {"value": B / (ms_inf * 1e-3), "unit": "point-clouds/s",
+                            "ms_per_batch": ms_inf, "path": "HIP index ops + fused GridConv"}
+        net.train()
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.points, kind)
     if rank == 0:

@@ -60,6 +60,7 @@ class GGCNSeg(nn.Module):
         nn.init.zeros_(self.fc2.bias)
 
     fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
+    jobs = None    # set to a list to record (name, layer, cent, src, nebidx) of every fused call
 
     def use_fused(self):
         return self.fused and (not self.training) and self.ix is HipIndexOps
@@ -79,6 +80,8 @@ class GGCNSeg(nn.Module):
                 data_loc.detach().contiguous(), nums[-1], **kw)                     # :154-159
             data_loc = cent
             if self.use_fused():
+                if self.jobs is not None:
+                    self.jobs.append(("down%d" % i, layer, cent, data_layer, nebidx))
                 cf = layer.forward_fused(cent, data_layer, nebidx, centmsk)
             else:
                 neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)        # :172-173
@@ -103,6 +106,8 @@ class GGCNSeg(nn.Module):
             f_this = feats[-i - 2]
             cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
             if self.use_fused():
+                if self.jobs is not None:
+                    self.jobs.append(("up%d" % i, layer, upl, f_last, nebidx))
                 cf = layer.forward_fused(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
             else:
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
