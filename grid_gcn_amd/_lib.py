@@ -15,7 +15,7 @@ EXPORTS = [
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
-    "gridgcn_gridconv_forward",
+    "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
 ]
 
 
@@ -74,6 +74,10 @@ def load():
     lib.gridgcn_batch_take.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
     lib.gridgcn_batch_take_backward.restype = ci
     lib.gridgcn_batch_take_backward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_edge_inputs.restype = ci
+    lib.gridgcn_edge_inputs.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]
+    lib.gridgcn_edge_inputs_backward.restype = ci
+    lib.gridgcn_edge_inputs_backward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     lib.gridgcn_gridconv_forward.restype = ci
     lib.gridgcn_gridconv_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                                              ctypes.POINTER(ConvLayer), ctypes.POINTER(ConvLayer),

@@ -19,7 +19,10 @@ int gg_ball_knn(const float *, const float *, const int *, const int *, int, int
 int gg_knn(const float *, const float *, const int *, const int *, int, int, int, int, int *,
            hipStream_t);
 int gg_batch_take(const float *, const int *, int, int, int, int, float *, hipStream_t);
-int gg_batch_take_backward(const float *, const int *, int, int, int, int, float *, hipStream_t);
+int gg_batch_take_backward(const float *, const int *, int, int, int, int, float *, int, int,
+                           hipStream_t);
+int gg_edge_inputs(const float *, const int *, const float *, int, int, int, int, int, int, int, int,
+                   float *, float *, hipStream_t);
 
 static int ensure_init()
 {
@@ -183,7 +186,33 @@ int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int
 {
     if (!grad_out || !index || !grad_data || B < 1 || N < 1 || C < 1 || M < 1)
         return GRIDGCN_EINVAL;
-    return gg_batch_take_backward(grad_out, index, B, N, C, M, grad_data, (hipStream_t)stream);
+    return gg_batch_take_backward(grad_out, index, B, N, C, M, grad_data, C, C,
+                                  (hipStream_t)stream);
+}
+
+int gridgcn_edge_inputs(const float *src, const int32_t *nebidx, const float *cent,
+                        int cent_stride, int B, int Nsrc, int Cs, int O, int P, int has_feats,
+                        int localfdim, float *nf, float *att, void *stream)
+{
+    if (!src || !nebidx || !cent || !nf || !att) return GRIDGCN_EINVAL;
+    if (B < 1 || Nsrc < 1 || O < 1 || P < 1 || Cs < 4 || (has_feats && Cs == 4))
+        return GRIDGCN_EINVAL;
+    return gg_edge_inputs(src, nebidx, cent, cent_stride, B, Nsrc, Cs, O, P, has_feats, localfdim,
+                          nf, att, (hipStream_t)stream);
+}
+
+int gridgcn_edge_inputs_backward(const float *grad_nf, const int32_t *nebidx, int B, int Nsrc,
+                                 int Cs, int O, int P, int has_feats, int localfdim,
+                                 float *grad_src, void *stream)
+{
+    if (!grad_nf || !nebidx || !grad_src || B < 1 || Nsrc < 1 || O < 1 || P < 1 || Cs <= 4 ||
+        !has_feats)
+        return GRIDGCN_EINVAL;
+    const int fo = localfdim != 0 ? 3 : 0;
+    const int cin = fo + Cs - 4;
+    // only the feature columns carry gradient: xyz/w come from the non-differentiable index ops
+    return gg_batch_take_backward(grad_nf + fo, nebidx, B, Nsrc, Cs - 4, O * P, grad_src + 4, cin,
+                                  Cs, (hipStream_t)stream);
 }
 
 int gridgcn_gridconv_forward(const float *src, const int32_t *nebidx, const float *cent,

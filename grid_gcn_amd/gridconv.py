@@ -115,6 +115,17 @@ class SubGUpdate(nn.Module):
         agg = pair.max(dim=2).values                                       # :57-59 (unmasked, F10)
         return self.finish(agg, center_masks, center_ori_feats)
 
+    def forward_src(self, cent, src, nebidx, center_masks=None, center_ori_feats=None):
+        """Training path on the GPU: the edge inputs (gather + geo features + concat) come from
+        one HIP kernel (ops.edge_inputs, scatter-add backward); the MLPs with batch-statistics
+        BatchNorm are stock PyTorch ops."""
+        from . import ops
+        nf, att_vec = ops.edge_inputs(src.contiguous(), nebidx, cent.contiguous(),
+                                      has_feats=self.has_feats, localfdim=self.localfdim)
+        pair = self.att2(self.att1(att_vec)) * self.pt_mlp(nf)
+        agg = pair.max(dim=2).values
+        return self.finish(agg, center_masks, center_ori_feats)
+
     def packed_layers(self):
         """BatchNorm-folded, padded weights for the fused kernel (cached; eval mode only)."""
         from . import ops

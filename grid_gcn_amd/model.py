@@ -61,6 +61,7 @@ class GGCNSeg(nn.Module):
 
     fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
     jobs = None    # set to a list to record (name, layer, cent, src, nebidx) of every fused call
+    edge_kernel = True  # training: edge inputs from one HIP kernel instead of take+slice+cat ops
 
     def use_fused(self):
         return self.fused and (not self.training) and self.ix is HipIndexOps
@@ -83,6 +84,8 @@ class GGCNSeg(nn.Module):
                 if self.jobs is not None:
                     self.jobs.append(("down%d" % i, layer, cent, data_layer, nebidx))
                 cf = layer.forward_fused(cent, data_layer, nebidx, centmsk)
+            elif self.ix is HipIndexOps and self.edge_kernel:
+                cf = layer.forward_src(cent, data_layer, nebidx, centmsk)
             else:
                 neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)        # :172-173
                 cf = layer(cent[..., 0:3], neighbors, centmsk)                      # :185
@@ -109,6 +112,8 @@ class GGCNSeg(nn.Module):
                 if self.jobs is not None:
                     self.jobs.append(("up%d" % i, layer, upl, f_last, nebidx))
                 cf = layer.forward_fused(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
+            elif self.ix is HipIndexOps and self.edge_kernel:
+                cf = layer.forward_src(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
             else:
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229

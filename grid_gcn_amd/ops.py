@@ -303,3 +303,51 @@ def gridconv_forward(src, nebidx, cent, pt_layers, att_layers, *, has_feats, loc
                                           len(pt_layers), pt, att, _ptr(out), _stream(src))
     _lib.check(rc, "gridgcn_gridconv_forward")
     return out
+
+
+class _EdgeInputs(torch.autograd.Function):
+    """nf, att_vec of sub_g_update straight from (src, nebidx, cent) -- gridgcn_edge_inputs."""
+
+    @staticmethod
+    def forward(ctx, src, nebidx, cent, has_feats, localfdim):
+        lib = _lib.load()
+        B, Nsrc, Cs = src.shape
+        _, O, P = nebidx.shape
+        geo = (not has_feats) or localfdim != 0
+        cin = (3 if geo else 0) + (Cs - 4 if has_feats else 0)
+        nf = torch.empty((B, O, P, cin), dtype=torch.float32, device=src.device)
+        att = torch.empty((B, O, P, 10), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            rc = lib.gridgcn_edge_inputs(_ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc,
+                                         Cs, O, P, int(has_feats), int(localfdim), _ptr(nf),
+                                         _ptr(att), _stream(src))
+        _lib.check(rc, "gridgcn_edge_inputs")
+        ctx.save_for_backward(nebidx)
+        ctx.meta = (B, Nsrc, Cs, O, P, has_feats, localfdim)
+        ctx.mark_non_differentiable(att)
+        return nf, att
+
+    @staticmethod
+    def backward(ctx, gnf, gatt):
+        B, Nsrc, Cs, O, P, has_feats, localfdim = ctx.meta
+        if not has_feats or not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        (nebidx,) = ctx.saved_tensors
+        gnf = gnf.contiguous()
+        gsrc = torch.zeros((B, Nsrc, Cs), dtype=torch.float32, device=gnf.device)
+        with torch.cuda.device(gnf.device):
+            rc = lib.gridgcn_edge_inputs_backward(_ptr(gnf), _ptr(nebidx), B, Nsrc, Cs, O, P,
+                                                  int(has_feats), int(localfdim), _ptr(gsrc),
+                                                  _stream(gnf))
+        _lib.check(rc, "gridgcn_edge_inputs_backward")
+        return gsrc, None, None, None, None
+
+
+def edge_inputs(src, nebidx, cent, *, has_feats, localfdim):
+    """(nf [B,O,P,cin], att_vec [B,O,P,10]) of sub_g_update (gcn_module_g_att.py:190-250) in one
+    kernel; differentiable w.r.t. the feature columns of src."""
+    _chk(src, "src", 3, torch.float32)
+    _chk(nebidx, "nebidx", 3, torch.int32)
+    _chk(cent, "cent", 3, torch.float32)
+    return _EdgeInputs.apply(src, nebidx, cent, bool(has_feats), int(localfdim))

@@ -119,6 +119,20 @@ int gridgcn_batch_take(const float *data, const int32_t *index, int B, int N, in
 int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int B, int N, int C,
                                 int M, float *grad_data, void *stream);
 
+/* ---- edge inputs of sub_g_update (training path) ----------------------------------------------
+ * One pass instead of batch_take_g + slice_axis + tile + sub + sqrt(sum(square)) + concat
+ * (segmentation/models/gcn_module_g_att.py:190-194, 217-218, 242-250):
+ *   nf [B,O,P,cin]  = geo_vec (no features) | features (localfdim == 0) | concat(geo_vec, features)
+ *   att[B,O,P,10]   = (geo_dist, geo_vec, centre xyz, neighbour xyz)           (attfdim == 10)
+ * Backward: only the feature columns of src receive gradient (scatter-add, grad_src zero-filled
+ * by the caller); positions come from the non-differentiable index ops (gridify-inl.h:227-231). */
+int gridgcn_edge_inputs(const float *src, const int32_t *nebidx, const float *cent,
+                        int cent_stride, int B, int Nsrc, int Cs, int O, int P, int has_feats,
+                        int localfdim, float *nf, float *att, void *stream);
+int gridgcn_edge_inputs_backward(const float *grad_nf, const int32_t *nebidx, int B, int Nsrc,
+                                 int Cs, int O, int P, int has_feats, int localfdim,
+                                 float *grad_src, void *stream);
+
 /* ---- GridConv edge pipeline (inference-mode BatchNorm) ----------------------------------------
  * Replaces, for one sub_g_update call (segmentation/models/gcn_module_g_att.py:172-287, aggtype
  * 'gcn', attfdim 10, pool max), the operators between the index op and update_func:

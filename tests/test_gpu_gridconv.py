@@ -73,6 +73,53 @@ def test_fused_gridconv_matches_torch(case):
     check_close(got, want)
 
 
+@pytest.mark.parametrize("cin,lfd", [(0, 0), (0, 3), (64, 0), (64, 3), (33, 3)])
+def test_edge_inputs_forward_backward(cin, lfd):
+    """ops.edge_inputs == batch_take_g + geo features + concat (bit-exact forward: pure copies and
+    the same fp32 subtraction/sqrt), scatter-add backward within fp32 summation tolerance."""
+    gen = torch.Generator().manual_seed(cin + lfd)
+    B, Nsrc, O, P = 3, 200, 90, 12        # M = O*P >= 4*Nsrc: LDS-privatised backward
+    layer = SubGUpdate(cin, [32], localfdim=lfd).to(DEV)
+    src = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV).requires_grad_(cin > 0)
+    nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    nf, att = ops.edge_inputs(src, nebidx, cent, has_feats=cin > 0, localfdim=lfd)
+    src2 = src.detach().clone().requires_grad_(cin > 0)
+    nf2, att2 = layer.edge_inputs(ops.batch_take_g(src2, nebidx), cent[..., :3])
+    assert torch.equal(nf, nf2) and torch.equal(att[..., 1:], att2[..., 1:])
+    # geo_dist: torch.sum's reduction order over the 3 squares is not pinned -> 1 ulp
+    assert torch.allclose(att[..., 0], att2[..., 0], rtol=3e-7, atol=1e-7)
+    if cin > 0:
+        g = torch.randn(nf.shape, generator=gen).to(DEV)
+        nf.backward(g)
+        nf2.backward(g)
+        assert torch.allclose(src.grad[..., 4:], src2.grad[..., 4:], rtol=1e-4, atol=1e-4)
+        # x,y,z,w columns: in the network they are `cent` (output of the non-differentiable
+        # Gridify, gridify-inl.h:227-231), so their gradient is never used; the kernel skips it
+        assert float(src.grad[..., :4].abs().max()) == 0.0
+
+
+def test_training_step_edge_kernel_matches_torch_ops():
+    """one fwd+bwd of the whole network: HIP edge-input kernel path vs stock-op path."""
+    torch.manual_seed(0)
+    net = model.GGCNSeg(model.SEG_81920).to(DEV).train()
+    data, npn = synth.make_batch(2, 4096, "planes")
+    x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    lab = torch.randint(0, 21, (2, 4096), device=DEV)
+    grads = []
+    for ek in (True, False):
+        net.zero_grad()
+        net.edge_kernel = ek
+        torch.manual_seed(5)                       # dropout mask
+        loss = model.seg_loss(net(x, n), lab)
+        loss.backward()
+        grads.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-4
+    scale = float(grads[1][1].abs().max())
+    assert float((grads[0][1] - grads[1][1]).abs().max()) < 2e-3 * scale
+
+
 def test_full_model_eval_fused_vs_torch():
     torch.manual_seed(0)
     net = model.GGCNSeg(model.SEG_81920).to(DEV).eval()

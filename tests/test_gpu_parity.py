@@ -130,9 +130,11 @@ def test_error_behaviour():
 
 def test_batch_take_matches_oracle_and_grad():
     rng = np.random.default_rng(0)
-    for C in (4, 7, 68):
+    # (20,6): global-atomic backward; (80,6) and (300,5): LDS-privatised backward (M >= 4N)
+    for C, ishape in ((4, (20, 6)), (7, (20, 6)), (68, (20, 6)), (7, (80, 6)), (68, (80, 6)),
+                      (132, (300, 5)), (260, (300, 5))):
         data = rng.standard_normal((3, 50, C)).astype(np.float32)
-        index = rng.integers(-1, 51, (3, 20, 6)).astype(np.int32)
+        index = rng.integers(-1, 51, (3,) + ishape).astype(np.int32)
         want = orc.batch_take(data, index)
         td = T(data).requires_grad_(True)
         out = ops.batch_take_g(td, T(index))
