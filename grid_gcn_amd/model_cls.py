@@ -1,0 +1,112 @@
+"""ModelNet40 classification network `get_symbol_cls_ggcn`
+(classification/models/ggcn_models_g.py:37-111) and its GridConv variant
+(classification/models/gcn_module_g.py:64-114 verts_pair_func, :116-209 sub_g_update,
+:212-223 contextvec_func) restated for PyTorch-ROCm on top of the HIP index operators.
+
+Shipped config (classification/configs/configs.yaml:47-63): attfdim=4, localfdim=3,
+att_full='next', cntxt_mlp_lst=[[],[],[]] (context = max over P of the raw edge features, tiled),
+att_ele_dim, gcn_outDim=[[],[],[]], relu=True, group_all=False, 3 Gridify layers (k = 7/3/1; the
+last is a 1-voxel grid = global pooling).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import synth
+from .gridconv import ConvBNReLU, mlp
+from .model import HipIndexOps
+
+CLS_MN40 = dict(
+    grid=synth.CLS_MODELNET40, inputDim=[0, 128, 256],
+    pt_ele_dim=[[64, 64, 128], [128, 128, 256], [256, 256, 512]],
+    att_ele_dim=[[64, 128, 128], [128, 256, 256], [256, 512, 512]],
+    localfdim=3, attfdim=4, relu=True, num_classes=40, bn_decay=0.9, dropout=0.5)
+
+
+class SubGUpdateCls(nn.Module):
+    """classification sub_g_update: pt-MLP, attention MLP fed with
+    concat(att1(att_vec), pt-MLP output, context) (att_full='next' + contextvec), product, max."""
+
+    def __init__(self, in_feats, pt_mlp, att_ele, localfdim=3, relu=True, bn_decay=0.9):
+        super().__init__()
+        self.has_feats = in_feats > 0
+        self.localfdim = localfdim
+        self.relu = relu
+        cin = 3 if not self.has_feats else in_feats + (3 if localfdim != 0 else 0)
+        self.cin = cin
+        C = pt_mlp[-1]
+        att_ele = list(att_ele)
+        att_ele[-1] = C                                        # gcn_module_g.py:86
+        self.pt_mlp = mlp(cin, pt_mlp, bn_decay)
+        self.att1 = mlp(4, [att_ele[0]], bn_decay)             # :88-89  (attfdim = 4)
+        self.att2 = mlp(att_ele[0] + C + cin, att_ele[1:], bn_decay)   # :93-101
+        self.out_channels = C
+
+    def forward(self, centers_xyz, neighbors, center_masks=None):
+        nbr_xyz = neighbors[..., 0:3]
+        geo_vec = nbr_xyz - centers_xyz[:, :, None, :]
+        geo_dist = torch.sqrt(torch.sum(geo_vec * geo_vec, dim=-1, keepdim=True))
+        att_vec = torch.cat([geo_dist, geo_vec], dim=-1)                       # attfdim == 4
+        if not self.has_feats:
+            nf0 = geo_vec
+        elif self.localfdim != 0:
+            nf0 = torch.cat([geo_vec, neighbors[..., 4:]], dim=-1)
+        else:
+            nf0 = neighbors[..., 4:]
+        ctx = nf0.max(dim=2, keepdim=True).values.expand_as(nf0)               # contextvec_func
+        nf = self.pt_mlp(nf0)
+        att = self.att2(torch.cat([self.att1(att_vec), nf, ctx], dim=-1))
+        agg = (att * nf).max(dim=2).values
+        if self.relu:
+            agg = F.relu(agg)
+        if center_masks is not None:
+            agg = agg * center_masks[..., None]
+        return agg
+
+
+class FCBNReLU(nn.Module):
+    """fully_connected of utils/ops.py:205-216: FC -> BN -> ReLU -> Dropout."""
+
+    def __init__(self, cin, cout, bn_decay, dropout):
+        super().__init__()
+        self.l = ConvBNReLU(cin, cout, bn_decay)
+        self.dropout = dropout
+
+    def forward(self, x):
+        return F.dropout(self.l(x), self.dropout, self.training)
+
+
+class GGCNCls(nn.Module):
+    def __init__(self, cfg=CLS_MN40, index_ops=HipIndexOps, seed=0):
+        super().__init__()
+        self.cfg, self.ix, self.seed = cfg, index_ops, seed
+        self.layers = nn.ModuleList(
+            SubGUpdateCls(cfg["inputDim"][i], cfg["pt_ele_dim"][i], cfg["att_ele_dim"][i],
+                          cfg["localfdim"], cfg["relu"], cfg["bn_decay"])
+            for i in range(len(cfg["grid"]["down"])))
+        c = self.layers[-1].out_channels * cfg["grid"]["down"][-1]["max_o_grid"]
+        self.fc1 = FCBNReLU(c, 512, cfg["bn_decay"], cfg["dropout"])          # get_cls_head :29-34
+        self.fc2 = FCBNReLU(512, 256, cfg["bn_decay"], cfg["dropout"])
+        self.fc3 = nn.Linear(256, cfg["num_classes"])
+        nn.init.xavier_uniform_(self.fc3.weight)
+        nn.init.zeros_(self.fc3.bias)
+
+    def forward(self, data_xyz, actual_centnum):
+        """data_xyz [B,N,3], actual_centnum [B,1] i32 -> logits [B,40]."""
+        g, ix = self.cfg["grid"], self.ix
+        data = torch.cat([data_xyz, torch.ones_like(data_xyz[..., :1])], dim=2)   # :55
+        data_loc, num = data, actual_centnum
+        for i, layer in enumerate(self.layers):
+            nebidx, nebidxmsk, cent, centmsk, num = ix.Gridify(
+                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, self.seed))
+            data_loc = cent
+            neighbors = ix.batch_take_g(data.contiguous(), nebidx)                # :94
+            cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104
+            data = torch.cat([cent, cf], dim=2)                                   # :106
+        net = cf.reshape(cf.shape[0], -1)                                         # flatten=True
+        return self.fc3(self.fc2(self.fc1(net)))
+
+
+def cls_loss(logits, label):
+    """SoftmaxOutput(normalization='batch') (ggcn_models_g.py:34)."""
+    return F.cross_entropy(logits, label.long(), reduction="mean")
