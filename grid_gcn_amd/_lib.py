@@ -16,6 +16,9 @@ EXPORTS = [
     "gridgcn_ball_knn", "gridgcn_knn",
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
+    "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
+    "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
+    "gridgcn_bn_relu_bwd_elemt",
 ]
 
 
@@ -74,6 +77,19 @@ def load():
     lib.gridgcn_batch_take.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
     lib.gridgcn_batch_take_backward.restype = ci
     lib.gridgcn_batch_take_backward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    ll = ctypes.c_longlong
+    lib.gridgcn_linear_fwd.restype = ci
+    lib.gridgcn_linear_fwd.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_linear_bwd_workspace_bytes.restype = ci
+    lib.gridgcn_linear_bwd_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_linear_bwd.restype = ci
+    lib.gridgcn_linear_bwd.argtypes = [vp] * 14 + [ll, ci, ci, vp, vp, vp, vp, cs, vp]
+    lib.gridgcn_bn_relu_apply.restype = ci
+    lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, vp]
+    lib.gridgcn_bn_relu_bwd_reduce.restype = ci
+    lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
+    lib.gridgcn_bn_relu_bwd_elemt.restype = ci
+    lib.gridgcn_bn_relu_bwd_elemt.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
     lib.gridgcn_edge_inputs.restype = ci
     lib.gridgcn_edge_inputs.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]
     lib.gridgcn_edge_inputs_backward.restype = ci

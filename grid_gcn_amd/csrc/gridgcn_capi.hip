@@ -4,6 +4,7 @@
 #include "../../include/gridgcn.h"
 #include "gridgcn_index.h"
 #include "gridgcn_conv.h"
+#include "gridgcn_train.h"
 
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
@@ -188,6 +189,74 @@ int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int
         return GRIDGCN_EINVAL;
     return gg_batch_take_backward(grad_out, index, B, N, C, M, grad_data, C, C,
                                   (hipStream_t)stream);
+}
+
+int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, const float *b, int K,
+                       int ldw, int cout, const float *scale, const float *shift, float *Z,
+                       double *sums, void *stream)
+{
+    if (!X || !W || !b || !Z || !sums || E < 1 || cin < 1 || cout < 1 || cout > ldw)
+        return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X; p.W = W; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
+    p.E = E; p.cin = cin; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = 0;
+    int rc = gg_linear_fwd(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *bytes)
+{
+    if (!bytes || E < 1 || cin < 1 || C < 1) return GRIDGCN_EINVAL;
+    return gg_linear_bwd_workspace(E, cin, C, bytes, nullptr);
+}
+
+int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, const float *shift,
+                       const float *mean, const float *rstd, const float *m1, const float *m2,
+                       const float *Aprev, const float *pscale, const float *pshift,
+                       const float *pmean, const float *prstd, const float *Wb, long long E,
+                       int C, int cin, float *dX, float *dW, double *psums, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Aprev || !Wb || !dW)
+        return GRIDGCN_EINVAL;
+    if (pscale && (!pshift || !pmean || !prstd || (dX && !psums))) return GRIDGCN_EINVAL;
+    size_t need = 0;
+    gg_linear_bwd_workspace(E, cin, C, &need, nullptr);
+    if (!workspace || workspace_bytes < need) return GRIDGCN_EWORKSPACE;
+    GGLinBwd p;
+    p.dY = dY; p.Z = Z; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
+    p.m1 = m1; p.m2 = m2; p.Aprev = Aprev; p.pscale = pscale; p.pshift = pshift; p.pmean = pmean;
+    p.prstd = prstd; p.Wb = Wb; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW;
+    p.psums = psums; p.E = E; p.C = C; p.cin = cin; p.ldd = 0; p.lda = 0;
+    int rc = gg_linear_bwd(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
+                          long long E, int C, void *stream)
+{
+    if (!Z || !scale || !shift || !Y || E < 1 || C < 1) return GRIDGCN_EINVAL;
+    return gg_bn_apply(Z, scale, shift, Y, E, C, (hipStream_t)stream);
+}
+
+int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
+                               const float *shift, const float *mean, const float *rstd,
+                               long long E, int C, double *sums, void *stream)
+{
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !sums || E < 1 || C < 1)
+        return GRIDGCN_EINVAL;
+    int rc = gg_bn_bwd_reduce(dY, Z, scale, shift, mean, rstd, E, C, sums, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scale,
+                              const float *shift, const float *mean, const float *rstd,
+                              const float *m1, const float *m2, long long E, int C, float *dZ,
+                              void *stream)
+{
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !dZ || E < 1 || C < 1)
+        return GRIDGCN_EINVAL;
+    return gg_bn_bwd_elemt(dY, Z, scale, shift, mean, rstd, m1, m2, E, C, dZ, (hipStream_t)stream);
 }
 
 int gridgcn_edge_inputs(const float *src, const int32_t *nebidx, const float *cent,

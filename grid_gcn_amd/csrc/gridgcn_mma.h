@@ -1,0 +1,61 @@
+// gridgcn_mma.h -- fp32 MFMA building blocks shared by the training kernels (gfx950, wave64).
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; exact fp32 FMA chain, 157.3 TFLOP/s peak.
+//   A operand: lane l holds A[row = l&31][k = l>>5]      (one float)
+//   B operand: lane l holds B[k = l>>5][col = l&31]      (one float)
+//   C/D      : lane l holds col = l&31, rows (reg&3) + 8*(reg>>2) + 4*(l>>5), reg = 0..15
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float ggm_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT> struct GGMVec;
+template <> struct GGMVec<1> { typedef float T; };
+template <> struct GGMVec<2> { typedef float2 T; };
+template <> struct GGMVec<4> { typedef float4 T; };
+
+template <int NT> __device__ __forceinline__ float ggm_vget(const typename GGMVec<NT>::T &v, int i);
+template <> __device__ __forceinline__ float ggm_vget<1>(const float &v, int) { return v; }
+template <> __device__ __forceinline__ float ggm_vget<2>(const float2 &v, int i) {
+    return i == 0 ? v.x : v.y;
+}
+template <> __device__ __forceinline__ float ggm_vget<4>(const float4 &v, int i) {
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ int ggm_row(int reg, int lane) {
+    return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+template <int NT> __device__ __forceinline__ void ggm_zero(ggm_f32x16 (&acc)[NT])
+{
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
+}
+
+// acc[nt] += A[32 rows, 0:K] * Wg[0:K, nt*32 : nt*32+32]
+// A : LDS, row-major, row stride lda (odd => conflict-free column reads).
+// Wg: global, packed [K][32 lanes][NT] (one vector load per k-step).  K multiple of 4.
+template <int NT>
+__device__ __forceinline__ void ggm_mma(const float *A, int lda, const float *__restrict__ Wg,
+                                        int K, ggm_f32x16 (&acc)[NT])
+{
+    typedef typename GGMVec<NT>::T V;
+    const int lane = threadIdx.x & 63;
+    const float *ap = A + (lane & 31) * lda + (lane >> 5);
+    const V *wp = (const V *)Wg + ((lane >> 5) * 32 + (lane & 31));
+    float a0 = ap[0], a1 = ap[2];
+    V b0 = wp[0], b1 = wp[2 * 32];
+    const int nk = K >> 1;
+    for (int s = 0; s < nk; s += 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ggm_vget<NT>(b0, nt), acc[nt], 0, 0, 0);
+        if (s + 2 < nk) { a0 = ap[2 * (s + 2)]; b0 = wp[(size_t)(2 * (s + 2)) * 32]; }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ggm_vget<NT>(b1, nt), acc[nt], 0, 0, 0);
+        if (s + 3 < nk) { a1 = ap[2 * (s + 3)]; b1 = wp[(size_t)(2 * (s + 3)) * 32]; }
+    }
+}

@@ -1,0 +1,43 @@
+// gridgcn_train.h -- parameter blocks / host entries of the training kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GGLinFwd {
+    const float *X;       // [E][cin] row-major
+    const float *W;       // packed [groups][K][32][NT] (see gridgcn.h)
+    const float *b;       // [>= cout]
+    const float *scale;   // prologue: x <- relu(x*scale[c] + shift[c]); nullptr = identity
+    const float *shift;
+    float *Z;             // [E][cout]
+    double *sums;         // [2][cout]: sum z, sum z^2 (accumulated; zeroed by the caller)
+    long long E;
+    int cin, K, ldw, cout, lda;
+};
+
+struct GGLinBwd {
+    const float *dY;      // [E][C] gradient w.r.t. relu(bn(Z))
+    const float *Z;       // [E][C] pre-BatchNorm output of this layer
+    const float *scale, *shift, *mean, *rstd;   // [C] this layer (scale = gamma*rstd)
+    const float *m1, *m2;                       // [C] sum(dyr)/E, sum(dyr*zhat)/E
+    const float *Aprev;   // [E][cin] raw input of this layer: Z of the previous layer, or X
+    const float *pscale, *pshift, *pmean, *prstd;  // [cin] previous layer's BN (nullptr: Aprev = X)
+    const float *Wb;      // W (torch layout [C][cin]) packed tile-major [ceil(cin/32)][C4][32]
+    float *dX;            // [E][cin] gradient w.r.t. act(Aprev) (nullptr: not needed)
+    float *dWpart;        // workspace [nwg][cinP][CP]
+    float *dW;            // [C][cin]
+    double *psums;        // [2][cin] BN-backward sums of the previous layer (zeroed by caller)
+    long long E;
+    int C, cin, ldd, lda;
+};
+
+int gg_linear_fwd(const GGLinFwd &p, hipStream_t st);
+int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
+int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
+int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
+                int C, hipStream_t st);
+int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const float *shift,
+                     const float *mean, const float *rstd, long long E, int C, double *sums,
+                     hipStream_t st);
+int gg_bn_bwd_elemt(const float *dY, const float *Z, const float *scale, const float *shift,
+                    const float *mean, const float *rstd, const float *m1, const float *m2,
+                    long long E, int C, float *dZ, hipStream_t st);

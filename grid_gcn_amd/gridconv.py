@@ -59,6 +59,18 @@ def mlp(cin, dims, bn_decay=0.9):
     return nn.Sequential(*layers)
 
 
+def run_mlp(layers, x, mfma=True):
+    """A stack of ConvBNReLU layers.  Training on the GPU: one autograd op over the hand-written
+    kernels (train_ops.mlp_bn_relu_train); otherwise the stock PyTorch modules."""
+    if mfma and x.is_cuda and layers and layers[0].training and torch.is_grad_enabled():
+        from . import train_ops
+        if train_ops.supported(layers, x):
+            return train_ops.mlp_bn_relu_train(x, layers)
+    for l in layers:
+        x = l(x)
+    return x
+
+
 def geo_features(neighbors, centers_xyz):
     """geo_vec, geo_dist and the attfdim=10 attention input (gcn_module_g_att.py:190-194, 217-218).
     neighbors [B,O,P,4+C], centers_xyz [B,O,3]."""
@@ -97,6 +109,8 @@ class SubGUpdate(nn.Module):
         self.update_mlp = mlp(agg_c, list(out_dim), bn_decay) if len(out_dim) else None
         self.out_channels = out_dim[-1] if len(out_dim) else agg_c
 
+    mfma_train = True   # training on the GPU: MLPs through csrc/gridgcn_train.hip
+
     def edge_inputs(self, neighbors, centers_xyz):
         geo_vec, _, att_vec = geo_features(neighbors, centers_xyz)
         if not self.has_feats:
@@ -122,7 +136,8 @@ class SubGUpdate(nn.Module):
         from . import ops
         nf, att_vec = ops.edge_inputs(src.contiguous(), nebidx, cent.contiguous(),
                                       has_feats=self.has_feats, localfdim=self.localfdim)
-        pair = self.att2(self.att1(att_vec)) * self.pt_mlp(nf)
+        pair = run_mlp([self.att1[0], self.att2[0]], att_vec, self.mfma_train) * \
+            run_mlp(list(self.pt_mlp), nf, self.mfma_train)
         agg = pair.max(dim=2).values
         return self.finish(agg, center_masks, center_ori_feats)
 
@@ -164,12 +179,13 @@ class SubGUpdate(nn.Module):
 
     def finish(self, agg, center_masks, center_ori_feats):
         if center_ori_feats is not None:
-            cf = self.center_mlp(center_ori_feats) if self.center_mlp is not None else center_ori_feats
+            cf = (run_mlp(list(self.center_mlp), center_ori_feats, self.mfma_train)
+                  if self.center_mlp is not None else center_ori_feats)
             agg = torch.cat([cf, agg], dim=-1)                             # up_center_inte=concat
         if self.relu:
             agg = F.relu(agg)                                              # update_func :31-32
         if self.update_mlp is not None:
-            agg = self.update_mlp(agg)
+            agg = run_mlp(list(self.update_mlp), agg, self.mfma_train)
         if center_masks is not None:
             agg = agg * center_masks[..., None]                            # :284-285
         return agg

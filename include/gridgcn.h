@@ -133,6 +133,43 @@ int gridgcn_edge_inputs_backward(const float *grad_nf, const int32_t *nebidx, in
                                  int Cs, int O, int P, int has_feats, int localfdim,
                                  float *grad_src, void *stream);
 
+/* ---- training-mode 1x1 conv + BatchNorm + ReLU (utils/ops.py:149-158 conv2d, :141-147 conv1d) ---
+ * gridgcn_linear_fwd: Z[E,cout] = act(X[E,cin]) * W + b on fp32 MFMA; act = identity (scale ==
+ *   NULL) or the previous layer's BatchNorm+ReLU x -> relu(x*scale[c] + shift[c]) applied while
+ *   staging; sums[0:cout] += sum_e Z, sums[cout:2cout] += sum_e Z^2 (fp64, zeroed by the caller):
+ *   the batch statistics of THIS layer's BatchNorm.  W packed as for gridgcn_gridconv_forward.
+ * gridgcn_bn_relu_apply: Y = relu(Z*scale + shift).
+ * gridgcn_bn_relu_bwd_reduce: sums[0:C] += sum dyr, sums[C:2C] += sum dyr*zhat with
+ *   dyr = dY * (Z*scale+shift > 0), zhat = (Z-mean)*rstd.  C must divide 256 or be a multiple.
+ * gridgcn_bn_relu_bwd_elemt: dZ = scale * (dyr - m1 - zhat*m2)   (m1 = s1/E, m2 = s2/E). */
+int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, const float *b, int K,
+                       int ldw, int cout, const float *scale, const float *shift, float *Z,
+                       double *sums, void *stream);
+/* gridgcn_linear_bwd: backward of one (linear -> BatchNorm(batch stats) -> ReLU) layer in ONE pass
+ *   over the edges: dZ = scale*(dyr - m1 - zhat*m2) is formed while staging (dyr, zhat as above),
+ *   dX[E,cin] = dZ * W (gradient w.r.t. this layer's input activation; NULL = not needed),
+ *   dW[C,cin] = dZ^T * act(Aprev) with act = the previous layer's BatchNorm+ReLU applied on the fly
+ *   to its raw output Aprev (pscale == NULL: Aprev is the plain input), and
+ *   psums[0:cin] += sum dxr, psums[cin:2cin] += sum dxr*zhat_prev: the BatchNorm-backward sums of
+ *   the PREVIOUS layer, so that no separate reduce pass is needed for it.
+ *   Wb = W (layout [C][cin]) packed tile-major [ceil(cin/32)][round4(C)][32]. */
+int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *bytes);
+int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, const float *shift,
+                       const float *mean, const float *rstd, const float *m1, const float *m2,
+                       const float *Aprev, const float *pscale, const float *pshift,
+                       const float *pmean, const float *prstd, const float *Wb, long long E,
+                       int C, int cin, float *dX, float *dW, double *psums, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
+                          long long E, int C, void *stream);
+int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
+                               const float *shift, const float *mean, const float *rstd,
+                               long long E, int C, double *sums, void *stream);
+int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scale,
+                              const float *shift, const float *mean, const float *rstd,
+                              const float *m1, const float *m2, long long E, int C, float *dZ,
+                              void *stream);
+
 /* ---- GridConv edge pipeline (inference-mode BatchNorm) ----------------------------------------
  * Replaces, for one sub_g_update call (segmentation/models/gcn_module_g_att.py:172-287, aggtype
  * 'gcn', attfdim 10, pool max), the operators between the index op and update_func:
