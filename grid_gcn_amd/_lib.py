@@ -17,6 +17,7 @@ EXPORTS = [
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
+    "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_bwd_elemt",
 ]
@@ -83,7 +84,11 @@ def load():
     lib.gridgcn_linear_bwd_workspace_bytes.restype = ci
     lib.gridgcn_linear_bwd_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_bwd.restype = ci
-    lib.gridgcn_linear_bwd.argtypes = [vp] * 14 + [ll, ci, ci, vp, vp, vp, vp, cs, vp]
+    lib.gridgcn_linear_bwd.argtypes = [vp] * 14 + [ll, ci, ci, vp, vp, vp, vp, vp, ci, vp, cs, vp]
+    lib.gridgcn_pairmax_fwd.restype = ci
+    lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, vp, vp]
+    lib.gridgcn_pairmax_bwd.restype = ci
+    lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_relu_apply.restype = ci
     lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, vp]
     lib.gridgcn_bn_relu_bwd_reduce.restype = ci

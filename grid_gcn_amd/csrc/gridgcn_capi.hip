@@ -25,6 +25,13 @@ int gg_batch_take_backward(const float *, const int *, int, int, int, int, float
 int gg_edge_inputs(const float *, const int *, const float *, int, int, int, int, int, int, int, int,
                    float *, float *, hipStream_t);
 
+int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
+                   const float *, long long, int, int, float *, int *, hipStream_t);
+int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
+                   const float *, const float *, const float *, const float *, const float *,
+                   const float *, const int *, long long, int, int, float *, float *, double *,
+                   double *, hipStream_t);
+
 static int ensure_init()
 {
     static int rc = gg_index_init();  // thread-safe one-time init (C++11 static)
@@ -214,9 +221,12 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *mean, const float *rstd, const float *m1, const float *m2,
                        const float *Aprev, const float *pscale, const float *pshift,
                        const float *pmean, const float *prstd, const float *Wb, long long E,
-                       int C, int cin, float *dX, float *dW, double *psums, void *workspace,
-                       size_t workspace_bytes, void *stream)
+                       int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
+                       const float *gval, int P, void *workspace, size_t workspace_bytes,
+                       void *stream)
 {
+    if (amax && (!gval || P < 1 || E % P != 0)) return GRIDGCN_EINVAL;
+    if (!dY && amax) dY = Z;     // unused in sparse mode
     if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Aprev || !Wb || !dW)
         return GRIDGCN_EINVAL;
     if (pscale && (!pshift || !pmean || !prstd || (dX && !psums))) return GRIDGCN_EINVAL;
@@ -228,7 +238,34 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     p.m1 = m1; p.m2 = m2; p.Aprev = Aprev; p.pscale = pscale; p.pshift = pshift; p.pmean = pmean;
     p.prstd = prstd; p.Wb = Wb; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW;
     p.psums = psums; p.E = E; p.C = C; p.cin = cin; p.ldd = 0; p.lda = 0;
+    p.amax = amax; p.gval = gval; p.P = P > 0 ? P : 1;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
+                        const float *shift_p, const float *scale_a, const float *shift_a,
+                        long long ncent, int P, int C, float *agg, int32_t *amax, void *stream)
+{
+    if (!Zp || !Za || !scale_p || !shift_p || !scale_a || !shift_a || !agg || !amax || ncent < 1 ||
+        P < 1 || C < 1)
+        return GRIDGCN_EINVAL;
+    return gg_pairmax_fwd(Zp, Za, scale_p, shift_p, scale_a, shift_a, ncent, P, C, agg, amax,
+                          (hipStream_t)stream);
+}
+
+int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
+                        const float *shift_p, const float *mean_p, const float *rstd_p,
+                        const float *scale_a, const float *shift_a, const float *mean_a,
+                        const float *rstd_a, const float *dagg, const int32_t *amax,
+                        long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
+                        double *sums_a, void *stream)
+{
+    if (!Zp || !Za || !dagg || !amax || !gp || !ga || !sums_p || !sums_a || ncent < 1 || P < 1)
+        return GRIDGCN_EINVAL;
+    int rc = gg_pairmax_bwd(Zp, Za, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
+                            rstd_a, dagg, amax, ncent, P, C, gp, ga, sums_p, sums_a,
+                            (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

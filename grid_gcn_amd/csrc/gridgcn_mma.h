@@ -37,6 +37,33 @@ template <int NT> __device__ __forceinline__ void ggm_zero(ggm_f32x16 (&acc)[NT]
 // acc[nt] += A[32 rows, 0:K] * Wg[0:K, nt*32 : nt*32+32]
 // A : LDS, row-major, row stride lda (odd => conflict-free column reads).
 // Wg: global, packed [K][32 lanes][NT] (one vector load per k-step).  K multiple of 4.
+// same contraction with the packed weights resident in LDS (persistent workgroups load them once)
+template <int NT>
+__device__ __forceinline__ void ggm_mma_lds(const float *A, int lda, const float *Wl, int K,
+                                            ggm_f32x16 (&acc)[NT])
+{
+    typedef typename GGMVec<NT>::T V;
+    const int lane = threadIdx.x & 63;
+    const float *ap = A + (lane & 31) * lda + (lane >> 5);
+    const V *wp = (const V *)Wl + ((lane >> 5) * 32 + (lane & 31));
+    float a0 = ap[0], a1 = ap[2];
+    V b0 = wp[0], b1 = wp[2 * 32];
+    const int nk = K >> 1;
+    for (int s = 0; s < nk; s += 2) {
+        float a2 = 0.f, a3 = 0.f;
+        V b2 = b0, b3 = b1;
+        if (s + 2 < nk) { a2 = ap[2 * (s + 2)]; b2 = wp[(2 * (s + 2)) * 32]; }
+        if (s + 3 < nk) { a3 = ap[2 * (s + 3)]; b3 = wp[(2 * (s + 3)) * 32]; }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ggm_vget<NT>(b0, nt), acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ggm_vget<NT>(b1, nt), acc[nt], 0, 0, 0);
+        a0 = a2; a1 = a3; b0 = b2; b1 = b3;
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void ggm_mma(const float *A, int lda, const float *__restrict__ Wg,
                                         int K, ggm_f32x16 (&acc)[NT])

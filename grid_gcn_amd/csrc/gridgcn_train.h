@@ -12,6 +12,7 @@ struct GGLinFwd {
     double *sums;         // [2][cout]: sum z, sum z^2 (accumulated; zeroed by the caller)
     long long E;
     int cin, K, ldw, cout, lda;
+    int dbg;              // ablation switches (GG_DBG env): 1 no Z store, 2 stage once, 4 no MFMA
 };
 
 struct GGLinBwd {
@@ -28,6 +29,11 @@ struct GGLinBwd {
     double *psums;        // [2][cin] BN-backward sums of the previous layer (zeroed by caller)
     long long E;
     int C, cin, ldd, lda;
+    const int *amax;      // sparse upstream gradient (nullptr: dense dY): arg-max neighbour [E/P][C]
+    const float *gval;    //   and its value [E/P][C]; row e = centre e/P, neighbour e%P
+    int P, ncen_max;
+    unsigned t1[4];       // per wave: up to 3 GEMM1 column tiles, one byte each, 0xff = none
+    unsigned t2[4][3];    // per wave: up to 12 GEMM2 (m,n) pair ids, one byte each, 0xff = none
 };
 
 int gg_linear_fwd(const GGLinFwd &p, hipStream_t st);

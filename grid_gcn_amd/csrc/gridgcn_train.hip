@@ -14,6 +14,10 @@
 //                     layer from dX, so no separate reduce / element-wise passes remain
 //                     (rocBLAS ran these tall-skinny GEMMs at ~13 TFLOP/s).      [1 launch backward]
 //   gg_k_bn_apply / gg_k_bn_bwd_reduce   only at the two ends of an MLP.
+//
+// Both GEMM kernels are PERSISTENT: a workgroup loads the layer's (packed) weights into LDS once
+// and then walks row tiles, so the B operand never waits on L2 (with 4-byte-per-lane global B
+// loads the backward GEMM was latency bound: 10.7 ms for the 3.3 M-edge layer of cfg4).
 #include "gridgcn_mma.h"
 #include "gridgcn_train.h"
 
@@ -28,24 +32,37 @@ __device__ __forceinline__ void gg_stage_rows(float *dst, int ld, const float *_
 {
     const int nel = nrows * cin;
     const float inv = 1.0f / (float)cin;
-    for (int base = 0; base < nel; base += nthr * 4) {
-        float v[4];
-        int idx[4];
+    // two chunks of 8 loads per thread are in flight at any time: the loads of chunk k+1 are
+    // issued before chunk k is written to LDS, so only the first round trip to HBM is exposed
+    constexpr int U = 8;
+    const int step = nthr * U;
+    float va[U], vb[U];
+    auto ldg = [&](float (&v)[U], int base) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            idx[u] = base + u * nthr + tid;
-            v[u] = idx[u] < nel ? src[idx[u]] : 0.f;
+        for (int u = 0; u < U; u++) {
+            int i = base + u * nthr + tid;
+            v[u] = i < nel ? src[i] : 0.f;
         }
+    };
+    auto sts = [&](const float (&v)[U], int base) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (idx[u] < nel) {
-                int r = (int)(((float)idx[u] + 0.5f) * inv);     // exact for nel <= 32768
-                int c = idx[u] - r * cin;
+        for (int u = 0; u < U; u++) {
+            int i = base + u * nthr + tid;
+            if (i < nel) {
+                int r = (int)(((float)i + 0.5f) * inv);          // exact for nel <= 32768
+                int c = i - r * cin;
                 float x = v[u];
                 if (XFORM) { x = x * scale[c] + shift[c]; x = x > 0.f ? x : 0.f; }
                 dst[r * ld + c] = x;
             }
         }
+    };
+    ldg(va, 0);
+    for (int base = 0; base < nel; base += 2 * step) {
+        if (base + step < nel) ldg(vb, base + step);
+        sts(va, base);
+        if (base + 2 * step < nel) ldg(va, base + 2 * step);
+        if (base + step < nel) sts(vb, base + step);
     }
     const int padc = K - cin;
     if (padc > 0)
@@ -60,13 +77,94 @@ __device__ __forceinline__ void gg_stage_rows(float *dst, int ld, const float *_
 }
 
 // ------------------------------------------------------------------------------------------
-// forward: persistent single-wave workgroups; wave w handles row tiles w, w+gridDim.x, ...
-template <int NT>
-__global__ __launch_bounds__(64) void gg_k_linear_fwd(GGLinFwd p)
+// Register-resident tile: thread t of nthr holds float4 number (u*nthr + t) of a contiguous chunk
+// of `nel` floats (a 32-row tile of a row-major matrix is one such chunk, 16-byte aligned for any
+// row length because 32 rows * 4 B is a multiple of 16).  Loading a tile into registers BEFORE
+// the MFMA phase of the previous tile and writing it to LDS AFTER lets the HBM round trip of
+// tile t+1 hide behind the math of tile t (the phases were measured fully serialised:
+// stage 1.0 ms + MFMA 0.65 ms + store 0.67 ms for one 3.3 M-row layer).
+template <int NV> struct GGTileRegs { float4 v[NV]; };
+
+template <int NV>
+__device__ __forceinline__ void gg_tile_load(GGTileRegs<NV> &t, const float *__restrict__ src,
+                                             int nel, int tid, int nthr)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [32][lda]
-    const int lane = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const int i = (u * nthr + tid) * 4;
+        if (i + 3 < nel) t.v[u] = *(const float4 *)(src + i);
+        else {
+            t.v[u].x = i < nel ? src[i] : 0.f;
+            t.v[u].y = i + 1 < nel ? src[i + 1] : 0.f;
+            t.v[u].z = i + 2 < nel ? src[i + 2] : 0.f;
+            t.v[u].w = 0.f;
+        }
+    }
+}
+
+// calls f(r, c, value) for every element of the tile held in registers
+template <int NV, class F>
+__device__ __forceinline__ void gg_tile_foreach(const GGTileRegs<NV> &t, int nel, int cin, int tid,
+                                                int nthr, F f)
+{
+    const float inv = 1.0f / (float)cin;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const int i = (u * nthr + tid) * 4;
+        if (i < nel) {
+            int r = (int)(((float)i + 0.5f) * inv);          // exact for nel <= 32768
+            int c = i - r * cin;
+            const float e[4] = {t.v[u].x, t.v[u].y, t.v[u].z, t.v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i + k < nel) f(r, c, e[k], u * 4 + k);
+                if (++c == cin) { c = 0; r++; }
+            }
+        }
+    }
+}
+
+// zero the K padding columns and the rows beyond nrows of a [32][ld] LDS tile
+__device__ __forceinline__ void gg_tile_pad(float *dst, int ld, int nrows, int cin, int K, int tid,
+                                            int nthr)
+{
+    const int padc = K - cin;
+    if (padc > 0)
+        for (int i = tid; i < nrows * padc; i += nthr) {
+            int r = i / padc, c = cin + (i - r * padc);
+            dst[r * ld + c] = 0.f;
+        }
+    if (nrows < 32)
+        for (int i = nrows * K + tid; i < 32 * K; i += nthr) {
+            int r = i / K, c = i - r * K;
+            dst[r * ld + c] = 0.f;
+        }
+}
+
+__device__ __forceinline__ void gg_copy_to_lds(float *dst, const float *__restrict__ src, int n,
+                                               int tid, int nthr)
+{
+    const int n4 = n >> 2;
+    for (int i = tid; i < n4; i += nthr) ((float4 *)dst)[i] = ((const float4 *)src)[i];
+    for (int i = (n4 << 2) + tid; i < n; i += nthr) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: persistent workgroups of nw independent waves; each wave owns one 32-row tile at a
+// time; WLDS: the packed weights live in LDS for the lifetime of the workgroup.
+template <int NT, bool WLDS, int NV>
+__global__ __launch_bounds__(256, 1) void gg_k_linear_fwd(GGLinFwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int lda = p.lda;
+    float *Wl = lds;
+    float *Aw = lds + (WLDS ? p.K * p.ldw : 0) + wave * 32 * lda;
+    if (WLDS) {
+        gg_copy_to_lds(Wl, p.W, p.K * p.ldw, tid, blockDim.x);
+        __syncthreads();
+    }
+    static_assert(NV >= 1, "");
     const long long ntile = (p.E + 31) >> 5;
     const int ngroup = p.ldw / (32 * NT);
     float ssum[2][NT], ssq[2][NT];
@@ -75,18 +173,26 @@ __global__ __launch_bounds__(64) void gg_k_linear_fwd(GGLinFwd p)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) { ssum[g][nt] = 0.f; ssq[g][nt] = 0.f; }
 
-    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    // (a register-resident prefetch of the next tile -- gg_tile_load/gg_tile_foreach above -- was
+    //  measured SLOWER here: the epilogue's 64 stores per lane sit behind the prefetch loads in the
+    //  in-order vmcnt queue, so waiting for the loads also drains the stores.)
+    for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
+         tile += (long long)gridDim.x * nw) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        if (p.scale) gg_stage_rows<true>(lds, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, p.scale, p.shift, lane, 64);
-        else gg_stage_rows<false>(lds, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, nullptr, nullptr, lane, 64);
-        __syncthreads();
+        if (p.scale) gg_stage_rows<true>(Aw, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, p.scale, p.shift, lane, 64);
+        else gg_stage_rows<false>(Aw, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, nullptr, nullptr, lane, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g = 0; g < 2; g++) {
             if (g >= ngroup) continue;
             ggm_f32x16 acc[NT];
             ggm_zero<NT>(acc);
-            ggm_mma<NT>(lds, lda, p.W + (size_t)p.K * g * 32 * NT, p.K, acc);
+            if (!(p.dbg & 4)) {
+            if (WLDS) ggm_mma_lds<NT>(Aw, lda, Wl + (size_t)p.K * g * 32 * NT, p.K, acc);
+            else ggm_mma<NT>(Aw, lda, p.W + (size_t)p.K * g * 32 * NT, p.K, acc);
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 const int col = (g * NT + nt) * 32 + (lane & 31);
@@ -98,7 +204,7 @@ __global__ __launch_bounds__(64) void gg_k_linear_fwd(GGLinFwd p)
                     const int row = ggm_row(r, lane);
                     const float z = acc[nt][r] + bias;
                     if (cok && row < nrows) {
-                        p.Z[(r0 + row) * p.cout + col] = z;
+                        if (!(p.dbg & 1)) p.Z[(r0 + row) * p.cout + col] = z;
                         s += z;
                         q += z * z;
                     }
@@ -107,7 +213,7 @@ __global__ __launch_bounds__(64) void gg_k_linear_fwd(GGLinFwd p)
                 ssq[g][nt] += q;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int g = 0; g < 2; g++)
@@ -123,47 +229,77 @@ __global__ __launch_bounds__(64) void gg_k_linear_fwd(GGLinFwd p)
         }
 }
 
+template <int NT, int NV>
+static int launch_fwd_nv(const GGLinFwd &q, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_linear_fwd<NT, true, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_linear_fwd<NT, false, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    const long long ntile = (q.E + 31) >> 5;
+    const size_t wbytes = (size_t)q.K * q.ldw * 4, abytes = (size_t)32 * q.lda * 4;
+    const size_t cap = 158 * 1024;
+    int nw = 4;
+    bool wlds = true;
+    if (wbytes + 4 * abytes > cap) {
+        if (wbytes + 2 * abytes <= cap) nw = 2;
+        else { wlds = false; nw = (4 * abytes <= cap) ? 4 : 1; if (abytes > cap) return 1; }
+    }
+    const size_t lds = (wlds ? wbytes : 0) + nw * abytes;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    long long nb = (ntile + nw - 1) / nw;
+    if (nb > 256 * per_cu) nb = 256 * per_cu;
+    if (wlds) gg_k_linear_fwd<NT, true, NV><<<(int)nb, 64 * nw, lds, st>>>(q);
+    else gg_k_linear_fwd<NT, false, NV><<<(int)nb, 64 * nw, lds, st>>>(q);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+template <int NT>
+static int launch_fwd(const GGLinFwd &q, hipStream_t st)
+{
+    return launch_fwd_nv<NT, 1>(q, st);        // NV: register-tile size, unused by the shipped path
+}
+
 int gg_linear_fwd(const GGLinFwd &p, hipStream_t st)
 {
     if (p.E < 1 || p.cin < 1 || p.K < 4 || (p.K & 3) || p.K < p.cin || p.cin > 1024) return 1;
     if (p.ldw != 32 && p.ldw != 64 && p.ldw != 128 && p.ldw != 256) return 1;
     GGLinFwd q = p;
     q.lda = p.K | 1;
-    size_t lds = (size_t)32 * q.lda * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)gg_k_linear_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_fwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        attr_done = true;
-    }
-    long long ntile = (p.E + 31) >> 5;
-    int grid = (int)(ntile < 4096 ? ntile : 4096);
-    if (p.ldw == 32) gg_k_linear_fwd<1><<<grid, 64, lds, st>>>(q);
-    else if (p.ldw == 64) gg_k_linear_fwd<2><<<grid, 64, lds, st>>>(q);
-    else gg_k_linear_fwd<4><<<grid, 64, lds, st>>>(q);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
+    q.dbg = getenv("GG_DBG") ? atoi(getenv("GG_DBG")) : 0;
+    if (p.ldw == 32) return launch_fwd<1>(q, st);
+    if (p.ldw == 64) return launch_fwd<2>(q, st);
+    return launch_fwd<4>(q, st);
 }
 
 // ------------------------------------------------------------------------------------------
 // backward of one (linear -> BatchNorm(batch stats) -> ReLU) layer.  256 threads = 4 waves share
 // one 32-row tile; persistent workgroups (tile = blockIdx.x, += gridDim.x).
 //   D  [32][ldd] = dZ tile        Zp [32][lda] = raw previous activation tile (Z_{l-1} or X)
-//   GEMM1: dX[32 x cin] = D * Wb            column tiles wave, wave+4, ...   (<= 3 per wave)
-//   GEMM2: dW[cin x C] += act(Zp)^T * D     (m,n) tile pairs wave, wave+4, ... (<= PAIRS per wave)
-template <int PAIRS>
-__global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
+//   GEMM1: dX[32 x cin] = D * Wb            column tiles listed in p.t1[wave]   (<= 3 per wave)
+//   GEMM2: dW[cin x C] += act(Zp)^T * D     (m,n) tile pairs listed in p.t2[wave] (<= PAIRS)
+// The host balances the two lists so that every wave issues the same number of MFMAs per tile.
+template <int PAIRS, bool WLDS>
+__global__ __launch_bounds__(256, 1) void gg_k_linear_bwd(GGLinBwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = p.C, cin = p.cin;
     const int ldd = p.ldd, lda = p.lda;
-    float *D = lds;                          // [32][ldd]
+    const int C4 = (C + 3) & ~3;
+    const int ntn1 = (cin + 31) >> 5;        // column tiles over cin
+    const int ntn2 = (C + 31) >> 5;          // column tiles over C
+    float *Wl = lds;                         // [ntn1][C4][32] when WLDS
+    float *D = lds + (WLDS ? ntn1 * C4 * 32 : 0);   // [32][ldd]
     float *Zp = D + 32 * ldd;                // [32][lda]
     float *cst = Zp + 32 * lda;              // per-channel constants
     float *c_scale = cst, *c_shift = cst + C, *c_mean = cst + 2 * C, *c_rstd = cst + 3 * C;
     float *c_m1 = cst + 4 * C, *c_m2 = cst + 5 * C;
     float *c_ps = cst + 6 * C, *c_psh = c_ps + cin, *c_pm = c_psh + cin, *c_pr = c_pm + cin;
+    int *s_am = (int *)(c_pr + cin);         // [ncen_max][C] arg max of the tile's centres
+    float *s_gv = (float *)(s_am + p.ncen_max * C);
     for (int c = tid; c < C; c += 256) {
         c_scale[c] = p.scale[c]; c_shift[c] = p.shift[c]; c_mean[c] = p.mean[c];
         c_rstd[c] = p.rstd[c]; c_m1[c] = p.m1[c]; c_m2[c] = p.m2[c];
@@ -173,11 +309,13 @@ __global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
         c_ps[c] = prevbn ? p.pscale[c] : 1.f; c_psh[c] = prevbn ? p.pshift[c] : 0.f;
         c_pm[c] = prevbn ? p.pmean[c] : 0.f; c_pr[c] = prevbn ? p.prstd[c] : 0.f;
     }
-    const int C4 = (C + 3) & ~3;
-    const int ntn1 = (cin + 31) >> 5;        // GEMM1 column tiles (over cin)
-    const int ntm = ntn1;                    // GEMM2 M tiles (over cin)
-    const int ntn2 = (C + 31) >> 5;          // GEMM2 N tiles (over C)
-    const int npairs = ntm * ntn2;
+    if (WLDS && p.dX) gg_copy_to_lds(Wl, p.Wb, ntn1 * C4 * 32, tid, 256);
+    // this wave's work lists (packed bytes, 0xff = none)
+    const unsigned t1 = wave == 0 ? p.t1[0] : (wave == 1 ? p.t1[1] : (wave == 2 ? p.t1[2] : p.t1[3]));
+    unsigned t2[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+        t2[w] = wave == 0 ? p.t2[0][w] : (wave == 1 ? p.t2[1][w] : (wave == 2 ? p.t2[2][w] : p.t2[3][w]));
     const long long ntile = (p.E + 31) >> 5;
 
     ggm_f32x16 accW[PAIRS];
@@ -188,31 +326,64 @@ __global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        // ---- sparse upstream gradient: (amax, gval) rows of the centres this tile touches ----
+        int rem0 = 0;
+        const float invP = 1.0f / (float)p.P;
+        if (p.amax) {
+            const long long o0 = r0 / p.P;
+            rem0 = (int)(r0 - o0 * p.P);
+            const int ncen = (rem0 + nrows - 1) / p.P + 1;
+            const int *am = p.amax + o0 * C;
+            const float *gv = p.gval + o0 * C;
+            for (int i = tid; i < ncen * C; i += 256) { s_am[i] = am[i]; s_gv[i] = gv[i]; }
+            __syncthreads();
+        }
         // ---- stage D = dZ (BatchNorm+ReLU backward, element-wise part) ----
         {
             const float *dy = p.dY + r0 * C, *zz = p.Z + r0 * C;
             const int nel = nrows * C;
             const float inv = 1.0f / (float)C;
-            for (int base = 0; base < nel; base += 1024) {
-                float g[4], z[4];
-                int idx[4];
+            // ping-pong chunks of 4+4 loads per thread: only the first HBM round trip is exposed
+            constexpr int U = 4;
+            float ga[U], za[U], gb[U], zb[U];
+            auto ldg = [&](float (&g)[U], float (&z)[U], int base) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    idx[u] = base + u * 256 + tid;
-                    g[u] = idx[u] < nel ? dy[idx[u]] : 0.f;
-                    z[u] = idx[u] < nel ? zz[idx[u]] : 0.f;
+                for (int u = 0; u < U; u++) {
+                    int i = base + u * 256 + tid;
+                    z[u] = i < nel ? zz[i] : 0.f;
+                    g[u] = (!p.amax && i < nel) ? dy[i] : 0.f;
                 }
+            };
+            auto sts = [&](const float (&g)[U], const float (&z)[U], int base) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (idx[u] < nel) {
-                        int r = (int)(((float)idx[u] + 0.5f) * inv);
-                        int c = idx[u] - r * C;
+                for (int u = 0; u < U; u++) {
+                    int i = base + u * 256 + tid;
+                    if (i < nel) {
+                        int r = (int)(((float)i + 0.5f) * inv);
+                        int c = i - r * C;
                         float sc = c_scale[c];
-                        float d = (z[u] * sc + c_shift[c] > 0.f) ? g[u] : 0.f;
+                        float gg = g[u];
+                        if (p.amax) {
+                            // sparse upstream gradient (max over P): only the arg-max edge of a
+                            // (centre, channel) carries gval; the tile's centres sit in LDS
+                            int t = rem0 + r;
+                            int oc = (int)(((float)t + 0.5f) * invP);
+                            int pp = t - oc * p.P;
+                            gg = (s_am[oc * C + c] == pp) ? s_gv[oc * C + c] : 0.f;
+                        }
+                        float d = (z[u] * sc + c_shift[c] > 0.f) ? gg : 0.f;
                         float zh = (z[u] - c_mean[c]) * c_rstd[c];
                         D[r * ldd + c] = sc * (d - c_m1[c] - zh * c_m2[c]);
                     }
                 }
+            };
+            const int step = 256 * U;
+            ldg(ga, za, 0);
+            for (int base = 0; base < nel; base += 2 * step) {
+                if (base + step < nel) ldg(gb, zb, base + step);
+                sts(ga, za, base);
+                if (base + 2 * step < nel) ldg(ga, za, base + 2 * step);
+                if (base + step < nel) sts(gb, zb, base + step);
             }
             const int padc = C4 - C;
             if (padc > 0)
@@ -226,19 +397,20 @@ __global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
             }
         }
         // ---- stage Zp = raw previous activation (BatchNorm+ReLU applied on the fly in GEMM2) ----
-        gg_stage_rows<false>(Zp, lda, p.Aprev + r0 * cin, nrows, cin, ntm * 32 < lda ? ntm * 32 : lda - 1,
-                             nullptr, nullptr, tid, 256);
+        gg_stage_rows<false>(Zp, lda, p.Aprev + r0 * cin, nrows, cin, ntn1 * 32, nullptr, nullptr,
+                             tid, 256);
         __syncthreads();
 
         // ---- GEMM1: dX = D * Wb, previous layer's BN-backward sums in the epilogue ----
         if (p.dX) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const int nt = wave + 4 * j;
-                if (nt >= ntn1) continue;
+                const int nt = (t1 >> (8 * j)) & 0xff;
+                if (nt == 0xff) continue;
                 ggm_f32x16 acc[1];
                 ggm_zero<1>(acc);
-                ggm_mma<1>(D, ldd, p.Wb + (size_t)nt * C4 * 32, C4, acc);
+                if (WLDS) ggm_mma_lds<1>(D, ldd, Wl + nt * C4 * 32, C4, acc);
+                else ggm_mma<1>(D, ldd, p.Wb + (size_t)nt * C4 * 32, C4, acc);
                 const int col = nt * 32 + (lane & 31);
                 if (col < cin) {
                     const float ps = c_ps[col], psh = c_psh[col], pm = c_pm[col], pr = c_pr[col];
@@ -265,31 +437,38 @@ __global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
         // ---- GEMM2: dW(m,n) += act(Zp)^T * D over the 32 rows of the tile ----
 #pragma unroll
         for (int j = 0; j < PAIRS; j++) {
-            const int q = wave + 4 * j;
-            if (q >= npairs) continue;
+            const int q = (t2[j >> 2] >> (8 * (j & 3))) & 0xff;
+            if (q == 0xff) continue;
             const int mt = q / ntn2, nt = q - mt * ntn2;
             const int mi = mt * 32 + (lane & 31);            // this lane's cin column
-            const float ps = mi < cin ? c_ps[mi] : 0.f, psh = mi < cin ? c_psh[mi] : 0.f;
-            const float *ap = Zp + (lane >> 5) * lda + (mi < lda ? mi : 0);
+            const bool mok = mi < cin;
+            const float ps = mok ? c_ps[mi] : 0.f, psh = mok ? c_psh[mi] : 0.f;
+            const float *ap = Zp + (lane >> 5) * lda + mi;
             const float *bp = D + (lane >> 5) * ldd + nt * 32 + (lane & 31);
-#pragma unroll 4
-            for (int k = 0; k < 32; k += 2) {
-                float a = ap[k * lda];
+            const bool nok = nt * 32 + (lane & 31) < C4;
+            float av[16], bv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                av[k] = ap[2 * k * lda];
+                bv[k] = nok ? bp[2 * k * ldd] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                float a = av[k];
                 if (prevbn) { a = a * ps + psh; a = a > 0.f ? a : 0.f; }
-                if (mi >= cin) a = 0.f;
-                const float b = (nt * 32 + (lane & 31) < C4) ? bp[k * ldd] : 0.f;
-                accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accW[j], 0, 0, 0);
+                if (!mok) a = 0.f;
+                accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[k], accW[j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
     // ---- flush: dW partials of this workgroup, BN-backward sums of the previous layer ----
-    const int cinP = ntm * 32, CP = ntn2 * 32;
+    const int cinP = ntn1 * 32, CP = ntn2 * 32;
     float *wpart = p.dWpart + (size_t)blockIdx.x * cinP * CP;
 #pragma unroll
     for (int j = 0; j < PAIRS; j++) {
-        const int q = wave + 4 * j;
-        if (q >= npairs) continue;
+        const int q = (t2[j >> 2] >> (8 * (j & 3))) & 0xff;
+        if (q == 0xff) continue;
         const int mt = q / ntn2, nt = q - mt * ntn2;
 #pragma unroll
         for (int r = 0; r < 16; r++)
@@ -298,11 +477,11 @@ __global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
     if (p.dX && prevbn) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const int nt = wave + 4 * j;
+            const int nt = (t1 >> (8 * j)) & 0xff;
             float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
             float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
             const int col = nt * 32 + lane;
-            if (nt < ntn1 && lane < 32 && col < cin) {
+            if (nt != 0xff && lane < 32 && col < cin) {
                 atomicAdd(&p.psums[col], (double)a1);
                 atomicAdd(&p.psums[cin + col], (double)a2);
             }
@@ -311,64 +490,114 @@ __global__ __launch_bounds__(256) void gg_k_linear_bwd(GGLinBwd p)
 }
 
 // dW[c][i] = sum_wg part[wg][i][c]   (part: [nwg][cinP][CP]; dW: torch layout [C][cin])
+// block = 64 elements x 4 slices of the workgroup range
 __global__ __launch_bounds__(256) void gg_k_dw_reduce(const float *__restrict__ part, int nwg,
                                                       int cinP, int CP, int cin, int C,
                                                       float *__restrict__ dW)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;           // over cinP*CP
-    if (e >= cinP * CP) return;
-    const int i = e / CP, c = e - i * CP;
-    if (i >= cin || c >= C) return;
+    __shared__ float sh[256];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const size_t S = (size_t)cinP * CP;
     float s = 0.f;
-    for (int w = 0; w < nwg; w++) s += part[(size_t)w * cinP * CP + e];
-    dW[(size_t)c * cin + i] = s;
+    if (e < (int)S)
+        for (int w = sl; w < nwg; w += 4) s += part[(size_t)w * S + e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && e < (int)S) {
+        s = sh[el] + sh[64 + el] + sh[128 + el] + sh[192 + el];
+        const int i = e / CP, c = e - i * CP;
+        if (i < cin && c < C) dW[(size_t)c * cin + i] = s;
+    }
 }
 
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg)
 {
+    // upper bound: up to 4 persistent workgroups per CU (the launcher picks by LDS footprint)
     long long ntile = (E + 31) >> 5;
-    int n = (int)(ntile < 512 ? ntile : 512);
+    int n = (int)(ntile < 1024 ? ntile : 1024);
     const int cinP = ((cin + 31) >> 5) * 32, CP = ((C + 31) >> 5) * 32;
     if (nwg) *nwg = n;
     if (bytes) *bytes = (size_t)n * cinP * CP * sizeof(float);
     return 0;
 }
 
+template <int PAIRS>
+static int launch_bwd(const GGLinBwd &p, bool wlds, size_t lds, int nwg, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_linear_bwd<PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_linear_bwd<PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    if (wlds) gg_k_linear_bwd<PAIRS, true><<<nwg, 256, lds, st>>>(p);
+    else gg_k_linear_bwd<PAIRS, false><<<nwg, 256, lds, st>>>(p);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
 {
     GGLinBwd p = pin;
-    if (p.E < 1 || p.C < 1 || p.C > 256 || p.cin < 1 || p.cin > 1024) return 1;
+    if (p.E < 1 || p.C < 1 || p.C > 256 || p.cin < 1 || p.cin > 384) return 1;
     const int C4 = (p.C + 3) & ~3;
     const int ntm = (p.cin + 31) >> 5, ntn2 = (p.C + 31) >> 5;
-    if (ntm > 12) return 1;                          // 3 column tiles per wave
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
     const int npairs = ntm * ntn2;
-    const int pairs_per_wave = (npairs + 3) / 4;
-    size_t lds = ((size_t)32 * p.ldd + (size_t)32 * p.lda + 6 * p.C + 4 * p.cin) * sizeof(float);
-    if (lds > 150 * 1024) return 1;
+    if (npairs > 48) return 1;
+    // ---- balance GEMM1 column tiles (cost C4/2 MFMAs) and GEMM2 pairs (16 MFMAs) over 4 waves ----
+    int load[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0}, n2[4] = {0, 0, 0, 0};
+    unsigned char l1[4][3], l2[4][12];
+    for (int w = 0; w < 4; w++) { for (int j = 0; j < 3; j++) l1[w][j] = 0xff; for (int j = 0; j < 12; j++) l2[w][j] = 0xff; }
+    if (p.dX)
+        for (int t = 0; t < ntm; t++) {
+            int w = 0;
+            for (int x = 1; x < 4; x++) if (load[x] < load[w]) w = x;
+            if (n1[w] >= 3) return 1;
+            l1[w][n1[w]++] = (unsigned char)t;
+            load[w] += C4 / 2;
+        }
+    for (int q = 0; q < npairs; q++) {
+        int w = -1;
+        for (int x = 0; x < 4; x++) if (n2[x] < 12 && (w < 0 || load[x] < load[w])) w = x;
+        if (w < 0) return 1;
+        l2[w][n2[w]++] = (unsigned char)q;
+        load[w] += 16;
+    }
+    int pmax = 0;
+    for (int w = 0; w < 4; w++) {
+        if (n2[w] > pmax) pmax = n2[w];
+        p.t1[w] = l1[w][0] | (l1[w][1] << 8) | (l1[w][2] << 16) | 0xff000000u;
+        for (int g = 0; g < 3; g++)
+            p.t2[w][g] = l2[w][4 * g] | (l2[w][4 * g + 1] << 8) | (l2[w][4 * g + 2] << 16) |
+                         ((unsigned)l2[w][4 * g + 3] << 24);
+    }
+    p.ncen_max = p.amax ? (31 + p.P - 1) / p.P + 2 : 0;   // centres a 32-row tile can touch
+    const size_t base = ((size_t)32 * p.ldd + (size_t)32 * p.lda + 6 * p.C + 4 * p.cin +
+                         2 * (size_t)p.ncen_max * p.C) * sizeof(float);
+    const size_t wbytes = (size_t)ntm * C4 * 32 * sizeof(float);
+    const bool wlds = p.dX && (base + wbytes <= 158 * 1024);
+    const size_t lds = base + (wlds ? wbytes : 0);
+    if (lds > 158 * 1024) return 1;
     int nwg;
     gg_linear_bwd_workspace(p.E, p.cin, p.C, nullptr, &nwg);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void *)gg_k_linear_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_bwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_bwd<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_bwd<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        hipFuncSetAttribute((const void *)gg_k_linear_bwd<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_done = true;
+    {
+        int per_cu = (int)((150 * 1024) / lds);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        if (nwg > 256 * per_cu) nwg = 256 * per_cu;
     }
-    if (pairs_per_wave <= 1) gg_k_linear_bwd<1><<<nwg, 256, lds, st>>>(p);
-    else if (pairs_per_wave <= 2) gg_k_linear_bwd<2><<<nwg, 256, lds, st>>>(p);
-    else if (pairs_per_wave <= 3) gg_k_linear_bwd<3><<<nwg, 256, lds, st>>>(p);
-    else if (pairs_per_wave <= 5) gg_k_linear_bwd<5><<<nwg, 256, lds, st>>>(p);
-    else if (pairs_per_wave <= 9) gg_k_linear_bwd<9><<<nwg, 256, lds, st>>>(p);
-    else if (pairs_per_wave <= 12) gg_k_linear_bwd<12><<<nwg, 256, lds, st>>>(p);
-    else return 1;
-    if (hipGetLastError() != hipSuccess) return 3;
+    int rc;
+    if (pmax <= 1) rc = launch_bwd<1>(p, wlds, lds, nwg, st);
+    else if (pmax <= 2) rc = launch_bwd<2>(p, wlds, lds, nwg, st);
+    else if (pmax <= 3) rc = launch_bwd<3>(p, wlds, lds, nwg, st);
+    else if (pmax <= 5) rc = launch_bwd<5>(p, wlds, lds, nwg, st);
+    else if (pmax <= 7) rc = launch_bwd<7>(p, wlds, lds, nwg, st);
+    else if (pmax <= 9) rc = launch_bwd<9>(p, wlds, lds, nwg, st);
+    else rc = launch_bwd<12>(p, wlds, lds, nwg, st);
+    if (rc) return rc;
     const int cinP = ntm * 32, CP = ntn2 * 32;
-    gg_k_dw_reduce<<<(cinP * CP + 255) / 256, 256, 0, st>>>(p.dWpart, nwg, cinP, CP, p.cin, p.C, p.dW);
+    gg_k_dw_reduce<<<(cinP * CP + 63) / 64, 256, 0, st>>>(p.dWpart, nwg, cinP, CP, p.cin, p.C, p.dW);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -136,8 +136,14 @@ class SubGUpdate(nn.Module):
         from . import ops
         nf, att_vec = ops.edge_inputs(src.contiguous(), nebidx, cent.contiguous(),
                                       has_feats=self.has_feats, localfdim=self.localfdim)
-        pair = run_mlp([self.att1[0], self.att2[0]], att_vec, self.mfma_train) * \
-            run_mlp(list(self.pt_mlp), nf, self.mfma_train)
+        att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
+        if self.mfma_train and self.training and torch.is_grad_enabled():
+            from . import train_ops
+            if train_ops.edge_block_supported(pt_layers, att_layers, nf):
+                agg = train_ops.edge_block_train(nf, att_vec, pt_layers, att_layers)
+                return self.finish(agg, center_masks, center_ori_feats)
+        pair = run_mlp(att_layers, att_vec, self.mfma_train) * \
+            run_mlp(pt_layers, nf, self.mfma_train)
         agg = pair.max(dim=2).values
         return self.finish(agg, center_masks, center_ori_feats)
 

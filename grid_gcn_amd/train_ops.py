@@ -1,14 +1,21 @@
-"""Training-mode per-edge MLPs on the hand-written gfx950 kernels (csrc/gridgcn_train.hip).
+"""Training-mode per-edge MLPs on the hand-written gfx950 kernels (csrc/gridgcn_train.hip,
+csrc/gridgcn_pairmax.hip).
 
-One autograd Function covers a whole stack of (1x1 conv -> BatchNorm(batch statistics) -> ReLU)
-layers (mlp2d_c / mlp1d_c, utils/ops.py:236-260):
+A "chain" is a stack of (1x1 conv -> BatchNorm(batch statistics) -> ReLU) layers (mlp2d_c /
+mlp1d_c, utils/ops.py:236-260):
 
   forward   per layer ONE kernel: Z_l = act_{l-1} * W_l + b_l on fp32 MFMA, where act_{l-1} =
             relu(bn(Z_{l-1})) is applied while the tile is staged (never materialised) and the
-            kernel's epilogue accumulates the batch statistics of Z_l; only the last layer's
-            activation is materialised.
-  backward  BatchNorm+ReLU backward in two passes per layer (reduce, element-wise); the two GEMMs
-            of each layer (dW = act^T dZ, dX = dZ W^T) go through rocBLAS for now.
+            kernel's epilogue accumulates the batch statistics of Z_l.
+  backward  per layer ONE kernel: dZ formed while staging, dX and dW on MFMA, the next layer's
+            BatchNorm-backward sums in the epilogue.
+
+Two autograd Functions use the chain:
+  _MLPTrain        one chain, dense output Y = relu(bn(Z_L))     (centre / update MLPs)
+  _EdgeBlockTrain  the GridConv edge block: pt chain and att chain on the [E, .] edge tensors, then
+                   agg[o,c] = max_p relu(bn(Zpt)) * relu(bn(Zatt)) without materialising the two
+                   activations, their product, or (in backward) any dense gradient of them
+                   (segmentation/models/gcn_module_g_att.py:135-167, 57-59).
 
 Numerics follow torch.nn.BatchNorm1d(eps, momentum) exactly as used by gridconv.ConvBNReLU (biased
 variance for normalisation, unbiased for the running estimate).
@@ -33,6 +40,104 @@ def supported(layers, x):
     return True
 
 
+def pack_tiles(W):
+    """W [K, N] -> tile-major [ceil(N/32)][round4(K)][32] (B operand of gridgcn_linear_bwd)."""
+    K, N = W.shape
+    K4, nt = (K + 3) & ~3, (N + 31) // 32
+    Wp = torch.zeros((K4, nt * 32), dtype=torch.float32, device=W.device)
+    Wp[:K, :N] = W
+    return Wp.reshape(K4, nt, 32).permute(1, 0, 2).contiguous()
+
+
+class _Chain:
+    """forward state of one chain: Z_l and the BatchNorm vectors of every layer."""
+
+    def __init__(self):
+        self.Z, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], []
+
+
+def _chain_forward(lib, x, params, bns, eps):
+    """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer."""
+    L = len(params) // 4
+    E, dev = x.shape[0], x.device
+    st = _Chain()
+    prev, pscale, pshift = x, None, None
+    for l in range(L):
+        W, b, gamma, beta = params[4 * l:4 * l + 4]
+        cout, cin = W.shape
+        Wp, Bp, K, ldw, _ = pack_conv_layer(W.detach().t(), b.detach())
+        Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
+        sums = torch.zeros((2, cout), dtype=torch.float64, device=dev)
+        rc = lib.gridgcn_linear_fwd(
+            _ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
+            _ptr(pscale) if pscale is not None else None,
+            _ptr(pshift) if pshift is not None else None, _ptr(Z), _ptr(sums), _stream(x))
+        _lib.check(rc, "gridgcn_linear_fwd")
+        mean64 = sums[0] / E
+        var64 = (sums[1] / E - mean64 * mean64).clamp_min(0.0)
+        mean, var = mean64.float(), var64.float()
+        rstd = torch.rsqrt(var + eps)
+        scale = (gamma.detach() * rstd).contiguous()
+        shift = (beta.detach() - mean * scale).contiguous()
+        bn = bns[l]
+        if bn is not None and bn.track_running_stats:
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var * (E / max(E - 1, 1)), alpha=m)
+            bn.num_batches_tracked += 1
+        st.Z.append(Z); st.scale.append(scale); st.shift.append(shift)
+        st.mean.append(mean.contiguous()); st.rstd.append(rstd.contiguous())
+        prev, pscale, pshift = Z, scale, shift
+    return st
+
+
+def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Ws, sums, dY, sparse, need_dx):
+    """backward through a chain.  `sums` [2,C_L] fp64 = BatchNorm-backward sums of the LAST layer;
+    upstream gradient either dense dY [E,C_L] or sparse = (amax, gval, P).  Returns (dX, grads)
+    with grads = [dW, db, dgamma, dbeta] * L."""
+    L = len(Zs)
+    E, dev = x.shape[0], x.device
+    grads = [None] * (4 * L)
+    for l in range(L - 1, -1, -1):
+        Z, C = Zs[l], Zs[l].shape[1]
+        cin = Ws[l].shape[1]
+        s1, s2 = sums[0], sums[1]
+        grads[4 * l + 3] = s1.float()                       # d beta
+        grads[4 * l + 2] = s2.float()                       # d gamma
+        # the conv bias feeds a BatchNorm: its gradient is sum(dZ) == 0 analytically
+        grads[4 * l + 1] = torch.zeros(C, dtype=torch.float32, device=dev)
+        m1 = (s1 / E).float().contiguous()
+        m2 = (s2 / E).float().contiguous()
+        want_dx = l > 0 or need_dx
+        dX = torch.empty((E, cin), dtype=torch.float32, device=dev) if want_dx else None
+        psums = torch.zeros((2, cin), dtype=torch.float64, device=dev) if l > 0 else None
+        dW = torch.empty((C, cin), dtype=torch.float32, device=dev)
+        Wb = pack_tiles(Ws[l].detach())
+        nbytes = ctypes.c_size_t(0)
+        lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        prev = Zs[l - 1] if l > 0 else x
+        pn = (lambda t: _ptr(t)) if l > 0 else (lambda t: None)
+        if sparse is not None:
+            amax, gval, P = sparse
+            sp = (_ptr(amax), _ptr(gval), int(P))
+            dyp = None
+        else:
+            sp = (None, None, 0)
+            dyp = _ptr(dY)
+        rc = lib.gridgcn_linear_bwd(
+            dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
+            _ptr(m1), _ptr(m2), _ptr(prev),
+            pn(scales[l - 1]), pn(shifts[l - 1]), pn(means[l - 1]), pn(rstds[l - 1]),
+            _ptr(Wb), E, C, cin, _ptr(dX) if want_dx else None, _ptr(dW),
+            _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
+            _ptr(ws), nbytes.value, _stream(x))
+        _lib.check(rc, "gridgcn_linear_bwd")
+        grads[4 * l] = dW
+        dY, sums, sparse = dX, psums, None
+    return dY, grads
+
+
 class _MLPTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *params):
@@ -40,43 +145,16 @@ class _MLPTrain(torch.autograd.Function):
         lib = _lib.load()
         eps, bns = meta
         L = len(params) // 4
-        E, dev = x.shape[0], x.device
         x = x.contiguous()
-        saved, scales, shifts, means, rstds = [], [], [], [], []
-        prev, pscale, pshift = x, None, None
-        with torch.cuda.device(dev):
-            for l in range(L):
-                W, b, gamma, beta = params[4 * l:4 * l + 4]
-                cout, cin = W.shape
-                Wp, Bp, K, ldw, _ = pack_conv_layer(W.detach().t(), b.detach())
-                Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
-                sums = torch.zeros((2, cout), dtype=torch.float64, device=dev)
-                rc = lib.gridgcn_linear_fwd(
-                    _ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
-                    _ptr(pscale) if pscale is not None else None,
-                    _ptr(pshift) if pshift is not None else None, _ptr(Z), _ptr(sums), _stream(x))
-                _lib.check(rc, "gridgcn_linear_fwd")
-                mean64 = sums[0] / E
-                var64 = (sums[1] / E - mean64 * mean64).clamp_min(0.0)
-                mean, var = mean64.float(), var64.float()
-                rstd = torch.rsqrt(var + eps)
-                scale = (gamma.detach() * rstd).contiguous()
-                shift = (beta.detach() - mean * scale).contiguous()
-                bn = bns[l]
-                if bn is not None and bn.track_running_stats:
-                    m = bn.momentum
-                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                    bn.running_var.mul_(1 - m).add_(var * (E / max(E - 1, 1)), alpha=m)
-                    bn.num_batches_tracked += 1
-                saved.append(Z); scales.append(scale); shifts.append(shift)
-                means.append(mean.contiguous()); rstds.append(rstd.contiguous())
-                prev, pscale, pshift = Z, scale, shift
-            Y = torch.empty_like(prev)
-            rc = lib.gridgcn_bn_relu_apply(_ptr(prev), _ptr(pscale), _ptr(pshift), _ptr(Y), E,
-                                           prev.shape[1], _stream(x))
+        E = x.shape[0]
+        with torch.cuda.device(x.device):
+            st = _chain_forward(lib, x, params, bns, eps)
+            Y = torch.empty_like(st.Z[-1])
+            rc = lib.gridgcn_bn_relu_apply(_ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]),
+                                           _ptr(Y), E, Y.shape[1], _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_apply")
         ctx.L = L
-        ctx.save_for_backward(x, *saved, *scales, *shifts, *means, *rstds,
+        ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd,
                               *[params[4 * l] for l in range(L)])
         return Y
 
@@ -89,60 +167,22 @@ class _MLPTrain(torch.autograd.Function):
         Zs, scales, shifts = t[1:1 + L], t[1 + L:1 + 2 * L], t[1 + 2 * L:1 + 3 * L]
         means, rstds, Ws = t[1 + 3 * L:1 + 4 * L], t[1 + 4 * L:1 + 5 * L], t[1 + 5 * L:1 + 6 * L]
         E, dev = x.shape[0], x.device
-        grads = [None] * (4 * L)
         dY = dY.contiguous()
         with torch.cuda.device(dev):
-            sums = None
-            for l in range(L - 1, -1, -1):
-                Z, C = Zs[l], Zs[l].shape[1]
-                cin = Ws[l].shape[1]
-                if sums is None:     # last layer: its BN-backward sums need their own pass
-                    sums = torch.zeros((2, C), dtype=torch.float64, device=dev)
-                    rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Z), _ptr(scales[l]),
-                                                        _ptr(shifts[l]), _ptr(means[l]),
-                                                        _ptr(rstds[l]), E, C, _ptr(sums), _stream(x))
-                    _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
-                s1, s2 = sums[0], sums[1]
-                grads[4 * l + 3] = s1.float()                       # d beta
-                grads[4 * l + 2] = s2.float()                       # d gamma
-                # the conv bias feeds a BatchNorm: its gradient is sum(dZ) == 0 analytically
-                grads[4 * l + 1] = torch.zeros(C, dtype=torch.float32, device=dev)
-                m1 = (s1 / E).float().contiguous()
-                m2 = (s2 / E).float().contiguous()
-                need_dx = l > 0 or ctx.needs_input_grad[0]
-                dX = torch.empty((E, cin), dtype=torch.float32, device=dev) if need_dx else None
-                psums = torch.zeros((2, cin), dtype=torch.float64, device=dev) if l > 0 else None
-                dW = torch.empty((C, cin), dtype=torch.float32, device=dev)
-                Wb = pack_tiles(Ws[l].detach())
-                nbytes = ctypes.c_size_t(0)
-                lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
-                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-                prev = Zs[l - 1] if l > 0 else x
-                pn = (lambda t: _ptr(t)) if l > 0 else (lambda t: None)
-                rc = lib.gridgcn_linear_bwd(
-                    _ptr(dY), _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]),
-                    _ptr(rstds[l]), _ptr(m1), _ptr(m2), _ptr(prev),
-                    pn(scales[l - 1]), pn(shifts[l - 1]), pn(means[l - 1]), pn(rstds[l - 1]),
-                    _ptr(Wb), E, C, cin, _ptr(dX) if need_dx else None, _ptr(dW),
-                    _ptr(psums) if psums is not None else None, _ptr(ws), nbytes.value, _stream(x))
-                _lib.check(rc, "gridgcn_linear_bwd")
-                grads[4 * l] = dW
-                dY, sums = dX, psums
-        return (dY, None) + tuple(grads)
-
-
-def pack_tiles(W):
-    """W [K, N] -> tile-major [ceil(N/32)][round4(K)][32] (B operand of gridgcn_linear_bwd)."""
-    K, N = W.shape
-    K4, nt = (K + 3) & ~3, (N + 31) // 32
-    Wp = torch.zeros((K4, nt * 32), dtype=torch.float32, device=W.device)
-    Wp[:K, :N] = W
-    return Wp.reshape(K4, nt, 32).permute(1, 0, 2).contiguous()
+            C = Zs[-1].shape[1]
+            sums = torch.zeros((2, C), dtype=torch.float64, device=dev)
+            rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Zs[-1]), _ptr(scales[-1]),
+                                                _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
+                                                E, C, _ptr(sums), _stream(x))
+            _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
+            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Ws, sums, dY,
+                                        None, ctx.needs_input_grad[0])
+        return (dX, None) + tuple(grads)
 
 
 def mlp_bn_relu_train(x, layers):
     """x [..., cin] -> [..., cout_last] through `layers` (gridconv.ConvBNReLU modules, training
-    mode).  Falls back to nothing: callers check supported() first."""
+    mode).  Callers check supported() first."""
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
     params = []
@@ -150,3 +190,81 @@ def mlp_bn_relu_train(x, layers):
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
     y = _MLPTrain.apply(x2, (layers[0].bn.eps, [l.bn for l in layers]), *params)
     return y.reshape(shp[:-1] + (y.shape[-1],))
+
+
+class _EdgeBlockTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nf, att_vec, meta, *params):
+        """nf [E,cin], att_vec [E,10]; params = pt chain params + att chain params (4 per layer);
+        meta = (eps, pt bns, att bns, ncent, P).  Returns agg [ncent, C]."""
+        lib = _lib.load()
+        eps, bns_p, bns_a, ncent, P = meta
+        Lp, La = len(bns_p), len(bns_a)
+        nf, att_vec = nf.contiguous(), att_vec.contiguous()
+        dev = nf.device
+        with torch.cuda.device(dev):
+            sp = _chain_forward(lib, nf, params[:4 * Lp], bns_p, eps)
+            sa = _chain_forward(lib, att_vec, params[4 * Lp:], bns_a, eps)
+            C = sp.Z[-1].shape[1]
+            agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            rc = lib.gridgcn_pairmax_fwd(_ptr(sp.Z[-1]), _ptr(sa.Z[-1]), _ptr(sp.scale[-1]),
+                                         _ptr(sp.shift[-1]), _ptr(sa.scale[-1]), _ptr(sa.shift[-1]),
+                                         ncent, P, C, _ptr(agg), _ptr(amax), _stream(nf))
+            _lib.check(rc, "gridgcn_pairmax_fwd")
+        ctx.dims = (Lp, La, ncent, P)
+        ctx.save_for_backward(
+            nf, att_vec, amax,
+            *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *[params[4 * l] for l in range(Lp)],
+            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd,
+            *[params[4 * Lp + 4 * l] for l in range(La)])
+        ctx.mark_non_differentiable(amax)
+        return agg
+
+    @staticmethod
+    def backward(ctx, dagg):
+        lib = _lib.load()
+        Lp, La, ncent, P = ctx.dims
+        t = ctx.saved_tensors
+        nf, att_vec, amax = t[0], t[1], t[2]
+        o = 3
+        pZ, pS, pH, pM, pR, pW = (t[o + k * Lp:o + (k + 1) * Lp] for k in range(6))
+        o += 6 * Lp
+        aZ, aS, aH, aM, aR, aW = (t[o + k * La:o + (k + 1) * La] for k in range(6))
+        dev = nf.device
+        dagg = dagg.contiguous()
+        C = pZ[-1].shape[1]
+        with torch.cuda.device(dev):
+            gp = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            ga = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            sums_p = torch.zeros((2, C), dtype=torch.float64, device=dev)
+            sums_a = torch.zeros((2, C), dtype=torch.float64, device=dev)
+            rc = lib.gridgcn_pairmax_bwd(_ptr(pZ[-1]), _ptr(aZ[-1]), _ptr(pS[-1]), _ptr(pH[-1]),
+                                         _ptr(pM[-1]), _ptr(pR[-1]), _ptr(aS[-1]), _ptr(aH[-1]),
+                                         _ptr(aM[-1]), _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent,
+                                         P, C, _ptr(gp), _ptr(ga), _ptr(sums_p), _ptr(sums_a),
+                                         _stream(nf))
+            _lib.check(rc, "gridgcn_pairmax_bwd")
+            dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pW, sums_p, None,
+                                           (amax, gp, P), ctx.needs_input_grad[0])
+            _, grads_a = _chain_backward(lib, att_vec, aZ, aS, aH, aM, aR, aW, sums_a, None,
+                                         (amax, ga, P), False)
+        return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
+
+
+def edge_block_supported(pt_layers, att_layers, nf):
+    C = pt_layers[-1].lin.out_features
+    return (supported(pt_layers, nf) and supported(att_layers, nf)
+            and att_layers[-1].lin.out_features == C)
+
+
+def edge_block_train(nf, att_vec, pt_layers, att_layers):
+    """nf [B,O,P,cin], att_vec [B,O,P,10] -> [B,O,C] = max_p att_mlp(att_vec) * pt_mlp(nf)."""
+    B, O, P, cin = nf.shape
+    params = []
+    for l in list(pt_layers) + list(att_layers):
+        params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
+    meta = (pt_layers[0].bn.eps, [l.bn for l in pt_layers], [l.bn for l in att_layers], B * O, P)
+    agg = _EdgeBlockTrain.apply(nf.reshape(-1, cin), att_vec.reshape(-1, att_vec.shape[-1]), meta,
+                                *params)
+    return agg.reshape(B, O, -1)

@@ -158,8 +158,26 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *mean, const float *rstd, const float *m1, const float *m2,
                        const float *Aprev, const float *pscale, const float *pshift,
                        const float *pmean, const float *prstd, const float *Wb, long long E,
-                       int C, int cin, float *dX, float *dW, double *psums, void *workspace,
-                       size_t workspace_bytes, void *stream);
+                       int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
+                       const float *gval, int P, void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* (amax != NULL: the upstream gradient is the sparse one of gridgcn_pairmax_bwd -- row e belongs to
+ *  centre e/P, neighbour e%P; dY[e,c] = (amax[e/P,c] == e%P) ? gval[e/P,c] : 0 -- and dY is ignored.)
+ *
+ * gridgcn_pairmax_fwd: agg[o,c] = max_p relu(Zp*scale_p+shift_p) * relu(Za*scale_a+shift_a) over the
+ *   P rows of centre o (Zp, Za [ncent*P, C] pre-BatchNorm outputs of the last pt / att layer;
+ *   gcn_module_g_att.py:167 and :57-59), amax = first arg max.
+ * gridgcn_pairmax_bwd: gp/ga[o,c] = gradient w.r.t. the two post-ReLU activations at the arg-max
+ *   edge, and the BatchNorm-backward sums (as gridgcn_bn_relu_bwd_reduce) of both layers. */
+int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
+                        const float *shift_p, const float *scale_a, const float *shift_a,
+                        long long ncent, int P, int C, float *agg, int32_t *amax, void *stream);
+int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
+                        const float *shift_p, const float *mean_p, const float *rstd_p,
+                        const float *scale_a, const float *shift_a, const float *mean_a,
+                        const float *rstd_a, const float *dagg, const int32_t *amax,
+                        long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
+                        double *sums_a, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
                           long long E, int C, void *stream);
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,

@@ -65,6 +65,53 @@ def test_mlp_train_matches_torch(E, cin, dims):
             close(b2, b1, 1e-5)
 
 
+EB_CASES = [
+    # B, O, P, cin, pt dims, C
+    (2, 300, 5, 131, [128]),
+    (2, 40, 32, 67, [64, 64, 128]),
+    (1, 33, 128, 3, [32, 32, 64]),
+    (3, 50, 7, 35, [32, 64]),
+]
+
+
+@pytest.mark.parametrize("B,O,P,cin,dims", EB_CASES,
+                         ids=["%dx%dx%d_%d" % (c[0], c[1], c[2], c[3]) for c in EB_CASES])
+def test_edge_block_train_matches_torch(B, O, P, cin, dims):
+    """max_p att_mlp(att_vec) * pt_mlp(nf): fused (pairmax + sparse-gradient backward) vs modules."""
+    torch.manual_seed(B * O + P)
+    C = dims[-1]
+    pt_ref = mlp(cin, dims).to(DEV).train()
+    a1_ref, a2_ref = mlp(10, [C // 4]).to(DEV).train(), mlp(C // 4, [C]).to(DEV).train()
+    for m in list(pt_ref.modules()) + list(a1_ref.modules()) + list(a2_ref.modules()):
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0.2, 0.3)
+    pt_new, a1_new, a2_new = (copy.deepcopy(m) for m in (pt_ref, a1_ref, a2_ref))
+    nf1 = torch.randn(B, O, P, cin, device=DEV).requires_grad_(True)
+    nf2 = nf1.detach().clone().requires_grad_(True)
+    av = torch.randn(B, O, P, 10, device=DEV)
+    y1 = (a2_ref(a1_ref(av)) * pt_ref(nf1)).max(dim=2).values
+    assert train_ops.edge_block_supported(list(pt_new), [a1_new[0], a2_new[0]], nf2)
+    y2 = train_ops.edge_block_train(nf2, av, list(pt_new), [a1_new[0], a2_new[0]])
+    s = max(1.0, float(y1.detach().abs().max()))
+    assert float((y1 - y2).abs().max()) <= 3e-5 * s
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+
+    def close(a, b, tol=5e-4):
+        sc = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * sc, (float((a - b).abs().max()), sc)
+    close(nf2.grad, nf1.grad)
+    for ref, new in ((pt_ref, pt_new), (a1_ref, a1_new), (a2_ref, a2_new)):
+        for (n1, p1), (n2, p2) in zip(ref.named_parameters(), new.named_parameters()):
+            if not n1.endswith("lin.bias"):
+                close(p2.grad, p1.grad)
+        for (n1, b1), (n2, b2) in zip(ref.named_buffers(), new.named_buffers()):
+            if "num_batches" not in n1:
+                close(b2, b1, 1e-5)
+
+
 def test_unsupported_width_falls_to_modules():
     m = mlp(8, [48]).to(DEV).train()
     x = torch.randn(10, 8, device=DEV)

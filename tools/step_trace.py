@@ -1,0 +1,27 @@
+"""Summarise one training step from a rocprofv3 kernel trace CSV (bench.py run).
+usage: python tools/step_trace.py <kernel_trace.csv> [min_us]"""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+minus = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "nll_loss_forward_reduce" in r["Kernel_Name"]]
+seq = rows[idx[-2]:idx[-1]]
+agg = collections.defaultdict(lambda: [0, 0.0])
+tot = 0.0
+for r in seq:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += d
+    k = r["Kernel_Name"][:60]
+    agg[k][0] += 1
+    agg[k][1] += d
+    if d > minus and ("gg_k" in k):
+        print("%9.1f us %-46s grid=%-9s wg=%s lds=%s" % (d, k[:46], r["Grid_Size_X"], r["Workgroup_Size_X"],
+                                                      r.get("LDS_Block_Size", "")))
+print("---- by kernel")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:18]:
+    print("%-62s n=%4d tot=%9.1f us" % (k, v[0], v[1]))
+print("sum %.1f ms, kernels %d, wall %.1f ms" % (
+    tot / 1e3, len(seq), (int(seq[-1]["End_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e6))
