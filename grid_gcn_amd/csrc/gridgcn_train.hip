@@ -577,7 +577,10 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     const size_t base = ((size_t)32 * p.ldd + (size_t)32 * p.lda + 6 * p.C + 4 * p.cin +
                          2 * (size_t)p.ncen_max * p.C) * sizeof(float);
     const size_t wbytes = (size_t)ntm * C4 * 32 * sizeof(float);
-    const bool wlds = p.dX && (base + wbytes <= 158 * 1024);
+    // weights resident in LDS only when that still leaves room for >= 2 workgroups per CU: with a
+    // single workgroup per CU nothing overlaps the staging round trips of a tile
+    const size_t wcap = getenv("GG_BWD_WCAP") ? (size_t)atoi(getenv("GG_BWD_WCAP")) * 1024 : 158 * 1024;
+    const bool wlds = p.dX && (base + wbytes <= wcap);
     const size_t lds = base + (wlds ? wbytes : 0);
     if (lds > 158 * 1024) return 1;
     int nwg;

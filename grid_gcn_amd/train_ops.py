@@ -252,6 +252,46 @@ class _EdgeBlockTrain(torch.autograd.Function):
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
+def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
+    """Time one gg_k_linear_bwd launch (+ its dW reduce) on synthetic tensors shaped like the last
+    pt layer of a GridConv edge block (sparse upstream gradient, input gradient needed).  Used by
+    bench.py for the roofline of the dominant kernel of the training step.  Returns ms/launch."""
+    lib = _lib.load()
+    E = ncent * P
+    g = torch.Generator(device=device).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=device, generator=g)  # noqa: E731
+    Z, X = rnd(E, C), rnd(E, cin)
+    scale, shift = rnd(C).abs() + 0.5, rnd(C) * 0.1
+    mean, rstd = rnd(C) * 0.1, rnd(C).abs() + 0.5
+    m1, m2 = rnd(C) * 1e-3, rnd(C) * 1e-3
+    amax = torch.randint(0, P, (ncent, C), device=device, dtype=torch.int32, generator=g)
+    gval = rnd(ncent, C)
+    Wb = pack_tiles(rnd(C, cin))
+    dX = torch.empty(E, cin, device=device)
+    dW = torch.empty(C, cin, device=device)
+    nbytes = ctypes.c_size_t(0)
+    lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+
+    def call():
+        rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+                                    _ptr(m1), _ptr(m2), _ptr(X), None, None, None, None, _ptr(Wb),
+                                    E, C, cin, _ptr(dX), _ptr(dW), None, _ptr(amax), _ptr(gval), P,
+                                    _ptr(ws), nbytes.value, _stream(Z))
+        _lib.check(rc, "gridgcn_linear_bwd")
+    with torch.cuda.device(device):
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def edge_block_supported(pt_layers, att_layers, nf):
     C = pt_layers[-1].lin.out_features
     return (supported(pt_layers, nf) and supported(att_layers, nf)
