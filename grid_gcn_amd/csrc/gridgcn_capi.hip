@@ -220,7 +220,7 @@ int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *byte
 int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, const float *shift,
                        const float *mean, const float *rstd, const float *m1, const float *m2,
                        const float *Aprev, const float *pscale, const float *pshift,
-                       const float *pmean, const float *prstd, const float *Wb, long long E,
+                       const float *pmean, const float *prstd, const float *Wb, const float *Wg, long long E,
                        int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
                        const float *gval, int P, void *workspace, size_t workspace_bytes,
                        void *stream)
@@ -236,7 +236,7 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     GGLinBwd p;
     p.dY = dY; p.Z = Z; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
     p.m1 = m1; p.m2 = m2; p.Aprev = Aprev; p.pscale = pscale; p.pshift = pshift; p.pmean = pmean;
-    p.prstd = prstd; p.Wb = Wb; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW;
+    p.prstd = prstd; p.Wb = Wb; p.Wg = Wg; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW;
     p.psums = psums; p.E = E; p.C = C; p.cin = cin; p.ldd = 0; p.lda = 0;
     p.amax = amax; p.gval = gval; p.P = P > 0 ? P : 1;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);

@@ -23,6 +23,8 @@ struct GGLinBwd {
     const float *Aprev;   // [E][cin] raw input of this layer: Z of the previous layer, or X
     const float *pscale, *pshift, *pmean, *prstd;  // [cin] previous layer's BN (nullptr: Aprev = X)
     const float *Wb;      // W (torch layout [C][cin]) packed tile-major [ceil(cin/32)][C4][32]
+    const float *Wg;      // same W packed in column blocks of 4/2/1 tiles: [block][C4][32][nt]
+                          // (nullptr: no split mode; dX comes from the monolithic kernel)
     float *dX;            // [E][cin] gradient w.r.t. act(Aprev) (nullptr: not needed)
     float *dWpart;        // workspace [nwg][cinP][CP]
     float *dW;            // [C][cin]
@@ -32,6 +34,7 @@ struct GGLinBwd {
     const int *amax;      // sparse upstream gradient (nullptr: dense dY): arg-max neighbour [E/P][C]
     const float *gval;    //   and its value [E/P][C]; row e = centre e/P, neighbour e%P
     int P, ncen_max;
+    int rt;               // rows per workgroup tile of gg_k_linear_dw (32/64/96/128)
     unsigned t1[4];       // per wave: up to 3 GEMM1 column tiles, one byte each, 0xff = none
     unsigned t2[4][3];    // per wave: up to 12 GEMM2 (m,n) pair ids, one byte each, 0xff = none
 };

@@ -28,7 +28,8 @@ template <bool XFORM>
 __device__ __forceinline__ void gg_stage_rows(float *dst, int ld, const float *__restrict__ src,
                                               int nrows, int cin, int K,
                                               const float *__restrict__ scale,
-                                              const float *__restrict__ shift, int tid, int nthr)
+                                              const float *__restrict__ shift, int tid, int nthr,
+                                              int rt = 32)
 {
     const int nel = nrows * cin;
     const float inv = 1.0f / (float)cin;
@@ -70,7 +71,76 @@ __device__ __forceinline__ void gg_stage_rows(float *dst, int ld, const float *_
             int r = i / padc, c = cin + (i - r * padc);
             dst[r * ld + c] = 0.f;
         }
-    for (int i = nrows * K + tid; i < 32 * K; i += nthr) {
+    for (int i = nrows * K + tid; i < rt * K; i += nthr) {
+        int r = i / K, c = i - r * K;
+        dst[r * ld + c] = 0.f;
+    }
+}
+
+// same, with 16-byte global loads: a tile of 32k rows starts 16-byte aligned for ANY row length
+// (32 rows * 4 B), so the chunk is read as float4 even when cin is odd; elements are routed to
+// their (row, column) one by one.  4-byte loads reach only about half the HBM rate on MI355X.
+template <bool XFORM>
+__device__ __forceinline__ void gg_stage_rows4(float *dst, int ld, const float *__restrict__ src,
+                                               int nrows, int cin, int K,
+                                               const float *__restrict__ scale,
+                                               const float *__restrict__ shift, int tid, int nthr,
+                                               int rt = 32)
+{
+    const int nel = nrows * cin;
+    const int nq = (nel + 3) >> 2;
+    const float inv = 1.0f / (float)cin;
+    constexpr int U = 4;
+    const int step = nthr * U;
+    float4 va[U], vb[U];
+    auto ldg = [&](float4 (&v)[U], int base) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = base + u * nthr + tid;
+            const int i = q * 4;
+            if (i + 3 < nel) v[u] = *(const float4 *)(src + i);
+            else {
+                v[u].x = i < nel ? src[i] : 0.f;
+                v[u].y = i + 1 < nel ? src[i + 1] : 0.f;
+                v[u].z = i + 2 < nel ? src[i + 2] : 0.f;
+                v[u].w = 0.f;
+            }
+        }
+    };
+    auto sts = [&](const float4 (&v)[U], int base) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = (base + u * nthr + tid) * 4;
+            if (i < nel) {
+                int r = (int)(((float)i + 0.5f) * inv);
+                int c = i - r * cin;
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (i + k < nel) {
+                        float x = e[k];
+                        if (XFORM) { x = x * scale[c] + shift[c]; x = x > 0.f ? x : 0.f; }
+                        dst[r * ld + c] = x;
+                    }
+                    if (++c == cin) { c = 0; r++; }
+                }
+            }
+        }
+    };
+    ldg(va, 0);
+    for (int base = 0; base < nq; base += 2 * step) {
+        if (base + step < nq) ldg(vb, base + step);
+        sts(va, base);
+        if (base + 2 * step < nq) ldg(va, base + 2 * step);
+        if (base + step < nq) sts(vb, base + step);
+    }
+    const int padc = K - cin;
+    if (padc > 0)
+        for (int i = tid; i < nrows * padc; i += nthr) {
+            int r = i / padc, c = cin + (i - r * padc);
+            dst[r * ld + c] = 0.f;
+        }
+    for (int i = nrows * K + tid; i < rt * K; i += nthr) {
         int r = i / K, c = i - r * K;
         dst[r * ld + c] = 0.f;
     }
@@ -180,8 +250,8 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_fwd(GGLinFwd p)
          tile += (long long)gridDim.x * nw) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        if (p.scale) gg_stage_rows<true>(Aw, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, p.scale, p.shift, lane, 64);
-        else gg_stage_rows<false>(Aw, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, nullptr, nullptr, lane, 64);
+        if (p.scale) gg_stage_rows4<true>(Aw, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, p.scale, p.shift, lane, 64);
+        else gg_stage_rows4<false>(Aw, lda, p.X + r0 * p.cin, nrows, p.cin, p.K, nullptr, nullptr, lane, 64);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -397,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_bwd(GGLinBwd p)
             }
         }
         // ---- stage Zp = raw previous activation (BatchNorm+ReLU applied on the fly in GEMM2) ----
-        gg_stage_rows<false>(Zp, lda, p.Aprev + r0 * cin, nrows, cin, ntn1 * 32, nullptr, nullptr,
+        gg_stage_rows4<false>(Zp, lda, p.Aprev + r0 * cin, nrows, cin, ntn1 * 32, nullptr, nullptr,
                              tid, 256);
         __syncthreads();
 
@@ -489,6 +559,322 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_bwd(GGLinBwd p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// dW += act(Aprev)^T * dZ only (split mode: dX comes from gg_k_linear_dx).  With 32-row tiles the
+// MFMA work per wave and tile (80 MFMAs, 2.4 us) is far smaller than the fixed cost of staging the
+// tile (two HBM round trips + barriers, ~8 us): measured 7.2 ms for 110 GFLOP.  Here a workgroup
+// stages RT = 64/128 rows per barrier pair, so the same round trips feed 2-4x the math.
+template <int PAIRS>
+__global__ __launch_bounds__(256) void gg_k_linear_dw(GGLinBwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = p.C, cin = p.cin, ldd = p.ldd, lda = p.lda, RT = p.rt;
+    const int C4 = (C + 3) & ~3;
+    const int ntm = (cin + 31) >> 5, ntn2 = (C + 31) >> 5, cinP = ntm * 32, CP = ntn2 * 32;
+    float *D = lds;                          // [RT][ldd]
+    float *Zp = D + RT * ldd;                // [RT][lda]
+    float *cst = Zp + RT * lda;
+    float *c_scale = cst, *c_shift = cst + C, *c_mean = cst + 2 * C, *c_rstd = cst + 3 * C;
+    float *c_m1 = cst + 4 * C, *c_m2 = cst + 5 * C, *c_ps = cst + 6 * C, *c_psh = c_ps + cin;
+    const bool prevbn = p.pscale != nullptr;
+    for (int c = tid; c < C; c += 256) {
+        c_scale[c] = p.scale[c]; c_shift[c] = p.shift[c]; c_mean[c] = p.mean[c];
+        c_rstd[c] = p.rstd[c]; c_m1[c] = p.m1[c]; c_m2[c] = p.m2[c];
+    }
+    for (int c = tid; c < cin; c += 256) {
+        c_ps[c] = prevbn ? p.pscale[c] : 1.f; c_psh[c] = prevbn ? p.pshift[c] : 0.f;
+    }
+    unsigned t2[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+        t2[w] = wave == 0 ? p.t2[0][w] : (wave == 1 ? p.t2[1][w] : (wave == 2 ? p.t2[2][w] : p.t2[3][w]));
+    ggm_f32x16 accW[PAIRS];
+    ggm_zero<PAIRS>(accW);
+    const long long ntile = (p.E + RT - 1) / RT;
+    const float invC = 1.0f / (float)C, invP = 1.0f / (float)p.P;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long r0 = tile * RT;
+        const int nrows = (p.E - r0 < RT) ? (int)(p.E - r0) : RT;
+        // ---- stage D = dZ (16-byte loads, two chunks in flight per thread) ----
+        {
+            const int nq = (nrows * C) >> 2;
+            const float4 *z4 = (const float4 *)(p.Z + r0 * C);
+            const float4 *g4 = (const float4 *)(p.dY + r0 * C);
+            const long long o0 = p.amax ? r0 / p.P : 0;
+            const int rem0 = p.amax ? (int)(r0 - o0 * p.P) : 0;
+            constexpr int U = 4;
+            float4 za[U], ga[U], zb[U], gb[U];
+            auto ldg = [&](float4 (&z)[U], float4 (&g)[U], int base) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = base + u * 256 + tid;
+                    z[u] = q < nq ? z4[q] : zero4;
+                    g[u] = zero4;
+                    if (q < nq) {
+                        if (p.amax) {
+                            const int i = q * 4;
+                            const int r = (int)(((float)i + 0.5f) * invC);
+                            const int c = i - r * C;
+                            const int t = rem0 + r;
+                            const int oc = (int)(((float)t + 0.5f) * invP);
+                            const int pp = t - oc * p.P;
+                            const long long idx = (o0 + oc) * C + c;
+                            const int4 am = *(const int4 *)(p.amax + idx);
+                            const float4 gv = *(const float4 *)(p.gval + idx);
+                            g[u].x = am.x == pp ? gv.x : 0.f; g[u].y = am.y == pp ? gv.y : 0.f;
+                            g[u].z = am.z == pp ? gv.z : 0.f; g[u].w = am.w == pp ? gv.w : 0.f;
+                        } else {
+                            g[u] = g4[q];
+                        }
+                    }
+                }
+            };
+            auto sts = [&](const float4 (&z)[U], const float4 (&g)[U], int base) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = base + u * 256 + tid;
+                    if (q < nq) {
+                        const int i = q * 4;
+                        const int r = (int)(((float)i + 0.5f) * invC);
+                        const int c = i - r * C;
+                        const float zv[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+                        const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int cc = c + k;
+                            const float sc = c_scale[cc];
+                            const float d = (zv[k] * sc + c_shift[cc] > 0.f) ? gv[k] : 0.f;
+                            const float zh = (zv[k] - c_mean[cc]) * c_rstd[cc];
+                            D[r * ldd + cc] = sc * (d - c_m1[cc] - zh * c_m2[cc]);
+                        }
+                    }
+                }
+            };
+            const int step = 256 * U;
+            ldg(za, ga, 0);
+            for (int base = 0; base < nq; base += 2 * step) {
+                if (base + step < nq) ldg(zb, gb, base + step);
+                sts(za, ga, base);
+                if (base + 2 * step < nq) ldg(za, ga, base + 2 * step);
+                if (base + step < nq) sts(zb, gb, base + step);
+            }
+            if (nrows < RT)
+                for (int i = nrows * C4 + tid; i < RT * C4; i += 256) {
+                    int r = i / C4;
+                    D[r * ldd + (i - r * C4)] = 0.f;
+                }
+        }
+        // ---- stage Zp = raw previous activation ----
+        gg_stage_rows4<false>(Zp, lda, p.Aprev + r0 * cin, nrows, cin, cinP, nullptr, nullptr, tid,
+                             256, RT);
+        __syncthreads();
+        // ---- dW(m,n) += act(Zp)^T * D over the RT rows ----
+#pragma unroll
+        for (int j = 0; j < PAIRS; j++) {
+            const int q = (t2[j >> 2] >> (8 * (j & 3))) & 0xff;
+            if (q == 0xff) continue;
+            const int mt = q / ntn2, nt = q - mt * ntn2;
+            const int mi = mt * 32 + (lane & 31);
+            const bool mok = mi < cin;
+            const float ps = mok ? c_ps[mi] : 0.f, psh = mok ? c_psh[mi] : 0.f;
+            const bool nok = nt * 32 + (lane & 31) < C4;
+            for (int rb = 0; rb < nrows; rb += 32) {
+                const float *ap = Zp + (rb + (lane >> 5)) * lda + mi;
+                const float *bp = D + (rb + (lane >> 5)) * ldd + nt * 32 + (lane & 31);
+                float av[16], bv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    av[k] = ap[2 * k * lda];
+                    bv[k] = nok ? bp[2 * k * ldd] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    float a = av[k];
+                    if (prevbn) { a = a * ps + psh; a = a > 0.f ? a : 0.f; }
+                    if (!mok) a = 0.f;
+                    accW[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[k], accW[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float *wpart = p.dWpart + (size_t)blockIdx.x * cinP * CP;
+#pragma unroll
+    for (int j = 0; j < PAIRS; j++) {
+        const int q = (t2[j >> 2] >> (8 * (j & 3))) & 0xff;
+        if (q == 0xff) continue;
+        const int mt = q / ntn2, nt = q - mt * ntn2;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            wpart[(size_t)(mt * 32 + ggm_row(r, lane)) * CP + nt * 32 + (lane & 31)] = accW[j][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dX = dZ * W of one layer with ONE WAVE PER 32-ROW TILE (persistent, 4 independent waves per
+// workgroup, ~17 KB of LDS and < 128 registers each): the monolithic kernel above needs the whole
+// register file and > 100 KB of LDS, so only one workgroup fits a CU and every staging round trip
+// is exposed (measured: its phases add up serially).  Many light waves let the CU overlap one
+// wave's loads with another's MFMAs.  Wg = W packed in column blocks of 4/2/1 tiles.
+__global__ __launch_bounds__(256) void gg_k_linear_dx(GGLinBwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int C = p.C, cin = p.cin, ldd = p.ldd;
+    const int C4 = (C + 3) & ~3;
+    const int ntn1 = (cin + 31) >> 5, cinP = ntn1 * 32;
+    float *c_scale = lds, *c_shift = lds + C, *c_mean = lds + 2 * C, *c_rstd = lds + 3 * C;
+    float *c_m1 = lds + 4 * C, *c_m2 = lds + 5 * C;
+    float *Dw = lds + 6 * C4 + wave * (32 * ldd + 2 * cinP);   // [32][ldd] + sums [2][cinP]
+    float *sacc = Dw + 32 * ldd;
+    for (int c = tid; c < C; c += blockDim.x) {
+        c_scale[c] = p.scale[c]; c_shift[c] = p.shift[c]; c_mean[c] = p.mean[c];
+        c_rstd[c] = p.rstd[c]; c_m1[c] = p.m1[c]; c_m2[c] = p.m2[c];
+    }
+    for (int c = lane; c < 2 * cinP; c += 64) sacc[c] = 0.f;
+    __syncthreads();
+    const bool prevbn = p.pscale != nullptr;
+    const long long ntile = (p.E + 31) >> 5;
+    const float invC = 1.0f / (float)C, invP = 1.0f / (float)p.P;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
+         tile += (long long)gridDim.x * nw) {
+        const long long r0 = tile << 5;
+        const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        // ---- stage D = dZ of this tile (16-byte loads, two chunks in flight) ----
+        {
+            const int nq = (nrows * C) >> 2;
+            const float4 *z4 = (const float4 *)(p.Z + r0 * C);
+            const float4 *g4 = (const float4 *)(p.dY + r0 * C);
+            const long long o0 = p.amax ? r0 / p.P : 0;
+            const int rem0 = p.amax ? (int)(r0 - o0 * p.P) : 0;
+            constexpr int U = 4;
+            float4 za[U], ga[U], zb[U], gb[U];
+            auto ldg = [&](float4 (&z)[U], float4 (&g)[U], int base) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = base + u * 64 + lane;
+                    z[u] = q < nq ? z4[q] : zero4;
+                    g[u] = zero4;
+                    if (q < nq) {
+                        if (p.amax) {
+                            // sparse upstream gradient: row e = centre e/P, neighbour e%P
+                            const int i = q * 4;
+                            const int r = (int)(((float)i + 0.5f) * invC);
+                            const int c = i - r * C;
+                            const int t = rem0 + r;
+                            const int oc = (int)(((float)t + 0.5f) * invP);
+                            const int pp = t - oc * p.P;
+                            const long long idx = (o0 + oc) * C + c;
+                            const int4 am = *(const int4 *)(p.amax + idx);
+                            const float4 gv = *(const float4 *)(p.gval + idx);
+                            g[u].x = am.x == pp ? gv.x : 0.f; g[u].y = am.y == pp ? gv.y : 0.f;
+                            g[u].z = am.z == pp ? gv.z : 0.f; g[u].w = am.w == pp ? gv.w : 0.f;
+                        } else {
+                            g[u] = g4[q];
+                        }
+                    }
+                }
+            };
+            auto sts = [&](const float4 (&z)[U], const float4 (&g)[U], int base) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = base + u * 64 + lane;
+                    if (q < nq) {
+                        const int i = q * 4;
+                        const int r = (int)(((float)i + 0.5f) * invC);
+                        const int c = i - r * C;
+                        const float zv[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+                        const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int cc = c + k;
+                            const float sc = c_scale[cc];
+                            const float d = (zv[k] * sc + c_shift[cc] > 0.f) ? gv[k] : 0.f;
+                            const float zh = (zv[k] - c_mean[cc]) * c_rstd[cc];
+                            Dw[r * ldd + cc] = sc * (d - c_m1[cc] - zh * c_m2[cc]);
+                        }
+                    }
+                }
+            };
+            const int step = 64 * U;
+            ldg(za, ga, 0);
+            for (int base = 0; base < nq; base += 2 * step) {
+                if (base + step < nq) ldg(zb, gb, base + step);
+                sts(za, ga, base);
+                if (base + 2 * step < nq) ldg(za, ga, base + 2 * step);
+                if (base + step < nq) sts(zb, gb, base + step);
+            }
+            gg_tile_pad(Dw, ldd, nrows, C, C4, lane, 64);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- dX tile = D * W, column blocks of 4 / 2 / 1 tiles ----
+        int done = 0;
+        const float *wg = p.Wg;
+        while (done < ntn1) {
+            const int rem = ntn1 - done;
+            const int nt = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+            ggm_f32x16 acc[4];
+            ggm_zero<4>(acc);
+            if (nt == 4) ggm_mma<4>(Dw, ldd, wg, C4, acc);
+            else if (nt == 2) {
+                ggm_f32x16 a2[2];
+                ggm_zero<2>(a2);
+                ggm_mma<2>(Dw, ldd, wg, C4, a2);
+                acc[0] = a2[0]; acc[1] = a2[1];
+            } else {
+                ggm_f32x16 a1[1];
+                ggm_zero<1>(a1);
+                ggm_mma<1>(Dw, ldd, wg, C4, a1);
+                acc[0] = a1[0];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j >= nt) continue;
+                const int col = (done + j) * 32 + (lane & 31);
+                float a1 = 0.f, a2 = 0.f;
+                if (col < cin) {
+                    const float ps = prevbn ? p.pscale[col] : 0.f, psh = prevbn ? p.pshift[col] : 0.f;
+                    const float pm = prevbn ? p.pmean[col] : 0.f, pr = prevbn ? p.prstd[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = ggm_row(r, lane);
+                        if (row < nrows) {
+                            const float dx = acc[j][r];
+                            p.dX[(r0 + row) * cin + col] = dx;
+                            if (prevbn) {
+                                const float zp = p.Aprev[(r0 + row) * cin + col];
+                                const float d = (zp * ps + psh > 0.f) ? dx : 0.f;
+                                a1 += d;
+                                a2 += d * ((zp - pm) * pr);
+                            }
+                        }
+                    }
+                }
+                if (prevbn) {
+                    a1 += __shfl_xor(a1, 32, 64);
+                    a2 += __shfl_xor(a2, 32, 64);
+                    if (lane < 32) { sacc[col] += a1; sacc[cinP + col] += a2; }
+                }
+            }
+            wg += (size_t)C4 * 32 * nt;
+            done += nt;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (prevbn)
+        for (int c = lane; c < cin; c += 64) {
+            atomicAdd(&p.psums[c], (double)sacc[c]);
+            atomicAdd(&p.psums[cin + c], (double)sacc[cinP + c]);
+        }
+}
+
 // dW[c][i] = sum_wg part[wg][i][c]   (part: [nwg][cinP][CP]; dW: torch layout [C][cin])
 // block = 64 elements x 4 slices of the workgroup range
 __global__ __launch_bounds__(256) void gg_k_dw_reduce(const float *__restrict__ part, int nwg,
@@ -544,6 +930,26 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     const int ntm = (p.cin + 31) >> 5, ntn2 = (p.C + 31) >> 5;
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
+    // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
+    if (p.dX && p.Wg && (p.C & 3) == 0 && !getenv("GG_BWD_MONO")) {
+        static bool attr_dx = false;
+        if (!attr_dx) {
+            if (hipFuncSetAttribute((const void *)gg_k_linear_dx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+            attr_dx = true;
+        }
+        const int nw = 4;
+        const size_t ldsx = ((size_t)6 * C4 + (size_t)nw * (32 * p.ldd + 2 * ntm * 32)) * sizeof(float);
+        if (ldsx <= 150 * 1024) {
+            int per_cu = (int)((150 * 1024) / ldsx);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+            const long long ntile = (p.E + 31) >> 5;
+            long long nb = (ntile + nw - 1) / nw;
+            if (nb > 256 * per_cu) nb = 256 * per_cu;
+            gg_k_linear_dx<<<(int)nb, 64 * nw, ldsx, st>>>(p);
+            if (hipGetLastError() != hipSuccess) return 3;
+            p.dX = nullptr;                      // the kernel below only accumulates dW now
+        }
+    }
     const int npairs = ntm * ntn2;
     if (npairs > 48) return 1;
     // ---- balance GEMM1 column tiles (cost C4/2 MFMAs) and GEMM2 pairs (16 MFMAs) over 4 waves ----
@@ -591,6 +997,44 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         if (nwg > 256 * per_cu) nwg = 256 * per_cu;
     }
     int rc;
+    // ---- dW-only kernel with large row tiles (split mode, or no input gradient needed) ----
+    if (!p.dX && (p.C & 3) == 0 && !getenv("GG_BWD_MONO")) {
+        const size_t cbytes = ((size_t)6 * p.C + 2 * p.cin) * sizeof(float);
+        int rt = 0;
+        const int cands[4] = {128, 96, 64, 32};
+        for (int k = 0; k < 4 && !rt; k++)
+            if ((size_t)cands[k] * (p.ldd + p.lda) * 4 + cbytes <= 150 * 1024) rt = cands[k];
+        if (rt) {
+            p.rt = rt;
+            const size_t ldsw = (size_t)rt * (p.ldd + p.lda) * 4 + cbytes;
+            const long long ntile = (p.E + rt - 1) / rt;
+            int per_cu = (int)((150 * 1024) / ldsw);
+            per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+            int nw2 = (int)(ntile < 256 * per_cu ? ntile : 256 * per_cu);
+            if (nw2 > nwg) nw2 = nwg;             // workspace was sized for nwg partials
+#define GG_DW(PP)                                                                               \
+    do {                                                                                        \
+        static bool done_##PP = false;                                                          \
+        if (!done_##PP) {                                                                       \
+            if (hipFuncSetAttribute((const void *)gg_k_linear_dw<PP>,                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,                 \
+                                    160 * 1024) != hipSuccess) return 3;                        \
+            done_##PP = true;                                                                   \
+        }                                                                                       \
+        gg_k_linear_dw<PP><<<nw2, 256, ldsw, st>>>(p);                                          \
+    } while (0)
+            if (pmax <= 2) GG_DW(2);
+            else if (pmax <= 5) GG_DW(5);
+            else if (pmax <= 8) GG_DW(8);
+            else GG_DW(12);
+#undef GG_DW
+            if (hipGetLastError() != hipSuccess) return 3;
+            const int cinP2 = ntm * 32, CP2 = ntn2 * 32;
+            gg_k_dw_reduce<<<(cinP2 * CP2 + 63) / 64, 256, 0, st>>>(p.dWpart, nw2, cinP2, CP2, p.cin,
+                                                                    p.C, p.dW);
+            return hipGetLastError() == hipSuccess ? 0 : 3;
+        }
+    }
     if (pmax <= 1) rc = launch_bwd<1>(p, wlds, lds, nwg, st);
     else if (pmax <= 2) rc = launch_bwd<2>(p, wlds, lds, nwg, st);
     else if (pmax <= 3) rc = launch_bwd<3>(p, wlds, lds, nwg, st);

@@ -49,6 +49,23 @@ def pack_tiles(W):
     return Wp.reshape(K4, nt, 32).permute(1, 0, 2).contiguous()
 
 
+def pack_groups(W):
+    """W [K, N] -> column blocks of 4/2/1 tiles, each [round4(K)][32][nt] (B operand of
+    gg_k_linear_dx: one vector load per k-step feeds nt MFMAs)."""
+    K, N = W.shape
+    K4, ntile = (K + 3) & ~3, (N + 31) // 32
+    Wp = torch.zeros((K4, ntile * 32), dtype=torch.float32, device=W.device)
+    Wp[:K, :N] = W
+    blocks, done = [], 0
+    while done < ntile:
+        rem = ntile - done
+        nt = 4 if rem >= 4 else (2 if rem >= 2 else 1)
+        blk = Wp[:, done * 32:(done + nt) * 32].reshape(K4, nt, 32).permute(0, 2, 1)
+        blocks.append(blk.contiguous().reshape(-1))
+        done += nt
+    return torch.cat(blocks).contiguous()
+
+
 class _Chain:
     """forward state of one chain: Z_l and the BatchNorm vectors of every layer."""
 
@@ -113,6 +130,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Ws, sums, dY, spar
         psums = torch.zeros((2, cin), dtype=torch.float64, device=dev) if l > 0 else None
         dW = torch.empty((C, cin), dtype=torch.float32, device=dev)
         Wb = pack_tiles(Ws[l].detach())
+        Wg = pack_groups(Ws[l].detach()) if want_dx else None
         nbytes = ctypes.c_size_t(0)
         lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
@@ -129,7 +147,8 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Ws, sums, dY, spar
             dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
             _ptr(m1), _ptr(m2), _ptr(prev),
             pn(scales[l - 1]), pn(shifts[l - 1]), pn(means[l - 1]), pn(rstds[l - 1]),
-            _ptr(Wb), E, C, cin, _ptr(dX) if want_dx else None, _ptr(dW),
+            _ptr(Wb), _ptr(Wg) if Wg is not None else None, E, C, cin,
+            _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
         _lib.check(rc, "gridgcn_linear_bwd")
@@ -266,7 +285,8 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
     m1, m2 = rnd(C) * 1e-3, rnd(C) * 1e-3
     amax = torch.randint(0, P, (ncent, C), device=device, dtype=torch.int32, generator=g)
     gval = rnd(ncent, C)
-    Wb = pack_tiles(rnd(C, cin))
+    Wt = rnd(C, cin)
+    Wb, Wg = pack_tiles(Wt), pack_groups(Wt)
     dX = torch.empty(E, cin, device=device)
     dW = torch.empty(C, cin, device=device)
     nbytes = ctypes.c_size_t(0)
@@ -276,7 +296,8 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
     def call():
         rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                     _ptr(m1), _ptr(m2), _ptr(X), None, None, None, None, _ptr(Wb),
-                                    E, C, cin, _ptr(dX), _ptr(dW), None, _ptr(amax), _ptr(gval), P,
+                                    _ptr(Wg), E, C, cin, _ptr(dX), _ptr(dW), None, _ptr(amax),
+                                    _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))
         _lib.check(rc, "gridgcn_linear_bwd")
     with torch.cuda.device(device):

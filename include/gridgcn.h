@@ -157,7 +157,7 @@ int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *byte
 int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, const float *shift,
                        const float *mean, const float *rstd, const float *m1, const float *m2,
                        const float *Aprev, const float *pscale, const float *pshift,
-                       const float *pmean, const float *prstd, const float *Wb, long long E,
+                       const float *pmean, const float *prstd, const float *Wb, const float *Wg, long long E,
                        int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
                        const float *gval, int P, void *workspace, size_t workspace_bytes,
                        void *stream);
