@@ -595,6 +595,14 @@ __global__ __launch_bounds__(256) void gg_k_linear_dw(GGLinBwd p)
     const float invC = 1.0f / (float)C, invP = 1.0f / (float)p.P;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    const int qsh = __ffs(C) - 3;                    // log2(C/4); C is a power of two >= 4
+    const int cc0 = (tid * 4) & (C - 1);
+    float k_sc[4], k_sh[4], k_mu[4], k_rs[4], k_m1[4], k_m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        k_sc[k] = c_scale[cc0 + k]; k_sh[k] = c_shift[cc0 + k]; k_mu[k] = c_mean[cc0 + k];
+        k_rs[k] = c_rstd[cc0 + k]; k_m1[k] = c_m1[cc0 + k]; k_m2[k] = c_m2[cc0 + k];
+    }
 
     for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long long r0 = tile * RT;
@@ -616,9 +624,7 @@ __global__ __launch_bounds__(256) void gg_k_linear_dw(GGLinBwd p)
                     g[u] = zero4;
                     if (q < nq) {
                         if (p.amax) {
-                            const int i = q * 4;
-                            const int r = (int)(((float)i + 0.5f) * invC);
-                            const int c = i - r * C;
+                            const int r = q >> qsh, c = cc0;
                             const int t = rem0 + r;
                             const int oc = (int)(((float)t + 0.5f) * invP);
                             const int pp = t - oc * p.P;
@@ -638,18 +644,16 @@ __global__ __launch_bounds__(256) void gg_k_linear_dw(GGLinBwd p)
                 for (int u = 0; u < U; u++) {
                     const int q = base + u * 256 + tid;
                     if (q < nq) {
-                        const int i = q * 4;
-                        const int r = (int)(((float)i + 0.5f) * invC);
-                        const int c = i - r * C;
+                        // 256 threads * 4 floats is a multiple of C (a power of two): this thread
+                        // always owns channels cc0..cc0+3, whose constants sit in registers
+                        const int r = q >> qsh;
                         const float zv[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
                         const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const int cc = c + k;
-                            const float sc = c_scale[cc];
-                            const float d = (zv[k] * sc + c_shift[cc] > 0.f) ? gv[k] : 0.f;
-                            const float zh = (zv[k] - c_mean[cc]) * c_rstd[cc];
-                            D[r * ldd + cc] = sc * (d - c_m1[cc] - zh * c_m2[cc]);
+                            const float d = (zv[k] * k_sc[k] + k_sh[k] > 0.f) ? gv[k] : 0.f;
+                            const float zh = (zv[k] - k_mu[k]) * k_rs[k];
+                            D[r * ldd + cc0 + k] = k_sc[k] * (d - k_m1[k] - zh * k_m2[k]);
                         }
                     }
                 }
@@ -741,6 +745,9 @@ __global__ __launch_bounds__(256) void gg_k_linear_dx(GGLinBwd p)
     const long long ntile = (p.E + 31) >> 5;
     const float invC = 1.0f / (float)C, invP = 1.0f / (float)p.P;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int qsh = __ffs(C) - 3;                    // log2(C/4); C is a power of two >= 4
+    const int cc0 = (lane * 4) & (C - 1);
+    (void)invC;
 
     for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
          tile += (long long)gridDim.x * nw) {
@@ -764,9 +771,7 @@ __global__ __launch_bounds__(256) void gg_k_linear_dx(GGLinBwd p)
                     if (q < nq) {
                         if (p.amax) {
                             // sparse upstream gradient: row e = centre e/P, neighbour e%P
-                            const int i = q * 4;
-                            const int r = (int)(((float)i + 0.5f) * invC);
-                            const int c = i - r * C;
+                            const int r = q >> qsh, c = cc0;
                             const int t = rem0 + r;
                             const int oc = (int)(((float)t + 0.5f) * invP);
                             const int pp = t - oc * p.P;
@@ -786,14 +791,16 @@ __global__ __launch_bounds__(256) void gg_k_linear_dx(GGLinBwd p)
                 for (int u = 0; u < U; u++) {
                     const int q = base + u * 64 + lane;
                     if (q < nq) {
-                        const int i = q * 4;
-                        const int r = (int)(((float)i + 0.5f) * invC);
-                        const int c = i - r * C;
+                        // 64 lanes * 4 floats is a multiple of C (a power of two <= 256): this lane
+                        // always owns channels cc0..cc0+3, whose constants sit in registers
+                        const int r = q >> qsh;
                         const float zv[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
                         const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const int cc = c + k;
+                            // (constants from LDS: keeping 24 of them in registers cost this
+                            //  light kernel occupancy -- measured 2.9 -> 3.7 ms)
+                            const int cc = cc0 + k;
                             const float sc = c_scale[cc];
                             const float d = (zv[k] * sc + c_shift[cc] > 0.f) ? gv[k] : 0.f;
                             const float zh = (zv[k] - c_mean[cc]) * c_rstd[cc];
@@ -931,7 +938,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
-    if (p.dX && p.Wg && (p.C & 3) == 0 && !getenv("GG_BWD_MONO")) {
+    if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0 && !getenv("GG_BWD_MONO")) {
         static bool attr_dx = false;
         if (!attr_dx) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_dx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -998,7 +1005,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     }
     int rc;
     // ---- dW-only kernel with large row tiles (split mode, or no input gradient needed) ----
-    if (!p.dX && (p.C & 3) == 0 && !getenv("GG_BWD_MONO")) {
+    if (!p.dX && p.C >= 4 && (p.C & (p.C - 1)) == 0 && !getenv("GG_BWD_MONO")) {
         const size_t cbytes = ((size_t)6 * p.C + 2 * p.cin) * sizeof(float);
         int rt = 0;
         const int cands[4] = {128, 96, 64, 32};
