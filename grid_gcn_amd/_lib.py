@@ -20,6 +20,7 @@ EXPORTS = [
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_bwd_elemt",
+    "gridgcn_pack_linear", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
 ]
 
 
@@ -95,6 +96,13 @@ def load():
     lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
     lib.gridgcn_bn_relu_bwd_elemt.restype = ci
     lib.gridgcn_bn_relu_bwd_elemt.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
+    lib.gridgcn_pack_linear.restype = ci
+    lib.gridgcn_pack_linear.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
+    cf = ctypes.c_float
+    lib.gridgcn_bn_finalize.restype = ci
+    lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_bn_bwd_finalize.restype = ci
+    lib.gridgcn_bn_bwd_finalize.argtypes = [vp, ll, ci, vp, vp, vp, vp, vp]
     lib.gridgcn_edge_inputs.restype = ci
     lib.gridgcn_edge_inputs.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]
     lib.gridgcn_edge_inputs_backward.restype = ci

@@ -32,6 +32,13 @@ int gg_pairmax_bwd(const float *, const float *, const float *, const float *, c
                    const float *, const int *, long long, int, int, float *, float *, double *,
                    double *, hipStream_t);
 
+int gg_pack_linear(const float *, const float *, int, int, float *, float *, float *, float *,
+                   hipStream_t);
+int gg_bn_finalize(const double *, const float *, const float *, long long, float, float, int,
+                   float *, float *, float *, float *, float *, float *, hipStream_t);
+int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
+                       hipStream_t);
+
 static int ensure_init()
 {
     static int rc = gg_index_init();  // thread-safe one-time init (C++11 static)
@@ -294,6 +301,32 @@ int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scal
     if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !dZ || E < 1 || C < 1)
         return GRIDGCN_EINVAL;
     return gg_bn_bwd_elemt(dY, Z, scale, shift, mean, rstd, m1, m2, E, C, dZ, (hipStream_t)stream);
+}
+
+int gridgcn_pack_linear(const float *W, const float *b, int C, int cin, float *Wp, float *Bp,
+                        float *Wb, float *Wg, void *stream)
+{
+    if (!W || (Bp && !b)) return GRIDGCN_EINVAL;
+    int rc = gg_pack_linear(W, b, C, cin, Wp, Bp, Wb, Wg, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
+                        float eps, float momentum, int C, float *scale, float *shift, float *mean,
+                        float *rstd, float *running_mean, float *running_var, void *stream)
+{
+    if (!sums || !gamma || !beta || !scale || !shift || !mean || !rstd || E < 1 || C < 1 ||
+        (running_mean && !running_var))
+        return GRIDGCN_EINVAL;
+    return gg_bn_finalize(sums, gamma, beta, E, eps, momentum, C, scale, shift, mean, rstd,
+                          running_mean, running_var, (hipStream_t)stream);
+}
+
+int gridgcn_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2,
+                            float *dgamma, float *dbeta, void *stream)
+{
+    if (!sums || !m1 || !m2 || !dgamma || !dbeta || E < 1 || C < 1) return GRIDGCN_EINVAL;
+    return gg_bn_bwd_finalize(sums, E, C, m1, m2, dgamma, dbeta, (hipStream_t)stream);
 }
 
 int gridgcn_edge_inputs(const float *src, const int32_t *nebidx, const float *cent,

@@ -85,6 +85,121 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping on [C]-sized vectors in ONE launch each (instead of ~10 tiny element-wise
+// launches per layer): batch statistics -> (scale, shift, mean, rstd) + running estimates
+// (torch.nn.BatchNorm1d semantics: biased variance to normalise, unbiased for running_var).
+__global__ void gg_k_bn_finalize(const double *__restrict__ sums, const float *__restrict__ gamma,
+                                 const float *__restrict__ beta, long long E, float eps,
+                                 float momentum, int C, float *__restrict__ scale,
+                                 float *__restrict__ shift, float *__restrict__ mean,
+                                 float *__restrict__ rstd, float *__restrict__ run_mean,
+                                 float *__restrict__ run_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / (double)E;
+    double v = sums[C + c] / (double)E - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    const float rs = rsqrtf(vf + eps);
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mf * sc;
+    mean[c] = mf;
+    rstd[c] = rs;
+    if (run_mean) {
+        const float unb = vf * ((float)E / (float)(E > 1 ? E - 1 : 1));
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mf;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+    }
+}
+
+// m1 = s1/E, m2 = s2/E, dbeta = s1, dgamma = s2
+__global__ void gg_k_bn_bwd_finalize(const double *__restrict__ sums, long long E, int C,
+                                     float *__restrict__ m1, float *__restrict__ m2,
+                                     float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = sums[c], s2 = sums[C + c];
+    m1[c] = (float)(s1 / (double)E);
+    m2[c] = (float)(s2 / (double)E);
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+
+// All operand layouts of one linear layer from the framework's W [C][cin] in ONE launch:
+//   Wp [groups][K][32][nt]   forward B operand (K = round4(cin), ldw = C rounded to 32/64/128/256)
+//   Bp [ldw]                 zero padded bias
+//   Wb [ceil(cin/32)][C4][32]            tile-major W (dW / monolithic backward), C4 = round4(C)
+//   Wg column blocks of 4/2/1 tiles, each [C4][32][nt]   (gg_k_linear_dx)
+__global__ void gg_k_pack_linear(const float *__restrict__ W, const float *__restrict__ b, int C,
+                                 int cin, int K, int ldw, float *__restrict__ Wp,
+                                 float *__restrict__ Bp, float *__restrict__ Wb,
+                                 float *__restrict__ Wg)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (Wp && t < K * ldw) {
+        const int gw = ldw < 128 ? ldw : 128, nt = gw / 32;
+        const int tt = t % nt, j = (t / nt) % 32, k = (t / (nt * 32)) % K, g = t / (nt * 32 * K);
+        const int col = g * gw + tt * 32 + j;
+        Wp[t] = (k < cin && col < C) ? W[(size_t)col * cin + k] : 0.f;
+    }
+    if (Bp && t < ldw) Bp[t] = t < C ? b[t] : 0.f;
+    const int C4 = (C + 3) & ~3, ntile = (cin + 31) / 32;
+    if (t < ntile * C4 * 32) {
+        if (Wb) {
+            const int j = t % 32, kc = (t / 32) % C4, tile = t / (32 * C4);
+            const int col = tile * 32 + j;
+            Wb[t] = (kc < C && col < cin) ? W[(size_t)kc * cin + col] : 0.f;
+        }
+        if (Wg) {
+            int idx = t, done = 0, nb = 1;
+            while (true) {
+                const int rem = ntile - done;
+                nb = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+                const int size = C4 * 32 * nb;
+                if (idx < size) break;
+                idx -= size;
+                done += nb;
+            }
+            const int tt = idx % nb, j = (idx / nb) % 32, kc = idx / (nb * 32);
+            const int col = (done + tt) * 32 + j;
+            Wg[t] = (kc < C && col < cin) ? W[(size_t)kc * cin + col] : 0.f;
+        }
+    }
+}
+
+int gg_pack_linear(const float *W, const float *b, int C, int cin, float *Wp, float *Bp, float *Wb,
+                   float *Wg, hipStream_t st)
+{
+    if (C < 1 || C > 256 || cin < 1) return 1;
+    const int K = (cin + 3) & ~3;
+    const int ldw = C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
+    const int C4 = (C + 3) & ~3, ntile = (cin + 31) / 32;
+    int n = K * ldw;
+    if (ntile * C4 * 32 > n) n = ntile * C4 * 32;
+    gg_k_pack_linear<<<(n + 255) / 256, 256, 0, st>>>(W, b, C, cin, K, ldw, Wp, Bp, Wb, Wg);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
+                   float eps, float momentum, int C, float *scale, float *shift, float *mean,
+                   float *rstd, float *run_mean, float *run_var, hipStream_t st)
+{
+    gg_k_bn_finalize<<<(C + 255) / 256, 256, 0, st>>>(sums, gamma, beta, E, eps, momentum, C, scale,
+                                                      shift, mean, rstd, run_mean, run_var);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2, float *dgamma,
+                       float *dbeta, hipStream_t st)
+{
+    gg_k_bn_bwd_finalize<<<(C + 255) / 256, 256, 0, st>>>(sums, E, C, m1, m2, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *sca, const float *sha, long long ncent, int P, int C, float *agg,
                    int *amax, hipStream_t st)

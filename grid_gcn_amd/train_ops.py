@@ -25,7 +25,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .ops import _ptr, _stream, pack_conv_layer
+from .ops import _ptr, _stream
 
 
 def supported(layers, x):
@@ -71,66 +71,99 @@ class _Chain:
 
     def __init__(self):
         self.Z, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], []
+        self.Wb, self.Wg = [], []
+
+
+def packed_sizes(C, cin):
+    """(K, ldw, floats of Wp, floats of Wb == floats of Wg) of gridgcn_pack_linear."""
+    K = (cin + 3) & ~3
+    ldw = next(x for x in (32, 64, 128, 256) if x >= C)
+    return K, ldw, K * ldw, ((cin + 31) // 32) * ((C + 3) & ~3) * 32
 
 
 def _chain_forward(lib, x, params, bns, eps):
-    """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer."""
+    """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer.  Per layer three launches:
+    pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping."""
     L = len(params) // 4
     E, dev = x.shape[0], x.device
     st = _Chain()
     prev, pscale, pshift = x, None, None
+    couts = [params[4 * l].shape[0] for l in range(L)]
+    allsums = torch.zeros(2 * sum(couts), dtype=torch.float64, device=dev)
+    so = 0
+    stream = _stream(x)
     for l in range(L):
         W, b, gamma, beta = params[4 * l:4 * l + 4]
         cout, cin = W.shape
-        Wp, Bp, K, ldw, _ = pack_conv_layer(W.detach().t(), b.detach())
+        K, ldw, nwp, nwb = packed_sizes(cout, cin)
+        pk = torch.empty(nwp + ldw + 2 * nwb, dtype=torch.float32, device=dev)
+        Wp, Bp = pk[:nwp], pk[nwp:nwp + ldw]
+        Wb, Wg = pk[nwp + ldw:nwp + ldw + nwb], pk[nwp + ldw + nwb:]
+        rc = lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), cout, cin,
+                                     _ptr(Wp), _ptr(Bp), _ptr(Wb), _ptr(Wg), stream)
+        _lib.check(rc, "gridgcn_pack_linear")
         Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
-        sums = torch.zeros((2, cout), dtype=torch.float64, device=dev)
+        sums = allsums[so:so + 2 * cout]
+        so += 2 * cout
         rc = lib.gridgcn_linear_fwd(
             _ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
             _ptr(pscale) if pscale is not None else None,
-            _ptr(pshift) if pshift is not None else None, _ptr(Z), _ptr(sums), _stream(x))
+            _ptr(pshift) if pshift is not None else None, _ptr(Z), _ptr(sums), stream)
         _lib.check(rc, "gridgcn_linear_fwd")
-        mean64 = sums[0] / E
-        var64 = (sums[1] / E - mean64 * mean64).clamp_min(0.0)
-        mean, var = mean64.float(), var64.float()
-        rstd = torch.rsqrt(var + eps)
-        scale = (gamma.detach() * rstd).contiguous()
-        shift = (beta.detach() - mean * scale).contiguous()
+        vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
         bn = bns[l]
-        if bn is not None and bn.track_running_stats:
-            m = bn.momentum
-            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var * (E / max(E - 1, 1)), alpha=m)
+        track = bn is not None and bn.track_running_stats
+        rc = lib.gridgcn_bn_finalize(
+            _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
+            bn.momentum if track else 0.0, cout, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+            _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
+            _ptr(bn.running_var) if track else None, stream)
+        _lib.check(rc, "gridgcn_bn_finalize")
+        if track:
             bn.num_batches_tracked += 1
-        st.Z.append(Z); st.scale.append(scale); st.shift.append(shift)
-        st.mean.append(mean.contiguous()); st.rstd.append(rstd.contiguous())
-        prev, pscale, pshift = Z, scale, shift
+        st.Z.append(Z); st.scale.append(vec[0]); st.shift.append(vec[1])
+        st.mean.append(vec[2]); st.rstd.append(vec[3])
+        st.Wb.append(Wb); st.Wg.append(Wg)
+        prev, pscale, pshift = Z, vec[0], vec[1]
     return st
 
 
-def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Ws, sums, dY, sparse, need_dx):
-    """backward through a chain.  `sums` [2,C_L] fp64 = BatchNorm-backward sums of the LAST layer;
+def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums, dY, sparse, need_dx):
+    """backward through a chain.  `sums` [2*C_L] fp64 = BatchNorm-backward sums of the LAST layer;
     upstream gradient either dense dY [E,C_L] or sparse = (amax, gval, P).  Returns (dX, grads)
     with grads = [dW, db, dgamma, dbeta] * L."""
     L = len(Zs)
     E, dev = x.shape[0], x.device
     grads = [None] * (4 * L)
+    Cs = [Zs[l].shape[1] for l in range(L)]
+    cins = [x.shape[1]] + Cs[:-1]
+    # one zero fill for the chain: BatchNorm-backward sums of layers 0..L-2 (fp64) + bias gradients
+    nps = 2 * sum(Cs[:-1])
+    zbuf = torch.zeros(nps * 8 + 4 * sum(Cs), dtype=torch.uint8, device=dev)
+    zps = zbuf[:nps * 8].view(torch.float64)
+    zdb = zbuf[nps * 8:].view(torch.float32)
+    po, bo = 0, 0
     for l in range(L - 1, -1, -1):
-        Z, C = Zs[l], Zs[l].shape[1]
-        cin = Ws[l].shape[1]
-        s1, s2 = sums[0], sums[1]
-        grads[4 * l + 3] = s1.float()                       # d beta
-        grads[4 * l + 2] = s2.float()                       # d gamma
+        Z, C, cin = Zs[l], Cs[l], cins[l]
+        v = torch.empty((4, C), dtype=torch.float32, device=dev)
+        m1, m2 = v[0], v[1]
+        rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums), E, C, _ptr(m1), _ptr(m2), _ptr(v[2]),
+                                         _ptr(v[3]), _stream(x))
+        _lib.check(rc, "gridgcn_bn_bwd_finalize")
+        grads[4 * l + 2] = v[2]                             # d gamma
+        grads[4 * l + 3] = v[3]                             # d beta
         # the conv bias feeds a BatchNorm: its gradient is sum(dZ) == 0 analytically
-        grads[4 * l + 1] = torch.zeros(C, dtype=torch.float32, device=dev)
-        m1 = (s1 / E).float().contiguous()
-        m2 = (s2 / E).float().contiguous()
+        grads[4 * l + 1] = zdb[bo:bo + C]
+        bo += C
         want_dx = l > 0 or need_dx
         dX = torch.empty((E, cin), dtype=torch.float32, device=dev) if want_dx else None
-        psums = torch.zeros((2, cin), dtype=torch.float64, device=dev) if l > 0 else None
+        psums = None
+        if l > 0:
+            psums = zps[po:po + 2 * cin]
+            po += 2 * cin
         dW = torch.empty((C, cin), dtype=torch.float32, device=dev)
-        Wb = pack_tiles(Ws[l].detach())
-        Wg = pack_groups(Ws[l].detach()) if want_dx else None
+        Wb = Wbs[l]
+        Wg = Wgs[l] if want_dx else None
         nbytes = ctypes.c_size_t(0)
         lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
@@ -173,8 +206,7 @@ class _MLPTrain(torch.autograd.Function):
                                            _ptr(Y), E, Y.shape[1], _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_apply")
         ctx.L = L
-        ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd,
-                              *[params[4 * l] for l in range(L)])
+        ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg)
         return Y
 
     @staticmethod
@@ -184,7 +216,8 @@ class _MLPTrain(torch.autograd.Function):
         t = ctx.saved_tensors
         x = t[0]
         Zs, scales, shifts = t[1:1 + L], t[1 + L:1 + 2 * L], t[1 + 2 * L:1 + 3 * L]
-        means, rstds, Ws = t[1 + 3 * L:1 + 4 * L], t[1 + 4 * L:1 + 5 * L], t[1 + 5 * L:1 + 6 * L]
+        means, rstds, Wbs = t[1 + 3 * L:1 + 4 * L], t[1 + 4 * L:1 + 5 * L], t[1 + 5 * L:1 + 6 * L]
+        Wgs = t[1 + 6 * L:1 + 7 * L]
         E, dev = x.shape[0], x.device
         dY = dY.contiguous()
         with torch.cuda.device(dev):
@@ -194,8 +227,8 @@ class _MLPTrain(torch.autograd.Function):
                                                 _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
                                                 E, C, _ptr(sums), _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
-            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Ws, sums, dY,
-                                        None, ctx.needs_input_grad[0])
+            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums,
+                                        dY, None, ctx.needs_input_grad[0])
         return (dX, None) + tuple(grads)
 
 
@@ -234,9 +267,8 @@ class _EdgeBlockTrain(torch.autograd.Function):
         ctx.dims = (Lp, La, ncent, P)
         ctx.save_for_backward(
             nf, att_vec, amax,
-            *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *[params[4 * l] for l in range(Lp)],
-            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd,
-            *[params[4 * Lp + 4 * l] for l in range(La)])
+            *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg,
+            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg)
         ctx.mark_non_differentiable(amax)
         return agg
 
@@ -247,26 +279,26 @@ class _EdgeBlockTrain(torch.autograd.Function):
         t = ctx.saved_tensors
         nf, att_vec, amax = t[0], t[1], t[2]
         o = 3
-        pZ, pS, pH, pM, pR, pW = (t[o + k * Lp:o + (k + 1) * Lp] for k in range(6))
-        o += 6 * Lp
-        aZ, aS, aH, aM, aR, aW = (t[o + k * La:o + (k + 1) * La] for k in range(6))
+        pZ, pS, pH, pM, pR, pWb, pWg = (t[o + k * Lp:o + (k + 1) * Lp] for k in range(7))
+        o += 7 * Lp
+        aZ, aS, aH, aM, aR, aWb, aWg = (t[o + k * La:o + (k + 1) * La] for k in range(7))
         dev = nf.device
         dagg = dagg.contiguous()
         C = pZ[-1].shape[1]
         with torch.cuda.device(dev):
             gp = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             ga = torch.empty((ncent, C), dtype=torch.float32, device=dev)
-            sums_p = torch.zeros((2, C), dtype=torch.float64, device=dev)
-            sums_a = torch.zeros((2, C), dtype=torch.float64, device=dev)
+            sums_pa = torch.zeros((2, 2 * C), dtype=torch.float64, device=dev)
+            sums_p, sums_a = sums_pa[0], sums_pa[1]
             rc = lib.gridgcn_pairmax_bwd(_ptr(pZ[-1]), _ptr(aZ[-1]), _ptr(pS[-1]), _ptr(pH[-1]),
                                          _ptr(pM[-1]), _ptr(pR[-1]), _ptr(aS[-1]), _ptr(aH[-1]),
                                          _ptr(aM[-1]), _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent,
                                          P, C, _ptr(gp), _ptr(ga), _ptr(sums_p), _ptr(sums_a),
                                          _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_bwd")
-            dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pW, sums_p, None,
+            dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pWb, pWg, sums_p, None,
                                            (amax, gp, P), ctx.needs_input_grad[0])
-            _, grads_a = _chain_backward(lib, att_vec, aZ, aS, aH, aM, aR, aW, sums_a, None,
+            _, grads_a = _chain_backward(lib, att_vec, aZ, aS, aH, aM, aR, aWb, aWg, sums_a, None,
                                          (amax, ga, P), False)
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 

@@ -152,7 +152,27 @@ int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, con
  *   to its raw output Aprev (pscale == NULL: Aprev is the plain input), and
  *   psums[0:cin] += sum dxr, psums[cin:2cin] += sum dxr*zhat_prev: the BatchNorm-backward sums of
  *   the PREVIOUS layer, so that no separate reduce pass is needed for it.
- *   Wb = W (layout [C][cin]) packed tile-major [ceil(cin/32)][round4(C)][32]. */
+ *   Wb = W (layout [C][cin]) packed tile-major [ceil(cin/32)][round4(C)][32];
+ *   Wg = the same W packed in column blocks of 4/2/1 tiles of 32 input channels, each block
+ *        [round4(C)][32][nt] (nt tiles of the block interleaved so that one vector load per k feeds
+ *        nt MFMAs).  Wg != NULL selects the split schedule (one dX kernel + one dW kernel); NULL
+ *        the single-kernel schedule.  gridgcn_pack_linear writes every layout in one launch. */
+int gridgcn_pack_linear(const float *W, const float *b, int C, int cin, float *Wp, float *Bp,
+                        float *Wb, float *Wg, void *stream);
+/* gridgcn_pack_linear: W[C][cin] (framework layout, C <= 256), b[C] ->
+ *   Wp[round4(cin) * ldw] / Bp[ldw] for gridgcn_linear_fwd (ldw = C rounded up to 32/64/128/256),
+ *   Wb, Wg [ceil(cin/32) * round4(C) * 32] each for gridgcn_linear_bwd.  Any output may be NULL.
+ * gridgcn_bn_finalize: batch statistics -> scale = gamma*rstd, shift = beta - mean*scale, mean,
+ *   rstd = rsqrt(var_biased + eps) from sums = (sum z, sum z^2) over E rows; running_mean/var
+ *   (NULL = not tracked) updated with `momentum`, the variance unbiased (mx.sym.BatchNorm /
+ *   utils/ops.py:149-158 semantics, as torch.nn.BatchNorm1d).
+ * gridgcn_bn_bwd_finalize: sums = (s1, s2) of gridgcn_bn_relu_bwd_reduce -> m1 = s1/E, m2 = s2/E,
+ *   dbeta = s1, dgamma = s2. */
+int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
+                        float eps, float momentum, int C, float *scale, float *shift, float *mean,
+                        float *rstd, float *running_mean, float *running_var, void *stream);
+int gridgcn_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2,
+                            float *dgamma, float *dbeta, void *stream);
 int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *bytes);
 int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, const float *shift,
                        const float *mean, const float *rstd, const float *m1, const float *m2,

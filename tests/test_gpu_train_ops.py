@@ -112,6 +112,29 @@ def test_edge_block_train_matches_torch(B, O, P, cin, dims):
                 close(b2, b1, 1e-5)
 
 
+@pytest.mark.parametrize("C,cin", [(32, 3), (16, 10), (128, 131), (256, 128), (64, 67), (128, 260),
+                                   (4, 5), (256, 384)])
+def test_pack_linear_layouts(C, cin):
+    """gridgcn_pack_linear (one launch) == the three layouts built with torch ops, bit for bit."""
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream, pack_conv_layer
+    lib = _lib.load()
+    torch.manual_seed(C * 1000 + cin)
+    W = torch.randn(C, cin, device=DEV)
+    b = torch.randn(C, device=DEV)
+    K, ldw, nwp, nwb = train_ops.packed_sizes(C, cin)
+    Wp, Bp = torch.full((nwp,), 7.0, device=DEV), torch.full((ldw,), 7.0, device=DEV)
+    Wb, Wg = torch.full((nwb,), 7.0, device=DEV), torch.full((nwb,), 7.0, device=DEV)
+    rc = lib.gridgcn_pack_linear(_ptr(W), _ptr(b), C, cin, _ptr(Wp), _ptr(Bp), _ptr(Wb), _ptr(Wg),
+                                 _stream(W))
+    assert rc == 0
+    rWp, rBp, rK, rldw, _ = pack_conv_layer(W.t(), b)
+    assert (rK, rldw) == (K, ldw)
+    assert torch.equal(Wp, rWp.reshape(-1)) and torch.equal(Bp, rBp)
+    assert torch.equal(Wb, train_ops.pack_tiles(W).reshape(-1))
+    assert torch.equal(Wg, train_ops.pack_groups(W))
+
+
 def test_unsupported_width_falls_to_modules():
     m = mlp(8, [48]).to(DEV).train()
     x = torch.randn(10, 8, device=DEV)
