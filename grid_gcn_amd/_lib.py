@@ -16,11 +16,12 @@ EXPORTS = [
     "gridgcn_ball_knn", "gridgcn_knn",
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
+    "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_bwd_elemt",
-    "gridgcn_pack_linear", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
+    "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
 ]
 
 
@@ -97,7 +98,13 @@ def load():
     lib.gridgcn_bn_relu_bwd_elemt.restype = ci
     lib.gridgcn_bn_relu_bwd_elemt.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
     lib.gridgcn_pack_linear.restype = ci
-    lib.gridgcn_pack_linear.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_pack_linear.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_edge_inputs_rows.restype = ci
+    lib.gridgcn_edge_inputs_rows.argtypes = [vp, vp, vp] + [ci] * 9 + [vp, vp, vp]
+    lib.gridgcn_edge_inputs_rows_backward.restype = ci
+    lib.gridgcn_edge_inputs_rows_backward.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_linear_fwd_direct.restype = ci
+    lib.gridgcn_linear_fwd_direct.argtypes = [vp, ll, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp]
     cf = ctypes.c_float
     lib.gridgcn_bn_finalize.restype = ci
     lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp]

@@ -25,6 +25,8 @@ int gg_batch_take_backward(const float *, const int *, int, int, int, int, float
 int gg_edge_inputs(const float *, const int *, const float *, int, int, int, int, int, int, int, int,
                    float *, float *, hipStream_t);
 
+int gg_edge_inputs_rows(const float *, const int *, const float *, int, int, int, int, int, int, int,
+                        int, int, float *, float *, hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, long long, int, int, float *, int *, hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
@@ -32,8 +34,8 @@ int gg_pairmax_bwd(const float *, const float *, const float *, const float *, c
                    const float *, const int *, long long, int, int, float *, float *, double *,
                    double *, hipStream_t);
 
-int gg_pack_linear(const float *, const float *, int, int, float *, float *, float *, float *,
-                   hipStream_t);
+int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
+                   float *, float *, float *, float *, hipStream_t);
 int gg_bn_finalize(const double *, const float *, const float *, long long, float, float, int,
                    float *, float *, float *, float *, float *, float *, hipStream_t);
 int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
@@ -303,11 +305,26 @@ int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scal
     return gg_bn_bwd_elemt(dY, Z, scale, shift, mean, rstd, m1, m2, E, C, dZ, (hipStream_t)stream);
 }
 
-int gridgcn_pack_linear(const float *W, const float *b, int C, int cin, float *Wp, float *Bp,
-                        float *Wb, float *Wg, void *stream)
+int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, int cin, int ndx,
+                        float *Wp, float *Bp, float *Wb, float *Wg, float *Wq, float *Wdx,
+                        void *stream)
 {
     if (!W || (Bp && !b)) return GRIDGCN_EINVAL;
-    int rc = gg_pack_linear(W, b, C, cin, Wp, Bp, Wb, Wg, (hipStream_t)stream);
+    int rc = gg_pack_linear(W, b, C, cin_w, rot, cin, ndx, Wp, Bp, Wb, Wg, Wq, Wdx,
+                            (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_linear_fwd_direct(const float *X, long long E, int K, const float *Wq, const float *b,
+                              int ldw, int cout, const float *scale, const float *shift, float *Z,
+                              double *sums, void *stream)
+{
+    if (!X || !Wq || !b || !Z || !sums || cout < 1 || cout > ldw || (scale && !shift))
+        return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = K; p.dbg = 0;
+    int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
@@ -351,6 +368,30 @@ int gridgcn_edge_inputs_backward(const float *grad_nf, const int32_t *nebidx, in
     const int cin = fo + Cs - 4;
     // only the feature columns carry gradient: xyz/w come from the non-differentiable index ops
     return gg_batch_take_backward(grad_nf + fo, nebidx, B, Nsrc, Cs - 4, O * P, grad_src + 4, cin,
+                                  Cs, (hipStream_t)stream);
+}
+
+int gridgcn_edge_inputs_rows(const float *src, const int32_t *nebidx, const float *cent,
+                             int cent_stride, int B, int Nsrc, int Cs, int O, int P, int has_feats,
+                             int localfdim, int nf_stride, float *nf, float *att16, void *stream)
+{
+    if (!src || !nebidx || !cent || !nf || !att16) return GRIDGCN_EINVAL;
+    if (B < 1 || Nsrc < 1 || O < 1 || P < 1 || Cs < 4 || (has_feats && Cs == 4))
+        return GRIDGCN_EINVAL;
+    int rc = gg_edge_inputs_rows(src, nebidx, cent, cent_stride, B, Nsrc, Cs, O, P, has_feats,
+                                 localfdim, nf_stride, nf, att16, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_edge_inputs_rows_backward(const float *grad_nf, int nf_stride, const int32_t *nebidx,
+                                      int B, int Nsrc, int Cs, int O, int P, float *grad_src,
+                                      void *stream)
+{
+    if (!grad_nf || !nebidx || !grad_src || B < 1 || Nsrc < 1 || O < 1 || P < 1 || Cs <= 4 ||
+        nf_stride < Cs - 4)
+        return GRIDGCN_EINVAL;
+    // features are the first Cs-4 columns of a row; xyz/w receive no gradient
+    return gg_batch_take_backward(grad_nf, nebidx, B, Nsrc, Cs - 4, O * P, grad_src + 4, nf_stride,
                                   Cs, (hipStream_t)stream);
 }
 

@@ -1,0 +1,230 @@
+// gridgcn_direct.hip -- register-direct fp32 MFMA kernels of the training path (gfx950).
+//
+// v_mfma_f32_32x32x2_f32 wants lane l of the A operand to hold A[row l&31][k = 2s + (l>>5)] at step
+// s.  A contraction does not care in which ORDER k is consumed, so instead of transposing row tiles
+// through LDS a lane reads 16 consecutive floats of ITS row with four 16-byte loads -- lanes 0..31
+// the first half of a 128-byte line, lanes 32..63 the second half -- and consumes them over 16 MFMA
+// steps; the weights are packed (gridgcn_pack_linear, layout "Wq") in exactly that order:
+//
+//     chunk c (32 k's; the last one may hold 8/16/24), nq = k's of the chunk / 8,
+//     step (c, q, i), q < nq, i < 4:   k = 32c + (l>>5)*4*nq + 4q + i
+//
+// No LDS staging of activations, no workgroup barrier in the main loop: every wave owns whole 32-row
+// tiles, keeps ~100 registers, and 16 waves per CU (4 per SIMD) overlap each other's loads, MFMAs
+// and stores -- the LDS-staged kernels of gridgcn_train.hip ran one wave per SIMD with the three
+// phases serialised (measured), at 25-40 TFLOP/s.
+#include "gridgcn_mma.h"
+#include "gridgcn_train.h"
+
+template <int NT> struct GGBVec { float v[NT]; };
+
+template <int NT>
+__device__ __forceinline__ void gg_ldb(const float *__restrict__ base, int idx, float (&b)[NT])
+{
+    if constexpr (NT == 1) {
+        b[0] = base[idx];
+    } else if constexpr (NT == 2) {
+        const float2 t = ((const float2 *)base)[idx];
+        b[0] = t.x; b[1] = t.y;
+    } else {
+#pragma unroll
+        for (int g = 0; g < NT / 4; g++) {
+            const float4 t = ((const float4 *)base)[idx * (NT / 4) + g];
+            b[4 * g + 0] = t.x; b[4 * g + 1] = t.y; b[4 * g + 2] = t.z; b[4 * g + 3] = t.w;
+        }
+    }
+}
+
+__device__ __forceinline__ float gg_f4(const float4 &v, int i)
+{
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const float4 sh)
+{
+    a.x = fmaxf(a.x * sc.x + sh.x, 0.f);
+    a.y = fmaxf(a.y * sc.y + sh.y, 0.f);
+    a.z = fmaxf(a.z * sc.z + sh.z, 0.f);
+    a.w = fmaxf(a.w * sc.w + sh.w, 0.f);
+    return a;
+}
+
+// Z[E, cout] = act(X[E, K]) * W + b, batch statistics of Z in the epilogue.  K % 8 == 0, X row
+// stride K.  NT = ldw / 32 column tiles per wave (all of them: the wave owns full rows of Z).
+template <int NT, bool WLDS, bool EXACT>
+__global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(GGLinFwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int K = p.K, h = lane >> 5;
+    float *Wl = lds;
+    float *scl = lds + (WLDS ? K * 32 * NT : 0);     // [K] scale, [K] shift
+    if (WLDS) {
+        const float4 *src = (const float4 *)p.W;
+        for (int i = tid; i < K * 8 * NT; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
+    }
+    if (p.scale)
+        for (int i = tid; i < K; i += blockDim.x) { scl[i] = p.scale[i]; scl[K + i] = p.shift[i]; }
+    __syncthreads();
+    const float *Wb = WLDS ? Wl : p.W;
+
+    float ssum[NT], ssq[NT], bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        ssum[t] = 0.f; ssq[t] = 0.f;
+        const int col = t * 32 + (lane & 31);
+        bias[t] = col < p.cout ? p.b[col] : 0.f;
+    }
+    const long long ntile = (p.E + 31) >> 5;
+    const int nfull = K >> 5, ktail = K & 31;
+    for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
+         tile += (long long)gridDim.x * nw) {
+        const long long r0 = tile << 5;
+        long long row = r0 + (lane & 31);
+        if (row >= p.E) row = p.E - 1;
+        const float *xr = p.X + row * K;
+        ggm_f32x16 acc[NT];
+        ggm_zero<NT>(acc);
+        int s = 0;
+        for (int c = 0; c < nfull; c++) {
+            const int k0 = c * 32 + h * 16;
+            float4 a[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = *(const float4 *)(xr + k0 + 4 * q);
+            if (p.scale) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    a[q] = gg_bnrelu4(a[q], *(const float4 *)(scl + k0 + 4 * q),
+                                      *(const float4 *)(scl + K + k0 + 4 * q));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float b[NT];
+                    gg_ldb<NT>(Wb, s * 64 + lane, b);
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
+                    s++;
+                }
+            }
+        }
+        if (ktail) {
+            const int nq = ktail >> 3;
+            const int k0 = nfull * 32 + h * 4 * nq;
+            for (int q = 0; q < nq; q++) {
+                float4 a = *(const float4 *)(xr + k0 + 4 * q);
+                if (p.scale)
+                    a = gg_bnrelu4(a, *(const float4 *)(scl + k0 + 4 * q),
+                                   *(const float4 *)(scl + K + k0 + 4 * q));
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float b[NT];
+                    gg_ldb<NT>(Wb, s * 64 + lane, b);
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
+                    s++;
+                }
+            }
+        }
+        const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        const int ldz = EXACT ? NT * 32 : p.cout;
+        float *zp = p.Z + (r0 + 4 * h) * ldz + (lane & 31);
+        if (nrows == 32) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (EXACT || t * 32 + (lane & 31) < p.cout) {
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float z = acc[t][r] + bias[t];
+                        zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;
+                        sm += z;
+                        sq += z * z;
+                    }
+                    ssum[t] += sm;
+                    ssq[t] += sq;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float z = acc[t][r] + bias[t];
+                    if ((EXACT || t * 32 + (lane & 31) < p.cout) && ggm_row(r, lane) < nrows) {
+                        zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;
+                        sm += z;
+                        sq += z * z;
+                    }
+                }
+                ssum[t] += sm;
+                ssq[t] += sq;
+            }
+        }
+    }
+    // statistics: halves -> waves (LDS) -> one fp64 atomic per column and workgroup
+    __syncthreads();
+    float *red = lds;                                  // [nw][2][NT*32]
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float sm = ssum[t] + __shfl_xor(ssum[t], 32, 64);
+        const float sq = ssq[t] + __shfl_xor(ssq[t], 32, 64);
+        if (lane < 32) {
+            red[(wave * 2 + 0) * NT * 32 + t * 32 + lane] = sm;
+            red[(wave * 2 + 1) * NT * 32 + t * 32 + lane] = sq;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * NT * 32; i += blockDim.x) {
+        const int which = i / (NT * 32), col = i - which * NT * 32;
+        if (col >= p.cout) continue;
+        float v = 0.f;
+        for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
+        atomicAdd(&p.sums[which * p.cout + col], (double)v);
+    }
+}
+
+template <int NT>
+static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        const void *fs[4] = {(const void *)gg_k_linear_fwd_direct<NT, true, true>,
+                             (const void *)gg_k_linear_fwd_direct<NT, true, false>,
+                             (const void *)gg_k_linear_fwd_direct<NT, false, true>,
+                             (const void *)gg_k_linear_fwd_direct<NT, false, false>};
+        for (int i = 0; i < 4; i++)
+            if (hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    const int threads = NT == 8 ? 512 : 1024, nw = threads / 64;
+    const size_t wbytes = (size_t)q.K * 32 * NT * 4, sbytes = (size_t)2 * q.K * 4;
+    const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
+    const bool wlds = wbytes + sbytes <= 156 * 1024;
+    size_t lds = (wlds ? wbytes : 0) + sbytes;
+    if (lds < rbytes) lds = rbytes;
+    const long long ntile = (q.E + 31) >> 5;
+    long long nb = (ntile + nw - 1) / nw;
+    if (nb > 256) nb = 256;
+    const bool exact = q.cout == NT * 32;
+    if (wlds && exact) gg_k_linear_fwd_direct<NT, true, true><<<(int)nb, threads, lds, st>>>(q);
+    else if (wlds) gg_k_linear_fwd_direct<NT, true, false><<<(int)nb, threads, lds, st>>>(q);
+    else if (exact) gg_k_linear_fwd_direct<NT, false, true><<<(int)nb, threads, lds, st>>>(q);
+    else gg_k_linear_fwd_direct<NT, false, false><<<(int)nb, threads, lds, st>>>(q);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// p.W = Wq layout, p.K = row length of X (multiple of 8), p.ldw = 32/64/128/256
+int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st)
+{
+    if (p.E < 1 || p.K < 8 || (p.K & 7) || p.K > 1024) return 1;
+    if (p.ldw == 32) return launch_fwd_direct<1>(p, st);
+    if (p.ldw == 64) return launch_fwd_direct<2>(p, st);
+    if (p.ldw == 128) return launch_fwd_direct<4>(p, st);
+    if (p.ldw == 256) return launch_fwd_direct<8>(p, st);
+    return 1;
+}

@@ -291,6 +291,64 @@ __global__ __launch_bounds__(256) void gg_k_edge_inputs(const float *__restrict_
     }
 }
 
+// "features first" layout for the MFMA kernels: one edge per half-wave, 16-byte loads and stores.
+//   nf [E, nfs]  = features (nfeat = Cs-4, a multiple of 4) | geo_vec (if geo) | zeros up to nfs
+//   att[E, 16]   = (geo_dist, geo_vec, centre xyz, neighbour xyz, 0 x 6)
+// nfs is a multiple of 8 so that every row is a whole number of 32-byte half-lines
+// (gg_k_linear_fwd_direct reads rows with 16-byte loads; the matching permutation of the weight
+// columns is done by gridgcn_pack_linear).
+__global__ __launch_bounds__(256) void gg_k_edge_inputs_rows(
+    const float *__restrict__ src, const int *__restrict__ nebidx, const float *__restrict__ cent,
+    int cent_stride, int Nsrc, long long rows, int Cs, int O, int P, int nfeat, int geo, int nfs,
+    int E, float *__restrict__ nf, float *__restrict__ att)
+{
+    const int sub = threadIdx.x & 31;
+    const int nhalf = gridDim.x * 8;
+    const int ntail4 = (nfs - nfeat) >> 2;
+    for (int e = blockIdx.x * 8 + (threadIdx.x >> 5); e < E; e += nhalf) {
+        const int ci = e / P;
+        const int b = ci / O;
+        long long flat = (long long)nebidx[e] + (long long)b * Nsrc;
+        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+        const float *srow = src + flat * Cs;
+        float *nrow = nf + (size_t)e * nfs;
+        for (int i = sub * 4; i < nfeat; i += 128)
+            *(float4 *)(nrow + i) = *(const float4 *)(srow + 4 + i);
+        // the last lanes of the half-wave write the geo tail and the attention row
+        const int j = 31 - sub;                      // 0..3: att float4 j; 4..: tail float4 j-4
+        if (j < 4 + ntail4) {
+            const float *cen = cent + (size_t)ci * cent_stride;
+            const float cx = cen[0], cy = cen[1], cz = cen[2];
+            const float nx = srow[0], ny = srow[1], nz = srow[2];
+            const float gx = nx - cx, gy = ny - cy, gz = nz - cz;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j == 0) v = make_float4(sqrtf((gx * gx + gy * gy) + gz * gz), gx, gy, gz);
+            else if (j == 1) v = make_float4(cx, cy, cz, nx);
+            else if (j == 2) v = make_float4(ny, nz, 0.f, 0.f);
+            else if (j == 4 && geo) v = make_float4(gx, gy, gz, 0.f);
+            if (j < 4) *(float4 *)(att + (size_t)e * 16 + 4 * j) = v;
+            else *(float4 *)(nrow + nfeat + 4 * (j - 4)) = v;
+        }
+    }
+}
+
+int gg_edge_inputs_rows(const float *src, const int *nebidx, const float *cent, int cent_stride,
+                        int B, int Nsrc, int Cs, int O, int P, int has_feats, int localfdim,
+                        int nfs, float *nf, float *att, hipStream_t st)
+{
+    const int geo = (!has_feats || localfdim != 0) ? 1 : 0;
+    const int nfeat = has_feats ? Cs - 4 : 0;
+    if ((nfeat & 3) || (nfs & 7) || nfs < nfeat + (geo ? 3 : 0) || nfs - nfeat > 96) return 1;
+    const long long E = (long long)B * O * P;
+    if (E >= (1ll << 31)) return 1;
+    long long nb = (E + 7) / 8;
+    const int grid = (int)(nb < 65536 ? nb : 65536);
+    gg_k_edge_inputs_rows<<<grid, 256, 0, st>>>(src, nebidx, cent, cent_stride, Nsrc,
+                                                (long long)B * Nsrc, Cs, O, P, nfeat, geo, nfs,
+                                                (int)E, nf, att);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 int gg_edge_inputs(const float *src, const int *nebidx, const float *cent, int cent_stride, int B,
                    int Nsrc, int Cs, int O, int P, int has_feats, int localfdim, float *nf,
                    float *att, hipStream_t st)

@@ -134,17 +134,62 @@ __global__ void gg_k_bn_bwd_finalize(const double *__restrict__ sums, long long 
 //   Bp [ldw]                 zero padded bias
 //   Wb [ceil(cin/32)][C4][32]            tile-major W (dW / monolithic backward), C4 = round4(C)
 //   Wg column blocks of 4/2/1 tiles, each [C4][32][nt]   (gg_k_linear_dx)
-__global__ void gg_k_pack_linear(const float *__restrict__ W, const float *__restrict__ b, int C,
-                                 int cin, int K, int ldw, float *__restrict__ Wp,
-                                 float *__restrict__ Bp, float *__restrict__ Wb,
-                                 float *__restrict__ Wg)
+//   Wq  forward B operand of gg_k_linear_fwd_direct, Wdx the dX B operand of gg_k_linear_dx_direct
+// The kernels see a layer of `cin` input channels; the framework's matrix has cin_w <= cin columns,
+// of which the first `rot` are moved behind the others (column k of the kernels' matrix = framework
+// column k + rot for k < cin_w - rot, k - (cin_w - rot) for k < cin_w, zero beyond): this is the
+// "features first, geo_vec last, zero padded" row layout written by gg_k_edge_inputs_rows.
+struct GGPackW {
+    const float *W;
+    int cin_w, rot;
+    __device__ float at(int row, int k) const
+    {
+        if (k >= cin_w) return 0.f;
+        const int src = k < cin_w - rot ? k + rot : k - (cin_w - rot);
+        return W[(size_t)row * cin_w + src];
+    }
+};
+
+__global__ void gg_k_pack_linear(const float *__restrict__ W_, const float *__restrict__ b, int C,
+                                 int cin_w, int rot, int cin, int K, int ldw, int ndx,
+                                 float *__restrict__ Wp, float *__restrict__ Bp,
+                                 float *__restrict__ Wb, float *__restrict__ Wg,
+                                 float *__restrict__ Wq, float *__restrict__ Wdx)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K8 = (cin + 7) & ~7;
+    const GGPackW W{W_, cin_w, rot};
+    if (Wdx && ndx > 0) {
+        // [step s over channels][lane][NTV], channel(s, lane) as k(s, lane) below, column
+        // n = t*32 + (lane&31) < ndx
+        const int C8 = (C + 7) & ~7, nt = (ndx + 31) / 32;
+        const int NTV = nt <= 1 ? 1 : (nt <= 2 ? 2 : (nt <= 4 ? 4 : 8));
+        if (t < (C8 / 2) * 64 * NTV) {
+            const int tt = t % NTV, lane = (t / NTV) % 64, s = t / (NTV * 64);
+            const int c = s >> 4, ws = s & 15;
+            const int kc = (C8 - 32 * c) < 32 ? (C8 - 32 * c) : 32, nq = kc >> 3;
+            const int ch = 32 * c + (lane >> 5) * 4 * nq + 4 * (ws >> 2) + (ws & 3);
+            const int n = tt * 32 + (lane & 31);
+            Wdx[t] = (ch < C && n < ndx && n < cin) ? W.at(ch, n) : 0.f;
+        }
+    }
+    if (Wq && t < K8 * ldw) {
+        // forward B operand of the register-direct kernel (gridgcn_direct.hip):
+        // [step s][lane][NT], k(s, lane) = 32c + (lane>>5)*4*nq + 4q + i
+        const int NT = ldw / 32;
+        const int tt = t % NT, lane = (t / NT) % 64, s = t / (NT * 64);
+        const int c = s >> 4, ws = s & 15;
+        const int kc = (K8 - 32 * c) < 32 ? (K8 - 32 * c) : 32, nq = kc >> 3;
+        const int q = ws >> 2, i = ws & 3;
+        const int k = 32 * c + (lane >> 5) * 4 * nq + 4 * q + i;
+        const int col = tt * 32 + (lane & 31);
+        Wq[t] = (k < cin && col < C) ? W.at(col, k) : 0.f;
+    }
     if (Wp && t < K * ldw) {
         const int gw = ldw < 128 ? ldw : 128, nt = gw / 32;
         const int tt = t % nt, j = (t / nt) % 32, k = (t / (nt * 32)) % K, g = t / (nt * 32 * K);
         const int col = g * gw + tt * 32 + j;
-        Wp[t] = (k < cin && col < C) ? W[(size_t)col * cin + k] : 0.f;
+        Wp[t] = (k < cin && col < C) ? W.at(col, k) : 0.f;
     }
     if (Bp && t < ldw) Bp[t] = t < C ? b[t] : 0.f;
     const int C4 = (C + 3) & ~3, ntile = (cin + 31) / 32;
@@ -152,7 +197,7 @@ __global__ void gg_k_pack_linear(const float *__restrict__ W, const float *__res
         if (Wb) {
             const int j = t % 32, kc = (t / 32) % C4, tile = t / (32 * C4);
             const int col = tile * 32 + j;
-            Wb[t] = (kc < C && col < cin) ? W[(size_t)kc * cin + col] : 0.f;
+            Wb[t] = (kc < C && col < cin) ? W.at(kc, col) : 0.f;
         }
         if (Wg) {
             int idx = t, done = 0, nb = 1;
@@ -166,21 +211,27 @@ __global__ void gg_k_pack_linear(const float *__restrict__ W, const float *__res
             }
             const int tt = idx % nb, j = (idx / nb) % 32, kc = idx / (nb * 32);
             const int col = (done + tt) * 32 + j;
-            Wg[t] = (kc < C && col < cin) ? W[(size_t)kc * cin + col] : 0.f;
+            Wg[t] = (kc < C && col < cin) ? W.at(kc, col) : 0.f;
         }
     }
 }
 
-int gg_pack_linear(const float *W, const float *b, int C, int cin, float *Wp, float *Bp, float *Wb,
-                   float *Wg, hipStream_t st)
+int gg_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, int cin, int ndx,
+                   float *Wp, float *Bp, float *Wb, float *Wg, float *Wq, float *Wdx,
+                   hipStream_t st)
 {
-    if (C < 1 || C > 256 || cin < 1) return 1;
-    const int K = (cin + 3) & ~3;
+    if (C < 1 || C > 256 || cin_w < 1 || cin < cin_w || rot < 0 || rot > cin_w || ndx < 0 ||
+        ndx > 256)
+        return 1;
+    const int K = (cin + 3) & ~3, K8 = (cin + 7) & ~7;
     const int ldw = C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
     const int C4 = (C + 3) & ~3, ntile = (cin + 31) / 32;
-    int n = K * ldw;
+    int n = K8 * ldw;
     if (ntile * C4 * 32 > n) n = ntile * C4 * 32;
-    gg_k_pack_linear<<<(n + 255) / 256, 256, 0, st>>>(W, b, C, cin, K, ldw, Wp, Bp, Wb, Wg);
+    const int C8 = (C + 7) & ~7;
+    if (C8 * 32 * 8 > n && Wdx) n = C8 * 32 * 8;
+    gg_k_pack_linear<<<(n + 255) / 256, 256, 0, st>>>(W, b, C, cin_w, rot, cin, K, ldw, ndx, Wp, Bp,
+                                                      Wb, Wg, Wq, Wdx);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

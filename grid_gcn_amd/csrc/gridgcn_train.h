@@ -40,6 +40,7 @@ struct GGLinBwd {
 };
 
 int gg_linear_fwd(const GGLinFwd &p, hipStream_t st);
+int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st);   // gridgcn_direct.hip
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,

@@ -134,9 +134,20 @@ class SubGUpdate(nn.Module):
         one HIP kernel (ops.edge_inputs, scatter-add backward); the MLPs with batch-statistics
         BatchNorm are stock PyTorch ops."""
         from . import ops
-        nf, att_vec = ops.edge_inputs(src.contiguous(), nebidx, cent.contiguous(),
-                                      has_feats=self.has_feats, localfdim=self.localfdim)
         att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
+        src = src.contiguous()
+        if self.mfma_train and self.training and torch.is_grad_enabled():
+            from . import train_ops
+            if train_ops.edge_block_supported(pt_layers, att_layers, src) and \
+                    ops.edge_inputs_rows_supported(src, self.has_feats):
+                # rows laid out for the MFMA kernels (features | geo_vec | zero padding)
+                nf, att16, rot = ops.edge_inputs_rows(src, nebidx, cent.contiguous(),
+                                                      has_feats=self.has_feats,
+                                                      localfdim=self.localfdim)
+                agg = train_ops.edge_block_train(nf, att16, pt_layers, att_layers, rot)
+                return self.finish(agg, center_masks, center_ori_feats)
+        nf, att_vec = ops.edge_inputs(src, nebidx, cent.contiguous(),
+                                      has_feats=self.has_feats, localfdim=self.localfdim)
         if self.mfma_train and self.training and torch.is_grad_enabled():
             from . import train_ops
             if train_ops.edge_block_supported(pt_layers, att_layers, nf):

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, synth
-from .gridconv import ConvBNReLU, SubGUpdate
+from .gridconv import ConvBNReLU, SubGUpdate, run_mlp
 
 SEG_8192 = dict(
     grid=synth.SEG_SCANNET_8192, inputDim=[0, 64, 128], pt_ele_dim=[[32, 32, 64], [64, 64, 128],
@@ -118,7 +118,7 @@ class GGCNSeg(nn.Module):
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
             f_last = torch.cat([upl, cf], dim=2)                                    # :231
-        net = self.fc1(cf)
+        net = run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
         return self.fc2(net)
 

@@ -344,6 +344,62 @@ class _EdgeInputs(torch.autograd.Function):
         return gsrc, None, None, None, None
 
 
+class _EdgeInputsRows(torch.autograd.Function):
+    """gridgcn_edge_inputs_rows: nf = features | geo_vec | zero padding (row length a multiple of
+    8), att16 = att_vec | 6 zeros -- the row layout the MFMA training kernels read directly."""
+
+    @staticmethod
+    def forward(ctx, src, nebidx, cent, has_feats, localfdim):
+        lib = _lib.load()
+        B, Nsrc, Cs = src.shape
+        _, O, P = nebidx.shape
+        geo = (not has_feats) or localfdim != 0
+        nfeat = Cs - 4 if has_feats else 0
+        nfs = (nfeat + (3 if geo else 0) + 7) & ~7
+        nf = torch.empty((B, O, P, nfs), dtype=torch.float32, device=src.device)
+        att = torch.empty((B, O, P, 16), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            rc = lib.gridgcn_edge_inputs_rows(_ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B,
+                                              Nsrc, Cs, O, P, int(has_feats), int(localfdim), nfs,
+                                              _ptr(nf), _ptr(att), _stream(src))
+        _lib.check(rc, "gridgcn_edge_inputs_rows")
+        ctx.save_for_backward(nebidx)
+        ctx.meta = (B, Nsrc, Cs, O, P, has_feats, nfs)
+        ctx.mark_non_differentiable(att)
+        return nf, att
+
+    @staticmethod
+    def backward(ctx, gnf, gatt):
+        B, Nsrc, Cs, O, P, has_feats, nfs = ctx.meta
+        if not has_feats or not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        (nebidx,) = ctx.saved_tensors
+        gnf = gnf.contiguous()
+        gsrc = torch.zeros((B, Nsrc, Cs), dtype=torch.float32, device=gnf.device)
+        with torch.cuda.device(gnf.device):
+            rc = lib.gridgcn_edge_inputs_rows_backward(_ptr(gnf), nfs, _ptr(nebidx), B, Nsrc, Cs, O,
+                                                       P, _ptr(gsrc), _stream(gnf))
+        _lib.check(rc, "gridgcn_edge_inputs_rows_backward")
+        return gsrc, None, None, None, None
+
+
+def edge_inputs_rows_supported(src, has_feats):
+    return (not has_feats) or (src.shape[2] - 4) % 4 == 0
+
+
+def edge_inputs_rows(src, nebidx, cent, *, has_feats, localfdim):
+    """(nf [B,O,P,nfs], att16 [B,O,P,16], rot): the edge inputs of sub_g_update in the padded
+    "features first" row layout; rot = number of leading reference channels (geo_vec) that were
+    moved behind the features (the first conv's weight columns must be rotated by it)."""
+    _chk(src, "src", 3, torch.float32)
+    _chk(nebidx, "nebidx", 3, torch.int32)
+    _chk(cent, "cent", 3, torch.float32)
+    nf, att = _EdgeInputsRows.apply(src, nebidx, cent, bool(has_feats), int(localfdim))
+    rot = 3 if (has_feats and localfdim != 0) else 0
+    return nf, att, rot
+
+
 def edge_inputs(src, nebidx, cent, *, has_feats, localfdim):
     """(nf [B,O,P,cin], att_vec [B,O,P,10]) of sub_g_update (gcn_module_g_att.py:190-250) in one
     kernel; differentiable w.r.t. the feature columns of src."""

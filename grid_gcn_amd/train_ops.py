@@ -28,6 +28,12 @@ from . import _lib
 from .ops import _ptr, _stream
 
 
+import os  # noqa: E402
+
+# register-direct forward kernel (csrc/gridgcn_direct.hip) for inputs whose width is a multiple of 8
+DIRECT_FWD = os.environ.get("GG_FWD_LDS", "0") != "1"
+
+
 def supported(layers, x):
     if not (x.is_cuda and x.dtype == torch.float32):
         return False
@@ -81,9 +87,11 @@ def packed_sizes(C, cin):
     return K, ldw, K * ldw, ((cin + 31) // 32) * ((C + 3) & ~3) * 32
 
 
-def _chain_forward(lib, x, params, bns, eps):
+def _chain_forward(lib, x, params, bns, eps, rot=0):
     """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer.  Per layer three launches:
-    pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping."""
+    pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping.
+    x may be wider than the first layer's weight (zero padded columns) and hold the layer's first
+    `rot` input channels behind the others (ops.edge_inputs_rows)."""
     L = len(params) // 4
     E, dev = x.shape[0], x.device
     st = _Chain()
@@ -94,21 +102,32 @@ def _chain_forward(lib, x, params, bns, eps):
     stream = _stream(x)
     for l in range(L):
         W, b, gamma, beta = params[4 * l:4 * l + 4]
-        cout, cin = W.shape
+        cout, cin_w = W.shape
+        cin = prev.shape[1]
+        assert cin >= cin_w and (l == 0 or cin == cin_w)
         K, ldw, nwp, nwb = packed_sizes(cout, cin)
-        pk = torch.empty(nwp + ldw + 2 * nwb, dtype=torch.float32, device=dev)
+        direct = DIRECT_FWD and cin % 8 == 0
+        nwq = cin * ldw if direct else 0
+        pk = torch.empty(nwp + ldw + 2 * nwb + nwq, dtype=torch.float32, device=dev)
         Wp, Bp = pk[:nwp], pk[nwp:nwp + ldw]
-        Wb, Wg = pk[nwp + ldw:nwp + ldw + nwb], pk[nwp + ldw + nwb:]
-        rc = lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), cout, cin,
-                                     _ptr(Wp), _ptr(Bp), _ptr(Wb), _ptr(Wg), stream)
+        Wb, Wg = pk[nwp + ldw:nwp + ldw + nwb], pk[nwp + ldw + nwb:nwp + ldw + 2 * nwb]
+        Wq = pk[nwp + ldw + 2 * nwb:] if direct else None
+        rc = lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), cout, cin_w,
+                                     rot if l == 0 else 0, cin, 0,
+                                     None if direct else _ptr(Wp), _ptr(Bp), _ptr(Wb), _ptr(Wg),
+                                     _ptr(Wq) if direct else None, None, stream)
         _lib.check(rc, "gridgcn_pack_linear")
         Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
         sums = allsums[so:so + 2 * cout]
         so += 2 * cout
-        rc = lib.gridgcn_linear_fwd(
-            _ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
-            _ptr(pscale) if pscale is not None else None,
-            _ptr(pshift) if pshift is not None else None, _ptr(Z), _ptr(sums), stream)
+        ps = _ptr(pscale) if pscale is not None else None
+        ph = _ptr(pshift) if pshift is not None else None
+        if direct:
+            rc = lib.gridgcn_linear_fwd_direct(_ptr(prev), E, cin, _ptr(Wq), _ptr(Bp), ldw, cout,
+                                               ps, ph, _ptr(Z), _ptr(sums), stream)
+        else:
+            rc = lib.gridgcn_linear_fwd(_ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
+                                        ps, ph, _ptr(Z), _ptr(sums), stream)
         _lib.check(rc, "gridgcn_linear_fwd")
         vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
         bn = bns[l]
@@ -128,11 +147,15 @@ def _chain_forward(lib, x, params, bns, eps):
     return st
 
 
-def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums, dY, sparse, need_dx):
+def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums, dY, sparse, need_dx,
+                    cin_w0=None, rot=0):
     """backward through a chain.  `sums` [2*C_L] fp64 = BatchNorm-backward sums of the LAST layer;
     upstream gradient either dense dY [E,C_L] or sparse = (amax, gval, P).  Returns (dX, grads)
-    with grads = [dW, db, dgamma, dbeta] * L."""
+    with grads = [dW, db, dgamma, dbeta] * L.  cin_w0 / rot: width of the first layer's weight and
+    its column rotation when x is in the padded row layout (see _chain_forward)."""
     L = len(Zs)
+    if cin_w0 is None:
+        cin_w0 = x.shape[1]
     E, dev = x.shape[0], x.device
     grads = [None] * (4 * L)
     Cs = [Zs[l].shape[1] for l in range(L)]
@@ -185,6 +208,10 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums, dY
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
         _lib.check(rc, "gridgcn_linear_bwd")
+        if l == 0 and (cin != cin_w0 or rot):
+            # back to the framework's column order / width
+            dW = torch.cat([dW[:, cin_w0 - rot:cin_w0], dW[:, :cin_w0 - rot]], dim=1) if rot \
+                else dW[:, :cin_w0].contiguous()
         grads[4 * l] = dW
         dY, sums, sparse = dX, psums, None
     return dY, grads
@@ -250,12 +277,12 @@ class _EdgeBlockTrain(torch.autograd.Function):
         """nf [E,cin], att_vec [E,10]; params = pt chain params + att chain params (4 per layer);
         meta = (eps, pt bns, att bns, ncent, P).  Returns agg [ncent, C]."""
         lib = _lib.load()
-        eps, bns_p, bns_a, ncent, P = meta
+        eps, bns_p, bns_a, ncent, P, rot = meta
         Lp, La = len(bns_p), len(bns_a)
         nf, att_vec = nf.contiguous(), att_vec.contiguous()
         dev = nf.device
         with torch.cuda.device(dev):
-            sp = _chain_forward(lib, nf, params[:4 * Lp], bns_p, eps)
+            sp = _chain_forward(lib, nf, params[:4 * Lp], bns_p, eps, rot)
             sa = _chain_forward(lib, att_vec, params[4 * Lp:], bns_a, eps)
             C = sp.Z[-1].shape[1]
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
@@ -264,7 +291,7 @@ class _EdgeBlockTrain(torch.autograd.Function):
                                          _ptr(sp.shift[-1]), _ptr(sa.scale[-1]), _ptr(sa.shift[-1]),
                                          ncent, P, C, _ptr(agg), _ptr(amax), _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_fwd")
-        ctx.dims = (Lp, La, ncent, P)
+        ctx.dims = (Lp, La, ncent, P, rot, params[0].shape[1], params[4 * Lp].shape[1])
         ctx.save_for_backward(
             nf, att_vec, amax,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg,
@@ -275,7 +302,7 @@ class _EdgeBlockTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dagg):
         lib = _lib.load()
-        Lp, La, ncent, P = ctx.dims
+        Lp, La, ncent, P, rot, cwp, cwa = ctx.dims
         t = ctx.saved_tensors
         nf, att_vec, amax = t[0], t[1], t[2]
         o = 3
@@ -297,9 +324,9 @@ class _EdgeBlockTrain(torch.autograd.Function):
                                          _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_bwd")
             dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pWb, pWg, sums_p, None,
-                                           (amax, gp, P), ctx.needs_input_grad[0])
+                                           (amax, gp, P), ctx.needs_input_grad[0], cwp, rot)
             _, grads_a = _chain_backward(lib, att_vec, aZ, aS, aH, aM, aR, aWb, aWg, sums_a, None,
-                                         (amax, ga, P), False)
+                                         (amax, ga, P), False, cwa, 0)
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
@@ -351,13 +378,16 @@ def edge_block_supported(pt_layers, att_layers, nf):
             and att_layers[-1].lin.out_features == C)
 
 
-def edge_block_train(nf, att_vec, pt_layers, att_layers):
-    """nf [B,O,P,cin], att_vec [B,O,P,10] -> [B,O,C] = max_p att_mlp(att_vec) * pt_mlp(nf)."""
+def edge_block_train(nf, att_vec, pt_layers, att_layers, rot=0):
+    """nf [B,O,P,cin], att_vec [B,O,P,10] -> [B,O,C] = max_p att_mlp(att_vec) * pt_mlp(nf).
+    nf / att_vec may come zero padded (and nf with its first `rot` channels moved behind the
+    others) from ops.edge_inputs_rows."""
     B, O, P, cin = nf.shape
     params = []
     for l in list(pt_layers) + list(att_layers):
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
-    meta = (pt_layers[0].bn.eps, [l.bn for l in pt_layers], [l.bn for l in att_layers], B * O, P)
+    meta = (pt_layers[0].bn.eps, [l.bn for l in pt_layers], [l.bn for l in att_layers], B * O, P,
+            rot)
     agg = _EdgeBlockTrain.apply(nf.reshape(-1, cin), att_vec.reshape(-1, att_vec.shape[-1]), meta,
                                 *params)
     return agg.reshape(B, O, -1)

@@ -133,6 +133,20 @@ int gridgcn_edge_inputs_backward(const float *grad_nf, const int32_t *nebidx, in
                                  int Cs, int O, int P, int has_feats, int localfdim,
                                  float *grad_src, void *stream);
 
+/* "rows" variant for the MFMA training kernels: the same values, laid out so that every row is read
+ * and written with 16-byte accesses --
+ *   nf [B,O,P,nf_stride] = features (Cs-4 columns, a multiple of 4) | geo_vec (if the layer has one)
+ *                          | zeros;  nf_stride a multiple of 8
+ *   att16[B,O,P,16]      = the 10 att_vec channels | 6 zeros
+ * (the first conv's weight columns are permuted/padded to match by gridgcn_pack_linear's `rot`).
+ * Backward: grad_src[.., 4:] += the first Cs-4 columns of grad_nf rows. */
+int gridgcn_edge_inputs_rows(const float *src, const int32_t *nebidx, const float *cent,
+                             int cent_stride, int B, int Nsrc, int Cs, int O, int P, int has_feats,
+                             int localfdim, int nf_stride, float *nf, float *att16, void *stream);
+int gridgcn_edge_inputs_rows_backward(const float *grad_nf, int nf_stride, const int32_t *nebidx,
+                                      int B, int Nsrc, int Cs, int O, int P, float *grad_src,
+                                      void *stream);
+
 /* ---- training-mode 1x1 conv + BatchNorm + ReLU (utils/ops.py:149-158 conv2d, :141-147 conv1d) ---
  * gridgcn_linear_fwd: Z[E,cout] = act(X[E,cin]) * W + b on fp32 MFMA; act = identity (scale ==
  *   NULL) or the previous layer's BatchNorm+ReLU x -> relu(x*scale[c] + shift[c]) applied while
@@ -157,10 +171,26 @@ int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, con
  *        [round4(C)][32][nt] (nt tiles of the block interleaved so that one vector load per k feeds
  *        nt MFMAs).  Wg != NULL selects the split schedule (one dX kernel + one dW kernel); NULL
  *        the single-kernel schedule.  gridgcn_pack_linear writes every layout in one launch. */
-int gridgcn_pack_linear(const float *W, const float *b, int C, int cin, float *Wp, float *Bp,
-                        float *Wb, float *Wg, void *stream);
-/* gridgcn_pack_linear: W[C][cin] (framework layout, C <= 256), b[C] ->
+int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, int cin, int ndx,
+                        float *Wp, float *Bp, float *Wb, float *Wg, float *Wq, float *Wdx,
+                        void *stream);
+/* gridgcn_linear_fwd_direct: as gridgcn_linear_fwd for X[E][K] with K % 8 == 0 (zero-padded input
+ *   channels), weights in the "Wq" order: each lane reads 16 consecutive floats of its row straight
+ *   into registers and consumes them over 16 MFMA steps -- step (c, q, i) of lane l multiplies
+ *   k = 32c + (l>>5)*4*nq + 4q + i (nq = 4, or K%32/8 in the last chunk) -- so Wq is
+ *   [K/2 steps][64 lanes][ldw/32] with element (s, l, t) = W[t*32 + (l&31)][k(s, l)].  No LDS
+ *   staging of X, 16 waves per CU. */
+int gridgcn_linear_fwd_direct(const float *X, long long E, int K, const float *Wq, const float *b,
+                              int ldw, int cout, const float *scale, const float *shift, float *Z,
+                              double *sums, void *stream);
+/* gridgcn_pack_linear: W[C][cin_w] (framework layout, C <= 256), b[C]; the kernels see `cin` >=
+ *   cin_w input channels: kernel column k = framework column k + rot (k < cin_w - rot), k - (cin_w -
+ *   rot) (k < cin_w), zero (k >= cin_w) -- i.e. the first `rot` columns moved behind the others and
+ *   zero padding, the row layout of gridgcn_edge_inputs_rows (rot = 3: geo_vec).  Outputs:
+ *   Wdx[round8(C)/2 * 64 * ntv] (ndx > 0): dX operand of gridgcn_linear_bwd's direct schedule for the
+ *   first ndx input channels, ntv = ceil(ndx/32) rounded up to 1/2/4/8, channel order as Wq;
  *   Wp[round4(cin) * ldw] / Bp[ldw] for gridgcn_linear_fwd (ldw = C rounded up to 32/64/128/256),
+ *   Wq[round8(cin) * ldw] for gridgcn_linear_fwd_direct,
  *   Wb, Wg [ceil(cin/32) * round4(C) * 32] each for gridgcn_linear_bwd.  Any output may be NULL.
  * gridgcn_bn_finalize: batch statistics -> scale = gamma*rstd, shift = beta - mean*scale, mean,
  *   rstd = rsqrt(var_biased + eps) from sums = (sum z, sum z^2) over E rows; running_mean/var

@@ -99,6 +99,36 @@ def test_edge_inputs_forward_backward(cin, lfd):
         assert float(src.grad[..., :4].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,lfd", [(0, 0), (0, 3), (64, 0), (64, 3), (128, 3), (36, 3), (256, 3)])
+def test_edge_inputs_rows_layout(cin, lfd):
+    """ops.edge_inputs_rows == ops.edge_inputs with the columns moved (features | geo_vec | zero
+    padding; att_vec | zeros), bit for bit; backward == backward of edge_inputs."""
+    gen = torch.Generator().manual_seed(cin + lfd + 1)
+    B, Nsrc, O, P = 3, 200, 90, 12
+    src = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV).requires_grad_(cin > 0)
+    nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    nf, att = ops.edge_inputs(src, nebidx, cent, has_feats=cin > 0, localfdim=lfd)
+    src2 = src.detach().clone().requires_grad_(cin > 0)
+    nfr, att16, rot = ops.edge_inputs_rows(src2, nebidx, cent, has_feats=cin > 0, localfdim=lfd)
+    w = nf.shape[-1]
+    assert nfr.shape[-1] % 8 == 0 and nfr.shape[-1] >= w and att16.shape[-1] == 16
+    assert rot == (3 if (cin > 0 and lfd) else 0)
+    assert torch.equal(nfr[..., :w - rot], nf[..., rot:])
+    assert torch.equal(nfr[..., w - rot:w], nf[..., :rot])
+    assert float(nfr[..., w:].abs().max()) == 0.0 if nfr.shape[-1] > w else True
+    assert torch.equal(att16[..., :10], att) and float(att16[..., 10:].abs().max()) == 0.0
+    if cin > 0:
+        g = torch.randn(nf.shape, generator=gen).to(DEV)
+        gr = torch.zeros_like(nfr)
+        gr[..., :w - rot] = g[..., rot:]
+        gr[..., w - rot:w] = g[..., :rot]
+        gr[..., w:] = 3.0                      # padding columns must be ignored
+        nf.backward(g)
+        nfr.backward(gr)
+        assert torch.allclose(src.grad, src2.grad, rtol=1e-5, atol=1e-5)
+
+
 def test_training_step_edge_kernel_matches_torch_ops():
     """one fwd+bwd of the whole network: HIP edge-input kernel path vs stock-op path."""
     torch.manual_seed(0)

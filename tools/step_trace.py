@@ -21,7 +21,7 @@ for r in seq:
         print("%9.1f us %-46s grid=%-9s wg=%s lds=%s" % (d, k[:46], r["Grid_Size_X"], r["Workgroup_Size_X"],
                                                       r.get("LDS_Block_Size", "")))
 print("---- by kernel")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:18]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 18]:
     print("%-62s n=%4d tot=%9.1f us" % (k, v[0], v[1]))
 print("sum %.1f ms, kernels %d, wall %.1f ms" % (
     tot / 1e3, len(seq), (int(seq[-1]["End_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e6))
