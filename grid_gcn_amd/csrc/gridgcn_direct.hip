@@ -228,3 +228,212 @@ int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st)
     if (p.ldw == 256) return launch_fwd_direct<8>(p, st);
     return 1;
 }
+
+// ------------------------------------------------------------------------------------------
+// dX[E, 0:ndx] = dZ[E, C] * W[C, 0:ndx] with dZ = BatchNorm/ReLU backward of (dY, Z) formed in
+// registers: a lane reads 16 consecutive channels of its row from Z and from the upstream gradient
+// (dense dY, or the sparse (amax, gval) of gridgcn_pairmax_bwd) -- the same k-permutation as the
+// forward kernel, with the channels as contraction index.  Epilogue: store dX and accumulate the
+// BatchNorm-backward sums of the PREVIOUS layer (its raw output Aprev read in the C/D layout).
+//   dz = scale*dyr - scale*m1 - scale*rstd*m2*(z - mean),   dyr = dy * (z*scale + shift > 0)
+// NT = ceil(ndx/32) column tiles, NTV = its vector width in Wdx (1/2/4/8).
+template <int NT>
+__global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
+{
+    constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int C = p.C, h = lane >> 5, ldx = p.cin;
+    float *Wl = lds;                              // [C/2 steps][64][NTV]
+    float *cst = lds + C * 32 * NTV;              // scale, shift, mean, bz, cz  [5][C]
+    {
+        const float4 *src = (const float4 *)p.Wdx;
+        for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
+        for (int c = tid; c < C; c += blockDim.x) {
+            const float sc = p.scale[c];
+            cst[c] = sc;
+            cst[C + c] = p.shift[c];
+            cst[2 * C + c] = p.mean[c];
+            cst[3 * C + c] = -(sc * p.rstd[c]) * p.m2[c];
+            cst[4 * C + c] = -(sc * p.m1[c]);
+        }
+    }
+    __syncthreads();
+    const bool prevbn = p.pscale != nullptr;
+    float a1[NT], a2[NT], ps[NT], psh[NT], pm[NT], pr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        a1[t] = 0.f; a2[t] = 0.f;
+        const int col = t * 32 + (lane & 31);
+        const bool ok = prevbn && col < p.ndx;
+        ps[t] = ok ? p.pscale[col] : 0.f; psh[t] = ok ? p.pshift[col] : 0.f;
+        pm[t] = ok ? p.pmean[col] : 0.f;  pr[t] = ok ? p.prstd[col] : 0.f;
+    }
+    const long long ntile = (p.E + 31) >> 5;
+    const int nfull = C >> 5, ktail = C & 31;
+    const bool sparse = p.amax != nullptr;
+
+    auto dz4 = [&](const float4 z, const float4 g, int k) -> float4 {
+        const float4 sc = *(const float4 *)(cst + k), sh = *(const float4 *)(cst + C + k);
+        const float4 mu = *(const float4 *)(cst + 2 * C + k), bz = *(const float4 *)(cst + 3 * C + k);
+        const float4 cz = *(const float4 *)(cst + 4 * C + k);
+        float4 d;
+        d.x = sc.x * ((z.x * sc.x + sh.x > 0.f) ? g.x : 0.f) + ((z.x - mu.x) * bz.x + cz.x);
+        d.y = sc.y * ((z.y * sc.y + sh.y > 0.f) ? g.y : 0.f) + ((z.y - mu.y) * bz.y + cz.y);
+        d.z = sc.z * ((z.z * sc.z + sh.z > 0.f) ? g.z : 0.f) + ((z.z - mu.z) * bz.z + cz.z);
+        d.w = sc.w * ((z.w * sc.w + sh.w > 0.f) ? g.w : 0.f) + ((z.w - mu.w) * bz.w + cz.w);
+        return d;
+    };
+
+    for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
+         tile += (long long)gridDim.x * nw) {
+        const long long r0 = tile << 5;
+        long long row = r0 + (lane & 31);
+        if (row >= p.E) row = p.E - 1;
+        const float *zr = p.Z + row * C;
+        const float *gr;
+        const int *ar = nullptr;
+        int pp = 0;
+        if (sparse) {
+            const long long cen = row / p.P;
+            pp = (int)(row - cen * p.P);
+            gr = p.gval + cen * C;
+            ar = p.amax + cen * C;
+        } else {
+            gr = p.dY + row * C;
+        }
+        auto ldg = [&](int k) -> float4 {
+            float4 g = *(const float4 *)(gr + k);
+            if (sparse) {
+                const int4 am = *(const int4 *)(ar + k);
+                g.x = am.x == pp ? g.x : 0.f; g.y = am.y == pp ? g.y : 0.f;
+                g.z = am.z == pp ? g.z : 0.f; g.w = am.w == pp ? g.w : 0.f;
+            }
+            return g;
+        };
+        ggm_f32x16 acc[NT];
+        ggm_zero<NT>(acc);
+        int s = 0;
+        for (int c = 0; c < nfull; c++) {
+            const int k0 = c * 32 + h * 16;
+            float4 z[4], g[4], a[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { z[q] = *(const float4 *)(zr + k0 + 4 * q); g[q] = ldg(k0 + 4 * q); }
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = dz4(z[q], g[q], k0 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float b[NTV];
+                    gg_ldb<NTV>(Wl, s * 64 + lane, b);
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
+                    s++;
+                }
+        }
+        if (ktail) {
+            const int nq = ktail >> 3;
+            const int k0 = nfull * 32 + h * 4 * nq;
+            for (int q = 0; q < nq; q++) {
+                const float4 a = dz4(*(const float4 *)(zr + k0 + 4 * q), ldg(k0 + 4 * q), k0 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float b[NTV];
+                    gg_ldb<NTV>(Wl, s * 64 + lane, b);
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
+                    s++;
+                }
+            }
+        }
+        const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        const long long base = (r0 + 4 * h) * ldx + (lane & 31);
+        float *xp = p.dX + base;
+        const float *ap = p.Aprev + base;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t * 32 + (lane & 31) < p.ndx) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (nrows == 32 || rr + 4 * h < nrows) {
+                        const int off = rr * ldx + t * 32;
+                        const float dx = acc[t][r];
+                        xp[off] = dx;
+                        if (prevbn) {
+                            const float zp = ap[off];
+                            const float d = (zp * ps[t] + psh[t] > 0.f) ? dx : 0.f;
+                            s1 += d;
+                            s2 += d * ((zp - pm[t]) * pr[t]);
+                        }
+                    }
+                }
+                a1[t] += s1;
+                a2[t] += s2;
+            }
+        }
+    }
+    if (!prevbn) return;
+    __syncthreads();
+    float *red = lds;                                  // [nw][2][NT*32]
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float s1 = a1[t] + __shfl_xor(a1[t], 32, 64);
+        const float s2 = a2[t] + __shfl_xor(a2[t], 32, 64);
+        if (lane < 32) {
+            red[(wave * 2 + 0) * NT * 32 + t * 32 + lane] = s1;
+            red[(wave * 2 + 1) * NT * 32 + t * 32 + lane] = s2;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * NT * 32; i += blockDim.x) {
+        const int which = i / (NT * 32), col = i - which * NT * 32;
+        if (col >= p.ndx) continue;
+        float v = 0.f;
+        for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
+        atomicAdd(&p.psums[which * p.cin + col], (double)v);
+    }
+}
+
+template <int NT>
+static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
+{
+    constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    const int threads = 512, nw = threads / 64;
+    size_t lds = ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
+    const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
+    if (lds < rbytes) lds = rbytes;
+    if (lds > 156 * 1024) return 1;
+    const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+    const long long ntile = (p.E + 31) >> 5;
+    long long nb = (ntile + nw - 1) / nw;
+    if (nb > 256 * per_cu) nb = 256 * per_cu;
+    gg_k_linear_dx_direct<NT><<<(int)nb, threads, lds, st>>>(p);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// requires C % 8 == 0, Wdx packed for ndx columns, psums (if any) indexed with stride cin
+int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
+{
+    if (!p.Wdx || !p.dX || p.ndx < 1 || p.ndx > 256 || p.ndx > p.cin || (p.C & 7) || p.C > 256) return 1;
+    if ((p.cin & 3) && false) return 1;
+    switch ((p.ndx + 31) / 32) {
+    case 1: return launch_dx_direct<1>(p, st);
+    case 2: return launch_dx_direct<2>(p, st);
+    case 3: return launch_dx_direct<3>(p, st);
+    case 4: return launch_dx_direct<4>(p, st);
+    case 5: return launch_dx_direct<5>(p, st);
+    case 6: return launch_dx_direct<6>(p, st);
+    case 7: return launch_dx_direct<7>(p, st);
+    default: return launch_dx_direct<8>(p, st);
+    }
+}

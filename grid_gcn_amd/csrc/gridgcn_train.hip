@@ -937,6 +937,12 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     const int ntm = (p.cin + 31) >> 5, ntn2 = (p.C + 31) >> 5;
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
+    // ---- register-direct dX (gridgcn_direct.hip) when the operand was packed for it ----
+    if (p.dX && p.Wdx && !getenv("GG_DX_LDS")) {
+        const int rc = gg_linear_dx_direct(p, st);
+        if (rc == 0) p.dX = nullptr;
+        else if (rc != 1) return rc;
+    }
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
     if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0 && !getenv("GG_BWD_MONO")) {
         static bool attr_dx = false;

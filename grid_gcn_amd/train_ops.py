@@ -32,6 +32,7 @@ import os  # noqa: E402
 
 # register-direct forward kernel (csrc/gridgcn_direct.hip) for inputs whose width is a multiple of 8
 DIRECT_FWD = os.environ.get("GG_FWD_LDS", "0") != "1"
+DIRECT_DX = os.environ.get("GG_DX_LDS", "0") != "1"
 
 
 def supported(layers, x):
@@ -77,7 +78,7 @@ class _Chain:
 
     def __init__(self):
         self.Z, self.scale, self.shift, self.mean, self.rstd = [], [], [], [], []
-        self.Wb, self.Wg = [], []
+        self.Wb, self.Wg, self.Wdx, self.ndx = [], [], [], []
 
 
 def packed_sizes(C, cin):
@@ -87,7 +88,7 @@ def packed_sizes(C, cin):
     return K, ldw, K * ldw, ((cin + 31) // 32) * ((C + 3) & ~3) * 32
 
 
-def _chain_forward(lib, x, params, bns, eps, rot=0):
+def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0):
     """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer.  Per layer three launches:
     pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping.
     x may be wider than the first layer's weight (zero padded columns) and hold the layer's first
@@ -108,15 +109,27 @@ def _chain_forward(lib, x, params, bns, eps, rot=0):
         K, ldw, nwp, nwb = packed_sizes(cout, cin)
         direct = DIRECT_FWD and cin % 8 == 0
         nwq = cin * ldw if direct else 0
-        pk = torch.empty(nwp + ldw + 2 * nwb + nwq, dtype=torch.float32, device=dev)
+        # input gradient: all columns of a hidden layer, the first ndx0 of the chain input
+        ndx = cin if l > 0 else ndx0
+        if not (DIRECT_DX and cout % 8 == 0 and 0 < ndx <= 256):
+            ndx = 0
+        nt = (ndx + 31) // 32
+        nwdx = cout * 32 * (1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8) if ndx else 0
+        pk = torch.empty(nwp + ldw + 2 * nwb + nwq + nwdx, dtype=torch.float32, device=dev)
         Wp, Bp = pk[:nwp], pk[nwp:nwp + ldw]
-        Wb, Wg = pk[nwp + ldw:nwp + ldw + nwb], pk[nwp + ldw + nwb:nwp + ldw + 2 * nwb]
-        Wq = pk[nwp + ldw + 2 * nwb:] if direct else None
+        o = nwp + ldw
+        Wb, Wg = pk[o:o + nwb], pk[o + nwb:o + 2 * nwb]
+        o += 2 * nwb
+        Wq = pk[o:o + nwq] if direct else None
+        Wdx = pk[o + nwq:] if ndx else None
         rc = lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), cout, cin_w,
-                                     rot if l == 0 else 0, cin, 0,
+                                     rot if l == 0 else 0, cin, ndx,
                                      None if direct else _ptr(Wp), _ptr(Bp), _ptr(Wb), _ptr(Wg),
-                                     _ptr(Wq) if direct else None, None, stream)
+                                     _ptr(Wq) if direct else None, _ptr(Wdx) if ndx else None,
+                                     stream)
         _lib.check(rc, "gridgcn_pack_linear")
+        st.Wdx.append(Wdx if ndx else Wb)
+        st.ndx.append(ndx)
         Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
         sums = allsums[so:so + 2 * cout]
         so += 2 * cout
@@ -147,8 +160,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0):
     return st
 
 
-def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums, dY, sparse, need_dx,
-                    cin_w0=None, rot=0):
+def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, ndxs, sums, dY, sparse,
+                    need_dx, cin_w0=None, rot=0):
     """backward through a chain.  `sums` [2*C_L] fp64 = BatchNorm-backward sums of the LAST layer;
     upstream gradient either dense dY [E,C_L] or sparse = (amax, gval, P).  Returns (dX, grads)
     with grads = [dW, db, dgamma, dbeta] * L.  cin_w0 / rot: width of the first layer's weight and
@@ -203,7 +216,8 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums, dY
             dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
             _ptr(m1), _ptr(m2), _ptr(prev),
             pn(scales[l - 1]), pn(shifts[l - 1]), pn(means[l - 1]), pn(rstds[l - 1]),
-            _ptr(Wb), _ptr(Wg) if Wg is not None else None, E, C, cin,
+            _ptr(Wb), _ptr(Wg) if Wg is not None else None,
+            _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin,
             _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
@@ -227,13 +241,16 @@ class _MLPTrain(torch.autograd.Function):
         x = x.contiguous()
         E = x.shape[0]
         with torch.cuda.device(x.device):
-            st = _chain_forward(lib, x, params, bns, eps)
+            st = _chain_forward(lib, x, params, bns, eps, 0,
+                                x.shape[1] if ctx.needs_input_grad[0] else 0)
             Y = torch.empty_like(st.Z[-1])
             rc = lib.gridgcn_bn_relu_apply(_ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]),
                                            _ptr(Y), E, Y.shape[1], _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_apply")
         ctx.L = L
-        ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg)
+        ctx.ndx = st.ndx
+        ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg,
+                              *st.Wdx)
         return Y
 
     @staticmethod
@@ -244,7 +261,7 @@ class _MLPTrain(torch.autograd.Function):
         x = t[0]
         Zs, scales, shifts = t[1:1 + L], t[1 + L:1 + 2 * L], t[1 + 2 * L:1 + 3 * L]
         means, rstds, Wbs = t[1 + 3 * L:1 + 4 * L], t[1 + 4 * L:1 + 5 * L], t[1 + 5 * L:1 + 6 * L]
-        Wgs = t[1 + 6 * L:1 + 7 * L]
+        Wgs, Wdxs = t[1 + 6 * L:1 + 7 * L], t[1 + 7 * L:1 + 8 * L]
         E, dev = x.shape[0], x.device
         dY = dY.contiguous()
         with torch.cuda.device(dev):
@@ -254,8 +271,8 @@ class _MLPTrain(torch.autograd.Function):
                                                 _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
                                                 E, C, _ptr(sums), _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
-            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, sums,
-                                        dY, None, ctx.needs_input_grad[0])
+            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
+                                        ctx.ndx, sums, dY, None, ctx.needs_input_grad[0])
         return (dX, None) + tuple(grads)
 
 
@@ -282,7 +299,10 @@ class _EdgeBlockTrain(torch.autograd.Function):
         nf, att_vec = nf.contiguous(), att_vec.contiguous()
         dev = nf.device
         with torch.cuda.device(dev):
-            sp = _chain_forward(lib, nf, params[:4 * Lp], bns_p, eps, rot)
+            # only the feature columns of nf (the leading ones) need a gradient
+            nfeat = params[0].shape[1] - rot
+            sp = _chain_forward(lib, nf, params[:4 * Lp], bns_p, eps, rot,
+                                nfeat if ctx.needs_input_grad[0] else 0)
             sa = _chain_forward(lib, att_vec, params[4 * Lp:], bns_a, eps)
             C = sp.Z[-1].shape[1]
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
@@ -292,10 +312,11 @@ class _EdgeBlockTrain(torch.autograd.Function):
                                          ncent, P, C, _ptr(agg), _ptr(amax), _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_fwd")
         ctx.dims = (Lp, La, ncent, P, rot, params[0].shape[1], params[4 * Lp].shape[1])
+        ctx.ndx = (sp.ndx, sa.ndx)
         ctx.save_for_backward(
             nf, att_vec, amax,
-            *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg,
-            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg)
+            *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
+            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
         ctx.mark_non_differentiable(amax)
         return agg
 
@@ -306,9 +327,9 @@ class _EdgeBlockTrain(torch.autograd.Function):
         t = ctx.saved_tensors
         nf, att_vec, amax = t[0], t[1], t[2]
         o = 3
-        pZ, pS, pH, pM, pR, pWb, pWg = (t[o + k * Lp:o + (k + 1) * Lp] for k in range(7))
-        o += 7 * Lp
-        aZ, aS, aH, aM, aR, aWb, aWg = (t[o + k * La:o + (k + 1) * La] for k in range(7))
+        pZ, pS, pH, pM, pR, pWb, pWg, pWx = (t[o + k * Lp:o + (k + 1) * Lp] for k in range(8))
+        o += 8 * Lp
+        aZ, aS, aH, aM, aR, aWb, aWg, aWx = (t[o + k * La:o + (k + 1) * La] for k in range(8))
         dev = nf.device
         dagg = dagg.contiguous()
         C = pZ[-1].shape[1]
@@ -323,10 +344,11 @@ class _EdgeBlockTrain(torch.autograd.Function):
                                          P, C, _ptr(gp), _ptr(ga), _ptr(sums_p), _ptr(sums_a),
                                          _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_bwd")
-            dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pWb, pWg, sums_p, None,
-                                           (amax, gp, P), ctx.needs_input_grad[0], cwp, rot)
-            _, grads_a = _chain_backward(lib, att_vec, aZ, aS, aH, aM, aR, aWb, aWg, sums_a, None,
-                                         (amax, ga, P), False, cwa, 0)
+            dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0],
+                                           sums_p, None, (amax, gp, P), ctx.needs_input_grad[0],
+                                           cwp, rot)
+            _, grads_a = _chain_backward(lib, att_vec, aZ, aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1],
+                                         sums_a, None, (amax, ga, P), False, cwa, 0)
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
@@ -346,6 +368,11 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
     gval = rnd(ncent, C)
     Wt = rnd(C, cin)
     Wb, Wg = pack_tiles(Wt), pack_groups(Wt)
+    ndx = min(cin, 256) if (DIRECT_DX and C % 8 == 0) else 0
+    Wdx = torch.empty(C * 32 * 8, device=device)
+    if ndx:
+        _lib.check(lib.gridgcn_pack_linear(_ptr(Wt), None, C, cin, 0, cin, ndx, None, None, None,
+                                           None, None, _ptr(Wdx), _stream(Wt)), "pack")
     dX = torch.empty(E, cin, device=device)
     dW = torch.empty(C, cin, device=device)
     nbytes = ctypes.c_size_t(0)
@@ -355,7 +382,8 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
     def call():
         rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                     _ptr(m1), _ptr(m2), _ptr(X), None, None, None, None, _ptr(Wb),
-                                    _ptr(Wg), E, C, cin, _ptr(dX), _ptr(dW), None, _ptr(amax),
+                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin,
+                                    _ptr(dX), _ptr(dW), None, _ptr(amax),
                                     _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))
         _lib.check(rc, "gridgcn_linear_bwd")

@@ -207,11 +207,14 @@ int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *byte
 int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, const float *shift,
                        const float *mean, const float *rstd, const float *m1, const float *m2,
                        const float *Aprev, const float *pscale, const float *pshift,
-                       const float *pmean, const float *prstd, const float *Wb, const float *Wg, long long E,
+                       const float *pmean, const float *prstd, const float *Wb, const float *Wg,
+                       const float *Wdx, int ndx, long long E,
                        int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
                        const float *gval, int P, void *workspace, size_t workspace_bytes,
                        void *stream);
-/* (amax != NULL: the upstream gradient is the sparse one of gridgcn_pairmax_bwd -- row e belongs to
+/* (Wdx != NULL: dX columns 0..ndx-1 only, by the register-direct schedule -- dZ is formed in
+ *  registers from 16-byte row reads, no LDS staging; needs C % 8 == 0, falls back otherwise.)
+ * (amax != NULL: the upstream gradient is the sparse one of gridgcn_pairmax_bwd -- row e belongs to
  *  centre e/P, neighbour e%P; dY[e,c] = (amax[e/P,c] == e%P) ? gval[e/P,c] : 0 -- and dY is ignored.)
  *
  * gridgcn_pairmax_fwd: agg[o,c] = max_p relu(Zp*scale_p+shift_p) * relu(Za*scale_a+shift_a) over the
