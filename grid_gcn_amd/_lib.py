@@ -86,8 +86,8 @@ def load():
     lib.gridgcn_linear_bwd_workspace_bytes.restype = ci
     lib.gridgcn_linear_bwd_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_bwd.restype = ci
-    lib.gridgcn_linear_bwd.argtypes = [vp] * 16 + [ci, ll, ci, ci, vp, vp, vp, vp, vp, ci, vp, cs,
-                                                   vp]
+    lib.gridgcn_linear_bwd.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci,
+                                                   vp, cs, vp]
     lib.gridgcn_pairmax_fwd.restype = ci
     lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, vp, vp]
     lib.gridgcn_pairmax_bwd.restype = ci

@@ -231,12 +231,13 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *Aprev, const float *pscale, const float *pshift,
                        const float *pmean, const float *prstd, const float *Wb, const float *Wg,
                        const float *Wdx, int ndx, long long E,
-                       int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
-                       const float *gval, int P, void *workspace, size_t workspace_bytes,
-                       void *stream)
+                       int C, int cin, int cin_w, int rot, float *dX, float *dW, double *psums,
+                       const int32_t *amax, const float *gval, int P, void *workspace,
+                       size_t workspace_bytes, void *stream)
 {
     if (amax && (!gval || P < 1 || E % P != 0)) return GRIDGCN_EINVAL;
     if (Wdx && (ndx < 1 || ndx > cin)) return GRIDGCN_EINVAL;
+    if (cin_w < 1 || cin_w > cin || rot < 0 || rot > cin_w) return GRIDGCN_EINVAL;
     if (!dY && amax) dY = Z;     // unused in sparse mode
     if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Aprev || !Wb || !dW)
         return GRIDGCN_EINVAL;
@@ -251,6 +252,7 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     p.psums = psums; p.E = E; p.C = C; p.cin = cin; p.ldd = 0; p.lda = 0;
     p.amax = amax; p.gval = gval; p.P = P > 0 ? P : 1;
     p.Wdx = Wdx; p.ndx = Wdx ? ndx : cin;
+    p.cin_w = cin_w; p.rot = rot;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }

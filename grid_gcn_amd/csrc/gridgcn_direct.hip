@@ -437,3 +437,270 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
     default: return launch_dx_direct<8>(p, st);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// dW[C, cin] = dZ^T[C, E] * act(Aprev)[E, cin]: the contraction runs over the ROWS, two per MFMA
+// step (lanes 0..31 row 2s, lanes 32..63 row 2s+1), so both operands are read row-wise and fully
+// coalesced straight into registers:
+//   A operand (dZ^T): lane c' holds MT channels  mg*32*MT + MT*c' + i        (one 4/8-byte load of
+//                     Z and of the upstream gradient; dZ formed with per-lane constants)
+//   B operand       : lane n' holds the columns of its units -- a "quad" is 128 columns read as
+//                     float4 (tile j <-> column 4n'+j), a "pair" 64 columns as float2, a "single"
+//                     up to 32 columns as float (tile <-> column n')
+// A wave owns MT x (4NQ + 2NP + NS) <= 10 accumulator tiles for a contiguous range of rows; the MG
+// m-groups of a workgroup walk the SAME rows (the B rows hit L1/L2), RS row streams fill the rest.
+// No LDS, no barriers; two register sets keep the next step's loads in flight.  Partials go to the
+// workspace as [wave][tile][reg][lane]; gg_k_dw_reduce_direct sums them into the framework layout.
+template <int MT, int NQ, int NP, int NS>
+__global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int MG, int RS,
+                                                                 long long rows_per_wg)
+{
+    constexpr int NJ = 4 * NQ + 2 * NP + NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cq = lane & 31, h = lane >> 5;
+    const int mg = wave % MG, rs = wave / MG;
+    const int C = p.C, cin = p.cin;
+    const bool prevbn = p.pscale != nullptr, sparse = p.amax != nullptr;
+
+    // row range of this wave
+    long long wa = (long long)blockIdx.x * rows_per_wg;
+    long long wb = wa + rows_per_wg < p.E ? wa + rows_per_wg : p.E;
+    long long per = ((wb - wa + RS - 1) / RS + 1) & ~1ll;
+    long long ra = wa + rs * per, rb = ra + per < wb ? ra + per : wb;
+    if (ra > rb) ra = rb;
+
+    // per-lane constants
+    const int chA = mg * 32 * MT + MT * cq;
+    float sc[MT], sh[MT], mu[MT], bz[MT], cz[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int c = chA + i;
+        const bool ok = c < C;
+        const float s = ok ? p.scale[c] : 0.f;
+        sc[i] = s; sh[i] = ok ? p.shift[c] : 0.f; mu[i] = ok ? p.mean[c] : 0.f;
+        bz[i] = ok ? -(s * p.rstd[c]) * p.m2[c] : 0.f;
+        cz[i] = ok ? -(s * p.m1[c]) : 0.f;
+    }
+    const bool chok = chA + MT - 1 < C;               // C % MT == 0: all or none of the MT channels
+    const int chl = chok ? chA : 0;
+    int col[NJ];
+    float psc[NJ], psh[NJ];
+    {
+        int j = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) col[j++] = q * 128 + 4 * cq + e;
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) col[j++] = NQ * 128 + 2 * cq + e;
+        if (NS) col[j++] = NQ * 128 + NP * 64 + cq;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const bool ok = prevbn && col[j] < cin;
+        psc[j] = ok ? p.pscale[col[j]] : 0.f;
+        psh[j] = ok ? p.pshift[col[j]] : 0.f;
+    }
+    const bool sok = NS ? (col[NJ - 1] < cin) : false;
+    const int scol = sok ? col[NJ - 1] : 0;
+
+    struct Regs {
+        float z[MT], g[MT], x[NJ];
+        int am[MT], pp;
+        bool ok;
+    };
+    long long cen = 0;
+    int pp = 0;
+    if (sparse) {
+        const long long r = ra + h;
+        cen = r / p.P;
+        pp = (int)(r - cen * p.P);
+    }
+    auto load = [&](Regs &R, long long s) {
+        const long long row = ra + 2 * s + h;
+        R.ok = row < rb;
+        const long long rw = R.ok ? row : (p.E - 1);
+        const float *zr = p.Z + rw * C + chl;
+        const float *gr;
+        if (sparse) {
+            const long long cc = R.ok ? cen : 0;
+            gr = p.gval + cc * C + chl;
+            const int *ar = p.amax + cc * C + chl;
+            if constexpr (MT == 2) { const int2 t = *(const int2 *)ar; R.am[0] = t.x; R.am[1] = t.y; }
+            else R.am[0] = ar[0];
+            R.pp = pp;
+            pp += 2;
+            while (pp >= p.P) { pp -= p.P; cen++; }
+        } else {
+            gr = p.dY + rw * C + chl;
+        }
+        if constexpr (MT == 2) {
+            const float2 t = *(const float2 *)zr, u = *(const float2 *)gr;
+            R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y;
+        } else {
+            R.z[0] = zr[0]; R.g[0] = gr[0];
+        }
+        const float *xr = p.Aprev + rw * cin;
+        int j = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const float4 t = *(const float4 *)(xr + q * 128 + 4 * cq);
+            R.x[j++] = t.x; R.x[j++] = t.y; R.x[j++] = t.z; R.x[j++] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const float2 t = *(const float2 *)(xr + NQ * 128 + 2 * cq);
+            R.x[j++] = t.x; R.x[j++] = t.y;
+        }
+        if (NS) R.x[j++] = xr[scol];
+    };
+
+    ggm_f32x16 acc[MT][NJ];
+#pragma unroll
+    for (int i = 0; i < MT; i++) ggm_zero<NJ>(acc[i]);
+
+    auto compute = [&](const Regs &R) {
+        float dz[MT], xa[NJ];
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            float g = R.g[i];
+            if (sparse) g = R.am[i] == R.pp ? g : 0.f;
+            const float d = sc[i] * ((R.z[i] * sc[i] + sh[i] > 0.f) ? g : 0.f) +
+                            ((R.z[i] - mu[i]) * bz[i] + cz[i]);
+            dz[i] = (R.ok && chok) ? d : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            float x = R.x[j];
+            if (prevbn) x = fmaxf(x * psc[j] + psh[j], 0.f);
+            if (NS && j == NJ - 1 && !sok) x = 0.f;
+            xa[j] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[i], xa[j], acc[i][j], 0, 0, 0);
+    };
+
+    const long long nsteps = (rb - ra + 1) >> 1;
+    Regs A, B;
+    if (nsteps > 0) load(A, 0);
+    for (long long s = 0; s < nsteps; s += 2) {
+        load(B, s + 1);          // past the end: ok = false, clamped addresses
+        compute(A);
+        load(A, s + 2);
+        if (s + 1 < nsteps) compute(B);
+    }
+
+    // partial: [wave_global][i*NJ + j][reg][lane]
+    const long long wg = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    float *out = p.dWpart + wg * (MT * NJ * 1024) + lane;
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) out[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
+}
+
+// dW[c][framework col] = sum over the waves of m-group mg(c) of their partial element.
+// thread = one partial element (tile, reg, lane) of one m-group; block = 64 elements x 4 wave slices.
+__global__ __launch_bounds__(256) void gg_k_dw_reduce_direct(const float *__restrict__ part,
+                                                             int nwaves, int MG, int MT, int NQ,
+                                                             int NP, int NS, int C, int cin,
+                                                             int cin_w, int rot,
+                                                             float *__restrict__ dW)
+{
+    __shared__ float sh[256];
+    const int NJ = 4 * NQ + 2 * NP + NS;
+    const int per = MT * NJ * 1024;
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;          // element of the partial
+    const int mg = blockIdx.y;
+    float s = 0.f;
+    if (e < per)
+        for (int w = mg + sl * MG; w < nwaves; w += 4 * MG) s += part[(size_t)w * per + e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (sl != 0 || e >= per) return;
+    s = sh[el] + sh[64 + el] + sh[128 + el] + sh[192 + el];
+    const int lane = e & 63, r = (e >> 6) & 15, tile = e >> 10;
+    const int i = tile / NJ, j = tile - i * NJ;
+    const int cq = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nq = lane & 31;
+    const int c = mg * 32 * MT + MT * cq + i;
+    int n;
+    if (j < 4 * NQ) n = (j >> 2) * 128 + 4 * nq + (j & 3);
+    else if (j < 4 * NQ + 2 * NP) n = NQ * 128 + 2 * nq + (j - 4 * NQ);
+    else n = NQ * 128 + NP * 64 + nq;
+    if (c >= C || n >= cin_w || n >= cin) return;
+    const int f = n < cin_w - rot ? n + rot : n - (cin_w - rot);
+    dW[(size_t)c * cin_w + f] = s;
+}
+
+struct GGDwCfg { int MT, NQ, NP, NS, MG, RS, threads, nwg; long long rows_per_wg; };
+
+static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
+{
+    if (cin > 320 || (cin & 3) || C > 256 || (C & 1)) return false;
+    int NQ = cin / 128, rem = cin - NQ * 128;
+    int NP = rem >= 64 ? 1 : 0;
+    rem -= NP * 64;
+    if (rem > 32) return false;   // 33..63 leftover columns: no unit reads them without overrun
+    int NS = rem > 0 ? 1 : 0;
+    const int NJ = 4 * NQ + 2 * NP + NS;
+    int MT = (C >= 64 && NJ <= 5) ? 2 : 1;
+    if (MT * NJ > 10 || NQ > 2) return false;
+    const int MG = (C + 32 * MT - 1) / (32 * MT);
+    if (MG > 8) return false;
+    const int RS = MG >= 4 ? 1 : 4 / MG;
+    c->MT = MT; c->NQ = NQ; c->NP = NP; c->NS = NS; c->MG = MG; c->RS = RS;
+    c->threads = 64 * MG * RS;
+    int nwg = 2048 / (MG * RS);                      // 2 waves per SIMD
+    long long maxwg = (E + 64LL * RS - 1) / (64LL * RS);
+    if (nwg > maxwg) nwg = (int)maxwg;
+    if (nwg < 1) nwg = 1;
+    long long rp = (E + nwg - 1) / nwg;
+    rp = (rp + 1) & ~1ll;
+    c->rows_per_wg = rp;
+    c->nwg = (int)((E + rp - 1) / rp);
+    return true;
+}
+
+size_t gg_linear_dw_direct_workspace(long long E, int cin, int C)
+{
+    GGDwCfg c;
+    if (!gg_dw_direct_cfg(E, C, cin, &c)) return 0;
+    return (size_t)c.nwg * (c.threads / 64) * c.MT * (4 * c.NQ + 2 * c.NP + c.NS) * 1024 * sizeof(float);
+}
+
+template <int MT, int NQ, int NP, int NS>
+static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
+{
+    gg_k_linear_dw_direct<MT, NQ, NP, NS><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// dW in the framework layout [C][cin_w] (columns rotated back by p.rot).  1 = unsupported.
+int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
+{
+    GGDwCfg c;
+    if (!gg_dw_direct_cfg(p.E, p.C, p.cin, &c)) return 1;
+    if (p.C % c.MT) return 1;
+    int rc = 1;
+#define GG_DWD(mt, nq, np, ns)                                                                   \
+    if (c.MT == mt && c.NQ == nq && c.NP == np && c.NS == ns) rc = launch_dw_direct<mt, nq, np, ns>(p, c, st);
+    GG_DWD(1, 0, 0, 1) GG_DWD(1, 0, 1, 0) GG_DWD(1, 0, 1, 1) GG_DWD(1, 1, 0, 0) GG_DWD(1, 1, 0, 1)
+    GG_DWD(1, 1, 1, 0) GG_DWD(1, 1, 1, 1) GG_DWD(1, 2, 0, 0) GG_DWD(1, 2, 0, 1) GG_DWD(1, 2, 1, 0)
+    GG_DWD(2, 0, 0, 1) GG_DWD(2, 0, 1, 0) GG_DWD(2, 0, 1, 1) GG_DWD(2, 1, 0, 0) GG_DWD(2, 1, 0, 1)
+#undef GG_DWD
+    if (rc) return rc;
+    const int NJ = 4 * c.NQ + 2 * c.NP + c.NS;
+    const int per = c.MT * NJ * 1024;
+    const int nwaves = c.nwg * (c.threads / 64);
+    gg_k_dw_reduce_direct<<<dim3((per + 63) / 64, c.MG), 256, 0, st>>>(
+        p.dWpart, nwaves, c.MG, c.MT, c.NQ, c.NP, c.NS, p.C, p.cin, p.cin_w, p.rot, p.dW);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -27,6 +27,8 @@ struct GGLinBwd {
                           // (nullptr: no split mode; dX comes from the monolithic kernel)
     const float *Wdx;     // register-direct dX operand (gridgcn_pack_linear), nullptr: LDS-staged dX
     int ndx;              // number of leading dX columns that are needed (<= cin, <= 256)
+    int cin_w, rot;       // dW is written as [C][cin_w] in the framework's column order: kernel
+                          // column k -> k + rot (k < cin_w - rot), k - (cin_w - rot) (k < cin_w)
     float *dX;            // [E][cin] gradient w.r.t. act(Aprev) (nullptr: not needed)
     float *dWpart;        // workspace [nwg][cinP][CP]
     float *dW;            // [C][cin]
@@ -45,6 +47,7 @@ int gg_linear_fwd(const GGLinFwd &p, hipStream_t st);
 int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st);   // gridgcn_direct.hip
 int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st);    // 1 = shape not supported
 int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st);
+size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shape not supported
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,

@@ -885,8 +885,8 @@ __global__ __launch_bounds__(256) void gg_k_linear_dx(GGLinBwd p)
 // dW[c][i] = sum_wg part[wg][i][c]   (part: [nwg][cinP][CP]; dW: torch layout [C][cin])
 // block = 64 elements x 4 slices of the workgroup range
 __global__ __launch_bounds__(256) void gg_k_dw_reduce(const float *__restrict__ part, int nwg,
-                                                      int cinP, int CP, int cin, int C,
-                                                      float *__restrict__ dW)
+                                                      int cinP, int CP, int cin, int C, int cin_w,
+                                                      int rot, float *__restrict__ dW)
 {
     __shared__ float sh[256];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -900,7 +900,11 @@ __global__ __launch_bounds__(256) void gg_k_dw_reduce(const float *__restrict__ 
     if (sl == 0 && e < (int)S) {
         s = sh[el] + sh[64 + el] + sh[128 + el] + sh[192 + el];
         const int i = e / CP, c = e - i * CP;
-        if (i < cin && c < C) dW[(size_t)c * cin + i] = s;
+        // framework layout [C][cin_w]: zero-padding columns dropped, rotated columns moved back
+        if (i < cin && i < cin_w && c < C) {
+            const int f = i < cin_w - rot ? i + rot : i - (cin_w - rot);
+            dW[(size_t)c * cin_w + f] = s;
+        }
     }
 }
 
@@ -911,7 +915,11 @@ int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg
     int n = (int)(ntile < 1024 ? ntile : 1024);
     const int cinP = ((cin + 31) >> 5) * 32, CP = ((C + 31) >> 5) * 32;
     if (nwg) *nwg = n;
-    if (bytes) *bytes = (size_t)n * cinP * CP * sizeof(float);
+    if (bytes) {
+        *bytes = (size_t)n * cinP * CP * sizeof(float);
+        const size_t d = gg_linear_dw_direct_workspace(E, cin, C);
+        if (d > *bytes) *bytes = d;
+    }
     return 0;
 }
 
@@ -962,6 +970,11 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
             if (hipGetLastError() != hipSuccess) return 3;
             p.dX = nullptr;                      // the kernel below only accumulates dW now
         }
+    }
+    // ---- register-direct dW (gridgcn_direct.hip) once dX is out of the way ----
+    if (!p.dX && !getenv("GG_DW_LDS")) {
+        const int rc = gg_linear_dw_direct(p, st);
+        if (rc != 1) return rc;
     }
     const int npairs = ntm * ntn2;
     if (npairs > 48) return 1;
@@ -1044,7 +1057,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
             if (hipGetLastError() != hipSuccess) return 3;
             const int cinP2 = ntm * 32, CP2 = ntn2 * 32;
             gg_k_dw_reduce<<<(cinP2 * CP2 + 63) / 64, 256, 0, st>>>(p.dWpart, nw2, cinP2, CP2, p.cin,
-                                                                    p.C, p.dW);
+                                                                    p.C, p.cin_w, p.rot, p.dW);
             return hipGetLastError() == hipSuccess ? 0 : 3;
         }
     }
@@ -1057,7 +1070,8 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     else rc = launch_bwd<12>(p, wlds, lds, nwg, st);
     if (rc) return rc;
     const int cinP = ntm * 32, CP = ntn2 * 32;
-    gg_k_dw_reduce<<<(cinP * CP + 63) / 64, 256, 0, st>>>(p.dWpart, nwg, cinP, CP, p.cin, p.C, p.dW);
+    gg_k_dw_reduce<<<(cinP * CP + 63) / 64, 256, 0, st>>>(p.dWpart, nwg, cinP, CP, p.cin, p.C,
+                                                          p.cin_w, p.rot, p.dW);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

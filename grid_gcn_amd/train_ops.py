@@ -197,7 +197,9 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         if l > 0:
             psums = zps[po:po + 2 * cin]
             po += 2 * cin
-        dW = torch.empty((C, cin), dtype=torch.float32, device=dev)
+        # written in the framework layout (padding dropped, rotated columns moved back)
+        cw, rt = (cin_w0, rot) if l == 0 else (cin, 0)
+        dW = torch.empty((C, cw), dtype=torch.float32, device=dev)
         Wb = Wbs[l]
         Wg = Wgs[l] if want_dx else None
         nbytes = ctypes.c_size_t(0)
@@ -217,15 +219,11 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
             _ptr(m1), _ptr(m2), _ptr(prev),
             pn(scales[l - 1]), pn(shifts[l - 1]), pn(means[l - 1]), pn(rstds[l - 1]),
             _ptr(Wb), _ptr(Wg) if Wg is not None else None,
-            _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin,
+            _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin, cw, rt,
             _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
         _lib.check(rc, "gridgcn_linear_bwd")
-        if l == 0 and (cin != cin_w0 or rot):
-            # back to the framework's column order / width
-            dW = torch.cat([dW[:, cin_w0 - rot:cin_w0], dW[:, :cin_w0 - rot]], dim=1) if rot \
-                else dW[:, :cin_w0].contiguous()
         grads[4 * l] = dW
         dY, sums, sparse = dX, psums, None
     return dY, grads
@@ -382,7 +380,7 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
     def call():
         rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                     _ptr(m1), _ptr(m2), _ptr(X), None, None, None, None, _ptr(Wb),
-                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin,
+                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin, cin, 0,
                                     _ptr(dX), _ptr(dW), None, _ptr(amax),
                                     _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))

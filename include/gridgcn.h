@@ -209,9 +209,12 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *Aprev, const float *pscale, const float *pshift,
                        const float *pmean, const float *prstd, const float *Wb, const float *Wg,
                        const float *Wdx, int ndx, long long E,
-                       int C, int cin, float *dX, float *dW, double *psums, const int32_t *amax,
-                       const float *gval, int P, void *workspace, size_t workspace_bytes,
-                       void *stream);
+                       int C, int cin, int cin_w, int rot, float *dX, float *dW, double *psums,
+                       const int32_t *amax, const float *gval, int P, void *workspace,
+                       size_t workspace_bytes, void *stream);
+/* (cin = row length of Aprev / dX as the kernels see it; dW is written in the FRAMEWORK layout
+ *  [C][cin_w]: zero-padding columns dropped and the `rot` columns moved back in front, the inverse
+ *  of gridgcn_pack_linear's mapping.  cin_w = cin, rot = 0 for an ordinary layer.) */
 /* (Wdx != NULL: dX columns 0..ndx-1 only, by the register-direct schedule -- dZ is formed in
  *  registers from 16-byte row reads, no LDS staging; needs C % 8 == 0, falls back otherwise.)
  * (amax != NULL: the upstream gradient is the sparse one of gridgcn_pairmax_bwd -- row e belongs to
