@@ -17,6 +17,7 @@ EXPORTS = [
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
     "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
+    "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
@@ -111,6 +112,12 @@ def load():
     lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_bwd_finalize.restype = ci
     lib.gridgcn_bn_bwd_finalize.argtypes = [vp, ll, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_softmax_ce_fwd.restype = ci
+    lib.gridgcn_softmax_ce_fwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp]
+    lib.gridgcn_softmax_ce_bwd.restype = ci
+    lib.gridgcn_softmax_ce_bwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_colsum.restype = ci
+    lib.gridgcn_colsum.argtypes = [vp, ll, ci, ci, vp, vp]
     lib.gridgcn_edge_inputs.restype = ci
     lib.gridgcn_edge_inputs.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]
     lib.gridgcn_edge_inputs_backward.restype = ci

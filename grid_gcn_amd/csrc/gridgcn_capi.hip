@@ -27,6 +27,11 @@ int gg_edge_inputs(const float *, const int *, const float *, int, int, int, int
 
 int gg_edge_inputs_rows(const float *, const int *, const float *, int, int, int, int, int, int, int,
                         int, int, float *, float *, hipStream_t);
+int gg_ce_fwd(const float *, int, int, const long long *, long long, int, float *, double *,
+              hipStream_t);
+int gg_ce_bwd(const float *, int, int, const long long *, long long, int, const float *,
+              const double *, const float *, float *, hipStream_t);
+int gg_colsum(const float *, long long, int, int, double *, hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, long long, int, int, float *, int *, hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
@@ -374,6 +379,32 @@ int gridgcn_edge_inputs_backward(const float *grad_nf, const int32_t *nebidx, in
     // only the feature columns carry gradient: xyz/w come from the non-differentiable index ops
     return gg_batch_take_backward(grad_nf + fo, nebidx, B, Nsrc, Cs - 4, O * P, grad_src + 4, cin,
                                   Cs, (hipStream_t)stream);
+}
+
+int gridgcn_softmax_ce_fwd(const float *logits, int ld, int ncls, const int64_t *label, long long E,
+                           int ignore_label, float *lse, double *acc, void *stream)
+{
+    if (!logits || !label || !lse || !acc) return GRIDGCN_EINVAL;
+    int rc = gg_ce_fwd(logits, ld, ncls, (const long long *)label, E, ignore_label, lse, acc,
+                       (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t *label, long long E,
+                           int ignore_label, const float *lse, const double *acc,
+                           const float *grad_loss, float *dlogits, void *stream)
+{
+    if (!logits || !label || !lse || !acc || !grad_loss || !dlogits) return GRIDGCN_EINVAL;
+    int rc = gg_ce_bwd(logits, ld, ncls, (const long long *)label, E, ignore_label, lse, acc,
+                       grad_loss, dlogits, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream)
+{
+    if (!X || !out) return GRIDGCN_EINVAL;
+    int rc = gg_colsum(X, E, ld, ncols, out, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
 int gridgcn_edge_inputs_rows(const float *src, const int32_t *nebidx, const float *cent,

@@ -607,26 +607,35 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
 }
 
 // dW[c][framework col] = sum over the waves of m-group mg(c) of their partial element.
-// thread = one partial element (tile, reg, lane) of one m-group; block = 64 elements x 4 wave slices.
-__global__ __launch_bounds__(256) void gg_k_dw_reduce_direct(const float *__restrict__ part,
-                                                             int nwaves, int MG, int MT, int NQ,
-                                                             int NP, int NS, int C, int cin,
-                                                             int cin_w, int rot,
-                                                             float *__restrict__ dW)
+// thread = one partial element (tile, reg, lane) of one m-group; block = 64 elements x 16 wave
+// slices (the partials are a few tens of MB: enough loads in flight to stream them at HBM speed).
+__global__ __launch_bounds__(1024) void gg_k_dw_reduce_direct(const float *__restrict__ part,
+                                                              int nwaves, int MG, int MT, int NQ,
+                                                              int NP, int NS, int C, int cin,
+                                                              int cin_w, int rot,
+                                                              float *__restrict__ dW)
 {
-    __shared__ float sh[256];
+    __shared__ float sh[1024];
     const int NJ = 4 * NQ + 2 * NP + NS;
     const int per = MT * NJ * 1024;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;          // element of the partial
     const int mg = blockIdx.y;
-    float s = 0.f;
-    if (e < per)
-        for (int w = mg + sl * MG; w < nwaves; w += 4 * MG) s += part[(size_t)w * per + e];
-    sh[threadIdx.x] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < per) {
+        int w = mg + sl * MG;
+        for (; w + 16 * MG < nwaves; w += 32 * MG) {
+            s0 += part[(size_t)w * per + e];
+            s1 += part[(size_t)(w + 16 * MG) * per + e];
+        }
+        if (w < nwaves) s0 += part[(size_t)w * per + e];
+    }
+    sh[threadIdx.x] = s0 + s1;
     __syncthreads();
     if (sl != 0 || e >= per) return;
-    s = sh[el] + sh[64 + el] + sh[128 + el] + sh[192 + el];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += sh[k * 64 + el];
     const int lane = e & 63, r = (e >> 6) & 15, tile = e >> 10;
     const int i = tile / NJ, j = tile - i * NJ;
     const int cq = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nq = lane & 31;
@@ -658,7 +667,9 @@ static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
     const int RS = MG >= 4 ? 1 : 4 / MG;
     c->MT = MT; c->NQ = NQ; c->NP = NP; c->NS = NS; c->MG = MG; c->RS = RS;
     c->threads = 64 * MG * RS;
-    int nwg = 2048 / (MG * RS);                      // 2 waves per SIMD
+    // waves per SIMD the register footprint allows (small tiles are latency bound: more waves)
+    const int wps = MT * NJ <= 2 ? 4 : (MT * NJ <= 5 ? 3 : 2);
+    int nwg = 1024 * wps / (MG * RS);
     long long maxwg = (E + 64LL * RS - 1) / (64LL * RS);
     if (nwg > maxwg) nwg = (int)maxwg;
     if (nwg < 1) nwg = 1;
@@ -700,7 +711,7 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
     const int NJ = 4 * c.NQ + 2 * c.NP + c.NS;
     const int per = c.MT * NJ * 1024;
     const int nwaves = c.nwg * (c.threads / 64);
-    gg_k_dw_reduce_direct<<<dim3((per + 63) / 64, c.MG), 256, 0, st>>>(
+    gg_k_dw_reduce_direct<<<dim3((per + 63) / 64, c.MG), 1024, 0, st>>>(
         p.dWpart, nwaves, c.MG, c.MT, c.NQ, c.NP, c.NS, p.C, p.cin, p.cin_w, p.rot, p.dW);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

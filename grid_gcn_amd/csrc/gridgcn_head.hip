@@ -1,0 +1,164 @@
+// gridgcn_head.hip -- segmentation head loss (gfx950).
+//
+// Reference: SoftmaxOutput(use_ignore=True, ignore_label=0, normalization='valid')
+// (segmentation/models/ggcn_models_g.py:41) on the [B*N, num_classes] logits of get_seg_head
+// (:30-43): softmax, cross-entropy averaged over the points whose label is not the ignore label.
+// The stock framework path costs a log-softmax pass, an NLL reduction done by one thread block and
+// their two backward passes over a [655360, 21] tensor (0.5-0.8 ms each on MI355X); here one thread
+// owns a row (<= 32 classes, read as 16-byte pieces of a zero-padded row of `ld` floats):
+//   gg_k_ce_fwd   lse[row], sum of -log p[label] and the number of counted rows (fp64 atomics)
+//   gg_k_ce_bwd   dlogits[row, c] = (softmax - onehot) * g / count, zeros in ignored rows and in the
+//                 padding columns (so the padded tensor feeds the MFMA backward kernels as is)
+//   gg_k_colsum   column sums of a [E, ld] tensor (bias gradient of the last linear layer)
+#include <hip/hip_runtime.h>
+
+template <int NV>
+__device__ __forceinline__ void gg_row_load(const float *__restrict__ p, float (&v)[4 * NV])
+{
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        const float4 t = ((const float4 *)p)[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ logits, int ncls,
+                                                   const long long *__restrict__ label,
+                                                   long long E, int ignore,
+                                                   float *__restrict__ lse_out,
+                                                   double *__restrict__ acc)
+{
+    __shared__ float red[2][4];
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    float loss = 0.f, cnt = 0.f;
+    if (row < E) {
+        float v[4 * NV];
+        gg_row_load<NV>(logits + row * (4 * NV), v);
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < 4 * NV; c++) if (c < ncls) m = fmaxf(m, v[c]);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4 * NV; c++) if (c < ncls) s += expf(v[c] - m);
+        const float lse = m + logf(s);
+        lse_out[row] = lse;
+        const long long lab = label[row];
+        if (lab != ignore && lab >= 0 && lab < ncls) {
+            float xl = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4 * NV; c++) xl = (c == (int)lab) ? v[c] : xl;
+            loss = lse - xl;
+            cnt = 1.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        loss += __shfl_xor(loss, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = loss; red[1][wave] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], (double)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
+        atomicAdd(&acc[1], (double)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void gg_k_ce_bwd(const float *__restrict__ logits, int ncls,
+                                                   const long long *__restrict__ label,
+                                                   long long E, int ignore,
+                                                   const float *__restrict__ lse,
+                                                   const double *__restrict__ acc,
+                                                   const float *__restrict__ gout,
+                                                   float *__restrict__ dlogits)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= E) return;
+    const float coef = (float)((double)gout[0] / acc[1]);
+    float v[4 * NV], d[4 * NV];
+    gg_row_load<NV>(logits + row * (4 * NV), v);
+    const long long lab = label[row];
+    const bool valid = lab != ignore && lab >= 0 && lab < ncls;
+    const float l = lse[row];
+#pragma unroll
+    for (int c = 0; c < 4 * NV; c++) {
+        float g = 0.f;
+        if (valid && c < ncls) g = (expf(v[c] - l) - ((c == (int)lab) ? 1.f : 0.f)) * coef;
+        d[c] = g;
+    }
+#pragma unroll
+    for (int q = 0; q < NV; q++)
+        ((float4 *)(dlogits + row * (4 * NV)))[q] =
+            make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, long long E,
+                                                   int ncols, double *__restrict__ out)
+{
+    __shared__ float red[4][4 * NV];
+    float a[4 * NV];
+#pragma unroll
+    for (int c = 0; c < 4 * NV; c++) a[c] = 0.f;
+    for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < E;
+         row += (long long)gridDim.x * 256) {
+        float v[4 * NV];
+        gg_row_load<NV>(X + row * (4 * NV), v);
+#pragma unroll
+        for (int c = 0; c < 4 * NV; c++) a[c] += v[c];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4 * NV; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[c] += __shfl_xor(a[c], o, 64);
+        if (lane == 0) red[wave][c] = a[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < ncols)
+        atomicAdd(&out[threadIdx.x], (double)((red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                              (red[2][threadIdx.x] + red[3][threadIdx.x])));
+}
+
+// logits rows of ld floats (ld in {4,8,...,32}), ncls <= ld
+int gg_ce_fwd(const float *logits, int ld, int ncls, const long long *label, long long E, int ignore,
+              float *lse, double *acc, hipStream_t st)
+{
+    if (ld < 4 || ld > 32 || (ld & 3) || ncls < 1 || ncls > ld || E < 1) return 1;
+    const int grid = (int)((E + 255) / 256);
+    switch (ld / 4) {
+#define GG_CASE(n) case n: gg_k_ce_fwd<n><<<grid, 256, 0, st>>>(logits, ncls, label, E, ignore, lse, acc); break;
+    GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
+#undef GG_CASE
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_ce_bwd(const float *logits, int ld, int ncls, const long long *label, long long E, int ignore,
+              const float *lse, const double *acc, const float *gout, float *dlogits, hipStream_t st)
+{
+    if (ld < 4 || ld > 32 || (ld & 3) || ncls < 1 || ncls > ld || E < 1) return 1;
+    const int grid = (int)((E + 255) / 256);
+    switch (ld / 4) {
+#define GG_CASE(n) case n: gg_k_ce_bwd<n><<<grid, 256, 0, st>>>(logits, ncls, label, E, ignore, lse, acc, gout, dlogits); break;
+    GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
+#undef GG_CASE
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_colsum(const float *X, long long E, int ld, int ncols, double *out, hipStream_t st)
+{
+    if (ld < 4 || ld > 32 || (ld & 3) || ncols < 1 || ncols > ld || E < 1) return 1;
+    long long nb = (E + 1023) / 1024;
+    const int grid = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    switch (ld / 4) {
+#define GG_CASE(n) case n: gg_k_colsum<n><<<grid, 256, 0, st>>>(X, E, ncols, out); break;
+    GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
+#undef GG_CASE
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

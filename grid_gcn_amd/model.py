@@ -5,12 +5,17 @@ data_layer = concat(cent, feats), up path BallKNN | GridifyUp -> gather -> sub_g
 
 Shape contract = segmentation/configs/configs.yaml:71-111 (8192-pt) and :144-189 (81920-pt).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, synth
 from .gridconv import ConvBNReLU, SubGUpdate, run_mlp
+
+# last linear layer + softmax cross-entropy on the hand-written kernels (GPU, float32)
+HEAD_KERNELS = os.environ.get("GG_HEAD_TORCH", "0") != "1"
 
 SEG_8192 = dict(
     grid=synth.SEG_SCANNET_8192, inputDim=[0, 64, 128], pt_ele_dim=[[32, 32, 64], [64, 64, 128],
@@ -120,11 +125,18 @@ class GGCNSeg(nn.Module):
             f_last = torch.cat([upl, cf], dim=2)                                    # :231
         net = run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
+        if HEAD_KERNELS and self.training and torch.is_grad_enabled() and self.ix is HipIndexOps:
+            from . import train_ops
+            if train_ops.linear_plain_supported(net, self.fc2):
+                return train_ops.linear_plain_train(net, self.fc2)
         return self.fc2(net)
 
 
 def seg_loss(logits, label):
     """SoftmaxOutput(use_ignore=True, ignore_label=0, normalization='valid')
     (segmentation/models/ggcn_models_g.py:41): mean cross-entropy over labels != 0."""
-    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), label.reshape(-1).long(),
-                           ignore_index=0, reduction="mean")
+    lg, lb = logits.reshape(-1, logits.shape[-1]), label.reshape(-1).long()
+    if lg.is_cuda and lg.dtype == torch.float32 and lg.shape[1] <= 32 and HEAD_KERNELS:
+        from . import train_ops
+        return train_ops.softmax_ce(lg, lb, 0)       # csrc/gridgcn_head.hip
+    return F.cross_entropy(lg, lb, ignore_index=0, reduction="mean")

@@ -417,3 +417,149 @@ def edge_block_train(nf, att_vec, pt_layers, att_layers, rot=0):
     agg = _EdgeBlockTrain.apply(nf.reshape(-1, cin), att_vec.reshape(-1, att_vec.shape[-1]), meta,
                                 *params)
     return agg.reshape(B, O, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# segmentation head: the last linear layer (no BatchNorm / ReLU) and the softmax cross-entropy.
+# The class dimension is zero padded to a multiple of 8 inside (logits live in an [E, Cp] buffer and
+# the op returns its [:, :C] view), so that the same register-direct MFMA kernels run the layer with
+# "identity BatchNorm" constants: scale 1, shift +inf (ReLU mask always open), mean 0, m1 = m2 = 0.
+_IDENT = {}
+
+
+def _identity_consts(Cp, dev):
+    key = (Cp, str(dev))
+    if key not in _IDENT:
+        v = torch.zeros((6, Cp), dtype=torch.float32, device=dev)
+        v[0] = 1.0             # scale
+        v[1] = float("inf")    # shift
+        v[3] = 1.0             # rstd      (v[2] mean, v[4] m1, v[5] m2 stay 0)
+        _IDENT[key] = v
+    return _IDENT[key]
+
+
+def linear_plain_supported(x, lin):
+    return (x.is_cuda and x.dtype == torch.float32 and DIRECT_FWD and DIRECT_DX
+            and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and lin.out_features <= 32
+            and lin.bias is not None)
+
+
+class _LinearPlain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        lib = _lib.load()
+        x = x.contiguous()
+        E, cin = x.shape
+        C = W.shape[0]
+        Cp = (C + 7) & ~7
+        dev = x.device
+        ndx = cin if ctx.needs_input_grad[0] else 0
+        nt = (ndx + 31) // 32
+        ntv = 1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8
+        K, ldw, nwp, nwb = packed_sizes(C, cin)
+        pk = torch.empty(ldw + nwb + cin * ldw + Cp * 32 * ntv, dtype=torch.float32, device=dev)
+        Bp, Wb, Wq = pk[:ldw], pk[ldw:ldw + nwb], pk[ldw + nwb:ldw + nwb + cin * ldw]
+        Wdx = pk[ldw + nwb + cin * ldw:]
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            _lib.check(lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), C,
+                                               cin, 0, cin, ndx, None, _ptr(Bp), _ptr(Wb), None,
+                                               _ptr(Wq), _ptr(Wdx) if ndx else None, st), "pack")
+            Z = torch.empty((E, Cp), dtype=torch.float32, device=dev)
+            scratch = torch.zeros(2 * Cp, dtype=torch.float64, device=dev)
+            _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(x), E, cin, _ptr(Wq), _ptr(Bp), ldw, Cp,
+                                                     None, None, _ptr(Z), _ptr(scratch), st),
+                       "gridgcn_linear_fwd_direct")
+        ctx.save_for_backward(x, Z, Wb, Wdx)
+        ctx.dims = (C, Cp, ndx)
+        return Z[:, :C]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, Z, Wb, Wdx = ctx.saved_tensors
+        C, Cp, ndx = ctx.dims
+        E, cin = x.shape
+        dev = x.device
+        # the loss op (softmax_ce below) hands back the [:, :C] view of a zero-padded [E, Cp] buffer
+        if g.stride() == (Cp, 1) and g.storage_offset() == 0 and \
+                g.untyped_storage().nbytes() == E * Cp * 4:
+            dL = g.as_strided((E, Cp), (Cp, 1))
+        else:
+            dL = torch.zeros((E, Cp), dtype=torch.float32, device=dev)
+            dL[:, :C] = g
+        ident = _identity_consts(Cp, dev)
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            dX = torch.empty((E, cin), dtype=torch.float32, device=dev) if ndx else None
+            dW = torch.empty((Cp, cin), dtype=torch.float32, device=dev)
+            nbytes = ctypes.c_size_t(0)
+            lib.gridgcn_linear_bwd_workspace_bytes(E, cin, Cp, ctypes.byref(nbytes))
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            rc = lib.gridgcn_linear_bwd(
+                _ptr(dL), _ptr(Z), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
+                _ptr(ident[4]), _ptr(ident[5]), _ptr(x), None, None, None, None, _ptr(Wb), None,
+                _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0,
+                _ptr(dX) if ndx else None, _ptr(dW), None, None, None, 0, _ptr(ws), nbytes.value, st)
+            _lib.check(rc, "gridgcn_linear_bwd")
+            db64 = torch.zeros(Cp, dtype=torch.float64, device=dev)
+            _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C, _ptr(db64), st), "gridgcn_colsum")
+        return dX, dW[:C], db64[:C].float()
+
+
+def linear_plain_train(x, lin):
+    """x [..., cin] -> [..., C] = x W^T + b of a torch.nn.Linear with C <= 32 (the class scores)."""
+    shp = x.shape
+    y = _LinearPlain.apply(x.reshape(-1, shp[-1]), lin.weight, lin.bias)
+    return y.reshape(shp[:-1] + (y.shape[-1],))
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, label, ignore):
+        lib = _lib.load()
+        E, C = logits.shape
+        dev = logits.device
+        ld = logits.stride(0)
+        if not (logits.stride(1) == 1 and ld % 4 == 0 and C <= ld <= 32
+                and logits.storage_offset() == 0 and (ld == C or _pad_is_zero(logits, ld))):
+            ld = (C + 7) & ~7
+            buf = torch.zeros((E, ld), dtype=torch.float32, device=dev)
+            buf[:, :C] = logits
+            logits = buf[:, :C]
+        label = label.contiguous()
+        lse = torch.empty(E, dtype=torch.float32, device=dev)
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gridgcn_softmax_ce_fwd(_ptr(logits), ld, C, _ptr(label), E, ignore,
+                                                  _ptr(lse), _ptr(acc), _stream(logits)),
+                       "gridgcn_softmax_ce_fwd")
+        ctx.save_for_backward(logits, label, lse, acc)
+        ctx.meta = (ld, ignore)
+        return (acc[0] / acc[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        logits, label, lse, acc = ctx.saved_tensors
+        ld, ignore = ctx.meta
+        E, C = logits.shape
+        dev = logits.device
+        d = torch.empty((E, ld), dtype=torch.float32, device=dev)
+        g = g.contiguous().float()
+        with torch.cuda.device(dev):
+            _lib.check(lib.gridgcn_softmax_ce_bwd(_ptr(logits), ld, C, _ptr(label), E, ignore,
+                                                  _ptr(lse), _ptr(acc), _ptr(g), _ptr(d),
+                                                  _stream(logits)), "gridgcn_softmax_ce_bwd")
+        return d[:, :C], None, None
+
+
+def _pad_is_zero(logits, ld):
+    # a [:, :C] view of an [E, ld] buffer produced by _LinearPlain: padding columns are exact zeros
+    return logits.untyped_storage().nbytes() == logits.shape[0] * ld * 4
+
+
+def softmax_ce(logits, label, ignore_index):
+    """mean over label != ignore_index of -log softmax(logits)[label]; logits [E, C <= 32] f32 on
+    the GPU, label [E] int64 (torch.nn.functional.cross_entropy(..., ignore_index, 'mean'))."""
+    return _SoftmaxCE.apply(logits, label.long(), int(ignore_index))

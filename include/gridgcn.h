@@ -244,6 +244,21 @@ int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scal
                               const float *m1, const float *m2, long long E, int C, float *dZ,
                               void *stream);
 
+/* ---- segmentation head loss: SoftmaxOutput(use_ignore, ignore_label, normalization='valid')
+ *      (segmentation/models/ggcn_models_g.py:41) ------------------------------------------------
+ * logits[E][ld] f32 rows zero-padded to ld floats (ld a multiple of 4, <= 32; ncls <= ld classes),
+ * label[E] i64.  fwd: lse[E] = log-sum-exp per row; acc[0] += sum over counted rows of
+ * -log softmax[label], acc[1] += number of counted rows (label != ignore_label; acc zeroed by the
+ * caller; loss = acc[0]/acc[1]).  bwd: dlogits[E][ld] = (softmax - onehot) * grad_loss[0] / acc[1]
+ * in counted rows, 0 elsewhere and in the padding columns.
+ * gridgcn_colsum: out[c] += sum_e X[e][c], c < ncols (X rows of ld floats as above). */
+int gridgcn_softmax_ce_fwd(const float *logits, int ld, int ncls, const int64_t *label, long long E,
+                           int ignore_label, float *lse, double *acc, void *stream);
+int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t *label, long long E,
+                           int ignore_label, const float *lse, const double *acc,
+                           const float *grad_loss, float *dlogits, void *stream);
+int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream);
+
 /* ---- GridConv edge pipeline (inference-mode BatchNorm) ----------------------------------------
  * Replaces, for one sub_g_update call (segmentation/models/gcn_module_g_att.py:172-287, aggtype
  * 'gcn', attfdim 10, pool max), the operators between the index op and update_func:

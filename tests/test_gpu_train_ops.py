@@ -166,6 +166,66 @@ def test_pack_linear_layouts(C, cin):
             assert torch.equal(o, r)
 
 
+@pytest.mark.parametrize("E,C", [(1000, 21), (70001, 21), (257, 8), (5000, 32), (300, 3)])
+def test_softmax_ce_matches_torch(E, C):
+    """gridgcn_softmax_ce_fwd/bwd == F.cross_entropy(ignore_index=0, reduction='mean')
+    (SoftmaxOutput use_ignore / normalization='valid', ggcn_models_g.py:41)."""
+    import torch.nn.functional as F
+    torch.manual_seed(E + C)
+    x1 = (torch.randn(E, C, device=DEV) * 3).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    lab = torch.randint(0, C, (E,), device=DEV)
+    l1 = F.cross_entropy(x1, lab, ignore_index=0, reduction="mean")
+    l2 = train_ops.softmax_ce(x2, lab, 0)
+    assert abs(float(l1) - float(l2)) <= 2e-6 * max(1.0, abs(float(l1)))
+    (l1 * 1.7).backward()
+    (l2 * 1.7).backward()
+    assert float((x1.grad - x2.grad).abs().max()) <= 1e-6 * float(x1.grad.abs().max()) + 1e-12
+    assert float(x2.grad[lab == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("E,cin,C", [(4000, 128, 21), (70001, 128, 21), (333, 64, 13), (900, 256, 32)])
+def test_linear_plain_and_loss_match_torch(E, cin, C):
+    """the segmentation head: Linear(cin, C) on the MFMA kernels (class dim zero padded inside) +
+    the fused loss, against torch.nn.Linear + F.cross_entropy: logits, loss, dX, dW, db."""
+    import torch.nn.functional as F
+    torch.manual_seed(E + cin + C)
+    lin1 = torch.nn.Linear(cin, C).to(DEV)
+    lin2 = copy.deepcopy(lin1)
+    x1 = torch.randn(E, cin, device=DEV).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    lab = torch.randint(0, C, (E,), device=DEV)
+    assert train_ops.linear_plain_supported(x2, lin2)
+    y1 = lin1(x1)
+    y2 = train_ops.linear_plain_train(x2, lin2)
+    assert y2.shape == y1.shape
+    assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))
+    l1 = F.cross_entropy(y1, lab, ignore_index=0, reduction="mean")
+    l2 = train_ops.softmax_ce(y2, lab, 0)
+    assert abs(float(l1) - float(l2)) <= 1e-5
+    l1.backward()
+    l2.backward()
+
+    def close(a, b, tol=2e-4):
+        s = max(1e-6, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * s, (float((a - b).abs().max()), s)
+    close(x2.grad, x1.grad)
+    close(lin2.weight.grad, lin1.weight.grad)
+    close(lin2.bias.grad, lin1.bias.grad)
+    # a generic (non padded) upstream gradient takes the copy path
+    x3 = x1.detach().clone().requires_grad_(True)
+    lin3 = copy.deepcopy(lin1)
+    lin3.zero_grad()
+    g = torch.randn(E, C, device=DEV)
+    train_ops.linear_plain_train(x3, lin3).backward(g)
+    x4 = x1.detach().clone().requires_grad_(True)
+    lin1.zero_grad()
+    lin1(x4).backward(g)
+    close(x3.grad, x4.grad)
+    close(lin3.weight.grad, lin1.weight.grad)
+    close(lin3.bias.grad, lin1.bias.grad)
+
+
 def test_unsupported_width_falls_to_modules():
     m = mlp(8, [48]).to(DEV).train()
     x = torch.randn(10, 8, device=DEV)
