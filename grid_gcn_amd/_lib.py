@@ -17,6 +17,7 @@ EXPORTS = [
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
     "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
+    "gridgcn_take_backward_workspace_bytes",
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
@@ -104,7 +105,9 @@ def load():
     lib.gridgcn_edge_inputs_rows.restype = ci
     lib.gridgcn_edge_inputs_rows.argtypes = [vp, vp, vp] + [ci] * 9 + [vp, vp, vp]
     lib.gridgcn_edge_inputs_rows_backward.restype = ci
-    lib.gridgcn_edge_inputs_rows_backward.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_edge_inputs_rows_backward.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp, vp, cs, vp]
+    lib.gridgcn_take_backward_workspace_bytes.restype = ci
+    lib.gridgcn_take_backward_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_fwd_direct.restype = ci
     lib.gridgcn_linear_fwd_direct.argtypes = [vp, ll, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp]
     cf = ctypes.c_float

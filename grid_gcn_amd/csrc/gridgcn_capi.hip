@@ -32,6 +32,9 @@ int gg_ce_fwd(const float *, int, int, const long long *, long long, int, float 
 int gg_ce_bwd(const float *, int, int, const long long *, long long, int, const float *,
               const double *, const float *, float *, hipStream_t);
 int gg_colsum(const float *, long long, int, int, double *, hipStream_t);
+size_t gg_take_bwd_sorted_workspace(int B, int N, int M);
+int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, int, int, void *,
+                       hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, long long, int, int, float *, int *, hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
@@ -419,14 +422,27 @@ int gridgcn_edge_inputs_rows(const float *src, const int32_t *nebidx, const floa
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_take_backward_workspace_bytes(int B, int N, int M, size_t *bytes)
+{
+    if (!bytes || B < 1 || N < 1 || M < 1) return GRIDGCN_EINVAL;
+    *bytes = gg_take_bwd_sorted_workspace(B, N, M);
+    return GRIDGCN_OK;
+}
+
 int gridgcn_edge_inputs_rows_backward(const float *grad_nf, int nf_stride, const int32_t *nebidx,
                                       int B, int Nsrc, int Cs, int O, int P, float *grad_src,
-                                      void *stream)
+                                      void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!grad_nf || !nebidx || !grad_src || B < 1 || Nsrc < 1 || O < 1 || P < 1 || Cs <= 4 ||
         nf_stride < Cs - 4)
         return GRIDGCN_EINVAL;
     // features are the first Cs-4 columns of a row; xyz/w receive no gradient
+    if (workspace) {
+        if (workspace_bytes < gg_take_bwd_sorted_workspace(B, Nsrc, O * P)) return GRIDGCN_EWORKSPACE;
+        const int rc = gg_take_bwd_sorted(grad_nf, nebidx, B, Nsrc, Cs - 4, O * P, grad_src + 4,
+                                          nf_stride, Cs, workspace, (hipStream_t)stream);
+        if (rc != 1) return rc;          // 1: shape not covered by the sorted path
+    }
     return gg_batch_take_backward(grad_nf, nebidx, B, Nsrc, Cs - 4, O * P, grad_src + 4, nf_stride,
                                   Cs, (hipStream_t)stream);
 }

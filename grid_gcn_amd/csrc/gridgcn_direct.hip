@@ -408,12 +408,13 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
         if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
+    // (768 threads = 3 waves per SIMD at 168 registers was measured: no gain, 59 spills)
     const int threads = 512, nw = threads / 64;
     size_t lds = ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     if (lds < rbytes) lds = rbytes;
     if (lds > 156 * 1024) return 1;
-    const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+    const int per_cu = (threads == 512 && lds <= 76 * 1024) ? 2 : 1;
     const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
     if (nb > 256 * per_cu) nb = 256 * per_cu;

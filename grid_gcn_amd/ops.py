@@ -25,11 +25,14 @@ path: the reference has none either for the grid ops (gridify.cc:28-39 LOG(FATAL
 All index ops are non-differentiable (gridify-inl.h:227-231, ball_k_nn.cc:60).
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
+# backward of the neighbour gather as a sorted segmented sum (csrc/gridgcn_scatter.hip)
+SORTED_TAKE_BWD = os.environ.get("GG_TAKE_BWD_ATOMIC", "0") != "1"
 
 def _require(cond, msg):
     if not cond:
@@ -378,8 +381,14 @@ class _EdgeInputsRows(torch.autograd.Function):
         gnf = gnf.contiguous()
         gsrc = torch.zeros((B, Nsrc, Cs), dtype=torch.float32, device=gnf.device)
         with torch.cuda.device(gnf.device):
+            ws, nbytes = None, ctypes.c_size_t(0)
+            if SORTED_TAKE_BWD:
+                lib.gridgcn_take_backward_workspace_bytes(B, Nsrc, O * P, ctypes.byref(nbytes))
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=gnf.device)
             rc = lib.gridgcn_edge_inputs_rows_backward(_ptr(gnf), nfs, _ptr(nebidx), B, Nsrc, Cs, O,
-                                                       P, _ptr(gsrc), _stream(gnf))
+                                                       P, _ptr(gsrc),
+                                                       _ptr(ws) if ws is not None else None,
+                                                       nbytes.value, _stream(gnf))
         _lib.check(rc, "gridgcn_edge_inputs_rows_backward")
         return gsrc, None, None, None, None
 

@@ -145,7 +145,13 @@ int gridgcn_edge_inputs_rows(const float *src, const int32_t *nebidx, const floa
                              int localfdim, int nf_stride, float *nf, float *att16, void *stream);
 int gridgcn_edge_inputs_rows_backward(const float *grad_nf, int nf_stride, const int32_t *nebidx,
                                       int B, int Nsrc, int Cs, int O, int P, float *grad_src,
-                                      void *stream);
+                                      void *workspace, size_t workspace_bytes, void *stream);
+/* workspace (gridgcn_take_backward_workspace_bytes(B, Nsrc, O*P)) != NULL selects the SORTED
+ * backward: the edges of each cloud are ordered by destination row with a counting sort of nebidx
+ * and summed run by run from whole gradient rows -- no scatter atomics except at the <= 2 run
+ * fragments a 256-edge chunk can cut.  NULL: LDS-privatised scatter-add.  grad_src zero-filled by
+ * the caller in both cases.  Sums are reproducible to fp32 round-off, not bit for bit. */
+int gridgcn_take_backward_workspace_bytes(int B, int N, int M, size_t *bytes);
 
 /* ---- training-mode 1x1 conv + BatchNorm + ReLU (utils/ops.py:149-158 conv2d, :141-147 conv1d) ---
  * gridgcn_linear_fwd: Z[E,cout] = act(X[E,cin]) * W + b on fp32 MFMA; act = identity (scale ==

@@ -7,7 +7,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 minus = float(sys.argv[2]) if len(sys.argv) > 2 else 150.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "nll_loss_forward_reduce" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "gg_k_ce_fwd" in r["Kernel_Name"]] or \
+      [i for i, r in enumerate(rows) if "nll_loss_forward_reduce" in r["Kernel_Name"]]
 seq = rows[idx[-2]:idx[-1]]
 agg = collections.defaultdict(lambda: [0, 0.0])
 tot = 0.0
