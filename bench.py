@@ -128,9 +128,10 @@ def main():
                                "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (a.points, B),
                    "global_batch": world * B, "points_per_cloud": a.points,
                    "parallelism": "dp%d" % world,
-                   "kernels": "hand-written HIP for Gridify/BallKNN, edge inputs (gather+geo), all "
-                              "conv+BatchNorm+ReLU stacks fwd+bwd (fp32 MFMA), att product + max; "
-                              "PyTorch-ROCm for concat/ReLU on [B,O,C], head, loss, Adam"},
+                   "kernels": "hand-written HIP for Gridify/BallKNN, edge inputs (gather+geo) and their "
+                              "sorted backward, all conv+BatchNorm+ReLU stacks fwd+bwd (fp32 MFMA), "
+                              "att product + max, class scores + softmax cross-entropy; "
+                              "PyTorch-ROCm for concat/mask/dropout on [B,O,C] and fused Adam"},
     }
 
     if rank == 0 and world == 1:
@@ -199,21 +200,29 @@ def main():
             "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
             "algorithmic_flops_per_launch": flops, "ms_per_launch": ms_k,
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
-        # ---- dominant kernel of the TIMED training step: gg_k_linear_bwd of that layer's pt
-        #      conv (dZ formed while staging, dX = dZ*W and dW = X^T*dZ on fp32 MFMA, one pass) ----
+        # ---- dominant kernels of the TIMED training step: backward of that layer's pt conv --
+        #      gg_k_linear_dx_direct (dZ formed in registers, dX = dZ*W^T for the feature columns)
+        #      + gg_k_linear_dw_direct (dW = dZ^T*X over the rows) + its reduce, fp32 MFMA.  The
+        #      edge rows are [features | geo_vec | pad]: cin real columns in a row of cin_pad ----
         from grid_gcn_amd import train_ops
         cin_b = layer.pt_mlp[-1].lin.in_features
         c_b = layer.pt_mlp[-1].lin.out_features
+        cin_pad = (cin_b + 7) & ~7
+        nfeat = cin_b - 3 if (layer.has_feats and layer.localfdim != 0) else cin_b
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
-        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=10, device=dev)
-        flops_b = 2.0 * 2.0 * ncent_b * p_b * cin_b * c_b
+        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_pad, c_b, iters=10, device=dev,
+                                         ndx=nfeat)
+        e_b = float(ncent_b * p_b)
+        flops_b = 2.0 * e_b * c_b * (nfeat + cin_b)          # dX (feature columns) + dW
         tf_b = flops_b / (ms_b * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gg_k_linear_bwd + gg_k_dw_reduce (backward "
-                           "of the %d->%d conv of GridConv %s over %d edges: BN/ReLU backward + dX "
-                           "+ dW in one pass)" % (cin_b, c_b, name, ncent_b * p_b),
+        out["roofline"] = {"bound": "mfma", "kernel": "gg_k_linear_dx_direct + gg_k_linear_dw_direct "
+                           "+ gg_k_dw_reduce_direct (backward of the %d->%d conv of GridConv %s over "
+                           "%d edges: BN/ReLU backward formed in registers, dX for the %d feature "
+                           "columns, dW)" % (cin_b, c_b, name, ncent_b * p_b, nfeat),
                            "achieved": tf_b, "peak": 157.3, "unit": "TFLOP/s",
                            "frac": tf_b / 157.3, "traffic": None,
                            "algorithmic_flops_per_launch": flops_b, "ms_per_launch": ms_b,
+                           "algorithmic_bytes_per_launch": 4.0 * e_b * (2 * c_b + cin_pad + nfeat),
                            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         out["inference"] = {"value": B / (ms_inf * 1e-3), "unit": "point-clouds/s",
                             "ms_per_batch": ms_inf, "path": "HIP index ops + fused GridConv"}

@@ -350,10 +350,11 @@ class _EdgeBlockTrain(torch.autograd.Function):
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
-def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
-    """Time one gg_k_linear_bwd launch (+ its dW reduce) on synthetic tensors shaped like the last
-    pt layer of a GridConv edge block (sparse upstream gradient, input gradient needed).  Used by
-    bench.py for the roofline of the dominant kernel of the training step.  Returns ms/launch."""
+def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0):
+    """Time one gridgcn_linear_bwd call (dX kernel + dW kernel + dW reduce) on synthetic tensors
+    shaped like the last pt layer of a GridConv edge block (sparse upstream gradient, input gradient
+    for the first `ndx` columns; cin = padded row length).  Used by bench.py for the roofline of the
+    dominant kernels of the training step.  Returns ms/call."""
     lib = _lib.load()
     E = ncent * P
     g = torch.Generator(device=device).manual_seed(0)
@@ -366,7 +367,7 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0"):
     gval = rnd(ncent, C)
     Wt = rnd(C, cin)
     Wb, Wg = pack_tiles(Wt), pack_groups(Wt)
-    ndx = min(cin, 256) if (DIRECT_DX and C % 8 == 0) else 0
+    ndx = (ndx or min(cin, 256)) if (DIRECT_DX and C % 8 == 0) else 0
     Wdx = torch.empty(C * 32 * 8, device=device)
     if ndx:
         _lib.check(lib.gridgcn_pack_linear(_ptr(Wt), None, C, cin, 0, cin, ndx, None, None, None,
