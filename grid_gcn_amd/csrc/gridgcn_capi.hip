@@ -5,6 +5,8 @@
 #include "gridgcn_index.h"
 #include "gridgcn_conv.h"
 #include "gridgcn_train.h"
+#include "gridgcn_csr.h"
+#include "gridgcn_edgelin.h"
 
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
@@ -328,15 +330,16 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
-int gridgcn_linear_fwd_direct(const float *X, long long E, int K, const float *Wq, const float *b,
-                              int ldw, int cout, const float *scale, const float *shift, float *Z,
-                              double *sums, void *stream)
+int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
+                              const float *b, int ldw, int cout, const float *scale,
+                              const float *shift, float *Z, double *sums, void *stream)
 {
-    if (!X || !Wq || !b || !Z || !sums || cout < 1 || cout > ldw || (scale && !shift))
+    if (!X || !Wq || !b || !Z || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
+        (ldx & 3) || ((uintptr_t)X & 15))
         return GRIDGCN_EINVAL;
     GGLinFwd p;
     p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
-    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = K; p.dbg = 0;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.dbg = 0;
     int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -419,6 +422,42 @@ int gridgcn_edge_inputs_rows(const float *src, const int32_t *nebidx, const floa
         return GRIDGCN_EINVAL;
     int rc = gg_edge_inputs_rows(src, nebidx, cent, cent_stride, B, Nsrc, Cs, O, P, has_feats,
                                  localfdim, nf_stride, nf, att16, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t *nebidx,
+                              const float *cent, int cent_stride, int B, int Nsrc, int Cs, int O,
+                              int P, int C0, const float *Wg, const float *b, float *Z0,
+                              float *att16, double *sums, void *stream)
+{
+    if (!src || !nebidx || !cent || !b || !Z0 || !att16 || !sums || B < 1 || Nsrc < 1 || Cs < 3 ||
+        O < 1 || P < 1 || C0 < 1 || (!Ysrc && !Wg) || (long long)B * O * P >= (1ll << 31))
+        return GRIDGCN_EINVAL;
+    GGEdgeLin0 p;
+    p.Ysrc = Ysrc; p.src = src; p.nebidx = nebidx; p.cent = cent; p.Wg = Wg; p.b = b; p.Z = Z0;
+    p.att16 = att16; p.sums = sums; p.cent_stride = cent_stride; p.B = B; p.Nsrc = Nsrc; p.Cs = Cs;
+    p.O = O; p.P = P; p.C0 = C0; p.E = B * O * P;
+    const int rc = gg_edge_lin0_fwd(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_edge_lin0_backward(const float *Z0, const float *dY, const int32_t *amax,
+                               const float *gval, const float *scale, const float *shift,
+                               const float *mean, const float *rstd, const float *m1,
+                               const float *m2, const float *att16, const int32_t *nebidx, int B,
+                               int Nsrc, int O, int P, int C0, float *dYsrc, double *dWg,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!Z0 || (!dY && (!amax || !gval)) || !scale || !shift || !mean || !rstd || !m1 || !m2 ||
+        !att16 || !nebidx || !dYsrc || B < 1 || Nsrc < 1 || O < 1 || P < 1 || C0 < 1)
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_csr_workspace(B, Nsrc, O * P)) return GRIDGCN_EWORKSPACE;
+    GGEdgeLin0Bwd p;
+    p.Z = Z0; p.dY = dY; p.amax = amax; p.gval = gval; p.scale = scale; p.shift = shift;
+    p.mean = mean; p.rstd = rstd; p.m1 = m1; p.m2 = m2; p.att16 = att16; p.index = nebidx;
+    p.perm = nullptr; p.keys = nullptr; p.rowptr = nullptr; p.dYsrc = dYsrc; p.dWg = dWg;
+    p.B = B; p.N = Nsrc; p.O = O; p.P = P; p.C0 = C0; p.M = O * P; p.cpc = 0;
+    const int rc = gg_edge_lin0_bwd(p, workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

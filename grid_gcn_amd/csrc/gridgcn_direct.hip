@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
         const long long r0 = tile << 5;
         long long row = r0 + (lane & 31);
         if (row >= p.E) row = p.E - 1;
-        const float *xr = p.X + row * K;
+        const float *xr = p.X + row * p.lda;          // lda = row stride of X (>= K)
         ggm_f32x16 acc[NT];
         ggm_zero<NT>(acc);
         int s = 0;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
         }
     }
     // statistics: halves -> waves (LDS) -> one fp64 atomic per column and workgroup
+    if (!p.sums) return;
     __syncthreads();
     float *red = lds;                                  // [nw][2][NT*32]
 #pragma unroll
@@ -409,12 +410,15 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
         attr_done = true;
     }
     // (768 threads = 3 waves per SIMD at 168 registers was measured: no gain, 59 spills)
-    const int threads = 512, nw = threads / 64;
+    // narrow outputs (NT <= 2) use ~150-170 registers = 3 waves per SIMD: workgroups of 4 waves so
+    // that three of them fit a CU (with 8-wave workgroups only one did)
+    const int threads = NT <= 2 ? 256 : 512, nw = threads / 64;
     size_t lds = ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     if (lds < rbytes) lds = rbytes;
     if (lds > 156 * 1024) return 1;
-    const int per_cu = (threads == 512 && lds <= 76 * 1024) ? 2 : 1;
+    int per_cu = NT <= 2 ? 3 : 2;
+    while (per_cu > 1 && per_cu * lds > 152 * 1024) per_cu--;
     const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
     if (nb > 256 * per_cu) nb = 256 * per_cu;

@@ -1,0 +1,33 @@
+// gridgcn_edgelin.h -- parameter blocks of gridgcn_edgelin.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GGEdgeLin0 {
+    const float *Ysrc;   // [B*Nsrc][C0] or nullptr (layer without neighbour features)
+    const float *src;    // [B*Nsrc][Cs]  x,y,z first
+    const int *nebidx;   // [E]
+    const float *cent;   // centre ci at cent + ci*cent_stride
+    const float *Wg;     // [3][C0] geo_vec weights or nullptr
+    const float *b;      // [C0]
+    float *Z;            // [E][C0]
+    float *att16;        // [E][16]
+    double *sums;        // [2][C0]
+    int cent_stride, B, Nsrc, Cs, O, P, C0, E;
+};
+
+struct GGEdgeLin0Bwd {
+    const float *Z;       // [E][C0]
+    const float *dY;      // dense upstream gradient [E][C0] (nullptr: sparse)
+    const int *amax;      // sparse: [B*O][C0] arg-max neighbour, value
+    const float *gval;
+    const float *scale, *shift, *mean, *rstd, *m1, *m2;   // [C0]
+    const float *att16;   // [E][16] (geo_vec at columns 1..3)
+    const int *index;     // nebidx [B][M]
+    const int *perm, *keys, *rowptr;
+    float *dYsrc;         // [B*N][C0], zero-filled
+    double *dWg;          // [3][C0], zero-filled (nullptr: no geo term)
+    int B, N, O, P, C0, M, cpc;
+};
+
+int gg_edge_lin0_fwd(const GGEdgeLin0 &p, hipStream_t st);
+int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st);   // workspace: gg_csr_workspace

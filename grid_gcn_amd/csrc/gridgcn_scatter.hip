@@ -18,10 +18,7 @@
 // indices clipped into any other cloud (never produced by the index ops; handled edge by edge).
 // The order of the edges inside a run depends on the LDS atomics of the sort: sums are reproducible
 // to fp32 round-off, not bit for bit (as the framework's own scatter-add backward).
-#include <hip/hip_runtime.h>
-
-#define GG_CSR_PARTS 16
-#define GG_CSR_CHUNK 256
+#include "gridgcn_csr.h"
 
 __device__ __forceinline__ int gg_csr_key(int idx, int b, int N, long long rows)
 {
@@ -200,21 +197,15 @@ __global__ __launch_bounds__(256) void gg_k_take_bwd_sorted(
     flush(cur, rs, e1);
 }
 
-size_t gg_take_bwd_sorted_workspace(int B, int N, int M)
+size_t gg_csr_workspace(int B, int N, int M)
 {
-    // perm + keys [B*M], rowptr [B][N+3], hist [B][PARTS][N+2]
     return ((size_t)2 * B * M + (size_t)B * (N + 3) + (size_t)B * GG_CSR_PARTS * (N + 2)) * sizeof(int);
 }
 
-// 1 = shape not supported (caller falls back to the scatter-add kernels)
-int gg_take_bwd_sorted(const float *gout, const int *index, int B, int N, int C, int M, float *gdata,
-                       int gs, int ds, void *workspace, hipStream_t st)
+int gg_csr_build(const int *index, int B, int N, int M, void *workspace, int **perm_, int **keys_,
+                 int **rowptr_, hipStream_t st)
 {
-    if (C < 1 || C > 256 || (size_t)(N + 2) * 4 > 150 * 1024 || M < 1) return 1;
-    const int VPL = C <= 64 ? 1 : (C <= 128 ? 2 : 4);
-    if ((gs % VPL) || (ds % VPL) || (C % VPL) || ((uintptr_t)gout & (4 * VPL - 1)) ||
-        ((uintptr_t)gdata & (4 * VPL - 1)))
-        return 1;
+    if ((size_t)(N + 2) * 4 > 150 * 1024 || M < 1 || B < 1) return 1;
     int *perm = (int *)workspace;
     int *keys = perm + (size_t)B * M;
     int *rowptr = keys + (size_t)B * M;
@@ -229,6 +220,24 @@ int gg_take_bwd_sorted(const float *gout, const int *index, int B, int N, int C,
     gg_k_csr_hist<<<dim3(GG_CSR_PARTS, B), 1024, lds, st>>>(index, B, N, M, hist);
     gg_k_csr_scan<<<B, 1024, 0, st>>>(N, hist, rowptr);
     gg_k_csr_scatter<<<dim3(GG_CSR_PARTS, B), 1024, lds, st>>>(index, B, N, M, hist, perm, keys);
+    *perm_ = perm; *keys_ = keys; *rowptr_ = rowptr;
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+size_t gg_take_bwd_sorted_workspace(int B, int N, int M) { return gg_csr_workspace(B, N, M); }
+
+// 1 = shape not supported (caller falls back to the scatter-add kernels)
+int gg_take_bwd_sorted(const float *gout, const int *index, int B, int N, int C, int M, float *gdata,
+                       int gs, int ds, void *workspace, hipStream_t st)
+{
+    if (C < 1 || C > 256) return 1;
+    const int VPL = C <= 64 ? 1 : (C <= 128 ? 2 : 4);
+    if ((gs % VPL) || (ds % VPL) || (C % VPL) || ((uintptr_t)gout & (4 * VPL - 1)) ||
+        ((uintptr_t)gdata & (4 * VPL - 1)))
+        return 1;
+    int *perm, *keys, *rowptr;
+    const int rc = gg_csr_build(index, B, N, M, workspace, &perm, &keys, &rowptr, st);
+    if (rc) return rc;
     const int cpc = (M + GG_CSR_CHUNK - 1) / GG_CSR_CHUNK;
     const int nwave = B * cpc, grid = (nwave + 3) / 4;
     if (VPL == 1) gg_k_take_bwd_sorted<1><<<grid, 256, 0, st>>>(gout, gs, perm, keys, rowptr, index, B, N, C, M, cpc, gdata, ds);

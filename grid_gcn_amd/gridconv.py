@@ -138,6 +138,11 @@ class SubGUpdate(nn.Module):
         src = src.contiguous()
         if self.mfma_train and self.training and torch.is_grad_enabled():
             from . import train_ops
+            if train_ops.edge_block_src_supported(pt_layers, att_layers, src, self.has_feats):
+                # first conv on the source points, gathered afterwards: no [E, 3+Cf] tensor at all
+                agg = train_ops.edge_block_src_train(src, nebidx, cent.contiguous(), pt_layers,
+                                                     att_layers, self.localfdim)
+                return self.finish(agg, center_masks, center_ori_feats)
             if train_ops.edge_block_supported(pt_layers, att_layers, src) and \
                     ops.edge_inputs_rows_supported(src, self.has_feats):
                 # rows laid out for the MFMA kernels (features | geo_vec | zero padding)

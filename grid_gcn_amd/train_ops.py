@@ -33,6 +33,8 @@ import os  # noqa: E402
 # register-direct forward kernel (csrc/gridgcn_direct.hip) for inputs whose width is a multiple of 8
 DIRECT_FWD = os.environ.get("GG_FWD_LDS", "0") != "1"
 DIRECT_DX = os.environ.get("GG_DX_LDS", "0") != "1"
+# first conv of the point MLP applied to the source points and gathered (csrc/gridgcn_edgelin.hip)
+SRC_FIRST_CONV = os.environ.get("GG_EDGE_GEMM", "0") != "1"
 
 
 def supported(layers, x):
@@ -88,15 +90,18 @@ def packed_sizes(C, cin):
     return K, ldw, K * ldw, ((cin + 31) // 32) * ((C + 3) & ~3) * 32
 
 
-def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0):
+def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
     """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer.  Per layer three launches:
     pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping.
     x may be wider than the first layer's weight (zero padded columns) and hold the layer's first
-    `rot` input channels behind the others (ops.edge_inputs_rows)."""
+    `rot` input channels behind the others (ops.edge_inputs_rows).  prev_bn = (scale, shift): x is
+    the raw (pre-BatchNorm) output of an earlier layer whose BatchNorm+ReLU is applied on the fly."""
     L = len(params) // 4
     E, dev = x.shape[0], x.device
     st = _Chain()
     prev, pscale, pshift = x, None, None
+    if prev_bn is not None:
+        pscale, pshift = prev_bn
     couts = [params[4 * l].shape[0] for l in range(L)]
     allsums = torch.zeros(2 * sum(couts), dtype=torch.float64, device=dev)
     so = 0
@@ -136,8 +141,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0):
         ps = _ptr(pscale) if pscale is not None else None
         ph = _ptr(pshift) if pshift is not None else None
         if direct:
-            rc = lib.gridgcn_linear_fwd_direct(_ptr(prev), E, cin, _ptr(Wq), _ptr(Bp), ldw, cout,
-                                               ps, ph, _ptr(Z), _ptr(sums), stream)
+            rc = lib.gridgcn_linear_fwd_direct(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
+                                               cout, ps, ph, _ptr(Z), _ptr(sums), stream)
         else:
             rc = lib.gridgcn_linear_fwd(_ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
                                         ps, ph, _ptr(Z), _ptr(sums), stream)
@@ -161,11 +166,13 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0):
 
 
 def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, ndxs, sums, dY, sparse,
-                    need_dx, cin_w0=None, rot=0):
+                    need_dx, cin_w0=None, rot=0, prev_bn=None):
     """backward through a chain.  `sums` [2*C_L] fp64 = BatchNorm-backward sums of the LAST layer;
     upstream gradient either dense dY [E,C_L] or sparse = (amax, gval, P).  Returns (dX, grads)
     with grads = [dW, db, dgamma, dbeta] * L.  cin_w0 / rot: width of the first layer's weight and
-    its column rotation when x is in the padded row layout (see _chain_forward)."""
+    its column rotation when x is in the padded row layout (see _chain_forward).
+    prev_bn = (scale, shift, mean, rstd) of an earlier layer whose raw output is x: dX is then the
+    gradient w.r.t. relu(bn(x)) and a third value is returned, the BatchNorm-backward sums of x."""
     L = len(Zs)
     if cin_w0 is None:
         cin_w0 = x.shape[1]
@@ -174,7 +181,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     Cs = [Zs[l].shape[1] for l in range(L)]
     cins = [x.shape[1]] + Cs[:-1]
     # one zero fill for the chain: BatchNorm-backward sums of layers 0..L-2 (fp64) + bias gradients
-    nps = 2 * sum(Cs[:-1])
+    nps = 2 * sum(Cs[:-1]) + (2 * x.shape[1] if prev_bn is not None else 0)
     zbuf = torch.zeros(nps * 8 + 4 * sum(Cs), dtype=torch.uint8, device=dev)
     zps = zbuf[:nps * 8].view(torch.float64)
     zdb = zbuf[nps * 8:].view(torch.float32)
@@ -194,7 +201,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         want_dx = l > 0 or need_dx
         dX = torch.empty((E, cin), dtype=torch.float32, device=dev) if want_dx else None
         psums = None
-        if l > 0:
+        if l > 0 or prev_bn is not None:
             psums = zps[po:po + 2 * cin]
             po += 2 * cin
         # written in the framework layout (padding dropped, rotated columns moved back)
@@ -206,7 +213,11 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         prev = Zs[l - 1] if l > 0 else x
-        pn = (lambda t: _ptr(t)) if l > 0 else (lambda t: None)
+        if l > 0:
+            pbn = (scales[l - 1], shifts[l - 1], means[l - 1], rstds[l - 1])
+        else:
+            pbn = prev_bn
+        pbn = [_ptr(t) for t in pbn] if pbn is not None else [None] * 4
         if sparse is not None:
             amax, gval, P = sparse
             sp = (_ptr(amax), _ptr(gval), int(P))
@@ -216,8 +227,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
             dyp = _ptr(dY)
         rc = lib.gridgcn_linear_bwd(
             dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
-            _ptr(m1), _ptr(m2), _ptr(prev),
-            pn(scales[l - 1]), pn(shifts[l - 1]), pn(means[l - 1]), pn(rstds[l - 1]),
+            _ptr(m1), _ptr(m2), _ptr(prev), pbn[0], pbn[1], pbn[2], pbn[3],
             _ptr(Wb), _ptr(Wg) if Wg is not None else None,
             _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin, cw, rt,
             _ptr(dX) if want_dx else None, _ptr(dW),
@@ -226,6 +236,8 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         _lib.check(rc, "gridgcn_linear_bwd")
         grads[4 * l] = dW
         dY, sums, sparse = dX, psums, None
+    if prev_bn is not None:
+        return dY, grads, sums
     return dY, grads
 
 
@@ -350,6 +362,163 @@ class _EdgeBlockTrain(torch.autograd.Function):
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
+class _EdgeBlockSrcTrain(torch.autograd.Function):
+    """The whole GridConv edge block from (src, nebidx, cent): the first conv of the point MLP is
+    applied to the SOURCE points (Ysrc = features * Wf^T, [B*Nsrc, C0]) and gathered, instead of
+    being applied to the gathered [E, 3+Cf] tensor (csrc/gridgcn_edgelin.hip); the remaining pt
+    layers, the att MLP and the product/max run as in _EdgeBlockTrain."""
+
+    @staticmethod
+    def forward(ctx, src, nebidx, cent, meta, *params):
+        lib = _lib.load()
+        eps, bns_p, bns_a, geo = meta
+        Lp, La = len(bns_p), len(bns_a)
+        B, Nsrc, Cs = src.shape
+        _, O, P = nebidx.shape
+        E, R, Cf = B * O * P, B * Nsrc, Cs - 4
+        dev = src.device
+        W0, b0, g0, be0 = params[:4]
+        C0 = W0.shape[0]
+        rot = 3 if geo else 0
+        with torch.cuda.device(dev):
+            st = _stream(src)
+            feat = src.detach()[..., 4:].reshape(R, Cf)
+            Wf = W0.detach()[:, rot:]
+            Ysrc = torch.matmul(feat, Wf.t()).contiguous()          # [R, C0]: once per source point
+            Wg = W0.detach()[:, :3].t().contiguous() if geo else None
+            Z0 = torch.empty((E, C0), dtype=torch.float32, device=dev)
+            att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
+            sums0 = torch.zeros(2 * C0, dtype=torch.float64, device=dev)
+            rc = lib.gridgcn_edge_lin0_forward(
+                _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P,
+                C0, _ptr(Wg) if geo else None, _ptr(b0.detach()), _ptr(Z0), _ptr(att16),
+                _ptr(sums0), st)
+            _lib.check(rc, "gridgcn_edge_lin0_forward")
+            vec0 = torch.empty((4, C0), dtype=torch.float32, device=dev)
+            bn = bns_p[0]
+            track = bn.track_running_stats
+            rc = lib.gridgcn_bn_finalize(
+                _ptr(sums0), _ptr(g0.detach()), _ptr(be0.detach()), E, eps,
+                bn.momentum if track else 0.0, C0, _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]),
+                _ptr(vec0[3]), _ptr(bn.running_mean) if track else None,
+                _ptr(bn.running_var) if track else None, st)
+            _lib.check(rc, "gridgcn_bn_finalize")
+            if track:
+                bn.num_batches_tracked += 1
+            if Lp > 1:
+                sp = _chain_forward(lib, Z0, params[4:4 * Lp], bns_p[1:], eps, 0, C0,
+                                    prev_bn=(vec0[0], vec0[1]))
+                Zl, scl, shl = sp.Z[-1], sp.scale[-1], sp.shift[-1]
+            else:
+                sp = _Chain()
+                Zl, scl, shl = Z0, vec0[0], vec0[1]
+            sa = _chain_forward(lib, att16, params[4 * Lp:], bns_a, eps)
+            C = Zl.shape[1]
+            ncent = B * O
+            agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
+                                         _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
+                                         _ptr(agg), _ptr(amax), st)
+            _lib.check(rc, "gridgcn_pairmax_fwd")
+        ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1])
+        ctx.ndx = (sp.ndx, sa.ndx)
+        ctx.save_for_backward(
+            src, nebidx, att16, amax, Z0, vec0, W0,
+            *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
+            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
+        ctx.mark_non_differentiable(amax)
+        return agg.reshape(B, O, C)
+
+    @staticmethod
+    def backward(ctx, dagg):
+        lib = _lib.load()
+        Lp, La, B, Nsrc, Cs, O, P, C0, rot, cwa = ctx.dims
+        t = ctx.saved_tensors
+        src, nebidx, att16, amax, Z0, vec0, W0 = t[:7]
+        o = 7
+        L1 = Lp - 1
+        pZ, pS, pH, pM, pR, pWb, pWg, pWx = (t[o + k * L1:o + (k + 1) * L1] for k in range(8))
+        o += 8 * L1
+        aZ, aS, aH, aM, aR, aWb, aWg, aWx = (t[o + k * La:o + (k + 1) * La] for k in range(8))
+        dev = src.device
+        E, R, Cf, ncent = B * O * P, B * Nsrc, Cs - 4, B * O
+        Zl = pZ[-1] if L1 else Z0
+        lS, lH, lM, lR = (pS[-1], pH[-1], pM[-1], pR[-1]) if L1 else (vec0[0], vec0[1], vec0[2],
+                                                                        vec0[3])
+        C = Zl.shape[1]
+        dagg = dagg.contiguous().reshape(ncent, C)
+        with torch.cuda.device(dev):
+            st = _stream(src)
+            gp = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            ga = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            sums_pa = torch.zeros((2, 2 * C), dtype=torch.float64, device=dev)
+            sums_p, sums_a = sums_pa[0], sums_pa[1]
+            rc = lib.gridgcn_pairmax_bwd(_ptr(Zl), _ptr(aZ[-1]), _ptr(lS), _ptr(lH), _ptr(lM),
+                                         _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
+                                         _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C, _ptr(gp),
+                                         _ptr(ga), _ptr(sums_p), _ptr(sums_a), st)
+            _lib.check(rc, "gridgcn_pairmax_bwd")
+            _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1],
+                                         sums_a, None, (amax, ga, P), False, cwa, 0)
+            if L1:
+                dY0, grads_rest, sums0 = _chain_backward(
+                    lib, Z0, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0], sums_p, None,
+                    (amax, gp, P), True, None, 0, prev_bn=(vec0[0], vec0[1], vec0[2], vec0[3]))
+                sparse0 = (None, None)
+            else:
+                dY0, grads_rest, sums0 = None, [], sums_p
+                sparse0 = (_ptr(amax), _ptr(gp))
+            v = torch.empty((4, C0), dtype=torch.float32, device=dev)
+            rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums0), E, C0, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]),
+                                             _ptr(v[3]), st)
+            _lib.check(rc, "gridgcn_bn_bwd_finalize")
+            zb = torch.zeros(R * C0 * 4 + 3 * C0 * 8, dtype=torch.uint8, device=dev)
+            dYsrc = zb[:R * C0 * 4].view(torch.float32).view(R, C0)
+            dWg = zb[R * C0 * 4:].view(torch.float64).view(3, C0)
+            nbytes = ctypes.c_size_t(0)
+            lib.gridgcn_take_backward_workspace_bytes(B, Nsrc, O * P, ctypes.byref(nbytes))
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            rc = lib.gridgcn_edge_lin0_backward(
+                _ptr(Z0), _ptr(dY0) if dY0 is not None else None, sparse0[0], sparse0[1],
+                _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]),
+                _ptr(att16), _ptr(nebidx), B, Nsrc, O, P, C0, _ptr(dYsrc),
+                _ptr(dWg) if rot else None, _ptr(ws), nbytes.value, st)
+            _lib.check(rc, "gridgcn_edge_lin0_backward")
+            # the two small GEMMs on the source points
+            feat = src.detach()[..., 4:].reshape(R, Cf)
+            dWf = torch.matmul(dYsrc.t(), feat)                       # [C0, Cf]
+            dW0 = torch.cat([dWg.t().float(), dWf], dim=1) if rot else dWf
+            gsrc = None
+            if ctx.needs_input_grad[0]:
+                gsrc = torch.zeros((B, Nsrc, Cs), dtype=torch.float32, device=dev)
+                gsrc[..., 4:] = torch.matmul(dYsrc, W0.detach()[:, rot:]).view(B, Nsrc, Cf)
+            db0 = torch.zeros(C0, dtype=torch.float32, device=dev)
+        grads0 = [dW0, db0, v[2], v[3]]
+        return (gsrc, None, None, None) + tuple(grads0) + tuple(grads_rest) + tuple(grads_a)
+
+
+def edge_block_src_supported(pt_layers, att_layers, src, has_feats):
+    """the source-side first conv needs neighbour features with a width the kernels can vector-load"""
+    if not (has_feats and src.is_cuda and src.dtype == torch.float32 and SRC_FIRST_CONV):
+        return False
+    C0 = pt_layers[0].lin.out_features
+    if C0 % 4 or C0 > 256 or (src.shape[2] % 4):
+        return False
+    return edge_block_supported(pt_layers, att_layers, src)
+
+
+def edge_block_src_train(src, nebidx, cent, pt_layers, att_layers, localfdim):
+    """[B,O,C] = max_p att_mlp(att_vec) * pt_mlp(concat(geo_vec, gathered features)) from
+    (src [B,Nsrc,4+Cf], nebidx [B,O,P], cent [B,O,>=3]) -- sub_g_update up to the pooling."""
+    params = []
+    for l in list(pt_layers) + list(att_layers):
+        params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
+    meta = (pt_layers[0].bn.eps, [l.bn for l in pt_layers], [l.bn for l in att_layers],
+            localfdim != 0)
+    return _EdgeBlockSrcTrain.apply(src, nebidx, cent, meta, *params)
+
+
 def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0):
     """Time one gridgcn_linear_bwd call (dX kernel + dW kernel + dW reduce) on synthetic tensors
     shaped like the last pt layer of a GridConv edge block (sparse upstream gradient, input gradient
@@ -467,9 +636,8 @@ class _LinearPlain(torch.autograd.Function):
                                                cin, 0, cin, ndx, None, _ptr(Bp), _ptr(Wb), None,
                                                _ptr(Wq), _ptr(Wdx) if ndx else None, st), "pack")
             Z = torch.empty((E, Cp), dtype=torch.float32, device=dev)
-            scratch = torch.zeros(2 * Cp, dtype=torch.float64, device=dev)
-            _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(x), E, cin, _ptr(Wq), _ptr(Bp), ldw, Cp,
-                                                     None, None, _ptr(Z), _ptr(scratch), st),
+            _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(x), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
+                                                     Cp, None, None, _ptr(Z), None, st),
                        "gridgcn_linear_fwd_direct")
         ctx.save_for_backward(x, Z, Wb, Wdx)
         ctx.dims = (C, Cp, ndx)

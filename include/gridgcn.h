@@ -153,6 +153,28 @@ int gridgcn_edge_inputs_rows_backward(const float *grad_nf, int nf_stride, const
  * the caller in both cases.  Sums are reproducible to fp32 round-off, not bit for bit. */
 int gridgcn_take_backward_workspace_bytes(int B, int N, int M, size_t *bytes);
 
+/* ---- first conv of the point MLP WITHOUT the gathered tensor ---------------------------------
+ * The first 1x1 conv of sub_g_update's point MLP acts on concat(geo_vec, gathered features)
+ * (gcn_module_g_att.py:190-194, 242-250, 135).  Linear + gather commute:
+ *   Z0[e] = Ysrc[src(e)] + Wg * geo_vec(e) + b,   Ysrc[B*Nsrc, C0] = features * Wf^T (once per point)
+ * forward : Z0[B*O*P, C0], att16[B*O*P, 16] and sums[2*C0] += (sum z, sum z^2) (BatchNorm statistics;
+ *           zeroed by the caller).  Ysrc NULL = no feature term, Wg[3][C0] NULL = no geo term.
+ * backward: dZ0 = BatchNorm/ReLU backward of the upstream gradient (dense dY[E,C0], or NULL and the
+ *           sparse (amax, gval)[B*O, C0] of gridgcn_pairmax_bwd) formed on the fly, summed per source
+ *           row over the edges sorted by destination -> dYsrc[B*Nsrc, C0] (zeroed by the caller),
+ *           dWg[3][C0] += sum_e geo_vec(e) dZ0[e] (fp64, zeroed by the caller; NULL = skip).
+ *           workspace: gridgcn_take_backward_workspace_bytes(B, Nsrc, O*P). */
+int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t *nebidx,
+                              const float *cent, int cent_stride, int B, int Nsrc, int Cs, int O,
+                              int P, int C0, const float *Wg, const float *b, float *Z0,
+                              float *att16, double *sums, void *stream);
+int gridgcn_edge_lin0_backward(const float *Z0, const float *dY, const int32_t *amax,
+                               const float *gval, const float *scale, const float *shift,
+                               const float *mean, const float *rstd, const float *m1,
+                               const float *m2, const float *att16, const int32_t *nebidx, int B,
+                               int Nsrc, int O, int P, int C0, float *dYsrc, double *dWg,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- training-mode 1x1 conv + BatchNorm + ReLU (utils/ops.py:149-158 conv2d, :141-147 conv1d) ---
  * gridgcn_linear_fwd: Z[E,cout] = act(X[E,cin]) * W + b on fp32 MFMA; act = identity (scale ==
  *   NULL) or the previous layer's BatchNorm+ReLU x -> relu(x*scale[c] + shift[c]) applied while
@@ -186,9 +208,10 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
  *   k = 32c + (l>>5)*4*nq + 4q + i (nq = 4, or K%32/8 in the last chunk) -- so Wq is
  *   [K/2 steps][64 lanes][ldw/32] with element (s, l, t) = W[t*32 + (l&31)][k(s, l)].  No LDS
  *   staging of X, 16 waves per CU. */
-int gridgcn_linear_fwd_direct(const float *X, long long E, int K, const float *Wq, const float *b,
-                              int ldw, int cout, const float *scale, const float *shift, float *Z,
-                              double *sums, void *stream);
+int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
+                              const float *b, int ldw, int cout, const float *scale,
+                              const float *shift, float *Z, double *sums, void *stream);
+/* (ldx = row stride of X in floats, >= K, a multiple of 4, X 16-byte aligned; sums may be NULL.) */
 /* gridgcn_pack_linear: W[C][cin_w] (framework layout, C <= 256), b[C]; the kernels see `cin` >=
  *   cin_w input channels: kernel column k = framework column k + rot (k < cin_w - rot), k - (cin_w -
  *   rot) (k < cin_w), zero (k >= cin_w) -- i.e. the first `rot` columns moved behind the others and

@@ -129,6 +129,51 @@ def test_edge_inputs_rows_layout(cin, lfd):
         assert torch.allclose(src.grad, src2.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("cin,lfd,dims,O,P", [(128, 3, [128], 700, 5), (64, 3, [64, 64, 128], 90, 12),
+                                              (64, 0, [32, 64], 200, 7), (256, 3, [128], 300, 6),
+                                              (32, 3, [256], 64, 33)])
+def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P):
+    """GridConv training forward/backward with the first pt conv applied to the SOURCE points and
+    gathered (train_ops.edge_block_src_train) == the stock modules on the gathered tensor."""
+    import copy
+    from grid_gcn_amd import train_ops
+    torch.manual_seed(cin + lfd + O)
+    gen = torch.Generator().manual_seed(cin + P)
+    B, Nsrc = 3, 150
+    ref = SubGUpdate(cin, dims, localfdim=lfd).to(DEV).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    new = copy.deepcopy(ref)
+    src1 = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV).requires_grad_(True)
+    src2 = src1.detach().clone().requires_grad_(True)
+    nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    assert train_ops.edge_block_src_supported(list(new.pt_mlp), [new.att1[0], new.att2[0]], src2, True)
+    y1 = ref(cent[..., 0:3], ops.batch_take_g(src1, nebidx), None)
+    y2 = new.forward_src(cent, src2, nebidx, None)
+    assert y1.shape == y2.shape
+    assert float((y1 - y2).abs().max()) <= 3e-5 * max(1.0, float(y1.abs().max()))
+    g = torch.randn(y1.shape, generator=gen).to(DEV)
+    y1.backward(g)
+    y2.backward(g)
+
+    def close(a, b, tol=3e-4):
+        s = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * s, (float((a - b).abs().max()), s)
+    close(src2.grad[..., 4:], src1.grad[..., 4:])
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), new.named_parameters()):
+        if p1.grad is None:
+            continue
+        if n1.endswith("lin.bias") and ("pt_mlp" in n1 or "att" in n1):
+            continue                      # bias in front of a BatchNorm: exact 0 vs round-off noise
+        close(p2.grad, p1.grad)
+    for (n1, b1), (n2, b2) in zip(ref.named_buffers(), new.named_buffers()):
+        if "num_batches" not in n1:
+            close(b2, b1, 1e-5)
+
+
 def test_training_step_edge_kernel_matches_torch_ops():
     """one fwd+bwd of the whole network: HIP edge-input kernel path vs stock-op path."""
     torch.manual_seed(0)

@@ -35,7 +35,7 @@ for E, cin, C, act in SHAPES:
                                       _ptr(Z1), _ptr(s1), _stream(X))
 
     def new():
-        return lib.gridgcn_linear_fwd_direct(_ptr(X), E, cin, _ptr(Wq), _ptr(Bp), ldw, C, ps(sc),
+        return lib.gridgcn_linear_fwd_direct(_ptr(X), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, C, ps(sc),
                                              ps(sh), _ptr(Z2), _ptr(s2), _stream(X))
     assert old() == 0 and new() == 0
     torch.cuda.synchronize()
