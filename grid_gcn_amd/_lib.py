@@ -113,7 +113,7 @@ def load():
     lib.gridgcn_linear_fwd_direct.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp]
     cf = ctypes.c_float
     lib.gridgcn_bn_finalize.restype = ci
-    lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_bwd_finalize.restype = ci
     lib.gridgcn_bn_bwd_finalize.argtypes = [vp, ll, ci, vp, vp, vp, vp, vp]
     lib.gridgcn_edge_lin0_forward.restype = ci

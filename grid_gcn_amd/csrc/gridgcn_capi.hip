@@ -47,7 +47,7 @@ int gg_pairmax_bwd(const float *, const float *, const float *, const float *, c
 int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
                    float *, float *, float *, float *, hipStream_t);
 int gg_bn_finalize(const double *, const float *, const float *, long long, float, float, int,
-                   float *, float *, float *, float *, float *, float *, hipStream_t);
+                   float *, float *, float *, float *, float *, float *, long long *, hipStream_t);
 int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
                        hipStream_t);
 
@@ -346,13 +346,15 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
 
 int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
                         float eps, float momentum, int C, float *scale, float *shift, float *mean,
-                        float *rstd, float *running_mean, float *running_var, void *stream)
+                        float *rstd, float *running_mean, float *running_var,
+                        int64_t *num_batches_tracked, void *stream)
 {
     if (!sums || !gamma || !beta || !scale || !shift || !mean || !rstd || E < 1 || C < 1 ||
         (running_mean && !running_var))
         return GRIDGCN_EINVAL;
     return gg_bn_finalize(sums, gamma, beta, E, eps, momentum, C, scale, shift, mean, rstd,
-                          running_mean, running_var, (hipStream_t)stream);
+                          running_mean, running_var, (long long *)num_batches_tracked,
+                          (hipStream_t)stream);
 }
 
 int gridgcn_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2,

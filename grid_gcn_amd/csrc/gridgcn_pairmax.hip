@@ -94,9 +94,10 @@ __global__ void gg_k_bn_finalize(const double *__restrict__ sums, const float *_
                                  float momentum, int C, float *__restrict__ scale,
                                  float *__restrict__ shift, float *__restrict__ mean,
                                  float *__restrict__ rstd, float *__restrict__ run_mean,
-                                 float *__restrict__ run_var)
+                                 float *__restrict__ run_var, long long *__restrict__ nbt)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;                  // BatchNorm1d.num_batches_tracked
     if (c >= C) return;
     const double m = sums[c] / (double)E;
     double v = sums[C + c] / (double)E - m * m;
@@ -237,10 +238,10 @@ int gg_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, in
 
 int gg_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
                    float eps, float momentum, int C, float *scale, float *shift, float *mean,
-                   float *rstd, float *run_mean, float *run_var, hipStream_t st)
+                   float *rstd, float *run_mean, float *run_var, long long *nbt, hipStream_t st)
 {
     gg_k_bn_finalize<<<(C + 255) / 256, 256, 0, st>>>(sums, gamma, beta, E, eps, momentum, C, scale,
-                                                      shift, mean, rstd, run_mean, run_var);
+                                                      shift, mean, rstd, run_mean, run_var, nbt);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -110,6 +110,8 @@ class SubGUpdate(nn.Module):
         self.out_channels = out_dim[-1] if len(out_dim) else agg_c
 
     mfma_train = True   # training on the GPU: MLPs through csrc/gridgcn_train.hip
+    tail_layers = ()    # ConvBNReLU layers of the caller that directly follow update_mlp (not owned)
+    tail_done = False   # set by finish(): the tail layers were applied
 
     def edge_inputs(self, neighbors, centers_xyz):
         geo_vec, _, att_vec = geo_features(neighbors, centers_xyz)
@@ -206,8 +208,15 @@ class SubGUpdate(nn.Module):
             agg = torch.cat([cf, agg], dim=-1)                             # up_center_inte=concat
         if self.relu:
             agg = F.relu(agg)                                              # update_func :31-32
+        self.tail_done = False
         if self.update_mlp is not None:
-            agg = run_mlp(list(self.update_mlp), agg, self.mfma_train)
+            layers = list(self.update_mlp)
+            if self.tail_layers and center_masks is None:
+                # conv+BN+ReLU layers that directly follow this block (the head's fc1 after the last
+                # up layer) join the same chain: one activation pass and one reduce pass less
+                layers += list(self.tail_layers)
+                self.tail_done = True
+            agg = run_mlp(layers, agg, self.mfma_train)
         if center_masks is not None:
             agg = agg * center_masks[..., None]                            # :284-285
         return agg

@@ -60,6 +60,8 @@ class GGCNSeg(nn.Module):
             last_c = layer.out_channels
         # get_seg_head (:30-43)
         self.fc1 = ConvBNReLU(last_c, 128, cfg["bn_decay"])
+        # fc1 directly follows the last up layer's update MLP: one conv+BN+ReLU chain (see finish())
+        object.__setattr__(self.up[-1], "tail_layers", (self.fc1,))
         self.fc2 = nn.Linear(128, cfg["num_classes"])
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
@@ -123,7 +125,7 @@ class GGCNSeg(nn.Module):
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
             f_last = torch.cat([upl, cf], dim=2)                                    # :231
-        net = run_mlp([self.fc1], cf)
+        net = cf if self.up[-1].tail_done else run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
         if HEAD_KERNELS and self.training and torch.is_grad_enabled() and self.ix is HipIndexOps:
             from . import train_ops

@@ -154,10 +154,9 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
             _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
             bn.momentum if track else 0.0, cout, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
             _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
-            _ptr(bn.running_var) if track else None, stream)
+            _ptr(bn.running_var) if track else None,
+            _ptr(bn.num_batches_tracked) if track else None, stream)
         _lib.check(rc, "gridgcn_bn_finalize")
-        if track:
-            bn.num_batches_tracked += 1
         st.Z.append(Z); st.scale.append(vec[0]); st.shift.append(vec[1])
         st.mean.append(vec[2]); st.rstd.append(vec[3])
         st.Wb.append(Wb); st.Wg.append(Wg)
@@ -401,10 +400,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 _ptr(sums0), _ptr(g0.detach()), _ptr(be0.detach()), E, eps,
                 bn.momentum if track else 0.0, C0, _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]),
                 _ptr(vec0[3]), _ptr(bn.running_mean) if track else None,
-                _ptr(bn.running_var) if track else None, st)
+                _ptr(bn.running_var) if track else None,
+                _ptr(bn.num_batches_tracked) if track else None, st)
             _lib.check(rc, "gridgcn_bn_finalize")
-            if track:
-                bn.num_batches_tracked += 1
             if Lp > 1:
                 sp = _chain_forward(lib, Z0, params[4:4 * Lp], bns_p[1:], eps, 0, C0,
                                     prev_bn=(vec0[0], vec0[1]))

@@ -229,7 +229,8 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
  *   dbeta = s1, dgamma = s2. */
 int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
                         float eps, float momentum, int C, float *scale, float *shift, float *mean,
-                        float *rstd, float *running_mean, float *running_var, void *stream);
+                        float *rstd, float *running_mean, float *running_var,
+                        int64_t *num_batches_tracked, void *stream);
 int gridgcn_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2,
                             float *dgamma, float *dbeta, void *stream);
 int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *bytes);

@@ -12,11 +12,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 orig = train_ops._chain_forward
 
 
-def logged(lib, x, params, bns, eps, rot=0, ndx0=0):
+def logged(lib, x, params, bns, eps, rot=0, ndx0=0, **kw):
     L = len(params) // 4
-    print("chain E=%d cin=%d couts=%s rot=%d ndx0=%d" % (
-        x.shape[0], x.shape[1], [params[4 * l].shape[0] for l in range(L)], rot, ndx0))
-    return orig(lib, x, params, bns, eps, rot, ndx0)
+    print("chain E=%d cin=%d couts=%s rot=%d ndx0=%d%s" % (
+        x.shape[0], x.shape[1], [params[4 * l].shape[0] for l in range(L)], rot, ndx0,
+        " (after a source-side first conv)" if kw.get("prev_bn") is not None else ""))
+    return orig(lib, x, params, bns, eps, rot, ndx0, **kw)
 
 
 train_ops._chain_forward = logged
