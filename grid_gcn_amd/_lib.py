@@ -92,9 +92,9 @@ def load():
     lib.gridgcn_linear_bwd.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci,
                                                    vp, cs, vp]
     lib.gridgcn_pairmax_fwd.restype = ci
-    lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, vp, vp]
+    lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, vp, vp, vp]
     lib.gridgcn_pairmax_bwd.restype = ci
-    lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_relu_apply.restype = ci
     lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, vp]
     lib.gridgcn_bn_relu_bwd_reduce.restype = ci

@@ -38,11 +38,11 @@ size_t gg_take_bwd_sorted_workspace(int B, int N, int M);
 int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, int, int, void *,
                        hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
-                   const float *, long long, int, int, float *, int *, hipStream_t);
+                   const float *, long long, int, int, float *, int *, float *, hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
                    const float *, const int *, long long, int, int, float *, float *, double *,
-                   double *, hipStream_t);
+                   double *, const float *, hipStream_t);
 
 int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
                    float *, float *, float *, float *, hipStream_t);
@@ -269,12 +269,13 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
 
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *scale_a, const float *shift_a,
-                        long long ncent, int P, int C, float *agg, int32_t *amax, void *stream)
+                        long long ncent, int P, int C, float *agg, int32_t *amax, float *zsel,
+                        void *stream)
 {
     if (!Zp || !Za || !scale_p || !shift_p || !scale_a || !shift_a || !agg || !amax || ncent < 1 ||
         P < 1 || C < 1)
         return GRIDGCN_EINVAL;
-    return gg_pairmax_fwd(Zp, Za, scale_p, shift_p, scale_a, shift_a, ncent, P, C, agg, amax,
+    return gg_pairmax_fwd(Zp, Za, scale_p, shift_p, scale_a, shift_a, ncent, P, C, agg, amax, zsel,
                           (hipStream_t)stream);
 }
 
@@ -283,12 +284,13 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
                         const float *rstd_a, const float *dagg, const int32_t *amax,
                         long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
-                        double *sums_a, void *stream)
+                        double *sums_a, const float *zsel, void *stream)
 {
-    if (!Zp || !Za || !dagg || !amax || !gp || !ga || !sums_p || !sums_a || ncent < 1 || P < 1)
+    if (((!Zp || !Za) && !zsel) || !dagg || !amax || !gp || !ga || !sums_p || !sums_a ||
+        ncent < 1 || P < 1)
         return GRIDGCN_EINVAL;
     int rc = gg_pairmax_bwd(Zp, Za, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
-                            rstd_a, dagg, amax, ncent, P, C, gp, ga, sums_p, sums_a,
+                            rstd_a, dagg, amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel,
                             (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }

@@ -44,47 +44,60 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_fwd(GGEdgeLin0 p, int epw)
     }
     const long long rows = (long long)p.B * p.Nsrc;
     const int e0 = wid * epw, e1 = (e0 + epw < p.E) ? e0 + epw : p.E;
-    constexpr int G = 4;
-    for (int e = e0; e < e1; e += G) {
-        float gx[G], gy[G], gz[G], cx[G], cy[G], cz[G], nx[G], ny[G], nz[G];
-        V y[G];
-#pragma unroll
-        for (int j = 0; j < G; j++) {
-            const int ee = e + j < e1 ? e + j : e1 - 1;
-            const int ci = ee / p.P, bi = ci / p.O;
-            long long flat = (long long)p.nebidx[ee] + (long long)bi * p.Nsrc;
-            flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
-            const float *srow = p.src + flat * p.Cs;
-            const float *cen = p.cent + (size_t)ci * p.cent_stride;
-            nx[j] = srow[0]; ny[j] = srow[1]; nz[j] = srow[2];
-            cx[j] = cen[0]; cy[j] = cen[1]; cz[j] = cen[2];
-            gx[j] = nx[j] - cx[j]; gy[j] = ny[j] - cy[j]; gz[j] = nz[j] - cz[j];
-            if (p.Ysrc) y[j] = *(const V *)(p.Ysrc + flat * C0 + cl);
+    // 64 edges at a time: every lane resolves ONE edge (index, source row, centre, geo_vec, its
+    // att_vec row) with ordinary vector loads, then the wave walks the 64 edges with the row
+    // addresses broadcast from those lanes -- no dependent scalar-load chain per edge, 8 row loads
+    // in flight
+    constexpr int G = 8;
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int nloc = e1 - eb < 64 ? e1 - eb : 64;
+        const bool ok = lane < nloc;
+        const int ee = ok ? eb + lane : e1 - 1;
+        const int ci = ee / p.P, bi = ci / p.O;
+        long long flat = (long long)p.nebidx[ee] + (long long)bi * p.Nsrc;
+        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+        const float *srow = p.src + flat * p.Cs;
+        const float *cen = p.cent + (size_t)ci * p.cent_stride;
+        const float nx = srow[0], ny = srow[1], nz = srow[2];
+        const float cx = cen[0], cy = cen[1], cz = cen[2];
+        const float gx = nx - cx, gy = ny - cy, gz = nz - cz;
+        if (ok) {
+            float4 *a = (float4 *)(p.att16 + (size_t)ee * 16);
+            a[0] = make_float4(sqrtf((gx * gx + gy * gy) + gz * gz), gx, gy, gz);
+            a[1] = make_float4(cx, cy, cz, nx);
+            a[2] = make_float4(ny, nz, 0.f, 0.f);
+            a[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        const int flat_i = (int)flat;                      // B*Nsrc < 2^31 (checked by the index ops)
+        for (int j = 0; j < nloc; j += G) {
+            V y[G];
+            float gxj[G], gyj[G], gzj[G];
 #pragma unroll
-        for (int j = 0; j < G; j++) {
-            if (e + j >= e1) break;
-            const int ee = e + j;
-            float z[VPL];
-            const float *yf = (const float *)&y[j];
-#pragma unroll
-            for (int i = 0; i < VPL; i++) {
-                float v = p.Ysrc ? yf[i] : 0.f;
-                v = fmaf(gx[j], w0[i], v);
-                v = fmaf(gy[j], w1[i], v);
-                v = fmaf(gz[j], w2[i], v);
-                v += bb[i];
-                z[i] = v;
-                s[i] += v;
-                q[i] += v * v;
+            for (int u = 0; u < G; u++) {
+                const int jj = j + u < nloc ? j + u : nloc - 1;
+                const int fl = __builtin_amdgcn_readlane(flat_i, jj);
+                gxj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gx), jj));
+                gyj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gy), jj));
+                gzj[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gz), jj));
+                if (p.Ysrc) y[u] = *(const V *)(p.Ysrc + (size_t)fl * C0 + cl);
             }
-            if (live) *(V *)(p.Z + (size_t)ee * C0 + c) = *(const V *)z;
-            if (lane < 4) {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lane == 0) a = make_float4(sqrtf((gx[j] * gx[j] + gy[j] * gy[j]) + gz[j] * gz[j]), gx[j], gy[j], gz[j]);
-                else if (lane == 1) a = make_float4(cx[j], cy[j], cz[j], nx[j]);
-                else if (lane == 2) a = make_float4(ny[j], nz[j], 0.f, 0.f);
-                *(float4 *)(p.att16 + (size_t)ee * 16 + 4 * lane) = a;
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                if (j + u >= nloc) break;
+                float z[VPL];
+                const float *yf = (const float *)&y[u];
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    float v = p.Ysrc ? yf[i] : 0.f;
+                    v = fmaf(gxj[u], w0[i], v);
+                    v = fmaf(gyj[u], w1[i], v);
+                    v = fmaf(gzj[u], w2[i], v);
+                    v += bb[i];
+                    z[i] = v;
+                    s[i] += v;
+                    q[i] += v * v;
+                }
+                if (live) *(V *)(p.Z + (size_t)(eb + j + u) * C0 + c) = *(const V *)z;
             }
         }
     }
@@ -147,32 +160,41 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
             }
         };
 
+        // 64 sorted edges at a time: every lane resolves one edge (perm, key, centre, geo_vec) with
+        // vector loads; the wave then walks them with the values broadcast from those lanes
         constexpr int G = 4;
-        for (int e = e0; e < e1; e += G) {
+        for (int eb = e0; eb < e1; eb += 64) {
+        const int nloc = e1 - eb < 64 ? e1 - eb : 64;
+        const int el = lane < nloc ? eb + lane : e1 - 1;
+        const int k_l = pk[el], m_l = pp[el];
+        const int o_l = m_l / p.P, pn_l = m_l - o_l * p.P;
+        const float4 a_l = *(const float4 *)(p.att16 + (ebase + m_l) * 16);
+        for (int jb = 0; jb < nloc; jb += G) {
+            const int e = eb + jb;
             int k[G], m[G], pn[G];
             V z[G], g[G];
             int am[G][VPL];
             float gx[G], gy[G], gz[G];
 #pragma unroll
             for (int j = 0; j < G; j++) {
-                const int ee = e + j < e1 ? e + j : e1 - 1;
-                k[j] = pk[ee];
-                m[j] = pp[ee];
+                const int jj = jb + j < nloc ? jb + j : nloc - 1;
+                k[j] = __builtin_amdgcn_readlane(k_l, jj);
+                m[j] = __builtin_amdgcn_readlane(m_l, jj);
+                pn[j] = __builtin_amdgcn_readlane(pn_l, jj);
+                gx[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l.y), jj));
+                gy[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l.z), jj));
+                gz[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l.w), jj));
                 const size_t row = ebase + m[j];
                 z[j] = *(const V *)(p.Z + row * C0 + cl);
                 if (p.dY) {
                     g[j] = *(const V *)(p.dY + row * C0 + cl);
-                    pn[j] = 0;
                 } else {
-                    const int o = m[j] / p.P;
-                    pn[j] = m[j] - o * p.P;
+                    const int o = __builtin_amdgcn_readlane(o_l, jj);
                     const size_t ar = ((size_t)b * p.O + o) * C0 + cl;
                     g[j] = *(const V *)(p.gval + ar);
 #pragma unroll
                     for (int i = 0; i < VPL; i++) am[j][i] = p.amax[ar + i];
                 }
-                const float *a = p.att16 + row * 16;
-                gx[j] = a[1]; gy[j] = a[2]; gz[j] = a[3];
             }
 #pragma unroll
             for (int j = 0; j < G; j++) {
@@ -209,6 +231,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
 #pragma unroll
                 for (int i = 0; i < VPL; i++) acc[i] += dz[i];
             }
+        }
         }
         flush(cur, rs, e1);
     }

@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
                                                         const float *__restrict__ sha,
                                                         long long ncent, int P, int C,
                                                         float *__restrict__ agg,
-                                                        int *__restrict__ amax)
+                                                        int *__restrict__ amax,
+                                                        float *__restrict__ zsel)
 {
     const long long total = ncent * C;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
@@ -29,16 +30,21 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
         const int c = (int)(t - o * C);
         const float a1 = scp[c], b1 = shp[c], a2 = sca[c], b2 = sha[c];
         const float *zp = Zp + (o * P) * C + c, *za = Za + (o * P) * C + c;
-        float best = -__builtin_inff();
+        float best = -__builtin_inff(), zps = zp[0], zas = za[0];
         int bi = 0;
         for (int p = 0; p < P; p++) {
-            float y1 = fmaxf(zp[(size_t)p * C] * a1 + b1, 0.f);
-            float y2 = fmaxf(za[(size_t)p * C] * a2 + b2, 0.f);
+            const float z1 = zp[(size_t)p * C], z2 = za[(size_t)p * C];
+            float y1 = fmaxf(z1 * a1 + b1, 0.f);
+            float y2 = fmaxf(z2 * a2 + b2, 0.f);
             float v = y1 * y2;
-            if (v > best) { best = v; bi = p; }
+            if (v > best) { best = v; bi = p; zps = z1; zas = z2; }
         }
         agg[t] = best;
         amax[t] = bi;
+        if (zsel) {              // the two pre-activations at the arg max: backward needs no gather
+            zsel[t] = zps;
+            zsel[total + t] = zas;
+        }
     }
 }
 
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     const float *__restrict__ sca, const float *__restrict__ sha, const float *__restrict__ mua,
     const float *__restrict__ rsa, const float *__restrict__ dagg, const int *__restrict__ amax,
     long long ncent, int P, int C, float *__restrict__ gp, float *__restrict__ ga,
-    double *__restrict__ sums_p, double *__restrict__ sums_a)
+    double *__restrict__ sums_p, double *__restrict__ sums_a, const float *__restrict__ zsel)
 {
     __shared__ float sh[4][256];
     const int tid = threadIdx.x;
@@ -60,8 +66,15 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     float s1p = 0.f, s2p = 0.f, s1a = 0.f, s2a = 0.f;
     for (long long o = (long long)blockIdx.x * rpp + rr; o < ncent; o += (long long)gridDim.x * rpp) {
         const long long t = o * C + c;
-        const long long e = o * P + amax[t];
-        const float zp = Zp[e * C + c], za = Za[e * C + c];
+        float zp, za;
+        if (zsel) {
+            zp = zsel[t];
+            za = zsel[ncent * C + t];
+        } else {
+            const long long e = o * P + amax[t];
+            zp = Zp[e * C + c];
+            za = Za[e * C + c];
+        }
         const float y1 = fmaxf(zp * a1 + b1, 0.f), y2 = fmaxf(za * a2 + b2, 0.f);
         const float g = dagg[t];
         // gradient w.r.t. the post-ReLU activations; the ReLU mask (y > 0) is applied by the
@@ -254,11 +267,12 @@ int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float 
 
 int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *sca, const float *sha, long long ncent, int P, int C, float *agg,
-                   int *amax, hipStream_t st)
+                   int *amax, float *zsel, hipStream_t st)
 {
     long long nb = (ncent * C + 255) / 256;
     int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
-    gg_k_pairmax_fwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax);
+    gg_k_pairmax_fwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
+                                           zsel);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -266,13 +280,13 @@ int gg_pairmax_bwd(const float *Zp, const float *Za, const float *scp, const flo
                    const float *mup, const float *rsp, const float *sca, const float *sha,
                    const float *mua, const float *rsa, const float *dagg, const int *amax,
                    long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
-                   double *sums_a, hipStream_t st)
+                   double *sums_a, const float *zsel, hipStream_t st)
 {
     if (C > 256 || 256 % C != 0) return 1;
     const int rpp = 256 / C;
     long long nb = (ncent + rpp * 8 - 1) / (rpp * 8);
     int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
     gg_k_pairmax_bwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, mup, rsp, sca, sha, mua, rsa, dagg,
-                                           amax, ncent, P, C, gp, ga, sums_p, sums_a);
+                                           amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

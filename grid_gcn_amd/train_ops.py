@@ -316,14 +316,15 @@ class _EdgeBlockTrain(torch.autograd.Function):
             C = sp.Z[-1].shape[1]
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             rc = lib.gridgcn_pairmax_fwd(_ptr(sp.Z[-1]), _ptr(sa.Z[-1]), _ptr(sp.scale[-1]),
                                          _ptr(sp.shift[-1]), _ptr(sa.scale[-1]), _ptr(sa.shift[-1]),
-                                         ncent, P, C, _ptr(agg), _ptr(amax), _stream(nf))
+                                         ncent, P, C, _ptr(agg), _ptr(amax), _ptr(zsel), _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_fwd")
         ctx.dims = (Lp, La, ncent, P, rot, params[0].shape[1], params[4 * Lp].shape[1])
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.save_for_backward(
-            nf, att_vec, amax,
+            nf, att_vec, amax, zsel,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
             *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
         ctx.mark_non_differentiable(amax)
@@ -334,8 +335,8 @@ class _EdgeBlockTrain(torch.autograd.Function):
         lib = _lib.load()
         Lp, La, ncent, P, rot, cwp, cwa = ctx.dims
         t = ctx.saved_tensors
-        nf, att_vec, amax = t[0], t[1], t[2]
-        o = 3
+        nf, att_vec, amax, zsel = t[0], t[1], t[2], t[3]
+        o = 4
         pZ, pS, pH, pM, pR, pWb, pWg, pWx = (t[o + k * Lp:o + (k + 1) * Lp] for k in range(8))
         o += 8 * Lp
         aZ, aS, aH, aM, aR, aWb, aWg, aWx = (t[o + k * La:o + (k + 1) * La] for k in range(8))
@@ -351,7 +352,7 @@ class _EdgeBlockTrain(torch.autograd.Function):
                                          _ptr(pM[-1]), _ptr(pR[-1]), _ptr(aS[-1]), _ptr(aH[-1]),
                                          _ptr(aM[-1]), _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent,
                                          P, C, _ptr(gp), _ptr(ga), _ptr(sums_p), _ptr(sums_a),
-                                         _stream(nf))
+                                         _ptr(zsel), _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_bwd")
             dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0],
                                            sums_p, None, (amax, gp, P), ctx.needs_input_grad[0],
@@ -415,14 +416,15 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             ncent = B * O
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
                                          _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
-                                         _ptr(agg), _ptr(amax), st)
+                                         _ptr(agg), _ptr(amax), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_fwd")
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1])
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.save_for_backward(
-            src, nebidx, att16, amax, Z0, vec0, W0,
+            src, nebidx, att16, amax, Z0, vec0, W0, zsel,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
             *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
         ctx.mark_non_differentiable(amax)
@@ -433,8 +435,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         lib = _lib.load()
         Lp, La, B, Nsrc, Cs, O, P, C0, rot, cwa = ctx.dims
         t = ctx.saved_tensors
-        src, nebidx, att16, amax, Z0, vec0, W0 = t[:7]
-        o = 7
+        src, nebidx, att16, amax, Z0, vec0, W0, zsel = t[:8]
+        o = 8
         L1 = Lp - 1
         pZ, pS, pH, pM, pR, pWb, pWg, pWx = (t[o + k * L1:o + (k + 1) * L1] for k in range(8))
         o += 8 * L1
@@ -455,7 +457,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             rc = lib.gridgcn_pairmax_bwd(_ptr(Zl), _ptr(aZ[-1]), _ptr(lS), _ptr(lH), _ptr(lM),
                                          _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
                                          _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C, _ptr(gp),
-                                         _ptr(ga), _ptr(sums_p), _ptr(sums_a), st)
+                                         _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_bwd")
             _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1],
                                          sums_a, None, (amax, ga, P), False, cwa, 0)

@@ -257,13 +257,16 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
  *   edge, and the BatchNorm-backward sums (as gridgcn_bn_relu_bwd_reduce) of both layers. */
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *scale_a, const float *shift_a,
-                        long long ncent, int P, int C, float *agg, int32_t *amax, void *stream);
+                        long long ncent, int P, int C, float *agg, int32_t *amax, float *zsel,
+                        void *stream);
+/* zsel (optional, [2][ncent*C]): the pre-BatchNorm values of Zp and Za at the arg max, written by
+ * the forward and read by the backward instead of gathering them again from Zp / Za. */
 int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *mean_p, const float *rstd_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
                         const float *rstd_a, const float *dagg, const int32_t *amax,
                         long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
-                        double *sums_a, void *stream);
+                        double *sums_a, const float *zsel, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
                           long long E, int C, void *stream);
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
