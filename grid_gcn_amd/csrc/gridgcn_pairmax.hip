@@ -48,6 +48,55 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
     }
 }
 
+// same, four channels per thread with 16-byte loads (C % 4 == 0)
+__global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict__ Zp,
+                                                         const float *__restrict__ Za,
+                                                         const float *__restrict__ scp,
+                                                         const float *__restrict__ shp,
+                                                         const float *__restrict__ sca,
+                                                         const float *__restrict__ sha,
+                                                         long long ncent, int P, int C,
+                                                         float *__restrict__ agg,
+                                                         int *__restrict__ amax,
+                                                         float *__restrict__ zsel)
+{
+    const int C4 = C >> 2;
+    const long long total4 = ncent * C4;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total4;
+         t += (long long)gridDim.x * 256) {
+        const long long o = t / C4;
+        const int c = (int)(t - o * C4) * 4;
+        const float4 a1 = *(const float4 *)(scp + c), b1 = *(const float4 *)(shp + c);
+        const float4 a2 = *(const float4 *)(sca + c), b2 = *(const float4 *)(sha + c);
+        const float *zp = Zp + (o * P) * C + c, *za = Za + (o * P) * C + c;
+        float best[4], zps[4], zas[4];
+        int bi[4];
+        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+        const float a2v[4] = {a2.x, a2.y, a2.z, a2.w}, b2v[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { best[i] = -__builtin_inff(); bi[i] = 0; zps[i] = zp[i]; zas[i] = za[i]; }
+        for (int p = 0; p < P; p++) {
+            const float4 z1 = *(const float4 *)(zp + (size_t)p * C);
+            const float4 z2 = *(const float4 *)(za + (size_t)p * C);
+            const float z1v[4] = {z1.x, z1.y, z1.z, z1.w}, z2v[4] = {z2.x, z2.y, z2.z, z2.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float y1 = fmaxf(z1v[i] * a1v[i] + b1v[i], 0.f);
+                const float y2 = fmaxf(z2v[i] * a2v[i] + b2v[i], 0.f);
+                const float v = y1 * y2;
+                if (v > best[i]) { best[i] = v; bi[i] = p; zps[i] = z1v[i]; zas[i] = z2v[i]; }
+            }
+        }
+        const long long e = o * C + c;
+        *(float4 *)(agg + e) = make_float4(best[0], best[1], best[2], best[3]);
+        *(int4 *)(amax + e) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+        if (zsel) {
+            *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
+            *(float4 *)(zsel + ncent * C + e) = make_float4(zas[0], zas[1], zas[2], zas[3]);
+        }
+    }
+}
+
 // thread = (centre strip, channel); requires 256 % C == 0 (C <= 256) like gg_k_bn_bwd_reduce
 __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     const float *__restrict__ Zp, const float *__restrict__ Za, const float *__restrict__ scp,
@@ -269,6 +318,13 @@ int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const flo
                    const float *sca, const float *sha, long long ncent, int P, int C, float *agg,
                    int *amax, float *zsel, hipStream_t st)
 {
+    if ((C & 3) == 0) {
+        long long nb = (ncent * (C / 4) + 255) / 256;
+        int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
+        gg_k_pairmax_fwd4<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
+                                                zsel);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     long long nb = (ncent * C + 255) / 256;
     int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
     gg_k_pairmax_fwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
