@@ -18,7 +18,7 @@ EXPORTS = [
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
     "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
     "gridgcn_take_backward_workspace_bytes",
-    "gridgcn_edge_lin0_forward", "gridgcn_edge_lin0_backward",
+    "gridgcn_edge_lin0_forward", "gridgcn_edge_lin0_backward", "gridgcn_pairmax_fwd_src",
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
@@ -119,7 +119,10 @@ def load():
     lib.gridgcn_edge_lin0_forward.restype = ci
     lib.gridgcn_edge_lin0_forward.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp] * 6
     lib.gridgcn_edge_lin0_backward.restype = ci
-    lib.gridgcn_edge_lin0_backward.argtypes = [vp] * 12 + [ci] * 5 + [vp, vp, vp, cs, vp]
+    lib.gridgcn_edge_lin0_backward.argtypes = [vp] * 15 + [ci] * 5 + [vp, vp, vp, cs, vp]
+    lib.gridgcn_pairmax_fwd_src.restype = ci
+    lib.gridgcn_pairmax_fwd_src.argtypes = [vp] * 5 + [ci, ci, ci] + [vp] * 5 + [ll, ci, ci, vp, vp,
+                                                                              vp, vp]
     lib.gridgcn_softmax_ce_fwd.restype = ci
     lib.gridgcn_softmax_ce_fwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp]
     lib.gridgcn_softmax_ce_bwd.restype = ci

@@ -39,6 +39,9 @@ int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, 
                        hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, long long, int, int, float *, int *, float *, hipStream_t);
+int gg_pairmax_fwd_src(const float *, const int *, const float *, const float *, const float *, int,
+                       int, int, const float *, const float *, const float *, const float *,
+                       const float *, long long, int, int, float *, int *, float *, hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
                    const float *, const int *, long long, int, int, float *, float *, double *,
@@ -279,6 +282,22 @@ int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                           (hipStream_t)stream);
 }
 
+int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const float *att16,
+                            const float *Wg, const float *b, int B, int Nsrc, int O,
+                            const float *Za, const float *scale_p, const float *shift_p,
+                            const float *scale_a, const float *shift_a, long long ncent, int P,
+                            int C, float *agg, int32_t *amax, float *zsel, void *stream)
+{
+    if ((!Ysrc && !Wg) || !nebidx || !att16 || !b || !Za || !scale_p || !shift_p || !scale_a ||
+        !shift_a || !agg || !amax || ncent < 1 || P < 1 || C < 1 || B < 1 || Nsrc < 1 || O < 1 ||
+        ncent != (long long)B * O)
+        return GRIDGCN_EINVAL;
+    const int rc = gg_pairmax_fwd_src(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Za, scale_p, shift_p,
+                                      scale_a, shift_a, ncent, P, C, agg, amax, zsel,
+                                      (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *mean_p, const float *rstd_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
@@ -434,7 +453,7 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
                               int P, int C0, const float *Wg, const float *b, float *Z0,
                               float *att16, double *sums, void *stream)
 {
-    if (!src || !nebidx || !cent || !b || !Z0 || !att16 || !sums || B < 1 || Nsrc < 1 || Cs < 3 ||
+    if (!src || !nebidx || !cent || !b || !att16 || !sums || B < 1 || Nsrc < 1 || Cs < 3 ||
         O < 1 || P < 1 || C0 < 1 || (!Ysrc && !Wg) || (long long)B * O * P >= (1ll << 31))
         return GRIDGCN_EINVAL;
     GGEdgeLin0 p;
@@ -445,19 +464,21 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
-int gridgcn_edge_lin0_backward(const float *Z0, const float *dY, const int32_t *amax,
+int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
+                               const float *dY, const int32_t *amax,
                                const float *gval, const float *scale, const float *shift,
                                const float *mean, const float *rstd, const float *m1,
                                const float *m2, const float *att16, const int32_t *nebidx, int B,
                                int Nsrc, int O, int P, int C0, float *dYsrc, double *dWg,
                                void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (!Z0 || (!dY && (!amax || !gval)) || !scale || !shift || !mean || !rstd || !m1 || !m2 ||
-        !att16 || !nebidx || !dYsrc || B < 1 || Nsrc < 1 || O < 1 || P < 1 || C0 < 1)
+    if ((!Z0 && (!b || (!Ysrc && !Wg))) || (!dY && (!amax || !gval)) || !scale || !shift || !mean ||
+        !rstd || !m1 || !m2 || !att16 || !nebidx || !dYsrc || B < 1 || Nsrc < 1 || O < 1 || P < 1 ||
+        C0 < 1)
         return GRIDGCN_EINVAL;
     if (!workspace || workspace_bytes < gg_csr_workspace(B, Nsrc, O * P)) return GRIDGCN_EWORKSPACE;
     GGEdgeLin0Bwd p;
-    p.Z = Z0; p.dY = dY; p.amax = amax; p.gval = gval; p.scale = scale; p.shift = shift;
+    p.Z = Z0; p.Ysrc = Ysrc; p.Wg = Wg; p.b = b; p.dY = dY; p.amax = amax; p.gval = gval; p.scale = scale; p.shift = shift;
     p.mean = mean; p.rstd = rstd; p.m1 = m1; p.m2 = m2; p.att16 = att16; p.index = nebidx;
     p.perm = nullptr; p.keys = nullptr; p.rowptr = nullptr; p.dYsrc = dYsrc; p.dWg = dWg;
     p.B = B; p.N = Nsrc; p.O = O; p.P = P; p.C0 = C0; p.M = O * P; p.cpc = 0;

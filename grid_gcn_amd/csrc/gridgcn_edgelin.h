@@ -9,14 +9,15 @@ struct GGEdgeLin0 {
     const float *cent;   // centre ci at cent + ci*cent_stride
     const float *Wg;     // [3][C0] geo_vec weights or nullptr
     const float *b;      // [C0]
-    float *Z;            // [E][C0]
+    float *Z;            // [E][C0] (nullptr: statistics and att16 only)
     float *att16;        // [E][16]
     double *sums;        // [2][C0]
     int cent_stride, B, Nsrc, Cs, O, P, C0, E;
 };
 
 struct GGEdgeLin0Bwd {
-    const float *Z;       // [E][C0]
+    const float *Z;       // [E][C0], or nullptr: recomputed from (Ysrc, Wg, b) as in the forward
+    const float *Ysrc, *Wg, *b;
     const float *dY;      // dense upstream gradient [E][C0] (nullptr: sparse)
     const int *amax;      // sparse: [B*O][C0] arg-max neighbour, value
     const float *gval;

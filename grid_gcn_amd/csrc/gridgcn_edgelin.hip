@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_fwd(GGEdgeLin0 p, int epw)
                     s[i] += v;
                     q[i] += v * v;
                 }
-                if (live) *(V *)(p.Z + (size_t)(eb + j + u) * C0 + c) = *(const V *)z;
+                if (live && p.Z) *(V *)(p.Z + (size_t)(eb + j + u) * C0 + c) = *(const V *)z;
             }
         }
     }
@@ -127,6 +127,15 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
     const bool live = c < C0;
     const int cl = live ? c : 0;
     float sc[VPL], sh[VPL], mu[VPL], bz[VPL], cz[VPL], wg[3][VPL], acc[VPL];
+    float w0[VPL], w1[VPL], w2[VPL], bb[VPL];        // forward constants (Z recomputed)
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const bool rw = !p.Z && live;
+        w0[i] = (rw && p.Wg) ? p.Wg[cl + i] : 0.f;
+        w1[i] = (rw && p.Wg) ? p.Wg[C0 + cl + i] : 0.f;
+        w2[i] = (rw && p.Wg) ? p.Wg[2 * C0 + cl + i] : 0.f;
+        bb[i] = rw ? p.b[cl + i] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         const float s = live ? p.scale[cl + i] : 0.f;
@@ -185,7 +194,38 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
                 gy[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l.z), jj));
                 gz[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l.w), jj));
                 const size_t row = ebase + m[j];
-                z[j] = *(const V *)(p.Z + row * C0 + cl);
+                if (p.Z) {
+                    z[j] = *(const V *)(p.Z + row * C0 + cl);
+                } else {
+                    // recompute as the forward did: source row = destination row of the edge
+                    long long flat;
+                    if (k[j] <= N) {
+                        flat = (long long)b * N - 1 + k[j];
+                        if (flat < 0) flat = 0;
+                    } else {
+                        flat = (long long)p.index[row] + (long long)b * N;
+                        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+                    }
+                    float zr[VPL];
+                    if (p.Ysrc) {
+                        const V y = *(const V *)(p.Ysrc + flat * C0 + cl);
+                        const float *yf = (const float *)&y;
+#pragma unroll
+                        for (int i = 0; i < VPL; i++) zr[i] = yf[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VPL; i++) zr[i] = 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < VPL; i++) {
+                        float v = zr[i];
+                        v = fmaf(gx[j], w0[i], v);
+                        v = fmaf(gy[j], w1[i], v);
+                        v = fmaf(gz[j], w2[i], v);
+                        zr[i] = v + bb[i];
+                    }
+                    z[j] = *(const V *)zr;
+                }
                 if (p.dY) {
                     g[j] = *(const V *)(p.dY + row * C0 + cl);
                 } else {

@@ -48,6 +48,89 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
     }
 }
 
+// Zp of a single-layer point MLP is never stored (gridgcn_edgelin.hip): it is recomputed here,
+// bit-identical to the statistics pass, from the per-source-point product and geo_vec:
+//   zp[e, c] = ((Ysrc[src(e), c] + gx*Wg[0,c]) + gy*Wg[1,c]) + gz*Wg[2,c] + b[c]
+struct GGPtRecompute {
+    const float *Ysrc;    // [B*Nsrc][C]   (nullptr: no feature term)
+    const int *nebidx;    // [ncent*P]
+    const float *att16;   // [ncent*P][16], geo_vec at 1..3
+    const float *Wg;      // [3][C] or nullptr
+    const float *b;       // [C]
+    int Nsrc, O, B;
+};
+
+__global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
+                                                             const float *__restrict__ Za,
+                                                             const float *__restrict__ scp,
+                                                             const float *__restrict__ shp,
+                                                             const float *__restrict__ sca,
+                                                             const float *__restrict__ sha,
+                                                             long long ncent, int P, int C,
+                                                             float *__restrict__ agg,
+                                                             int *__restrict__ amax,
+                                                             float *__restrict__ zsel)
+{
+    const int C4 = C >> 2;
+    const long long total4 = ncent * C4;
+    const long long rows = (long long)r.B * r.Nsrc;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total4;
+         t += (long long)gridDim.x * 256) {
+        const long long o = t / C4;
+        const int c = (int)(t - o * C4) * 4;
+        const int bi = (int)(o / r.O);
+        const float4 a1 = *(const float4 *)(scp + c), b1 = *(const float4 *)(shp + c);
+        const float4 a2 = *(const float4 *)(sca + c), b2 = *(const float4 *)(sha + c);
+        const float4 bb = *(const float4 *)(r.b + c);
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0;
+        if (r.Wg) {
+            w0 = *(const float4 *)(r.Wg + c);
+            w1 = *(const float4 *)(r.Wg + C + c);
+            w2 = *(const float4 *)(r.Wg + 2 * C + c);
+        }
+        const float *za = Za + (o * P) * C + c;
+        float best[4], zps[4], zas[4];
+        int bi4[4];
+        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+        const float a2v[4] = {a2.x, a2.y, a2.z, a2.w}, b2v[4] = {b2.x, b2.y, b2.z, b2.w};
+        const float w0v[4] = {w0.x, w0.y, w0.z, w0.w}, w1v[4] = {w1.x, w1.y, w1.z, w1.w};
+        const float w2v[4] = {w2.x, w2.y, w2.z, w2.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { best[i] = -__builtin_inff(); bi4[i] = 0; zps[i] = 0.f; zas[i] = 0.f; }
+        for (int p = 0; p < P; p++) {
+            const long long e = o * P + p;
+            long long flat = (long long)r.nebidx[e] + (long long)bi * r.Nsrc;
+            flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+            const float4 g = *(const float4 *)(r.att16 + e * 16);       // (dist, gx, gy, gz)
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r.Ysrc) y = *(const float4 *)(r.Ysrc + flat * C + c);
+            const float4 z2 = *(const float4 *)(za + (size_t)p * C);
+            const float yv[4] = {y.x, y.y, y.z, y.w}, z2v[4] = {z2.x, z2.y, z2.z, z2.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float z1 = yv[i];
+                z1 = fmaf(g.y, w0v[i], z1);
+                z1 = fmaf(g.z, w1v[i], z1);
+                z1 = fmaf(g.w, w2v[i], z1);
+                z1 += bv[i];
+                const float y1 = fmaxf(z1 * a1v[i] + b1v[i], 0.f);
+                const float y2 = fmaxf(z2v[i] * a2v[i] + b2v[i], 0.f);
+                const float v = y1 * y2;
+                const bool upd = v > best[i];
+                if (upd || p == 0) { zps[i] = z1; zas[i] = z2v[i]; }
+                if (upd) { best[i] = v; bi4[i] = p; }
+            }
+        }
+        const long long e = o * C + c;
+        *(float4 *)(agg + e) = make_float4(best[0], best[1], best[2], best[3]);
+        *(int4 *)(amax + e) = make_int4(bi4[0], bi4[1], bi4[2], bi4[3]);
+        if (zsel) {
+            *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
+            *(float4 *)(zsel + ncent * C + e) = make_float4(zas[0], zas[1], zas[2], zas[3]);
+        }
+    }
+}
+
 // same, four channels per thread with 16-byte loads (C % 4 == 0)
 __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict__ Zp,
                                                          const float *__restrict__ Za,
@@ -311,6 +394,22 @@ int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float 
                        float *dbeta, hipStream_t st)
 {
     gg_k_bn_bwd_finalize<<<(C + 255) / 256, 256, 0, st>>>(sums, E, C, m1, m2, dgamma, dbeta);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16, const float *Wg,
+                       const float *b, int B, int Nsrc, int O, const float *Za, const float *scp,
+                       const float *shp, const float *sca, const float *sha, long long ncent, int P,
+                       int C, float *agg, int *amax, float *zsel, hipStream_t st)
+{
+    if (C & 3) return 1;
+    GGPtRecompute r;
+    r.Ysrc = Ysrc; r.nebidx = nebidx; r.att16 = att16; r.Wg = Wg; r.b = b;
+    r.Nsrc = Nsrc; r.O = O; r.B = B;
+    long long nb = (ncent * (C / 4) + 255) / 256;
+    int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
+    gg_k_pairmax_fwd4_src<<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
+                                                zsel);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

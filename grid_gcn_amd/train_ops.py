@@ -35,6 +35,8 @@ DIRECT_FWD = os.environ.get("GG_FWD_LDS", "0") != "1"
 DIRECT_DX = os.environ.get("GG_DX_LDS", "0") != "1"
 # first conv of the point MLP applied to the source points and gathered (csrc/gridgcn_edgelin.hip)
 SRC_FIRST_CONV = os.environ.get("GG_EDGE_GEMM", "0") != "1"
+# ... and, for single-layer point MLPs, recomputed by its consumers instead of stored
+NO_Z0 = os.environ.get("GG_STORE_Z0", "0") != "1"
 
 
 def supported(layers, x):
@@ -385,14 +387,21 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             feat = src.detach()[..., 4:].reshape(R, Cf)
             Wf = W0.detach()[:, rot:]
             Ysrc = torch.matmul(feat, Wf.t()).contiguous()          # [R, C0]: once per source point
-            Wg = W0.detach()[:, :3].t().contiguous() if geo else None
-            Z0 = torch.empty((E, C0), dtype=torch.float32, device=dev)
+            # rows 0..2: geo_vec weights [3][C0] (zeros without geo_vec), row 3: bias
+            wgb = torch.zeros((4, C0), dtype=torch.float32, device=dev)
+            if geo:
+                wgb[:3] = W0.detach()[:, :3].t()
+            wgb[3] = b0.detach()
+            Wg = wgb if geo else None
+            # a single-layer point MLP never materialises Z0: its consumers recompute it
+            noz = Lp == 1 and NO_Z0 and C0 % 4 == 0
+            Z0 = None if noz else torch.empty((E, C0), dtype=torch.float32, device=dev)
             att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
             sums0 = torch.zeros(2 * C0, dtype=torch.float64, device=dev)
             rc = lib.gridgcn_edge_lin0_forward(
                 _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P,
-                C0, _ptr(Wg) if geo else None, _ptr(b0.detach()), _ptr(Z0), _ptr(att16),
-                _ptr(sums0), st)
+                C0, _ptr(Wg) if geo else None, _ptr(wgb[3]), None if noz else _ptr(Z0),
+                _ptr(att16), _ptr(sums0), st)
             _lib.check(rc, "gridgcn_edge_lin0_forward")
             vec0 = torch.empty((4, C0), dtype=torch.float32, device=dev)
             bn = bns_p[0]
@@ -412,19 +421,25 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 sp = _Chain()
                 Zl, scl, shl = Z0, vec0[0], vec0[1]
             sa = _chain_forward(lib, att16, params[4 * Lp:], bns_a, eps)
-            C = Zl.shape[1]
+            C = sa.Z[-1].shape[1]
             ncent = B * O
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
-            rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
-                                         _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
-                                         _ptr(agg), _ptr(amax), _ptr(zsel), st)
+            if noz:
+                rc = lib.gridgcn_pairmax_fwd_src(
+                    _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
+                    B, Nsrc, O, _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl), _ptr(sa.scale[-1]),
+                    _ptr(sa.shift[-1]), ncent, P, C, _ptr(agg), _ptr(amax), _ptr(zsel), st)
+            else:
+                rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
+                                             _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
+                                             _ptr(agg), _ptr(amax), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_fwd")
-        ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1])
+        ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.save_for_backward(
-            src, nebidx, att16, amax, Z0, vec0, W0, zsel,
+            src, nebidx, att16, amax, Ysrc if noz else Z0, vec0, W0, zsel, wgb,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
             *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
         ctx.mark_non_differentiable(amax)
@@ -433,10 +448,13 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dagg):
         lib = _lib.load()
-        Lp, La, B, Nsrc, Cs, O, P, C0, rot, cwa = ctx.dims
+        Lp, La, B, Nsrc, Cs, O, P, C0, rot, cwa, noz = ctx.dims
         t = ctx.saved_tensors
-        src, nebidx, att16, amax, Z0, vec0, W0, zsel = t[:8]
-        o = 8
+        src, nebidx, att16, amax, Z0, vec0, W0, zsel, wgb = t[:9]
+        Ysrc = None
+        if noz:
+            Ysrc, Z0 = Z0, None
+        o = 9
         L1 = Lp - 1
         pZ, pS, pH, pM, pR, pWb, pWg, pWx = (t[o + k * L1:o + (k + 1) * L1] for k in range(8))
         o += 8 * L1
@@ -446,7 +464,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         Zl = pZ[-1] if L1 else Z0
         lS, lH, lM, lR = (pS[-1], pH[-1], pM[-1], pR[-1]) if L1 else (vec0[0], vec0[1], vec0[2],
                                                                         vec0[3])
-        C = Zl.shape[1]
+        C = aZ[-1].shape[1]
         dagg = dagg.contiguous().reshape(ncent, C)
         with torch.cuda.device(dev):
             st = _stream(src)
@@ -454,7 +472,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             ga = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             sums_pa = torch.zeros((2, 2 * C), dtype=torch.float64, device=dev)
             sums_p, sums_a = sums_pa[0], sums_pa[1]
-            rc = lib.gridgcn_pairmax_bwd(_ptr(Zl), _ptr(aZ[-1]), _ptr(lS), _ptr(lH), _ptr(lM),
+            # (the arg-max pre-activations come from zsel: Zl may not exist)
+            rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None, _ptr(aZ[-1]),
+                                         _ptr(lS), _ptr(lH), _ptr(lM),
                                          _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
                                          _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C, _ptr(gp),
                                          _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
@@ -480,7 +500,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             lib.gridgcn_take_backward_workspace_bytes(B, Nsrc, O * P, ctypes.byref(nbytes))
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
             rc = lib.gridgcn_edge_lin0_backward(
-                _ptr(Z0), _ptr(dY0) if dY0 is not None else None, sparse0[0], sparse0[1],
+                _ptr(Z0) if Z0 is not None else None, _ptr(Ysrc) if noz else None,
+                _ptr(wgb) if (noz and rot) else None, _ptr(wgb[3]) if noz else None,
+                _ptr(dY0) if dY0 is not None else None, sparse0[0], sparse0[1],
                 _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]),
                 _ptr(att16), _ptr(nebidx), B, Nsrc, O, P, C0, _ptr(dYsrc),
                 _ptr(dWg) if rot else None, _ptr(ws), nbytes.value, st)

@@ -168,7 +168,16 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
                               const float *cent, int cent_stride, int B, int Nsrc, int Cs, int O,
                               int P, int C0, const float *Wg, const float *b, float *Z0,
                               float *att16, double *sums, void *stream);
-int gridgcn_edge_lin0_backward(const float *Z0, const float *dY, const int32_t *amax,
+/* Z0 may be NULL in both calls: the forward then only produces the statistics and att16, and the
+ * consumers (gridgcn_pairmax_fwd_src, the backward) recompute Z0 from (Ysrc, Wg, b) with the same
+ * operation order, i.e. bit-identical -- the [E, C0] tensor never exists (single-layer point MLPs). */
+int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const float *att16,
+                            const float *Wg, const float *b, int B, int Nsrc, int O,
+                            const float *Za, const float *scale_p, const float *shift_p,
+                            const float *scale_a, const float *shift_a, long long ncent, int P,
+                            int C, float *agg, int32_t *amax, float *zsel, void *stream);
+int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
+                               const float *dY, const int32_t *amax,
                                const float *gval, const float *scale, const float *shift,
                                const float *mean, const float *rstd, const float *m1,
                                const float *m2, const float *att16, const int32_t *nebidx, int B,
