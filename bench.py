@@ -200,30 +200,43 @@ def main():
             "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
             "algorithmic_flops_per_launch": flops, "ms_per_launch": ms_k,
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
-        # ---- dominant kernels of the TIMED training step: backward of that layer's pt conv --
-        #      gg_k_linear_dx_direct (dZ formed in registers, dX = dZ*W^T for the feature columns)
-        #      + gg_k_linear_dw_direct (dW = dZ^T*X over the rows) + its reduce, fp32 MFMA.  The
-        #      edge rows are [features | geo_vec | pad]: cin real columns in a row of cin_pad ----
+        # ---- dominant kernels of the TIMED training step.  The point conv of this layer runs on
+        #      the source points (gridgcn_edgelin.hip), so the largest per-edge GEMMs left are those
+        #      of the attention MLP: backward of its C/4 -> C conv = gg_k_linear_dx_direct (dZ
+        #      formed in registers, dX) + gg_k_linear_dw_direct (dW over the rows) + reduce.  With
+        #      K = C/4 they are HBM bound: Z [E,C] is read by both kernels. ----
         from grid_gcn_amd import train_ops
-        cin_b = layer.pt_mlp[-1].lin.in_features
-        c_b = layer.pt_mlp[-1].lin.out_features
-        cin_pad = (cin_b + 7) & ~7
-        nfeat = cin_b - 3 if (layer.has_feats and layer.localfdim != 0) else cin_b
+        cin_b = layer.att2[0].lin.in_features
+        c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
-        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_pad, c_b, iters=10, device=dev,
-                                         ndx=nfeat)
+        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=10, device=dev)
         e_b = float(ncent_b * p_b)
-        flops_b = 2.0 * e_b * c_b * (nfeat + cin_b)          # dX (feature columns) + dW
-        tf_b = flops_b / (ms_b * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gg_k_linear_dx_direct + gg_k_linear_dw_direct "
-                           "+ gg_k_dw_reduce_direct (backward of the %d->%d conv of GridConv %s over "
-                           "%d edges: BN/ReLU backward formed in registers, dX for the %d feature "
-                           "columns, dW)" % (cin_b, c_b, name, ncent_b * p_b, nfeat),
-                           "achieved": tf_b, "peak": 157.3, "unit": "TFLOP/s",
-                           "frac": tf_b / 157.3, "traffic": None,
-                           "algorithmic_flops_per_launch": flops_b, "ms_per_launch": ms_b,
-                           "algorithmic_bytes_per_launch": 4.0 * e_b * (2 * c_b + cin_pad + nfeat),
+        # dX kernel: read Z [E,C], the sparse upstream gradient (amax, gval) [ncent,C] and the
+        # previous layer's raw output [E,cin] (BatchNorm-backward sums), write dX [E,cin];
+        # dW kernel: read Z, (amax, gval) and the previous layer's output
+        bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 8.0 * ncent_b * c_b + \
+            4.0 * e_b * (c_b + cin_b) + 8.0 * ncent_b * c_b
+        gbs_b = bytes_b / (ms_b * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "gg_k_linear_dx_direct + gg_k_linear_dw_direct "
+                           "+ gg_k_dw_reduce_direct (backward of the %d->%d attention conv of "
+                           "GridConv %s over %d edges: BN/ReLU backward formed in registers from the "
+                           "sparse arg-max gradient, dX, dW)" % (cin_b, c_b, name, ncent_b * p_b),
+                           "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs_b / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
+                           "algorithmic_flops_per_launch": 4.0 * e_b * cin_b * c_b,
                            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        # the largest MFMA-bound kernel of the step: forward of the 256->128 update conv over
+        # all B*N points (previous BatchNorm+ReLU applied while loading, statistics epilogue)
+        e_f, cin_f, c_f = B * a.points, 256, 128
+        ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=10, device=dev)
+        tf_f = 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12
+        out["roofline_mfma"] = {"bound": "mfma", "kernel": "gg_k_linear_fwd_direct (%d->%d conv + "
+                                "BN/ReLU prologue + statistics over %d rows)" % (cin_f, c_f, e_f),
+                                "achieved": tf_f, "peak": 157.3, "unit": "TFLOP/s",
+                                "frac": tf_f / 157.3, "traffic": None,
+                                "algorithmic_flops_per_launch": 2.0 * e_f * cin_f * c_f,
+                                "ms_per_launch": ms_f, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         out["inference"] = {"value": B / (ms_inf * 1e-3), "unit": "point-clouds/s",
                             "ms_per_batch": ms_inf, "path": "HIP index ops + fused GridConv"}
         net.train()

@@ -541,6 +541,40 @@ def edge_block_src_train(src, nebidx, cent, pt_layers, att_layers, localfdim):
     return _EdgeBlockSrcTrain.apply(src, nebidx, cent, meta, *params)
 
 
+def time_linear_fwd(E, cin, C, iters=10, device="cuda:0"):
+    """Time one gridgcn_linear_fwd_direct launch (previous layer's BatchNorm+ReLU applied on the fly,
+    statistics epilogue) on synthetic tensors.  Returns ms/launch."""
+    lib = _lib.load()
+    g = torch.Generator(device=device).manual_seed(0)
+    X = torch.randn(E, cin, device=device, generator=g)
+    W = torch.randn(C, cin, device=device, generator=g) * 0.1
+    b = torch.randn(C, device=device, generator=g)
+    sc = torch.rand(cin, device=device, generator=g) + 0.5
+    sh = torch.randn(cin, device=device, generator=g) * 0.1
+    K, ldw, nwp, nwb = packed_sizes(C, cin)
+    Bp, Wq = torch.empty(ldw, device=device), torch.empty(cin * ldw, device=device)
+    _lib.check(lib.gridgcn_pack_linear(_ptr(W), _ptr(b), C, cin, 0, cin, 0, None, _ptr(Bp), None,
+                                       None, _ptr(Wq), None, _stream(W)), "pack")
+    Z = torch.empty(E, C, device=device)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=device)
+
+    def call():
+        _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(X), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, C,
+                                                 _ptr(sc), _ptr(sh), _ptr(Z), _ptr(sums),
+                                                 _stream(X)), "gridgcn_linear_fwd_direct")
+    with torch.cuda.device(device):
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0):
     """Time one gridgcn_linear_bwd call (dX kernel + dW kernel + dW reduce) on synthetic tensors
     shaped like the last pt layer of a GridConv edge block (sparse upstream gradient, input gradient
