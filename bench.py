@@ -222,7 +222,10 @@ def main():
                            "GridConv %s over %d edges: BN/ReLU backward formed in registers from the "
                            "sparse arg-max gradient, dX, dW)" % (cin_b, c_b, name, ncent_b * p_b),
                            "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs_b / HBM_PEAK_GBS, "traffic": None,
+                           "frac": gbs_b / HBM_PEAK_GBS,
+                           # FETCH_SIZE (x2: 16-byte streaming reads) + WRITE_SIZE of the two
+                           # kernels at this shape, profiles/r1_pmc_summary.txt
+                           "traffic": 5.61e9 if (a.points == 81920 and B == 8) else None,
                            "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
                            "algorithmic_flops_per_launch": 4.0 * e_b * cin_b * c_b,
                            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
