@@ -92,11 +92,11 @@ def load():
     lib.gridgcn_linear_bwd.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci,
                                                    vp, cs, vp]
     lib.gridgcn_pairmax_fwd.restype = ci
-    lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, vp, vp, vp]
+    lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, ci, vp, vp, vp]
     lib.gridgcn_pairmax_bwd.restype = ci
     lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_relu_apply.restype = ci
-    lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, vp]
+    lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, vp]
     lib.gridgcn_bn_relu_bwd_reduce.restype = ci
     lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
     lib.gridgcn_bn_relu_bwd_elemt.restype = ci
@@ -121,8 +121,8 @@ def load():
     lib.gridgcn_edge_lin0_backward.restype = ci
     lib.gridgcn_edge_lin0_backward.argtypes = [vp] * 15 + [ci] * 5 + [vp, vp, vp, cs, vp]
     lib.gridgcn_pairmax_fwd_src.restype = ci
-    lib.gridgcn_pairmax_fwd_src.argtypes = [vp] * 5 + [ci, ci, ci] + [vp] * 5 + [ll, ci, ci, vp, vp,
-                                                                              vp, vp]
+    lib.gridgcn_pairmax_fwd_src.argtypes = [vp] * 5 + [ci, ci, ci] + [vp] * 5 + [ll, ci, ci, vp, ci,
+                                                                              vp, vp, vp]
     lib.gridgcn_softmax_ce_fwd.restype = ci
     lib.gridgcn_softmax_ce_fwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp]
     lib.gridgcn_softmax_ce_bwd.restype = ci

@@ -38,10 +38,11 @@ size_t gg_take_bwd_sorted_workspace(int B, int N, int M);
 int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, int, int, void *,
                        hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
-                   const float *, long long, int, int, float *, int *, float *, hipStream_t);
+                   const float *, long long, int, int, float *, int, int *, float *, hipStream_t);
 int gg_pairmax_fwd_src(const float *, const int *, const float *, const float *, const float *, int,
                        int, int, const float *, const float *, const float *, const float *,
-                       const float *, long long, int, int, float *, int *, float *, hipStream_t);
+                       const float *, long long, int, int, float *, int, int *, float *,
+                       hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
                    const float *, const int *, long long, int, int, float *, float *, double *,
@@ -272,28 +273,29 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
 
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *scale_a, const float *shift_a,
-                        long long ncent, int P, int C, float *agg, int32_t *amax, float *zsel,
-                        void *stream)
+                        long long ncent, int P, int C, float *agg, int ld_agg, int32_t *amax,
+                        float *zsel, void *stream)
 {
     if (!Zp || !Za || !scale_p || !shift_p || !scale_a || !shift_a || !agg || !amax || ncent < 1 ||
-        P < 1 || C < 1)
+        P < 1 || C < 1 || ld_agg < C)
         return GRIDGCN_EINVAL;
-    return gg_pairmax_fwd(Zp, Za, scale_p, shift_p, scale_a, shift_a, ncent, P, C, agg, amax, zsel,
-                          (hipStream_t)stream);
+    return gg_pairmax_fwd(Zp, Za, scale_p, shift_p, scale_a, shift_a, ncent, P, C, agg, ld_agg,
+                          amax, zsel, (hipStream_t)stream);
 }
 
 int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const float *att16,
                             const float *Wg, const float *b, int B, int Nsrc, int O,
                             const float *Za, const float *scale_p, const float *shift_p,
                             const float *scale_a, const float *shift_a, long long ncent, int P,
-                            int C, float *agg, int32_t *amax, float *zsel, void *stream)
+                            int C, float *agg, int ld_agg, int32_t *amax, float *zsel,
+                            void *stream)
 {
     if ((!Ysrc && !Wg) || !nebidx || !att16 || !b || !Za || !scale_p || !shift_p || !scale_a ||
         !shift_a || !agg || !amax || ncent < 1 || P < 1 || C < 1 || B < 1 || Nsrc < 1 || O < 1 ||
-        ncent != (long long)B * O)
+        ncent != (long long)B * O || ld_agg < C)
         return GRIDGCN_EINVAL;
     const int rc = gg_pairmax_fwd_src(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Za, scale_p, shift_p,
-                                      scale_a, shift_a, ncent, P, C, agg, amax, zsel,
+                                      scale_a, shift_a, ncent, P, C, agg, ld_agg, amax, zsel,
                                       (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -315,10 +317,10 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
 }
 
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
-                          long long E, int C, void *stream)
+                          long long E, int C, int ldy, void *stream)
 {
-    if (!Z || !scale || !shift || !Y || E < 1 || C < 1) return GRIDGCN_EINVAL;
-    return gg_bn_apply(Z, scale, shift, Y, E, C, (hipStream_t)stream);
+    if (!Z || !scale || !shift || !Y || E < 1 || C < 1 || ldy < C) return GRIDGCN_EINVAL;
+    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, (hipStream_t)stream);
 }
 
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
                                                         long long ncent, int P, int C,
                                                         float *__restrict__ agg,
                                                         int *__restrict__ amax,
-                                                        float *__restrict__ zsel)
+                                                        float *__restrict__ zsel, int lda)
 {
     const long long total = ncent * C;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
             float v = y1 * y2;
             if (v > best) { best = v; bi = p; zps = z1; zas = z2; }
         }
-        agg[t] = best;
+        agg[o * lda + c] = best;
         amax[t] = bi;
         if (zsel) {              // the two pre-activations at the arg max: backward needs no gather
             zsel[t] = zps;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
                                                              long long ncent, int P, int C,
                                                              float *__restrict__ agg,
                                                              int *__restrict__ amax,
-                                                             float *__restrict__ zsel)
+                                                             float *__restrict__ zsel, int lda)
 {
     const int C4 = C >> 2;
     const long long total4 = ncent * C4;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
             }
         }
         const long long e = o * C + c;
-        *(float4 *)(agg + e) = make_float4(best[0], best[1], best[2], best[3]);
+        *(float4 *)(agg + o * lda + c) = make_float4(best[0], best[1], best[2], best[3]);
         *(int4 *)(amax + e) = make_int4(bi4[0], bi4[1], bi4[2], bi4[3]);
         if (zsel) {
             *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict
                                                          long long ncent, int P, int C,
                                                          float *__restrict__ agg,
                                                          int *__restrict__ amax,
-                                                         float *__restrict__ zsel)
+                                                         float *__restrict__ zsel, int lda)
 {
     const int C4 = C >> 2;
     const long long total4 = ncent * C4;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict
             }
         }
         const long long e = o * C + c;
-        *(float4 *)(agg + e) = make_float4(best[0], best[1], best[2], best[3]);
+        *(float4 *)(agg + o * lda + c) = make_float4(best[0], best[1], best[2], best[3]);
         *(int4 *)(amax + e) = make_int4(bi[0], bi[1], bi[2], bi[3]);
         if (zsel) {
             *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
@@ -400,34 +400,34 @@ int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float 
 int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16, const float *Wg,
                        const float *b, int B, int Nsrc, int O, const float *Za, const float *scp,
                        const float *shp, const float *sca, const float *sha, long long ncent, int P,
-                       int C, float *agg, int *amax, float *zsel, hipStream_t st)
+                       int C, float *agg, int lda, int *amax, float *zsel, hipStream_t st)
 {
-    if (C & 3) return 1;
+    if ((C & 3) || (lda & 3)) return 1;
     GGPtRecompute r;
     r.Ysrc = Ysrc; r.nebidx = nebidx; r.att16 = att16; r.Wg = Wg; r.b = b;
     r.Nsrc = Nsrc; r.O = O; r.B = B;
     long long nb = (ncent * (C / 4) + 255) / 256;
     int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
     gg_k_pairmax_fwd4_src<<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
-                                                zsel);
+                                                zsel, lda);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *sca, const float *sha, long long ncent, int P, int C, float *agg,
-                   int *amax, float *zsel, hipStream_t st)
+                   int lda, int *amax, float *zsel, hipStream_t st)
 {
-    if ((C & 3) == 0) {
+    if ((C & 3) == 0 && (lda & 3) == 0) {
         long long nb = (ncent * (C / 4) + 255) / 256;
         int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
         gg_k_pairmax_fwd4<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
-                                                zsel);
+                                                zsel, lda);
         return hipGetLastError() == hipSuccess ? 0 : 3;
     }
     long long nb = (ncent * C + 255) / 256;
     int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
     gg_k_pairmax_fwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
-                                           zsel);
+                                           zsel, lda);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

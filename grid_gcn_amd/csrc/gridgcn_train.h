@@ -51,7 +51,7 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shap
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
-                int C, hipStream_t st);
+                int C, int ldy, hipStream_t st);
 int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const float *shift,
                      const float *mean, const float *rstd, long long E, int C, double *sums,
                      hipStream_t st);

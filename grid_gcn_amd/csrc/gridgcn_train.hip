@@ -1080,25 +1080,28 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
 __global__ __launch_bounds__(256) void gg_k_bn_apply(const float *__restrict__ Z,
                                                      const float *__restrict__ scale,
                                                      const float *__restrict__ shift,
-                                                     float *__restrict__ Y, long long total, int C)
+                                                     float *__restrict__ Y, long long total, int C,
+                                                     int ldy)
 {
-    if ((C & 3) == 0) {
+    if ((C & 3) == 0 && (ldy & 3) == 0) {
         const long long n4 = total >> 2;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4;
              i += (long long)gridDim.x * 256) {
             float4 z = ((const float4 *)Z)[i];
-            const int c = (int)((i * 4) % C);
+            const long long row = (i * 4) / C;
+            const int c = (int)(i * 4 - row * C);
             const float4 sc = *(const float4 *)(scale + c), sh = *(const float4 *)(shift + c);
             float4 y;
             y.x = fmaxf(z.x * sc.x + sh.x, 0.f); y.y = fmaxf(z.y * sc.y + sh.y, 0.f);
             y.z = fmaxf(z.z * sc.z + sh.z, 0.f); y.w = fmaxf(z.w * sc.w + sh.w, 0.f);
-            ((float4 *)Y)[i] = y;
+            *(float4 *)(Y + row * ldy + c) = y;
         }
     } else {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
              i += (long long)gridDim.x * 256) {
-            const int c = (int)(i % C);
-            Y[i] = fmaxf(Z[i] * scale[c] + shift[c], 0.f);
+            const long long row = i / C;
+            const int c = (int)(i - row * C);
+            Y[row * ldy + c] = fmaxf(Z[i] * scale[c] + shift[c], 0.f);
         }
     }
 }
@@ -1180,10 +1183,11 @@ static int grid_for(long long work, int per_block, int cap)
 }
 
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
-                int C, hipStream_t st)
+                int C, int ldy, hipStream_t st)
 {
     long long total = E * C;
-    gg_k_bn_apply<<<grid_for(total / 4 + 1, 256, 65536), 256, 0, st>>>(Z, scale, shift, Y, total, C);
+    gg_k_bn_apply<<<grid_for(total / 4 + 1, 256, 65536), 256, 0, st>>>(Z, scale, shift, Y, total, C,
+                                                                      ldy);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

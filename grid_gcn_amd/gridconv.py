@@ -142,9 +142,19 @@ class SubGUpdate(nn.Module):
             from . import train_ops
             if train_ops.edge_block_src_supported(pt_layers, att_layers, src, self.has_feats):
                 # first conv on the source points, gathered afterwards: no [E, 3+Cf] tensor at all
+                buf, out = None, None
+                if center_ori_feats is not None and self.center_mlp is not None and \
+                        train_ops.supported(list(self.center_mlp), src):
+                    # update_func concatenates (centre MLP output, aggregate): both producers
+                    # write their half of one buffer instead of a concat pass
+                    B, O = nebidx.shape[0], nebidx.shape[1]
+                    ccf = self.center_mlp[-1].lin.out_features
+                    C = pt_layers[-1].lin.out_features
+                    buf = torch.empty((B * O, ccf + C), dtype=torch.float32, device=src.device)
+                    out = train_ops.alias_columns(buf, ccf, C)
                 agg = train_ops.edge_block_src_train(src, nebidx, cent.contiguous(), pt_layers,
-                                                     att_layers, self.localfdim)
-                return self.finish(agg, center_masks, center_ori_feats)
+                                                     att_layers, self.localfdim, out=out)
+                return self.finish(agg, center_masks, center_ori_feats, buf=buf)
             if train_ops.edge_block_supported(pt_layers, att_layers, src) and \
                     ops.edge_inputs_rows_supported(src, self.has_feats):
                 # rows laid out for the MFMA kernels (features | geo_vec | zero padding)
@@ -201,8 +211,16 @@ class SubGUpdate(nn.Module):
                                    has_feats=self.has_feats, localfdim=self.localfdim)
         return self.finish(agg, center_masks, center_ori_feats)
 
-    def finish(self, agg, center_masks, center_ori_feats):
-        if center_ori_feats is not None:
+    def finish(self, agg, center_masks, center_ori_feats, buf=None):
+        if center_ori_feats is not None and buf is not None:
+            # `agg` already sits in the right half of buf; the centre MLP writes the left half
+            from . import train_ops
+            B, O = center_ori_feats.shape[0], center_ori_feats.shape[1]
+            ccf = self.center_mlp[-1].lin.out_features
+            cf = train_ops.mlp_bn_relu_train(center_ori_feats, list(self.center_mlp),
+                                             out=train_ops.alias_columns(buf, 0, ccf))
+            agg = train_ops._Cat2.apply(cf, agg, buf).reshape(B, O, buf.shape[1])
+        elif center_ori_feats is not None:
             cf = (run_mlp(list(self.center_mlp), center_ori_feats, self.mfma_train)
                   if self.center_mlp is not None else center_ori_feats)
             agg = torch.cat([cf, agg], dim=-1)                             # up_center_inte=concat

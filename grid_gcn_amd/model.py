@@ -124,7 +124,8 @@ class GGCNSeg(nn.Module):
             else:
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
-            f_last = torch.cat([upl, cf], dim=2)                                    # :231
+            if i != nup - 1:                      # (the last layer's features go to the head only)
+                f_last = torch.cat([upl, cf], dim=2)                                # :231
         net = cf if self.up[-1].tail_done else run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
         if HEAD_KERNELS and self.training and torch.is_grad_enabled() and self.ix is HipIndexOps:

@@ -242,21 +242,43 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     return dY, grads
 
 
+def alias_columns(buf, col0, ncol):
+    """A fresh tensor (no autograd / view relation) over columns [col0, col0+ncol) of the contiguous
+    2-D buffer `buf`: lets two producers write the halves of a concatenation in place."""
+    E, ld = buf.shape
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+        buf.untyped_storage(), buf.storage_offset() + col0, (E, ncol), (ld, 1))
+
+
+class _Cat2(torch.autograd.Function):
+    """concat([a, b], -1) where a and b already ARE the two halves of `full` (alias_columns)."""
+
+    @staticmethod
+    def forward(ctx, a, b, full):
+        ctx.ca = a.shape[-1]
+        return alias_columns(full, 0, full.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.ca], g[..., ctx.ca:], None
+
+
 class _MLPTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *params):
-        """x [E,cin]; params = (W, b, gamma, beta) per layer; meta = (eps, [bn modules])."""
+        """x [E,cin]; params = (W, b, gamma, beta) per layer; meta = (eps, [bn modules], out):
+        out = None or a [E, C_last] tensor (row stride >= C_last) that receives the result."""
         lib = _lib.load()
-        eps, bns = meta
+        eps, bns, out = meta
         L = len(params) // 4
         x = x.contiguous()
         E = x.shape[0]
         with torch.cuda.device(x.device):
             st = _chain_forward(lib, x, params, bns, eps, 0,
                                 x.shape[1] if ctx.needs_input_grad[0] else 0)
-            Y = torch.empty_like(st.Z[-1])
+            Y = out if out is not None else torch.empty_like(st.Z[-1])
             rc = lib.gridgcn_bn_relu_apply(_ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]),
-                                           _ptr(Y), E, Y.shape[1], _stream(x))
+                                           _ptr(Y), E, Y.shape[1], Y.stride(0), _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_apply")
         ctx.L = L
         ctx.ndx = st.ndx
@@ -287,15 +309,18 @@ class _MLPTrain(torch.autograd.Function):
         return (dX, None) + tuple(grads)
 
 
-def mlp_bn_relu_train(x, layers):
+def mlp_bn_relu_train(x, layers, out=None):
     """x [..., cin] -> [..., cout_last] through `layers` (gridconv.ConvBNReLU modules, training
-    mode).  Callers check supported() first."""
+    mode).  Callers check supported() first.  out: optional [E, cout_last] destination
+    (alias_columns); the 2-D result is then returned as is."""
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
     params = []
     for l in layers:
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
-    y = _MLPTrain.apply(x2, (layers[0].bn.eps, [l.bn for l in layers]), *params)
+    y = _MLPTrain.apply(x2, (layers[0].bn.eps, [l.bn for l in layers], out), *params)
+    if out is not None:
+        return y
     return y.reshape(shp[:-1] + (y.shape[-1],))
 
 
@@ -321,7 +346,8 @@ class _EdgeBlockTrain(torch.autograd.Function):
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             rc = lib.gridgcn_pairmax_fwd(_ptr(sp.Z[-1]), _ptr(sa.Z[-1]), _ptr(sp.scale[-1]),
                                          _ptr(sp.shift[-1]), _ptr(sa.scale[-1]), _ptr(sa.shift[-1]),
-                                         ncent, P, C, _ptr(agg), _ptr(amax), _ptr(zsel), _stream(nf))
+                                         ncent, P, C, _ptr(agg), C, _ptr(amax), _ptr(zsel),
+                                         _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_fwd")
         ctx.dims = (Lp, La, ncent, P, rot, params[0].shape[1], params[4 * Lp].shape[1])
         ctx.ndx = (sp.ndx, sa.ndx)
@@ -373,7 +399,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, nebidx, cent, meta, *params):
         lib = _lib.load()
-        eps, bns_p, bns_a, geo = meta
+        eps, bns_p, bns_a, geo, out = meta
         Lp, La = len(bns_p), len(bns_a)
         B, Nsrc, Cs = src.shape
         _, O, P = nebidx.shape
@@ -423,18 +449,20 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             sa = _chain_forward(lib, att16, params[4 * Lp:], bns_a, eps)
             C = sa.Z[-1].shape[1]
             ncent = B * O
-            agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+            agg = out if out is not None else torch.empty((ncent, C), dtype=torch.float32,
+                                                           device=dev)
+            lda = agg.stride(0)
             amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             if noz:
                 rc = lib.gridgcn_pairmax_fwd_src(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
                     B, Nsrc, O, _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl), _ptr(sa.scale[-1]),
-                    _ptr(sa.shift[-1]), ncent, P, C, _ptr(agg), _ptr(amax), _ptr(zsel), st)
+                    _ptr(sa.shift[-1]), ncent, P, C, _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
             else:
                 rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
                                              _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
-                                             _ptr(agg), _ptr(amax), _ptr(zsel), st)
+                                             _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_fwd")
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
@@ -443,7 +471,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
             *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
         ctx.mark_non_differentiable(amax)
-        return agg.reshape(B, O, C)
+        return agg if out is not None else agg.reshape(B, O, C)
 
     @staticmethod
     def backward(ctx, dagg):
@@ -530,14 +558,15 @@ def edge_block_src_supported(pt_layers, att_layers, src, has_feats):
     return edge_block_supported(pt_layers, att_layers, src)
 
 
-def edge_block_src_train(src, nebidx, cent, pt_layers, att_layers, localfdim):
+def edge_block_src_train(src, nebidx, cent, pt_layers, att_layers, localfdim, out=None):
     """[B,O,C] = max_p att_mlp(att_vec) * pt_mlp(concat(geo_vec, gathered features)) from
-    (src [B,Nsrc,4+Cf], nebidx [B,O,P], cent [B,O,>=3]) -- sub_g_update up to the pooling."""
+    (src [B,Nsrc,4+Cf], nebidx [B,O,P], cent [B,O,>=3]) -- sub_g_update up to the pooling.
+    out: optional [B*O, C] destination (alias_columns); the 2-D result is then returned."""
     params = []
     for l in list(pt_layers) + list(att_layers):
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
     meta = (pt_layers[0].bn.eps, [l.bn for l in pt_layers], [l.bn for l in att_layers],
-            localfdim != 0)
+            localfdim != 0, out)
     return _EdgeBlockSrcTrain.apply(src, nebidx, cent, meta, *params)
 
 

@@ -175,7 +175,8 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             const float *Wg, const float *b, int B, int Nsrc, int O,
                             const float *Za, const float *scale_p, const float *shift_p,
                             const float *scale_a, const float *shift_a, long long ncent, int P,
-                            int C, float *agg, int32_t *amax, float *zsel, void *stream);
+                            int C, float *agg, int ld_agg, int32_t *amax, float *zsel,
+                            void *stream);
 int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
                                const float *dY, const int32_t *amax,
                                const float *gval, const float *scale, const float *shift,
@@ -266,8 +267,10 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
  *   edge, and the BatchNorm-backward sums (as gridgcn_bn_relu_bwd_reduce) of both layers. */
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *scale_a, const float *shift_a,
-                        long long ncent, int P, int C, float *agg, int32_t *amax, float *zsel,
-                        void *stream);
+                        long long ncent, int P, int C, float *agg, int ld_agg, int32_t *amax,
+                        float *zsel, void *stream);
+/* ld_agg / ldy (gridgcn_bn_relu_apply): row stride in floats of the output, >= C -- lets the two
+ * halves of update_func's concat (gcn_module_g_att.py:31-36) be written in place, no concat pass. */
 /* zsel (optional, [2][ncent*C]): the pre-BatchNorm values of Zp and Za at the arg max, written by
  * the forward and read by the backward instead of gathering them again from Zp / Za. */
 int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
@@ -277,7 +280,7 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
                         double *sums_a, const float *zsel, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
-                          long long E, int C, void *stream);
+                          long long E, int C, int ldy, void *stream);
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
                                const float *shift, const float *mean, const float *rstd,
                                long long E, int C, double *sums, void *stream);
