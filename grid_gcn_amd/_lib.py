@@ -89,16 +89,16 @@ def load():
     lib.gridgcn_linear_bwd_workspace_bytes.restype = ci
     lib.gridgcn_linear_bwd_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_bwd.restype = ci
-    lib.gridgcn_linear_bwd.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci,
-                                                   vp, cs, vp]
+    lib.gridgcn_linear_bwd.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp,
+                                                   ci, vp, cs, vp]
     lib.gridgcn_pairmax_fwd.restype = ci
     lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, ci, vp, vp, vp]
     lib.gridgcn_pairmax_bwd.restype = ci
-    lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_relu_apply.restype = ci
     lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, vp]
     lib.gridgcn_bn_relu_bwd_reduce.restype = ci
-    lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
+    lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, ci, vp, vp]
     lib.gridgcn_bn_relu_bwd_elemt.restype = ci
     lib.gridgcn_bn_relu_bwd_elemt.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ll, ci, vp, vp]
     lib.gridgcn_pack_linear.restype = ci

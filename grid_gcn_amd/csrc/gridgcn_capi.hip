@@ -45,7 +45,7 @@ int gg_pairmax_fwd_src(const float *, const int *, const float *, const float *,
                        hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
-                   const float *, const int *, long long, int, int, float *, float *, double *,
+                   const float *, const int *, long long, int, int, int, float *, float *, double *,
                    double *, const float *, hipStream_t);
 
 int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
@@ -245,7 +245,8 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *Aprev, const float *pscale, const float *pshift,
                        const float *pmean, const float *prstd, const float *Wb, const float *Wg,
                        const float *Wdx, int ndx, long long E,
-                       int C, int cin, int cin_w, int rot, float *dX, float *dW, double *psums,
+                       int C, int cin, int cin_w, int rot, int ldy, float *dX, float *dW,
+                       double *psums,
                        const int32_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream)
 {
@@ -267,6 +268,8 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     p.amax = amax; p.gval = gval; p.P = P > 0 ? P : 1;
     p.Wdx = Wdx; p.ndx = Wdx ? ndx : cin;
     p.cin_w = cin_w; p.rot = rot;
+    p.ldy = (dY && !amax && ldy > 0) ? ldy : C;
+    if (p.ldy < C) return GRIDGCN_EINVAL;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -304,14 +307,14 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *mean_p, const float *rstd_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
                         const float *rstd_a, const float *dagg, const int32_t *amax,
-                        long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
-                        double *sums_a, const float *zsel, void *stream)
+                        long long ncent, int P, int C, int ld_dagg, float *gp, float *ga,
+                        double *sums_p, double *sums_a, const float *zsel, void *stream)
 {
     if (((!Zp || !Za) && !zsel) || !dagg || !amax || !gp || !ga || !sums_p || !sums_a ||
-        ncent < 1 || P < 1)
+        ncent < 1 || P < 1 || ld_dagg < C)
         return GRIDGCN_EINVAL;
     int rc = gg_pairmax_bwd(Zp, Za, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
-                            rstd_a, dagg, amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel,
+                            rstd_a, dagg, amax, ncent, P, C, ld_dagg, gp, ga, sums_p, sums_a, zsel,
                             (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -325,11 +328,12 @@ int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift
 
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
                                const float *shift, const float *mean, const float *rstd,
-                               long long E, int C, double *sums, void *stream)
+                               long long E, int C, int ldy, double *sums, void *stream)
 {
-    if (!dY || !Z || !scale || !shift || !mean || !rstd || !sums || E < 1 || C < 1)
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !sums || E < 1 || C < 1 || ldy < C)
         return GRIDGCN_EINVAL;
-    int rc = gg_bn_bwd_reduce(dY, Z, scale, shift, mean, rstd, E, C, sums, (hipStream_t)stream);
+    int rc = gg_bn_bwd_reduce(dY, Z, scale, shift, mean, rstd, E, C, sums, ldy,
+                              (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             gr = p.gval + cen * C;
             ar = p.amax + cen * C;
         } else {
-            gr = p.dY + row * C;
+            gr = p.dY + row * p.ldy;
         }
         auto ldg = [&](int k) -> float4 {
             float4 g = *(const float4 *)(gr + k);
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             pp += 2;
             while (pp >= p.P) { pp -= p.P; cen++; }
         } else {
-            gr = p.dY + rw * C + chl;
+            gr = p.dY + rw * p.ldy + chl;
         }
         if constexpr (MT == 2) {
             const float2 t = *(const float2 *)zr, u = *(const float2 *)gr;

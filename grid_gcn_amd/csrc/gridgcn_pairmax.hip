@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     const float *__restrict__ sca, const float *__restrict__ sha, const float *__restrict__ mua,
     const float *__restrict__ rsa, const float *__restrict__ dagg, const int *__restrict__ amax,
     long long ncent, int P, int C, float *__restrict__ gp, float *__restrict__ ga,
-    double *__restrict__ sums_p, double *__restrict__ sums_a, const float *__restrict__ zsel)
+    double *__restrict__ sums_p, double *__restrict__ sums_a, const float *__restrict__ zsel,
+    int ldd)
 {
     __shared__ float sh[4][256];
     const int tid = threadIdx.x;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
             za = Za[e * C + c];
         }
         const float y1 = fmaxf(zp * a1 + b1, 0.f), y2 = fmaxf(za * a2 + b2, 0.f);
-        const float g = dagg[t];
+        const float g = dagg[o * ldd + c];
         // gradient w.r.t. the post-ReLU activations; the ReLU mask (y > 0) is applied by the
         // consumer (gg_k_linear_bwd staging) and here for the sums
         const float g1 = g * y2, g2 = g * y1;
@@ -434,7 +435,7 @@ int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const flo
 int gg_pairmax_bwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *mup, const float *rsp, const float *sca, const float *sha,
                    const float *mua, const float *rsa, const float *dagg, const int *amax,
-                   long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
+                   long long ncent, int P, int C, int ldd, float *gp, float *ga, double *sums_p,
                    double *sums_a, const float *zsel, hipStream_t st)
 {
     if (C > 256 || 256 % C != 0) return 1;
@@ -442,6 +443,6 @@ int gg_pairmax_bwd(const float *Zp, const float *Za, const float *scp, const flo
     long long nb = (ncent + rpp * 8 - 1) / (rpp * 8);
     int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
     gg_k_pairmax_bwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, mup, rsp, sca, sha, mua, rsa, dagg,
-                                           amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel);
+                                           amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel, ldd);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

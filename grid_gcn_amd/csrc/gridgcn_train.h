@@ -27,6 +27,7 @@ struct GGLinBwd {
                           // (nullptr: no split mode; dX comes from the monolithic kernel)
     const float *Wdx;     // register-direct dX operand (gridgcn_pack_linear), nullptr: LDS-staged dX
     int ndx;              // number of leading dX columns that are needed (<= cin, <= 256)
+    int ldy;              // row stride of the dense dY (>= C; the register-direct kernels only)
     int cin_w, rot;       // dW is written as [C][cin_w] in the framework's column order: kernel
                           // column k -> k + rot (k < cin_w - rot), k - (cin_w - rot) (k < cin_w)
     float *dX;            // [E][cin] gradient w.r.t. act(Aprev) (nullptr: not needed)
@@ -54,7 +55,7 @@ int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y
                 int C, int ldy, hipStream_t st);
 int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const float *shift,
                      const float *mean, const float *rstd, long long E, int C, double *sums,
-                     hipStream_t st);
+                     int ldy, hipStream_t st);
 int gg_bn_bwd_elemt(const float *dY, const float *Z, const float *scale, const float *shift,
                     const float *mean, const float *rstd, const float *m1, const float *m2,
                     long long E, int C, float *dZ, hipStream_t st);

@@ -951,6 +951,8 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         if (rc == 0) p.dX = nullptr;
         else if (rc != 1) return rc;
     }
+    // a strided dense dY is only understood by the register-direct kernels
+    if (p.dX && !p.amax && p.ldy != p.C) return 1;
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
     if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0 && !getenv("GG_BWD_MONO")) {
         static bool attr_dx = false;
@@ -976,6 +978,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         const int rc = gg_linear_dw_direct(p, st);
         if (rc != 1) return rc;
     }
+    if (!p.amax && p.ldy != p.C) return 1;
     const int npairs = ntm * ntn2;
     if (npairs > 48) return 1;
     // ---- balance GEMM1 column tiles (cost C4/2 MFMAs) and GEMM2 pairs (16 MFMAs) over 4 waves ----
@@ -1115,7 +1118,7 @@ __global__ __launch_bounds__(256) void gg_k_bn_bwd_reduce(const float *__restric
                                                           const float *__restrict__ mean,
                                                           const float *__restrict__ rstd,
                                                           long long E, int C,
-                                                          double *__restrict__ sums)
+                                                          double *__restrict__ sums, int ldy)
 {
     __shared__ float sh1[256], sh2[256];
     const int tid = threadIdx.x;
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(256) void gg_k_bn_bwd_reduce(const float *__restric
         float a1 = 0.f, a2 = 0.f;
         for (long long r = (long long)blockIdx.x * rpp + rr; r < E; r += (long long)gridDim.x * rpp) {
             const float z = Z[r * C + c];
-            const float d = (z * sc + sf > 0.f) ? dY[r * C + c] : 0.f;
+            const float d = (z * sc + sf > 0.f) ? dY[r * ldy + c] : 0.f;
             a1 += d;
             a2 += d * ((z - mu) * rs);
         }
@@ -1143,7 +1146,7 @@ __global__ __launch_bounds__(256) void gg_k_bn_bwd_reduce(const float *__restric
             float a1 = 0.f, a2 = 0.f;
             for (long long r = blockIdx.x; r < E; r += gridDim.x) {
                 const float z = Z[r * C + c];
-                const float d = (z * sc + sf > 0.f) ? dY[r * C + c] : 0.f;
+                const float d = (z * sc + sf > 0.f) ? dY[r * ldy + c] : 0.f;
                 a1 += d;
                 a2 += d * ((z - mu) * rs);
             }
@@ -1193,12 +1196,12 @@ int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y
 
 int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const float *shift,
                      const float *mean, const float *rstd, long long E, int C, double *sums,
-                     hipStream_t st)
+                     int ldy, hipStream_t st)
 {
     if (!((C <= 256 && 256 % C == 0) || (C % 256 == 0))) return 1;
     int rpp = C <= 256 ? 256 / C : 1;
     gg_k_bn_bwd_reduce<<<grid_for(E, rpp * 16, 2048), 256, 0, st>>>(dY, Z, scale, shift, mean, rstd,
-                                                                     E, C, sums);
+                                                                     E, C, sums, ldy);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -231,6 +231,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
             _ptr(m1), _ptr(m2), _ptr(prev), pbn[0], pbn[1], pbn[2], pbn[3],
             _ptr(Wb), _ptr(Wg) if Wg is not None else None,
             _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin, cw, rt,
+            dY.stride(0) if (sparse is None and dY is not None) else 0,
             _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
@@ -261,6 +262,21 @@ class _Cat2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g[..., :ctx.ca], g[..., ctx.ca:], None
+
+
+def _dw_direct_ok(C, cin):
+    """mirror of gg_dw_direct_cfg (csrc/gridgcn_direct.hip): shapes the register-direct dW kernel
+    takes (the dX kernel additionally needs C % 8 == 0, i.e. a packed Wdx)."""
+    if cin > 320 or cin % 4 or C > 256 or C % 8:
+        return False
+    nq, rem = cin // 128, cin % 128
+    np_ = 1 if rem >= 64 else 0
+    rem -= 64 * np_
+    if rem > 32:
+        return False
+    nj = 4 * nq + 2 * np_ + (1 if rem else 0)
+    mt = 2 if (C >= 64 and nj <= 5) else 1
+    return mt * nj <= 10 and nq <= 2 and (C + 32 * mt - 1) // (32 * mt) <= 8
 
 
 class _MLPTrain(torch.autograd.Function):
@@ -296,13 +312,21 @@ class _MLPTrain(torch.autograd.Function):
         means, rstds, Wbs = t[1 + 3 * L:1 + 4 * L], t[1 + 4 * L:1 + 5 * L], t[1 + 5 * L:1 + 6 * L]
         Wgs, Wdxs = t[1 + 6 * L:1 + 7 * L], t[1 + 7 * L:1 + 8 * L]
         E, dev = x.shape[0], x.device
-        dY = dY.contiguous()
+        C = Zs[-1].shape[1]
+        cin_last = Zs[-2].shape[1] if L > 1 else x.shape[1]
+        need_dx_last = L > 1 or ctx.needs_input_grad[0]
+        # a row-strided gradient (one half of a concat's gradient) is consumed in place when the
+        # register-direct kernels take this layer; otherwise it is packed first
+        if not (dY.dim() == 2 and dY.stride(1) == 1 and dY.stride(0) % 4 == 0
+                and dY.storage_offset() % 4 == 0 and _dw_direct_ok(C, cin_last)
+                and DIRECT_DX and not os.environ.get("GG_DW_LDS")
+                and (not need_dx_last or ctx.ndx[-1] > 0)):
+            dY = dY.contiguous()
         with torch.cuda.device(dev):
-            C = Zs[-1].shape[1]
             sums = torch.zeros((2, C), dtype=torch.float64, device=dev)
             rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Zs[-1]), _ptr(scales[-1]),
                                                 _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
-                                                E, C, _ptr(sums), _stream(x))
+                                                E, C, dY.stride(0), _ptr(sums), _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
             dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
                                         ctx.ndx, sums, dY, None, ctx.needs_input_grad[0])
@@ -379,7 +403,7 @@ class _EdgeBlockTrain(torch.autograd.Function):
             rc = lib.gridgcn_pairmax_bwd(_ptr(pZ[-1]), _ptr(aZ[-1]), _ptr(pS[-1]), _ptr(pH[-1]),
                                          _ptr(pM[-1]), _ptr(pR[-1]), _ptr(aS[-1]), _ptr(aH[-1]),
                                          _ptr(aM[-1]), _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent,
-                                         P, C, _ptr(gp), _ptr(ga), _ptr(sums_p), _ptr(sums_a),
+                                         P, C, C, _ptr(gp), _ptr(ga), _ptr(sums_p), _ptr(sums_a),
                                          _ptr(zsel), _stream(nf))
             _lib.check(rc, "gridgcn_pairmax_bwd")
             dnf, grads_p = _chain_backward(lib, nf, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0],
@@ -493,7 +517,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         lS, lH, lM, lR = (pS[-1], pH[-1], pM[-1], pR[-1]) if L1 else (vec0[0], vec0[1], vec0[2],
                                                                         vec0[3])
         C = aZ[-1].shape[1]
-        dagg = dagg.contiguous().reshape(ncent, C)
+        if not (dagg.dim() == 2 and dagg.stride(1) == 1):       # (a concat half: used in place)
+            dagg = dagg.contiguous().reshape(ncent, C)
         with torch.cuda.device(dev):
             st = _stream(src)
             gp = torch.empty((ncent, C), dtype=torch.float32, device=dev)
@@ -504,7 +529,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None, _ptr(aZ[-1]),
                                          _ptr(lS), _ptr(lH), _ptr(lM),
                                          _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
-                                         _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C, _ptr(gp),
+                                         _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C,
+                                         dagg.stride(0), _ptr(gp),
                                          _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_bwd")
             _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1],
@@ -635,7 +661,7 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0):
     def call():
         rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                     _ptr(m1), _ptr(m2), _ptr(X), None, None, None, None, _ptr(Wb),
-                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin, cin, 0,
+                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin, cin, 0, 0,
                                     _ptr(dX), _ptr(dW), None, _ptr(amax),
                                     _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))
@@ -753,7 +779,7 @@ class _LinearPlain(torch.autograd.Function):
             rc = lib.gridgcn_linear_bwd(
                 _ptr(dL), _ptr(Z), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
                 _ptr(ident[4]), _ptr(ident[5]), _ptr(x), None, None, None, None, _ptr(Wb), None,
-                _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0,
+                _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0, 0,
                 _ptr(dX) if ndx else None, _ptr(dW), None, None, None, 0, _ptr(ws), nbytes.value, st)
             _lib.check(rc, "gridgcn_linear_bwd")
             db64 = torch.zeros(Cp, dtype=torch.float64, device=dev)

@@ -249,7 +249,8 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *Aprev, const float *pscale, const float *pshift,
                        const float *pmean, const float *prstd, const float *Wb, const float *Wg,
                        const float *Wdx, int ndx, long long E,
-                       int C, int cin, int cin_w, int rot, float *dX, float *dW, double *psums,
+                       int C, int cin, int cin_w, int rot, int ldy, float *dX, float *dW,
+                       double *psums,
                        const int32_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream);
 /* (cin = row length of Aprev / dX as the kernels see it; dW is written in the FRAMEWORK layout
@@ -277,13 +278,16 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *mean_p, const float *rstd_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
                         const float *rstd_a, const float *dagg, const int32_t *amax,
-                        long long ncent, int P, int C, float *gp, float *ga, double *sums_p,
+                        long long ncent, int P, int C, int ld_dagg, float *gp, float *ga,
+                        double *sums_p,
                         double *sums_a, const float *zsel, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
                           long long E, int C, int ldy, void *stream);
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
                                const float *shift, const float *mean, const float *rstd,
-                               long long E, int C, double *sums, void *stream);
+                               long long E, int C, int ldy, double *sums, void *stream);
+/* ldy (also gridgcn_linear_bwd, dense dY only) / ld_dagg: row stride of the upstream gradient, so
+ * that the two halves of update_func's concat gradient are consumed in place. */
 int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scale,
                               const float *shift, const float *mean, const float *rstd,
                               const float *m1, const float *m2, long long E, int C, float *dZ,
