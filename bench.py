@@ -69,12 +69,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (GG_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than
+    #  ranks -- several ranks then share a device; never used for reported numbers)
+    backend = os.environ.get("GG_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local if backend == "nccl" else local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
 
     cfg = model.SEG_81920 if a.points > 8192 else model.SEG_8192
     if a.points not in (8192, 81920):       # off-config sizes keep the layer tables
