@@ -1,21 +1,29 @@
-"""Training-mode per-edge MLPs on the hand-written gfx950 kernels (csrc/gridgcn_train.hip,
-csrc/gridgcn_pairmax.hip).
+"""Training path on the hand-written gfx950 kernels: the host logic of one training step between
+the index ops and the optimizer (kernels: csrc/gridgcn_direct.hip, gridgcn_edgelin.hip,
+gridgcn_pairmax.hip, gridgcn_scatter.hip, gridgcn_head.hip; LDS-staged fallbacks for odd shapes in
+gridgcn_train.hip).  Everything goes through the C ABI of include/gridgcn.h.
 
 A "chain" is a stack of (1x1 conv -> BatchNorm(batch statistics) -> ReLU) layers (mlp2d_c /
 mlp1d_c, utils/ops.py:236-260):
 
-  forward   per layer ONE kernel: Z_l = act_{l-1} * W_l + b_l on fp32 MFMA, where act_{l-1} =
-            relu(bn(Z_{l-1})) is applied while the tile is staged (never materialised) and the
-            kernel's epilogue accumulates the batch statistics of Z_l.
-  backward  per layer ONE kernel: dZ formed while staging, dX and dW on MFMA, the next layer's
-            BatchNorm-backward sums in the epilogue.
+  forward   per layer: pack the weight layouts (1 launch), Z_l = act_{l-1} * W_l + b_l on fp32 MFMA
+            where act_{l-1} = relu(bn(Z_{l-1})) is applied while the rows are loaded (never
+            materialised) and the epilogue accumulates the batch statistics of Z_l, then the
+            BatchNorm bookkeeping (1 launch).
+  backward  per layer: dZ formed in registers, a dX kernel (with the previous layer's
+            BatchNorm-backward sums in its epilogue) and a dW kernel + reduce.
 
-Two autograd Functions use the chain:
-  _MLPTrain        one chain, dense output Y = relu(bn(Z_L))     (centre / update MLPs)
-  _EdgeBlockTrain  the GridConv edge block: pt chain and att chain on the [E, .] edge tensors, then
-                   agg[o,c] = max_p relu(bn(Zpt)) * relu(bn(Zatt)) without materialising the two
-                   activations, their product, or (in backward) any dense gradient of them
-                   (segmentation/models/gcn_module_g_att.py:135-167, 57-59).
+autograd Functions:
+  _MLPTrain           one chain, dense output Y = relu(bn(Z_L))     (centre / update MLPs, fc1)
+  _EdgeBlockSrcTrain  the GridConv edge block from (src, nebidx, cent): first point conv on the
+                      source points + gather-add, remaining pt layers and the att chain on [E, .]
+                      tensors, then agg[o,c] = max_p relu(bn(Zpt)) * relu(bn(Zatt)) without
+                      materialising the two activations, their product, or (in backward) any dense
+                      gradient of them (segmentation/models/gcn_module_g_att.py:135-167, 57-59)
+  _EdgeBlockTrain     the same block on already gathered edge rows (layers without neighbour
+                      features)
+  _LinearPlain, _SoftmaxCE   the class scores and SoftmaxOutput(use_ignore, 'valid')
+  _Cat2               update_func's concat, written in place by its two producers
 
 Numerics follow torch.nn.BatchNorm1d(eps, momentum) exactly as used by gridconv.ConvBNReLU (biased
 variance for normalisation, unbiased for the running estimate).
