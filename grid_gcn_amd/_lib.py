@@ -19,6 +19,7 @@ EXPORTS = [
     "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
     "gridgcn_take_backward_workspace_bytes",
     "gridgcn_edge_lin0_forward", "gridgcn_edge_lin0_backward", "gridgcn_pairmax_fwd_src",
+    "gridgcn_edge_lin0_backward_sparse_workspace_bytes", "gridgcn_edge_lin0_backward_sparse",
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
@@ -123,6 +124,10 @@ def load():
     lib.gridgcn_pairmax_fwd_src.restype = ci
     lib.gridgcn_pairmax_fwd_src.argtypes = [vp] * 5 + [ci, ci, ci] + [vp] * 5 + [ll, ci, ci, vp, ci,
                                                                               vp, vp, vp]
+    lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes.restype = ci
+    lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_edge_lin0_backward_sparse.restype = ci
+    lib.gridgcn_edge_lin0_backward_sparse.argtypes = [vp] * 14 + [ci] * 5 + [vp] * 5 + [cs, vp]
     lib.gridgcn_softmax_ce_fwd.restype = ci
     lib.gridgcn_softmax_ce_fwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp]
     lib.gridgcn_softmax_ce_bwd.restype = ci

@@ -492,6 +492,34 @@ int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_edge_lin0_backward_sparse_workspace_bytes(int B, int Nsrc, int C0, size_t *bytes)
+{
+    if (!bytes || B < 1 || Nsrc < 1 || C0 < 1) return GRIDGCN_EINVAL;
+    *bytes = gg_edge_lin0_sparse_workspace(B, Nsrc, C0);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
+                                      const int32_t *amax, const float *gval, const float *zsel,
+                                      const float *Ysrc, const float *Wg, const float *b,
+                                      const float *scale, const float *shift, const float *mean,
+                                      const float *rstd, const float *m1, const float *m2, int B,
+                                      int Nsrc, int O, int P, int C0, float *dYsrc, float *Gsum,
+                                      double *wgs, double *gg, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    if (!nebidx || !att16 || !amax || !gval || !zsel || (!Ysrc && !Wg) || !b || !scale || !shift ||
+        !mean || !rstd || !m1 || !m2 || !dYsrc || !Gsum || !wgs || !gg || B < 1 || Nsrc < 1 ||
+        O < 1 || P < 1 || C0 < 1)
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_edge_lin0_sparse_workspace(B, Nsrc, C0))
+        return GRIDGCN_EWORKSPACE;
+    const int rc = gg_edge_lin0_bwd_sparse(nebidx, att16, amax, gval, zsel, Ysrc, Wg, b, scale,
+                                           shift, mean, rstd, m1, m2, B, Nsrc, O, P, C0, dYsrc, Gsum,
+                                           wgs, gg, workspace, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_take_backward_workspace_bytes(int B, int N, int M, size_t *bytes)
 {
     if (!bytes || B < 1 || N < 1 || M < 1) return GRIDGCN_EINVAL;

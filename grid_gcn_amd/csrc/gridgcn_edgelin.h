@@ -30,5 +30,13 @@ struct GGEdgeLin0Bwd {
     int B, N, O, P, C0, M, cpc;
 };
 
+size_t gg_edge_lin0_sparse_workspace(int B, int N, int C);
+int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *amax,
+                            const float *gval, const float *zsel, const float *Ysrc,
+                            const float *Wg, const float *bias, const float *scale,
+                            const float *shift, const float *mean, const float *rstd,
+                            const float *m1, const float *m2, int B, int N, int O, int P, int C,
+                            float *dYsrc, float *Gsum, double *wgs, double *gg, void *workspace,
+                            hipStream_t st);
 int gg_edge_lin0_fwd(const GGEdgeLin0 &p, hipStream_t st);
 int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st);   // workspace: gg_csr_workspace

@@ -324,3 +324,247 @@ int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st)
     else gg_k_edge_lin0_bwd<4><<<grid, 256, 0, st>>>(p);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+// ------------------------------------------------------------------------------------------
+// Sparse form of the same backward, for a SINGLE-layer point MLP (upstream = the max pool).
+// dZ0[e,c] = [e is the arg-max edge of (o,c)] s[o,c] + (z0[e,c] - mu_c) bz_c + cz_c, and z0 is
+// affine in per-source / per-edge quantities (z0 = Ysrc[src(e)] + Wg geo(e) + b), so the per-source
+// sum of the DENSE part needs only cnt(n) = #edges of source n and G(n) = sum of their geo_vec:
+//   dYsrc[n,c] = sum_{(o,c): src(e*) = n} s[o,c]
+//              + bz_c (cnt(n) (Ysrc[n,c] + b_c) + G(n) . Wg[:,c]) + cnt(n) (cz_c - mu_c bz_c)
+// The edge x channel work (420 M values at cfg4 up2) shrinks to the ncent x C arg-max entries (84 M),
+// scattered with LDS atomics into a per-(cloud, 32-channel slice) copy of the destination rows.
+//   gg_k_edge_lin0_bwd_sparse   grid (nsplit, C/32, B): LDS acc[(N+1)][32]; slice 0 also collects
+//                               cnt / G per source, sum geo geo^T, sum geo; partials are stored
+//   gg_k_edge_lin0_bwd_finish   dYsrc = partials + dense part; per-source (G, cnt) for dWg
+struct GGEdgeSparse {
+    const int *nebidx;       // [B][O*P]
+    const float *att16;      // [E][16]
+    const int *amax;         // [B*O][C]
+    const float *gval, *zsel;   // [B*O][C]: gradient w.r.t. relu(bn(z0)) and z0 at the arg max
+    const float *sc, *sh;    // [C] BatchNorm scale / shift of the layer
+    float *part;             // [B][nsplit][N+1][C]
+    float *gpart;            // [B][nsplit][N+1][4]   (gx, gy, gz, count)
+    float *fpart, *fgs;      // [B*N][C], [B*N][4]: zero-filled; edges clipped into another cloud
+    double *wgs;             // [3][C] += sum_(o,c) geo_j(e*) s[o,c]
+    double *gg;              // [12] += (sum geo_j geo_k [9], sum geo_j [3])
+    int B, N, O, P, C, nsplit;
+};
+
+__global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[16][16];
+    const int N = p.N, O = p.O, P = p.P, C = p.C;
+    const int sp = blockIdx.x, sl = blockIdx.y, b = blockIdx.z;
+    const int c0 = sl * 32, tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;   // 32 groups
+    float *acc = lds;                          // [(N+1)][32]
+    float *gs = lds + (size_t)(N + 1) * 32;    // [(N+1)][4], slice 0 only
+    const bool geo_wg = sl == 0;
+    for (int i = tid; i < (N + 1) * 32; i += 1024) acc[i] = 0.f;
+    if (geo_wg)
+        for (int i = tid; i < (N + 1) * 4; i += 1024) gs[i] = 0.f;
+    __syncthreads();
+    const long long rows = (long long)p.B * N;
+    const int per = (O + p.nsplit - 1) / p.nsplit;
+    const int o0 = sp * per, o1 = o0 + per < O ? o0 + per : O;
+    const int c = c0 + lane;
+    const bool cok = c < C;
+    const float scv = cok ? p.sc[c] : 0.f, shv = cok ? p.sh[c] : 0.f;
+    float wg0 = 0.f, wg1 = 0.f, wg2 = 0.f;
+    float g9[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) g9[i] = 0.f;
+    const int *nb = p.nebidx + (size_t)b * O * P;
+    // key in [0, N] = destination row - (b*N - 1); an index clipped into ANOTHER cloud (never
+    // produced by the index ops) goes to the global side buffers fpart / fgs by its flat row
+    long long flat_ = 0;
+    auto keyof = [&](int idx) -> int {
+        long long flat = (long long)idx + (long long)b * N;
+        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+        flat_ = flat;
+        const long long li = flat - ((long long)b * N - 1);
+        return (li < 0 || li > N) ? -1 : (int)li;
+    };
+    // four centres per group and round, every load level issued for all four before it is used:
+    // amax -> nebidx[arg-max edge] -> LDS row is a dependent chain (the loop was latency bound)
+    constexpr int U = 4;
+    for (int ob0 = o0 + grp; ob0 < o1; ob0 += 32 * U) {
+        int pm[U], idx[U];
+        float gv[U], zs[U];
+        float4 av[U];
+        if (cok) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+                const size_t ob = ((size_t)b * O + o) * C;
+                pm[u] = p.amax[ob + c];
+                gv[u] = p.gval[ob + c];
+                zs[u] = p.zsel[ob + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+                idx[u] = nb[(size_t)o * P + pm[u]];
+                av[u] = *(const float4 *)(p.att16 + (((size_t)b * O + o) * P + pm[u]) * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (ob0 + 32 * u >= o1) break;
+                const float s = (zs[u] * scv + shv > 0.f) ? scv * gv[u] : 0.f;
+                const int key = keyof(idx[u]);
+                if (s != 0.f) {
+                    if (key >= 0) atomicAdd(&acc[key * 32 + lane], s);
+                    else atomicAdd(&p.fpart[flat_ * C + c], s);
+                }
+                wg0 = fmaf(av[u].y, s, wg0); wg1 = fmaf(av[u].z, s, wg1); wg2 = fmaf(av[u].w, s, wg2);
+            }
+        }
+        if (geo_wg)
+        for (int u = 0; u < U; u++) {
+            const int o = ob0 + 32 * u;
+            if (o >= o1) break;
+            const size_t eb = ((size_t)b * O + o) * P;
+            for (int pp = lane; pp < P; pp += 32) {
+                const float4 a = *(const float4 *)(p.att16 + (eb + pp) * 16);
+                const int key = keyof(nb[(size_t)o * P + pp]);
+                if (key >= 0) {
+                    atomicAdd(&gs[key * 4 + 0], a.y); atomicAdd(&gs[key * 4 + 1], a.z);
+                    atomicAdd(&gs[key * 4 + 2], a.w); atomicAdd(&gs[key * 4 + 3], 1.f);
+                } else {
+                    atomicAdd(&p.fgs[flat_ * 4 + 0], a.y); atomicAdd(&p.fgs[flat_ * 4 + 1], a.z);
+                    atomicAdd(&p.fgs[flat_ * 4 + 2], a.w); atomicAdd(&p.fgs[flat_ * 4 + 3], 1.f);
+                }
+                g9[0] += a.y * a.y; g9[1] += a.y * a.z; g9[2] += a.y * a.w;
+                g9[3] += a.z * a.y; g9[4] += a.z * a.z; g9[5] += a.z * a.w;
+                g9[6] += a.w * a.y; g9[7] += a.w * a.z; g9[8] += a.w * a.w;
+                g9[9] += a.y; g9[10] += a.z; g9[11] += a.w;
+            }
+        }
+    }
+    __syncthreads();
+    // flush: every element of the LDS copy is stored (the finish kernel sums the splits)
+    float *pp_ = p.part + (((size_t)b * p.nsplit + sp) * (N + 1)) * C;
+    for (int i = tid; i < (N + 1) * 32; i += 1024) {
+        const int key = i >> 5, l = i & 31;
+        if (c0 + l < C) pp_[(size_t)key * C + c0 + l] = acc[i];
+    }
+    if (geo_wg) {
+        float *gp_ = p.gpart + (((size_t)b * p.nsplit + sp) * (N + 1)) * 4;
+        for (int i = tid; i < (N + 1) * 4; i += 1024) gp_[i] = gs[i];
+    }
+    // dWg sparse part: lanes hold channel c, 32 groups -> LDS -> one atomic per channel
+    __syncthreads();
+    float *wr = lds;                                   // [3][32][32]
+    wr[(0 * 32 + grp) * 32 + lane] = wg0;
+    wr[(1 * 32 + grp) * 32 + lane] = wg1;
+    wr[(2 * 32 + grp) * 32 + lane] = wg2;
+    __syncthreads();
+    if (tid < 96) {
+        const int j = tid >> 5, l = tid & 31;
+        float v = 0.f;
+        for (int g = 0; g < 32; g++) v += wr[(j * 32 + g) * 32 + l];
+        if (c0 + l < C) atomicAdd(&p.wgs[j * C + c0 + l], (double)v);
+    }
+    if (geo_wg) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            float v = g9[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 63) == 0) red[tid >> 6][i] = v;
+        }
+        __syncthreads();
+        if (tid < 12) {
+            float v = 0.f;
+            for (int w = 0; w < 16; w++) v += red[w][tid];
+            atomicAdd(&p.gg[tid], (double)v);
+        }
+    }
+}
+
+// dYsrc[r][c], Gsum[r][4] from the partials + the dense (affine) part
+__global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd_finish(
+    const float *__restrict__ part, const float *__restrict__ gpart, const float *__restrict__ Ysrc,
+    const float *__restrict__ Wg, const float *__restrict__ bias, const float *__restrict__ scale,
+    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ m1,
+    const float *__restrict__ m2, int B, int N, int C, int nsplit, float *__restrict__ dYsrc,
+    float *__restrict__ Gsum, const float *__restrict__ fpart, const float *__restrict__ fgs)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * N * C) return;
+    const long long r = t / C;
+    const int c = (int)(t - r * C);
+    const int b = (int)(r / N), n = (int)(r - (long long)b * N);
+    // destination row r collects key n+1 of its own cloud and, for its last row, key 0 of the next
+    const float4 f4 = *(const float4 *)(fgs + r * 4);
+    float s = fpart[t], g0 = f4.x, g1 = f4.y, g2 = f4.z, cnt = f4.w;
+    for (int sp = 0; sp < nsplit; sp++) {
+        const size_t base = ((size_t)b * nsplit + sp) * (N + 1) + (n + 1);
+        s += part[base * C + c];
+        const float4 g = *(const float4 *)(gpart + base * 4);
+        g0 += g.x; g1 += g.y; g2 += g.z; cnt += g.w;
+        if (n == N - 1 && b + 1 < B) {
+            const size_t nb_ = ((size_t)(b + 1) * nsplit + sp) * (N + 1);
+            s += part[nb_ * C + c];
+            const float4 h = *(const float4 *)(gpart + nb_ * 4);
+            g0 += h.x; g1 += h.y; g2 += h.z; cnt += h.w;
+        }
+    }
+    const float sc = scale[c];
+    const float bz = -(sc * rstd[c]) * m2[c], cz = -(sc * m1[c]);
+    float lin = cnt * ((Ysrc ? Ysrc[r * C + c] : 0.f) + bias[c]);
+    if (Wg) lin += g0 * Wg[c] + g1 * Wg[C + c] + g2 * Wg[2 * C + c];
+    dYsrc[t] = s + (bz * lin + cnt * (cz - mean[c] * bz));
+    if (c == 0) *(float4 *)(Gsum + r * 4) = make_float4(g0, g1, g2, cnt);
+}
+
+int gg_edge_lin0_sparse_nsplit(int B, int C);
+
+size_t gg_edge_lin0_sparse_workspace(int B, int N, int C)
+{
+    const int nsplit = gg_edge_lin0_sparse_nsplit(B, C);
+    return ((size_t)B * nsplit * (N + 1) * (C + 4) + (size_t)B * N * (C + 4)) * sizeof(float);
+}
+
+int gg_edge_lin0_sparse_nsplit(int B, int C)
+{
+    int ns = 512 / (B * ((C + 31) / 32));
+    return ns < 1 ? 1 : (ns > 32 ? 32 : ns);
+}
+
+// 1 = shape not supported.  wgs[3*C] and gg[12] (fp64) must be zero-filled by the caller.
+int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *amax,
+                            const float *gval, const float *zsel, const float *Ysrc,
+                            const float *Wg, const float *bias, const float *scale,
+                            const float *shift, const float *mean, const float *rstd,
+                            const float *m1, const float *m2, int B, int N, int O, int P, int C,
+                            float *dYsrc, float *Gsum, double *wgs, double *gg, void *workspace,
+                            hipStream_t st)
+{
+    size_t lds = (size_t)(N + 1) * 36 * 4;
+    if (lds > 150 * 1024 || C < 1 || (C & 3)) return 1;
+    if (lds < 3 * 32 * 32 * 4) lds = 3 * 32 * 32 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        // (the kernel also has 1 KB of static LDS: dynamic + static must stay within 160 KB)
+        if (hipFuncSetAttribute((const void *)gg_k_edge_lin0_bwd_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    GGEdgeSparse p;
+    p.nebidx = nebidx; p.att16 = att16; p.amax = amax; p.gval = gval; p.zsel = zsel;
+    p.sc = scale; p.sh = shift; p.B = B; p.N = N; p.O = O; p.P = P; p.C = C;
+    p.nsplit = gg_edge_lin0_sparse_nsplit(B, C);
+    p.part = (float *)workspace;
+    p.gpart = p.part + (size_t)B * p.nsplit * (N + 1) * C;
+    p.fpart = p.gpart + (size_t)B * p.nsplit * (N + 1) * 4;
+    p.fgs = p.fpart + (size_t)B * N * C;
+    p.wgs = wgs; p.gg = gg;
+    if (hipMemsetAsync(p.fpart, 0, (size_t)B * N * (C + 4) * sizeof(float), st) != hipSuccess) return 3;
+    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 31) / 32, B), 1024, lds, st>>>(p);
+    const long long tot = (long long)B * N * C;
+    gg_k_edge_lin0_bwd_finish<<<(int)((tot + 255) / 256), 256, 0, st>>>(
+        p.part, p.gpart, Ysrc, Wg, bias, scale, mean, rstd, m1, m2, B, N, C, p.nsplit, dYsrc, Gsum,
+        p.fpart, p.fgs);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

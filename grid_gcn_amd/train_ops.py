@@ -45,6 +45,8 @@ DIRECT_DX = os.environ.get("GG_DX_LDS", "0") != "1"
 SRC_FIRST_CONV = os.environ.get("GG_EDGE_GEMM", "0") != "1"
 # ... and, for single-layer point MLPs, recomputed by its consumers instead of stored
 NO_Z0 = os.environ.get("GG_STORE_Z0", "0") != "1"
+# ... and its backward reduced to the sparse arg-max entries (gg_k_edge_lin0_bwd_sparse)
+SPARSE_L0 = os.environ.get("GG_SORTED_L0", "0") != "1"
 
 
 def supported(layers, x):
@@ -555,20 +557,45 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums0), E, C0, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]),
                                              _ptr(v[3]), st)
             _lib.check(rc, "gridgcn_bn_bwd_finalize")
-            zb = torch.zeros(R * C0 * 4 + 3 * C0 * 8, dtype=torch.uint8, device=dev)
-            dYsrc = zb[:R * C0 * 4].view(torch.float32).view(R, C0)
-            dWg = zb[R * C0 * 4:].view(torch.float64).view(3, C0)
-            nbytes = ctypes.c_size_t(0)
-            lib.gridgcn_take_backward_workspace_bytes(B, Nsrc, O * P, ctypes.byref(nbytes))
-            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-            rc = lib.gridgcn_edge_lin0_backward(
-                _ptr(Z0) if Z0 is not None else None, _ptr(Ysrc) if noz else None,
-                _ptr(wgb) if (noz and rot) else None, _ptr(wgb[3]) if noz else None,
-                _ptr(dY0) if dY0 is not None else None, sparse0[0], sparse0[1],
-                _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]),
-                _ptr(att16), _ptr(nebidx), B, Nsrc, O, P, C0, _ptr(dYsrc),
-                _ptr(dWg) if rot else None, _ptr(ws), nbytes.value, st)
-            _lib.check(rc, "gridgcn_edge_lin0_backward")
+            if noz and SPARSE_L0 and (Nsrc + 1) * 144 <= 150 * 1024:
+                # single-layer point MLP: only the arg-max entries are scattered; the dense
+                # BatchNorm terms collapse onto per-source counts and geo_vec sums
+                dYsrc = torch.empty((R, C0), dtype=torch.float32, device=dev)
+                Gsum = torch.empty((R, 4), dtype=torch.float32, device=dev)
+                acc64 = torch.zeros(3 * C0 + 12, dtype=torch.float64, device=dev)
+                wgs, gg = acc64[:3 * C0].view(3, C0), acc64[3 * C0:]
+                nbytes = ctypes.c_size_t(0)
+                lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes(B, Nsrc, C0,
+                                                                      ctypes.byref(nbytes))
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                rc = lib.gridgcn_edge_lin0_backward_sparse(
+                    _ptr(nebidx), _ptr(att16), _ptr(amax), _ptr(gp), _ptr(zsel[0]), _ptr(Ysrc),
+                    _ptr(wgb) if rot else None, _ptr(wgb[3]), _ptr(vec0[0]), _ptr(vec0[1]),
+                    _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), B, Nsrc, O, P, C0,
+                    _ptr(dYsrc), _ptr(Gsum), _ptr(wgs), _ptr(gg), _ptr(ws), nbytes.value, st)
+                _lib.check(rc, "gridgcn_edge_lin0_backward_sparse")
+                dWg = None
+                if rot:
+                    bz = -(vec0[0] * vec0[3]) * v[1]                      # [C0]
+                    cz = -(vec0[0] * v[0])
+                    GG, Gtot = gg[:9].view(3, 3).float(), gg[9:].float()
+                    t1 = torch.matmul(Gsum[:, :3].t(), Ysrc + wgb[3]) + torch.matmul(GG, wgb[:3])
+                    dWg = wgs.float() + bz * t1 + (cz - vec0[2] * bz) * Gtot[:, None]
+            else:
+                zb = torch.zeros(R * C0 * 4 + 3 * C0 * 8, dtype=torch.uint8, device=dev)
+                dYsrc = zb[:R * C0 * 4].view(torch.float32).view(R, C0)
+                dWg = zb[R * C0 * 4:].view(torch.float64).view(3, C0)
+                nbytes = ctypes.c_size_t(0)
+                lib.gridgcn_take_backward_workspace_bytes(B, Nsrc, O * P, ctypes.byref(nbytes))
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                rc = lib.gridgcn_edge_lin0_backward(
+                    _ptr(Z0) if Z0 is not None else None, _ptr(Ysrc) if noz else None,
+                    _ptr(wgb) if (noz and rot) else None, _ptr(wgb[3]) if noz else None,
+                    _ptr(dY0) if dY0 is not None else None, sparse0[0], sparse0[1],
+                    _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]),
+                    _ptr(v[1]), _ptr(att16), _ptr(nebidx), B, Nsrc, O, P, C0, _ptr(dYsrc),
+                    _ptr(dWg) if rot else None, _ptr(ws), nbytes.value, st)
+                _lib.check(rc, "gridgcn_edge_lin0_backward")
             # the two small GEMMs on the source points
             feat = src.detach()[..., 4:].reshape(R, Cf)
             dWf = torch.matmul(dYsrc.t(), feat)                       # [C0, Cf]

@@ -185,6 +185,24 @@ int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *
                                int Nsrc, int O, int P, int C0, float *dYsrc, double *dWg,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* Sparse form of that backward for a SINGLE-layer point MLP (upstream = the max pool: (amax, gval)
+ * of gridgcn_pairmax_bwd, zsel = Z0 at the arg max as kept by gridgcn_pairmax_fwd*).  dZ0's dense
+ * BatchNorm terms are affine in z0 = Ysrc[src] + Wg geo + b, so their per-source sum needs only the
+ * per-source edge count and sum of geo_vec; the ncent*C0 arg-max entries are scattered with LDS
+ * atomics.  Outputs: dYsrc[B*Nsrc, C0]; Gsum[B*Nsrc, 4] = (sum geo_vec, count) per source;
+ * wgs[3*C0] += sum_(o,c) geo_vec(e*) s[o,c]; gg[12] += (sum geo geo^T [9], sum geo [3]) (fp64, zeroed by
+ * the caller) -- from which dWg = wgs + bz (Gsum[:, :3]^T (Ysrc + b) + GG Wg) + (cz - mean bz) sum geo,
+ * bz = -scale*rstd*m2, cz = -scale*m1. */
+int gridgcn_edge_lin0_backward_sparse_workspace_bytes(int B, int Nsrc, int C0, size_t *bytes);
+int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
+                                      const int32_t *amax, const float *gval, const float *zsel,
+                                      const float *Ysrc, const float *Wg, const float *b,
+                                      const float *scale, const float *shift, const float *mean,
+                                      const float *rstd, const float *m1, const float *m2, int B,
+                                      int Nsrc, int O, int P, int C0, float *dYsrc, float *Gsum,
+                                      double *wgs, double *gg, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+
 /* ---- training-mode 1x1 conv + BatchNorm + ReLU (utils/ops.py:149-158 conv2d, :141-147 conv1d) ---
  * gridgcn_linear_fwd: Z[E,cout] = act(X[E,cin]) * W + b on fp32 MFMA; act = identity (scale ==
  *   NULL) or the previous layer's BatchNorm+ReLU x -> relu(x*scale[c] + shift[c]) applied while
