@@ -14,6 +14,7 @@ EXPORTS = [
     "gridgcn_gridify_knn_workspace_bytes", "gridgcn_gridify_knn",
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
+    "gridgcn_ball_knn_grid_workspace_bytes", "gridgcn_ball_knn_grid",
     "gridgcn_batch_take", "gridgcn_batch_take_backward",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
     "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
@@ -78,6 +79,11 @@ def load():
     lib.gridgcn_gridify_up.argtypes = [vp, vp, vp, vp, ci, ci, pp, vp, vp, vp, cs, vp]
     lib.gridgcn_ball_knn.restype = ci
     lib.gridgcn_ball_knn.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp]
+    lib.gridgcn_ball_knn_grid_workspace_bytes.restype = ci
+    lib.gridgcn_ball_knn_grid_workspace_bytes.argtypes = [ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_ball_knn_grid.restype = ci
+    lib.gridgcn_ball_knn_grid.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp,
+                                          cs, vp]
     lib.gridgcn_knn.restype = ci
     lib.gridgcn_knn.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
     lib.gridgcn_batch_take.restype = ci

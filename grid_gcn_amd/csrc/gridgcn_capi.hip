@@ -34,6 +34,9 @@ int gg_ce_fwd(const float *, int, int, const long long *, long long, int, float 
 int gg_ce_bwd(const float *, int, int, const long long *, long long, int, const float *,
               const double *, const float *, float *, hipStream_t);
 int gg_colsum(const float *, long long, int, int, double *, hipStream_t);
+size_t gg_ball_grid_workspace(int B, int m);
+int gg_ball_knn_grid(const float *, const float *, const int *, const int *, int, int, int, int,
+                     float, int *, void *, hipStream_t);
 size_t gg_take_bwd_sorted_workspace(int B, int N, int M);
 int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, int, int, void *,
                        hipStream_t);
@@ -517,6 +520,26 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
     const int rc = gg_edge_lin0_bwd_sparse(nebidx, att16, amax, gval, zsel, Ysrc, Wg, b, scale,
                                            shift, mean, rstd, m1, m2, B, Nsrc, O, P, C0, dYsrc, Gsum,
                                            wgs, gg, workspace, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_ball_knn_grid_workspace_bytes(int B, int m, size_t *bytes)
+{
+    if (!bytes || B < 1 || m < 1) return GRIDGCN_EINVAL;
+    *bytes = gg_ball_grid_workspace(B, m);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_ball_knn_grid(const float *unknown, const float *known, const int32_t *downnum,
+                          const int32_t *upnum, int B, int n, int m, int k, float radius,
+                          int32_t *idx, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!unknown || !known || !downnum || !upnum || !idx || B < 1 || n < 1 || m < 1 || k < 1 ||
+        k > 6 || !(radius >= 0.f) || (long long)B * n >= (1ll << 31))
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_ball_grid_workspace(B, m)) return GRIDGCN_EWORKSPACE;
+    const int rc = gg_ball_knn_grid(unknown, known, downnum, upnum, B, n, m, k, radius, idx,
+                                    workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

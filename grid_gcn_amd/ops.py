@@ -33,6 +33,8 @@ from . import _lib
 
 # backward of the neighbour gather as a sorted segmented sum (csrc/gridgcn_scatter.hip)
 SORTED_TAKE_BWD = os.environ.get("GG_TAKE_BWD_ATOMIC", "0") != "1"
+# BallKNN through a cell grid over the known points instead of the all-pairs scan
+BALL_GRID = os.environ.get("GG_BALL_SCAN", "0") != "1"
 
 def _require(cond, msg):
     if not cond:
@@ -183,7 +185,15 @@ def _knn_common(ball, unknown, known, downnum, upnum, k, radius, out):
     else:
         _chk(out, "out", 3, torch.int32, int(k))
     with torch.cuda.device(dev):
-        if ball:
+        if ball and BALL_GRID and int(k) <= 6 and m >= 64 and n * m >= (1 << 16) and radius >= 0:
+            # same indices through a cell grid over the known points (csrc/gridgcn_ballgrid.hip)
+            nb = ctypes.c_size_t(0)
+            lib.gridgcn_ball_knn_grid_workspace_bytes(B, m, ctypes.byref(nb))
+            ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+            rc = lib.gridgcn_ball_knn_grid(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum),
+                                           B, n, m, int(k), ctypes.c_float(radius), _ptr(out),
+                                           _ptr(ws), nb.value, _stream(unknown))
+        elif ball:
             rc = lib.gridgcn_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n,
                                       m, int(k), ctypes.c_float(radius), _ptr(out),
                                       _stream(unknown))

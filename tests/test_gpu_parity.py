@@ -112,6 +112,46 @@ def test_gridify_synth200k():
         d, n = want[2], want[4]
 
 
+@pytest.mark.parametrize("n,m,k,radius,kind", [
+    (4096, 512, 5, 0.1275, "ball"), (4096, 512, 3, 0.05, "planes"), (2000, 300, 6, 0.4, "ball"),
+    (3000, 128, 5, 5.0, "ball"), (3000, 128, 4, 0.0, "ball"), (5000, 1024, 6, 0.02, "lattice"),
+    (1500, 700, 5, 0.3, "special")])
+def test_ball_knn_grid_equals_scan(n, m, k, radius, kind):
+    """BallKNN through the cell grid (gridgcn_ball_knn_grid) == the S0 oracle's all-pairs scan, bit
+    for bit: ties (lattice: many equal distances), queries outside the known points' box, partial
+    downnum / upnum, non-finite coordinates, radius 0 and radius >> extent."""
+    rng = np.random.default_rng(n + m + k)
+    B = 3
+    if kind == "lattice":       # coordinates on a coarse lattice: lots of exactly equal distances
+        un = rng.integers(-8, 9, (B, n, 3)).astype(np.float32) * 0.01
+        kn = rng.integers(-8, 9, (B, m, 3)).astype(np.float32) * 0.01
+    else:
+        d1, _ = synth.make_batch(B, n, "planes" if kind == "planes" else "ball", first_id=7)
+        d2, _ = synth.make_batch(B, m, "planes" if kind == "planes" else "ball", first_id=70)
+        un, kn = d1[..., :3].copy() * 1.3, d2[..., :3].copy()      # some queries outside the box
+    if kind == "special":
+        kn[0, 5] = np.nan
+        kn[1, 7, 1] = np.inf
+        kn[2, 9] = -np.inf
+        un[0, 3, 0] = np.nan
+        un[1, 4] = np.inf
+        un[2, 6] = 1e30
+    dn = np.array([[m], [m - 17], [m // 2]], np.int32)
+    upn = np.array([[n], [n - 100], [1]], np.int32)
+    want = orc.ball_knn(un, kn, dn, upn, k=k, radius=radius)
+    assert ops.BALL_GRID and n * m >= (1 << 16) and m >= 64          # the grid path is taken
+    got = NP((ops.BallKNN(T(un), T(kn), T(dn), T(upn), k=k, radius=radius),))[0]
+    assert np.array_equal(got, want)
+    # and the library's own all-pairs kernel agrees as well
+    import os
+    ops.BALL_GRID = False
+    try:
+        scan = NP((ops.BallKNN(T(un), T(kn), T(dn), T(upn), k=k, radius=radius),))[0]
+    finally:
+        ops.BALL_GRID = True
+    assert np.array_equal(scan, want)
+
+
 def test_error_behaviour():
     data, npn = synth.make_batch(1, 256, "ball")
     kw = synth.gridify_kwargs(synth.SEG_SCANNET_8192, 0)
