@@ -66,6 +66,10 @@ def run_mlp(layers, x, mfma=True):
         from . import train_ops
         if train_ops.supported(layers, x):
             return train_ops.mlp_bn_relu_train(x, layers)
+    if mfma and x.is_cuda and layers and not layers[0].training and not torch.is_grad_enabled():
+        from . import train_ops
+        if train_ops.supported(layers, x) and all(l.lin.in_features <= 1024 for l in layers):
+            return train_ops.mlp_bn_relu_eval(x, layers)      # same MFMA kernel, running stats
     for l in layers:
         x = l(x)
     return x

@@ -343,6 +343,43 @@ class _MLPTrain(torch.autograd.Function):
         return (dX, None) + tuple(grads)
 
 
+@torch.no_grad()
+def mlp_bn_relu_eval(x, layers):
+    """Inference through the same forward kernel: layer l computes Z_l = act(Z_{l-1}) W_l^T + b_l
+    with act = the previous layer's BatchNorm (running statistics) + ReLU applied while the rows are
+    loaded; one BatchNorm+ReLU pass at the end.  x [..., cin] float32 on the GPU."""
+    lib = _lib.load()
+    shp = x.shape
+    prev = x.reshape(-1, shp[-1]).contiguous()
+    E, dev = prev.shape[0], prev.device
+    if prev.shape[1] % 8:                      # the kernel reads rows in 32-byte pieces
+        prev = torch.nn.functional.pad(prev, (0, 8 - prev.shape[1] % 8))
+    sc = sh = None
+    with torch.cuda.device(dev):
+        st = _stream(prev)
+        for l in layers:
+            W, b, bn = l.lin.weight, l.lin.bias, l.bn
+            cout, cin_w = W.shape
+            cin = prev.shape[1]
+            K, ldw, nwp, nwb = packed_sizes(cout, cin)
+            pk = torch.empty(ldw + cin * ldw, dtype=torch.float32, device=dev)
+            Bp, Wq = pk[:ldw], pk[ldw:]
+            _lib.check(lib.gridgcn_pack_linear(_ptr(W), _ptr(b), cout, cin_w, 0, cin, 0, None,
+                                               _ptr(Bp), None, None, _ptr(Wq), None, st), "pack")
+            Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
+            _lib.check(lib.gridgcn_linear_fwd_direct(
+                _ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, cout,
+                _ptr(sc) if sc is not None else None, _ptr(sh) if sh is not None else None,
+                _ptr(Z), None, st), "gridgcn_linear_fwd_direct")
+            sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+            sh = (bn.bias - bn.running_mean * sc).contiguous()
+            prev = Z
+        Y = torch.empty_like(prev)
+        _lib.check(lib.gridgcn_bn_relu_apply(_ptr(prev), _ptr(sc), _ptr(sh), _ptr(Y), E,
+                                             Y.shape[1], Y.shape[1], st), "gridgcn_bn_relu_apply")
+    return Y.reshape(shp[:-1] + (Y.shape[1],))
+
+
 def mlp_bn_relu_train(x, layers, out=None):
     """x [..., cin] -> [..., cout_last] through `layers` (gridconv.ConvBNReLU modules, training
     mode).  Callers check supported() first.  out: optional [E, cout_last] destination

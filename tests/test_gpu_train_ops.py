@@ -226,6 +226,27 @@ def test_linear_plain_and_loss_match_torch(E, cin, C):
     close(lin3.bias.grad, lin1.bias.grad)
 
 
+@pytest.mark.parametrize("E,cin,dims", [(5000, 4, [128]), (4097, 256, [128, 128]), (300, 67, [64, 32]),
+                                        (70001, 128, [128, 256])])
+def test_mlp_eval_matches_modules(E, cin, dims):
+    """inference through the forward kernel with running statistics == the stock modules in eval()"""
+    torch.manual_seed(E + cin)
+    ref = mlp(cin, dims).to(DEV)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+            m.running_mean.normal_(0, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+    ref.eval()
+    x = torch.randn(E, cin, device=DEV) * 1.5
+    with torch.no_grad():
+        y1 = ref(x)
+        y2 = train_ops.mlp_bn_relu_eval(x, list(ref))
+    assert y1.shape == y2.shape
+    assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))
+
+
 def test_unsupported_width_falls_to_modules():
     m = mlp(8, [48]).to(DEV).train()
     x = torch.randn(10, 8, device=DEV)
