@@ -25,6 +25,7 @@ EXPORTS = [
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
+    "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
 ]
@@ -104,6 +105,12 @@ def load():
     lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_relu_apply.restype = ci
     lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, vp]
+    lib.gridgcn_bn_relu_dropout_apply.restype = ci
+    lib.gridgcn_bn_relu_dropout_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, ctypes.c_float,
+                                                  ctypes.c_uint64, vp]
+    lib.gridgcn_linear_dx.restype = ci
+    lib.gridgcn_linear_dx.argtypes = [vp] * 14 + [ci, ll, ci, ci, ci, ctypes.c_float,
+                                                  ctypes.c_uint64, vp, vp, vp]
     lib.gridgcn_bn_relu_bwd_reduce.restype = ci
     lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, ci, vp, vp]
     lib.gridgcn_bn_relu_bwd_elemt.restype = ci

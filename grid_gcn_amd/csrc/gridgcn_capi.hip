@@ -263,7 +263,7 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     size_t need = 0;
     gg_linear_bwd_workspace(E, cin, C, &need, nullptr);
     if (!workspace || workspace_bytes < need) return GRIDGCN_EWORKSPACE;
-    GGLinBwd p;
+    GGLinBwd p = {};
     p.dY = dY; p.Z = Z; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
     p.m1 = m1; p.m2 = m2; p.Aprev = Aprev; p.pscale = pscale; p.pshift = pshift; p.pmean = pmean;
     p.prstd = prstd; p.Wb = Wb; p.Wg = Wg; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW;
@@ -275,6 +275,38 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     if (p.ldy < C) return GRIDGCN_EINVAL;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const float *shift,
+                      const float *mean, const float *rstd, const float *m1, const float *m2,
+                      const float *Aprev, const float *pscale, const float *pshift,
+                      const float *pmean, const float *prstd, const float *Wdx, int ndx,
+                      long long E, int C, int cin, int ldy, float drop_p, uint64_t drop_seed,
+                      float *dX, double *psums, void *stream)
+{
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Wdx || !dX)
+        return GRIDGCN_EINVAL;
+    if (E < 1 || C < 1 || cin < 1 || ndx < 1 || ndx > cin || ldy < C) return GRIDGCN_EINVAL;
+    if (pscale && (!pshift || !pmean || !prstd || !psums || !Aprev)) return GRIDGCN_EINVAL;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return GRIDGCN_EINVAL;
+    GGLinBwd p = {};
+    p.dY = dY; p.Z = Z; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
+    p.m1 = m1; p.m2 = m2; p.Aprev = Aprev ? Aprev : dX; p.pscale = pscale; p.pshift = pshift;
+    p.pmean = pmean; p.prstd = prstd; p.dX = dX; p.psums = psums; p.E = E; p.C = C; p.cin = cin;
+    p.P = 1; p.Wdx = Wdx; p.ndx = ndx; p.cin_w = cin; p.ldy = ldy;
+    gg_drop_consts(drop_p, &p.drop_thr, &p.drop_scale);
+    p.drop_lo = (unsigned)drop_seed; p.drop_hi = (unsigned)(drop_seed >> 32);
+    const int rc = gg_linear_dx_direct(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_bn_relu_dropout_apply(const float *Z, const float *scale, const float *shift, float *Y,
+                                  long long E, int C, int ldy, float drop_p, uint64_t drop_seed,
+                                  void *stream)
+{
+    if (!Z || !scale || !shift || !Y || E < 1 || C < 1 || ldy < C) return GRIDGCN_EINVAL;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return GRIDGCN_EINVAL;
+    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, drop_p, drop_seed, (hipStream_t)stream);
 }
 
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
@@ -326,7 +358,7 @@ int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift
                           long long E, int C, int ldy, void *stream)
 {
     if (!Z || !scale || !shift || !Y || E < 1 || C < 1 || ldy < C) return GRIDGCN_EINVAL;
-    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, (hipStream_t)stream);
+    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, 0.f, 0ull, (hipStream_t)stream);
 }
 
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,

@@ -363,7 +363,10 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                     const int rr = (r & 3) + 8 * (r >> 2);
                     if (nrows == 32 || rr + 4 * h < nrows) {
                         const int off = rr * ldx + t * 32;
-                        const float dx = acc[t][r];
+                        float dx = acc[t][r];
+                        if (p.drop_thr)   // the input activation went through Dropout (gg_k_bn_apply)
+                            dx = gg_drop_keep((unsigned long long)(base + off), p.drop_lo, p.drop_hi,
+                                              p.drop_thr) ? dx * p.drop_scale : 0.f;
                         xp[off] = dx;
                         if (prevbn) {
                             const float zp = ap[off];

@@ -22,6 +22,21 @@ template <> __device__ __forceinline__ float ggm_vget<4>(const float4 &v, int i)
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// Dropout mask as a counter-based hash of (seed, element index): the forward pass and the backward
+// pass regenerate the same bit, no mask tensor is stored.  Element idx of a [E][C] activation is
+// row*C + col.  keep <=> hash >= thr with thr = p * 2^32 (p = drop probability; thr 0 keeps all).
+__device__ __forceinline__ bool gg_drop_keep(unsigned long long idx, unsigned seed_lo,
+                                             unsigned seed_hi, unsigned thr)
+{
+    unsigned h = (unsigned)idx ^ seed_lo;
+    h *= 0x9E3779B1u;
+    h ^= (unsigned)(idx >> 32) * 0x7FEB352Du + seed_hi;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h >= thr;
+}
+
 __device__ __forceinline__ int ggm_row(int reg, int lane) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }

@@ -39,6 +39,8 @@ struct GGLinBwd {
     const int *amax;      // sparse upstream gradient (nullptr: dense dY): arg-max neighbour [E/P][C]
     const float *gval;    //   and its value [E/P][C]; row e = centre e/P, neighbour e%P
     int P, ncen_max;
+    unsigned drop_thr, drop_lo, drop_hi;   // register-direct dX only: dX *= dropout mask of the
+    float drop_scale;                      // [E][cin] input activation (gg_drop_keep), thr 0 = off
     int rt;               // rows per workgroup tile of gg_k_linear_dw (32/64/96/128)
     unsigned t1[4];       // per wave: up to 3 GEMM1 column tiles, one byte each, 0xff = none
     unsigned t2[4][3];    // per wave: up to 12 GEMM2 (m,n) pair ids, one byte each, 0xff = none
@@ -52,7 +54,8 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shap
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
-                int C, int ldy, hipStream_t st);
+                int C, int ldy, float drop_p, unsigned long long seed, hipStream_t st);
+void gg_drop_consts(float p, unsigned *thr, float *dscale);
 int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const float *shift,
                      const float *mean, const float *rstd, long long E, int C, double *sums,
                      int ldy, hipStream_t st);

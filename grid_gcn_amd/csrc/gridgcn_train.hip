@@ -1084,8 +1084,10 @@ __global__ __launch_bounds__(256) void gg_k_bn_apply(const float *__restrict__ Z
                                                      const float *__restrict__ scale,
                                                      const float *__restrict__ shift,
                                                      float *__restrict__ Y, long long total, int C,
-                                                     int ldy)
+                                                     int ldy, unsigned thr, float dscale,
+                                                     unsigned slo, unsigned shi)
 {
+    // thr != 0: Dropout behind the ReLU (mx.sym.Dropout, ggcn_models_g.py:36): kept values * dscale
     if ((C & 3) == 0 && (ldy & 3) == 0) {
         const long long n4 = total >> 2;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4;
@@ -1097,6 +1099,13 @@ __global__ __launch_bounds__(256) void gg_k_bn_apply(const float *__restrict__ Z
             float4 y;
             y.x = fmaxf(z.x * sc.x + sh.x, 0.f); y.y = fmaxf(z.y * sc.y + sh.y, 0.f);
             y.z = fmaxf(z.z * sc.z + sh.z, 0.f); y.w = fmaxf(z.w * sc.w + sh.w, 0.f);
+            if (thr) {
+                const unsigned long long e = (unsigned long long)i * 4;
+                y.x = gg_drop_keep(e, slo, shi, thr) ? y.x * dscale : 0.f;
+                y.y = gg_drop_keep(e + 1, slo, shi, thr) ? y.y * dscale : 0.f;
+                y.z = gg_drop_keep(e + 2, slo, shi, thr) ? y.z * dscale : 0.f;
+                y.w = gg_drop_keep(e + 3, slo, shi, thr) ? y.w * dscale : 0.f;
+            }
             *(float4 *)(Y + row * ldy + c) = y;
         }
     } else {
@@ -1104,7 +1113,9 @@ __global__ __launch_bounds__(256) void gg_k_bn_apply(const float *__restrict__ Z
              i += (long long)gridDim.x * 256) {
             const long long row = i / C;
             const int c = (int)(i - row * C);
-            Y[row * ldy + c] = fmaxf(Z[i] * scale[c] + shift[c], 0.f);
+            float y = fmaxf(Z[i] * scale[c] + shift[c], 0.f);
+            if (thr) y = gg_drop_keep((unsigned long long)i, slo, shi, thr) ? y * dscale : 0.f;
+            Y[row * ldy + c] = y;
         }
     }
 }
@@ -1185,12 +1196,23 @@ static int grid_for(long long work, int per_block, int cap)
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
 
+// drop probability p -> (threshold on the 32-bit hash, scale of the kept values)
+void gg_drop_consts(float p, unsigned *thr, float *dscale)
+{
+    double t = (double)p * 4294967296.0;
+    *thr = p > 0.f ? (unsigned)(t > 4294967295.0 ? 4294967295.0 : t) : 0u;
+    *dscale = p > 0.f ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+}
+
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
-                int C, int ldy, hipStream_t st)
+                int C, int ldy, float drop_p, unsigned long long seed, hipStream_t st)
 {
     long long total = E * C;
-    gg_k_bn_apply<<<grid_for(total / 4 + 1, 256, 65536), 256, 0, st>>>(Z, scale, shift, Y, total, C,
-                                                                      ldy);
+    unsigned thr;
+    float ds;
+    gg_drop_consts(drop_p, &thr, &ds);
+    gg_k_bn_apply<<<grid_for(total / 4 + 1, 256, 65536), 256, 0, st>>>(
+        Z, scale, shift, Y, total, C, ldy, thr, ds, (unsigned)seed, (unsigned)(seed >> 32));
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

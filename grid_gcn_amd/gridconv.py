@@ -115,7 +115,8 @@ class SubGUpdate(nn.Module):
 
     mfma_train = True   # training on the GPU: MLPs through csrc/gridgcn_train.hip
     tail_layers = ()    # ConvBNReLU layers of the caller that directly follow update_mlp (not owned)
-    tail_done = False   # set by finish(): the tail layers were applied
+    tail_done = False   # set by finish(): the tail layers were applied (2: the tail head as well)
+    tail_head = None    # (dropout p, nn.Linear) of the caller that follows the tail layers
 
     def edge_inputs(self, neighbors, centers_xyz):
         geo_vec, _, att_vec = geo_features(neighbors, centers_xyz)
@@ -238,6 +239,14 @@ class SubGUpdate(nn.Module):
                 # up layer) join the same chain: one activation pass and one reduce pass less
                 layers += list(self.tail_layers)
                 self.tail_done = True
+                if self.tail_head is not None and self.mfma_train and agg.is_cuda and \
+                        self.training and torch.is_grad_enabled():
+                    from . import train_ops
+                    p, lin = self.tail_head
+                    if train_ops.head_supported(agg, layers, lin):
+                        # ... and the Dropout + class-score Linear behind them (train_ops._HeadTrain)
+                        self.tail_done = 2
+                        return train_ops.head_train(agg, layers, p, lin)
             agg = run_mlp(layers, agg, self.mfma_train)
         if center_masks is not None:
             agg = agg * center_masks[..., None]                            # :284-285

@@ -16,6 +16,8 @@ from .gridconv import ConvBNReLU, SubGUpdate, run_mlp
 
 # last linear layer + softmax cross-entropy on the hand-written kernels (GPU, float32)
 HEAD_KERNELS = os.environ.get("GG_HEAD_TORCH", "0") != "1"
+# fc1 -> dropout -> fc2 as one op with the dropout folded into the neighbouring kernels
+FUSED_HEAD = os.environ.get("GG_HEAD_UNFUSED", "0") != "1"
 
 SEG_8192 = dict(
     grid=synth.SEG_SCANNET_8192, inputDim=[0, 64, 128], pt_ele_dim=[[32, 32, 64], [64, 64, 128],
@@ -65,6 +67,9 @@ class GGCNSeg(nn.Module):
         self.fc2 = nn.Linear(128, cfg["num_classes"])
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
+        if HEAD_KERNELS and FUSED_HEAD and index_ops is HipIndexOps:
+            # ... and so do fc1/dropout + fc2 (:36-38): train_ops._HeadTrain
+            object.__setattr__(self.up[-1], "tail_head", (cfg["dropout"], self.fc2))
 
     fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
     jobs = None    # set to a list to record (name, layer, cent, src, nebidx) of every fused call
@@ -126,6 +131,8 @@ class GGCNSeg(nn.Module):
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
             if i != nup - 1:                      # (the last layer's features go to the head only)
                 f_last = torch.cat([upl, cf], dim=2)                                # :231
+        if self.up[-1].tail_done == 2:            # fc1, dropout and fc2 ran inside the last up layer
+            return cf
         net = cf if self.up[-1].tail_done else run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
         if HEAD_KERNELS and self.training and torch.is_grad_enabled() and self.ix is HipIndexOps:

@@ -253,6 +253,18 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     return dY, grads
 
 
+def _tn_matmul(a, b):
+    """a^T b for tall operands a [R,m], b [R,n] with small m, n: the contraction is cut into
+    128-row slabs (one batched GEMM + a sum) so that the work spreads over the chip -- a plain
+    [m,R]x[R,n] GEMM runs on m*n/tile workgroups only."""
+    R = a.shape[0]
+    if R >= 1024 and R % 128 == 0:
+        S = R // 128
+        return torch.bmm(a.view(S, 128, a.shape[1]).transpose(1, 2),
+                         b.view(S, 128, b.shape[1])).sum(0)
+    return torch.matmul(a.t(), b)
+
+
 def alias_columns(buf, col0, ncol):
     """A fresh tensor (no autograd / view relation) over columns [col0, col0+ncol) of the contiguous
     2-D buffer `buf`: lets two producers write the halves of a concatenation in place."""
@@ -616,7 +628,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                     bz = -(vec0[0] * vec0[3]) * v[1]                      # [C0]
                     cz = -(vec0[0] * v[0])
                     GG, Gtot = gg[:9].view(3, 3).float(), gg[9:].float()
-                    t1 = torch.matmul(Gsum[:, :3].t(), Ysrc + wgb[3]) + torch.matmul(GG, wgb[:3])
+                    t1 = _tn_matmul(Gsum, Ysrc + wgb[3])[:3] + torch.matmul(GG, wgb[:3])
                     dWg = wgs.float() + bz * t1 + (cz - vec0[2] * bz) * Gtot[:, None]
             else:
                 zb = torch.zeros(R * C0 * 4 + 3 * C0 * 8, dtype=torch.uint8, device=dev)
@@ -635,7 +647,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 _lib.check(rc, "gridgcn_edge_lin0_backward")
             # the two small GEMMs on the source points
             feat = src.detach()[..., 4:].reshape(R, Cf)
-            dWf = torch.matmul(dYsrc.t(), feat)                       # [C0, Cf]
+            dWf = _tn_matmul(dYsrc, feat)                             # [C0, Cf]
             dW0 = torch.cat([dWg.t().float(), dWf], dim=1) if rot else dWf
             gsrc = None
             if ctx.needs_input_grad[0]:
@@ -864,6 +876,132 @@ def linear_plain_train(x, lin):
     shp = x.shape
     y = _LinearPlain.apply(x.reshape(-1, shp[-1]), lin.weight, lin.bias)
     return y.reshape(shp[:-1] + (y.shape[-1],))
+
+
+class _HeadTrain(torch.autograd.Function):
+    """conv+BN+ReLU chain -> Dropout(p) -> Linear (ggcn_models_g.py:33-38: fc1, fc1/dropout, fc2)
+    as one op.  The Dropout mask is a hash of (seed, element index): the forward applies it while
+    the last BatchNorm+ReLU is written, the backward while fc2's input gradient is written -- whose
+    epilogue also accumulates fc1's BatchNorm-backward sums.  Against the separate ops this drops
+    the dropout forward / backward passes and one reduce pass over the [E, C] gradient."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        lib = _lib.load()
+        eps, bns, p, seed = meta
+        L = (len(params) - 2) // 4
+        W2, b2 = params[4 * L], params[4 * L + 1]
+        x = x.contiguous()
+        E, dev = x.shape[0], x.device
+        C2 = W2.shape[0]
+        Cp = (C2 + 7) & ~7
+        with torch.cuda.device(dev):
+            stream = _stream(x)
+            st = _chain_forward(lib, x, params[:4 * L], bns, eps, 0,
+                                x.shape[1] if ctx.needs_input_grad[0] else 0)
+            C = st.Z[-1].shape[1]
+            Hd = torch.empty((E, C), dtype=torch.float32, device=dev)
+            _lib.check(lib.gridgcn_bn_relu_dropout_apply(
+                _ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]), _ptr(Hd), E, C, C,
+                float(p), int(seed), stream), "gridgcn_bn_relu_dropout_apply")
+            K, ldw, nwp, nwb = packed_sizes(C2, C)
+            ntv = next(v for v in (1, 2, 4, 8) if v * 32 >= C)
+            pk = torch.empty(ldw + nwb + C * ldw + Cp * 32 * ntv, dtype=torch.float32, device=dev)
+            Bp, Wb, Wq = pk[:ldw], pk[ldw:ldw + nwb], pk[ldw + nwb:ldw + nwb + C * ldw]
+            Wdx = pk[ldw + nwb + C * ldw:]
+            _lib.check(lib.gridgcn_pack_linear(_ptr(W2.detach().contiguous()), _ptr(b2.detach()),
+                                               C2, C, 0, C, C, None, _ptr(Bp), _ptr(Wb), None,
+                                               _ptr(Wq), _ptr(Wdx), stream), "pack")
+            Z2 = torch.empty((E, Cp), dtype=torch.float32, device=dev)
+            _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(Hd), E, C, C, _ptr(Wq), _ptr(Bp), ldw,
+                                                     Cp, None, None, _ptr(Z2), None, stream),
+                       "gridgcn_linear_fwd_direct")
+        ctx.L = L
+        ctx.ndx = st.ndx
+        ctx.drop = (float(p), int(seed))
+        ctx.dims = (C2, Cp)
+        ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg,
+                              *st.Wdx, Hd, Z2, Wb, Wdx)
+        return Z2[:, :C2]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        L = ctx.L
+        t = ctx.saved_tensors
+        x = t[0]
+        Zs, scales, shifts = t[1:1 + L], t[1 + L:1 + 2 * L], t[1 + 2 * L:1 + 3 * L]
+        means, rstds, Wbs = t[1 + 3 * L:1 + 4 * L], t[1 + 4 * L:1 + 5 * L], t[1 + 5 * L:1 + 6 * L]
+        Wgs, Wdxs = t[1 + 6 * L:1 + 7 * L], t[1 + 7 * L:1 + 8 * L]
+        Hd, Z2, Wb2, Wdx2 = t[1 + 8 * L:]
+        C2, Cp = ctx.dims
+        E, dev = x.shape[0], x.device
+        C = Zs[-1].shape[1]
+        if g.stride() == (Cp, 1) and g.storage_offset() == 0 and \
+                g.untyped_storage().nbytes() == E * Cp * 4:
+            dL = g.as_strided((E, Cp), (Cp, 1))      # softmax_ce's zero-padded gradient buffer
+        else:
+            dL = torch.zeros((E, Cp), dtype=torch.float32, device=dev)
+            dL[:, :C2] = g
+        ident = _identity_consts(Cp, dev)
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            dH = torch.empty((E, C), dtype=torch.float32, device=dev)
+            acc = torch.zeros(2 * C + Cp, dtype=torch.float64, device=dev)
+            sums, db64 = acc[:2 * C], acc[2 * C:]
+            # gradient w.r.t. relu(bn(Z_fc1)) (dropout mask applied) + fc1's BatchNorm-backward sums
+            _lib.check(lib.gridgcn_linear_dx(
+                _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
+                _ptr(ident[4]), _ptr(ident[5]), _ptr(Zs[-1]), _ptr(scales[-1]), _ptr(shifts[-1]),
+                _ptr(means[-1]), _ptr(rstds[-1]), _ptr(Wdx2), C, E, Cp, C, Cp, ctx.drop[0],
+                ctx.drop[1], _ptr(dH), _ptr(sums), st), "gridgcn_linear_dx")
+            dW2 = torch.empty((Cp, C), dtype=torch.float32, device=dev)
+            nbytes = ctypes.c_size_t(0)
+            lib.gridgcn_linear_bwd_workspace_bytes(E, C, Cp, ctypes.byref(nbytes))
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            _lib.check(lib.gridgcn_linear_bwd(
+                _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
+                _ptr(ident[4]), _ptr(ident[5]), _ptr(Hd), None, None, None, None, _ptr(Wb2), None,
+                None, 0, E, Cp, C, C, 0, 0, None, _ptr(dW2), None, None, None, 0, _ptr(ws),
+                nbytes.value, st), "gridgcn_linear_bwd")
+            _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C2, _ptr(db64), st), "gridgcn_colsum")
+            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
+                                        ctx.ndx, sums, dH, None, ctx.needs_input_grad[0])
+        return (dX, None) + tuple(grads) + (dW2[:C2], db64[:C2].float())
+
+
+def head_supported(x, layers, lin):
+    C = layers[-1].lin.out_features
+    return (supported(layers, x) and DIRECT_FWD and DIRECT_DX and lin.bias is not None
+            and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
+
+
+def head_train(x, layers, p, lin, seed=None):
+    """x [..., cin] -> class scores [..., lin.out_features] through `layers` (ConvBNReLU modules in
+    training mode), Dropout(p) and the Linear `lin`.  seed: dropout seed (None: drawn from torch's
+    CPU generator, i.e. reproducible under torch.manual_seed)."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    shp = x.shape
+    params = []
+    for l in layers:
+        params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
+    params += [lin.weight, lin.bias]
+    y = _HeadTrain.apply(x.reshape(-1, shp[-1]), (layers[0].bn.eps, [l.bn for l in layers],
+                                                  float(p), seed), *params)
+    return y.reshape(shp[:-1] + (y.shape[-1],))
+
+
+def dropout_mask(E, C, p, seed, device):
+    """The {0, 1/(1-p)} factors head_train applies for (p, seed) on an [E, C] activation (tests)."""
+    lib = _lib.load()
+    one = torch.ones((E, C), dtype=torch.float32, device=device)
+    sc, sh = torch.ones(C, device=device), torch.zeros(C, device=device)
+    m = torch.empty_like(one)
+    with torch.cuda.device(one.device):
+        _lib.check(lib.gridgcn_bn_relu_dropout_apply(_ptr(one), _ptr(sc), _ptr(sh), _ptr(m), E, C,
+                                                     C, float(p), int(seed), _stream(one)), "drop")
+    return m
 
 
 class _SoftmaxCE(torch.autograd.Function):

@@ -310,6 +310,25 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         double *sums_a, const float *zsel, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
                           long long E, int C, int ldy, void *stream);
+/* Head of the segmentation net: fc1 (conv+BN+ReLU) -> Dropout(p) -> fc2
+ * (segmentation/models/ggcn_models_g.py:33-38).  The Dropout is folded into the two kernels either
+ * side of it; its mask is a counter-based hash of (drop_seed, element index row*C + col) that the
+ * backward regenerates, so no mask is stored and no separate pass runs:
+ *   gridgcn_bn_relu_dropout_apply: Y = dropout(relu(Z*scale + shift)), kept values * 1/(1-p).
+ *   gridgcn_linear_dx: the dX half of gridgcn_linear_bwd on its own (register-direct schedule only,
+ *     EINVAL if the shape is outside it): dX[E,0:ndx] = dZ W, times the dropout mask of the
+ *     [E][cin] input activation when drop_p > 0 (ndx = cin then), and psums of the layer in front
+ *     (Aprev = its raw output, pscale.. its BatchNorm) accumulated from the masked dX.
+ * 0 <= drop_p < 1; drop_p = 0 is the identity. */
+int gridgcn_bn_relu_dropout_apply(const float *Z, const float *scale, const float *shift, float *Y,
+                                  long long E, int C, int ldy, float drop_p, uint64_t drop_seed,
+                                  void *stream);
+int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const float *shift,
+                      const float *mean, const float *rstd, const float *m1, const float *m2,
+                      const float *Aprev, const float *pscale, const float *pshift,
+                      const float *pmean, const float *prstd, const float *Wdx, int ndx,
+                      long long E, int C, int cin, int ldy, float drop_p, uint64_t drop_seed,
+                      float *dX, double *psums, void *stream);
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
                                const float *shift, const float *mean, const float *rstd,
                                long long E, int C, int ldy, double *sums, void *stream);

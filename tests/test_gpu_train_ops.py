@@ -253,3 +253,87 @@ def test_unsupported_width_falls_to_modules():
     assert not train_ops.supported(list(m), x)      # 256 % 48 != 0
     from grid_gcn_amd.gridconv import run_mlp
     assert run_mlp(list(m), x).shape == (10, 48)
+
+
+@pytest.mark.parametrize("E,cin,dims,C2,p", [(5000, 256, [128, 128], 21, 0.5), (70001, 128, [128], 21, 0.5),
+                                             (333, 64, [64], 13, 0.3), (4097, 256, [128, 128], 21, 0.0)])
+def test_head_train_matches_torch(E, cin, dims, C2, p):
+    """fc1 chain -> Dropout(p) -> fc2 as one op (dropout folded into the neighbouring kernels)
+    against the stock modules with the SAME mask (train_ops.dropout_mask regenerates it)."""
+    torch.manual_seed(E + cin + C2)
+    ref = mlp(cin, dims).to(DEV).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    lin1 = torch.nn.Linear(dims[-1], C2).to(DEV)
+    new, lin2 = copy.deepcopy(ref), copy.deepcopy(lin1)
+    x1 = (torch.randn(E, cin, device=DEV) * 1.5).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    seed = 987654321012345 + E
+    assert train_ops.head_supported(x2, list(new), lin2)
+    mask = train_ops.dropout_mask(E, dims[-1], p, seed, DEV)
+    keep = float((mask > 0).float().mean())
+    assert abs(keep - (1.0 - p)) < 0.01, keep                  # the hash drops a fraction p
+    import numpy as np
+    assert set(mask.unique().tolist()) <= {0.0, float(np.float32(1.0 / (1.0 - float(np.float32(p)))))}
+    if p > 0:                                                  # and its bits are not correlated
+        m01 = (mask > 0).float()
+        assert abs(float((m01[:, 1:] * m01[:, :-1]).mean()) - (1 - p) ** 2) < 0.01
+        assert abs(float((m01[1:] * m01[:-1]).mean()) - (1 - p) ** 2) < 0.01
+        assert not torch.equal(mask, train_ops.dropout_mask(E, dims[-1], p, seed + 1, DEV))
+    y1 = lin1(ref(x1) * mask)
+    y2 = train_ops.head_train(x2, list(new), p, lin2, seed)
+    assert y1.shape == y2.shape
+    assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+
+    def close(a, b, tol=2e-4):
+        s = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * s, (float((a - b).abs().max()), s)
+    s = max(1e-3, float(x1.grad.abs().max()))
+    bad = ((x2.grad - x1.grad).abs().amax(dim=1) > 2e-4 * s)
+    assert int(bad.sum()) <= E // 10000, (int(bad.sum()), E)
+    wtol = 2e-4 if E < 20000 else 5e-3
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), new.named_parameters()):
+        if n1.endswith("lin.bias"):
+            assert float(p2.grad.abs().max()) == 0.0
+        else:
+            close(p2.grad, p1.grad, wtol)
+    close(lin2.weight.grad, lin1.weight.grad, wtol)
+    close(lin2.bias.grad, lin1.bias.grad)
+    for (n1, b1), (n2, b2) in zip(ref.named_buffers(), new.named_buffers()):
+        if "num_batches" not in n1:
+            close(b2, b1, 1e-5)
+
+
+def test_head_in_model_matches_unfused_head_without_dropout():
+    """GGCNSeg with the fused head == the separate fc1 / dropout / fc2 ops when dropout is off."""
+    from grid_gcn_amd import model, synth
+    cfg = dict(model.SEG_8192, dropout=0.0)
+    torch.manual_seed(3)
+    net = model.GGCNSeg(cfg).to(DEV).train()
+    assert net.up[-1].tail_head is not None
+    data, npn = synth.make_batch(2, 8192, "planes")
+    x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    lab = torch.randint(0, 21, (2, 8192), device=DEV)
+    state = copy.deepcopy(net.state_dict())
+    out = []
+    for fused in (True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        object.__setattr__(net.up[-1], "tail_head", (0.0, net.fc2) if fused else None)
+        logits = net(x, n)
+        assert (net.up[-1].tail_done == 2) == fused
+        loss = model.seg_loss(logits, lab)
+        loss.backward()
+        out.append((logits.detach().clone(), float(loss),
+                    {k: v.grad.detach().clone() for k, v in net.named_parameters()}))
+    assert float((out[0][0] - out[1][0]).abs().max()) <= 2e-5 * max(1.0, float(out[1][0].abs().max()))
+    assert abs(out[0][1] - out[1][1]) <= 1e-5
+    for k, gref in out[1][2].items():
+        sc = max(1e-6, float(gref.abs().max()))
+        assert float((out[0][2][k] - gref).abs().max()) <= 2e-3 * sc + 1e-7, k
