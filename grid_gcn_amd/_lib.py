@@ -144,7 +144,7 @@ def load():
     lib.gridgcn_softmax_ce_fwd.restype = ci
     lib.gridgcn_softmax_ce_fwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp]
     lib.gridgcn_softmax_ce_bwd.restype = ci
-    lib.gridgcn_softmax_ce_bwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_softmax_ce_bwd.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_colsum.restype = ci
     lib.gridgcn_colsum.argtypes = [vp, ll, ci, ci, vp, vp]
     lib.gridgcn_edge_inputs.restype = ci

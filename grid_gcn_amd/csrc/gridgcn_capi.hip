@@ -32,7 +32,7 @@ int gg_edge_inputs_rows(const float *, const int *, const float *, int, int, int
 int gg_ce_fwd(const float *, int, int, const long long *, long long, int, float *, double *,
               hipStream_t);
 int gg_ce_bwd(const float *, int, int, const long long *, long long, int, const float *,
-              const double *, const float *, float *, hipStream_t);
+              const double *, const float *, const float *, float *, hipStream_t);
 int gg_colsum(const float *, long long, int, int, double *, hipStream_t);
 size_t gg_ball_grid_workspace(int B, int m);
 int gg_ball_knn_grid(const float *, const float *, const int *, const int *, int, int, int, int,
@@ -462,11 +462,12 @@ int gridgcn_softmax_ce_fwd(const float *logits, int ld, int ncls, const int64_t 
 
 int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t *label, long long E,
                            int ignore_label, const float *lse, const double *acc,
-                           const float *grad_loss, float *dlogits, void *stream)
+                           const float *grad_loss, const float *class_weight, float *dlogits,
+                           void *stream)
 {
     if (!logits || !label || !lse || !acc || !grad_loss || !dlogits) return GRIDGCN_EINVAL;
     int rc = gg_ce_bwd(logits, ld, ncls, (const long long *)label, E, ignore_label, lse, acc,
-                       grad_loss, dlogits, (hipStream_t)stream);
+                       grad_loss, class_weight, dlogits, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void gg_k_ce_bwd(const float *__restrict__ log
                                                    const float *__restrict__ lse,
                                                    const double *__restrict__ acc,
                                                    const float *__restrict__ gout,
+                                                   const float *__restrict__ cw,
                                                    float *__restrict__ dlogits)
 {
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -88,6 +89,16 @@ __global__ __launch_bounds__(256) void gg_k_ce_bwd(const float *__restrict__ log
         float g = 0.f;
         if (valid && c < ncls) g = (expf(v[c] - l) - ((c == (int)lab) ? 1.f : 0.f)) * coef;
         d[c] = g;
+    }
+    if (cw) {
+        // weighted_gradient (custom_op/weighted_gradient.py:22-26): the row's gradient times
+        // max_c [grad_c < 0] * weight_c -- only the label's entry of softmax - onehot is negative
+        float f = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4 * NV; c++)
+            if (c < ncls && d[c] < 0.f) f = fmaxf(f, cw[c]);
+#pragma unroll
+        for (int c = 0; c < 4 * NV; c++) d[c] *= f;
     }
 #pragma unroll
     for (int q = 0; q < NV; q++)
@@ -138,12 +149,13 @@ int gg_ce_fwd(const float *logits, int ld, int ncls, const long long *label, lon
 }
 
 int gg_ce_bwd(const float *logits, int ld, int ncls, const long long *label, long long E, int ignore,
-              const float *lse, const double *acc, const float *gout, float *dlogits, hipStream_t st)
+              const float *lse, const double *acc, const float *gout, const float *cw,
+              float *dlogits, hipStream_t st)
 {
     if (ld < 4 || ld > 32 || (ld & 3) || ncls < 1 || ncls > ld || E < 1) return 1;
     const int grid = (int)((E + 255) / 256);
     switch (ld / 4) {
-#define GG_CASE(n) case n: gg_k_ce_bwd<n><<<grid, 256, 0, st>>>(logits, ncls, label, E, ignore, lse, acc, gout, dlogits); break;
+#define GG_CASE(n) case n: gg_k_ce_bwd<n><<<grid, 256, 0, st>>>(logits, ncls, label, E, ignore, lse, acc, gout, cw, dlogits); break;
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }

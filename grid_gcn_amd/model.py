@@ -142,11 +142,44 @@ class GGCNSeg(nn.Module):
         return self.fc2(net)
 
 
-def seg_loss(logits, label):
+class WeightedGradient(torch.autograd.Function):
+    """custom_op/weighted_gradient.py:10-26 as stock PyTorch ops: identity forward; backward
+    multiplies every row of the gradient by max_c [grad_c < 0] * weight_c (class axis last)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(weight)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        f = ((g < 0).to(g.dtype) * w).amax(dim=-1, keepdim=True)
+        return f * g, None
+
+
+def seg_loss(logits, label, weights=None):
     """SoftmaxOutput(use_ignore=True, ignore_label=0, normalization='valid')
-    (segmentation/models/ggcn_models_g.py:41): mean cross-entropy over labels != 0."""
+    (segmentation/models/ggcn_models_g.py:41): mean cross-entropy over labels != 0.
+    weights: optional per-class gradient weights (the 'weighted_gradient' op of :39-40)."""
     lg, lb = logits.reshape(-1, logits.shape[-1]), label.reshape(-1).long()
     if lg.is_cuda and lg.dtype == torch.float32 and lg.shape[1] <= 32 and HEAD_KERNELS:
         from . import train_ops
-        return train_ops.softmax_ce(lg, lb, 0)       # csrc/gridgcn_head.hip
+        return train_ops.softmax_ce(lg, lb, 0, weights)       # csrc/gridgcn_head.hip
+    if weights is not None:
+        lg = WeightedGradient.apply(lg, torch.as_tensor(weights, dtype=lg.dtype, device=lg.device))
     return F.cross_entropy(lg, lb, ignore_index=0, reduction="mean")
+
+
+def bn_decay_at(step, bn_decay=0.9, factor=0.5, clip=0.99):
+    """BaseSolver.reset_bn_decay (segmentation/train_test/base_solver.py:71-74): the BatchNorm
+    momentum after `step` decays, min(1 - bn_decay * factor**step, clip)."""
+    return min(1.0 - bn_decay * (factor ** step), clip)
+
+
+def set_bn_decay(net, bn_decay):
+    """Give every BatchNorm of `net` the MXNet momentum `bn_decay` (running = bn_decay * running +
+    (1 - bn_decay) * batch); the kernels read the module's momentum at every call."""
+    for m in net.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.momentum = 1.0 - bn_decay

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import synth
 from .gridconv import ConvBNReLU, mlp
-from .model import HipIndexOps
+from .model import HipIndexOps, WeightedGradient
 
 CLS_MN40 = dict(
     grid=synth.CLS_MODELNET40, inputDim=[0, 128, 256],
@@ -107,6 +107,10 @@ class GGCNCls(nn.Module):
         return self.fc3(self.fc2(self.fc1(net)))
 
 
-def cls_loss(logits, label):
-    """SoftmaxOutput(normalization='batch') (ggcn_models_g.py:34)."""
+def cls_loss(logits, label, weights=None):
+    """SoftmaxOutput(normalization='batch') (ggcn_models_g.py:34), behind the optional
+    'weighted_gradient' op (:32-33) when per-class weights are given."""
+    if weights is not None:
+        logits = WeightedGradient.apply(logits, torch.as_tensor(weights, dtype=logits.dtype,
+                                                                device=logits.device))
     return F.cross_entropy(logits, label.long(), reduction="mean")

@@ -234,16 +234,24 @@ class _BatchTake(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        lib = _lib.load()
         (index,) = ctx.saved_tensors
-        B, N, C, M = ctx.dims
-        grad_out = grad_out.contiguous()
-        gdata = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
-        with torch.cuda.device(grad_out.device):
-            rc = lib.gridgcn_batch_take_backward(_ptr(grad_out), _ptr(index), B, N, C, M,
-                                                 _ptr(gdata), _stream(grad_out))
-        _lib.check(rc, "gridgcn_batch_take_backward")
-        return gdata, None
+        return batch_take_g_backward(grad_out, index, ctx.dims[1]), None
+
+
+@torch.no_grad()
+def batch_take_g_backward(grad_out, index, N):
+    """Scatter-add backward of batch_take_g: grad_out [B,...,C] f32, index [B,...] i32 -> gradient
+    w.r.t. data [B,N,C] (what MXNet's take backward does, utils/ops.py:87-92)."""
+    lib = _lib.load()
+    B, C = index.shape[0], grad_out.shape[-1]
+    M = index.numel() // B
+    grad_out = grad_out.contiguous()
+    gdata = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = lib.gridgcn_batch_take_backward(_ptr(grad_out), _ptr(index), B, N, C, M,
+                                             _ptr(gdata), _stream(grad_out))
+    _lib.check(rc, "gridgcn_batch_take_backward")
+    return gdata
 
 
 def batch_take_g(data, index, shape=None, scope=""):

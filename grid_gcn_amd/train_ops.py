@@ -1006,7 +1006,7 @@ def dropout_mask(E, C, p, seed, device):
 
 class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, label, ignore):
+    def forward(ctx, logits, label, ignore, cw=None):
         lib = _lib.load()
         E, C = logits.shape
         dev = logits.device
@@ -1026,6 +1026,7 @@ class _SoftmaxCE(torch.autograd.Function):
                        "gridgcn_softmax_ce_fwd")
         ctx.save_for_backward(logits, label, lse, acc)
         ctx.meta = (ld, ignore)
+        ctx.cw = cw
         return (acc[0] / acc[1]).float()
 
     @staticmethod
@@ -1039,9 +1040,11 @@ class _SoftmaxCE(torch.autograd.Function):
         g = g.contiguous().float()
         with torch.cuda.device(dev):
             _lib.check(lib.gridgcn_softmax_ce_bwd(_ptr(logits), ld, C, _ptr(label), E, ignore,
-                                                  _ptr(lse), _ptr(acc), _ptr(g), _ptr(d),
-                                                  _stream(logits)), "gridgcn_softmax_ce_bwd")
-        return d[:, :C], None, None
+                                                  _ptr(lse), _ptr(acc), _ptr(g),
+                                                  _ptr(ctx.cw) if ctx.cw is not None else None,
+                                                  _ptr(d), _stream(logits)),
+                       "gridgcn_softmax_ce_bwd")
+        return d[:, :C], None, None, None
 
 
 def _pad_is_zero(logits, ld):
@@ -1049,7 +1052,14 @@ def _pad_is_zero(logits, ld):
     return logits.untyped_storage().nbytes() == logits.shape[0] * ld * 4
 
 
-def softmax_ce(logits, label, ignore_index):
+def softmax_ce(logits, label, ignore_index, class_weight=None):
     """mean over label != ignore_index of -log softmax(logits)[label]; logits [E, C <= 32] f32 on
-    the GPU, label [E] int64 (torch.nn.functional.cross_entropy(..., ignore_index, 'mean'))."""
-    return _SoftmaxCE.apply(logits, label.long(), int(ignore_index))
+    the GPU, label [E] int64 (torch.nn.functional.cross_entropy(..., ignore_index, 'mean')).
+    class_weight [C] (optional): the 'weighted_gradient' op of the reference in front of the loss
+    (custom_op/weighted_gradient.py): the loss VALUE is unchanged, the gradient of a row is
+    multiplied by the weight of its label."""
+    cw = None
+    if class_weight is not None:
+        cw = torch.as_tensor(class_weight, dtype=torch.float32, device=logits.device).contiguous()
+        assert cw.numel() == logits.shape[1]
+    return _SoftmaxCE.apply(logits, label.long(), int(ignore_index), cw)

@@ -351,7 +351,11 @@ int gridgcn_softmax_ce_fwd(const float *logits, int ld, int ncls, const int64_t 
                            int ignore_label, float *lse, double *acc, void *stream);
 int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t *label, long long E,
                            int ignore_label, const float *lse, const double *acc,
-                           const float *grad_loss, float *dlogits, void *stream);
+                           const float *grad_loss, const float *class_weight, float *dlogits,
+                           void *stream);
+/* class_weight (optional, [ncls]): the reference's 'weighted_gradient' custom op between fc2 and
+ * the loss (custom_op/weighted_gradient.py:18-26, ggcn_models_g.py:40): every row of dlogits is
+ * multiplied by max_c [dlogits_c < 0] * class_weight_c, i.e. by the weight of the row's label. */
 int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream);
 
 /* ---- GridConv edge pipeline (inference-mode BatchNorm) ----------------------------------------

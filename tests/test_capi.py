@@ -78,3 +78,30 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_torch_ops_are_registered_with_fake_kernels():
+    """`import grid_gcn_amd` makes torch.ops.gridgcn.* appear (the analogue of the reference's
+    static registration on loading additional.so) and the ops trace on fake tensors (no GPU)."""
+    import torch
+    import grid_gcn_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ("gridify", "gridify_knn", "gridify_up", "ball_knn", "knn", "batch_take",
+                 "batch_take_backward"):
+        assert hasattr(torch.ops.gridgcn, name), name
+    schema = str(torch.ops.gridgcn.gridify.default._schema)
+    for arg in ("max_p_grid", "max_o_grid", "kernel_size", "stride", "loc", "coord_shift",
+                "voxel_size", "grid_size", "seed"):
+        assert arg in schema, (arg, schema)
+    with FakeTensorMode():
+        data = torch.empty((2, 100, 4), device="cuda")
+        num = torch.empty((2, 1), dtype=torch.int32, device="cuda")
+        out = torch.ops.gridgcn.gridify(data, num, max_p_grid=8, max_o_grid=16, kernel_size=3,
+                                        stride=1, loc=1, coord_shift=[1.0] * 3,
+                                        voxel_size=[0.1] * 3, grid_size=[20] * 3)
+        assert [tuple(t.shape) for t in out] == [(2, 16, 8), (2, 16, 8), (2, 16, 4), (2, 16), (2, 1)]
+        assert out[0].dtype == torch.int32 and out[4].dtype == torch.int32
+        idx = torch.ops.gridgcn.ball_knn(data[..., :3], data[..., :3], num, num, k=5, radius=0.2)
+        assert tuple(idx.shape) == (2, 100, 5) and idx.dtype == torch.int32
+        g = torch.ops.gridgcn.batch_take(data, out[0])
+        assert tuple(g.shape) == (2, 16, 8, 4)

@@ -185,3 +185,43 @@ def test_batch_take_matches_oracle_and_grad():
         ref = np.zeros((150, C), np.float64)
         np.add.at(ref, flat, g.reshape(-1, C).astype(np.float64))
         np.testing.assert_allclose(td.grad.cpu().numpy().reshape(150, C), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_torch_ops_namespace_runs_the_same_kernels():
+    """torch.ops.gridgcn.* (grid_gcn_amd/torch_ops.py) == grid_gcn_amd.ops, bit for bit, and
+    batch_take is differentiable through the dispatcher."""
+    import grid_gcn_amd  # noqa: F401  (registers the ops)
+    data, npn = synth.make_batch(2, 4096, "planes")
+    d = torch.from_numpy(data).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    kw = synth.gridify_kwargs(synth.SEG_SCANNET_8192, 0, seed=7)
+    a = ops.Gridify(d, n, **kw)
+    b = torch.ops.gridgcn.gridify(d, n, **kw)
+    c = torch.ops.gridgcn.gridify_knn(d, n, **kw)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    for x, y in zip(ops.GridifyKNN(d, n, **kw), c):
+        assert torch.equal(x, y)
+    cent, cnum = a[2], a[4]
+    i1 = ops.BallKNN(d[..., :3].contiguous(), cent[..., :3].contiguous(), cnum, n, k=5, radius=0.2)
+    i2 = torch.ops.gridgcn.ball_knn(d[..., :3].contiguous(), cent[..., :3].contiguous(), cnum, n,
+                                    k=5, radius=0.2)
+    assert torch.equal(i1, i2)
+    k1 = ops.KNN(d[..., :3].contiguous(), cent[..., :3].contiguous(), cnum, n, k=3)
+    k2 = torch.ops.gridgcn.knn(d[..., :3].contiguous(), cent[..., :3].contiguous(), cnum, n, k=3)
+    assert torch.equal(k1, k2)
+    ukw = synth.gridify_up_kwargs(synth.SEG_SCANNET_8192, 2, seed=7)
+    up = torch.zeros((2, ukw["max_o_grid"], 4), device=DEV)
+    up[:, :4096] = d
+    u1 = ops.GridifyUp(cent.contiguous(), up, cnum, n, **ukw)
+    u2 = torch.ops.gridgcn.gridify_up(cent.contiguous(), up, cnum, n, **ukw)
+    assert torch.equal(u1[0], u2[0]) and torch.equal(u1[1], u2[1])
+    f1 = torch.randn(2, 4096, 12, device=DEV).requires_grad_(True)
+    f2 = f1.detach().clone().requires_grad_(True)
+    g1 = ops.batch_take_g(f1, a[0])
+    g2 = torch.ops.gridgcn.batch_take(f2, a[0])
+    assert torch.equal(g1, g2)
+    w = torch.randn_like(g1)
+    (g1 * w).sum().backward()
+    (g2 * w).sum().backward()
+    assert torch.allclose(f1.grad, f2.grad, rtol=1e-5, atol=1e-5)

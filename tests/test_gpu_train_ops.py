@@ -337,3 +337,23 @@ def test_head_in_model_matches_unfused_head_without_dropout():
     for k, gref in out[1][2].items():
         sc = max(1e-6, float(gref.abs().max()))
         assert float((out[0][2][k] - gref).abs().max()) <= 2e-3 * sc + 1e-7, k
+
+
+def test_softmax_ce_class_weights_match_weighted_gradient_op():
+    """gridgcn_softmax_ce_bwd with class_weight == the reference's weighted_gradient op in front of
+    SoftmaxOutput (custom_op/weighted_gradient.py), here model.WeightedGradient + F.cross_entropy."""
+    import torch.nn.functional as F
+    from grid_gcn_amd import model
+    torch.manual_seed(5)
+    E, C = 3001, 21
+    lg1 = torch.randn(E, C, device=DEV).requires_grad_(True)
+    lg2 = lg1.detach().clone().requires_grad_(True)
+    lab = torch.randint(0, C, (E,), device=DEV)
+    w = (torch.rand(C, device=DEV) * 2 + 0.25)
+    l1 = F.cross_entropy(model.WeightedGradient.apply(lg1, w), lab, ignore_index=0)
+    l2 = model.seg_loss(lg2, lab, weights=w)
+    assert abs(float(l1) - float(l2)) <= 1e-5
+    l1.backward()
+    l2.backward()
+    assert float((lg1.grad - lg2.grad).abs().max()) <= 1e-6 * float(lg1.grad.abs().max()) + 1e-12
+    assert float(lg2.grad[lab == 0].abs().max()) == 0.0

@@ -108,3 +108,33 @@ def test_dp_gloo_world2_matches_full_batch():
     net(*args).square().sum().backward()
     g_full = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy() / 2
     np.testing.assert_allclose(g_dp, g_full, rtol=1e-4, atol=1e-6)
+
+
+def test_weighted_gradient_scales_rows_by_label_weight():
+    """custom_op/weighted_gradient.py: identity forward, gradient row * weight[label]."""
+    from grid_gcn_amd import model
+    torch.manual_seed(0)
+    lg1 = torch.randn(50, 21, requires_grad=True)
+    lg2 = lg1.detach().clone().requires_grad_(True)
+    lab = torch.randint(0, 21, (50,))
+    w = torch.rand(21) + 0.5
+    l1 = model.seg_loss(lg1, lab)
+    l2 = model.seg_loss(lg2, lab, weights=w.tolist())
+    assert float(l1) == float(l2)
+    l1.backward()
+    l2.backward()
+    exp = lg1.grad * w[lab][:, None]
+    assert torch.allclose(lg2.grad, exp, rtol=1e-6, atol=1e-9)
+    assert float(lg2.grad[lab == 0].abs().max()) == 0.0
+
+
+def test_bn_decay_schedule_and_setter():
+    from grid_gcn_amd import model
+    # base_solver.py:74 with the shipped configs.yaml values (bn_decay .9, factor .5, clip .99)
+    assert abs(model.bn_decay_at(1) - 0.55) < 1e-12
+    assert abs(model.bn_decay_at(2) - 0.775) < 1e-12
+    assert model.bn_decay_at(20) == 0.99
+    net = model.GGCNSeg(model.SEG_8192, index_ops=OracleIndexOps)
+    model.set_bn_decay(net, 0.775)
+    moms = {m.momentum for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)}
+    assert len(moms) == 1 and abs(moms.pop() - 0.225) < 1e-12

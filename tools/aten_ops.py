@@ -49,3 +49,16 @@ for (k, shp), (cnt, dt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print("%8.1f us/step n=%5.1f %-40s %s" % (dt / K, cnt / K, k[:40], shp))
     tot += dt
 print("listed total %.1f us/step" % (tot / K))
+# the small stock ops by name: each costs ~4 us of GPU time however little it does
+byop = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.key_averages():
+    dt = getattr(ev, "self_device_time_total", 0.0)
+    if dt > 0 and ev.key.startswith("aten::"):
+        byop[ev.key][0] += ev.count
+        byop[ev.key][1] += dt
+print("---- aten ops with device time")
+n = t = 0
+for k, (cnt, dt) in sorted(byop.items(), key=lambda kv: -kv[1][1]):
+    print("%8.1f us/step n=%5.1f %s" % (dt / K, cnt / K, k))
+    n += cnt; t += dt
+print("aten total: %.1f launches, %.1f us per step" % (n / K, t / K))
