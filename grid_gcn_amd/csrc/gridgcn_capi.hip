@@ -556,6 +556,18 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
+                          const float *scale, const float *mean, const float *rstd,
+                          const float *m1, const float *m2, int C0, float *dW, int ld,
+                          void *stream)
+{
+    if (!wgs || !gg || !T || !wgb || !scale || !mean || !rstd || !m1 || !m2 || !dW || C0 < 1 ||
+        ld < 3)
+        return GRIDGCN_EINVAL;
+    return gg_edge_lin0_dwg(wgs, gg, T, wgb, scale, mean, rstd, m1, m2, C0, dW, ld,
+                            (hipStream_t)stream);
+}
+
 int gridgcn_ball_knn_grid_workspace_bytes(int B, int m, size_t *bytes)
 {
     if (!bytes || B < 1 || m < 1) return GRIDGCN_EINVAL;

@@ -38,5 +38,8 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *am
                             const float *m1, const float *m2, int B, int N, int O, int P, int C,
                             float *dYsrc, float *Gsum, double *wgs, double *gg, void *workspace,
                             hipStream_t st);
+int gg_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
+                     const float *scale, const float *mean, const float *rstd, const float *m1,
+                     const float *m2, int C, float *dW, int ld, hipStream_t st);
 int gg_edge_lin0_fwd(const GGEdgeLin0 &p, hipStream_t st);
 int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st);   // workspace: gg_csr_workspace

@@ -568,3 +568,40 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *am
         p.fpart, p.fgs);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the geo_vec columns of the source-side first conv, from the pieces the sparse
+// backward leaves behind (one launch instead of ~20 element-wise ops on [3][C] tensors):
+//   dWg[j][c] = wgs[j][c]                                         arg-max entries
+//             + bz_c (T[j][c] + Gtot_j b_c + sum_k GG[j][k] Wg[k][c])      dense part, z0 affine
+//             + (cz_c - mean_c bz_c) Gtot_j
+// T = Gsum^T Ysrc ([>=3][C], rows 0..2 used), gg = (GG[9], Gtot[3]), wgb = (Wg[3][C], b[C]).
+// Written transposed into dW[c][j] with row stride ld (columns 0..2 of the layer's dW).
+__global__ __launch_bounds__(256) void gg_k_edge_lin0_dwg(
+    const double *__restrict__ wgs, const double *__restrict__ gg, const float *__restrict__ T,
+    const float *__restrict__ wgb, const float *__restrict__ scale, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ m1, const float *__restrict__ m2, int C,
+    float *__restrict__ dW, int ld)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = scale[c];
+    const float bz = -(sc * rstd[c]) * m2[c], cz = -(sc * m1[c]);
+    const float w0 = wgb[c], w1 = wgb[C + c], w2 = wgb[2 * C + c], b = wgb[3 * C + c];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float gt = (float)gg[9 + j];
+        const float t1 = (T[j * C + c] + gt * b) +
+                         (((float)gg[3 * j] * w0 + (float)gg[3 * j + 1] * w1) + (float)gg[3 * j + 2] * w2);
+        dW[(size_t)c * ld + j] = (float)wgs[j * C + c] + bz * t1 + (cz - mean[c] * bz) * gt;
+    }
+}
+
+int gg_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
+                     const float *scale, const float *mean, const float *rstd, const float *m1,
+                     const float *m2, int C, float *dW, int ld, hipStream_t st)
+{
+    gg_k_edge_lin0_dwg<<<(C + 255) / 256, 256, 0, st>>>(wgs, gg, T, wgb, scale, mean, rstd, m1, m2, C,
+                                                       dW, ld);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -253,15 +253,17 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     return dY, grads
 
 
-def _tn_matmul(a, b):
+def _tn_matmul(a, b, out=None):
     """a^T b for tall operands a [R,m], b [R,n] with small m, n: the contraction is cut into
     128-row slabs (one batched GEMM + a sum) so that the work spreads over the chip -- a plain
-    [m,R]x[R,n] GEMM runs on m*n/tile workgroups only."""
+    [m,R]x[R,n] GEMM runs on m*n/tile workgroups only.  out: optional (strided) destination."""
     R = a.shape[0]
     if R >= 1024 and R % 128 == 0:
         S = R // 128
-        return torch.bmm(a.view(S, 128, a.shape[1]).transpose(1, 2),
-                         b.view(S, 128, b.shape[1])).sum(0)
+        prod = torch.bmm(a.view(S, 128, a.shape[1]).transpose(1, 2), b.view(S, 128, b.shape[1]))
+        return torch.sum(prod, dim=0, out=out) if out is not None else prod.sum(0)
+    if out is not None:
+        return out.copy_(torch.matmul(a.t(), b))
     return torch.matmul(a.t(), b)
 
 
@@ -625,11 +627,13 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 _lib.check(rc, "gridgcn_edge_lin0_backward_sparse")
                 dWg = None
                 if rot:
-                    bz = -(vec0[0] * vec0[3]) * v[1]                      # [C0]
-                    cz = -(vec0[0] * v[0])
-                    GG, Gtot = gg[:9].view(3, 3).float(), gg[9:].float()
-                    t1 = _tn_matmul(Gsum, Ysrc + wgb[3])[:3] + torch.matmul(GG, wgb[:3])
-                    dWg = wgs.float() + bz * t1 + (cz - vec0[2] * bz) * Gtot[:, None]
+                    # geo_vec columns of dW0, written in place by one kernel
+                    dW0 = torch.empty((C0, rot + Cf), dtype=torch.float32, device=dev)
+                    rc = lib.gridgcn_edge_lin0_dwg(
+                        _ptr(wgs), _ptr(gg), _ptr(_tn_matmul(Gsum, Ysrc)), _ptr(wgb),
+                        _ptr(vec0[0]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), C0,
+                        _ptr(dW0), rot + Cf, st)
+                    _lib.check(rc, "gridgcn_edge_lin0_dwg")
             else:
                 zb = torch.zeros(R * C0 * 4 + 3 * C0 * 8, dtype=torch.uint8, device=dev)
                 dYsrc = zb[:R * C0 * 4].view(torch.float32).view(R, C0)
@@ -647,8 +651,11 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 _lib.check(rc, "gridgcn_edge_lin0_backward")
             # the two small GEMMs on the source points
             feat = src.detach()[..., 4:].reshape(R, Cf)
-            dWf = _tn_matmul(dYsrc, feat)                             # [C0, Cf]
-            dW0 = torch.cat([dWg.t().float(), dWf], dim=1) if rot else dWf
+            if rot and dWg is None:
+                _tn_matmul(dYsrc, feat, out=dW0[:, rot:])             # [C0, Cf] beside dWg
+            else:
+                dWf = _tn_matmul(dYsrc, feat)
+                dW0 = torch.cat([dWg.t().float(), dWf], dim=1) if rot else dWf
             gsrc = None
             if ctx.needs_input_grad[0]:
                 gsrc = torch.zeros((B, Nsrc, Cs), dtype=torch.float32, device=dev)

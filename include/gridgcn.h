@@ -211,6 +211,13 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
                                       int Nsrc, int O, int P, int C0, float *dYsrc, float *Gsum,
                                       double *wgs, double *gg, void *workspace,
                                       size_t workspace_bytes, void *stream);
+/* gridgcn_edge_lin0_dwg: that last formula in one launch.  T[>=3][C0] = Gsum^T Ysrc (rows 0..2),
+ * wgb[4][C0] = (Wg rows, b).  dWg is written transposed into dW[c*ld + j], j = 0..2: the geo_vec
+ * columns of the layer's weight gradient [C0][3 + Cf] (ld = 3 + Cf). */
+int gridgcn_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
+                          const float *scale, const float *mean, const float *rstd,
+                          const float *m1, const float *m2, int C0, float *dW, int ld,
+                          void *stream);
 
 /* ---- training-mode 1x1 conv + BatchNorm + ReLU (utils/ops.py:149-158 conv2d, :141-147 conv1d) ---
  * gridgcn_linear_fwd: Z[E,cout] = act(X[E,cin]) * W + b on fp32 MFMA; act = identity (scale ==
