@@ -358,6 +358,16 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         for (int t = 0; t < NT; t++) {
             if (t * 32 + (lane & 31) < p.ndx) {
                 float s1 = 0.f, s2 = 0.f;
+                // all 16 loads of the previous layer's raw output first: dX and Aprev may alias as
+                // far as the compiler knows, so loads placed between the stores were serialised
+                float zpv[16];
+                if (prevbn) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int rr = (r & 3) + 8 * (r >> 2);
+                        zpv[r] = (nrows == 32 || rr + 4 * h < nrows) ? ap[rr * ldx + t * 32] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int rr = (r & 3) + 8 * (r >> 2);
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                                               p.drop_thr) ? dx * p.drop_scale : 0.f;
                         xp[off] = dx;
                         if (prevbn) {
-                            const float zp = ap[off];
+                            const float zp = zpv[r];
                             const float d = (zp * ps[t] + psh[t] > 0.f) ? dx : 0.f;
                             s1 += d;
                             s2 += d * ((zp - pm[t]) * pr[t]);

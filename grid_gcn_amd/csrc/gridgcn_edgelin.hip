@@ -575,7 +575,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *am
 //   dWg[j][c] = wgs[j][c]                                         arg-max entries
 //             + bz_c (T[j][c] + Gtot_j b_c + sum_k GG[j][k] Wg[k][c])      dense part, z0 affine
 //             + (cz_c - mean_c bz_c) Gtot_j
-// T = Gsum^T Ysrc ([>=3][C], rows 0..2 used), gg = (GG[9], Gtot[3]), wgb = (Wg[3][C], b[C]).
+// T = Ysrc^T Gsum ([C][4], columns 0..2 used), gg = (GG[9], Gtot[3]), wgb = (Wg[3][C], b[C]).
 // Written transposed into dW[c][j] with row stride ld (columns 0..2 of the layer's dW).
 __global__ __launch_bounds__(256) void gg_k_edge_lin0_dwg(
     const double *__restrict__ wgs, const double *__restrict__ gg, const float *__restrict__ T,
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_dwg(
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const float gt = (float)gg[9 + j];
-        const float t1 = (T[j * C + c] + gt * b) +
+        const float t1 = (T[c * 4 + j] + gt * b) +
                          (((float)gg[3 * j] * w0 + (float)gg[3 * j + 1] * w1) + (float)gg[3 * j + 2] * w2);
         dW[(size_t)c * ld + j] = (float)wgs[j * C + c] + bz * t1 + (cz - mean[c] * bz) * gt;
     }

@@ -267,6 +267,17 @@ def _tn_matmul(a, b, out=None):
     return torch.matmul(a.t(), b)
 
 
+_ZEROS = {}
+
+
+def _cached_zeros(n, dev):
+    """a read-only zero vector"""
+    key = (n, str(dev))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return _ZEROS[key]
+
+
 def alias_columns(buf, col0, ncol):
     """A fresh tensor (no autograd / view relation) over columns [col0, col0+ncol) of the contiguous
     2-D buffer `buf`: lets two producers write the halves of a concatenation in place."""
@@ -496,13 +507,11 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(src)
             feat = src.detach()[..., 4:].reshape(R, Cf)
-            Wf = W0.detach()[:, rot:]
-            Ysrc = torch.matmul(feat, Wf.t()).contiguous()          # [R, C0]: once per source point
+            # [R, C0]: once per source point
+            Ysrc = torch.matmul(feat, W0.detach()[:, rot:].t()).contiguous()
             # rows 0..2: geo_vec weights [3][C0] (zeros without geo_vec), row 3: bias
-            wgb = torch.zeros((4, C0), dtype=torch.float32, device=dev)
-            if geo:
-                wgb[:3] = W0.detach()[:, :3].t()
-            wgb[3] = b0.detach()
+            wgb = torch.cat([W0.detach()[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0),
+                             b0.detach()[None]])
             Wg = wgb if geo else None
             # a single-layer point MLP never materialises Z0: its consumers recompute it
             noz = Lp == 1 and NO_Z0 and C0 % 4 == 0
@@ -630,7 +639,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                     # geo_vec columns of dW0, written in place by one kernel
                     dW0 = torch.empty((C0, rot + Cf), dtype=torch.float32, device=dev)
                     rc = lib.gridgcn_edge_lin0_dwg(
-                        _ptr(wgs), _ptr(gg), _ptr(_tn_matmul(Gsum, Ysrc)), _ptr(wgb),
+                        _ptr(wgs), _ptr(gg), _ptr(_tn_matmul(Ysrc, Gsum)), _ptr(wgb),
                         _ptr(vec0[0]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), C0,
                         _ptr(dW0), rot + Cf, st)
                     _lib.check(rc, "gridgcn_edge_lin0_dwg")
@@ -658,8 +667,10 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 dW0 = torch.cat([dWg.t().float(), dWf], dim=1) if rot else dWf
             gsrc = None
             if ctx.needs_input_grad[0]:
-                gsrc = torch.zeros((B, Nsrc, Cs), dtype=torch.float32, device=dev)
-                gsrc[..., 4:] = torch.matmul(dYsrc, W0.detach()[:, rot:]).view(B, Nsrc, Cf)
+                # gradient of the source rows [xyz w | features]: the four leading columns are zero
+                # rows of the (transposed) weight, so the product IS the full row
+                Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0), W0.detach()[:, rot:].t()])
+                gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
             db0 = torch.zeros(C0, dtype=torch.float32, device=dev)
         grads0 = [dW0, db0, v[2], v[3]]
         return (gsrc, None, None, None) + tuple(grads0) + tuple(grads_rest) + tuple(grads_a)

@@ -211,7 +211,7 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
                                       int Nsrc, int O, int P, int C0, float *dYsrc, float *Gsum,
                                       double *wgs, double *gg, void *workspace,
                                       size_t workspace_bytes, void *stream);
-/* gridgcn_edge_lin0_dwg: that last formula in one launch.  T[>=3][C0] = Gsum^T Ysrc (rows 0..2),
+/* gridgcn_edge_lin0_dwg: that last formula in one launch.  T[C0][4] = Ysrc^T Gsum (columns 0..2),
  * wgb[4][C0] = (Wg rows, b).  dWg is written transposed into dW[c*ld + j], j = 0..2: the geo_vec
  * columns of the layer's weight gradient [C0][3 + Cf] (ld = 3 + Cf). */
 int gridgcn_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
