@@ -133,8 +133,9 @@ def main():
                    "parallelism": "dp%d" % world,
                    "kernels": "hand-written HIP for Gridify/BallKNN, edge inputs (gather+geo) and their "
                               "sorted backward, all conv+BatchNorm+ReLU stacks fwd+bwd (fp32 MFMA), "
-                              "att product + max, class scores + softmax cross-entropy; "
-                              "PyTorch-ROCm for concat/mask/dropout on [B,O,C] and fused Adam"},
+                              "att product + max, fc1 + dropout + class scores (one op) + softmax "
+                              "cross-entropy; PyTorch-ROCm for the small GEMMs on source points, "
+                              "concat/mask on [B,O,C] and fused Adam"},
     }
 
     if rank == 0 and world == 1:
