@@ -115,7 +115,7 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
     if prev_bn is not None:
         pscale, pshift = prev_bn
     couts = [params[4 * l].shape[0] for l in range(L)]
-    allsums = torch.zeros(2 * sum(couts), dtype=torch.float64, device=dev)
+    allsums = _zeros(2 * sum(couts), torch.float64, dev)
     so = 0
     stream = _stream(x)
     for l in range(L):
@@ -193,7 +193,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     cins = [x.shape[1]] + Cs[:-1]
     # one zero fill for the chain: BatchNorm-backward sums of layers 0..L-2 (fp64) + bias gradients
     nps = 2 * sum(Cs[:-1]) + (2 * x.shape[1] if prev_bn is not None else 0)
-    zbuf = torch.zeros(nps * 8 + 4 * sum(Cs), dtype=torch.uint8, device=dev)
+    zbuf = _zeros(nps * 8 + 4 * sum(Cs), torch.uint8, dev)
     zps = zbuf[:nps * 8].view(torch.float64)
     zdb = zbuf[nps * 8:].view(torch.float32)
     po, bo = 0, 0
@@ -267,6 +267,45 @@ def _tn_matmul(a, b, out=None):
     return torch.matmul(a.t(), b)
 
 
+class _ZeroArena:
+    """Small zero-filled accumulators (BatchNorm sums, bias gradients) carved from 4 MB zero chunks:
+    one fill per chunk instead of one ~3 us launch per buffer (about 70 per training step).  Slices
+    are handed out once and never reused; a chunk is freed when its last slice dies.  Each slice is a
+    fresh tensor over the chunk's storage (no view relation, own autograd version counter)."""
+    CHUNK = 1 << 22
+    LIMIT = 1 << 16
+
+    def __init__(self):
+        self.chunk, self.off = {}, {}
+
+    def zeros(self, shape, dtype, dev):
+        if isinstance(shape, int):
+            shape = (shape,)
+        n = 1
+        for d in shape:
+            n *= d
+        item = torch.empty(0, dtype=dtype).element_size()
+        nbytes = n * item
+        if nbytes > self.LIMIT or not ZERO_ARENA:
+            return torch.zeros(shape, dtype=dtype, device=dev)
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        need = (nbytes + 255) & ~255
+        if key not in self.chunk or self.off[key] + need > self.CHUNK:
+            self.chunk[key] = torch.zeros(self.CHUNK, dtype=torch.uint8, device=dev)
+            self.off[key] = 0
+        o = self.off[key]
+        self.off[key] = o + need
+        strides, acc = [], 1
+        for d in reversed(shape):
+            strides.append(acc)
+            acc *= d
+        return torch.empty(0, dtype=dtype, device=dev).set_(
+            self.chunk[key].untyped_storage(), o // item, tuple(shape), tuple(reversed(strides)))
+
+
+ZERO_ARENA = os.environ.get("GG_NO_ZERO_ARENA", "0") != "1"
+_ARENA = _ZeroArena()
+_zeros = _ARENA.zeros
 _ZEROS = {}
 
 
@@ -358,7 +397,7 @@ class _MLPTrain(torch.autograd.Function):
                 and (not need_dx_last or ctx.ndx[-1] > 0)):
             dY = dY.contiguous()
         with torch.cuda.device(dev):
-            sums = torch.zeros((2, C), dtype=torch.float64, device=dev)
+            sums = _zeros((2, C), torch.float64, dev)
             rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Zs[-1]), _ptr(scales[-1]),
                                                 _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
                                                 E, C, dY.stride(0), _ptr(sums), _stream(x))
@@ -470,7 +509,7 @@ class _EdgeBlockTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             gp = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             ga = torch.empty((ncent, C), dtype=torch.float32, device=dev)
-            sums_pa = torch.zeros((2, 2 * C), dtype=torch.float64, device=dev)
+            sums_pa = _zeros((2, 2 * C), torch.float64, dev)
             sums_p, sums_a = sums_pa[0], sums_pa[1]
             rc = lib.gridgcn_pairmax_bwd(_ptr(pZ[-1]), _ptr(aZ[-1]), _ptr(pS[-1]), _ptr(pH[-1]),
                                          _ptr(pM[-1]), _ptr(pR[-1]), _ptr(aS[-1]), _ptr(aH[-1]),
@@ -517,7 +556,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             noz = Lp == 1 and NO_Z0 and C0 % 4 == 0
             Z0 = None if noz else torch.empty((E, C0), dtype=torch.float32, device=dev)
             att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
-            sums0 = torch.zeros(2 * C0, dtype=torch.float64, device=dev)
+            sums0 = _zeros(2 * C0, torch.float64, dev)
             rc = lib.gridgcn_edge_lin0_forward(
                 _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P,
                 C0, _ptr(Wg) if geo else None, _ptr(wgb[3]), None if noz else _ptr(Z0),
@@ -593,7 +632,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             st = _stream(src)
             gp = torch.empty((ncent, C), dtype=torch.float32, device=dev)
             ga = torch.empty((ncent, C), dtype=torch.float32, device=dev)
-            sums_pa = torch.zeros((2, 2 * C), dtype=torch.float64, device=dev)
+            sums_pa = _zeros((2, 2 * C), torch.float64, dev)
             sums_p, sums_a = sums_pa[0], sums_pa[1]
             # (the arg-max pre-activations come from zsel: Zl may not exist)
             rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None, _ptr(aZ[-1]),
@@ -622,7 +661,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 # BatchNorm terms collapse onto per-source counts and geo_vec sums
                 dYsrc = torch.empty((R, C0), dtype=torch.float32, device=dev)
                 Gsum = torch.empty((R, 4), dtype=torch.float32, device=dev)
-                acc64 = torch.zeros(3 * C0 + 12, dtype=torch.float64, device=dev)
+                acc64 = _zeros(3 * C0 + 12, torch.float64, dev)
                 wgs, gg = acc64[:3 * C0].view(3, C0), acc64[3 * C0:]
                 nbytes = ctypes.c_size_t(0)
                 lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes(B, Nsrc, C0,
@@ -671,7 +710,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 # rows of the (transposed) weight, so the product IS the full row
                 Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0), W0.detach()[:, rot:].t()])
                 gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
-            db0 = torch.zeros(C0, dtype=torch.float32, device=dev)
+            db0 = _zeros(C0, torch.float32, dev)
         grads0 = [dW0, db0, v[2], v[3]]
         return (gsrc, None, None, None) + tuple(grads0) + tuple(grads_rest) + tuple(grads_a)
 
@@ -884,7 +923,7 @@ class _LinearPlain(torch.autograd.Function):
                 _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0, 0,
                 _ptr(dX) if ndx else None, _ptr(dW), None, None, None, 0, _ptr(ws), nbytes.value, st)
             _lib.check(rc, "gridgcn_linear_bwd")
-            db64 = torch.zeros(Cp, dtype=torch.float64, device=dev)
+            db64 = _zeros(Cp, torch.float64, dev)
             _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C, _ptr(db64), st), "gridgcn_colsum")
         return dX, dW[:C], db64[:C].float()
 
@@ -965,7 +1004,7 @@ class _HeadTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(x)
             dH = torch.empty((E, C), dtype=torch.float32, device=dev)
-            acc = torch.zeros(2 * C + Cp, dtype=torch.float64, device=dev)
+            acc = _zeros(2 * C + Cp, torch.float64, dev)
             sums, db64 = acc[:2 * C], acc[2 * C:]
             # gradient w.r.t. relu(bn(Z_fc1)) (dropout mask applied) + fc1's BatchNorm-backward sums
             _lib.check(lib.gridgcn_linear_dx(
@@ -1037,7 +1076,7 @@ class _SoftmaxCE(torch.autograd.Function):
             logits = buf[:, :C]
         label = label.contiguous()
         lse = torch.empty(E, dtype=torch.float32, device=dev)
-        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        acc = _zeros(2, torch.float64, dev)
         with torch.cuda.device(dev):
             _lib.check(lib.gridgcn_softmax_ce_fwd(_ptr(logits), ld, C, _ptr(label), E, ignore,
                                                   _ptr(lse), _ptr(acc), _stream(logits)),
