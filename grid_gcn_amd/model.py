@@ -36,6 +36,17 @@ class HipIndexOps:
     batch_take_g = staticmethod(ops.batch_take_g)
 
 
+class HipIndexOpsKNN(HipIndexOps):
+    """Same, with the centres' neighbours chosen as the exact top-P by distance to the voxel centre
+    (mx.sym.GridifyKNN, gridifyknn.cu; built by the reference's Makefile but used by none of its
+    shipped configs)."""
+    Gridify = staticmethod(ops.GridifyKNN)
+
+
+def _is_hip(ix):
+    return isinstance(ix, type) and issubclass(ix, HipIndexOps)
+
+
 class GGCNSeg(nn.Module):
     def __init__(self, cfg=SEG_8192, index_ops=HipIndexOps, seed=0):
         super().__init__()
@@ -67,16 +78,15 @@ class GGCNSeg(nn.Module):
         self.fc2 = nn.Linear(128, cfg["num_classes"])
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
-        if HEAD_KERNELS and FUSED_HEAD and index_ops is HipIndexOps:
-            # ... and so do fc1/dropout + fc2 (:36-38): train_ops._HeadTrain
-            object.__setattr__(self.up[-1], "tail_head", (cfg["dropout"], self.fc2))
+        # ... and so do fc1/dropout + fc2 (:36-38): train_ops._HeadTrain
+        self.fused_head = HEAD_KERNELS and FUSED_HEAD and _is_hip(index_ops)
 
     fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
     jobs = None    # set to a list to record (name, layer, cent, src, nebidx) of every fused call
     edge_kernel = True  # training: edge inputs from one HIP kernel instead of take+slice+cat ops
 
     def use_fused(self):
-        return self.fused and (not self.training) and self.ix is HipIndexOps
+        return self.fused and (not self.training) and _is_hip(self.ix)
 
     def forward(self, data_xyz, actual_centnum):
         """data_xyz [B,N,3] f32, actual_centnum [B,1] i32 -> logits [B,N,num_classes]."""
@@ -96,7 +106,7 @@ class GGCNSeg(nn.Module):
                 if self.jobs is not None:
                     self.jobs.append(("down%d" % i, layer, cent, data_layer, nebidx))
                 cf = layer.forward_fused(cent, data_layer, nebidx, centmsk)
-            elif self.ix is HipIndexOps and self.edge_kernel:
+            elif _is_hip(self.ix) and self.edge_kernel:
                 cf = layer.forward_src(cent, data_layer, nebidx, centmsk)
             else:
                 neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)        # :172-173
@@ -105,6 +115,8 @@ class GGCNSeg(nn.Module):
             locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
         f_last = feats[-1]
         nup = len(self.up)
+        object.__setattr__(self.up[-1], "tail_head",
+                           (cfg["dropout"], self.fc2) if self.fused_head else None)
         for i, layer in enumerate(self.up):
             down, upl = locs[-i - 1], locs[-i - 2]
             downnum, upnum = nums[-i - 1], nums[-i - 2]
@@ -124,7 +136,7 @@ class GGCNSeg(nn.Module):
                 if self.jobs is not None:
                     self.jobs.append(("up%d" % i, layer, upl, f_last, nebidx))
                 cf = layer.forward_fused(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
-            elif self.ix is HipIndexOps and self.edge_kernel:
+            elif _is_hip(self.ix) and self.edge_kernel:
                 cf = layer.forward_src(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
             else:
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
@@ -135,7 +147,7 @@ class GGCNSeg(nn.Module):
             return cf
         net = cf if self.up[-1].tail_done else run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
-        if HEAD_KERNELS and self.training and torch.is_grad_enabled() and self.ix is HipIndexOps:
+        if HEAD_KERNELS and self.training and torch.is_grad_enabled() and _is_hip(self.ix):
             from . import train_ops
             if train_ops.linear_plain_supported(net, self.fc2):
                 return train_ops.linear_plain_train(net, self.fc2)

@@ -36,3 +36,11 @@ class OracleIndexOps:
             B, *([1] * (index.dim() - 1)))
         flat = flat.clamp(0, B * N - 1)
         return data.reshape(B * N, C)[flat]
+
+
+class OracleIndexOpsKNN(OracleIndexOps):
+    """centre neighbours from the S0 restatement of GridifyKNN (gridifyknn.cu:115-204, 231-332)"""
+    @staticmethod
+    def Gridify(data, actual_numpoints, **kw):
+        return tuple(_t(x) for x in orc.gridify_knn(data.detach().cpu().numpy(),
+                                                    actual_numpoints.cpu().numpy(), **kw))

@@ -315,7 +315,7 @@ def test_head_in_model_matches_unfused_head_without_dropout():
     cfg = dict(model.SEG_8192, dropout=0.0)
     torch.manual_seed(3)
     net = model.GGCNSeg(cfg).to(DEV).train()
-    assert net.up[-1].tail_head is not None
+    assert net.fused_head
     data, npn = synth.make_batch(2, 8192, "planes")
     x = torch.from_numpy(data[..., :3].copy()).to(DEV)
     n = torch.from_numpy(npn).to(DEV)
@@ -325,7 +325,7 @@ def test_head_in_model_matches_unfused_head_without_dropout():
     for fused in (True, False):
         net.load_state_dict(state)
         net.zero_grad(set_to_none=True)
-        object.__setattr__(net.up[-1], "tail_head", (0.0, net.fc2) if fused else None)
+        net.fused_head = fused
         logits = net(x, n)
         assert (net.up[-1].tail_done == 2) == fused
         loss = model.seg_loss(logits, lab)
