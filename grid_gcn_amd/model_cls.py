@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import synth
-from .gridconv import ConvBNReLU, mlp
+from .gridconv import ConvBNReLU, mlp, run_mlp
 from .model import HipIndexOps, WeightedGradient
 
 CLS_MN40 = dict(
@@ -42,6 +42,8 @@ class SubGUpdateCls(nn.Module):
         self.att2 = mlp(att_ele[0] + C + cin, att_ele[1:], bn_decay)   # :93-101
         self.out_channels = C
 
+    mfma_train = True
+
     def forward(self, centers_xyz, neighbors, center_masks=None):
         nbr_xyz = neighbors[..., 0:3]
         geo_vec = nbr_xyz - centers_xyz[:, :, None, :]
@@ -54,8 +56,11 @@ class SubGUpdateCls(nn.Module):
         else:
             nf0 = neighbors[..., 4:]
         ctx = nf0.max(dim=2, keepdim=True).values.expand_as(nf0)               # contextvec_func
-        nf = self.pt_mlp(nf0)
-        att = self.att2(torch.cat([self.att1(att_vec), nf, ctx], dim=-1))
+        # training on the GPU: every conv+BN+ReLU stack the MFMA kernels take (<= 256 output and
+        # <= 384 input channels) runs through them, the wider ones through the stock modules
+        nf = run_mlp(list(self.pt_mlp), nf0, self.mfma_train)
+        a1 = run_mlp(list(self.att1), att_vec, self.mfma_train)
+        att = run_mlp(list(self.att2), torch.cat([a1, nf, ctx], dim=-1), self.mfma_train)
         agg = (att * nf).max(dim=2).values
         if self.relu:
             agg = F.relu(agg)

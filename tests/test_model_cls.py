@@ -43,3 +43,34 @@ def test_cls_model_hip_index_ops_match_oracle_path():
         got = net_gpu(x.to("cuda:0"), n.to("cuda:0")).cpu()
     # identical neighbour sets (bit-exact index ops) -> only fp32 GEMM order differs
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_cls_training_step_mfma_kernels_match_stock_modules():
+    """classification net, one fwd+bwd on the GPU: conv+BN+ReLU stacks through the hand-written
+    training kernels (where their width limits allow) vs the stock PyTorch modules."""
+    torch.manual_seed(0)
+    cfg = dict(model_cls.CLS_MN40, dropout=0.0)
+    net = model_cls.GGCNCls(cfg).to("cuda:0").train()
+    x, n = _inputs(8, 1024)
+    x, n = x.to("cuda:0"), n.to("cuda:0")
+    lab = torch.randint(0, 40, (8,), device="cuda:0")
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = []
+    for mfma in (True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        for l in net.layers:
+            l.mfma_train = mfma
+        loss = model_cls.cls_loss(net(x, n), lab)
+        loss.backward()
+        res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
+    assert abs(res[0][0] - res[1][0]) < 1e-4 * max(1.0, abs(res[1][0]))
+    # this net is discretely sensitive at fp32 round-off (max-pool arg-max over 128 padded
+    # neighbours, BatchNorm over 8 rows in the head): perturbing the INPUT of the stock path by 1e-7
+    # already moves single weight gradients by ~1e-2 of their scale (tools/dbg_cls.py), so the
+    # two paths are compared as vectors
+    a, b = res[0][1].double(), res[1][1].double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.9995, cos
+    assert float((a - b).norm() / b.norm()) < 3e-2
