@@ -246,3 +246,32 @@ def test_seg_model_with_gridify_knn_matches_cpu_oracle_model():
     loss_gpu.backward()
     assert net_gpu.up[-1].tail_done == 2                      # the HIP training path ran
     assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu)))
+
+
+@pytest.mark.parametrize("cfgname,npts", [("SEG_8192", (2048, 1311)), ("SEG_81920", (3000, 4096))])
+def test_seg_model_ragged_batch_matches_cpu_oracle_model(cfgname, npts):
+    """clouds of different size in one batch (actual_numpoints < N for one of them): training loss and
+    gradients of the HIP path == the CPU model with the oracle's index ops + stock PyTorch ops."""
+    import copy
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(2)
+    cfg = dict(getattr(model, cfgname), dropout=0.0)
+    net_cpu = model.GGCNSeg(cfg, index_ops=OracleIndexOps).train()
+    net_gpu = model.GGCNSeg(cfg)
+    net_gpu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    net_gpu = net_gpu.to(DEV).train()
+    N = max(npts)
+    data, npn = synth.make_batch(2, N, "planes")
+    npn[:, 0] = npts
+    x = torch.from_numpy(data[..., :3].copy())
+    n = torch.from_numpy(npn)
+    lab = torch.randint(0, 21, (2, N))
+    loss_cpu = model.seg_loss(net_cpu(x, n), lab)
+    loss_gpu = model.seg_loss(net_gpu(x.to(DEV), n.to(DEV)), lab.to(DEV))
+    assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu)))
+    loss_cpu.backward()
+    loss_gpu.backward()
+    a = torch.cat([p.grad.reshape(-1) for p in net_gpu.parameters()]).cpu().double()
+    b = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.999, cos
