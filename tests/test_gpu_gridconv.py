@@ -275,3 +275,4 @@ def test_seg_model_ragged_batch_matches_cpu_oracle_model(cfgname, npts):
     b = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.999, cos
+
