@@ -1,0 +1,270 @@
+// gridgcn_attbwd.hip -- backward of a (32 -> C) conv + BatchNorm + ReLU layer in ONE pass over the
+// edges: dX, the BatchNorm-backward sums of the layer in front AND dW (gfx950, fp32 MFMA).
+//
+// This is the second attention conv of GridConv (update_att_mlp2d_scnd, gcn_module_g_att.py:152:
+// C/4 -> C channels, C = 128 in every up layer): its [E, C] pre-activation Z is the widest tensor of
+// the step and the separate dX / dW kernels (gridgcn_direct.hip) each read it once.  Here a wave
+//   1. forms dZ for a 32-row tile in the dX layout (lane = row, 16 consecutive channels; BatchNorm /
+//      ReLU backward of the dense or sparse upstream gradient, as gg_k_linear_dx_direct),
+//   2. feeds it to the dX MFMAs (contraction over channels) and parks it in a per-wave LDS tile,
+//   3. reads it back in the transposed role -- lane = channel, rows along k -- as the B operand of
+//      dW^T[cin, C] += act(Aprev)^T dZ, whose A operand is the previous layer's raw output in the
+//      C/D row order, i.e. exactly the 16 values per lane the dX epilogue needs anyway.
+// Z is read once, Aprev once; algorithmic bytes per edge 4(C + 2*32) instead of 4(2C + 3*32).
+#include "gridgcn_mma.h"
+#include "gridgcn_train.h"
+
+#define GG_AF_TS 68    // LDS row stride (floats) of the staged half tile: 64 channels + 4
+
+__device__ __forceinline__ float gg_af_f4(const float4 &v, int i)
+{
+    return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+}
+
+// NJ = C / 32 (2 or 4).  cin == ndx == 32, previous layer's BatchNorm given, C % 64 == 0.
+template <int NJ>
+__global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int C = NJ * 32;
+    const int h = lane >> 5, l31 = lane & 31;
+    float *Wl = lds;                                   // Wdx: [C/2 steps][64]
+    float *cst = lds + C * 32;                         // scale, shift, mean, bz, cz  [5][C]
+    float *T = cst + 5 * C + wave * (32 * GG_AF_TS);   // this wave's dZ half tile [32][TS]
+    {
+        const float4 *src = (const float4 *)p.Wdx;
+        for (int i = tid; i < C * 8; i += 256) ((float4 *)Wl)[i] = src[i];
+        for (int c = tid; c < C; c += 256) {
+            const float sc = p.scale[c];
+            cst[c] = sc;
+            cst[C + c] = p.shift[c];
+            cst[2 * C + c] = p.mean[c];
+            cst[3 * C + c] = -(sc * p.rstd[c]) * p.m2[c];
+            cst[4 * C + c] = -(sc * p.m1[c]);
+        }
+    }
+    __syncthreads();
+    const float ps = p.pscale[l31], psh = p.pshift[l31], pm = p.pmean[l31], pr = p.prstd[l31];
+    float a1 = 0.f, a2 = 0.f;
+    ggm_f32x16 accw[NJ];
+    ggm_zero<NJ>(accw);
+    const long long ntile = (p.E + 31) >> 5;
+    const bool sparse = p.amax != nullptr;
+
+    auto dz4 = [&](const float4 z, const float4 g, int k) -> float4 {
+        const float4 sc = *(const float4 *)(cst + k), sh = *(const float4 *)(cst + C + k);
+        const float4 mu = *(const float4 *)(cst + 2 * C + k), bz = *(const float4 *)(cst + 3 * C + k);
+        const float4 cz = *(const float4 *)(cst + 4 * C + k);
+        float4 d;
+        d.x = sc.x * ((z.x * sc.x + sh.x > 0.f) ? g.x : 0.f) + ((z.x - mu.x) * bz.x + cz.x);
+        d.y = sc.y * ((z.y * sc.y + sh.y > 0.f) ? g.y : 0.f) + ((z.y - mu.y) * bz.y + cz.y);
+        d.z = sc.z * ((z.z * sc.z + sh.z > 0.f) ? g.z : 0.f) + ((z.z - mu.z) * bz.z + cz.z);
+        d.w = sc.w * ((z.w * sc.w + sh.w > 0.f) ? g.w : 0.f) + ((z.w - mu.w) * bz.w + cz.w);
+        return d;
+    };
+
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile;
+         tile += (long long)gridDim.x * 4) {
+        const long long r0 = tile << 5;
+        const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        const bool rowok = l31 < nrows;               // rows past E are clamped copies: no weight
+        long long row = r0 + l31;
+        if (row >= p.E) row = p.E - 1;
+        const float *zr = p.Z + row * C;
+        const float *gr;
+        const int *ar = nullptr;
+        int pp = 0;
+        if (sparse) {
+            const long long cen = row / p.P;
+            pp = (int)(row - cen * p.P);
+            gr = p.gval + cen * C;
+            ar = p.amax + cen * C;
+        } else {
+            gr = p.dY + row * p.ldy;
+        }
+        auto ldg = [&](int k) -> float4 {
+            float4 g = *(const float4 *)(gr + k);
+            if (sparse) {
+                const int4 am = *(const int4 *)(ar + k);
+                g.x = am.x == pp ? g.x : 0.f; g.y = am.y == pp ? g.y : 0.f;
+                g.z = am.z == pp ? g.z : 0.f; g.w = am.w == pp ? g.w : 0.f;
+            }
+            return g;
+        };
+        // the previous layer's raw outputs in the C/D row order (rows (r&3) + 8(r>>2) + 4h, column
+        // l31): A operand of the dW product and input of the epilogue's BatchNorm-backward sums
+        const long long base = (r0 + 4 * h) * 32 + l31;
+        float zpv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const bool ok = nrows == 32 || rr + 4 * h < nrows;
+            zpv[r] = ok ? p.Aprev[base + rr * 32] : 0.f;
+        }
+        ggm_f32x16 accx;
+#pragma unroll
+        for (int r = 0; r < 16; r++) accx[r] = 0.f;
+        int s = 0;
+#pragma unroll
+        for (int hc = 0; hc < NJ / 2; hc++) {
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const int k0 = (2 * hc + cc) * 32 + h * 16;
+                float4 z[4], g[4], a[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { z[q] = *(const float4 *)(zr + k0 + 4 * q); g[q] = ldg(k0 + 4 * q); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    a[q] = dz4(z[q], g[q], k0 + 4 * q);
+                    if (!rowok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = a[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_af_f4(a[q], i), Wl[s * 64 + lane],
+                                                                    accx, 0, 0, 0);
+                        s++;
+                    }
+            }
+            // the tile belongs to this wave alone: its LDS writes only have to land before its reads
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
+                // (rows past E: their dZ rows in T are zero, whatever act() makes of the padding)
+                const float av = fmaxf(zpv[r] * ps + psh, 0.f);
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    accw[2 * hc + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, trow[jj * 32],
+                                                                             accw[2 * hc + jj], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // dX tile + BatchNorm-backward sums of the previous layer
+        float *xp = p.dX + base;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            if (nrows == 32 || rr + 4 * h < nrows) {
+                const float dx = accx[r];
+                xp[rr * 32] = dx;
+                const float d = (zpv[r] * ps + psh > 0.f) ? dx : 0.f;
+                s1 += d;
+                s2 += d * ((zpv[r] - pm) * pr);
+            }
+        }
+        a1 += s1;
+        a2 += s2;
+    }
+    // dW^T partials: the four waves add up in LDS (fixed order), one [tile j][reg][lane] block per
+    // workgroup goes to the workspace
+    {
+        float *blk = cst + 5 * C;                      // NJ*1024 floats over the tile area
+        __syncthreads();
+        for (int w = 0; w < 4; w++) {
+            if (wave == w) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int idx = (j * 16 + r) * 64 + lane;
+                        blk[idx] = (w == 0 ? 0.f : blk[idx]) + accw[j][r];
+                    }
+            }
+            __syncthreads();
+        }
+        float *part = p.dWpart + (size_t)blockIdx.x * NJ * 1024;
+        for (int i = tid; i < NJ * 1024; i += 256) part[i] = blk[i];
+    }
+    __syncthreads();
+    float *red = lds;                                  // [4 waves][2][32]
+    {
+        const float t1 = a1 + __shfl_xor(a1, 32, 64);
+        const float t2 = a2 + __shfl_xor(a2, 32, 64);
+        if (lane < 32) {
+            red[(wave * 2 + 0) * 32 + lane] = t1;
+            red[(wave * 2 + 1) * 32 + lane] = t2;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int which = tid >> 5, col = tid & 31;
+        float v = 0.f;
+        for (int w = 0; w < 4; w++) v += red[(w * 2 + which) * 32 + col];
+        atomicAdd(&p.psums[which * 32 + col], (double)v);
+    }
+}
+
+// dW[ch][i] = sum over workgroups of the partial D tiles: tile j, lane l, reg r hold dW^T[i][ch] with
+// ch = 32j + (l & 31), i = (r & 3) + 8(r >> 2) + 4(l >> 5).  One 1024-thread workgroup per (j, r):
+// 16 groups of 64 lanes each sum a slice of the waves, LDS adds the groups (deterministic order).
+__global__ __launch_bounds__(1024) void gg_k_att_dw_reduce(const float *__restrict__ part, int nwaves,
+                                                           int NJ, float *__restrict__ dW)
+{
+    __shared__ float sh[16][64];
+    const int j = blockIdx.x >> 4, r = blockIdx.x & 15;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float v = 0.f;
+    for (int w = grp; w < nwaves; w += 16) v += part[((size_t)w * NJ + j) * 1024 + r * 64 + lane];
+    sh[grp][lane] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int g = 0; g < 16; g++) t += sh[g][lane];
+        const int ch = 32 * j + (lane & 31), i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dW[ch * 32 + i] = t;
+    }
+}
+
+static int gg_att_fused_grid(long long E)
+{
+    const long long ntile = (E + 31) >> 5;
+    long long nb = (ntile + 3) / 4;
+    if (nb > 256 * 3) nb = 256 * 3;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+// shapes the fused kernel takes (mirrored by gg_linear_bwd_workspace)
+bool gg_att_bwd_fused_ok(long long E, int cin, int C)
+{
+    return cin == 32 && (C == 64 || C == 128) && E >= 32;
+}
+
+size_t gg_att_bwd_fused_workspace(long long E, int cin, int C)
+{
+    if (!gg_att_bwd_fused_ok(E, cin, C)) return 0;
+    return (size_t)gg_att_fused_grid(E) * (C / 32) * 1024 * sizeof(float);
+}
+
+template <int NJ>
+static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_fused<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    const int C = NJ * 32;
+    const size_t lds = ((size_t)C * 32 + 5 * C + 4 * 32 * GG_AF_TS) * sizeof(float);
+    const int grid = gg_att_fused_grid(p.E);
+    gg_k_att_bwd_fused<NJ><<<grid, 256, lds, st>>>(p);
+    if (hipGetLastError() != hipSuccess) return 3;
+    gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.dW);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+// 1 = not this kernel's shape (the caller falls back to the separate dX / dW kernels)
+int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st)
+{
+    if (!gg_att_bwd_fused_ok(p.E, p.cin, p.C)) return 1;
+    if (!p.Wdx || p.ndx != 32 || !p.dX || !p.dW || !p.dWpart || !p.pscale || !p.psums) return 1;
+    if (p.cin_w != 32 || p.rot != 0 || p.drop_thr) return 1;
+    if (!p.amax && (p.ldy & 3)) return 1;
+    return p.C == 64 ? launch_att_fused<2>(p, st) : launch_att_fused<4>(p, st);
+}

@@ -919,6 +919,8 @@ int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg
         *bytes = (size_t)n * cinP * CP * sizeof(float);
         const size_t d = gg_linear_dw_direct_workspace(E, cin, C);
         if (d > *bytes) *bytes = d;
+        const size_t f = gg_att_bwd_fused_workspace(E, cin, C);
+        if (f > *bytes) *bytes = f;
     }
     return 0;
 }
@@ -945,6 +947,12 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     const int ntm = (p.cin + 31) >> 5, ntn2 = (p.C + 31) >> 5;
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
+    // ---- 32 -> 64/128 layer behind a BatchNorm'd layer: dX, sums and dW in one pass over Z ----
+    const char *nf = getenv("GG_NO_ATT_FUSED");
+    if (p.dX && p.Wdx && !(nf && nf[0] && nf[0] != '0')) {
+        const int rc = gg_att_bwd_fused(p, st);
+        if (rc != 1) return rc;
+    }
     // ---- register-direct dX (gridgcn_direct.hip) when the operand was packed for it ----
     if (p.dX && p.Wdx && !getenv("GG_DX_LDS")) {
         const int rc = gg_linear_dx_direct(p, st);

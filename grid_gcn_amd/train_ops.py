@@ -771,11 +771,13 @@ def time_linear_fwd(E, cin, C, iters=10, device="cuda:0"):
     return e0.elapsed_time(e1) / iters
 
 
-def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0):
+def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=False):
     """Time one gridgcn_linear_bwd call (dX kernel + dW kernel + dW reduce) on synthetic tensors
     shaped like the last pt layer of a GridConv edge block (sparse upstream gradient, input gradient
     for the first `ndx` columns; cin = padded row length).  Used by bench.py for the roofline of the
-    dominant kernels of the training step.  Returns ms/call."""
+    dominant kernels of the training step.  prev_bn: the layer's input is the raw output of a
+    BatchNorm'd layer (as the second attention conv's is): its BatchNorm+ReLU is applied on the fly
+    and its BatchNorm-backward sums are accumulated.  Returns ms/call."""
     lib = _lib.load()
     E = ncent * P
     g = torch.Generator(device=device).manual_seed(0)
@@ -798,12 +800,15 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0):
     nbytes = ctypes.c_size_t(0)
     lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+    pv = [rnd(cin).abs() + 0.5, rnd(cin) * 0.1, rnd(cin) * 0.1, rnd(cin).abs() + 0.5]
+    pb = [_ptr(t) for t in pv] if prev_bn else [None] * 4
+    psums = torch.zeros(2 * cin, dtype=torch.float64, device=device)
 
     def call():
         rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
-                                    _ptr(m1), _ptr(m2), _ptr(X), None, None, None, None, _ptr(Wb),
+                                    _ptr(m1), _ptr(m2), _ptr(X), pb[0], pb[1], pb[2], pb[3], _ptr(Wb),
                                     _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin, cin, 0, 0,
-                                    _ptr(dX), _ptr(dW), None, _ptr(amax),
+                                    _ptr(dX), _ptr(dW), _ptr(psums) if prev_bn else None, _ptr(amax),
                                     _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))
         _lib.check(rc, "gridgcn_linear_bwd")
