@@ -206,30 +206,31 @@ def main():
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         # ---- dominant kernels of the TIMED training step.  The point conv of this layer runs on
         #      the source points (gridgcn_edgelin.hip), so the largest per-edge GEMMs left are those
-        #      of the attention MLP: backward of its C/4 -> C conv = gg_k_linear_dx_direct (dZ
-        #      formed in registers, dX) + gg_k_linear_dw_direct (dW over the rows) + reduce.  With
-        #      K = C/4 they are HBM bound: Z [E,C] is read by both kernels. ----
+        #      of the attention MLP: backward of its C/4 -> C conv = gg_k_att_bwd_fused (dZ formed
+        #      in registers from the sparse arg-max gradient; dX, the BatchNorm-backward sums of
+        #      the layer in front and dW in ONE pass over Z) + its small reduce.  With K = C/4 it is
+        #      HBM bound. ----
         from grid_gcn_amd import train_ops
         cin_b = layer.att2[0].lin.in_features
         c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
-        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=10, device=dev)
+        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=10, device=dev,
+                                         ndx=cin_b, prev_bn=True)
         e_b = float(ncent_b * p_b)
-        # dX kernel: read Z [E,C], the sparse upstream gradient (amax, gval) [ncent,C] and the
-        # previous layer's raw output [E,cin] (BatchNorm-backward sums), write dX [E,cin];
-        # dW kernel: read Z, (amax, gval) and the previous layer's output
-        bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 8.0 * ncent_b * c_b + \
-            4.0 * e_b * (c_b + cin_b) + 8.0 * ncent_b * c_b
+        # algorithmic bytes of the operation: read Z [E,C] once, the sparse upstream gradient
+        # (amax, gval) [ncent,C], the previous layer's raw output [E,cin]; write dX [E,cin]
+        bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 8.0 * ncent_b * c_b
         gbs_b = bytes_b / (ms_b * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "gg_k_linear_dx_direct + gg_k_linear_dw_direct "
-                           "+ gg_k_dw_reduce_direct (backward of the %d->%d attention conv of "
-                           "GridConv %s over %d edges: BN/ReLU backward formed in registers from the "
-                           "sparse arg-max gradient, dX, dW)" % (cin_b, c_b, name, ncent_b * p_b),
+        out["roofline"] = {"bound": "hbm", "kernel": "gg_k_att_bwd_fused + gg_k_att_dw_reduce "
+                           "(fused backward of the %d->%d attention conv of GridConv %s over %d "
+                           "edges: BN/ReLU backward formed in registers from the sparse arg-max "
+                           "gradient; dX, BN-backward sums of the layer in front and dW in one pass "
+                           "over Z)" % (cin_b, c_b, name, ncent_b * p_b),
                            "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": gbs_b / HBM_PEAK_GBS,
-                           # FETCH_SIZE (x2: 16-byte streaming reads) + WRITE_SIZE of the two
-                           # kernels at this shape, profiles/r1_pmc_summary.txt
-                           "traffic": 5.61e9 if (a.points == 81920 and B == 8) else None,
+                           # FETCH_SIZE (x2: 16-byte streaming reads) + WRITE_SIZE of the kernel at
+                           # this shape, profiles/r1_pmc_summary.txt
+                           "traffic": 3.23e9 if (a.points == 81920 and B == 8) else None,
                            "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
                            "algorithmic_flops_per_launch": 4.0 * e_b * cin_b * c_b,
                            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
