@@ -21,7 +21,7 @@ __device__ __forceinline__ float gg_af_f4(const float4 &v, int i)
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-// NJ = C / 32 (2 or 4).  cin == ndx == 32, previous layer's BatchNorm given, C % 64 == 0.
+// NJ = C / 32 (2 or 4).  cin == ndx in {16, 32}, previous layer's BatchNorm given, C % 64 == 0.
 template <int NJ>
 __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
 {
@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int C = NJ * 32;
     const int h = lane >> 5, l31 = lane & 31;
+    const int cin = p.cin;
+    const bool colok = l31 < cin;                      // cin = 16: half of the dX / dW^T tile is idle
     float *Wl = lds;                                   // Wdx: [C/2 steps][64]
     float *cst = lds + C * 32;                         // scale, shift, mean, bz, cz  [5][C]
     float *T = cst + 5 * C + wave * (32 * GG_AF_TS);   // this wave's dZ half tile [32][TS]
@@ -45,7 +47,8 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
         }
     }
     __syncthreads();
-    const float ps = p.pscale[l31], psh = p.pshift[l31], pm = p.pmean[l31], pr = p.prstd[l31];
+    const float ps = colok ? p.pscale[l31] : 0.f, psh = colok ? p.pshift[l31] : 0.f;
+    const float pm = colok ? p.pmean[l31] : 0.f, pr = colok ? p.prstd[l31] : 0.f;
     float a1 = 0.f, a2 = 0.f;
     ggm_f32x16 accw[NJ];
     ggm_zero<NJ>(accw);
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
         };
         // the previous layer's raw outputs in the C/D row order (rows (r&3) + 8(r>>2) + 4h, column
         // l31): A operand of the dW product and input of the epilogue's BatchNorm-backward sums
-        const long long base = (r0 + 4 * h) * 32 + l31;
+        const long long base = (r0 + 4 * h) * cin + l31;
         float zpv[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rr = (r & 3) + 8 * (r >> 2);
-            const bool ok = nrows == 32 || rr + 4 * h < nrows;
-            zpv[r] = ok ? p.Aprev[base + rr * 32] : 0.f;
+            const bool ok = colok && (nrows == 32 || rr + 4 * h < nrows);
+            zpv[r] = ok ? p.Aprev[base + rr * cin] : 0.f;
         }
         ggm_f32x16 accx;
 #pragma unroll
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
             for (int r = 0; r < 16; r++) {
                 const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
                 // (rows past E: their dZ rows in T are zero, whatever act() makes of the padding)
-                const float av = fmaxf(zpv[r] * ps + psh, 0.f);
+                const float av = fmaxf(zpv[r] * ps + psh, 0.f);      // 0 in the idle columns
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++)
                     accw[2 * hc + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, trow[jj * 32],
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rr = (r & 3) + 8 * (r >> 2);
-            if (nrows == 32 || rr + 4 * h < nrows) {
+            if (colok && (nrows == 32 || rr + 4 * h < nrows)) {
                 const float dx = accx[r];
-                xp[rr * 32] = dx;
+                xp[rr * cin] = dx;
                 const float d = (zpv[r] * ps + psh > 0.f) ? dx : 0.f;
                 s1 += d;
                 s2 += d * ((zpv[r] - pm) * pr);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
         const int which = tid >> 5, col = tid & 31;
         float v = 0.f;
         for (int w = 0; w < 4; w++) v += red[(w * 2 + which) * 32 + col];
-        atomicAdd(&p.psums[which * 32 + col], (double)v);
+        if (col < cin) atomicAdd(&p.psums[which * cin + col], (double)v);
     }
 }
 
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
 // ch = 32j + (l & 31), i = (r & 3) + 8(r >> 2) + 4(l >> 5).  One 1024-thread workgroup per (j, r):
 // 16 groups of 64 lanes each sum a slice of the waves, LDS adds the groups (deterministic order).
 __global__ __launch_bounds__(1024) void gg_k_att_dw_reduce(const float *__restrict__ part, int nwaves,
-                                                           int NJ, float *__restrict__ dW)
+                                                           int NJ, int cin, float *__restrict__ dW)
 {
     __shared__ float sh[16][64];
     const int j = blockIdx.x >> 4, r = blockIdx.x & 15;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(1024) void gg_k_att_dw_reduce(const float *__restri
         float t = 0.f;
         for (int g = 0; g < 16; g++) t += sh[g][lane];
         const int ch = 32 * j + (lane & 31), i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        dW[ch * 32 + i] = t;
+        if (i < cin) dW[ch * cin + i] = t;
     }
 }
 
@@ -233,7 +236,7 @@ static int gg_att_fused_grid(long long E)
 // shapes the fused kernel takes (mirrored by gg_linear_bwd_workspace)
 bool gg_att_bwd_fused_ok(long long E, int cin, int C)
 {
-    return cin == 32 && (C == 64 || C == 128) && E >= 32;
+    return (cin == 32 || cin == 16) && (C == 64 || C == 128) && E >= 32;
 }
 
 size_t gg_att_bwd_fused_workspace(long long E, int cin, int C)
@@ -255,7 +258,7 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
     const int grid = gg_att_fused_grid(p.E);
     gg_k_att_bwd_fused<NJ><<<grid, 256, lds, st>>>(p);
     if (hipGetLastError() != hipSuccess) return 3;
-    gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.dW);
+    gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.cin, p.dW);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -263,8 +266,8 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
 int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st)
 {
     if (!gg_att_bwd_fused_ok(p.E, p.cin, p.C)) return 1;
-    if (!p.Wdx || p.ndx != 32 || !p.dX || !p.dW || !p.dWpart || !p.pscale || !p.psums) return 1;
-    if (p.cin_w != 32 || p.rot != 0 || p.drop_thr) return 1;
+    if (!p.Wdx || p.ndx != p.cin || !p.dX || !p.dW || !p.dWpart || !p.pscale || !p.psums) return 1;
+    if (p.cin_w != p.cin || p.rot != 0 || p.drop_thr) return 1;
     if (!p.amax && (p.ldy & 3)) return 1;
     return p.C == 64 ? launch_att_fused<2>(p, st) : launch_att_fused<4>(p, st);
 }
