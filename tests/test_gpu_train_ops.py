@@ -357,3 +357,57 @@ def test_softmax_ce_class_weights_match_weighted_gradient_op():
     l2.backward()
     assert float((lg1.grad - lg2.grad).abs().max()) <= 1e-6 * float(lg1.grad.abs().max()) + 1e-12
     assert float(lg2.grad[lab == 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ncent,P,cin,C,sparse", [(700, 5, 32, 128, True), (1001, 12, 16, 64, True),
+                                                  (4099, 1, 32, 64, False), (20000, 5, 32, 128, False)])
+def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
+    """gg_k_att_bwd_fused (one pass over Z: dX, previous layer's BN-backward sums, dW) against the
+    separate register-direct dX and dW kernels on the same inputs (GG_NO_ATT_FUSED=1)."""
+    import ctypes
+    import os
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    E = ncent * P
+    g = torch.Generator(device=DEV).manual_seed(ncent + C)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    Z, X = rnd(E, C), rnd(E, cin)
+    scale, shift = rnd(C).abs() + 0.5, rnd(C) * 0.3
+    mean, rstd = rnd(C) * 0.1, rnd(C).abs() + 0.5
+    m1, m2 = rnd(C) * 1e-2, rnd(C) * 1e-2
+    pv = [rnd(cin).abs() + 0.5, rnd(cin) * 0.3, rnd(cin) * 0.1, rnd(cin).abs() + 0.5]
+    amax = torch.randint(0, P, (ncent, C), device=DEV, dtype=torch.int32, generator=g)
+    gval = rnd(ncent, C)
+    dY = rnd(E, C)
+    W = rnd(C, cin)
+    Wb = train_ops.pack_tiles(W)
+    Wdx = torch.empty(C * 32, device=DEV)
+    _lib.check(lib.gridgcn_pack_linear(_ptr(W), None, C, cin, 0, cin, cin, None, None, None, None,
+                                       None, _ptr(Wdx), _stream(W)), "pack")
+    nbytes = ctypes.c_size_t(0)
+    lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
+    res = []
+    for nofused in ("1", "0"):
+        os.environ["GG_NO_ATT_FUSED"] = nofused
+        dX = torch.full((E, cin), float("nan"), device=DEV)
+        dW = torch.full((C, cin), float("nan"), device=DEV)
+        psums = torch.zeros(2 * cin, dtype=torch.float64, device=DEV)
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
+        rc = lib.gridgcn_linear_bwd(
+            None if sparse else _ptr(dY), _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+            _ptr(m1), _ptr(m2), _ptr(X), _ptr(pv[0]), _ptr(pv[1]), _ptr(pv[2]), _ptr(pv[3]),
+            _ptr(Wb), None, _ptr(Wdx), cin, E, C, cin, cin, 0, 0, _ptr(dX), _ptr(dW), _ptr(psums),
+            _ptr(amax) if sparse else None, _ptr(gval) if sparse else None, P if sparse else 0,
+            _ptr(ws), nbytes.value, _stream(Z))
+        _lib.check(rc, "gridgcn_linear_bwd")
+        torch.cuda.synchronize()
+        res.append((dX, dW, psums))
+    os.environ.pop("GG_NO_ATT_FUSED")
+    (x0, w0, s0), (x1, w1, s1) = res
+    assert torch.isfinite(x1).all() and torch.isfinite(w1).all()
+    # dX: the same MFMA chain over the channels in both kernels
+    assert float((x0 - x1).abs().max()) <= 1e-6 * max(1.0, float(x0.abs().max()))
+    # dW and the sums: different summation order over the rows
+    assert float((w0 - w1).abs().max()) <= 2e-5 * max(1.0, float(w0.abs().max()))
+    assert float((s0 - s1).abs().max()) <= 1e-5 * max(1.0, float(s0.abs().max()))
