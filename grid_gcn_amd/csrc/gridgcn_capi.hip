@@ -495,7 +495,7 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
                               int P, int C0, const float *Wg, const float *b, float *Z0,
                               float *att16, double *sums, void *stream)
 {
-    if (!src || !nebidx || !cent || !b || !att16 || !sums || B < 1 || Nsrc < 1 || Cs < 3 ||
+    if (!src || !nebidx || !cent || !b || !att16 || B < 1 || Nsrc < 1 || Cs < 3 ||
         O < 1 || P < 1 || C0 < 1 || (!Ysrc && !Wg) || (long long)B * O * P >= (1ll << 31))
         return GRIDGCN_EINVAL;
     GGEdgeLin0 p;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_fwd(GGEdgeLin0 p, int epw)
             a[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int flat_i = (int)flat;                      // B*Nsrc < 2^31 (checked by the index ops)
+        if (!p.Z && !p.sums) continue;                     // evaluation: only att16 is wanted
         for (int j = 0; j < nloc; j += G) {
             V y[G];
             float gxj[G], gyj[G], gzj[G];
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_fwd(GGEdgeLin0 p, int epw)
         }
     }
     // batch statistics: lanes -> waves (LDS) -> fp64 atomics
+    if (!p.sums) return;
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         red[wave][0][lane * VPL + i] = live ? s[i] : 0.f;

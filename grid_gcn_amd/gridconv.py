@@ -211,6 +211,13 @@ class SubGUpdate(nn.Module):
         src [B,Nsrc,4+C] (NOT gathered), nebidx [B,O,P], cent [B,O,>=3]."""
         from . import ops
         assert not self.training, "the fused kernel folds BatchNorm: eval() mode only"
+        from . import train_ops
+        att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
+        if train_ops.edge_block_src_eval_supported(pt_layers, att_layers, src, self.has_feats):
+            # up layers (one point conv): that conv on the source points, gathered by the max kernel
+            agg = train_ops.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
+                                                att_layers, self.localfdim)
+            return self.finish(agg, center_masks, center_ori_feats)
         pt, att = self.packed_layers()
         agg = ops.gridconv_forward(src.contiguous(), nebidx, cent.contiguous(), pt, att,
                                    has_feats=self.has_feats, localfdim=self.localfdim)

@@ -304,6 +304,8 @@ class _ZeroArena:
 
 
 ZERO_ARENA = os.environ.get("GG_NO_ZERO_ARENA", "0") != "1"
+# evaluation of single-layer-pt edge blocks (the up layers) through the source-side kernels
+SRC_EVAL = os.environ.get("GG_NO_SRC_EVAL", "0") != "1"
 _ARENA = _ZeroArena()
 _zeros = _ARENA.zeros
 _ZEROS = {}
@@ -407,17 +409,11 @@ class _MLPTrain(torch.autograd.Function):
         return (dX, None) + tuple(grads)
 
 
-@torch.no_grad()
-def mlp_bn_relu_eval(x, layers):
-    """Inference through the same forward kernel: layer l computes Z_l = act(Z_{l-1}) W_l^T + b_l
-    with act = the previous layer's BatchNorm (running statistics) + ReLU applied while the rows are
-    loaded; one BatchNorm+ReLU pass at the end.  x [..., cin] float32 on the GPU."""
-    lib = _lib.load()
-    shp = x.shape
-    prev = x.reshape(-1, shp[-1]).contiguous()
+def _chain_eval_raw(lib, prev, layers):
+    """prev [E, cin % 8 == 0] through `layers` with running statistics: returns the LAST layer's
+    raw output Z and its BatchNorm (scale, shift) -- the caller applies them (or hands them to a
+    kernel that does)."""
     E, dev = prev.shape[0], prev.device
-    if prev.shape[1] % 8:                      # the kernel reads rows in 32-byte pieces
-        prev = torch.nn.functional.pad(prev, (0, 8 - prev.shape[1] % 8))
     sc = sh = None
     with torch.cuda.device(dev):
         st = _stream(prev)
@@ -438,9 +434,77 @@ def mlp_bn_relu_eval(x, layers):
             sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
             sh = (bn.bias - bn.running_mean * sc).contiguous()
             prev = Z
-        Y = torch.empty_like(prev)
-        _lib.check(lib.gridgcn_bn_relu_apply(_ptr(prev), _ptr(sc), _ptr(sh), _ptr(Y), E,
-                                             Y.shape[1], Y.shape[1], st), "gridgcn_bn_relu_apply")
+    return prev, sc, sh
+
+
+def edge_block_src_eval_supported(pt_layers, att_layers, src, has_feats):
+    """single-layer point MLP on neighbour features (every up layer): evaluation through the
+    training path's forward kernels with running statistics"""
+    if len(pt_layers) != 1 or not SRC_EVAL:
+        return False
+    if not edge_block_src_supported(pt_layers, att_layers, src, has_feats):
+        return False
+    return all(l.lin.out_features % 8 == 0 and l.lin.out_features <= 256 for l in att_layers)
+
+
+@torch.no_grad()
+def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim):
+    """GridConv edge block in evaluation mode, [B,O,C]: first (only) point conv on the SOURCE points
+    (Ysrc = features W_f^T, gathered by the max-pool kernel), attention MLP on the forward MFMA
+    kernel with running statistics, product + max over P in gg_k_pairmax_fwd4_src.  For the up
+    layers this is faster than the one-launch kernel of csrc/gridgcn_conv.hip, which repeats the
+    131 -> 128 conv for every edge (2.45 ms against ~1.2 ms at cfg4 up2)."""
+    lib = _lib.load()
+    B, Nsrc, Cs = src.shape
+    _, O, P = nebidx.shape
+    E, R, Cf = B * O * P, B * Nsrc, Cs - 4
+    dev = src.device
+    W0, b0, bn0 = pt_layer.lin.weight, pt_layer.lin.bias, pt_layer.bn
+    C0 = W0.shape[0]
+    geo = localfdim != 0
+    rot = 3 if geo else 0
+    src = src.contiguous()
+    with torch.cuda.device(dev):
+        st = _stream(src)
+        feat = src[..., 4:].reshape(R, Cf)
+        Ysrc = torch.matmul(feat, W0[:, rot:].t()).contiguous()
+        wgb = torch.cat([W0[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0), b0[None]])
+        att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
+        rc = lib.gridgcn_edge_lin0_forward(
+            _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P, C0,
+            _ptr(wgb) if geo else None, _ptr(wgb[3]), None, _ptr(att16), None, st)
+        _lib.check(rc, "gridgcn_edge_lin0_forward")
+        Za, sc_a, sh_a = _chain_eval_raw(lib, att16, att_layers)
+        sc_p = (bn0.weight * torch.rsqrt(bn0.running_var + bn0.eps)).contiguous()
+        sh_p = (bn0.bias - bn0.running_mean * sc_p).contiguous()
+        ncent, C = B * O, Za.shape[1]
+        agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+        amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+        rc = lib.gridgcn_pairmax_fwd_src(
+            _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None, _ptr(wgb[3]), B,
+            Nsrc, O, _ptr(Za), _ptr(sc_p), _ptr(sh_p), _ptr(sc_a), _ptr(sh_a), ncent, P, C,
+            _ptr(agg), C, _ptr(amax), None, st)
+        _lib.check(rc, "gridgcn_pairmax_fwd_src")
+    return agg.view(B, O, C)
+
+
+@torch.no_grad()
+def mlp_bn_relu_eval(x, layers):
+    """Inference through the same forward kernel: layer l computes Z_l = act(Z_{l-1}) W_l^T + b_l
+    with act = the previous layer's BatchNorm (running statistics) + ReLU applied while the rows are
+    loaded; one BatchNorm+ReLU pass at the end.  x [..., cin] float32 on the GPU."""
+    lib = _lib.load()
+    shp = x.shape
+    prev = x.reshape(-1, shp[-1]).contiguous()
+    E, dev = prev.shape[0], prev.device
+    if prev.shape[1] % 8:                      # the kernel reads rows in 32-byte pieces
+        prev = torch.nn.functional.pad(prev, (0, 8 - prev.shape[1] % 8))
+    Z, sc, sh = _chain_eval_raw(lib, prev, layers)
+    with torch.cuda.device(dev):
+        Y = torch.empty_like(Z)
+        _lib.check(lib.gridgcn_bn_relu_apply(_ptr(Z), _ptr(sc), _ptr(sh), _ptr(Y), E,
+                                             Y.shape[1], Y.shape[1], _stream(Z)),
+                   "gridgcn_bn_relu_apply")
     return Y.reshape(shp[:-1] + (Y.shape[1],))
 
 

@@ -168,6 +168,7 @@ int gridgcn_take_backward_workspace_bytes(int B, int N, int M, size_t *bytes);
  *   Z0[e] = Ysrc[src(e)] + Wg * geo_vec(e) + b,   Ysrc[B*Nsrc, C0] = features * Wf^T (once per point)
  * forward : Z0[B*O*P, C0], att16[B*O*P, 16] and sums[2*C0] += (sum z, sum z^2) (BatchNorm statistics;
  *           zeroed by the caller).  Ysrc NULL = no feature term, Wg[3][C0] NULL = no geo term.
+ *           Z0 NULL = not stored; Z0 and sums both NULL (evaluation) = only att16 is produced.
  * backward: dZ0 = BatchNorm/ReLU backward of the upstream gradient (dense dY[E,C0], or NULL and the
  *           sparse (amax, gval)[B*O, C0] of gridgcn_pairmax_bwd) formed on the fly, summed per source
  *           row over the edges sorted by destination -> dYsrc[B*Nsrc, C0] (zeroed by the caller),
