@@ -276,3 +276,40 @@ def test_seg_model_ragged_batch_matches_cpu_oracle_model(cfgname, npts):
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.999, cos
 
+
+
+def test_full_size_training_step_matches_stock_pytorch_ops():
+    """BASELINE configs[3] at its full size (B = 8 x 81920 points): one forward + backward through
+    the hand-written kernels against the same network on stock PyTorch-ROCm ops only (index ops are
+    shared and bit-exact): loss and the gradient vector."""
+    torch.manual_seed(0)
+    cfg = dict(model.SEG_81920, dropout=0.0)
+    net = model.GGCNSeg(cfg).to(DEV).train()
+    data, npn = synth.make_batch(8, 81920, "planes")
+    x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    lab = torch.randint(0, 21, (8, 81920), device=DEV)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = []
+    for hip in (True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        net.edge_kernel = hip
+        net.fused_head = hip
+        for l in list(net.down) + list(net.up):
+            l.mfma_train = hip
+        old = model.HEAD_KERNELS
+        model.HEAD_KERNELS = hip
+        try:
+            loss = model.seg_loss(net(x, n), lab)
+            loss.backward()
+        finally:
+            model.HEAD_KERNELS = old
+        res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()))
+        del loss
+        torch.cuda.empty_cache()
+    assert abs(res[0][0] - res[1][0]) <= 1e-4 * max(1.0, abs(res[1][0])), (res[0][0], res[1][0])
+    a, b = res
+    cos = float((a[1] * b[1]).sum() / (a[1].norm() * b[1].norm()))
+    assert cos > 0.9999, cos
+    assert float((a[1] - b[1]).norm() / b[1].norm()) < 1e-2
