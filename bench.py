@@ -16,8 +16,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver only supports dmabuf IPC: without this RCCL's peer-to-peer setup fails
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
