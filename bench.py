@@ -267,6 +267,41 @@ def main():
                                 "frac": tf_f / 157.3, "traffic": None,
                                 "algorithmic_flops_per_launch": 2.0 * e_f * cin_f * c_f,
                                 "ms_per_launch": ms_f, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        # ---- the materialising neighbour gather as an operator (SURVEY §8(d) algorithmic bytes):
+        #      batch_take_g forward + its sorted backward at the shape of layer up2 ----
+        with torch.no_grad():
+            gsrc = src_.contiguous()
+            tk = lambda: ops.batch_take_g(gsrc, idx_, neighbour_index=True)  # noqa: E731
+            for _ in range(3):
+                tk()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                tk()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_g = e0.elapsed_time(e1) / 20
+            gout = tk()
+            tb = lambda: ops.batch_take_g_backward(gout, idx_, gsrc.shape[1], True)  # noqa: E731
+            for _ in range(3):
+                tb()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                tb()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_gb = e0.elapsed_time(e1) / 20
+        alg_g = 4.0 * gsrc.numel() + 4.0 * idx_.numel() + 4.0 * idx_.numel() * gsrc.shape[2]
+        out["roofline_gather"] = {
+            "bound": "hbm", "kernel": "gridgcn_batch_take (batch_take_g of GridConv %s: src %s, "
+            "index %s)" % (name, list(gsrc.shape), list(idx_.shape)),
+            "achieved": alg_g / (ms_g * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_g / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg_g, "ms_per_launch": ms_g,
+            "backward_sorted_ms": ms_gb,
+            "backward_sorted_GBps": alg_g / (ms_gb * 1e-3) / 1e9}
+        del gout
         out["inference"] = {"value": B / (ms_inf * 1e-3), "unit": "point-clouds/s",
                             "ms_per_batch": ms_inf, "path": "HIP index ops + gg_k_gridconv (down layers) / source-side "
                                     "conv + max kernels (up layers) + MFMA eval MLPs"}

@@ -15,7 +15,7 @@ EXPORTS = [
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
     "gridgcn_ball_knn_grid_workspace_bytes", "gridgcn_ball_knn_grid",
-    "gridgcn_batch_take", "gridgcn_batch_take_backward",
+    "gridgcn_batch_take", "gridgcn_batch_take_backward", "gridgcn_batch_take_backward_sorted",
     "gridgcn_gridconv_forward", "gridgcn_edge_inputs", "gridgcn_edge_inputs_backward",
     "gridgcn_edge_inputs_rows", "gridgcn_edge_inputs_rows_backward",
     "gridgcn_take_backward_workspace_bytes",
@@ -92,6 +92,8 @@ def load():
     lib.gridgcn_batch_take.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
     lib.gridgcn_batch_take_backward.restype = ci
     lib.gridgcn_batch_take_backward.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.gridgcn_batch_take_backward_sorted.restype = ci
+    lib.gridgcn_batch_take_backward_sorted.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, cs, vp]
     ll = ctypes.c_longlong
     lib.gridgcn_linear_fwd.restype = ci
     lib.gridgcn_linear_fwd.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]

@@ -224,6 +224,21 @@ int gridgcn_batch_take_backward(const float *grad_out, const int32_t *index, int
                                   (hipStream_t)stream);
 }
 
+int gridgcn_batch_take_backward_sorted(const float *grad_out, const int32_t *index, int B, int N,
+                                       int C, int M, float *grad_data, void *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    if (!grad_out || !index || !grad_data || B < 1 || N < 1 || C < 1 || M < 1)
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_take_bwd_sorted_workspace(B, N, M))
+        return GRIDGCN_EWORKSPACE;
+    const int rc = gg_take_bwd_sorted(grad_out, index, B, N, C, M, grad_data, C, C, workspace,
+                                      (hipStream_t)stream);
+    if (rc != 1) return rc;              // 1: row width not covered by the sorted path
+    return gg_batch_take_backward(grad_out, index, B, N, C, M, grad_data, C, C,
+                                  (hipStream_t)stream);
+}
+
 int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, const float *b, int K,
                        int ldw, int cout, const float *scale, const float *shift, float *Z,
                        double *sums, void *stream)

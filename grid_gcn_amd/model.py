@@ -80,6 +80,8 @@ class GGCNSeg(nn.Module):
         nn.init.zeros_(self.fc2.bias)
         # ... and so do fc1/dropout + fc2 (:36-38): train_ops._HeadTrain
         self.fused_head = HEAD_KERNELS and FUSED_HEAD and _is_hip(index_ops)
+        # indices from the index operators lie in [-1, N-1]: sorted segmented-sum gather backward
+        self._take_kw = dict(neighbour_index=True) if _is_hip(index_ops) else {}
 
     fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
     jobs = None    # set to a list to record (name, layer, cent, src, nebidx) of every fused call
@@ -109,7 +111,7 @@ class GGCNSeg(nn.Module):
             elif _is_hip(self.ix) and self.edge_kernel:
                 cf = layer.forward_src(cent, data_layer, nebidx, centmsk)
             else:
-                neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx)        # :172-173
+                neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx, **self._take_kw)  # :172-173
                 cf = layer(cent[..., 0:3], neighbors, centmsk)                      # :185
             data_layer = torch.cat([cent, cf], dim=2)                               # :186
             locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
@@ -139,7 +141,7 @@ class GGCNSeg(nn.Module):
             elif _is_hip(self.ix) and self.edge_kernel:
                 cf = layer.forward_src(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
             else:
-                neighbors = ix.batch_take_g(f_last.contiguous(), nebidx)            # :217-218
+                neighbors = ix.batch_take_g(f_last.contiguous(), nebidx, **self._take_kw)  # :217-218
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
             if i != nup - 1:                      # (the last layer's features go to the head only)
                 f_last = torch.cat([upl, cf], dim=2)                                # :231

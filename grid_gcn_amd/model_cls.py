@@ -85,6 +85,8 @@ class GGCNCls(nn.Module):
     def __init__(self, cfg=CLS_MN40, index_ops=HipIndexOps, seed=0):
         super().__init__()
         self.cfg, self.ix, self.seed = cfg, index_ops, seed
+        self._take_kw = (dict(neighbour_index=True)
+                         if isinstance(index_ops, type) and issubclass(index_ops, HipIndexOps) else {})
         self.layers = nn.ModuleList(
             SubGUpdateCls(cfg["inputDim"][i], cfg["pt_ele_dim"][i], cfg["att_ele_dim"][i],
                           cfg["localfdim"], cfg["relu"], cfg["bn_decay"])
@@ -105,7 +107,7 @@ class GGCNCls(nn.Module):
             nebidx, nebidxmsk, cent, centmsk, num = ix.Gridify(
                 data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, self.seed))
             data_loc = cent
-            neighbors = ix.batch_take_g(data.contiguous(), nebidx)                # :94
+            neighbors = ix.batch_take_g(data.contiguous(), nebidx, **self._take_kw)  # :94
             cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104
             data = torch.cat([cent, cf], dim=2)                                   # :106
         net = cf.reshape(cf.shape[0], -1)                                         # flatten=True

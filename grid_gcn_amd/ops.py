@@ -219,10 +219,11 @@ def KNN(unknown, known, downnum, upnum, *, k=3, out=None):
 
 class _BatchTake(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, data, index):
+    def forward(ctx, data, index, neighbour_index=False):
         lib = _lib.load()
         B, N, C = data.shape
         M = index.numel() // B
+        ctx.neighbour_index = neighbour_index
         out = torch.empty(tuple(index.shape) + (C,), dtype=torch.float32, device=data.device)
         with torch.cuda.device(data.device):
             rc = lib.gridgcn_batch_take(_ptr(data), _ptr(index), B, N, C, M, _ptr(out),
@@ -235,34 +236,46 @@ class _BatchTake(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (index,) = ctx.saved_tensors
-        return batch_take_g_backward(grad_out, index, ctx.dims[1]), None
+        return batch_take_g_backward(grad_out, index, ctx.dims[1], ctx.neighbour_index), None, None
 
 
 @torch.no_grad()
-def batch_take_g_backward(grad_out, index, N):
+def batch_take_g_backward(grad_out, index, N, neighbour_index=False):
     """Scatter-add backward of batch_take_g: grad_out [B,...,C] f32, index [B,...] i32 -> gradient
-    w.r.t. data [B,N,C] (what MXNet's take backward does, utils/ops.py:87-92)."""
+    w.r.t. data [B,N,C] (what MXNet's take backward does, utils/ops.py:87-92).
+    neighbour_index: every index lies in [-1, N-1] (what Gridify / GridifyUp / BallKNN produce):
+    the gradient is then formed as a sorted segmented sum, 3-6x faster at the layer sizes."""
     lib = _lib.load()
     B, C = index.shape[0], grad_out.shape[-1]
     M = index.numel() // B
     grad_out = grad_out.contiguous()
     gdata = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        rc = lib.gridgcn_batch_take_backward(_ptr(grad_out), _ptr(index), B, N, C, M,
-                                             _ptr(gdata), _stream(grad_out))
+        if SORTED_TAKE_BWD and neighbour_index:
+            # sorted segmented sum (csrc/gridgcn_scatter.hip); scatter-add inside for odd widths
+            nb = ctypes.c_size_t(0)
+            lib.gridgcn_take_backward_workspace_bytes(B, N, M, ctypes.byref(nb))
+            ws = torch.empty(nb.value, dtype=torch.uint8, device=grad_out.device)
+            rc = lib.gridgcn_batch_take_backward_sorted(_ptr(grad_out), _ptr(index), B, N, C, M,
+                                                        _ptr(gdata), _ptr(ws), nb.value,
+                                                        _stream(grad_out))
+        else:
+            rc = lib.gridgcn_batch_take_backward(_ptr(grad_out), _ptr(index), B, N, C, M,
+                                                 _ptr(gdata), _stream(grad_out))
     _lib.check(rc, "gridgcn_batch_take_backward")
     return gdata
 
 
-def batch_take_g(data, index, shape=None, scope=""):
+def batch_take_g(data, index, shape=None, scope="", neighbour_index=False):
     """Per-cloud gather: data [B,N,C] f32, index [B,...] i32 -> [B,...,C]
     (utils/ops.py:78-93; flat take with mode='clip').  `shape`/`scope` are accepted for
-    signature compatibility and ignored (they only size the MXNet symbol)."""
+    signature compatibility and ignored (they only size the MXNet symbol).
+    neighbour_index=True promises indices in [-1, N-1] (see batch_take_g_backward)."""
     _chk(data, "data", 3, torch.float32)
     _require(isinstance(index, torch.Tensor) and index.is_cuda and index.dtype == torch.int32
              and index.is_contiguous() and index.shape[0] == data.shape[0],
              "index must be a contiguous int32 GPU tensor [B,...]")
-    return _BatchTake.apply(data, index)
+    return _BatchTake.apply(data, index, bool(neighbour_index))
 
 
 # ---- fused GridConv edge pipeline (inference-mode BatchNorm) -----------------------------------

@@ -185,6 +185,16 @@ def test_batch_take_matches_oracle_and_grad():
         ref = np.zeros((150, C), np.float64)
         np.add.at(ref, flat, g.reshape(-1, C).astype(np.float64))
         np.testing.assert_allclose(td.grad.cpu().numpy().reshape(150, C), ref, rtol=1e-5, atol=1e-5)
+        # neighbour indices ([-1, N-1], as the index ops produce): sorted segmented-sum backward
+        index2 = rng.integers(-1, 50, (3,) + ishape).astype(np.int32)
+        td2 = T(data).requires_grad_(True)
+        out2 = ops.batch_take_g(td2, T(index2), neighbour_index=True)
+        np.testing.assert_array_equal(out2.detach().cpu().numpy(), orc.batch_take(data, index2))
+        out2.backward(T(g))
+        flat2 = np.clip(index2 + (np.arange(3) * 50)[:, None, None], 0, 149).reshape(-1)
+        ref2 = np.zeros((150, C), np.float64)
+        np.add.at(ref2, flat2, g.reshape(-1, C).astype(np.float64))
+        np.testing.assert_allclose(td2.grad.cpu().numpy().reshape(150, C), ref2, rtol=1e-5, atol=1e-5)
 
 
 def test_torch_ops_namespace_runs_the_same_kernels():
