@@ -304,7 +304,7 @@ def main():
         del gout
         out["inference"] = {"value": B / (ms_inf * 1e-3), "unit": "point-clouds/s",
                             "ms_per_batch": ms_inf, "path": "HIP index ops + gg_k_gridconv (down layers) / source-side "
-                                    "conv + max kernels (up layers) + MFMA eval MLPs"}
+                                    "conv + fused attention-max kernel (up layers) + MFMA eval MLPs"}
         net.train()
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.points, kind)

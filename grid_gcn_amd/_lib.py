@@ -21,7 +21,7 @@ EXPORTS = [
     "gridgcn_take_backward_workspace_bytes",
     "gridgcn_edge_lin0_forward", "gridgcn_edge_lin0_backward", "gridgcn_pairmax_fwd_src",
     "gridgcn_edge_lin0_backward_sparse_workspace_bytes", "gridgcn_edge_lin0_backward_sparse",
-    "gridgcn_edge_lin0_dwg",
+    "gridgcn_edge_lin0_dwg", "gridgcn_att_max_eval",
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
@@ -144,6 +144,8 @@ def load():
     lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_edge_lin0_backward_sparse.restype = ci
     lib.gridgcn_edge_lin0_backward_sparse.argtypes = [vp] * 14 + [ci] * 5 + [vp] * 5 + [cs, vp]
+    lib.gridgcn_att_max_eval.restype = ci
+    lib.gridgcn_att_max_eval.argtypes = [vp] * 14 + [ci] * 5 + [vp, ci, vp]
     lib.gridgcn_edge_lin0_dwg.restype = ci
     lib.gridgcn_edge_lin0_dwg.argtypes = [vp] * 9 + [ci, vp, ci, vp]
     lib.gridgcn_softmax_ce_fwd.restype = ci

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libgridgcn_hip.so")
 SOURCES = ["gridgcn_index.hip", "gridgcn_query.hip", "gridgcn_query_knn.hip", "gridgcn_knn.hip",
-           "gridgcn_conv.hip", "gridgcn_train.hip", "gridgcn_direct.hip", "gridgcn_attbwd.hip", "gridgcn_pairmax.hip", "gridgcn_head.hip", "gridgcn_scatter.hip", "gridgcn_edgelin.hip", "gridgcn_ballgrid.hip", "gridgcn_capi.hip"]
+           "gridgcn_conv.hip", "gridgcn_train.hip", "gridgcn_direct.hip", "gridgcn_attbwd.hip", "gridgcn_atteval.hip", "gridgcn_pairmax.hip", "gridgcn_head.hip", "gridgcn_scatter.hip", "gridgcn_edgelin.hip", "gridgcn_ballgrid.hip", "gridgcn_capi.hip"]
 # -ffp-contract=off: the parity contract is "fp32, IEEE, no FMA contraction" (SURVEY App. A);
 # the MFMA/FMA use inside the GridConv kernels is explicit (intrinsics), never compiler-made.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -7,6 +7,7 @@
 #include "gridgcn_train.h"
 #include "gridgcn_csr.h"
 #include "gridgcn_edgelin.h"
+#include "gridgcn_atteval.h"
 
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
@@ -581,6 +582,26 @@ int gridgcn_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, c
         return GRIDGCN_EINVAL;
     return gg_edge_lin0_dwg(wgs, gg, T, wgb, scale, mean, rstd, m1, m2, C0, dW, ld,
                             (hipStream_t)stream);
+}
+
+int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shift1, const float *W2,
+                         const float *b2, const float *scale_a, const float *shift_a,
+                         const float *Ysrc, const int32_t *nebidx, const float *att16,
+                         const float *Wg, const float *b, const float *scale_p,
+                         const float *shift_p, int B, int Nsrc, int O, int P, int C, float *agg,
+                         int ld_agg, void *stream)
+{
+    if (!Z1 || !scale1 || !shift1 || !W2 || !b2 || !scale_a || !shift_a || !Ysrc || !nebidx ||
+        !att16 || !b || !scale_p || !shift_p || !agg || B < 1 || Nsrc < 1 || O < 1 || P < 1 ||
+        ld_agg < C)
+        return GRIDGCN_EINVAL;
+    GGAttEval p;
+    p.Z1 = Z1; p.s1 = scale1; p.h1 = shift1; p.W2 = W2; p.b2 = b2; p.sa = scale_a; p.ha = shift_a;
+    p.Ysrc = Ysrc; p.nebidx = nebidx; p.att16 = att16; p.Wg = Wg; p.bp = b; p.sp = scale_p;
+    p.hp = shift_p; p.out = agg; p.E = (long long)B * O * P; p.P = P; p.O = O; p.Nsrc = Nsrc;
+    p.B = B; p.ldo = ld_agg;
+    const int rc = gg_att_max_eval(p, C, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
 int gridgcn_ball_knn_grid_workspace_bytes(int B, int m, size_t *bytes)

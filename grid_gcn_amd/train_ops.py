@@ -306,6 +306,7 @@ class _ZeroArena:
 ZERO_ARENA = os.environ.get("GG_NO_ZERO_ARENA", "0") != "1"
 # evaluation of single-layer-pt edge blocks (the up layers) through the source-side kernels
 SRC_EVAL = os.environ.get("GG_NO_SRC_EVAL", "0") != "1"
+ATT_MAX_EVAL = os.environ.get("GG_NO_ATT_MAX_EVAL", "0") != "1"
 _ARENA = _ZeroArena()
 _zeros = _ARENA.zeros
 _ZEROS = {}
@@ -474,11 +475,26 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim):
             _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P, C0,
             _ptr(wgb) if geo else None, _ptr(wgb[3]), None, _ptr(att16), None, st)
         _lib.check(rc, "gridgcn_edge_lin0_forward")
-        Za, sc_a, sh_a = _chain_eval_raw(lib, att16, att_layers)
         sc_p = (bn0.weight * torch.rsqrt(bn0.running_var + bn0.eps)).contiguous()
         sh_p = (bn0.bias - bn0.running_mean * sc_p).contiguous()
-        ncent, C = B * O, Za.shape[1]
+        a2 = att_layers[-1]
+        C = a2.lin.out_features
+        ncent = B * O
         agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+        if ATT_MAX_EVAL and a2.lin.in_features == 32 and C in (64, 128) and P <= 128:
+            # second attention conv + activations + product + max in one kernel: the [E, C]
+            # attention tensor is never written (csrc/gridgcn_atteval.hip)
+            Z1, s1, h1 = _chain_eval_raw(lib, att16, att_layers[:-1])
+            bn2 = a2.bn
+            sc_a = (bn2.weight * torch.rsqrt(bn2.running_var + bn2.eps)).contiguous()
+            sh_a = (bn2.bias - bn2.running_mean * sc_a).contiguous()
+            rc = lib.gridgcn_att_max_eval(
+                _ptr(Z1), _ptr(s1), _ptr(h1), _ptr(a2.lin.weight), _ptr(a2.lin.bias), _ptr(sc_a),
+                _ptr(sh_a), _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None,
+                _ptr(wgb[3]), _ptr(sc_p), _ptr(sh_p), B, Nsrc, O, P, C, _ptr(agg), C, st)
+            _lib.check(rc, "gridgcn_att_max_eval")
+            return agg.view(B, O, C)
+        Za, sc_a, sh_a = _chain_eval_raw(lib, att16, att_layers)
         amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
         rc = lib.gridgcn_pairmax_fwd_src(
             _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None, _ptr(wgb[3]), B,

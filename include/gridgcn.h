@@ -197,6 +197,18 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             const float *scale_a, const float *shift_a, long long ncent, int P,
                             int C, float *agg, int ld_agg, int32_t *amax, float *zsel,
                             void *stream);
+/* Evaluation-mode tail of the edge block in one kernel (csrc/gridgcn_atteval.hip): with every
+ * BatchNorm a fixed affine map (scale = gamma*rsqrt(running_var+eps), shift = beta - mean*scale),
+ *   agg[o,c] = max_p relu((Ysrc[src(e)][c] + Wg[:,c].geo(e) + b[c]) * scale_p[c] + shift_p[c])
+ *                  * relu((W2[c,:] . relu(Z1[e,:]*scale1 + shift1) + b2[c]) * scale_a[c] + shift_a[c])
+ * Z1[E,32] = raw output of the first attention conv, W2[C][32] (torch layout) / b2 the second one;
+ * C = 64 or 128, P <= 8, agg[B*O][ld_agg].  The [E, C] attention tensor is never materialised. */
+int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shift1, const float *W2,
+                         const float *b2, const float *scale_a, const float *shift_a,
+                         const float *Ysrc, const int32_t *nebidx, const float *att16,
+                         const float *Wg, const float *b, const float *scale_p,
+                         const float *shift_p, int B, int Nsrc, int O, int P, int C, float *agg,
+                         int ld_agg, void *stream);
 int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
                                const float *dY, const int32_t *amax,
                                const float *gval, const float *scale, const float *shift,
