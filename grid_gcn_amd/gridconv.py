@@ -215,6 +215,20 @@ class SubGUpdate(nn.Module):
         att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
         if train_ops.edge_block_src_eval_supported(pt_layers, att_layers, src, self.has_feats):
             # up layers (one point conv): that conv on the source points, gathered by the max kernel
+            if center_ori_feats is not None and self.center_mlp is not None and \
+                    train_ops.supported(list(self.center_mlp), src) and \
+                    all(l.lin.in_features <= 1024 for l in self.center_mlp):
+                # update_func's concat: centre MLP and aggregate write the two halves of one buffer
+                B, O = nebidx.shape[0], nebidx.shape[1]
+                ccf = self.center_mlp[-1].lin.out_features
+                C = pt_layers[-1].lin.out_features
+                buf = torch.empty((B * O, ccf + C), dtype=torch.float32, device=src.device)
+                train_ops.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
+                                              att_layers, self.localfdim,
+                                              out=train_ops.alias_columns(buf, ccf, C))
+                train_ops.mlp_bn_relu_eval(center_ori_feats, list(self.center_mlp),
+                                           out=train_ops.alias_columns(buf, 0, ccf))
+                return self.finish(buf.view(B, O, ccf + C), center_masks, None)
             agg = train_ops.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
                                                 att_layers, self.localfdim)
             return self.finish(agg, center_masks, center_ori_feats)

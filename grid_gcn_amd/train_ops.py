@@ -449,7 +449,7 @@ def edge_block_src_eval_supported(pt_layers, att_layers, src, has_feats):
 
 
 @torch.no_grad()
-def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim):
+def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim, out=None):
     """GridConv edge block in evaluation mode, [B,O,C]: first (only) point conv on the SOURCE points
     (Ysrc = features W_f^T, gathered by the max-pool kernel), attention MLP on the forward MFMA
     kernel with running statistics, product + max over P in gg_k_pairmax_fwd4_src.  For the up
@@ -480,7 +480,9 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim):
         a2 = att_layers[-1]
         C = a2.lin.out_features
         ncent = B * O
-        agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
+        # out: [ncent, C] destination with its own row stride (one half of update_func's concat)
+        agg = out if out is not None else torch.empty((ncent, C), dtype=torch.float32, device=dev)
+        ldo = agg.stride(0)
         if ATT_MAX_EVAL and a2.lin.in_features == 32 and C in (64, 128) and P <= 128:
             # second attention conv + activations + product + max in one kernel: the [E, C]
             # attention tensor is never written (csrc/gridgcn_atteval.hip)
@@ -491,22 +493,23 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim):
             rc = lib.gridgcn_att_max_eval(
                 _ptr(Z1), _ptr(s1), _ptr(h1), _ptr(a2.lin.weight), _ptr(a2.lin.bias), _ptr(sc_a),
                 _ptr(sh_a), _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None,
-                _ptr(wgb[3]), _ptr(sc_p), _ptr(sh_p), B, Nsrc, O, P, C, _ptr(agg), C, st)
+                _ptr(wgb[3]), _ptr(sc_p), _ptr(sh_p), B, Nsrc, O, P, C, _ptr(agg), ldo, st)
             _lib.check(rc, "gridgcn_att_max_eval")
-            return agg.view(B, O, C)
+            return agg if out is not None else agg.view(B, O, C)
         Za, sc_a, sh_a = _chain_eval_raw(lib, att16, att_layers)
         amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
         rc = lib.gridgcn_pairmax_fwd_src(
             _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None, _ptr(wgb[3]), B,
             Nsrc, O, _ptr(Za), _ptr(sc_p), _ptr(sh_p), _ptr(sc_a), _ptr(sh_a), ncent, P, C,
-            _ptr(agg), C, _ptr(amax), None, st)
+            _ptr(agg), ldo, _ptr(amax), None, st)
         _lib.check(rc, "gridgcn_pairmax_fwd_src")
-    return agg.view(B, O, C)
+    return agg if out is not None else agg.view(B, O, C)
 
 
 @torch.no_grad()
-def mlp_bn_relu_eval(x, layers):
-    """Inference through the same forward kernel: layer l computes Z_l = act(Z_{l-1}) W_l^T + b_l
+def mlp_bn_relu_eval(x, layers, out=None):
+    """(out: optional [E, cout] destination with its own row stride; returned as is.)
+    Inference through the same forward kernel: layer l computes Z_l = act(Z_{l-1}) W_l^T + b_l
     with act = the previous layer's BatchNorm (running statistics) + ReLU applied while the rows are
     loaded; one BatchNorm+ReLU pass at the end.  x [..., cin] float32 on the GPU."""
     lib = _lib.load()
@@ -517,10 +520,12 @@ def mlp_bn_relu_eval(x, layers):
         prev = torch.nn.functional.pad(prev, (0, 8 - prev.shape[1] % 8))
     Z, sc, sh = _chain_eval_raw(lib, prev, layers)
     with torch.cuda.device(dev):
-        Y = torch.empty_like(Z)
+        Y = out if out is not None else torch.empty_like(Z)
         _lib.check(lib.gridgcn_bn_relu_apply(_ptr(Z), _ptr(sc), _ptr(sh), _ptr(Y), E,
-                                             Y.shape[1], Y.shape[1], _stream(Z)),
+                                             Y.shape[1], Y.stride(0), _stream(Z)),
                    "gridgcn_bn_relu_apply")
+    if out is not None:
+        return Y
     return Y.reshape(shp[:-1] + (Y.shape[1],))
 
 
