@@ -268,6 +268,14 @@ class SubGUpdate(nn.Module):
                         # ... and the Dropout + class-score Linear behind them (train_ops._HeadTrain)
                         self.tail_done = 2
                         return train_ops.head_train(agg, layers, p, lin)
+                if self.tail_head is not None and self.mfma_train and agg.is_cuda and \
+                        not self.training and not torch.is_grad_enabled():
+                    from . import train_ops
+                    p, lin = self.tail_head
+                    if train_ops.head_supported(agg, layers, lin) and \
+                            all(l.lin.in_features <= 1024 for l in layers):
+                        self.tail_done = 2              # evaluation: dropout is the identity
+                        return train_ops.head_eval(agg, layers, lin)
             agg = run_mlp(layers, agg, self.mfma_train)
         if center_masks is not None:
             agg = agg * center_masks[..., None]                            # :284-285

@@ -529,6 +529,35 @@ def mlp_bn_relu_eval(x, layers, out=None):
     return Y.reshape(shp[:-1] + (Y.shape[1],))
 
 
+@torch.no_grad()
+def head_eval(x, layers, lin):
+    """Evaluation of conv+BN+ReLU `layers` followed by the Linear `lin` (dropout is the identity):
+    the last BatchNorm+ReLU is applied while `lin`'s kernel loads its rows, so no activation pass and
+    no stock GEMM remain.  x [..., cin] -> [..., lin.out_features] (a view of class-padded rows)."""
+    lib = _lib.load()
+    shp = x.shape
+    prev = x.reshape(-1, shp[-1]).contiguous()
+    if prev.shape[1] % 8:
+        prev = torch.nn.functional.pad(prev, (0, 8 - prev.shape[1] % 8))
+    Z, sc, sh = _chain_eval_raw(lib, prev, layers)
+    E, cin = Z.shape
+    dev = Z.device
+    C = lin.out_features
+    Cp = (C + 7) & ~7
+    K, ldw, nwp, nwb = packed_sizes(C, cin)
+    with torch.cuda.device(dev):
+        st = _stream(Z)
+        pk = torch.empty(ldw + cin * ldw, dtype=torch.float32, device=dev)
+        Bp, Wq = pk[:ldw], pk[ldw:]
+        _lib.check(lib.gridgcn_pack_linear(_ptr(lin.weight), _ptr(lin.bias), C, cin, 0, cin, 0, None,
+                                           _ptr(Bp), None, None, _ptr(Wq), None, st), "pack")
+        Y = torch.empty((E, Cp), dtype=torch.float32, device=dev)
+        _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(Z), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, Cp,
+                                                 _ptr(sc), _ptr(sh), _ptr(Y), None, st),
+                   "gridgcn_linear_fwd_direct")
+    return Y[:, :C].reshape(shp[:-1] + (C,))
+
+
 def mlp_bn_relu_train(x, layers, out=None):
     """x [..., cin] -> [..., cout_last] through `layers` (gridconv.ConvBNReLU modules, training
     mode).  Callers check supported() first.  out: optional [E, cout_last] destination

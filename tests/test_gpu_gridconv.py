@@ -210,8 +210,13 @@ def test_full_model_eval_fused_vs_torch():
     with torch.no_grad():
         net.fused = True
         a = net(x, n)
+        assert net.up[-1].tail_done == 2             # head through the hand-written kernels too
+        # reference: stock PyTorch modules everywhere (index ops shared)
         net.fused = False
+        for l in list(net.down) + list(net.up):
+            l.mfma_train = False
         b = net(x, n)
+        assert net.up[-1].tail_done != 2
     scale = max(1.0, float(b.abs().max()))
     assert float((a - b).abs().max()) <= 2e-4 * scale   # 12 stacked layers of fp32 round-off
 
