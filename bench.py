@@ -225,7 +225,10 @@ def main():
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
             # evaluation runs this layer through the source-side kernels instead (first conv once
             # per source point, gathered by the max kernel): same result, fewer executed flops
-            "ms_source_side_path": ms_src}
+            "ms_source_side_path": ms_src,
+            "note": "kernel-level figure for gg_k_gridconv on this layer's shape; the evaluation "
+                    "forward itself runs up layers through ms_source_side_path (source-side conv + "
+                    "gridgcn_att_max_eval) and uses gg_k_gridconv for the down layers"}
         # ---- dominant kernels of the TIMED training step.  The point conv of this layer runs on
         #      the source points (gridgcn_edgelin.hip), so the largest per-edge GEMMs left are those
         #      of the attention MLP: backward of its C/4 -> C conv = gg_k_att_bwd_fused (dZ formed
