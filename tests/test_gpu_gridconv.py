@@ -318,3 +318,35 @@ def test_full_size_training_step_matches_stock_pytorch_ops():
     cos = float((a[1] * b[1]).sum() / (a[1].norm() * b[1].norm()))
     assert cos > 0.9999, cos
     assert float((a[1] - b[1]).norm() / b[1].norm()) < 1e-2
+
+
+@pytest.mark.parametrize("cin,C,O,P", [(128, 128, 700, 5), (64, 64, 90, 7), (32, 128, 41, 33), (256, 128, 300, 1)])
+def test_att_max_eval_kernel_equals_two_kernel_path(cin, C, O, P):
+    """evaluation edge block: the one-kernel attention conv + product + max (gridgcn_att_max_eval,
+    transposed MFMA product, a lane owns a centre) against the path that materialises the [E, C]
+    attention tensor (forward MFMA kernel + gg_k_pairmax_fwd4_src), and both against the stock
+    modules."""
+    from grid_gcn_amd import train_ops
+    torch.manual_seed(cin + C + P)
+    gen = torch.Generator().manual_seed(O + P)
+    B, Nsrc = 3, 150
+    layer = SubGUpdate(cin, [C], localfdim=3).to(DEV)
+    randomise_bn(layer.cpu(), gen)
+    layer = layer.to(DEV).eval()
+    src = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV)
+    nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    att_layers, pt = [layer.att1[0], layer.att2[0]], layer.pt_mlp[0]
+    assert train_ops.edge_block_src_eval_supported([pt], att_layers, src, True)
+    outs = []
+    for flag in (True, False):
+        train_ops.ATT_MAX_EVAL = flag
+        try:
+            outs.append(train_ops.edge_block_src_eval(src, nebidx, cent, pt, att_layers, 3))
+        finally:
+            train_ops.ATT_MAX_EVAL = True
+    with torch.no_grad():
+        ref = layer(cent[..., 0:3], ops.batch_take_g(src, nebidx), None)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
+    assert float((outs[0] - ref).abs().max()) <= 5e-5 * scale
