@@ -6,11 +6,12 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgridgcn_hip.so")
+# GG_HIP_LIB: profiling variant of the same library (lib/libgridgcn_hip_prof.so, tools/prof_phases.py)
+LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
 EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version",
-    "gridgcn_gridify_workspace_bytes", "gridgcn_gridify",
+    "gridgcn_gridify_workspace_bytes", "gridgcn_gridify", "gridgcn_gridify_timed",
     "gridgcn_gridify_knn_workspace_bytes", "gridgcn_gridify_knn",
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
@@ -77,6 +78,9 @@ def load():
         f = getattr(lib, name)
         f.restype = ci
         f.argtypes = [vp, vp, ci, ci, pp, vp, vp, vp, vp, vp, vp, cs, vp]
+    lib.gridgcn_gridify_timed.restype = ci
+    lib.gridgcn_gridify_timed.argtypes = [vp, vp, ci, ci, pp, vp, vp, vp, vp, vp, vp, cs, vp, ci,
+                                          ctypes.POINTER(ctypes.c_float)]
     lib.gridgcn_gridify_up.restype = ci
     lib.gridgcn_gridify_up.argtypes = [vp, vp, vp, vp, ci, ci, pp, vp, vp, vp, cs, vp]
     lib.gridgcn_ball_knn.restype = ci

@@ -151,6 +151,34 @@ int gridgcn_gridify(const float *data, const int32_t *np, int B, int N,
                           ws_bytes, stream);
 }
 
+int gridgcn_gridify_timed(const float *data, const int32_t *np, int B, int N,
+                          const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk, float *cent,
+                          float *centmsk, int32_t *centnum, void *ws, size_t ws_bytes, void *stream,
+                          int iters, float *ms_per_call)
+{
+    if (iters < 1 || !ms_per_call) return GRIDGCN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return GRIDGCN_ELAUNCH;
+    int rc = GRIDGCN_OK;
+    for (int w = 0; w < 3 && !rc; w++)
+        rc = gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
+                            ws_bytes, stream);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < iters && !rc; i++)
+        rc = gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
+                            ws_bytes, stream);
+    hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = rc ? rc : GRIDGCN_ELAUNCH;
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_per_call = ms / (float)iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
 int gridgcn_gridify_knn_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes)
 {
     return gridgcn_gridify_workspace_bytes(B, N, p, bytes);

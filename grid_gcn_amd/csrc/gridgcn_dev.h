@@ -59,6 +59,26 @@ __device__ __forceinline__ int gg_voxel_of(float x, float y, float z, const GGGr
     return c2 * gp.gxy + c1 * gp.g[0] + c0;
 }
 
+// Phase stamps for tools/prof_phases.py: only in the -DGG_PROF build (libgridgcn_hip_prof.so).
+// gg_prof_buf[(kernel*4096 + workgroup%4096)*16 + k] = 100 MHz wall clock at stamp k.
+#ifdef GG_PROF
+static __device__ unsigned long long *gg_prof_buf = nullptr;
+#define GG_STAMP(kid, wg, k)                                                                   \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && gg_prof_buf)                                                   \
+            gg_prof_buf[((size_t)(kid) * 4096 + ((unsigned)(wg) & 4095u)) * 16 + (k)] =        \
+                wall_clock64();                                                                \
+    } while (0)
+#define GG_PROF_SETTER(name)                                                                   \
+    extern "C" int name(void *buf)                                                             \
+    {                                                                                          \
+        return hipMemcpyToSymbol(HIP_SYMBOL(gg_prof_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : 3; \
+    }
+#else
+#define GG_STAMP(kid, wg, k) do {} while (0)
+#define GG_PROF_SETTER(name)
+#endif
+
 __device__ __forceinline__ int gg_lane() { return (int)(threadIdx.x & 63); }
 
 // inclusive prefix sum across the 64 lanes of a wave

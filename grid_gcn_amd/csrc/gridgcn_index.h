@@ -3,25 +3,52 @@
 #include "gridgcn_dev.h"
 #include <stddef.h>
 
-// Byte offsets into the caller's workspace (all 256-byte aligned).
+#define GG_CHUNK_MAX 4096  // points per chunk of the first split: 1024, 2048 or 4096
+                           // (12-bit local point number)
+#define GG_MAX_SLABS 1024  // slabs per cloud (per-wave counters of the first split live in LDS)
+#define GG_MAX_SB 12       // log2 of the largest slab (voxels): per-wave counters of the second split
+#define GG_XRB 4           // log2 of the voxel run that stays together in a slab (16 voxels = 128 B
+                           // of the voxel table)
+#define GG_MAX_CHUNKS 1024 // chunks per cloud (run table of a slab lives in LDS)
+
+// Byte offsets into the caller's workspace (all 256-byte aligned).  What the query kernels read
+// (cnt, off, sorted, bkt, slotfirst1, exact) means the same in both build generations.
 struct GGIndexWs {
-    size_t o_cnt;         // int [B*G]   voxel population            (coor_counter, gridify.cu:358)
-    size_t o_slotfirst1;  // int [B*O]   first point id + 1 of the voxel in centre slot o
-    size_t o_blkcnt;      // int [B*nblk] voxel leaders per 1024-point block
-    size_t o_wsum;        // u64 [B*nblk] per-block sum |w| of in-grid points, bit 63 = non-integer seen
-    size_t o_exact;       // int [B]     1: weights are small integers -> order-free total_weight
-    size_t o_cursor;      // int [B]     bump allocator of segment space inside [b*N, (b+1)*N)
-    size_t zero_bytes;    // the region [0, zero_bytes) is memset to 0 every call
-    size_t o_off;         // int [B*G]   start of the voxel's segment in seg/sorted/bkt
-    size_t o_vox;         // int [B*N]   voxel id of the point or -1 (dropped)
-    size_t o_arr;         // int [B*N]   arrival order inside the voxel
-    size_t o_seg;         // int [B*N]   point ids grouped by voxel, arrival order
+    // ---- read by the query kernels ----
+    size_t o_vtab;        // int2 [B*G]  per voxel: .x = start of its segment in sorted/bkt (absolute),
+                          //             .y = population (coor_counter, gridify.cu:358)
     size_t o_sorted;      // int [B*N]   point ids grouped by voxel, ascending
     size_t o_bkt;         // int [B*N]   first P entries of a segment with population > P:
                           //             the S0 reservoir bucket (coor_to_pntidx, gridify.cu:357)
-    size_t o_lead;        // u8  [B*N]   1 if the point is the first (smallest id) of its voxel
+    size_t o_slotfirst1;  // int [B*O]   first point id + 1 of the voxel in centre slot o
+    size_t o_exact;       // int [B]     bit 0: weights are small integers -> order-free
+                          //             total_weight; bit 1: every in-grid weight is exactly 1.0
+    // ---- build scratch, two-level split (gridgcn_index.hip) ----
+    size_t o_part;        // u32 [B*N]   chunk-local split by slab: (voxel number inside the slab) << 12
+                          //             | local point number
+    size_t o_ctab;        // int [B*nchunk*(nslab+1)] chunk-local exclusive slab offsets
+    size_t o_lead;        // int [B*N]   first point id of every occupied voxel: slab s keeps its
+                          //             leaders at [base_s, base_s + occupied_s), grouped by the
+                          //             point range (id >> RSB) they fall in
+    size_t o_ltab;        // int [B*nslab*(R+1)] start of range r's group inside o_lead (absolute
+                          //             within the cloud); entry R = end of the slab's leaders
+    size_t o_cursor;      // legacy: int [B] bump allocator of segment space
+    size_t o_wsum;        // u64 [B*nblk] per-chunk sum |w| of in-grid points, bit 63 = non-integer
+                          //             seen, bit 62 = weight != 1.0 seen
+    // ---- build scratch, legacy generation (gridgcn_index_legacy.hip) ----
+    size_t o_cnt, o_off;  // int [B*G] each (packed into o_vtab by a last kernel)
+    size_t o_blkcnt, o_vox, o_arr, o_seg, o_leadflag;
+    size_t zero_bytes;    // legacy: the region [0, zero_bytes) is memset to 0 every call
     size_t total;
-    int nblk, nslab, S;
+    int nblk;             // legacy: 1024-point blocks; split: chunks per cloud
+    int nslab, S;         // voxel slabs per cloud, voxels per slab
+    int SB;               // split: log2(S)
+    int KB, MB;           // split: log2(nslab), bits of the 16-voxel run number
+    unsigned HA, HAinv;   // split: odd multiplier of the run-number hash and its inverse mod 2^MB
+    int NW2;              // split: waves per workgroup of the slab kernel
+    int CH;               // split: points per chunk
+    int R, RSB;           // split: point ranges per cloud in the centre kernel, log2(points per range)
+    int legacy;           // 1: built by the legacy generation
 };
 
 size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres, GGIndexWs *ws);
@@ -29,3 +56,10 @@ int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid 
                    bool with_centres, int *centnum, char *wsbase, const GGIndexWs &w,
                    hipStream_t st);
 int gg_index_init();
+
+size_t gg_index_legacy_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres,
+                                       GGIndexWs *ws);
+int gg_index_legacy_build(const float *data, const int *np, int B, int N, const GGGrid &gp,
+                          bool with_centres, int *centnum, char *wsbase, const GGIndexWs &w,
+                          hipStream_t st);
+int gg_index_legacy_init();

@@ -2,356 +2,788 @@
 //
 // Replaces gridify_kernel_build_index (gridifyop/gridify.cu:102-191, gridifyknn.cu:115-204,
 // gridify_up.cu:102-170).  The reference appends points to a dense [B*G, P] bucket table with
-// atomics in arrival order (non-deterministic, 262-524 MB of scratch per call).  Here the result
-// of the canonical schedule S0 (threads in ascending index) is computed order-independently:
+// atomics in arrival order (non-deterministic, 262-524 MB of scratch per call).  Under the
+// canonical schedule S0 (threads in ascending index) a voxel's bucket is its points in ascending
+// id with a "last writer wins" reservoir past P, and the centre slots are the occupied voxels in
+// order of first appearance with the same reservoir past O.  So the whole build
+// is a STABLE sort of the point ids by voxel, done here as a two-level split with no global
+// atomics on the data path and three launches:
 //
-//   K1 voxelize : voxel id per point (coalesced float4 stream, no atomics)
-//   K2 slabs    : LDS-staged voxel slabs: per-voxel population + arrival slot via LDS atomics,
-//                 LDS scan + one bump allocation per slab -> compact segment offsets
-//   K3 scatter  : point ids into their voxel's segment in arrival order (order irrelevant)
-//   K4 rank     : rank n of a point inside its voxel = #{ids in the segment smaller than mine};
-//                 sorted[off+n] = id; reservoir of S0 resolved as "largest n wins" == atomicMax
-//                 on the point id (ids ascend with n); voxel leaders (n == 0) flagged
-//   K5 centres  : t = number of leaders before mine (block prefix + in-block scan) = the order of
-//                 first appearance of the voxel; centre reservoir again "largest t wins"
+//   K1 gg_k_chunk_split  (chunk of 1024-4096 points, cloud): voxel of each point (coalesced
+//      float4 stream, read once), stable split of the chunk by SLAB (a scattered sample of the
+//      voxel grid, see GGSplit) in LDS; the chunk's items leave as one coalesced run per slab, 4
+//      bytes per point: (voxel number inside the slab) << 12 | local point number; the
+//      chunk-local exclusive slab offsets go to a small table.  Also zeroes the centre-slot array
+//      and reduces the weight statistics.
+//   K2 gg_k_slab_build   (slab, cloud): gathers the slab's runs of every chunk (they are in
+//      ascending point id by construction), stable split by voxel -> the sorted segment of every
+//      voxel, the (start, population) table of the slab's voxels (dense, 128-byte lines, no
+//      memset), the stage-1 bucket reservoir of over-full voxels (gridify.cu:145-154) and the first
+//      point of every occupied voxel ("leader"), grouped by point range for K3.
+//   K3 gg_k_centre_slots (point range, cloud): rank of a leader among the cloud's leaders = the
+//      voxel's order of first appearance; RVS reservoir over the centre slots (gridify.cu:165-189).
 //
-// Every atomic used is commutative/idempotent on the final value (arrival slots and segment
-// placement only permute scratch), so the output is bit-identical from run to run and equal to
-// schedule S0 of the reference.
+// The stable split of 64 items inside a wave finds, for every lane, the set of lanes with the same
+// key by one ballot per key bit; waves own contiguous ranges of the item list and keep private
+// counters, so the result does not depend on any arrival order: the output is bit-identical from
+// run to run and equal to schedule S0 of the reference.
 #include "gridgcn_index.h"
+#include <stdlib.h>
+
+#define GG_NT1 1024
+#define GG_NW1 16
+#define GG_GS 8       // lanes that copy one run together
+#define GG_NT3 1024
+#define GG_MAX_R 64   // point ranges per cloud in K3
+
+// Slab assignment.  Voxels are taken in runs of 16 consecutive ids (128 bytes of the voxel table,
+// x-neighbours mostly together); the run number u < 2^MB is scrambled by an odd multiplier (a
+// bijection mod 2^MB) and the HIGH KB bits of the product pick the slab, so that every slab is a
+// scattered sample of the grid and holds about the same number of points whatever the geometry
+// (contiguous slabs of a plane-like cloud differ 4x in population; the tail workgroups of K2 then
+// run 3x longer than the median).
+struct GGSplit {
+    unsigned HA, HAinv, mmask;
+    int LB;       // MB - KB: bits of the run number inside a slab
+    int SB;       // LB + 4: log2 of voxels per slab
+    int KB;       // log2(nslab)
+    int nslab, nchunk, CH, R, RSB;
+};
+
+__device__ __forceinline__ void gg_slab_of(int v, const GGSplit &sp, int &slab, int &vl)
+{
+    const unsigned h = (((unsigned)v >> GG_XRB) * sp.HA) & sp.mmask;
+    slab = (int)(h >> sp.LB);
+    vl = (int)(((h & ((1u << sp.LB) - 1u)) << GG_XRB) | ((unsigned)v & ((1u << GG_XRB) - 1u)));
+}
+
+// voxel id of voxel number vl of slab s (may be >= G: no such voxel)
+__device__ __forceinline__ unsigned gg_voxel_of_slab(int s, int vl, const GGSplit &sp)
+{
+    const unsigned h = ((unsigned)s << sp.LB) | ((unsigned)vl >> GG_XRB);
+    const unsigned u = (h * sp.HAinv) & sp.mmask;
+    return (u << GG_XRB) | ((unsigned)vl & ((1u << GG_XRB) - 1u));
+}
+
+// exclusive prefix sum over the threads of a block of NW waves; *total = block sum.
+// s_w: NW ints of LDS.  Two barriers; every thread of the block must call it.
+template <int NW>
+__device__ __forceinline__ int gg_block_excl_scan(int v, int *s_w, int *total)
+{
+    const int lane = gg_lane(), wave = (int)(threadIdx.x >> 6);
+    const int incl = gg_wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int t = s_w[w];
+        if (w < wave) wbase += t;
+        tot += t;
+    }
+    *total = tot;
+    return wbase + incl - v;
+}
+
+// block sum of two ints (NW waves); s_w: 2*NW ints of LDS.  Two barriers.
+template <int NW>
+__device__ __forceinline__ void gg_block_sum2(int &x, int &y, int *s_w)
+{
+    const int lane = gg_lane(), wave = (int)(threadIdx.x >> 6);
+    const int sx = gg_wave_sum(x), sy = gg_wave_sum(y);
+    __syncthreads();
+    if (lane == 0) { s_w[wave] = sx; s_w[NW + wave] = sy; }
+    __syncthreads();
+    int tx = 0, ty = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { tx += s_w[w]; ty += s_w[NW + w]; }
+    x = tx;
+    y = ty;
+}
+
+// lanes of the wave whose key equals mine (valid lanes only); one ballot per key bit.
+__device__ __forceinline__ unsigned long long gg_wave_peers(bool valid, unsigned key, int nbits)
+{
+    unsigned long long peers = __ballot(valid);
+    for (int k = 0; k < nbits; k++) {
+        const bool bit = (key >> k) & 1u;
+        const unsigned long long bal = __ballot(valid && bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
 
 // ------------------------------------------------------------------------------------------
-// K1: one thread per point, coalesced float4 loads, NO atomics.  grid (ceil(N/1024), B).
-// Also reduces the per-block weight statistic that selects the exact-integer total_weight path.
-__global__ __launch_bounds__(1024) void gg_k_voxelize(const float4 *__restrict__ data,
-                                                      const int *__restrict__ np, int N, GGGrid gp,
-                                                      int *__restrict__ vox,
-                                                      unsigned long long *__restrict__ wsum_blk)
+// K1.  grid (nchunk, B), block 1024, chunk = 1024*IPT points, dynamic LDS = (16*nslab + chunk)
+// ints.  Wave w owns the points [w*64*IPT, (w+1)*64*IPT) of the chunk, 64 at a time: order of
+// (wave, iteration, lane) = ascending point id, which the split preserves inside every slab.
+template <int IPT>
+__global__ __launch_bounds__(GG_NT1) void gg_k_chunk_split(
+    const float4 *__restrict__ data, const int *__restrict__ np, int N, GGGrid gp, GGSplit sp,
+    unsigned *__restrict__ part, int *__restrict__ ctab, unsigned long long *__restrict__ wsum_blk,
+    int *__restrict__ zero_base, int zero_words)
 {
-    __shared__ long long sw[16];
-    __shared__ int sbad[16];
-    const int b = blockIdx.y;
-    const int ip = blockIdx.x * 1024 + threadIdx.x;
-    const int nvalid = np[b];
-    int v = -1;
+    constexpr int CH = GG_NT1 * IPT;
+    extern __shared__ __attribute__((aligned(16))) int lds1[];
+    const int nslab = sp.nslab;
+    int *wc = lds1;                                         // [16][nslab]
+    unsigned *stage = (unsigned *)(lds1 + GG_NW1 * nslab);  // [CH]
+    __shared__ int s_w[GG_NW1];
+    __shared__ long long s_sum[GG_NW1];
+    __shared__ int s_flag[GG_NW1];
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wgid = b * nchunk + chunk;
+    GG_STAMP(0, wgid, 0);
+
+    // the point loads do not wait for anything (the valid-count mask is applied afterwards)
+    float4 p[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int ip = chunk * CH + wave * (64 * IPT) + j * 64 + lane;
+        p[j] = ip < N ? data[(size_t)b * N + ip] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int nvalid = np[b];
+    nvalid = nvalid < N ? nvalid : N;
+    for (int j = tid; j < GG_NW1 * nslab; j += GG_NT1) wc[j] = 0;
+    if (zero_words > 0) {  // centre slots, zeroed for K3 (stream order)
+        const int nwg = nchunk * gridDim.y;
+        const int per = (zero_words + nwg - 1) / nwg;
+        const int z0 = wgid * per, z1 = (z0 + per < zero_words) ? z0 + per : zero_words;
+        for (int j = z0 + tid; j < z1; j += GG_NT1) zero_base[j] = 0;
+    }
+    __syncthreads();
+    GG_STAMP(0, wgid, 1);
+
+    int slab[IPT], vl[IPT];
     long long aw = 0;
-    bool bad = false;
-    if (ip < N && ip < nvalid) {
-        float4 p = data[(size_t)b * N + ip];
-        v = gg_voxel_of(p.x, p.y, p.z, gp, nullptr);
-        if (v >= 0) {
-            float w = p.w;
-            bad = !(truncf(w) == w) || !(fabsf(w) < 8388608.0f);
-            aw = bad ? 0 : (long long)fabsf(w);
+    int flags = 0;  // bit 0: non-integer / huge weight, bit 1: weight != 1
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int ip = chunk * CH + wave * (64 * IPT) + j * 64 + lane;
+        slab[j] = -1;
+        vl[j] = 0;
+        if (ip < nvalid) {
+            const int v = gg_voxel_of(p[j].x, p[j].y, p[j].z, gp, nullptr);
+            if (v >= 0) {
+                const float w = p[j].w;
+                const bool bad = !(truncf(w) == w) || !(fabsf(w) < 8388608.0f);
+                flags |= (bad ? 1 : 0) | ((w == 1.0f) ? 0 : 2);
+                aw += bad ? 0 : (long long)fabsf(w);
+                gg_slab_of(v, sp, slab[j], vl[j]);
+                atomicAdd(&wc[wave * nslab + slab[j]], 1);
+            }
         }
     }
-    if (ip < N) vox[(size_t)b * N + ip] = v;
-    long long s = gg_wave_sum_ll(aw);
-    bool anybad = __any(bad);
-    if (gg_lane() == 0) { sw[threadIdx.x >> 6] = s; sbad[threadIdx.x >> 6] = anybad ? 1 : 0; }
+    {   // weight statistics of the chunk (finished by thread 1023 behind the next barrier)
+        const long long ws = gg_wave_sum_ll(aw);
+        int f = flags;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) f |= __shfl_xor(f, d, 64);
+        if (lane == 0) { s_sum[wave] = ws; s_flag[wave] = f; }
+    }
+    GG_STAMP(0, wgid, 2);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == GG_NT1 - 1) {
         long long t = 0;
-        int nb = 0;
+        int ff = 0;
 #pragma unroll
-        for (int w = 0; w < 16; w++) { t += sw[w]; nb |= sbad[w]; }
-        // bit 63 = "some weight is not a small integer"
-        wsum_blk[(size_t)b * gridDim.x + blockIdx.x] =
-            (unsigned long long)t | (nb ? (1ull << 63) : 0ull);
+        for (int w = 0; w < GG_NW1; w++) { t += s_sum[w]; ff |= s_flag[w]; }
+        wsum_blk[(size_t)b * nchunk + chunk] = (unsigned long long)t |
+                                              ((ff & 1) ? (1ull << 63) : 0ull) |
+                                              ((ff & 2) ? (1ull << 62) : 0ull);
     }
+    // per slab: exclusive prefix over the waves (in registers), then over the slabs
+    int c[GG_NW1];
+    int tot = 0;
+    if (tid < nslab) {
+#pragma unroll
+        for (int w = 0; w < GG_NW1; w++) c[w] = wc[w * nslab + tid];
+#pragma unroll
+        for (int w = 0; w < GG_NW1; w++) { const int t = c[w]; c[w] = tot; tot += t; }
+    }
+    int total;
+    const int excl = gg_block_excl_scan<GG_NW1>(tot, s_w, &total);
+    int *row = ctab + ((size_t)b * nchunk + chunk) * (nslab + 1);
+    if (tid < nslab) {
+        row[tid] = excl;
+#pragma unroll
+        for (int w = 0; w < GG_NW1; w++) wc[w * nslab + tid] = c[w] + excl;
+    }
+    if (tid == 0) row[nslab] = total;
+    __syncthreads();
+    GG_STAMP(0, wgid, 3);
+    // stable placement
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const bool valid = slab[j] >= 0;
+        const unsigned key = valid ? (unsigned)slab[j] : 0u;
+        const unsigned long long peers = gg_wave_peers(valid, key, sp.KB);
+        if (valid) {
+            const int rank = __popcll(peers & lt), npeer = __popcll(peers);
+            const int base = wc[wave * nslab + key];
+            const unsigned q = (unsigned)(wave * (64 * IPT) + j * 64 + lane);
+            stage[base + rank] = ((unsigned)vl[j] << 12) | q;
+            if (IPT > 1 && rank == npeer - 1) wc[wave * nslab + key] = base + npeer;
+        }
+    }
+    GG_STAMP(0, wgid, 4);
+    __syncthreads();
+    unsigned *dst = part + (size_t)b * N + (size_t)chunk * CH;
+    for (int t = tid; t < total; t += GG_NT1) dst[t] = stage[t];
+    GG_STAMP(0, wgid, 5);
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: LDS-staged voxel slabs.  grid (nslab, B), block 1024, dynamic LDS = S ints.
-// A workgroup owns the contiguous voxel range [s*S, (s+1)*S) of one cloud.  It streams the
-// cloud's voxel ids (4 B per point, L2 resident) and counts its own voxels with LDS atomics:
-// the returned value is the arrival slot of the point inside its voxel.  (Global returning
-// atomics run memory-side on MI355X at only ~5 G/s -- measured 140 us for 655k points; LDS
-// atomics make this kernel a pure L2 stream.)  Then: LDS exclusive scan of the slab's
-// populations, one bump allocation per slab for its compact segment range, coalesced stores of
-// cnt[] and off[] -- so no dense memset and no global scan pass either.
-__global__ __launch_bounds__(1024) void gg_k_slab_count(const int *__restrict__ vox, int N, int G,
-                                                        int S, int *__restrict__ arr,
-                                                        int *__restrict__ cnt,
-                                                        int *__restrict__ off,
-                                                        int *__restrict__ cursor)
+// K2.  grid (nslab, B), block 64*NW, dynamic LDS:
+//   wc[NW][S] | voff[S+1] | ltmp[S] | roff[nchunk+1] | rsrc[nchunk] | hist[65] | lid[NW][CAPW] |
+//   lvl[NW][CAPW] (u16)
+// The slab's item list = its runs in ascending chunk order (ascending point id).  Wave w owns the
+// runs of the chunks [nchunk*w/NW, nchunk*(w+1)/NW) and streams that part of the list through its
+// private LDS tile (CAPW items at a time; one tile in the common case, then the second pass
+// reuses it).  Runs are copied by groups of 8 lanes, two runs in flight per group.
+struct GGSlabArgs {
+    const unsigned *part;
+    const int *ctab;
+    int2 *vtab;
+    int *sorted, *bkt, *lead, *ltab;
+    int N;
+};
+
+template <int NW> struct GGCapW { static constexpr int value = NW >= 8 ? 256 : 512; };
+
+template <bool WITH_CENTRES, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void gg_k_slab_build(GGSlabArgs a, GGGrid gp, GGSplit sp)
 {
-    extern __shared__ __attribute__((aligned(16))) int lcnt[];
-    __shared__ int swc[16];
-    __shared__ int sbase;
-    const int b = blockIdx.y;
-    const int v0 = blockIdx.x * S;
-    const int v1 = (v0 + S < G) ? v0 + S : G;
-    const int ns = v1 - v0;
-    for (int j = threadIdx.x; j < ns; j += 1024) lcnt[j] = 0;
-    __syncthreads();
-    const int *vb = vox + (size_t)b * N;
-    int *ab = arr + (size_t)b * N;
-    const int N4 = ((((size_t)b * N) & 3) == 0) ? (N >> 2) : 0;  // int4 path needs 16 B alignment
-    // four 16-byte loads in flight per thread (measured: no change -- the kernel's 20 us at
-    // N = 81920 are the LDS atomics and the scattered arr[] stores, not the vox stream)
-    for (int q0 = threadIdx.x; q0 < N4; q0 += 4 * 1024) {
-        int4 v4[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int q = q0 + u * 1024;
-            v4[u] = q < N4 ? ((const int4 *)vb)[q] : make_int4(-1, -1, -1, -1);
+    constexpr int NT = 64 * NW;
+    constexpr int CAPW = GGCapW<NW>::value;
+    extern __shared__ __attribute__((aligned(16))) int lds2[];
+    const int S = 1 << sp.SB, nchunk = sp.nchunk, N = a.N, CH = sp.CH;
+    int *wc = lds2;                      // [NW][S]
+    int *voff = wc + NW * S;             // [S+1]
+    int *ltmp = voff + S + 1;            // [S]
+    int *roff = ltmp + S;                // [nchunk+1]
+    int *rsrc = roff + nchunk + 1;       // [nchunk]
+    int *hist = rsrc + nchunk;           // [GG_MAX_R+1]
+    int *lid = hist + GG_MAX_R + 1;      // [NW][CAPW]
+    unsigned short *lvl = (unsigned short *)(lid + NW * CAPW);
+    __shared__ int s_w[2 * NW];
+    __shared__ int s_dense;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wgid = b * sp.nslab + s;
+    GG_STAMP(1, wgid, 0);
+
+    // ---- runs of this slab: list offsets, and the slab's base = points in lower slabs ----
+    int n_s = 0, base_s = 0;
+    for (int c0 = 0; c0 < nchunk; c0 += NT) {
+        const int c = c0 + tid;
+        int st = 0, len = 0;
+        if (c < nchunk) {
+            const int *row = a.ctab + ((size_t)b * nchunk + c) * (sp.nslab + 1);
+            st = row[s];
+            len = row[s + 1] - st;
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int q = q0 + u * 1024;
-            const int vv[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = vv[j];
-                if (v >= v0 && v < v1) ab[q * 4 + j] = atomicAdd(&lcnt[v - v0], 1);
+        if (c0 == 0) {  // overlapped with the table loads
+            for (int j = tid; j < NW * S; j += NT) wc[j] = 0;
+            for (int j = tid; j <= GG_MAX_R; j += NT) hist[j] = 0;
+            if (tid == 0) s_dense = 0;
+        }
+        int tl;
+        const int ex = gg_block_excl_scan<NW>(len, s_w, &tl);
+        if (c < nchunk) {
+            roff[c] = n_s + ex;
+            rsrc[c] = c * CH + st - (n_s + ex);
+        }
+        n_s += tl;
+        base_s += st;  // per thread; summed below
+    }
+    {
+        int dummy = 0;
+        gg_block_sum2<NW>(base_s, dummy, s_w);
+    }
+    if (tid == 0) roff[nchunk] = n_s;
+    __syncthreads();
+    GG_STAMP(1, wgid, 1);
+
+    const int cw0 = (nchunk * wave) / NW, cw1 = (nchunk * (wave + 1)) / NW;
+    const int L0 = roff[cw0], L1 = roff[cw1];
+    const int ntile = (L1 - L0 + CAPW - 1) / CAPW;  // per wave
+    int *mylid = lid + wave * CAPW;
+    unsigned short *mylvl = lvl + wave * CAPW;
+    const unsigned *cloudpart = a.part + (size_t)b * N;
+    const int grp = lane / GG_GS, gl = lane % GG_GS;
+
+    // stage the list positions [T0, T1) of this wave: group g copies the runs cw0+g, cw0+g+8, ...
+    auto gather_tile = [&](int T0, int T1) {
+        for (int c = cw0 + grp; c < cw1; c += 2 * (64 / GG_GS)) {
+            const int c2 = c + 64 / GG_GS;
+            const int r0 = roff[c], r1 = roff[c + 1];
+            int q0 = 0, q1 = 0;
+            if (c2 < cw1) { q0 = roff[c2]; q1 = roff[c2 + 1]; }
+            const int lo0 = r0 > T0 ? r0 : T0, hi0 = r1 < T1 ? r1 : T1;
+            const int lo1 = q0 > T0 ? q0 : T0, hi1 = q1 < T1 ? q1 : T1;
+            int pa = lo0 + gl, pb = lo1 + gl;
+            while (pa < hi0 || pb < hi1) {  // two runs in flight per group
+                unsigned ia = 0u, ib = 0u;
+                if (pa < hi0) ia = cloudpart[rsrc[c] + pa];
+                if (pb < hi1) ib = cloudpart[rsrc[c2] + pb];
+                if (pa < hi0) {
+                    mylid[pa - T0] = c * CH + (int)(ia & 4095u);
+                    mylvl[pa - T0] = (unsigned short)(ia >> 12);
+                }
+                if (pb < hi1) {
+                    mylid[pb - T0] = c2 * CH + (int)(ib & 4095u);
+                    mylvl[pb - T0] = (unsigned short)(ib >> 12);
+                }
+                pa += GG_GS;
+                pb += GG_GS;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- pass 1: per-wave voxel populations ----
+    for (int t = 0; t < ntile; t++) {
+        const int T0 = L0 + t * CAPW, T1 = (T0 + CAPW < L1) ? T0 + CAPW : L1;
+        gather_tile(T0, T1);
+        for (int i = lane; i < T1 - T0; i += 64) atomicAdd(&wc[wave * S + mylvl[i]], 1);
+        __builtin_amdgcn_wave_barrier();
     }
-    for (int i = N4 * 4 + threadIdx.x; i < N; i += 1024) {
-        int v = vb[i];
-        if (v >= v0 && v < v1) ab[i] = atomicAdd(&lcnt[v - v0], 1);
-    }
+    GG_STAMP(1, wgid, 2);
     __syncthreads();
-    // exclusive scan of lcnt[0..ns): each thread owns a contiguous run of `per` entries
-    const int per = (ns + 1023) / 1024;
-    const int j0 = threadIdx.x * per;
-    int s = 0;
-    for (int j = j0; j < j0 + per && j < ns; j++) s += lcnt[j];
-    int incl = gg_wave_incl_scan(s);
-    if (gg_lane() == 63) swc[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
+    GG_STAMP(1, wgid, 3);
+
+    // ---- voxel offsets: thread t owns the VPT consecutive voxels [t*VPT, (t+1)*VPT) ----
+    const int VPT = (S + NT - 1) / NT;
+    const int j0 = tid * VPT;
+    int mine = 0;
+    for (int j = j0; j < j0 + VPT && j < S; j++) {
+        int run = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
-        int t = swc[w];
-        if (w < (int)(threadIdx.x >> 6)) wbase += t;
-        total += t;
-    }
-    if (threadIdx.x == 0) sbase = b * N + (total ? atomicAdd(&cursor[b], total) : 0);
-    __syncthreads();
-    int run = sbase + wbase + incl - s;
-    size_t gb = (size_t)b * G + v0;
-    for (int j = j0; j < j0 + per && j < ns; j++) {
-        int c = lcnt[j];
-        cnt[gb + j] = c;
-        off[gb + j] = run;
-        run += c;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K3: arrival-order scatter into the voxel segment; also resets the reservoir slots.
-__global__ __launch_bounds__(256) void gg_k_scatter(int N, int G, const int *__restrict__ vox,
-                                                    const int *__restrict__ arr,
-                                                    const int *__restrict__ off,
-                                                    int *__restrict__ seg, int *__restrict__ bkt)
-{
-    const int b = blockIdx.y;
-    const int ip = blockIdx.x * 256 + threadIdx.x;
-    if (ip >= N) return;
-    size_t i = (size_t)b * N + ip;
-    int v = vox[i];
-    if (bkt) bkt[i] = -1;
-    if (v >= 0) seg[off[(size_t)b * G + v] + arr[i]] = ip;
-}
-
-// ------------------------------------------------------------------------------------------
-// K4: rank inside the voxel, sorted segment, bucket reservoir (gridify.cu:145-154), leaders.
-// grid (ceil(N/1024), B), block 1024.  WITH_CENTRES=false for GridifyUp (no buckets/leaders).
-template <bool WITH_CENTRES>
-__global__ __launch_bounds__(1024) void gg_k_rank(int N, GGGrid gp, const int *__restrict__ vox,
-                                                  const int *__restrict__ cnt,
-                                                  const int *__restrict__ off,
-                                                  const int *__restrict__ seg,
-                                                  int *__restrict__ sorted, int *__restrict__ bkt,
-                                                  unsigned char *__restrict__ lead,
-                                                  int *__restrict__ blkcnt)
-{
-    __shared__ int swc[16];
-    const int b = blockIdx.y;
-    const int ip = blockIdx.x * 1024 + threadIdx.x;
-    const size_t i = (size_t)b * N + ip;
-    int v = (ip < N) ? vox[i] : -1;
-    int is_lead = 0;
-    if (v >= 0) {
-        size_t vb = (size_t)b * gp.G + v;
-        int c = cnt[vb];
-        int o = off[vb];
-        int n = 0;
-        int j = 0;
-        for (; j + 4 <= c; j += 4) {
-            int a0 = seg[o + j], a1 = seg[o + j + 1], a2 = seg[o + j + 2], a3 = seg[o + j + 3];
-            n += (a0 < ip) + (a1 < ip) + (a2 < ip) + (a3 < ip);
+        for (int w = 0; w < NW; w++) {
+            const int cw = wc[w * S + j];
+            wc[w * S + j] = run;
+            run += cw;
         }
-        for (; j < c; j++) n += (seg[o + j] < ip);
-        sorted[o + n] = ip;
-        if (WITH_CENTRES) {
-            if (c > gp.P) {
-                // S0: item n < P sits in slot n; item n >= P overwrites slot r(n) if r(n) < P
-                // (gridify.cu:146-153).  Last writer = largest n = largest point id.
-                int s = n;
-                if (n >= gp.P)
-                    s = gg_reservoir_pick((unsigned long long)(long long)(int)i + gp.seed, n + 1);
-                if (s < gp.P) atomicMax(&bkt[o + s], ip);
+        ltmp[j] = run;  // population, replaced by the leader id in pass 2
+        mine += run;
+    }
+    int tot_chk;
+    int run0 = gg_block_excl_scan<NW>(mine, s_w, &tot_chk);
+    for (int j = j0; j < j0 + VPT && j < S; j++) {
+        const int cj = ltmp[j];
+        voff[j] = run0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) wc[w * S + j] += run0;
+        run0 += cj;
+    }
+    if (tid == NT - 1) voff[S] = run0;
+    __syncthreads();
+    // voxel table of the slab's voxels (coalesced: 16 consecutive voxel numbers = 16 consecutive
+    // voxel ids = one 128-byte line), -1 fill of the bucket of over-full voxels
+    const size_t gbase = (size_t)b * N + base_s;  // absolute start of the slab in sorted/bkt/lead
+    bool dense = false;
+    for (int j = tid; j < S; j += NT) {
+        const unsigned v = gg_voxel_of_slab(s, j, sp);
+        if (v < (unsigned)gp.G) {
+            const int vo = voff[j], cj = voff[j + 1] - vo;
+            a.vtab[(size_t)b * gp.G + v] = make_int2((int)(gbase + vo), cj);
+            if (WITH_CENTRES && cj > gp.P) {
+                dense = true;
+                for (int q = 0; q < gp.P; q++) a.bkt[gbase + vo + q] = -1;
             }
-            is_lead = (n == 0);
         }
     }
     if (WITH_CENTRES) {
-        if (ip < N) lead[i] = (unsigned char)is_lead;
-        unsigned long long m = __ballot(is_lead);
-        if (gg_lane() == 0) swc[threadIdx.x >> 6] = __popcll(m);
+        if (dense) s_dense = 1;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-#pragma unroll
-            for (int w = 0; w < 16; w++) t += swc[w];
-            blkcnt[(size_t)b * gridDim.x + blockIdx.x] = t;
+        if (s_dense) {
+            // the -1 fills above must be in L2 before other waves' atomicMax on the same words
+            __threadfence();
+            __syncthreads();
         }
     }
+    GG_STAMP(1, wgid, 4);
+
+    // ---- pass 2: stable placement ----
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int t = 0; t < ntile; t++) {
+        const int T0 = L0 + t * CAPW, T1 = (T0 + CAPW < L1) ? T0 + CAPW : L1;
+        if (ntile > 1) gather_tile(T0, T1);
+        const int len = T1 - T0;
+        for (int i0 = 0; i0 < len; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < len;
+            const unsigned vl = valid ? (unsigned)mylvl[i] : 0u;
+            const int id = valid ? mylid[i] : 0;
+            const unsigned long long peers = gg_wave_peers(valid, vl, sp.SB);
+            if (valid) {
+                const int rank = __popcll(peers & lt), npeer = __popcll(peers);
+                const int base = wc[wave * S + vl];
+                const int pos = base + rank;
+                if (rank == npeer - 1) wc[wave * S + vl] = base + npeer;
+                a.sorted[gbase + pos] = id;
+                if (WITH_CENTRES) {
+                    const int vo = voff[vl];
+                    const int n = pos - vo;            // rank of the point inside its voxel
+                    const int cv = voff[vl + 1] - vo;  // population of the voxel
+                    if (n == 0) ltmp[vl] = id;
+                    if (cv > gp.P) {
+                        // S0: item n < P sits in slot n; item n >= P overwrites slot r(n) if
+                        // r(n) < P (gridify.cu:146-153).  Last writer = largest n = largest id.
+                        int sl = n;
+                        if (n >= gp.P) {
+                            const int gi = (int)((long long)b * N + id);
+                            sl = gg_reservoir_pick((unsigned long long)(long long)gi + gp.seed,
+                                                   n + 1);
+                        }
+                        if (sl < gp.P) atomicMax(&a.bkt[gbase + vo + sl], id);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    GG_STAMP(1, wgid, 5);
+    if (!WITH_CENTRES) return;
+    __syncthreads();
+    // ---- leaders of the slab (first point of every occupied voxel), grouped by the point range
+    //      id >> RSB they fall in (any order inside a group: K3 only needs the set) ----
+    for (int j = tid; j < S; j += NT)
+        if (voff[j + 1] - voff[j] > 0) atomicAdd(&hist[ltmp[j] >> sp.RSB], 1);
+    __syncthreads();
+    if (wave == 0) {
+        const int h = lane < sp.R ? hist[lane] : 0;  // R <= 64
+        const int incl = gg_wave_incl_scan(h);
+        int *row = a.ltab + ((size_t)b * sp.nslab + s) * (sp.R + 1);
+        if (lane < sp.R) {
+            hist[lane] = incl - h;
+            row[lane] = base_s + incl - h;
+        }
+        if (lane == 63) row[sp.R] = base_s + incl;
+    }
+    __syncthreads();
+    int *ldst = a.lead + gbase;
+    for (int j = tid; j < S; j += NT)
+        if (voff[j + 1] - voff[j] > 0) {
+            const int id = ltmp[j];
+            ldst[atomicAdd(&hist[id >> sp.RSB], 1)] = id;
+        }
+    GG_STAMP(1, wgid, 6);
 }
 
-template __global__ void gg_k_rank<true>(int, GGGrid, const int *, const int *, const int *,
-                                         const int *, int *, int *, unsigned char *, int *);
-template __global__ void gg_k_rank<false>(int, GGGrid, const int *, const int *, const int *,
-                                          const int *, int *, int *, unsigned char *, int *);
-
 // ------------------------------------------------------------------------------------------
-// K5: centre slots = RVS reservoir over voxels in order of first appearance (gridify.cu:165-189).
-// slotfirst1[b,O] holds (first point id of the chosen voxel) + 1, 0 = empty.
-__global__ __launch_bounds__(1024) void gg_k_centres(int N, GGGrid gp,
-                                                     const unsigned char *__restrict__ lead,
-                                                     const int *__restrict__ blkcnt,
-                                                     const unsigned long long *__restrict__ wsum_blk,
-                                                     int *__restrict__ slotfirst1,
-                                                     int *__restrict__ centnum,
-                                                     int *__restrict__ exact)
+// K3.  grid (R, B), block 256, dynamic LDS = 2*(2^RSB/32) + 2*(nslab+1) ints.  Centre slots = RVS
+// reservoir over the occupied voxels in order of first appearance (gridify.cu:165-189): t = rank
+// of the voxel's first point among all first points.  A workgroup owns the point range
+// [r << RSB, (r+1) << RSB): from every slab's table row it takes the number of leaders below its
+// range and the position of the slab's leaders inside it, marks those in an LDS bitmap; a prefix
+// popcount gives t.  slotfirst1[b,O] holds (first point id of the chosen voxel) + 1, 0 = empty;
+// "last writer wins" of S0 = largest t = largest id -> atomicMax.
+__global__ __launch_bounds__(GG_NT3) void gg_k_centre_slots(
+    int N, GGGrid gp, GGSplit sp, const int *__restrict__ lead, const int *__restrict__ ltab,
+    const unsigned long long *__restrict__ wsum_blk, int *__restrict__ slotfirst1,
+    int *__restrict__ centnum, int *__restrict__ exact)
 {
-    __shared__ int swc[16];
-    __shared__ int sred[16];
-    const int b = blockIdx.y;
-    const int nblk = gridDim.x;
-    const int ip = blockIdx.x * 1024 + threadIdx.x;
-    const size_t i = (size_t)b * N + ip;
-    // leaders in the preceding blocks of this cloud (and, for block 0, in the whole cloud)
-    int before = 0, all = 0;
-    for (int j = threadIdx.x; j < nblk; j += 1024) {
-        int c = blkcnt[(size_t)b * nblk + j];
-        all += c;
-        if (j < (int)blockIdx.x) before += c;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds3[];
+    const int nslab = sp.nslab, R = sp.R, RSB = sp.RSB;
+    const int nw = (1 << RSB) >> 5;
+    unsigned *bm = lds3;                    // [nw]   leaders of this range
+    int *pre = (int *)(bm + nw);            // [nw]   exclusive prefix popcount
+    int *rpos = pre + nw;                   // [nslab+1] list offset of the slab's run
+    int *rsrc = rpos + nslab + 1;           // [nslab]   its position in lead[] minus the offset
+    __shared__ int s_w[2 * (GG_NT3 / 64)];
+    const int b = blockIdx.y, r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lo = r << RSB;
+    const int wgid = b * gridDim.x + r;
+    GG_STAMP(2, wgid, 0);
+    for (int j = tid; j < nw; j += GG_NT3) bm[j] = 0u;
+    const int *lb = lead + (size_t)b * N;
+    int before = 0, nlead = 0, nown = 0;
+    for (int s0 = 0; s0 < nslab; s0 += GG_NT3) {
+        const int s = s0 + tid;
+        int a0 = 0, len = 0;
+        if (s < nslab) {
+            const int *row = ltab + ((size_t)b * nslab + s) * (R + 1);
+            const int t0 = row[0], tR = row[R];
+            a0 = row[r];
+            len = row[r + 1] - a0;
+            before += a0 - t0;
+            nlead += tR - t0;
+        }
+        int tl;
+        const int ex = gg_block_excl_scan<GG_NT3 / 64>(len, s_w, &tl);
+        if (s < nslab) {
+            rpos[s] = nown + ex;
+            rsrc[s] = a0 - (nown + ex);
+        }
+        nown += tl;
     }
-    before = gg_wave_sum(before);
-    all = gg_wave_sum(all);
-    if (gg_lane() == 0) { swc[threadIdx.x >> 6] = before; sred[threadIdx.x >> 6] = all; }
-    __syncthreads();
-    int t0 = 0, total = 0;
+    if (tid == 0) rpos[nslab] = nown;
+    gg_block_sum2<GG_NT3 / 64>(before, nlead, s_w);  // + barriers: rpos/rsrc/bm visible
+    GG_STAMP(2, wgid, 1);
+    // the range's own leaders, flat over the runs: four loads in flight per thread
+    for (int p0 = tid; p0 < nown; p0 += 4 * GG_NT3) {
+        int id[4];
 #pragma unroll
-    for (int w = 0; w < 16; w++) { t0 += swc[w]; total += sred[w]; }
-    __syncthreads();
-    int flag = (ip < N) ? (int)lead[i] : 0;
-    unsigned long long m = __ballot(flag);
-    int pre = __popcll(m & ((1ull << gg_lane()) - 1ull));
-    if (gg_lane() == 0) swc[threadIdx.x >> 6] = __popcll(m);
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += swc[w];
-    if (flag) {
-        int t = t0 + wbase + pre;
-        int s = t;
-        if (t >= gp.O)
-            s = gg_reservoir_pick((unsigned long long)(long long)(int)i + 2ull * gp.seed, t + 1);
-        if (s < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + s], ip + 1);
+        for (int u = 0; u < 4; u++) {
+            const int p = p0 + u * GG_NT3;
+            id[u] = -1;
+            if (p < nown) {
+                int l = 0, h = nslab;  // rpos[l] <= p < rpos[h]
+                while (h - l > 1) {
+                    const int mid = (l + h) >> 1;
+                    if (rpos[mid] <= p) l = mid; else h = mid;
+                }
+                id[u] = lb[rsrc[l] + p];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (id[u] >= 0) {
+                const unsigned d = (unsigned)(id[u] - lo);
+                atomicOr(&bm[d >> 5], 1u << (d & 31u));
+            }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        centnum[b] = total < gp.O ? total : gp.O;
+    __syncthreads();
+    GG_STAMP(2, wgid, 2);
+    int nbefore = before;
+    for (int w0 = 0; w0 < nw; w0 += GG_NT3) {
+        const int wi = w0 + tid;
+        const int pc = wi < nw ? __popc(bm[wi]) : 0;
+        int tot;
+        const int ex = gg_block_excl_scan<GG_NT3 / 64>(pc, s_w, &tot);
+        if (wi < nw) pre[wi] = nbefore + ex;
+        nbefore += tot;
+    }
+    __syncthreads();
+    // one bit position per thread and step: the picks spread evenly over the block
+    for (int q = tid; q < (1 << RSB); q += GG_NT3) {
+        const unsigned word = bm[q >> 5];
+        if ((word >> (q & 31)) & 1u) {
+            const int t = pre[q >> 5] + __popc(word & ((1u << (q & 31)) - 1u));
+            const int id = lo + q;
+            int sl = t;
+            if (t >= gp.O) {
+                const int gi = (int)((long long)b * N + id);
+                sl = gg_reservoir_pick((unsigned long long)(long long)gi + 2ull * gp.seed, t + 1);
+            }
+            if (sl < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + sl], id + 1);
+        }
+    }
+    GG_STAMP(2, wgid, 3);
+    if (r == 0 && tid < 64) {
         // weights of the cloud are integers and sum(|w|) < 2^23: every partial sum of S0's
         // total_weight accumulation is exact, so it may be evaluated in any order
-        unsigned long long ws = 0, bad = 0;
-        for (int j = 0; j < nblk; j++) {
-            unsigned long long x = wsum_blk[(size_t)b * nblk + j];
-            bad |= x >> 63;
-            ws += x & ~(1ull << 63);
+        long long ws = 0;
+        int fl = 0;
+        for (int j = tid; j < sp.nchunk; j += 64) {
+            const unsigned long long x = wsum_blk[(size_t)b * sp.nchunk + j];
+            fl |= (int)(x >> 62);
+            ws += (long long)(x & ~(3ull << 62));
         }
-        exact[b] = (!bad && ws < (1ull << 23)) ? 1 : 0;
+        ws = gg_wave_sum_ll(ws);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) fl |= __shfl_xor(fl, d, 64);
+        if (tid == 0) {
+            centnum[b] = nlead < gp.O ? nlead : gp.O;
+            const int ex = (!(fl & 2) && ws < (1ll << 23)) ? 1 : 0;
+            exact[b] = ex | ((ex && !(fl & 1)) ? 2 : 0);
+        }
     }
+    GG_STAMP(2, wgid, 4);
 }
+GG_PROF_SETTER(gridgcn_prof_set_index)
 
 // ------------------------------------------------------------------------------------------
+static unsigned gg_inv_odd(unsigned a)  // inverse of an odd number mod 2^32 (Newton)
+{
+    unsigned x = a;
+    for (int i = 0; i < 5; i++) x *= 2u - a * x;
+    return x;
+}
+
+static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
+{
+    static const bool forced = [] {
+        const char *e = getenv("GG_INDEX_LEGACY");
+        return e && e[0] == '1';
+    }();
+    const long long nruns = ((long long)gp.G + (1 << GG_XRB) - 1) >> GG_XRB;
+    int MB = 0;
+    while ((1ll << MB) < nruns) MB++;
+    // slabs: 2^KB per cloud.  At least so many that a slab has <= 4096 voxels; more while the
+    // launch is below 1024 workgroups and a slab still gets >= 256 points on average, or while
+    // a slab has more than 1024 voxels and still gets >= 128 points.
+    int KB = MB - (GG_MAX_SB - GG_XRB);
+    KB = KB < 0 ? 0 : KB;
+    while (KB < MB && KB < 10) {
+        const long long after = (long long)N >> (KB + 1);
+        const bool grow = ((long long)B << KB) < 1024 && after >= 256;
+        const bool shrink = (MB - KB + GG_XRB) > 10 && after >= 128;
+        if (!grow && !shrink) break;
+        KB++;
+    }
+    if (forced || KB > 10 || MB - KB + GG_XRB > GG_MAX_SB) return false;
+    w->KB = KB;
+    w->MB = MB;
+    w->SB = MB - KB + GG_XRB;
+    w->S = 1 << w->SB;
+    w->nslab = 1 << KB;
+    w->HA = 0x9E3779B1u;
+    w->HAinv = gg_inv_odd(w->HA);
+    w->NW2 = w->SB <= 9 ? 8 : (w->SB == 10 ? 4 : 2);  // per-wave counters <= 16 KB (32 KB at S = 4096)
+    // chunks of 1024 / 2048 / 4096 points: small chunks while the launch stays within one wave
+    // of workgroups (2 per CU), and never more than GG_MAX_CHUNKS per cloud
+    int CH = 1024;
+    while (CH < GG_CHUNK_MAX &&
+           ((long long)B * ((N + CH - 1) / CH) > 512 || (N + CH - 1) / CH > GG_MAX_CHUNKS))
+        CH *= 2;
+    w->CH = CH;
+    w->nblk = (N + CH - 1) / CH;
+    if (w->nblk > GG_MAX_CHUNKS) return false;
+    // centre kernel: ranges of 2^RSB >= 4096 points, at most GG_MAX_R per cloud
+    int RSB = 12;
+    while ((((long long)N + (1ll << RSB) - 1) >> RSB) > GG_MAX_R) RSB++;
+    w->RSB = RSB;
+    w->R = (int)(((long long)N + (1ll << RSB) - 1) >> RSB);
+    return true;
+}
+
+static GGSplit gg_split_of(const GGIndexWs &w)
+{
+    GGSplit sp;
+    sp.HA = w.HA;
+    sp.HAinv = w.HAinv;
+    sp.mmask = w.MB >= 32 ? 0xffffffffu : ((1u << w.MB) - 1u);
+    sp.LB = w.MB - w.KB;
+    sp.SB = w.SB;
+    sp.KB = w.KB;
+    sp.nslab = w.nslab;
+    sp.nchunk = w.nblk;
+    sp.CH = w.CH;
+    sp.R = w.R;
+    sp.RSB = w.RSB;
+    return sp;
+}
+
+static size_t gg_k1_lds(int nslab, int CH) { return (size_t)(GG_NW1 * nslab + CH) * 4; }
+static size_t gg_k2_lds(int SB, int nchunk, int NW)
+{
+    const size_t S = (size_t)1 << SB;
+    const size_t capw = NW >= 8 ? 256 : 512;
+    return (NW * S + (S + 1) + S + (nchunk + 1) + nchunk + (GG_MAX_R + 1) + NW * capw) * 4 +
+           NW * capw * 2;
+}
+static size_t gg_k3_lds(int RSB, int nslab)
+{
+    return (size_t)(2 * ((1 << RSB) >> 5) + 2 * (nslab + 1)) * 4;
+}
+
 size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres, GGIndexWs *ws)
 {
+    GGIndexWs w = {};
+    if (!gg_plan(B, N, gp, &w))
+        return gg_index_legacy_workspace_bytes(B, N, gp, with_centres, ws);
     const size_t BG = (size_t)B * gp.G, BN = (size_t)B * N;
-    const int nblk = (N + 1023) / 1024;
-    // slabs: enough workgroups to fill 256 CUs twice, each slab <= 32768 voxels (128 KB of LDS)
-    int nslab = (512 + B - 1) / B;
-    const int min_slab = (gp.G + 32767) / 32768;
-    if (nslab < min_slab) nslab = min_slab;
-    if (nslab > gp.G) nslab = gp.G;
-    const int S = (gp.G + nslab - 1) / nslab;
-    nslab = (gp.G + S - 1) / S;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
-    GGIndexWs w;
-    // ---- zero-filled region (one hipMemsetAsync) ----
+    // ---- zeroed by K1 ----
     w.o_slotfirst1 = take(with_centres ? (size_t)B * gp.O * 4 : 0);
-    w.o_cursor = take((size_t)B * 4);
     w.zero_bytes = o;
     // ---- written before read ----
-    w.o_cnt = take(BG * 4);
-    w.o_off = take(BG * 4);
-    w.o_blkcnt = take(with_centres ? (size_t)B * nblk * 4 : 0);
-    w.o_wsum = take((size_t)B * nblk * 8);
-    w.o_exact = take((size_t)B * 4);
-    w.o_vox = take(BN * 4);
-    w.o_arr = take(BN * 4);
-    w.o_seg = take(BN * 4);
+    w.o_vtab = take(BG * 8);
     w.o_sorted = take(BN * 4);
     w.o_bkt = take(with_centres ? BN * 4 : 0);
-    w.o_lead = take(with_centres ? BN : 0);
+    w.o_exact = take((size_t)B * 4);
+    w.o_part = take(BN * 4);
+    w.o_ctab = take((size_t)B * w.nblk * (w.nslab + 1) * 4);
+    w.o_lead = take(with_centres ? BN * 4 : 0);
+    w.o_ltab = take(with_centres ? (size_t)B * w.nslab * (w.R + 1) * 4 : 0);
+    w.o_wsum = take((size_t)B * w.nblk * 8);
     w.total = o;
-    w.nblk = nblk;
-    w.nslab = nslab;
-    w.S = S;
+    w.legacy = 0;
     if (ws) *ws = w;
     return o;
+}
+
+template <bool WC, int NW>
+static void gg_launch_k2(const GGSlabArgs &a, const GGGrid &gp, const GGSplit &sp, int B,
+                         hipStream_t st)
+{
+    gg_k_slab_build<WC, NW><<<dim3(sp.nslab, B), 64 * NW, gg_k2_lds(sp.SB, sp.nchunk, NW), st>>>(
+        a, gp, sp);
 }
 
 int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid &gp,
                    bool with_centres, int *centnum, char *wsbase, const GGIndexWs &w,
                    hipStream_t st)
 {
-    int *cnt = (int *)(wsbase + w.o_cnt), *off = (int *)(wsbase + w.o_off);
-    int *vox = (int *)(wsbase + w.o_vox);
-    int *arr = (int *)(wsbase + w.o_arr), *seg = (int *)(wsbase + w.o_seg);
-    int *sorted = (int *)(wsbase + w.o_sorted);
-    int *bkt = with_centres ? (int *)(wsbase + w.o_bkt) : nullptr;
-    unsigned char *lead = with_centres ? (unsigned char *)(wsbase + w.o_lead) : nullptr;
-    int *slotfirst1 = (int *)(wsbase + w.o_slotfirst1), *blkcnt = (int *)(wsbase + w.o_blkcnt);
+    if (w.legacy)
+        return gg_index_legacy_build(data, np, B, N, gp, with_centres, centnum, wsbase, w, st);
+    const GGSplit sp = gg_split_of(w);
+    unsigned *part = (unsigned *)(wsbase + w.o_part);
+    int *ctab = (int *)(wsbase + w.o_ctab);
     unsigned long long *wsum = (unsigned long long *)(wsbase + w.o_wsum);
-    int *exact = (int *)(wsbase + w.o_exact);
-    int *cursor = (int *)(wsbase + w.o_cursor);
-
-    if (hipMemsetAsync(wsbase, 0, w.zero_bytes, st) != hipSuccess) return 3;
-    dim3 g256((N + 255) / 256, B), g1024(w.nblk, B), gslab(w.nslab, B);
-    gg_k_voxelize<<<g1024, 1024, 0, st>>>((const float4 *)data, np, N, gp, vox, wsum);
-    gg_k_slab_count<<<gslab, 1024, (size_t)w.S * 4, st>>>(vox, N, gp.G, w.S, arr, cnt, off,
-                                                          cursor);
-    gg_k_scatter<<<g256, 256, 0, st>>>(N, gp.G, vox, arr, off, seg, bkt);
+    const dim3 g1(sp.nchunk, B);
+    const size_t l1 = gg_k1_lds(sp.nslab, sp.CH);
+    const float4 *d4 = (const float4 *)data;
+    int *zb = (int *)wsbase;
+    const int zw = (int)(w.zero_bytes / 4);
+    if (sp.CH == 1024)
+        gg_k_chunk_split<1><<<g1, GG_NT1, l1, st>>>(d4, np, N, gp, sp, part, ctab, wsum, zb, zw);
+    else if (sp.CH == 2048)
+        gg_k_chunk_split<2><<<g1, GG_NT1, l1, st>>>(d4, np, N, gp, sp, part, ctab, wsum, zb, zw);
+    else
+        gg_k_chunk_split<4><<<g1, GG_NT1, l1, st>>>(d4, np, N, gp, sp, part, ctab, wsum, zb, zw);
+    GGSlabArgs a;
+    a.part = part;
+    a.ctab = ctab;
+    a.vtab = (int2 *)(wsbase + w.o_vtab);
+    a.sorted = (int *)(wsbase + w.o_sorted);
+    a.bkt = with_centres ? (int *)(wsbase + w.o_bkt) : nullptr;
+    a.lead = with_centres ? (int *)(wsbase + w.o_lead) : nullptr;
+    a.ltab = with_centres ? (int *)(wsbase + w.o_ltab) : nullptr;
+    a.N = N;
     if (with_centres) {
-        gg_k_rank<true><<<g1024, 1024, 0, st>>>(N, gp, vox, cnt, off, seg, sorted, bkt, lead,
-                                                blkcnt);
-        gg_k_centres<<<g1024, 1024, 0, st>>>(N, gp, lead, blkcnt, wsum, slotfirst1, centnum,
-                                             exact);
+        if (w.NW2 == 8) gg_launch_k2<true, 8>(a, gp, sp, B, st);
+        else if (w.NW2 == 4) gg_launch_k2<true, 4>(a, gp, sp, B, st);
+        else gg_launch_k2<true, 2>(a, gp, sp, B, st);
+        gg_k_centre_slots<<<dim3(sp.R, B), GG_NT3, gg_k3_lds(sp.RSB, sp.nslab), st>>>(
+            N, gp, sp, a.lead, a.ltab, wsum, (int *)(wsbase + w.o_slotfirst1), centnum,
+            (int *)(wsbase + w.o_exact));
     } else {
-        gg_k_rank<false><<<g1024, 1024, 0, st>>>(N, gp, vox, cnt, off, seg, sorted, nullptr,
-                                                 nullptr, nullptr);
+        if (w.NW2 == 8) gg_launch_k2<false, 8>(a, gp, sp, B, st);
+        else if (w.NW2 == 4) gg_launch_k2<false, 4>(a, gp, sp, B, st);
+        else gg_launch_k2<false, 2>(a, gp, sp, B, st);
     }
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-int gg_index_init() {
-    // slabs may use up to 128 KB of dynamic LDS (default limit is 64 KB)
-    return hipFuncSetAttribute((const void *)gg_k_slab_count,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) == hipSuccess
-               ? 0 : 3;
+int gg_index_init()
+{
+    // dynamic LDS above the 64 KB default
+    const int l1 = (int)gg_k1_lds(GG_MAX_SLABS, GG_CHUNK_MAX);
+    const void *k1[3] = {(const void *)gg_k_chunk_split<1>, (const void *)gg_k_chunk_split<2>,
+                         (const void *)gg_k_chunk_split<4>};
+    for (int i = 0; i < 3; i++)
+        if (hipFuncSetAttribute(k1[i], hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess)
+            return 3;
+    const void *k2[6] = {(const void *)gg_k_slab_build<true, 8>, (const void *)gg_k_slab_build<true, 4>,
+                         (const void *)gg_k_slab_build<true, 2>, (const void *)gg_k_slab_build<false, 8>,
+                         (const void *)gg_k_slab_build<false, 4>, (const void *)gg_k_slab_build<false, 2>};
+    const int nw2[6] = {8, 4, 2, 8, 4, 2};
+    const int sb2[6] = {9, 10, 12, 9, 10, 12};
+    for (int i = 0; i < 6; i++)
+        if (hipFuncSetAttribute(k2[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)gg_k2_lds(sb2[i], GG_MAX_CHUNKS, nw2[i])) != hipSuccess)
+            return 3;
+    if (hipFuncSetAttribute((const void *)gg_k_centre_slots,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess)
+        return 3;
+    return gg_index_legacy_init();
 }

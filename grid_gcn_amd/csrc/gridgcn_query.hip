@@ -10,8 +10,12 @@
 #include "gridgcn_index.h"
 
 struct GGQueryPtrs {
-    const int *cnt, *off, *vox, *sorted, *bkt, *slotfirst1, *centnum, *exact;
+    const int2 *vtab;  // .x = segment start, .y = population
+    const int *sorted, *bkt, *slotfirst1, *centnum, *exact;
 };
+
+#define GG_QW 4    // waves per workgroup of the Gridify query (they never synchronise)
+#define GG_QCS 12  // ints of per-centre state in LDS
 
 // item g0 (0-based, flat over the neighbour table) -> point id
 __device__ __forceinline__ int gg_item(const int *s_excl, const int *s_off, int k3, int g0,
@@ -29,161 +33,390 @@ __device__ __forceinline__ int gg_item(const int *s_excl, const int *s_off, int 
     return src[(so & 0x7fffffff) + j];
 }
 
-// grid = B*O blocks of 64 threads.
-__global__ __launch_bounds__(64) void gg_k_query_gridify(const float4 *__restrict__ data, int N,
-                                                         GGGrid gp, GGQueryPtrs q,
-                                                         int *__restrict__ nebidx,
-                                                         float *__restrict__ nebmsk,
-                                                         float4 *__restrict__ cent,
-                                                         float *__restrict__ centmsk)
+// inclusive max-scan across the 64 lanes of a wave
+__device__ __forceinline__ int gg_wave_incl_max(int v)
 {
-    __shared__ int s_excl[GG_K3MAX + 1];
-    __shared__ int s_off[GG_K3MAX];
-    __shared__ int s_slotg[GG_PMAX];
-    __shared__ int s_slotid[GG_PMAX];
-    __shared__ float s_curw[GG_PMAX];
-
-    const int lane = threadIdx.x;
-    const int index = blockIdx.x;  // b*O + o
-    const int b = index / gp.O;
-    const int o = index - b * gp.O;
-    const int P = gp.P, k = gp.k, k3 = gp.k3;
-    const int cn = q.centnum[b];
-    int *row = nebidx + (size_t)index * P;
-    float *mrow = nebmsk + (size_t)index * P;
-
-    if (o >= cn) {  // GridifyOp::Forward fill values (gridify-inl.h:117-121)
-        for (int s = lane; s < P; s += 64) { row[s] = 0; mrow[s] = 0.0f; }
-        if (lane == 0) { cent[index] = make_float4(1.f, 1.f, 1.f, 1.f); centmsk[index] = 0.0f; }
-        return;
+    const int lane = gg_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v = v > t ? v : t;
     }
-    const float4 *cloud = data + (size_t)b * N;
-    const int i0 = q.slotfirst1[index] - 1;
-    const int v = q.vox[(size_t)b * N + i0];
-    const int c2 = v / gp.gxy;                         // gridify.cu:232-234
-    const int c1 = (v - c2 * gp.gxy) / gp.g[0];
-    const int c0 = v - c2 * gp.gxy - c1 * gp.g[0];
-    const int hk = (k - 1) / 2;
+    return v;
+}
 
-    // ---- neighbour table: flat item offsets over the k^3 voxels in (z,y,x) order (:240-249) ----
-    int M = 0;
-    for (int base = 0; base < k3; base += 64) {
-        int nei = base + lane;
-        int a = 0, so = 0;
-        if (nei < k3) {
-            int d = nei / (k * k) - hk + c2;
-            int h = (nei % (k * k)) / k - hk + c1;
-            int w = nei % k - hk + c0;
-            if (d >= 0 && d < gp.g[2] && h >= 0 && h < gp.g[1] && w >= 0 && w < gp.g[0]) {
-                size_t nb = (size_t)b * gp.G + (size_t)d * gp.gxy + h * gp.g[0] + w;
-                int c = q.cnt[nb];
-                a = c < P ? c : P;
-                so = q.off[nb] | (c > P ? 0x80000000 : 0);
+// Gridify query: a wave owns NC consecutive centre slots and walks them through the dependent
+// levels of the lookup TOGETHER, so that NC times the loads are in flight per level:
+//   A  slot -> first point of the chosen voxel -> voxel coordinates        (2 loads, lanes < NC)
+//   B  (start, population) of the k^3 neighbour voxels of every centre      (lane = neighbour)
+//   C  exclusive scans = flat item offsets (:240-249)
+//   D  ids of the first min(M,P) items (:251-258) and of the centre voxel's own points
+//   E  their weights (skipped when every weight of the cloud is 1) and the own-voxel points
+//   F  reservoir past P (:260-268), total weight, padding (:275-279), centre (:280-289)
+// grid = ceil(B*O / (4*NC)) workgroups of 4 independent waves; dynamic LDS = 4 * NC *
+// (GG_QCS + 2*k^3 + 1 + 3*P + 64) ints.
+template <int NC>
+__global__ __launch_bounds__(64 * GG_QW) void gg_k_query_gridify(
+    const float4 *__restrict__ data, int N, GGGrid gp, GGQueryPtrs q, int ncent,
+    int *__restrict__ nebidx, float *__restrict__ nebmsk, float4 *__restrict__ cent,
+    float *__restrict__ centmsk)
+{
+    extern __shared__ __attribute__((aligned(16))) int qlds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int P = gp.P, k = gp.k, k3 = gp.k3, hk = (k - 1) / 2;
+    int *wl = qlds + wave * (NC * (GG_QCS + 2 * k3 + 1 + 3 * P + 64));
+    int *s_ctr = wl;                         // [NC][QCS]: c0 c1 c2 b state exact ccnt coff total
+    int *s_excl = s_ctr + NC * GG_QCS;       // [NC][k3+1]
+    int *s_off = s_excl + NC * (k3 + 1);     // [NC][k3]
+    int *s_slotg = s_off + NC * k3;          // [NC][P]
+    int *s_slotid = s_slotg + NC * P;        // [NC][P]
+    float *s_curw = (float *)(s_slotid + NC * P);   // [NC][P]
+    float *s_mem = s_curw + NC * P;          // [NC][16][4] w*x, w*y, w*z, w of the own-voxel points
+    const int cbase = (blockIdx.x * GG_QW + wave) * NC;
+    GG_STAMP(3, blockIdx.x, 0);
+    if (cbase >= ncent) return;
+
+    // ---- A ----
+    if (lane < NC) {
+        const int index = cbase + lane;
+        int c3[3] = {0, 0, 0};
+        int b = 0, state = 0, ex = 0;  // state 0: beyond B*O, 1: empty slot (fill values), 2: centre
+        if (index < ncent) {
+            b = index / gp.O;
+            const int o = index - b * gp.O;
+            const int cn = q.centnum[b];
+            const int sf = q.slotfirst1[index];
+            ex = q.exact[b];
+            state = 1;
+            if (o < cn) {
+                const float4 p0 = data[(size_t)b * N + (sf - 1)];
+                (void)gg_voxel_of(p0.x, p0.y, p0.z, gp, c3);  // gridify.cu:232-234
+                state = 2;
             }
         }
-        int incl = gg_wave_incl_scan(a);
-        if (nei < k3) { s_excl[nei] = M + incl - a; s_off[nei] = so; }
-        M += __shfl(incl, 63, 64);
+        int *ct = s_ctr + lane * GG_QCS;
+        ct[0] = c3[0]; ct[1] = c3[1]; ct[2] = c3[2]; ct[3] = b; ct[4] = state; ct[5] = ex;
+        ct[6] = 0; ct[7] = 0;
     }
-    if (lane == 0) s_excl[k3] = M;
-    for (int s = lane; s < P; s += 64) s_slotg[s] = 0;
-    __syncthreads();
+    for (int s = lane; s < NC * P; s += 64) s_slotg[s] = 0;
+    __builtin_amdgcn_wave_barrier();
+    GG_STAMP(3, blockIdx.x, 1);
 
-    const int Mc = M < P ? M : P;
-    // ---- first P items fill slots 0..P-1 in order (:251-258) ----
-    for (int g0 = lane; g0 < Mc; g0 += 64) {
-        int id = gg_item(s_excl, s_off, k3, g0, q.sorted, q.bkt);
-        s_slotid[g0] = id;
-        s_curw[g0] = cloud[id].w;
-    }
-    __syncthreads();
-
-    const bool exact = q.exact[b] != 0;
-    const unsigned seedbase = (unsigned)index * (unsigned)P * (unsigned)k3;  // int wrap (:260)
-    float total;
-    if (exact) {
-        // ---- overflow items: slot r(g) <- item g, last writer (largest g) wins (:260-268) ----
-        for (int g0 = P + lane; g0 < M; g0 += 64) {
-            int g = g0 + 1;
-            int s32 = (int)(seedbase + (unsigned)g);
-            int r = gg_reservoir_pick((unsigned long long)(long long)s32, g);
-            if (r < P) atomicMax(&s_slotg[r], g);
+    // ---- B + C: neighbour voxels in (z,y,x) order (:240-249) ----
+    int Mr[NC];
+    if (k3 <= 64) {
+        // lane = neighbour number; the table entries of all NC centres are loaded together
+        const int kk = k * k;
+        const int dz = lane / kk - hk, dy = (lane % kk) / k - hk, dx = lane % k - hk;
+        int2 vt[NC];
+        bool inb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int *ct = s_ctr + c * GG_QCS;
+            const int d = dz + ct[2], h = dy + ct[1], w = dx + ct[0];
+            inb[c] = lane < k3 && ct[4] == 2 && d >= 0 && d < gp.g[2] && h >= 0 && h < gp.g[1] &&
+                     w >= 0 && w < gp.g[0];
+            vt[c] = make_int2(0, 0);
+            if (inb[c])
+                vt[c] = q.vtab[(size_t)ct[3] * gp.G + (size_t)d * gp.gxy + h * gp.g[0] + w];
         }
-        __syncthreads();
-        // integer weights: the running total of S0 telescopes to the sum over the final slots
-        long long acc = 0;
-        for (int s = lane; s < Mc; s += 64) {
-            int g = s_slotg[s];
-            int id = s_slotid[s];
-            float w = s_curw[s];
-            if (g > 0) {
-                id = gg_item(s_excl, s_off, k3, g - 1, q.sorted, q.bkt);
-                w = cloud[id].w;
-                s_slotid[s] = id;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int cn = inb[c] ? vt[c].y : 0;
+            const int a = cn < P ? cn : P;
+            if (inb[c] && lane == (k3 - 1) / 2) {  // the centre voxel itself
+                s_ctr[c * GG_QCS + 6] = cn;
+                s_ctr[c * GG_QCS + 7] = vt[c].x;
             }
-            acc += (long long)(int)w;
+            const int incl = gg_wave_incl_scan(a);
+            if (lane < k3) {
+                s_excl[c * (k3 + 1) + lane] = incl - a;
+                s_off[c * k3 + lane] = vt[c].x | (cn > P ? 0x80000000 : 0);
+                // head marker of the neighbour's first item (consumed in D)
+                if (a > 0 && incl - a < P) s_slotg[c * P + incl - a] = lane + 1;
+            }
+            Mr[c] = __shfl(incl, 63, 64);
+            if (lane == 0) s_excl[c * (k3 + 1) + k3] = Mr[c];
         }
-        acc = gg_wave_sum_ll(acc);
-        total = (float)acc;
     } else {
-        // ---- general weights: replay S0's float accumulation in its own order ----
-        total = 0.0f;
-        for (int s = 0; s < Mc; s++) total = __fadd_rn(total, (float)(int)s_curw[s]);
-        for (int base = P; base < M; base += 64) {
-            int g0 = base + lane;
-            bool ev = false;
-            int r = 0, idn = 0;
-            float wn = 0.0f;
-            if (g0 < M) {
-                int g = g0 + 1;
-                int s32 = (int)(seedbase + (unsigned)g);
-                r = gg_reservoir_pick((unsigned long long)(long long)s32, g);
-                ev = r < P;
+        const int kk = k * k;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int *ct = s_ctr + c * GG_QCS;
+            int M = 0;
+            for (int base = 0; base < k3; base += 64) {
+                const int nei = base + lane;
+                int a = 0, so = 0, cn = 0;
+                if (nei < k3 && ct[4] == 2) {
+                    const int d = nei / kk - hk + ct[2];
+                    const int h = (nei % kk) / k - hk + ct[1];
+                    const int w = nei % k - hk + ct[0];
+                    if (d >= 0 && d < gp.g[2] && h >= 0 && h < gp.g[1] && w >= 0 && w < gp.g[0]) {
+                        const int2 vt = q.vtab[(size_t)ct[3] * gp.G + (size_t)d * gp.gxy + h * gp.g[0] + w];
+                        cn = vt.y;
+                        a = cn < P ? cn : P;
+                        so = vt.x | (cn > P ? 0x80000000 : 0);
+                        if (nei == (k3 - 1) / 2) {
+                            s_ctr[c * GG_QCS + 6] = cn;
+                            s_ctr[c * GG_QCS + 7] = vt.x;
+                        }
+                    }
+                }
+                const int incl = gg_wave_incl_scan(a);
+                if (nei < k3) {
+                    s_excl[c * (k3 + 1) + nei] = M + incl - a;
+                    s_off[c * k3 + nei] = so;
+                    if (a > 0 && M + incl - a < P) s_slotg[c * P + M + incl - a] = nei + 1;
+                }
+                M += __shfl(incl, 63, 64);
             }
-            if (ev) {
-                idn = gg_item(s_excl, s_off, k3, g0, q.sorted, q.bkt);
-                wn = cloud[idn].w;
+            if (lane == 0) s_excl[c * (k3 + 1) + k3] = M;
+            Mr[c] = M;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    GG_STAMP(3, blockIdx.x, 2);
+
+    // ---- D: item g0 belongs to the last head marker at or before it ----
+    int idr[NC][2], cidr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int Mc = Mr[c] < P ? Mr[c] : P;
+        int carry = 0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int g0 = g * 64 + lane;
+            idr[c][g] = -1;
+            if (g * 64 < Mc) {  // uniform
+                int hd = g0 < P ? s_slotg[c * P + g0] : 0;
+                hd = gg_wave_incl_max(hd);
+                hd = hd > carry ? hd : carry;
+                carry = __shfl(hd, 63, 64);
+                if (g0 < Mc) {
+                    const int e = hd - 1;
+                    const int so = s_off[c * k3 + e];
+                    const int *src = (so < 0) ? q.bkt : q.sorted;
+                    idr[c][g] = src[(so & 0x7fffffff) + g0 - s_excl[c * (k3 + 1) + e]];
+                }
             }
-            unsigned long long mask = __ballot(ev);
-            while (mask) {
-                int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                int rr = __shfl(r, l, 64);
-                float wl = __shfl(wn, l, 64);
-                int il = __shfl(idn, l, 64);
-                float old = s_curw[rr];
-                total = __fadd_rn(total, __fsub_rn((float)(int)wl, old));
-                __syncthreads();
-                if (lane == 0) { s_curw[rr] = wl; s_slotid[rr] = il; }
-                __syncthreads();
+        }
+        cidr[c] = -1;
+        const int *ct = s_ctr + c * GG_QCS;
+        if (gp.loc == 1 && ct[4] == 2 && lane < ct[6] && lane < 16) cidr[c] = q.sorted[ct[7] + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < NC * P; s += 64) s_slotg[s] = 0;  // markers consumed
+    // ---- E ----
+    float wr[NC][2];
+    float4 cp[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int *ct = s_ctr + c * GG_QCS;
+        const float4 *cloud = data + (size_t)ct[3] * N;
+        const bool allone = (ct[5] & 2) != 0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            wr[c][g] = 1.0f;
+            if (idr[c][g] >= 0 && !allone) wr[c][g] = cloud[idr[c][g]].w;
+        }
+        cp[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cidr[c] >= 0) cp[c] = cloud[cidr[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+            if (idr[c][g] >= 0) {
+                s_slotid[c * P + g * 64 + lane] = idr[c][g];
+                s_curw[c * P + g * 64 + lane] = wr[c][g];
+            }
+        if (lane < 16) {
+            float *m = s_mem + (c * 16 + lane) * 4;
+            m[0] = __fmul_rn(cp[c].x, cp[c].w);
+            m[1] = __fmul_rn(cp[c].y, cp[c].w);
+            m[2] = __fmul_rn(cp[c].z, cp[c].w);
+            m[3] = cp[c].w;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    GG_STAMP(3, blockIdx.x, 3);
+
+    // ---- F: reservoir past P (:260-268) and total weight.  Clouds with small integer weights
+    //      (always, in the reference models): the running total of S0 telescopes to the sum over
+    //      the final slots, so the levels below run for all NC centres together ----
+    // F1: overflow items only evaluate their draw; slot r(g) <- item g, largest g wins
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int *ct = s_ctr + c * GG_QCS;
+        if (ct[4] == 2 && (ct[5] & 1) && Mr[c] > P) {
+            const unsigned seedbase = (unsigned)(cbase + c) * (unsigned)P * (unsigned)k3;  // int wrap (:260)
+            for (int g0 = P + lane; g0 < Mr[c]; g0 += 64) {
+                const int g = g0 + 1;
+                const int s32 = (int)(seedbase + (unsigned)g);
+                const int r = gg_reservoir_pick((unsigned long long)(long long)s32, g);
+                if (r < P) atomicMax(&s_slotg[c * P + r], g);
             }
         }
     }
-    __syncthreads();
-
-    // ---- outputs: ids, mask, pad with the first id (:275-279) ----
-    const int first = s_slotid[0];
-    for (int s = lane; s < P; s += 64) {
-        row[s] = s < Mc ? s_slotid[s] : first;
-        mrow[s] = s < Mc ? 1.0f : 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    // F2: ids of the winners
+    int rid[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int *ct = s_ctr + c * GG_QCS;
+        const bool ov = ct[4] == 2 && (ct[5] & 1) && Mr[c] > P;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; g2++) {
+            const int sl = g2 * 64 + lane;
+            rid[c][g2] = -1;
+            if (ov && sl < P) {
+                const int g = s_slotg[c * P + sl];
+                if (g > 0)
+                    rid[c][g2] = gg_item(s_excl + c * (k3 + 1), s_off + c * k3, k3, g - 1, q.sorted, q.bkt);
+            }
+        }
+    }
+    // F3: their weights
+    float rw[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int *ct = s_ctr + c * GG_QCS;
+        const float4 *cloud = data + (size_t)ct[3] * N;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; g2++) {
+            rw[c][g2] = 1.0f;
+            if (rid[c][g2] >= 0 && !(ct[5] & 2)) rw[c][g2] = cloud[rid[c][g2]].w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int g2 = 0; g2 < 2; g2++)
+            if (rid[c][g2] >= 0) {
+                s_slotid[c * P + g2 * 64 + lane] = rid[c][g2];
+                s_curw[c * P + g2 * 64 + lane] = rw[c][g2];
+            }
+    __builtin_amdgcn_wave_barrier();
+    // F4: totals (and, for clouds with general weights, the replay of S0's float accumulation)
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int index = cbase + c;
+        int *ct = s_ctr + c * GG_QCS;
+        if (ct[4] != 2) continue;
+        const bool exact = (ct[5] & 1) != 0, allone = (ct[5] & 2) != 0;
+        const int M = Mr[c], Mc = M < P ? M : P;
+        float *curw = s_curw + c * P;
+        float total;
+        if (exact) {
+            if (allone) {
+                total = (float)Mc;  // every weight is 1
+            } else {
+                long long acc = 0;
+                for (int sl = lane; sl < Mc; sl += 64) acc += (long long)(int)curw[sl];
+                total = (float)gg_wave_sum_ll(acc);
+            }
+        } else {
+            const float4 *cloud = data + (size_t)ct[3] * N;
+            const int *ex = s_excl + c * (k3 + 1), *sof = s_off + c * k3;
+            int *slotid = s_slotid + c * P;
+            const unsigned seedbase = (unsigned)index * (unsigned)P * (unsigned)k3;
+            total = 0.0f;
+            for (int sl = 0; sl < Mc; sl++) total = __fadd_rn(total, (float)(int)curw[sl]);
+            for (int base = P; base < M; base += 64) {
+                const int g0 = base + lane;
+                bool ev = false;
+                int r = 0, idn = 0;
+                float wn = 0.0f;
+                if (g0 < M) {
+                    const int g = g0 + 1;
+                    const int s32 = (int)(seedbase + (unsigned)g);
+                    r = gg_reservoir_pick((unsigned long long)(long long)s32, g);
+                    ev = r < P;
+                }
+                if (ev) {
+                    idn = gg_item(ex, sof, k3, g0, q.sorted, q.bkt);
+                    wn = cloud[idn].w;
+                }
+                unsigned long long mask = __ballot(ev);
+                while (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int rr = __shfl(r, l, 64);
+                    const float wl_ = __shfl(wn, l, 64);
+                    const int il = __shfl(idn, l, 64);
+                    const float old = curw[rr];
+                    total = __fadd_rn(total, __fsub_rn((float)(int)wl_, old));
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { curw[rr] = wl_; slotid[rr] = il; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (lane == 0) ct[8] = __float_as_int(total);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- outputs: ids, mask, pad with the first id (:275-279); fill values of empty slots ----
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int index = cbase + c;
+        const int state = s_ctr[c * GG_QCS + 4];
+        if (state == 0) break;
+        int *row = nebidx + (size_t)index * P;
+        float *mrow = nebmsk + (size_t)index * P;
+        const int Mc = state == 2 ? (Mr[c] < P ? Mr[c] : P) : 0;
+        const int first = state == 2 ? s_slotid[c * P] : 0;  // GridifyOp::Forward fill: 0
+        for (int s = lane; s < P; s += 64) {
+            row[s] = s < Mc ? s_slotid[c * P + s] : first;
+            mrow[s] = s < Mc ? 1.0f : 0.0f;
+        }
     }
     // ---- centre location: weighted mean of ALL points of the centre voxel, accumulated in
-    //      ascending point id with separate multiply and add (:155-162, :280-289) ----
-    float cx = 1.0f, cy = 1.0f, cz = 1.0f;
-    if (gp.loc == 1) {
-        size_t vb = (size_t)b * gp.G + v;
-        int c = q.cnt[vb];
-        int so = q.off[vb];
-        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-        for (int base = 0; base < c; base += 64) {
-            int j = base + lane;
-            float px = 0.f, py = 0.f, pz = 0.f, pw = 0.f;
-            if (j < c) {
-                float4 p = cloud[q.sorted[so + j]];
-                px = __fmul_rn(p.x, p.w); py = __fmul_rn(p.y, p.w); pz = __fmul_rn(p.z, p.w);
-                pw = p.w;
+    //      ascending point id with separate multiply and add (:155-162, :280-289); lane c sums
+    //      the points of centre c (the common case of <= 16 points), all centres at once ----
+    bool big = false;
+    if (lane < NC && cbase + lane < ncent) {
+        const int index = cbase + lane;
+        const int *ct = s_ctr + lane * GG_QCS;
+        if (ct[4] == 2) {
+            float cx = 1.0f, cy = 1.0f, cz = 1.0f;
+            const int cc = ct[6];
+            if (gp.loc == 1) {
+                if (cc <= 16) {
+                    float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+                    for (int l = 0; l < cc; l++) {
+                        const float *m = s_mem + (lane * 16 + l) * 4;
+                        sx = __fadd_rn(sx, m[0]); sy = __fadd_rn(sy, m[1]);
+                        sz = __fadd_rn(sz, m[2]); sw = __fadd_rn(sw, m[3]);
+                    }
+                    cx = __fdiv_rn(sx, sw); cy = __fdiv_rn(sy, sw); cz = __fdiv_rn(sz, sw);
+                } else {
+                    big = true;
+                }
             }
-            int nn = c - base < 64 ? c - base : 64;
+            if (!big) {
+                cent[index] = make_float4(cx, cy, cz, __int_as_float(ct[8]));
+                centmsk[index] = 1.0f;
+            }
+        } else {  // gridify-inl.h:117-121
+            cent[index] = make_float4(1.f, 1.f, 1.f, 1.f);
+            centmsk[index] = 0.0f;
+        }
+    }
+    unsigned long long bigm = __ballot(big);
+    while (bigm) {  // centre voxels with more than 16 points: the whole wave walks the segment
+        const int c = __builtin_ctzll(bigm);
+        bigm &= bigm - 1;
+        const int *ct = s_ctr + c * GG_QCS;
+        const float4 *cloud = data + (size_t)ct[3] * N;
+        const int cc = ct[6], so = ct[7];
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        for (int base = 0; base < cc; base += 64) {
+            const int j = base + lane;
+            float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < cc) pp = cloud[q.sorted[so + j]];
+            const float px = __fmul_rn(pp.x, pp.w), py = __fmul_rn(pp.y, pp.w),
+                        pz = __fmul_rn(pp.z, pp.w), pw = pp.w;
+            const int nn = cc - base < 64 ? cc - base : 64;
             for (int l = 0; l < nn; l++) {
                 sx = __fadd_rn(sx, __shfl(px, l, 64));
                 sy = __fadd_rn(sy, __shfl(py, l, 64));
@@ -191,13 +424,15 @@ __global__ __launch_bounds__(64) void gg_k_query_gridify(const float4 *__restric
                 sw = __fadd_rn(sw, __shfl(pw, l, 64));
             }
         }
-        cx = __fdiv_rn(sx, sw); cy = __fdiv_rn(sy, sw); cz = __fdiv_rn(sz, sw);
+        if (lane == 0) {
+            cent[cbase + c] = make_float4(__fdiv_rn(sx, sw), __fdiv_rn(sy, sw), __fdiv_rn(sz, sw),
+                                          __int_as_float(ct[8]));
+            centmsk[cbase + c] = 1.0f;
+        }
     }
-    if (lane == 0) {
-        cent[index] = make_float4(cx, cy, cz, total);
-        centmsk[index] = 1.0f;
-    }
+    GG_STAMP(3, blockIdx.x, 4);
 }
+GG_PROF_SETTER(gridgcn_prof_set_query)
 
 // ------------------------------------------------------------------------------------------
 // GridifyUp query.  grid = B*O blocks of 64 threads (one wave per up point).
@@ -246,8 +481,9 @@ __global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ u
             int w = nei % k - hk + c3[0];
             if (d >= 0 && d < gp.g[2] && h >= 0 && h < gp.g[1] && w >= 0 && w < gp.g[0]) {
                 size_t nb = (size_t)b * gp.G + (size_t)d * gp.gxy + h * gp.g[0] + w;
-                a = q.cnt[nb];
-                so = q.off[nb];
+                const int2 vt = q.vtab[nb];
+                a = vt.y;
+                so = vt.x;
             }
         }
         int incl = gg_wave_incl_scan(a);
@@ -298,21 +534,39 @@ __global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ u
 
 // ------------------------------------------------------------------------------------------
 // host launchers (used by gridgcn_capi.hip)
+static size_t gg_query_lds(int NC, int k3, int P)
+{
+    return (size_t)GG_QW * NC * (GG_QCS + 2 * k3 + 1 + 3 * P + 64) * 4;
+}
+
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
                             float *centmsk, const int *centnum, hipStream_t st)
 {
     GGQueryPtrs q;
-    q.cnt = (const int *)(wsbase + w.o_cnt);
-    q.off = (const int *)(wsbase + w.o_off);
-    q.vox = (const int *)(wsbase + w.o_vox);
+    q.vtab = (const int2 *)(wsbase + w.o_vtab);
     q.sorted = (const int *)(wsbase + w.o_sorted);
     q.bkt = (const int *)(wsbase + w.o_bkt);
     q.slotfirst1 = (const int *)(wsbase + w.o_slotfirst1);
     q.centnum = centnum;
     q.exact = (const int *)(wsbase + w.o_exact);
-    gg_k_query_gridify<<<B * gp.O, 64, 0, st>>>((const float4 *)data, N, gp, q, nebidx, nebmsk,
-                                                (float4 *)cent, centmsk);
+    const long long ncent = (long long)B * gp.O;
+    // centres per wave: more loads in flight per wave once there are more centres than wave slots
+    int NC = 1;
+    if (gp.k3 <= 64) NC = ncent > 65536 ? 4 : (ncent > 16384 ? 2 : 1);
+    const int per = GG_QW * NC;
+    const unsigned grid = (unsigned)((ncent + per - 1) / per);
+    const size_t lds = gg_query_lds(NC, gp.k3, gp.P);
+    const float4 *d4 = (const float4 *)data;
+    if (NC == 4)
+        gg_k_query_gridify<4><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, (int)ncent, nebidx, nebmsk,
+                                                             (float4 *)cent, centmsk);
+    else if (NC == 2)
+        gg_k_query_gridify<2><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, (int)ncent, nebidx, nebmsk,
+                                                             (float4 *)cent, centmsk);
+    else
+        gg_k_query_gridify<1><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, (int)ncent, nebidx, nebmsk,
+                                                             (float4 *)cent, centmsk);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -321,9 +575,7 @@ int gg_launch_query_up(const float *updata, const int *up_np, int B, int Nd, con
                        hipStream_t st)
 {
     GGQueryPtrs q = {};
-    q.cnt = (const int *)(wsbase + w.o_cnt);
-    q.off = (const int *)(wsbase + w.o_off);
-    q.vox = (const int *)(wsbase + w.o_vox);
+    q.vtab = (const int2 *)(wsbase + w.o_vtab);
     q.sorted = (const int *)(wsbase + w.o_sorted);
     gg_k_query_up<<<B * gp.O, 64, 0, st>>>((const float4 *)updata, up_np, Nd, gp, q, nebidx,
                                            nebmsk);

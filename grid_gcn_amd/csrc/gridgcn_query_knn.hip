@@ -13,7 +13,8 @@
 #define GG_KNN_CAP 2048  // candidates staged per LDS tile
 
 struct GGKnnPtrs {
-    const int *cnt, *off, *vox, *sorted, *bkt, *slotfirst1, *centnum, *exact;
+    const int2 *vtab;
+    const int *sorted, *bkt, *slotfirst1, *centnum, *exact;
 };
 
 __global__ __launch_bounds__(64) void gg_k_query_knn(const float4 *__restrict__ data, int N,
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(64) void gg_k_query_knn(const float4 *__restrict__ 
     }
     const float4 *cloud = data + (size_t)b * N;
     const int i0 = q.slotfirst1[index] - 1;
-    const int v = q.vox[(size_t)b * N + i0];
-    const int c2 = v / gp.gxy;
-    const int c1 = (v - c2 * gp.gxy) / gp.g[0];
-    const int c0 = v - c2 * gp.gxy - c1 * gp.g[0];
+    int c3[3];
+    const float4 p0 = cloud[i0];
+    const int v = gg_voxel_of(p0.x, p0.y, p0.z, gp, c3);
+    const int c0 = c3[0], c1 = c3[1], c2 = c3[2];
     const int hk = (k - 1) / 2;
     // gridifyknn.cu:253-255: (int + 0.5) * voxel_size in double, coord_shift NOT subtracted
     const float ux = (float)((c0 + 0.5) * (double)gp.vs[0]);
@@ -74,9 +75,10 @@ __global__ __launch_bounds__(64) void gg_k_query_knn(const float4 *__restrict__ 
                 if (mine && dc >= 0 && dc < gp.g[2] && hc >= 0 && hc < gp.g[1] && wc >= 0 &&
                     wc < gp.g[0]) {
                     size_t nb = (size_t)b * gp.G + (size_t)dc * gp.gxy + hc * gp.g[0] + wc;
-                    int c = q.cnt[nb];
+                    const int2 vt = q.vtab[nb];
+                    int c = vt.y;
                     a = c < P ? c : P;
-                    so = q.off[nb] | (c > P ? 0x80000000 : 0);
+                    so = vt.x | (c > P ? 0x80000000 : 0);
                 }
             }
             unsigned long long m = __ballot(mine);
@@ -166,8 +168,9 @@ __global__ __launch_bounds__(64) void gg_k_query_knn(const float4 *__restrict__ 
     float cx = 1.0f, cy = 1.0f, cz = 1.0f;
     if (gp.loc == 1) {
         size_t vb = (size_t)b * gp.G + v;
-        int c = q.cnt[vb];
-        int so = q.off[vb];
+        const int2 vt = q.vtab[vb];
+        int c = vt.y;
+        int so = vt.x;
         float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
         for (int base = 0; base < c; base += 64) {
             int j = base + lane;
@@ -198,9 +201,7 @@ int gg_launch_query_knn(const float *data, int B, int N, const GGGrid &gp, char 
                         float *centmsk, const int *centnum, hipStream_t st)
 {
     GGKnnPtrs q;
-    q.cnt = (const int *)(wsbase + w.o_cnt);
-    q.off = (const int *)(wsbase + w.o_off);
-    q.vox = (const int *)(wsbase + w.o_vox);
+    q.vtab = (const int2 *)(wsbase + w.o_vtab);
     q.sorted = (const int *)(wsbase + w.o_sorted);
     q.bkt = (const int *)(wsbase + w.o_bkt);
     q.slotfirst1 = (const int *)(wsbase + w.o_slotfirst1);

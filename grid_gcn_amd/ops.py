@@ -129,6 +129,39 @@ def Gridify(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stri
 
 
 @torch.no_grad()
+def gridify_timed(data, actual_numpoints, iters=50, *, max_p_grid, max_o_grid, kernel_size,
+                  stride=1, loc=0, coord_shift, voxel_size, grid_size, seed=0):
+    """Average device time (ms) of one Gridify call: `iters` back-to-back calls inside the
+    library between two HIP events on the launch stream (gridgcn_gridify_timed) -- no Python,
+    no allocation between the calls.  Returns (ms_per_call, outputs of the last call)."""
+    lib = _lib.load()
+    _chk(data, "data", 3, torch.float32, 4)
+    B, N, _ = data.shape
+    _num(actual_numpoints, "actual_numpoints", B)
+    p = _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size,
+                grid_size, seed)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.gridgcn_gridify_workspace_bytes(B, N, ctypes.byref(p), ctypes.byref(nbytes)),
+               "gridgcn_gridify_workspace_bytes")
+    dev = data.device
+    O, P = int(max_o_grid), int(max_p_grid)
+    ms = ctypes.c_float(0.0)
+    with torch.cuda.device(dev):
+        ws = _workspace(nbytes.value, dev)
+        nebidx = torch.empty((B, O, P), dtype=torch.int32, device=dev)
+        nebidxmsk = torch.empty((B, O, P), dtype=torch.float32, device=dev)
+        cent = torch.empty((B, O, 4), dtype=torch.float32, device=dev)
+        centmsk = torch.empty((B, O), dtype=torch.float32, device=dev)
+        actual_centnum = torch.empty((B, 1), dtype=torch.int32, device=dev)
+        rc = lib.gridgcn_gridify_timed(_ptr(data), _ptr(actual_numpoints), B, N, ctypes.byref(p),
+                                       _ptr(nebidx), _ptr(nebidxmsk), _ptr(cent), _ptr(centmsk),
+                                       _ptr(actual_centnum), _ptr(ws), nbytes.value,
+                                       _stream(data), int(iters), ctypes.byref(ms))
+    _lib.check(rc, "gridgcn_gridify_timed")
+    return float(ms.value), (nebidx, nebidxmsk, cent, centmsk, actual_centnum)
+
+
+@torch.no_grad()
 def GridifyKNN(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
                coord_shift, voxel_size, grid_size, seed=0):
     """As Gridify, neighbours = exact top-P by distance to the voxel centre

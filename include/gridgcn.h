@@ -76,6 +76,16 @@ int gridgcn_gridify(const float *data, const int32_t *actual_numpoints, int B, i
                     int32_t *actual_centnum,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Measurement helper: `iters` back-to-back gridgcn_gridify calls on `stream`, bracketed by HIP
+ * events recorded on that stream; *ms_per_call = average device time of one call (all of its
+ * launches, no host work in between except the launches themselves).  Synchronises the stream. */
+int gridgcn_gridify_timed(const float *data, const int32_t *actual_numpoints, int B, int N,
+                          const gridgcn_grid_params *p,
+                          int32_t *nebidx, float *nebidxmsk, float *cent, float *centmsk,
+                          int32_t *actual_centnum,
+                          void *workspace, size_t workspace_bytes, void *stream, int iters,
+                          float *ms_per_call);
+
 /* ---- GridifyKNN : replaces GridifyKNNForward<gpu>, gridifyknn.cu:336-455 ----------------------
  * same tensors as Gridify; neighbours = exact top-P by distance to the voxel centre over
  * Chebyshev shells (gridifyknn.cu:231-332). */

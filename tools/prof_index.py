@@ -37,12 +37,15 @@ def timeit(fn, iters):
 levels = [(d, n)]
 for l in range(len(cfg["down"])):
     kw = synth.gridify_kwargs(cfg, l)
-    ms, out = timeit(lambda: ops.Gridify(levels[-1][0], levels[-1][1], **kw), a.iters)
+    # device time of the whole call: back-to-back launches inside the library between two HIP
+    # events (a Python loop would be host-bound at these durations)
+    ms, out = ops.gridify_timed(levels[-1][0], levels[-1][1], a.iters, **kw)
     N = levels[-1][0].shape[1]
     byts = a.B * synth.gridify_algorithmic_bytes(N, kw["max_o_grid"], kw["max_p_grid"])
-    print("gridify L%d N=%d O=%d P=%d k=%d: %.3f ms  alg %.2f MB -> %.1f GB/s  (mean nn %.1f)" % (
+    print("gridify L%d N=%d O=%d P=%d k=%d: %.4f ms  alg %.2f MB -> %.1f GB/s = %.1f%% of 8 TB/s (mean nn %.1f, centres %.0f)" % (
         l, N, kw["max_o_grid"], kw["max_p_grid"], kw["kernel_size"], ms, byts / 1e6,
-        byts / ms / 1e6, float(out[1].sum(-1)[out[3] > 0].mean())))
+        byts / ms / 1e6, byts / ms / 1e6 / 80.0, float(out[1].sum(-1)[out[3] > 0].mean()),
+        float(out[4].float().mean())))
     levels.append((out[2], out[4]))
 if "up" in cfg:
     for u in range(3):
