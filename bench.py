@@ -2,13 +2,18 @@
 segmentation network (configs[3]: batch 8 per GPU, data parallel), plus ms per CAGQ layer
 (= one Gridify call) with its HBM roofline, and the CPU baseline timed beside it.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config cfg1|cfg2|cfg3|cfg3up|cfg5      (the other BASELINE.json configs)
 
 A step = zero_grad, forward (3 Gridify + 3 BallKNN + 6 gathers + 6 GridConv layers + head),
 loss, backward, one flat RCCL all-reduce of the gradients (N > 1), Adam update.  Inputs are
 synthetic clouds already resident in HBM (no dataset offline); weights are Xavier random.
+
+Every number in the JSON line is measured in this run, except `traffic` (HBM bytes per launch from
+the PMC counters): that one is read from profiles/traffic.json, written by tools/pmc_traffic.py from
+separate rocprofv3 --pmc passes of the same kernels at the same shapes; null if no entry matches.
 """
 import argparse
 import json
@@ -21,51 +26,109 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import torch.distributed as dist
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from grid_gcn_amd import dp, model, ops, synth  # noqa: E402
+from grid_gcn_amd import dp, model, model_cls, ops, synth  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32, dense
 
 
-def cpu_baseline(cfg, points, kind):
-    """Reference-side number: the S0 oracle (C, scalar) for the index ops + PyTorch CPU for
-    gather/GridConv, fwd+bwd of ONE cloud of the same workload (bounded sample)."""
+def load_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def cpu_baseline(cfg, B, points, kind, sample_clouds):
+    """Reference-side numbers on the host cores.  The S0 oracle (C, OpenMP
+    across clouds) for the index ops, PyTorch-CPU for gather/GridConv.  The CAGQ layer is timed
+    on the SAME batch as the GPU; the whole fwd+bwd step on a bounded sample of that batch."""
+    from oracle import oracle as orc
     from oracle.torch_index_ops import OracleIndexOps
+    data, npn = synth.make_batch(B, points, kind)
+    kw = synth.gridify_kwargs(cfg["grid"], 0)
+    orc.gridify(data, npn, **kw)                              # builds / loads the oracle, starts the team
+    t1 = time.perf_counter()
+    for _ in range(3):
+        orc.gridify(data, npn, **kw)
+    dt_g = (time.perf_counter() - t1) / 3
+    cagq_threads = orc.threads_for(B)
     torch.manual_seed(0)
     m = model.GGCNSeg(cfg, index_ops=OracleIndexOps)
     m.train()
-    data, npn = synth.make_batch(1, points, kind)
-    x = torch.from_numpy(data[..., :3].copy())
-    n = torch.from_numpy(npn)
-    lab = torch.randint(0, cfg["num_classes"], (1, points))
-    t0 = time.time()
+    S = min(B, sample_clouds)
+    x = torch.from_numpy(data[:S, :, :3].copy())
+    n = torch.from_numpy(npn[:S])
+    lab = torch.randint(0, cfg["num_classes"], (S, points))
+    t0 = time.perf_counter()
     loss = model.seg_loss(m(x, n), lab)
     loss.backward()
-    dt = time.time() - t0
-    # the CAGQ layer alone on the CPU (oracle, 1 core)
-    from oracle import oracle as orc
-    kw = synth.gridify_kwargs(cfg["grid"], 0)
-    t1 = time.time()
-    orc.gridify(data, npn, **kw)
-    dt_g = time.time() - t1
-    return {"value": 1.0 / dt, "unit": "point-clouds/s", "cores": torch.get_num_threads(),
+    dt = time.perf_counter() - t0
+    return {"value": S / dt, "unit": "point-clouds/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": "1 cloud x %d pts, fwd+bwd: S0 oracle (C, 1 thread) for Gridify/BallKNN + "
-                      "PyTorch-CPU (%d threads) for gather/GridConv" % (points, torch.get_num_threads()),
-            "ms_per_cagq_layer_1core": dt_g * 1e3}
+            "sample": "%d of the %d clouds x %d pts, one fwd+bwd: S0 oracle (C, OpenMP across clouds) for "
+                      "Gridify/BallKNN + PyTorch-CPU (%d threads) for gather/GridConv" % (
+                          S, B, points, torch.get_num_threads()),
+            "ms_per_cagq_layer": dt_g * 1e3,
+            "cagq_threads": cagq_threads,
+            "cagq_sample": "Gridify down layer 0 on the same %d-cloud batch, OpenMP across clouds "
+                           "(%d threads), mean of 3 calls" % (B, cagq_threads)}
+
+
+def time_training(step, steps, warmup, world, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.
+    Also returns the host time needed to ENQUEUE the K steps (before the final synchronize)."""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item()
+    return dt, t_enq
+
+
+def cagq_roofline(d4, n, kw, B, N, traffic, key):
+    ms, _ = ops.gridify_timed(d4, n, 100, **kw)
+    alg = B * synth.gridify_algorithmic_bytes(N, kw["max_o_grid"], kw["max_p_grid"])
+    ach = alg / (ms * 1e-3) / 1e9
+    return ms, {"bound": "hbm",
+                "kernel": "gridgcn_gridify (gg_k_chunk_split + gg_k_slab_build + gg_k_centre_slots "
+                          "+ gg_k_query_gridify; 100 back-to-back calls between two HIP events on "
+                          "the launch stream)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic.get(key), "traffic_key": key,
+                "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="clouds per GPU")
-    ap.add_argument("--points", type=int, default=81920)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg4",
+                    choices=["cfg1", "cfg2", "cfg3", "cfg3up", "cfg4", "cfg5"],
+                    help="BASELINE.json configs[0..4]; cfg4 (configs[3]) carries the headline metric")
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (0: the config's own)")
+    ap.add_argument("--points", type=int, default=0, help="points per cloud (0: the config's own)")
+    ap.add_argument("--cpu-sample", type=int, default=1, help="clouds of the CPU fwd+bwd sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -81,23 +144,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    traffic = load_traffic()
 
-    cfg = model.SEG_81920 if a.points > 8192 else model.SEG_8192
-    if a.points not in (8192, 81920):       # off-config sizes keep the layer tables
-        cfg = dict(cfg)
+    if a.config != "cfg4":
+        import bench_configs
+        out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    points = a.points or 81920
+    B = a.batch or 8
+    cfg = model.SEG_81920 if points > 8192 else model.SEG_8192
     kind = "planes"
     torch.manual_seed(0)
-    net = model.GGCNSeg(cfg).to(dev)
+    net = model.GGCNSeg(cfg, seed=rank).to(dev)
     net.train()
     # one multi-tensor kernel for the whole update instead of ~10 tiny launches per parameter
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
     sync = dp.FlatGradAllReduce(net)
     sync.broadcast_parameters()
-    B = a.batch
-    data, npn = synth.make_batch(B, a.points, kind, first_id=rank * B)   # a different shard per rank
+    data, npn = synth.make_batch(B, points, kind, first_id=rank * B)   # a different shard per rank
     x = torch.from_numpy(data[..., :3].copy()).to(dev)
     n = torch.from_numpy(npn).to(dev)
-    lab = torch.randint(0, cfg["num_classes"], (B, a.points), device=dev)
+    lab = torch.randint(0, cfg["num_classes"], (B, points), device=dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -107,64 +179,46 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(loss).item()
+    dt, t_enq = time_training(step, a.steps, a.warmup, world, dev)
+    ms_step = dt / a.steps * 1e3
+    fe, fr = model.seg_forward_flops(net, B, points)
+    step_flops = 3.0 * (fe + fr)
+    tf_step = step_flops / (ms_step * 1e-3) / 1e12
 
     out = {
         "metric": "point-clouds/sec fwd+bwd (ScanNet 81920-pt)", "value": world * B * a.steps / dt,
         "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3]: ScanNet %d-pt segmentation, batch %d per GPU, "
-                               "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (a.points, B),
-                   "global_batch": world * B, "points_per_cloud": a.points,
+                               "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (points, B),
+                   "global_batch": world * B, "points_per_cloud": points,
                    "parallelism": "dp%d" % world,
                    "kernels": "hand-written HIP for Gridify/BallKNN, edge inputs (gather+geo) and their "
                               "sorted backward, all conv+BatchNorm+ReLU stacks fwd+bwd (fp32 MFMA), "
                               "att product + max, fc1 + dropout + class scores (one op) + softmax "
                               "cross-entropy; PyTorch-ROCm for the small GEMMs on source points, "
                               "concat/mask on [B,O,C] and fused Adam"},
+        # host side of the timed region: time to ENQUEUE the K steps (Python + ctypes + launches);
+        # the step is GPU-bound while this stays below ms_per_step
+        "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
+        # whole step against the fp32 matrix peak: SURVEY section 8(d) algorithmic flops of the step
+        # (3 x forward: per-edge MLPs + per-point MLPs + head) / ms_per_step
+        "roofline_step": {"bound": "mfma", "kernel": "whole training step (all kernels)",
+                          "achieved": tf_step, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": tf_step / MFMA_F32_PEAK_TF, "traffic": None,
+                          "algorithmic_flops_per_step": step_flops,
+                          "edge_flops_fwd": fe, "per_point_flops_fwd": fr},
     }
 
     if rank == 0 and world == 1:
-        # ---- ms per CAGQ layer: Gridify of down layer 0 on the same batch, HIP events on the
-        #      stream the kernels are launched on (torch's current stream) ----
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # ---- ms per CAGQ layer: Gridify of down layer 0 on the same batch ----
         kw = synth.gridify_kwargs(cfg["grid"], 0)
         d4 = torch.from_numpy(data).to(dev)
-        for _ in range(5):
-            ops.Gridify(d4, n, **kw)
-        torch.cuda.synchronize()
-        iters = 50
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.Gridify(d4, n, **kw)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        alg = B * synth.gridify_algorithmic_bytes(a.points, kw["max_o_grid"], kw["max_p_grid"])
-        ach = alg / (ms * 1e-3) / 1e9
+        ms, rc = cagq_roofline(d4, n, kw, B, points, traffic, "gridify_N%d_B%d" % (points, B))
         out["ms_per_cagq_layer"] = ms
-        out["roofline_cagq"] = {"bound": "hbm", "kernel": "gridgcn_gridify (memset + 6 launches, "
-                                "down layer 0)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                "traffic": 134e6,  # FETCH+WRITE_SIZE, profiles/r1_pmc_index.txt
-                                "algorithmic_bytes_per_launch": alg}
+        out["roofline_cagq"] = rc
         # ---- inference forward through the fused GridConv kernels (the reference's own speed
         #      recipe times inference: train_gpu_speed_profiling.py:105-118) + the dominant
         #      hand-written kernel of the path: gg_k_gridconv of up layer 2 (fp32 MFMA bound) ----
@@ -220,7 +274,8 @@ def main():
         out["roofline_inference"] = {
             "bound": "mfma", "kernel": "gg_k_gridconv (GridConv %s: gather + per-edge MLPs + att "
             "product + max, one launch, inference-mode BatchNorm)" % name,
-            "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+            "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
             "algorithmic_flops_per_launch": flops, "ms_per_launch": ms_k,
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
             # evaluation runs this layer through the source-side kernels instead (first conv once
@@ -246,6 +301,7 @@ def main():
         # (amax, gval) [ncent,C], the previous layer's raw output [E,cin]; write dX [E,cin]
         bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 8.0 * ncent_b * c_b
         gbs_b = bytes_b / (ms_b * 1e-3) / 1e9
+        key_b = "att_bwd_fused_E%d_%dto%d" % (int(e_b), cin_b, c_b)
         out["roofline"] = {"bound": "hbm", "kernel": "gg_k_att_bwd_fused + gg_k_att_dw_reduce "
                            "(fused backward of the %d->%d attention conv of GridConv %s over %d "
                            "edges: BN/ReLU backward formed in registers from the sparse arg-max "
@@ -253,21 +309,19 @@ def main():
                            "over Z)" % (cin_b, c_b, name, ncent_b * p_b),
                            "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": gbs_b / HBM_PEAK_GBS,
-                           # FETCH_SIZE (x2: 16-byte streaming reads) + WRITE_SIZE of the kernel at
-                           # this shape, profiles/r1_pmc_summary.txt
-                           "traffic": 3.23e9 if (a.points == 81920 and B == 8) else None,
+                           "traffic": traffic.get(key_b), "traffic_key": key_b,
                            "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
                            "algorithmic_flops_per_launch": 4.0 * e_b * cin_b * c_b,
                            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         # the largest MFMA-bound kernel of the step: forward of the 256->128 update conv over
         # all B*N points (previous BatchNorm+ReLU applied while loading, statistics epilogue)
-        e_f, cin_f, c_f = B * a.points, 256, 128
+        e_f, cin_f, c_f = B * points, 256, 128
         ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=10, device=dev)
         tf_f = 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12
         out["roofline_mfma"] = {"bound": "mfma", "kernel": "gg_k_linear_fwd_direct (%d->%d conv + "
                                 "BN/ReLU prologue + statistics over %d rows)" % (cin_f, c_f, e_f),
-                                "achieved": tf_f, "peak": 157.3, "unit": "TFLOP/s",
-                                "frac": tf_f / 157.3, "traffic": None,
+                                "achieved": tf_f, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": tf_f / MFMA_F32_PEAK_TF, "traffic": None,
                                 "algorithmic_flops_per_launch": 2.0 * e_f * cin_f * c_f,
                                 "ms_per_launch": ms_f, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         # ---- the materialising neighbour gather as an operator (SURVEY §8(d) algorithmic bytes):
@@ -310,7 +364,7 @@ def main():
                                     "conv + fused attention-max kernel (up layers) + MFMA eval MLPs"}
         net.train()
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, a.points, kind)
+            out["cpu_baseline"] = cpu_baseline(cfg, B, points, kind, a.cpu_sample)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

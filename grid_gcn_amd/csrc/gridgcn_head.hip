@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void gg_k_ce_bwd(const float *__restrict__ log
 {
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
     if (row >= E) return;
-    const float coef = (float)((double)gout[0] / acc[1]);
+    // normalization='valid' with no valid label: MXNet clamps the count to 1 (loss and gradient 0)
+    const float coef = (float)((double)gout[0] / (acc[1] > 1.0 ? acc[1] : 1.0));
     float v[4 * NV], d[4 * NV];
     gg_row_load<NV>(logits + row * (4 * NV), v);
     const long long lab = label[row];

@@ -47,12 +47,29 @@ def _is_hip(ix):
     return isinstance(ix, type) and issubclass(ix, HipIndexOps)
 
 
+def call_seed(seed, forward_no, call_no):
+    """Seed of one index-operator call.  The reference reseeds cuRAND from gettimeofday().tv_usec
+    at EVERY operator call (gridify.cu:377-379), so the random voxel sampling and the neighbour
+    reservoirs are redrawn every iteration.  Here the draw is a splitmix64 step of (model seed,
+    number of the training forward, number of the call inside it): fresh every call, reproducible
+    from the model seed, identical for two models fed the same sequence (the parity tests)."""
+    x = (int(seed) + 0x9E3779B97F4A7C15 * (forward_no * 64 + call_no + 1)) & (2 ** 64 - 1)
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    return (x ^ (x >> 31)) & (2 ** 63 - 1)
+
+
 class GGCNSeg(nn.Module):
-    def __init__(self, cfg=SEG_8192, index_ops=HipIndexOps, seed=0):
+    def __init__(self, cfg=SEG_8192, index_ops=HipIndexOps, seed=0, fixed_seed=False):
+        """seed: base of the per-call sampling seeds (training mode redraws the random voxel
+        sampling at every call, see call_seed).  fixed_seed=True, or eval mode: every call uses
+        `seed` itself -- the reference's fast_apprxmt build (seed 0)."""
         super().__init__()
         self.cfg = cfg
         self.ix = index_ops
         self.seed = seed
+        self.fixed_seed = fixed_seed
+        self.forward_no = 0
         g = cfg["grid"]
         nd = len(g["down"])
         self.down = nn.ModuleList()
@@ -88,7 +105,15 @@ class GGCNSeg(nn.Module):
     edge_kernel = True  # training: edge inputs from one HIP kernel instead of take+slice+cat ops
 
     def use_fused(self):
-        return self.fused and (not self.training) and _is_hip(self.ix)
+        # the fused evaluation kernels return tensors without a grad_fn: eval() WITH grad enabled
+        # (frozen-BatchNorm fine-tuning, saliency) must take the differentiable path
+        return (self.fused and (not self.training) and (not torch.is_grad_enabled())
+                and _is_hip(self.ix))
+
+    def _seed(self, forward_no, call_no):
+        if self.fixed_seed or not self.training:
+            return self.seed
+        return call_seed(self.seed, forward_no, call_no)
 
     def forward(self, data_xyz, actual_centnum):
         """data_xyz [B,N,3] f32, actual_centnum [B,1] i32 -> logits [B,N,num_classes]."""
@@ -99,8 +124,11 @@ class GGCNSeg(nn.Module):
         feats = [data]                # center_locnfeat_alllayers: [B,n,4+C]
         masks, nums = [], [actual_centnum]
         data_loc, data_layer = data, data
+        fwd_no = self.forward_no
+        if self.training:
+            self.forward_no += 1
         for i, layer in enumerate(self.down):
-            kw = synth.gridify_kwargs(g, i, self.seed)
+            kw = synth.gridify_kwargs(g, i, self._seed(fwd_no, i))
             nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
                 data_loc.detach().contiguous(), nums[-1], **kw)                     # :154-159
             data_loc = cent
@@ -131,7 +159,7 @@ class GGCNSeg(nn.Module):
             else:
                 nebidx, _ = ix.GridifyUp(down.detach().contiguous(), upl.detach().contiguous(),
                                          downnum, upnum,
-                                         **synth.gridify_up_kwargs(g, i, self.seed))  # :206-210
+                                         **synth.gridify_up_kwargs(g, i, self._seed(fwd_no, 16 + i)))  # :206-210
             f_this = feats[-i - 2]
             cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
             if self.use_fused():
@@ -154,6 +182,33 @@ class GGCNSeg(nn.Module):
             if train_ops.linear_plain_supported(net, self.fc2):
                 return train_ops.linear_plain_train(net, self.fc2)
         return self.fc2(net)
+
+
+def _mlp_macs(seq):
+    return sum(l.lin.in_features * l.lin.out_features for l in (seq or []))
+
+
+def seg_forward_flops(net, B, N):
+    """Algorithmic flops of ONE forward of GGCNSeg on B clouds of N points:
+    2 * rows * sum(Cin*Cout) over every 1x1 conv -- per edge (B*O*P rows) for the point / attention
+    MLPs, per centre for the centre / update MLPs, per point for the head.  Element-wise work,
+    BatchNorm and the max-pool are not counted.  A training step = 3x (backward = 2x forward).
+    Returns (edge_flops, per_point_flops)."""
+    g = net.cfg["grid"]
+    edge = rows = 0.0
+    for i, layer in enumerate(net.down):
+        L = g["down"][i]
+        e = B * L["max_o_grid"] * L["max_p_grid"]
+        edge += 2.0 * e * (_mlp_macs(layer.pt_mlp) + _mlp_macs(layer.att1) + _mlp_macs(layer.att2))
+        rows += 2.0 * B * L["max_o_grid"] * (_mlp_macs(layer.center_mlp) + _mlp_macs(layer.update_mlp))
+    for i, layer in enumerate(net.up):
+        U = g["up"][i]
+        m = N if i == len(net.up) - 1 else U["max_o_grid"]
+        e = B * m * U["max_p_grid"]
+        edge += 2.0 * e * (_mlp_macs(layer.pt_mlp) + _mlp_macs(layer.att1) + _mlp_macs(layer.att2))
+        rows += 2.0 * B * m * (_mlp_macs(layer.center_mlp) + _mlp_macs(layer.update_mlp))
+    rows += 2.0 * B * N * (_mlp_macs([net.fc1]) + net.fc2.in_features * net.fc2.out_features)
+    return edge, rows
 
 
 class WeightedGradient(torch.autograd.Function):

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import synth
 from .gridconv import ConvBNReLU, mlp, run_mlp
-from .model import HipIndexOps, WeightedGradient
+from .model import HipIndexOps, WeightedGradient, call_seed
 
 CLS_MN40 = dict(
     grid=synth.CLS_MODELNET40, inputDim=[0, 128, 256],
@@ -82,9 +82,12 @@ class FCBNReLU(nn.Module):
 
 
 class GGCNCls(nn.Module):
-    def __init__(self, cfg=CLS_MN40, index_ops=HipIndexOps, seed=0):
+    def __init__(self, cfg=CLS_MN40, index_ops=HipIndexOps, seed=0, fixed_seed=False):
+        """seed / fixed_seed: as GGCNSeg (training redraws the voxel sampling at every call)."""
         super().__init__()
         self.cfg, self.ix, self.seed = cfg, index_ops, seed
+        self.fixed_seed = fixed_seed
+        self.forward_no = 0
         self._take_kw = (dict(neighbour_index=True)
                          if isinstance(index_ops, type) and issubclass(index_ops, HipIndexOps) else {})
         self.layers = nn.ModuleList(
@@ -103,9 +106,14 @@ class GGCNCls(nn.Module):
         g, ix = self.cfg["grid"], self.ix
         data = torch.cat([data_xyz, torch.ones_like(data_xyz[..., :1])], dim=2)   # :55
         data_loc, num = data, actual_centnum
+        fwd_no = self.forward_no
+        if self.training:
+            self.forward_no += 1
         for i, layer in enumerate(self.layers):
+            seed = self.seed if (self.fixed_seed or not self.training) else \
+                call_seed(self.seed, fwd_no, i)
             nebidx, nebidxmsk, cent, centmsk, num = ix.Gridify(
-                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, self.seed))
+                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed))
             data_loc = cent
             neighbors = ix.batch_take_g(data.contiguous(), nebidx, **self._take_kw)  # :94
             cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104

@@ -49,6 +49,16 @@ NO_Z0 = os.environ.get("GG_STORE_Z0", "0") != "1"
 SPARSE_L0 = os.environ.get("GG_SORTED_L0", "0") != "1"
 
 
+
+def _momentum(bn):
+    """BatchNorm momentum handed to gg_k_bn_finalize.  momentum=None (torch's cumulative moving
+    average) has no counterpart in the reference (mx.sym.BatchNorm(momentum=bn_decay)) nor in the
+    kernel: refuse it instead of passing None through ctypes."""
+    if bn.momentum is None:
+        raise RuntimeError("BatchNorm momentum=None (cumulative average) is not supported by the "
+                           "training kernels; use momentum = 1 - bn_decay (gridconv.ConvBNReLU)")
+    return float(bn.momentum)
+
 def supported(layers, x):
     if not (x.is_cuda and x.dtype == torch.float32):
         return False
@@ -164,7 +174,7 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
         track = bn is not None and bn.track_running_stats
         rc = lib.gridgcn_bn_finalize(
             _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
-            bn.momentum if track else 0.0, cout, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+            _momentum(bn) if track else 0.0, cout, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
             _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
             _ptr(bn.running_var) if track else None,
             _ptr(bn.num_batches_tracked) if track else None, stream)
@@ -681,7 +691,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             track = bn.track_running_stats
             rc = lib.gridgcn_bn_finalize(
                 _ptr(sums0), _ptr(g0.detach()), _ptr(be0.detach()), E, eps,
-                bn.momentum if track else 0.0, C0, _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]),
+                _momentum(bn) if track else 0.0, C0, _ptr(vec0[0]), _ptr(vec0[1]), _ptr(vec0[2]),
                 _ptr(vec0[3]), _ptr(bn.running_mean) if track else None,
                 _ptr(bn.running_var) if track else None,
                 _ptr(bn.num_batches_tracked) if track else None, st)
@@ -1203,7 +1213,9 @@ class _SoftmaxCE(torch.autograd.Function):
         ctx.save_for_backward(logits, label, lse, acc)
         ctx.meta = (ld, ignore)
         ctx.cw = cw
-        return (acc[0] / acc[1]).float()
+        # SoftmaxOutput(normalization='valid'): the valid count is clamped to >= 1, so a batch
+        # whose labels are all ignore_label gives loss 0 and gradient 0 instead of 0/0
+        return (acc[0] / acc[1].clamp_min(1.0)).float()
 
     @staticmethod
     def backward(ctx, g):

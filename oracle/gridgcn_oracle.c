@@ -68,6 +68,27 @@ float gridgcn_oracle_xorwow_uniform(uint64_t seed)
 }
 
 /* "int insrtidx = ceilf(curand_uniform(&state) * (n)) - 1;"  gridify.cu:150 */
+/* OpenMP team size of the loops over clouds / queries: min(work items, gridgcn_oracle_set_threads()
+ * or the OpenMP default).  A clause per region, so the calling process's own OpenMP settings
+ * (PyTorch-CPU shares the runtime) are left alone. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int g_oracle_threads = 0;
+void gridgcn_oracle_set_threads(int n) { g_oracle_threads = n; }
+static int oracle_threads(long long work)
+{
+    int t = g_oracle_threads;
+#ifdef _OPENMP
+    if (t <= 0) t = omp_get_max_threads();
+#else
+    t = 1;
+#endif
+    if ((long long)t > work) t = (int)work;
+    return t < 1 ? 1 : t;
+}
+int gridgcn_oracle_threads(long long work) { return oracle_threads(work); }
+
 static inline int reservoir_pick(uint64_t seed, int n)
 {
     float u = gridgcn_oracle_xorwow_uniform(seed);
@@ -177,6 +198,9 @@ int gridgcn_oracle_gridify(const float *data, const int *actual_numpoints, int B
     const int G = grid[0] * grid[1] * grid[2];
     const int size = ksz * ksz * ksz;
     const int gxy = grid[0] * grid[1];
+    /* clouds are independent (every kernel indexes i_batch = index / N): OpenMP across clouds only,
+     * the schedule S0 inside a cloud stays strictly sequential */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_threads(B))
     for (int b = 0; b < B; b++) {
         int *o_idx = nebidx + (size_t)b * O * P;
         float *o_msk = nebmsk + (size_t)b * O * P;
@@ -263,6 +287,9 @@ int gridgcn_oracle_gridify_knn(const float *data, const int *actual_numpoints, i
     if (P > 128) return 1; /* best[128] */
     const int G = grid[0] * grid[1] * grid[2];
     const int gxy = grid[0] * grid[1];
+    /* clouds are independent (every kernel indexes i_batch = index / N): OpenMP across clouds only,
+     * the schedule S0 inside a cloud stays strictly sequential */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_threads(B))
     for (int b = 0; b < B; b++) {
         int *o_idx = nebidx + (size_t)b * O * P;
         float *o_msk = nebmsk + (size_t)b * O * P;
@@ -367,11 +394,11 @@ int gridgcn_oracle_gridify_up(const float *downdata, const float *updata,
     const int size = ksz * ksz * ksz;
     memset(nebidx, 0, (size_t)B * O * P * sizeof(int));
     memset(nebmsk, 0, (size_t)B * O * P * sizeof(float));
-    int *cnt = (int *)malloc((size_t)G * sizeof(int));
-    int *bucket = (int *)malloc((size_t)G * P * sizeof(int));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_threads(B))
     for (int b = 0; b < B; b++) {
-        memset(cnt, 0, (size_t)G * sizeof(int));
-        memset(bucket, 0, (size_t)G * P * sizeof(int));          /* gridify_up.cu:284 */
+        /* per-cloud tables (the reference indexes one dense [B*G, P] table by i_batch) */
+        int *cnt = (int *)calloc((size_t)G, sizeof(int));
+        int *bucket = (int *)calloc((size_t)G * P, sizeof(int)); /* gridify_up.cu:284 */
         for (int i = 0; i < Nd; i++) {
             if (!(i < down_np[b])) continue;
             int index = b * Nd + i;
@@ -414,8 +441,8 @@ int gridgcn_oracle_gridify_up(const float *downdata, const float *updata,
                 }
             }
         }
+        free(cnt); free(bucket);
     }
-    free(cnt); free(bucket);
     return 0;
 }
 
@@ -427,6 +454,8 @@ int gridgcn_oracle_ball_knn(const float *unknown, const float *known, const int 
 {
     if (topk > 6) return 1; /* best[6] */
     float r2 = radius * radius;
+    /* queries are independent: what mxnet_op::Kernel<..., cpu>::Launch does upstream */
+#pragma omp parallel for schedule(static) num_threads(oracle_threads(B * n))
     for (int i = 0; i < B * n; i++) {
         int b = i / n;
         int downnum_val = downnum[b], upnum_val = upnum[b];
@@ -459,8 +488,9 @@ int gridgcn_oracle_ball_knn(const float *unknown, const float *known, const int 
 int gridgcn_oracle_knn(const float *unknown, const float *known, const int *downnum,
                        const int *upnum, int B, int n, int m, int topk, int *idx_out)
 {
-    float *best = (float *)malloc(sizeof(float) * (size_t)topk);
-    int *besti = (int *)malloc(sizeof(int) * (size_t)topk);
+    if (topk > 64) return 1; /* the HIP operator's limit as well */
+    /* queries are independent: what mxnet_op::Kernel<..., cpu>::Launch does upstream */
+#pragma omp parallel for schedule(static) num_threads(oracle_threads(B * n))
     for (int i = 0; i < B * n; i++) {
         int b = i / n;
         int downnum_val = downnum[b], upnum_val = upnum[b];
@@ -469,6 +499,7 @@ int gridgcn_oracle_knn(const float *unknown, const float *known, const int *down
         const float *un = unknown + (size_t)i * 3;
         int *idx = idx_out + (size_t)i * topk;
         float ux = un[0], uy = un[1], uz = un[2];
+        float best[64]; int besti[64];                 /* per query (k_nn-inl.h: new[] per thread) */
         for (int l = 0; l < topk; l++) { best[l] = FLT_MAX; besti[l] = -1; }
         for (int k = 0; k < downnum_val; ++k) {
             float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
@@ -484,7 +515,6 @@ int gridgcn_oracle_knn(const float *unknown, const float *known, const int *down
         }
         for (int l = 0; l < topk; l++) idx[l] = besti[l];
     }
-    free(best); free(besti);
     return 0;
 }
 

@@ -37,6 +37,14 @@ def _load():
     return _lib
 
 
+def threads_for(work):
+    """OpenMP team size the oracle uses for a loop of `work` independent clouds / queries."""
+    lib = _load()
+    lib.gridgcn_oracle_threads.restype = ctypes.c_int
+    lib.gridgcn_oracle_threads.argtypes = [ctypes.c_longlong]
+    return int(lib.gridgcn_oracle_threads(int(work)))
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
