@@ -53,11 +53,15 @@ __device__ __forceinline__ int gg_wave_incl_max(int v)
 //   D  ids of the first min(M,P) items (:251-258) and of the centre voxel's own points
 //   E  their weights (skipped when every weight of the cloud is 1) and the own-voxel points
 //   F  reservoir past P (:260-268), total weight, padding (:275-279), centre (:280-289)
-// grid = ceil(B*O / (4*NC)) workgroups of 4 independent waves; dynamic LDS = 4 * NC *
+// grid = B * ceil(O / (4*NC)) workgroups of 4 independent waves; dynamic LDS = 4 * NC *
 // (GG_QCS + 2*k^3 + 1 + 3*P + 64) ints.
+// XCD-aware mapping: workgroup w runs on XCD w % 8 (observed dispatch order; only speed depends on
+// it).  With B a multiple of 8 all workgroups of an XCD work on the clouds b = XCD (mod 8), so the
+// voxel table, the sorted ids and the points a cloud's centres share stay in ONE 4 MB L2 instead
+// of being fetched into all eight (cfg5: 92 MB fetched by this kernel with the linear mapping).
 template <int NC>
 __global__ __launch_bounds__(64 * GG_QW) void gg_k_query_gridify(
-    const float4 *__restrict__ data, int N, GGGrid gp, GGQueryPtrs q, int ncent,
+    const float4 *__restrict__ data, int N, GGGrid gp, GGQueryPtrs q, int B,
     int *__restrict__ nebidx, float *__restrict__ nebmsk, float4 *__restrict__ cent,
     float *__restrict__ centmsk)
 {
@@ -72,18 +76,28 @@ __global__ __launch_bounds__(64 * GG_QW) void gg_k_query_gridify(
     int *s_slotid = s_slotg + NC * P;        // [NC][P]
     float *s_curw = (float *)(s_slotid + NC * P);   // [NC][P]
     float *s_mem = s_curw + NC * P;          // [NC][16][4] w*x, w*y, w*z, w of the own-voxel points
-    const int cbase = (blockIdx.x * GG_QW + wave) * NC;
+    const int wgpc = (gp.O + GG_QW * NC - 1) / (GG_QW * NC);  // workgroups per cloud
+    int wb, wg;
+    if ((B & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        wb = (j / wgpc) * 8 + xcd;
+        wg = j % wgpc;
+    } else {
+        wb = blockIdx.x / wgpc;
+        wg = blockIdx.x % wgpc;
+    }
+    const int o0 = (wg * GG_QW + wave) * NC;       // first centre slot of this wave in cloud wb
+    const int cbase = wb * gp.O + o0;
     GG_STAMP(3, blockIdx.x, 0);
-    if (cbase >= ncent) return;
+    if (o0 >= gp.O) return;
 
     // ---- A ----
     if (lane < NC) {
         const int index = cbase + lane;
         int c3[3] = {0, 0, 0};
-        int b = 0, state = 0, ex = 0;  // state 0: beyond B*O, 1: empty slot (fill values), 2: centre
-        if (index < ncent) {
-            b = index / gp.O;
-            const int o = index - b * gp.O;
+        int b = wb, state = 0, ex = 0;  // state 0: beyond the cloud's O slots, 1: empty slot (fill values), 2: centre
+        if (o0 + lane < gp.O) {
+            const int o = o0 + lane;
             const int cn = q.centnum[b];
             const int sf = q.slotfirst1[index];
             ex = q.exact[b];
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(64 * GG_QW) void gg_k_query_gridify(
     //      ascending point id with separate multiply and add (:155-162, :280-289); lane c sums
     //      the points of centre c (the common case of <= 16 points), all centres at once ----
     bool big = false;
-    if (lane < NC && cbase + lane < ncent) {
+    if (lane < NC && o0 + lane < gp.O) {
         const int index = cbase + lane;
         const int *ct = s_ctr + lane * GG_QCS;
         if (ct[4] == 2) {
@@ -555,17 +569,17 @@ int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, c
     int NC = 1;
     if (gp.k3 <= 64) NC = ncent > 65536 ? 4 : (ncent > 16384 ? 2 : 1);
     const int per = GG_QW * NC;
-    const unsigned grid = (unsigned)((ncent + per - 1) / per);
+    const unsigned grid = (unsigned)B * (unsigned)((gp.O + per - 1) / per);
     const size_t lds = gg_query_lds(NC, gp.k3, gp.P);
     const float4 *d4 = (const float4 *)data;
     if (NC == 4)
-        gg_k_query_gridify<4><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, (int)ncent, nebidx, nebmsk,
+        gg_k_query_gridify<4><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, B, nebidx, nebmsk,
                                                              (float4 *)cent, centmsk);
     else if (NC == 2)
-        gg_k_query_gridify<2><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, (int)ncent, nebidx, nebmsk,
+        gg_k_query_gridify<2><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, B, nebidx, nebmsk,
                                                              (float4 *)cent, centmsk);
     else
-        gg_k_query_gridify<1><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, (int)ncent, nebidx, nebmsk,
+        gg_k_query_gridify<1><<<grid, 64 * GG_QW, lds, st>>>(d4, N, gp, q, B, nebidx, nebmsk,
                                                              (float4 *)cent, centmsk);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
