@@ -253,6 +253,35 @@ def test_seg_model_with_gridify_knn_matches_cpu_oracle_model():
     assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu)))
 
 
+def test_seg_model_gridify_up_variant_matches_cpu_oracle_model():
+    """the up path through GridifyUp (up_neigh_fetch: False, ggcn_models_g.py:206-210) on the GPU:
+    HIP GridifyUp + training kernels == the CPU model with the oracle's GridifyUp + stock ops (the
+    model seeds every call from call_seed(), identically on both sides)."""
+    import copy
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(3)
+    cfg = dict(model.SEG_8192, dropout=0.0, up_neigh_fetch=False)
+    net_cpu = model.GGCNSeg(cfg, index_ops=OracleIndexOps).train()
+    net_gpu = model.GGCNSeg(cfg)
+    net_gpu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    net_gpu = net_gpu.to(DEV).train()
+    data, npn = synth.make_batch(2, 8192, "planes")     # GridifyUp: M = max_o_grid of the up layer
+    npn[1, 0] = 7000
+    x = torch.from_numpy(data[..., :3].copy())
+    n = torch.from_numpy(npn)
+    lab = torch.randint(0, 21, (2, 8192))
+    for step in range(2):                      # second forward: the per-call seeds have moved on
+        loss_cpu = model.seg_loss(net_cpu(x, n), lab)
+        loss_gpu = model.seg_loss(net_gpu(x.to(DEV), n.to(DEV)), lab.to(DEV))
+        assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu))), step
+    net_cpu.zero_grad(); net_gpu.zero_grad()
+    loss_cpu.backward()
+    loss_gpu.backward()
+    a = torch.cat([p.grad.reshape(-1) for p in net_gpu.parameters()]).cpu().double()
+    b = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    assert float((a - b).norm() / b.norm()) < 1e-2
+
+
 @pytest.mark.parametrize("cfgname,npts", [("SEG_8192", (2048, 1311)), ("SEG_81920", (3000, 4096))])
 def test_seg_model_ragged_batch_matches_cpu_oracle_model(cfgname, npts):
     """clouds of different size in one batch (actual_numpoints < N for one of them): training loss and
@@ -350,3 +379,34 @@ def test_att_max_eval_kernel_equals_two_kernel_path(cin, C, O, P):
     scale = max(1.0, float(ref.abs().max()))
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
     assert float((outs[0] - ref).abs().max()) <= 5e-5 * scale
+
+
+def test_synth200k_model_matches_cpu_oracle_model():
+    """BASELINE configs[4] workload (model_synth.GGCNSynth: 4 GridConv layers, 64^3..8^3 grids) at a
+    reduced batch: HIP index ops + training kernels == the CPU model with the oracle's index ops +
+    stock ops; loss, every layer's features and the gradient."""
+    import copy
+    from oracle.torch_index_ops import OracleIndexOps
+    from grid_gcn_amd import model_synth
+    torch.manual_seed(4)
+    net_cpu = model_synth.GGCNSynth(index_ops=OracleIndexOps).train()
+    net_gpu = model_synth.GGCNSynth()
+    net_gpu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    net_gpu = net_gpu.to(DEV).train()
+    data, npn = synth.make_batch(1, 200000, "planes", first_id=60)
+    x = torch.from_numpy(data[..., :3].copy())
+    n = torch.from_numpy(npn)
+    lab = torch.randint(0, 40, (1,))
+    lc, oc = net_cpu(x, n, return_layers=True)
+    lg, og = net_gpu(x.to(DEV), n.to(DEV), return_layers=True)
+    for i, (a, b) in enumerate(zip(og, oc)):
+        err = float((a.detach().cpu() - b.detach()).abs().max())
+        assert err <= 2e-3 * max(1.0, float(b.detach().abs().max())), (i, err)
+    loss_cpu = model_synth.synth_loss(lc, lab)
+    loss_gpu = model_synth.synth_loss(lg, lab.to(DEV))
+    assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu)))
+    loss_cpu.backward()
+    loss_gpu.backward()
+    a = torch.cat([p.grad.reshape(-1) for p in net_gpu.parameters()]).cpu().double()
+    b = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    assert float((a - b).norm() / b.norm()) < 2e-2

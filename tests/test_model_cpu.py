@@ -138,3 +138,116 @@ def test_bn_decay_schedule_and_setter():
     model.set_bn_decay(net, 0.775)
     moms = {m.momentum for m in net.modules() if isinstance(m, torch.nn.BatchNorm1d)}
     assert len(moms) == 1 and abs(moms.pop() - 0.225) < 1e-12
+
+
+# ---- bench.py's step() wiring under data parallelism (2 processes, gloo) ------------------------
+TINY_GRID = dict(
+    num_points=512, coord_shift=[1.0, 1.0, 1.0], loc=1,
+    down=[dict(voxel_size=[0.2] * 3, grid_size=[10] * 3, kernel_size=3, max_p_grid=8, max_o_grid=64),
+          dict(voxel_size=[0.4] * 3, grid_size=[5] * 3, kernel_size=3, max_p_grid=8, max_o_grid=16),
+          dict(voxel_size=[1.0] * 3, grid_size=[2] * 3, kernel_size=3, max_p_grid=8, max_o_grid=4)],
+    up=[dict(voxel_size=[1.0] * 3, grid_size=[2] * 3, kernel_size=3, max_p_grid=3, max_o_grid=16),
+        dict(voxel_size=[0.4] * 3, grid_size=[5] * 3, kernel_size=3, max_p_grid=3, max_o_grid=64),
+        dict(voxel_size=[0.2] * 3, grid_size=[10] * 3, kernel_size=3, max_p_grid=3, max_o_grid=512)])
+TINY_SEG = dict(grid=TINY_GRID, inputDim=[0, 16, 32], pt_ele_dim=[[8, 16], [16, 32], [32, 64]],
+                localfdim=3, relu=False, up_inputDim=[64, 32, 32], up_center_dim=[[16]] * 3,
+                up_pt_ele_dim=[[32]] * 3, up_gcn_outDim=[[32]] * 3, up_neigh_fetch=True,
+                num_classes=5, bn_decay=0.9, dropout=0.0)
+
+
+def _tiny_shard(rank, S=2, N=512):
+    from grid_gcn_amd import synth
+    data, npn = synth.make_batch(S, N, "planes", first_id=300 + rank * S)
+    g = torch.Generator().manual_seed(900 + rank)
+    lab = torch.randint(0, 5, (S, N), generator=g)
+    return torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn), lab
+
+
+def _tiny_net(seed):
+    from grid_gcn_amd import model
+    torch.manual_seed(seed)
+    return model.GGCNSeg(TINY_SEG, index_ops=OracleIndexOps, seed=0, fixed_seed=True).train()
+
+
+def _step_worker(rank, world, port, q, nsteps):
+    from grid_gcn_amd import model
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _tiny_net(200 + rank)                      # different init per rank: broadcast must fix it
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    sync = dp.FlatGradAllReduce(net)
+    sync.broadcast_parameters()
+    x, n, lab = _tiny_shard(rank)
+
+    def step():                                       # == bench.py's step()
+        opt.zero_grad(set_to_none=True)
+        loss = model.seg_loss(net(x, n), lab)
+        loss.backward()
+        sync()
+        opt.step()
+        return loss
+
+    g1 = None
+    for s in range(nsteps):
+        step()
+        if s == 0:
+            g1 = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+        # gradients have become views of the flat bucket (no scatter-back copies)
+        base = sync.flat.untyped_storage().data_ptr()
+        assert all(p.grad.untyped_storage().data_ptr() == base for p in net.parameters())
+    q.put((rank, g1.numpy(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()))
+    dist.destroy_process_group()
+
+
+def test_dp_step_wiring_gloo_world2():
+    """bench.py's step() -- model + FlatGradAllReduce (gradients as views of the flat bucket) +
+    Adam + zero_grad(set_to_none=True) -- on two gloo ranks, each owning a 2-cloud shard:
+    (1) the first step's synchronised gradient == mean of the shard gradients computed in ONE process,
+    (2) after 3 steps the parameters equal those of the single process applying Adam to the averaged
+        gradients, and (3) they are bitwise identical on both ranks."""
+    from grid_gcn_amd import model
+    nsteps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, q, nsteps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        r, g1, par = q.get(timeout=600)
+        res[r] = (g1, par)
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert res[0][1].tobytes() == res[1][1].tobytes(), "parameters diverged across ranks"
+    assert res[0][0].tobytes() == res[1][0].tobytes(), "synchronised gradients differ across ranks"
+    # single-process emulation: BatchNorm statistics per shard (per device in the reference, too)
+    net = _tiny_net(200)                              # rank 0's weights == what the broadcast gives
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    shards = [_tiny_shard(r) for r in range(2)]
+    params = list(net.parameters())
+    g_first = None
+    for s in range(nsteps):
+        acc = [torch.zeros_like(p) for p in params]
+        for x, n, lab in shards:
+            opt.zero_grad(set_to_none=True)
+            model.seg_loss(net(x, n), lab).backward()
+            for a, p in zip(acc, params):
+                if p.grad is not None:
+                    a += p.grad
+        for a, p in zip(acc, params):
+            p.grad = a / 2
+        if s == 0:
+            g_first = torch.cat([p.grad.reshape(-1) for p in params]).numpy()
+        opt.step()
+    gmax = float(np.abs(g_first).max())
+    np.testing.assert_allclose(res[0][0], g_first, rtol=1e-4, atol=2e-6 * gmax)
+    want = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
+    # Adam divides by sqrt(v): where the gradient is far from zero the update is well conditioned and
+    # the parameters must agree closely; near-zero gradients (fp32 summation-order noise decides
+    # their sign) may differ by up to one full update lr per step
+    stable = np.abs(g_first) > 1e-3 * gmax
+    np.testing.assert_allclose(res[0][1][stable], want[stable], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(res[0][1], want, rtol=0, atol=2.1e-3 * nsteps)
