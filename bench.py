@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from grid_gcn_amd import dp, model, model_cls, ops, synth  # noqa: E402
+from grid_gcn_amd import dp, graph, model, model_cls, ops, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32, dense
@@ -79,6 +79,29 @@ def cpu_baseline(cfg, B, points, kind, sample_clouds):
             "cagq_threads": cagq_threads,
             "cagq_sample": "Gridify down layer 0 on the same %d-cloud batch, OpenMP across clouds "
                            "(%d threads), mean of 3 calls" % (B, cagq_threads)}
+
+
+def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
+    """The timed step.  Default: one captured hipGraph (two around the all-reduce for N > 1) --
+    grid_gcn_amd/graph.py -- so that the result does not depend on how fast the host enqueues ~350
+    launches; the GPU work of a replay is that of the eager step, launch for launch, with the
+    random draws still fresh per step (device-side seed).  Falls back to the eager step when the
+    capture fails; `step_mode` in the JSON line says which one was timed."""
+    def eager():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(net(*inputs), target)
+        loss.backward()
+        sync()
+        opt.step()
+        return loss
+
+    if use_graph:
+        try:
+            return graph.GraphedTrainStep(net, opt, loss_fn, inputs, target, sync), "hipgraph"
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("graph capture failed (%s: %s); timing the eager step\n" % (type(e).__name__, e))
+            net.seed_dev = None
+    return eager, "eager"
 
 
 def time_training(step, steps, warmup, world, dev):
@@ -130,6 +153,7 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="points per cloud (0: the config's own)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="clouds of the CPU fwd+bwd sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="time the eager step instead of the hipGraph replay")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +172,7 @@ def main():
 
     if a.config != "cfg4":
         import bench_configs
-        out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline)
+        out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step)
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
@@ -163,21 +187,15 @@ def main():
     net = model.GGCNSeg(cfg, seed=rank).to(dev)
     net.train()
     # one multi-tensor kernel for the whole update instead of ~10 tiny launches per parameter
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True,
+                           capturable=not a.eager)
     sync = dp.FlatGradAllReduce(net)
     sync.broadcast_parameters()
     data, npn = synth.make_batch(B, points, kind, first_id=rank * B)   # a different shard per rank
     x = torch.from_numpy(data[..., :3].copy()).to(dev)
     n = torch.from_numpy(npn).to(dev)
     lab = torch.randint(0, cfg["num_classes"], (B, points), device=dev)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = model.seg_loss(net(x, n), lab)
-        loss.backward()
-        sync()
-        opt.step()
-        return loss
+    step, step_mode = make_step(net, opt, sync, model.seg_loss, (x, n), lab, not a.eager)
 
     dt, t_enq = time_training(step, a.steps, a.warmup, world, dev)
     ms_step = dt / a.steps * 1e3
@@ -189,7 +207,7 @@ def main():
         "metric": "point-clouds/sec fwd+bwd (ScanNet 81920-pt)", "value": world * B * a.steps / dt,
         "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "step_mode": step_mode,
         "config": {"workload": "BASELINE configs[3]: ScanNet %d-pt segmentation, batch %d per GPU, "
                                "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (points, B),
                    "global_batch": world * B, "points_per_cloud": points,

@@ -23,7 +23,7 @@ def _line(metric, value, unit, a, world, ms_step, workload, extra):
     return out
 
 
-def run(a, world, rank, dev, traffic, time_training, cagq_roofline):
+def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step):
     torch.manual_seed(0)
     if a.config == "cfg1":
         # latency of one CAGQ layer on one cloud: the reference's CPU-runnable case
@@ -71,23 +71,17 @@ def run(a, world, rank, dev, traffic, time_training, cagq_roofline):
         metric = "point-clouds/sec fwd+bwd (synthetic 200k-pt, 4-layer GridConv)"
         flops = 3.0 * model_synth.forward_flops(net, B)
 
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True,
+                           capturable=not a.eager)
     sync = dp.FlatGradAllReduce(net)
     sync.broadcast_parameters()
     x = torch.from_numpy(data[..., :3].copy()).to(dev)
     n = torch.from_numpy(npn).to(dev)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = loss_fn(net(x, n), lab)
-        loss.backward()
-        sync()
-        opt.step()
-        return loss
+    step, step_mode = make_step(net, opt, sync, loss_fn, (x, n), lab, not a.eager)
 
     dt, t_enq = time_training(step, a.steps, a.warmup, world, dev)
     ms_step = dt / a.steps * 1e3
-    extra = {"host_enqueue_ms_per_step": t_enq / a.steps * 1e3}
+    extra = {"host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "step_mode": step_mode}
     extra["config_extra"] = {"global_batch": world * B, "points_per_cloud": N}
     if flops is not None:
         tf = flops / (ms_step * 1e-3) / 1e12

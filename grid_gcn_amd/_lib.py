@@ -39,7 +39,7 @@ class GridParams(ctypes.Structure):
                 ("kernel_size", ctypes.c_int32), ("stride", ctypes.c_int32),
                 ("loc", ctypes.c_int32), ("coord_shift", ctypes.c_float * 3),
                 ("voxel_size", ctypes.c_float * 3), ("grid_size", ctypes.c_int32 * 3),
-                ("seed", ctypes.c_uint64)]
+                ("seed", ctypes.c_uint64), ("seed_dev", ctypes.c_void_p)]
 
 
 class ConvLayer(ctypes.Structure):
@@ -114,10 +114,10 @@ def load():
     lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, vp]
     lib.gridgcn_bn_relu_dropout_apply.restype = ci
     lib.gridgcn_bn_relu_dropout_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, ctypes.c_float,
-                                                  ctypes.c_uint64, vp]
+                                                  ctypes.c_uint64, vp, vp]
     lib.gridgcn_linear_dx.restype = ci
     lib.gridgcn_linear_dx.argtypes = [vp] * 14 + [ci, ll, ci, ci, ci, ctypes.c_float,
-                                                  ctypes.c_uint64, vp, vp, vp]
+                                                  ctypes.c_uint64, vp, vp, vp, vp]
     lib.gridgcn_bn_relu_bwd_reduce.restype = ci
     lib.gridgcn_bn_relu_bwd_reduce.argtypes = [vp, vp, vp, vp, vp, vp, ll, ci, ci, vp, vp]
     lib.gridgcn_bn_relu_bwd_elemt.restype = ci

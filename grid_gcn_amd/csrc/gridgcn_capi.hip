@@ -93,6 +93,7 @@ static int fill_grid(const gridgcn_grid_params *p, int B, int N, bool up, GGGrid
     gp->k3 = (int)k3;
     gp->loc = p->loc;
     gp->seed = p->seed;
+    gp->seed_dev = (const unsigned long long *)p->seed_dev;
     return GRIDGCN_OK;
 }
 
@@ -109,7 +110,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 1; }
+int gridgcn_abi_version(void) { return 2; }
 
 int gridgcn_gridify_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes)
 {
@@ -326,7 +327,7 @@ int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const
                       const float *Aprev, const float *pscale, const float *pshift,
                       const float *pmean, const float *prstd, const float *Wdx, int ndx,
                       long long E, int C, int cin, int ldy, float drop_p, uint64_t drop_seed,
-                      float *dX, double *psums, void *stream)
+                      const uint64_t *drop_seed_dev, float *dX, double *psums, void *stream)
 {
     if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Wdx || !dX)
         return GRIDGCN_EINVAL;
@@ -340,17 +341,19 @@ int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const
     p.P = 1; p.Wdx = Wdx; p.ndx = ndx; p.cin_w = cin; p.ldy = ldy;
     gg_drop_consts(drop_p, &p.drop_thr, &p.drop_scale);
     p.drop_lo = (unsigned)drop_seed; p.drop_hi = (unsigned)(drop_seed >> 32);
+    p.drop_dev = (const unsigned long long *)drop_seed_dev;
     const int rc = gg_linear_dx_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
 int gridgcn_bn_relu_dropout_apply(const float *Z, const float *scale, const float *shift, float *Y,
                                   long long E, int C, int ldy, float drop_p, uint64_t drop_seed,
-                                  void *stream)
+                                  const uint64_t *drop_seed_dev, void *stream)
 {
     if (!Z || !scale || !shift || !Y || E < 1 || C < 1 || ldy < C) return GRIDGCN_EINVAL;
     if (!(drop_p >= 0.f && drop_p < 1.f)) return GRIDGCN_EINVAL;
-    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, drop_p, drop_seed, (hipStream_t)stream);
+    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, drop_p, drop_seed,
+                       (const unsigned long long *)drop_seed_dev, (hipStream_t)stream);
 }
 
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
@@ -402,7 +405,7 @@ int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift
                           long long E, int C, int ldy, void *stream)
 {
     if (!Z || !scale || !shift || !Y || E < 1 || C < 1 || ldy < C) return GRIDGCN_EINVAL;
-    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, 0.f, 0ull, (hipStream_t)stream);
+    return gg_bn_apply(Z, scale, shift, Y, E, C, ldy, 0.f, 0ull, nullptr, (hipStream_t)stream);
 }
 
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,

@@ -16,7 +16,15 @@ struct GGGrid {
     int gxy;   // g0*g1
     int P, O, k, k3, loc;
     unsigned long long seed;
+    const unsigned long long *seed_dev;  // optional device scalar added to `seed` (graph replay)
 };
+
+// effective sampling seed of the call: seed (+ *seed_dev when a device scalar is given, so that a
+// captured hipGraph draws a fresh sample at every replay)
+__device__ __forceinline__ unsigned long long gg_seed(const GGGrid &gp)
+{
+    return gp.seed_dev ? gp.seed + *gp.seed_dev : gp.seed;
+}
 
 // cuRAND XORWOW curand_init(seed,0,0) + first curand_uniform (gridify.cu:149-150).
 // Restated integer-for-integer; rocRAND's XORWOW uses different scramble constants.

@@ -245,6 +245,12 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int C = p.C, h = lane >> 5, ldx = p.cin;
+    unsigned drop_lo = p.drop_lo, drop_hi = p.drop_hi;
+    if (p.drop_thr && p.drop_dev) {  // graph replay: the dropout seed advances through a device scalar
+        const unsigned long long sd = (((unsigned long long)drop_hi << 32) | drop_lo) + *p.drop_dev;
+        drop_lo = (unsigned)sd;
+        drop_hi = (unsigned)(sd >> 32);
+    }
     float *Wl = lds;                              // [C/2 steps][64][NTV]
     float *cst = lds + C * 32 * NTV;              // scale, shift, mean, bz, cz  [5][C]
     {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                         const int off = rr * ldx + t * 32;
                         float dx = acc[t][r];
                         if (p.drop_thr)   // the input activation went through Dropout (gg_k_bn_apply)
-                            dx = gg_drop_keep((unsigned long long)(base + off), p.drop_lo, p.drop_hi,
+                            dx = gg_drop_keep((unsigned long long)(base + off), drop_lo, drop_hi,
                                               p.drop_thr) ? dx * p.drop_scale : 0.f;
                         xp[off] = dx;
                         if (prevbn) {

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
                         int sl = n;
                         if (n >= gp.P) {
                             const int gi = (int)((long long)b * N + id);
-                            sl = gg_reservoir_pick((unsigned long long)(long long)gi + gp.seed,
+                            sl = gg_reservoir_pick((unsigned long long)(long long)gi + gg_seed(gp),
                                                    n + 1);
                         }
                         if (sl < gp.P) atomicMax(&a.bkt[gbase + vo + sl], id);
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(GG_NT3) void gg_k_centre_slots(
             int sl = t;
             if (t >= gp.O) {
                 const int gi = (int)((long long)b * N + id);
-                sl = gg_reservoir_pick((unsigned long long)(long long)gi + 2ull * gp.seed, t + 1);
+                sl = gg_reservoir_pick((unsigned long long)(long long)gi + 2ull * gg_seed(gp), t + 1);
             }
             if (sl < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + sl], id + 1);
         }

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void gg_k_rank(int N, GGGrid gp, const int *_
                 // (gridify.cu:146-153).  Last writer = largest n = largest point id.
                 int s = n;
                 if (n >= gp.P)
-                    s = gg_reservoir_pick((unsigned long long)(long long)(int)i + gp.seed, n + 1);
+                    s = gg_reservoir_pick((unsigned long long)(long long)(int)i + gg_seed(gp), n + 1);
                 if (s < gp.P) atomicMax(&bkt[o + s], ip);
             }
             is_lead = (n == 0);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(1024) void gg_k_centres(int N, GGGrid gp,
         int t = t0 + wbase + pre;
         int s = t;
         if (t >= gp.O)
-            s = gg_reservoir_pick((unsigned long long)(long long)(int)i + 2ull * gp.seed, t + 1);
+            s = gg_reservoir_pick((unsigned long long)(long long)(int)i + 2ull * gg_seed(gp), t + 1);
         if (s < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + s], ip + 1);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {

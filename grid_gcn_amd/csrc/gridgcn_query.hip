@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ u
             // the scatter thread of this (point, voxel) pair used offset index nei' with
             // own_voxel + offset(nei') = query voxel, i.e. the mirror of `lo`
             long long threadindex = ((long long)b * Nd + id) * k3 + (k3 - 1 - lo);
-            s = gg_reservoir_pick(gp.seed + (unsigned long long)threadindex, n + 1);
+            s = gg_reservoir_pick(gg_seed(gp) + (unsigned long long)threadindex, n + 1);
         }
         if (s < P) atomicMax(&s_slot[s], id);
     }

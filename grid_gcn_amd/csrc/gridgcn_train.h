@@ -39,6 +39,7 @@ struct GGLinBwd {
     const int *amax;      // sparse upstream gradient (nullptr: dense dY): arg-max neighbour [E/P][C]
     const float *gval;    //   and its value [E/P][C]; row e = centre e/P, neighbour e%P
     int P, ncen_max;
+    const unsigned long long *drop_dev;    // optional device scalar added to the dropout seed
     unsigned drop_thr, drop_lo, drop_hi;   // register-direct dX only: dX *= dropout mask of the
     float drop_scale;                      // [E][cin] input activation (gg_drop_keep), thr 0 = off
     int rt;               // rows per workgroup tile of gg_k_linear_dw (32/64/96/128)
@@ -56,7 +57,8 @@ size_t gg_att_bwd_fused_workspace(long long E, int cin, int C);
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
-                int C, int ldy, float drop_p, unsigned long long seed, hipStream_t st);
+                int C, int ldy, float drop_p, unsigned long long seed,
+                const unsigned long long *seed_dev, hipStream_t st);
 void gg_drop_consts(float p, unsigned *thr, float *dscale);
 int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const float *shift,
                      const float *mean, const float *rstd, long long E, int C, double *sums,

@@ -1093,8 +1093,14 @@ __global__ __launch_bounds__(256) void gg_k_bn_apply(const float *__restrict__ Z
                                                      const float *__restrict__ shift,
                                                      float *__restrict__ Y, long long total, int C,
                                                      int ldy, unsigned thr, float dscale,
-                                                     unsigned slo, unsigned shi)
+                                                     unsigned slo, unsigned shi,
+                                                     const unsigned long long *__restrict__ sdev)
 {
+    if (sdev) {  // graph replay: the seed advances through a device scalar
+        const unsigned long long sd = (((unsigned long long)shi << 32) | slo) + *sdev;
+        slo = (unsigned)sd;
+        shi = (unsigned)(sd >> 32);
+    }
     // thr != 0: Dropout behind the ReLU (mx.sym.Dropout, ggcn_models_g.py:36): kept values * dscale
     if ((C & 3) == 0 && (ldy & 3) == 0) {
         const long long n4 = total >> 2;
@@ -1213,14 +1219,15 @@ void gg_drop_consts(float p, unsigned *thr, float *dscale)
 }
 
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
-                int C, int ldy, float drop_p, unsigned long long seed, hipStream_t st)
+                int C, int ldy, float drop_p, unsigned long long seed,
+                const unsigned long long *seed_dev, hipStream_t st)
 {
     long long total = E * C;
     unsigned thr;
     float ds;
     gg_drop_consts(drop_p, &thr, &ds);
     gg_k_bn_apply<<<grid_for(total / 4 + 1, 256, 65536), 256, 0, st>>>(
-        Z, scale, shift, Y, total, C, ldy, thr, ds, (unsigned)seed, (unsigned)(seed >> 32));
+        Z, scale, shift, Y, total, C, ldy, thr, ds, (unsigned)seed, (unsigned)(seed >> 32), seed_dev);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

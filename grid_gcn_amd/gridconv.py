@@ -263,15 +263,16 @@ class SubGUpdate(nn.Module):
                 if self.tail_head is not None and self.mfma_train and agg.is_cuda and \
                         self.training and torch.is_grad_enabled():
                     from . import train_ops
-                    p, lin = self.tail_head
+                    p, lin = self.tail_head[:2]
                     if train_ops.head_supported(agg, layers, lin):
                         # ... and the Dropout + class-score Linear behind them (train_ops._HeadTrain)
                         self.tail_done = 2
-                        return train_ops.head_train(agg, layers, p, lin)
+                        seed_dev = self.tail_head[2] if len(self.tail_head) > 2 else None
+                        return train_ops.head_train(agg, layers, p, lin, seed_dev=seed_dev)
                 if self.tail_head is not None and self.mfma_train and agg.is_cuda and \
                         not self.training and not torch.is_grad_enabled():
                     from . import train_ops
-                    p, lin = self.tail_head
+                    p, lin = self.tail_head[:2]
                     if train_ops.head_supported(agg, layers, lin) and \
                             all(l.lin.in_features <= 1024 for l in layers):
                         self.tail_done = 2              # evaluation: dropout is the identity

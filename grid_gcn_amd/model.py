@@ -70,6 +70,9 @@ class GGCNSeg(nn.Module):
         self.seed = seed
         self.fixed_seed = fixed_seed
         self.forward_no = 0
+        # int64 GPU scalar added to every sampling / dropout seed inside the kernels (None: off).
+        # graph.GraphedTrainStep sets and bumps it so that replays of ONE captured step still redraw
+        self.seed_dev = None
         g = cfg["grid"]
         nd = len(g["down"])
         self.down = nn.ModuleList()
@@ -127,8 +130,9 @@ class GGCNSeg(nn.Module):
         fwd_no = self.forward_no
         if self.training:
             self.forward_no += 1
+        sd = dict(seed_dev=self.seed_dev) if (self.seed_dev is not None and _is_hip(ix)) else {}
         for i, layer in enumerate(self.down):
-            kw = synth.gridify_kwargs(g, i, self._seed(fwd_no, i))
+            kw = dict(synth.gridify_kwargs(g, i, self._seed(fwd_no, i)), **sd)
             nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
                 data_loc.detach().contiguous(), nums[-1], **kw)                     # :154-159
             data_loc = cent
@@ -146,7 +150,7 @@ class GGCNSeg(nn.Module):
         f_last = feats[-1]
         nup = len(self.up)
         object.__setattr__(self.up[-1], "tail_head",
-                           (cfg["dropout"], self.fc2) if self.fused_head else None)
+                           (cfg["dropout"], self.fc2, self.seed_dev) if self.fused_head else None)
         for i, layer in enumerate(self.up):
             down, upl = locs[-i - 1], locs[-i - 2]
             downnum, upnum = nums[-i - 1], nums[-i - 2]
@@ -159,7 +163,8 @@ class GGCNSeg(nn.Module):
             else:
                 nebidx, _ = ix.GridifyUp(down.detach().contiguous(), upl.detach().contiguous(),
                                          downnum, upnum,
-                                         **synth.gridify_up_kwargs(g, i, self._seed(fwd_no, 16 + i)))  # :206-210
+                                         **synth.gridify_up_kwargs(g, i, self._seed(fwd_no, 16 + i)),
+                                         **sd)  # :206-210
             f_this = feats[-i - 2]
             cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
             if self.use_fused():

@@ -88,6 +88,7 @@ class GGCNCls(nn.Module):
         self.cfg, self.ix, self.seed = cfg, index_ops, seed
         self.fixed_seed = fixed_seed
         self.forward_no = 0
+        self.seed_dev = None      # see GGCNSeg
         self._take_kw = (dict(neighbour_index=True)
                          if isinstance(index_ops, type) and issubclass(index_ops, HipIndexOps) else {})
         self.layers = nn.ModuleList(
@@ -112,8 +113,9 @@ class GGCNCls(nn.Module):
         for i, layer in enumerate(self.layers):
             seed = self.seed if (self.fixed_seed or not self.training) else \
                 call_seed(self.seed, fwd_no, i)
+            sd = dict(seed_dev=self.seed_dev) if (self.seed_dev is not None and self._take_kw) else {}
             nebidx, nebidxmsk, cent, centmsk, num = ix.Gridify(
-                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed))
+                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed), **sd)
             data_loc = cent
             neighbors = ix.batch_take_g(data.contiguous(), nebidx, **self._take_kw)  # :94
             cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104

@@ -27,6 +27,7 @@ class GGCNSynth(nn.Module):
         super().__init__()
         self.cfg, self.ix, self.seed, self.fixed_seed = cfg, index_ops, seed, fixed_seed
         self.forward_no = 0
+        self.seed_dev = None      # see GGCNSeg
         self.down = nn.ModuleList(
             SubGUpdate(cfg["inputDim"][i], cfg["pt_ele_dim"][i], cfg["localfdim"], cfg["relu"],
                        bn_decay=cfg["bn_decay"]) for i in range(len(cfg["grid"]["down"])))
@@ -49,8 +50,9 @@ class GGCNSynth(nn.Module):
         for i, layer in enumerate(self.down):
             seed = self.seed if (self.fixed_seed or not self.training) else \
                 call_seed(self.seed, fwd_no, i)
+            sd = dict(seed_dev=self.seed_dev) if (self.seed_dev is not None and _is_hip(ix)) else {}
             nebidx, _, cent, centmsk, num = ix.Gridify(
-                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed))
+                data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed), **sd)
             data_loc = cent
             if _is_hip(ix) and self.edge_kernel:
                 cf = layer.forward_src(cent, data_layer, nebidx, centmsk)

@@ -60,7 +60,7 @@ def _num(t, name, B):
 
 
 def _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size,
-            seed):
+            seed, seed_dev=None):
     p = _lib.GridParams()
     p.max_p_grid, p.max_o_grid, p.kernel_size = int(max_p_grid), int(max_o_grid), int(kernel_size)
     p.stride, p.loc = int(stride), int(loc)
@@ -71,6 +71,15 @@ def _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel
         p.voxel_size[j] = float(voxel_size[j])
         p.grid_size[j] = int(grid_size[j])
     p.seed = int(seed) & (2 ** 64 - 1)
+    # optional device scalar (int64 tensor) added to the seed when the kernels run: a captured
+    # hipGraph then draws a fresh sample at every replay (graph.GraphedTrainStep bumps it)
+    if seed_dev is not None:
+        _require(isinstance(seed_dev, torch.Tensor) and seed_dev.is_cuda and
+                 seed_dev.dtype == torch.int64 and seed_dev.numel() >= 1,
+                 "seed_dev must be an int64 GPU tensor")
+        p.seed_dev = seed_dev.data_ptr()
+    else:
+        p.seed_dev = None
     return p
 
 
@@ -88,14 +97,14 @@ def _workspace(nbytes, device):
 
 
 def _gridify_like(fn_name, data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, stride,
-                  loc, coord_shift, voxel_size, grid_size, seed):
+                  loc, coord_shift, voxel_size, grid_size, seed, seed_dev=None):
     lib = _lib.load()
     _chk(data, "data", 3, torch.float32, 4)
     B, N, _ = data.shape
     _num(actual_numpoints, "actual_numpoints", B)
     _require(actual_numpoints.device == data.device, "inputs must be on the same device")
     p = _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size,
-                grid_size, seed)
+                grid_size, seed, seed_dev)
     nbytes = ctypes.c_size_t(0)
     _lib.check(getattr(lib, fn_name + "_workspace_bytes")(B, N, ctypes.byref(p),
                                                           ctypes.byref(nbytes)), fn_name)
@@ -117,7 +126,7 @@ def _gridify_like(fn_name, data, actual_numpoints, max_p_grid, max_o_grid, kerne
 
 @torch.no_grad()
 def Gridify(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
-            coord_shift, voxel_size, grid_size, seed=0):
+            coord_shift, voxel_size, grid_size, seed=0, seed_dev=None):
     """Coverage-aware grid query with random voxel sampling (RVS).
 
     data [B,N,4] f32 (x,y,z,w), actual_numpoints [B,1] i32 ->
@@ -125,7 +134,8 @@ def Gridify(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stri
     actual_centnum [B,1] i32.  Reference: GridifyForward<gpu>, gridify.cu:294-413.
     """
     return _gridify_like("gridgcn_gridify", data, actual_numpoints, max_p_grid, max_o_grid,
-                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed)
+                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed,
+                         seed_dev)
 
 
 @torch.no_grad()
@@ -163,16 +173,17 @@ def gridify_timed(data, actual_numpoints, iters=50, *, max_p_grid, max_o_grid, k
 
 @torch.no_grad()
 def GridifyKNN(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
-               coord_shift, voxel_size, grid_size, seed=0):
+               coord_shift, voxel_size, grid_size, seed=0, seed_dev=None):
     """As Gridify, neighbours = exact top-P by distance to the voxel centre
     (GridifyKNNForward<gpu>, gridifyknn.cu:337-455)."""
     return _gridify_like("gridgcn_gridify_knn", data, actual_numpoints, max_p_grid, max_o_grid,
-                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed)
+                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed,
+                         seed_dev)
 
 
 @torch.no_grad()
 def GridifyUp(downdata, updata, down_actual_numpoints, up_actual_numpoints, *, max_p_grid,
-              max_o_grid, kernel_size, coord_shift, voxel_size, grid_size, seed=0):
+              max_o_grid, kernel_size, coord_shift, voxel_size, grid_size, seed=0, seed_dev=None):
     """downdata [B,Nd,4], updata [B,max_o_grid,4] -> nebidx [B,O,P] i32, nebidxmsk [B,O,P] f32.
     Reference: GridifyUpForward<gpu>, gridify_up.cu:229-323."""
     lib = _lib.load()
@@ -185,7 +196,8 @@ def GridifyUp(downdata, updata, down_actual_numpoints, up_actual_numpoints, *, m
              "gridify_up.cu:196)")
     _num(down_actual_numpoints, "down_actual_numpoints", B)
     _num(up_actual_numpoints, "up_actual_numpoints", B)
-    p = _params(max_p_grid, max_o_grid, kernel_size, 1, 0, coord_shift, voxel_size, grid_size, seed)
+    p = _params(max_p_grid, max_o_grid, kernel_size, 1, 0, coord_shift, voxel_size, grid_size, seed,
+                seed_dev)
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.gridgcn_gridify_up_workspace_bytes(B, Nd, ctypes.byref(p), ctypes.byref(nbytes)),
                "gridgcn_gridify_up")

@@ -1074,7 +1074,7 @@ class _HeadTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *params):
         lib = _lib.load()
-        eps, bns, p, seed = meta
+        eps, bns, p, seed, seed_dev = meta
         L = (len(params) - 2) // 4
         W2, b2 = params[4 * L], params[4 * L + 1]
         x = x.contiguous()
@@ -1089,7 +1089,8 @@ class _HeadTrain(torch.autograd.Function):
             Hd = torch.empty((E, C), dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_bn_relu_dropout_apply(
                 _ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]), _ptr(Hd), E, C, C,
-                float(p), int(seed), stream), "gridgcn_bn_relu_dropout_apply")
+                float(p), int(seed), _ptr(seed_dev) if seed_dev is not None else None, stream),
+                "gridgcn_bn_relu_dropout_apply")
             K, ldw, nwp, nwb = packed_sizes(C2, C)
             ntv = next(v for v in (1, 2, 4, 8) if v * 32 >= C)
             pk = torch.empty(ldw + nwb + C * ldw + Cp * 32 * ntv, dtype=torch.float32, device=dev)
@@ -1104,7 +1105,7 @@ class _HeadTrain(torch.autograd.Function):
                        "gridgcn_linear_fwd_direct")
         ctx.L = L
         ctx.ndx = st.ndx
-        ctx.drop = (float(p), int(seed))
+        ctx.drop = (float(p), int(seed), seed_dev)
         ctx.dims = (C2, Cp)
         ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg,
                               *st.Wdx, Hd, Z2, Wb, Wdx)
@@ -1140,7 +1141,8 @@ class _HeadTrain(torch.autograd.Function):
                 _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
                 _ptr(ident[4]), _ptr(ident[5]), _ptr(Zs[-1]), _ptr(scales[-1]), _ptr(shifts[-1]),
                 _ptr(means[-1]), _ptr(rstds[-1]), _ptr(Wdx2), C, E, Cp, C, Cp, ctx.drop[0],
-                ctx.drop[1], _ptr(dH), _ptr(sums), st), "gridgcn_linear_dx")
+                ctx.drop[1], _ptr(ctx.drop[2]) if ctx.drop[2] is not None else None,
+                _ptr(dH), _ptr(sums), st), "gridgcn_linear_dx")
             dW2 = torch.empty((Cp, C), dtype=torch.float32, device=dev)
             nbytes = ctypes.c_size_t(0)
             lib.gridgcn_linear_bwd_workspace_bytes(E, C, Cp, ctypes.byref(nbytes))
@@ -1162,19 +1164,22 @@ def head_supported(x, layers, lin):
             and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
 
 
-def head_train(x, layers, p, lin, seed=None):
+def head_train(x, layers, p, lin, seed=None, seed_dev=None):
     """x [..., cin] -> class scores [..., lin.out_features] through `layers` (ConvBNReLU modules in
     training mode), Dropout(p) and the Linear `lin`.  seed: dropout seed (None: drawn from torch's
-    CPU generator, i.e. reproducible under torch.manual_seed)."""
+    CPU generator, i.e. reproducible under torch.manual_seed).  seed_dev: optional int64 GPU scalar
+    added to the seed inside the kernels (a captured hipGraph then drops a fresh mask per replay)."""
     if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # with a device-side seed the variation comes from that scalar (and a host draw would be
+        # frozen into a captured graph anyway)
+        seed = 0 if seed_dev is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
     shp = x.shape
     params = []
     for l in layers:
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
     params += [lin.weight, lin.bias]
     y = _HeadTrain.apply(x.reshape(-1, shp[-1]), (layers[0].bn.eps, [l.bn for l in layers],
-                                                  float(p), seed), *params)
+                                                  float(p), seed, seed_dev), *params)
     return y.reshape(shp[:-1] + (y.shape[-1],))
 
 
@@ -1186,7 +1191,7 @@ def dropout_mask(E, C, p, seed, device):
     m = torch.empty_like(one)
     with torch.cuda.device(one.device):
         _lib.check(lib.gridgcn_bn_relu_dropout_apply(_ptr(one), _ptr(sc), _ptr(sh), _ptr(m), E, C,
-                                                     C, float(p), int(seed), _stream(one)), "drop")
+                                                     C, float(p), int(seed), None, _stream(one)), "drop")
     return m
 
 

@@ -59,11 +59,14 @@ typedef struct gridgcn_grid_params {
     float voxel_size[3];
     int32_t grid_size[3];   /* gx*gy*gz < 2^24 and B*gx*gy*gz < 2^31                             */
     uint64_t seed;
+    const uint64_t *seed_dev; /* optional DEVICE scalar added to `seed` when the kernels run (NULL:
+                               * none).  Lets a captured hipGraph of the operator draw a fresh
+                               * sample at every replay: the caller bumps the scalar on the stream. */
 } gridgcn_grid_params;
 
 const char *gridgcn_strerror(int code);
 /* library/ABI version, bumped on any signature change */
-int gridgcn_abi_version(void);
+int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev */
 
 /* ---- Gridify : replaces GridifyForward<gpu>, gridify.cu:294-413 -------------------------------
  * in : data[B,N,4] f32 (x,y,z,w)   actual_numpoints[B] i32
@@ -362,12 +365,14 @@ int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift
  * 0 <= drop_p < 1; drop_p = 0 is the identity. */
 int gridgcn_bn_relu_dropout_apply(const float *Z, const float *scale, const float *shift, float *Y,
                                   long long E, int C, int ldy, float drop_p, uint64_t drop_seed,
+                                  const uint64_t *drop_seed_dev,
                                   void *stream);
 int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const float *shift,
                       const float *mean, const float *rstd, const float *m1, const float *m2,
                       const float *Aprev, const float *pscale, const float *pshift,
                       const float *pmean, const float *prstd, const float *Wdx, int ndx,
                       long long E, int C, int cin, int ldy, float drop_p, uint64_t drop_seed,
+                      const uint64_t *drop_seed_dev,
                       float *dX, double *psums, void *stream);
 int gridgcn_bn_relu_bwd_reduce(const float *dY, const float *Z, const float *scale,
                                const float *shift, const float *mean, const float *rstd,

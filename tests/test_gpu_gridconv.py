@@ -181,7 +181,7 @@ def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P):
 def test_training_step_edge_kernel_matches_torch_ops():
     """one fwd+bwd of the whole network: HIP edge-input kernel path vs stock-op path."""
     torch.manual_seed(0)
-    net = model.GGCNSeg(model.SEG_81920).to(DEV).train()
+    net = model.GGCNSeg(model.SEG_81920, fixed_seed=True).to(DEV).train()
     data, npn = synth.make_batch(2, 4096, "planes")
     x = torch.from_numpy(data[..., :3].copy()).to(DEV)
     n = torch.from_numpy(npn).to(DEV)
@@ -318,7 +318,7 @@ def test_full_size_training_step_matches_stock_pytorch_ops():
     shared and bit-exact): loss and the gradient vector."""
     torch.manual_seed(0)
     cfg = dict(model.SEG_81920, dropout=0.0)
-    net = model.GGCNSeg(cfg).to(DEV).train()
+    net = model.GGCNSeg(cfg, fixed_seed=True).to(DEV).train()
     data, npn = synth.make_batch(8, 81920, "planes")
     x = torch.from_numpy(data[..., :3].copy()).to(DEV)
     n = torch.from_numpy(npn).to(DEV)
@@ -410,3 +410,42 @@ def test_synth200k_model_matches_cpu_oracle_model():
     a = torch.cat([p.grad.reshape(-1) for p in net_gpu.parameters()]).cpu().double()
     b = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
     assert float((a - b).norm() / b.norm()) < 2e-2
+
+
+def test_graphed_train_step_equals_eager_step():
+    """graph.GraphedTrainStep: replays of the captured step == eager steps fed the same device-side
+    seeds (voxel sampling, reservoirs and the dropout mask all take seed + *seed_dev), and the
+    draws move on from replay to replay."""
+    import copy
+    from grid_gcn_amd import graph
+    torch.manual_seed(5)
+    cfg = model.SEG_8192
+    net_e = model.GGCNSeg(cfg, fixed_seed=True).to(DEV).train()
+    net_g = model.GGCNSeg(cfg, fixed_seed=True).to(DEV).train()
+    net_g.load_state_dict(copy.deepcopy(net_e.state_dict()))
+    data, npn = synth.make_batch(2, 8192, "planes", first_id=70)
+    x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    lab = torch.randint(0, 21, (2, 8192), device=DEV)
+    mk = lambda net: torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)  # noqa: E731
+    opt_e, opt_g = mk(net_e), mk(net_g)
+    W = 2
+    gs = graph.GraphedTrainStep(net_g, opt_g, model.seg_loss, (x, n), lab, warmup=W)
+    net_e.seed_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+
+    def eager():
+        net_e.seed_dev.add_(graph._GOLDEN)
+        opt_e.zero_grad(set_to_none=True)
+        loss = model.seg_loss(net_e(x, n), lab)
+        loss.backward()
+        opt_e.step()
+        return float(loss)
+
+    for _ in range(W):                       # the graph's constructor ran W real steps
+        eager()
+    assert int(net_e.seed_dev) == int(net_g.seed_dev)   # the capture itself executed nothing
+    le = [eager() for _ in range(3)]
+    lg = [float(gs()) for _ in range(3)]
+    assert len(set(lg)) == 3                 # fresh draws per replay
+    for a, b in zip(le, lg):
+        assert abs(a - b) < 2e-3 * abs(a), (le, lg)

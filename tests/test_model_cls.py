@@ -51,7 +51,7 @@ def test_cls_training_step_mfma_kernels_match_stock_modules():
     training kernels (where their width limits allow) vs the stock PyTorch modules."""
     torch.manual_seed(0)
     cfg = dict(model_cls.CLS_MN40, dropout=0.0)
-    net = model_cls.GGCNCls(cfg).to("cuda:0").train()
+    net = model_cls.GGCNCls(cfg, fixed_seed=True).to("cuda:0").train()
     x, n = _inputs(8, 1024)
     x, n = x.to("cuda:0"), n.to("cuda:0")
     lab = torch.randint(0, 40, (8,), device="cuda:0")
