@@ -154,6 +154,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1, help="clouds of the CPU fwd+bwd sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="time the eager step instead of the hipGraph replay")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="contraction precision of the training GEMM kernels: f32 = exact fp32 MFMA "
+                         "(parity path, the headline), bf16 = bf16 MFMA operands with fp32 storage, "
+                         "accumulation and statistics (BASELINE configs[2] 'bf16 MLP / fp32 indices')")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +173,8 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     traffic = load_traffic()
+    from grid_gcn_amd import train_ops as _tops
+    _tops.set_mlp_precision("bf16" if a.dtype == "bf16" else "fp32")
 
     if a.config != "cfg4":
         import bench_configs
@@ -207,7 +213,7 @@ def main():
         "metric": "point-clouds/sec fwd+bwd (ScanNet 81920-pt)", "value": world * B * a.steps / dt,
         "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "step_mode": step_mode,
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "step_mode": step_mode,
         "config": {"workload": "BASELINE configs[3]: ScanNet %d-pt segmentation, batch %d per GPU, "
                                "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (points, B),
                    "global_batch": world * B, "points_per_cloud": points,
@@ -223,8 +229,10 @@ def main():
         # whole step against the fp32 matrix peak: SURVEY section 8(d) algorithmic flops of the step
         # (3 x forward: per-edge MLPs + per-point MLPs + head) / ms_per_step
         "roofline_step": {"bound": "mfma", "kernel": "whole training step (all kernels)",
-                          "achieved": tf_step, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": tf_step / MFMA_F32_PEAK_TF, "traffic": None,
+                          "achieved": tf_step, "peak": MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0,
+                          "unit": "TFLOP/s",
+                          "frac": tf_step / (MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0),
+                          "traffic": None,
                           "algorithmic_flops_per_step": step_flops,
                           "edge_flops_fwd": fe, "per_point_flops_fwd": fr},
     }

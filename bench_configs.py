@@ -17,7 +17,7 @@ MFMA_F32_PEAK_TF = 157.3
 def _line(metric, value, unit, a, world, ms_step, workload, extra):
     out = {"metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": unit != "ms",
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": workload, "parallelism": "dp%d" % world}}
     out.update(extra)
     return out
@@ -85,9 +85,10 @@ def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step):
     extra["config_extra"] = {"global_batch": world * B, "points_per_cloud": N}
     if flops is not None:
         tf = flops / (ms_step * 1e-3) / 1e12
+        peak = MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0
         extra["roofline_step"] = {"bound": "mfma", "kernel": "whole training step (all kernels)",
-                                  "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                  "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                                  "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": tf / peak, "traffic": None,
                                   "algorithmic_flops_per_step": flops}
     if rank == 0 and world == 1:
         grid = net.cfg["grid"]

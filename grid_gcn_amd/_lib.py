@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
 EXPORTS = [
-    "gridgcn_strerror", "gridgcn_abi_version",
+    "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",
+    "gridgcn_get_mlp_precision",
     "gridgcn_gridify_workspace_bytes", "gridgcn_gridify", "gridgcn_gridify_timed",
     "gridgcn_gridify_knn_workspace_bytes", "gridgcn_gridify_knn",
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
@@ -69,6 +70,9 @@ def load():
     lib.gridgcn_strerror.restype = ctypes.c_char_p
     lib.gridgcn_strerror.argtypes = [ci]
     lib.gridgcn_abi_version.restype = ci
+    lib.gridgcn_set_mlp_precision.restype = ci
+    lib.gridgcn_set_mlp_precision.argtypes = [ci]
+    lib.gridgcn_get_mlp_precision.restype = ci
     for name in ("gridgcn_gridify_workspace_bytes", "gridgcn_gridify_knn_workspace_bytes",
                  "gridgcn_gridify_up_workspace_bytes"):
         f = getattr(lib, name)

@@ -112,6 +112,14 @@ const char *gridgcn_strerror(int code)
 
 int gridgcn_abi_version(void) { return 2; }
 
+int gridgcn_set_mlp_precision(int bf16)
+{
+    gg_set_mlp_bf16(bf16);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_get_mlp_precision(void) { return gg_get_mlp_bf16(); }
+
 int gridgcn_gridify_workspace_bytes(int B, int N, const gridgcn_grid_params *p, size_t *bytes)
 {
     GGGrid gp;

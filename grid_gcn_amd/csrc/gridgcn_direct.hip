@@ -18,6 +18,58 @@
 
 template <int NT> struct GGBVec { float v[NT]; };
 
+// ---- optional bf16 contraction (process-wide switch gridgcn_set_mlp_precision) ----------------
+// The register-direct kernels keep their fp32 operands in HBM and their fp32 accumulators, BatchNorm
+// statistics and epilogues; only the MFMA itself changes: eight consecutive steps of the fp32
+// schedule (v_mfma_f32_32x32x2_f32: 2 k's per step, lanes 0..31 one k, lanes 32..63 the other) are
+// ONE v_mfma_f32_32x32x16_bf16 whose lane holds the 8 A values and the 8 B values of those steps
+// (element j of the bf16x8 operand = step 8g + j): the same (lane half, k) pairing, 1/16 of the
+// matrix-pipe time.  The weights are converted while a workgroup copies them into LDS.
+static int g_mlp_bf16 = 0;
+void gg_set_mlp_bf16(int on) { g_mlp_bf16 = on ? 1 : 0; }
+int gg_get_mlp_bf16() { return g_mlp_bf16; }
+
+typedef __bf16 ggm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ggm_u32x4 __attribute__((ext_vector_type(4)));
+
+// two floats -> one register of two bf16 (round to nearest even), through the COMPILER's conversion
+// (v_cvt_pk_bf16_f32): an inline-asm cvt is opaque to hipcc's hazard recogniser, which then omits
+// the wait states a VALU result needs before an MFMA may read it as an operand (seen as garbage dX)
+typedef __bf16 ggm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ggm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gg_pk_bf16(float lo, float hi)
+{
+    const ggm_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ggm_bf16x2));
+}
+
+__device__ __forceinline__ ggm_f32x16 gg_mfma_bf16(const ggm_u32x4 a, const ggm_u32x4 b, ggm_f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ggm_bf16x8, a),
+                                                   __builtin_bit_cast(ggm_bf16x8, b), c, 0, 0, 0);
+}
+
+// fp32 packed weights [step][64 lanes][NV] -> LDS bf16 [group of 8 steps][64 lanes][NV] (16 bytes
+// per entry), zero beyond `nsteps`
+template <int NV>
+__device__ __forceinline__ void gg_stage_w_bf16(ggm_u32x4 *dst, const float *__restrict__ W,
+                                                int nsteps, int tid, int nthr)
+{
+    const int ng = (nsteps + 7) >> 3;
+    for (int e = tid; e < ng * 64 * NV; e += nthr) {
+        const int t = e % NV, lane = (e / NV) & 63, g = e / (NV * 64);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int st = g * 8 + j;
+            v[j] = st < nsteps ? W[((size_t)st * 64 + lane) * NV + t] : 0.f;
+        }
+        ggm_u32x4 o = {gg_pk_bf16(v[0], v[1]), gg_pk_bf16(v[2], v[3]), gg_pk_bf16(v[4], v[5]),
+                       gg_pk_bf16(v[6], v[7])};
+        dst[e] = o;
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void gg_ldb(const float *__restrict__ base, int idx, float (&b)[NT])
 {
@@ -51,15 +103,18 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 
 // Z[E, cout] = act(X[E, K]) * W + b, batch statistics of Z in the epilogue.  K % 8 == 0, X row
 // stride K.  NT = ldw / 32 column tiles per wave (all of them: the wave owns full rows of Z).
-template <int NT, bool WLDS, bool EXACT>
+template <int NT, bool WLDS, bool EXACT, bool BF16 = false>
 __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int K = p.K, h = lane >> 5;
     float *Wl = lds;
-    float *scl = lds + (WLDS ? K * 32 * NT : 0);     // [K] scale, [K] shift
-    if (WLDS) {
+    const int ng8 = (K / 2 + 7) >> 3;               // bf16: groups of 8 steps
+    float *scl = lds + (BF16 ? ng8 * 64 * NT * 4 : (WLDS ? K * 32 * NT : 0));     // [K] scale, [K] shift
+    if (BF16) {
+        gg_stage_w_bf16<NT>((ggm_u32x4 *)Wl, p.W, K / 2, tid, blockDim.x);
+    } else if (WLDS) {
         const float4 *src = (const float4 *)p.W;
         for (int i = tid; i < K * 8 * NT; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
     }
@@ -97,6 +152,18 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
                     a[q] = gg_bnrelu4(a[q], *(const float4 *)(scl + k0 + 4 * q),
                                       *(const float4 *)(scl + K + k0 + 4 * q));
             }
+            if constexpr (BF16) {
+                const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const ggm_u32x4 a8 = {gg_pk_bf16(a[2 * g].x, a[2 * g].y), gg_pk_bf16(a[2 * g].z, a[2 * g].w),
+                                          gg_pk_bf16(a[2 * g + 1].x, a[2 * g + 1].y),
+                                          gg_pk_bf16(a[2 * g + 1].z, a[2 * g + 1].w)};
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = gg_mfma_bf16(a8, W16[((2 * c + g) * 64 + lane) * NT + t], acc[t]);
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
 #pragma unroll
@@ -109,10 +176,36 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
                     s++;
                 }
             }
+            }
         }
         if (ktail) {
             const int nq = ktail >> 3;
             const int k0 = nfull * 32 + h * 4 * nq;
+            if constexpr (BF16) {
+                const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
+                float4 at[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    at[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q < nq) {
+                        at[q] = *(const float4 *)(xr + k0 + 4 * q);
+                        if (p.scale)
+                            at[q] = gg_bnrelu4(at[q], *(const float4 *)(scl + k0 + 4 * q),
+                                               *(const float4 *)(scl + K + k0 + 4 * q));
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    if (2 * g < nq) {
+                        const ggm_u32x4 a8 = {gg_pk_bf16(at[2 * g].x, at[2 * g].y), gg_pk_bf16(at[2 * g].z, at[2 * g].w),
+                                              gg_pk_bf16(at[2 * g + 1].x, at[2 * g + 1].y),
+                                              gg_pk_bf16(at[2 * g + 1].z, at[2 * g + 1].w)};
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = gg_mfma_bf16(a8, W16[((2 * nfull + g) * 64 + lane) * NT + t], acc[t]);
+                    }
+                }
+            } else {
             for (int q = 0; q < nq; q++) {
                 float4 a = *(const float4 *)(xr + k0 + 4 * q);
                 if (p.scale)
@@ -127,6 +220,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
                     s++;
                 }
+            }
             }
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
@@ -205,13 +299,28 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
     const int threads = NT == 8 ? 512 : 1024, nw = threads / 64;
     const size_t wbytes = (size_t)q.K * 32 * NT * 4, sbytes = (size_t)2 * q.K * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
-    const bool wlds = wbytes + sbytes <= 156 * 1024;
-    size_t lds = (wlds ? wbytes : 0) + sbytes;
-    if (lds < rbytes) lds = rbytes;
     const long long ntile = (q.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
     if (nb > 256) nb = 256;
     const bool exact = q.cout == NT * 32;
+    const size_t w16 = (size_t)((q.K / 2 + 7) / 8) * 64 * NT * 16;
+    if (g_mlp_bf16 && w16 + sbytes <= 156 * 1024) {
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return 3;
+            attr16 = true;
+        }
+        size_t l16 = w16 + sbytes;
+        if (l16 < rbytes) l16 = rbytes;
+        if (exact) gg_k_linear_fwd_direct<NT, true, true, true><<<(int)nb, threads, l16, st>>>(q);
+        else gg_k_linear_fwd_direct<NT, true, false, true><<<(int)nb, threads, l16, st>>>(q);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
+    const bool wlds = wbytes + sbytes <= 156 * 1024;
+    size_t lds = (wlds ? wbytes : 0) + sbytes;
+    if (lds < rbytes) lds = rbytes;
     if (wlds && exact) gg_k_linear_fwd_direct<NT, true, true><<<(int)nb, threads, lds, st>>>(q);
     else if (wlds) gg_k_linear_fwd_direct<NT, true, false><<<(int)nb, threads, lds, st>>>(q);
     else if (exact) gg_k_linear_fwd_direct<NT, false, true><<<(int)nb, threads, lds, st>>>(q);
@@ -238,7 +347,7 @@ int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st)
 // BatchNorm-backward sums of the PREVIOUS layer (its raw output Aprev read in the C/D layout).
 //   dz = scale*dyr - scale*m1 - scale*rstd*m2*(z - mean),   dyr = dy * (z*scale + shift > 0)
 // NT = ceil(ndx/32) column tiles, NTV = its vector width in Wdx (1/2/4/8).
-template <int NT>
+template <int NT, bool BF16 = false>
 __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
 {
     constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
@@ -252,10 +361,15 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         drop_hi = (unsigned)(sd >> 32);
     }
     float *Wl = lds;                              // [C/2 steps][64][NTV]
-    float *cst = lds + C * 32 * NTV;              // scale, shift, mean, bz, cz  [5][C]
+    const int ng8 = (C / 2 + 7) >> 3;             // bf16: groups of 8 steps, 16 bytes per entry
+    float *cst = lds + (BF16 ? ng8 * 64 * NTV * 4 : C * 32 * NTV);   // scale, shift, mean, bz, cz  [5][C]
     {
-        const float4 *src = (const float4 *)p.Wdx;
-        for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
+        if (BF16) {
+            gg_stage_w_bf16<NTV>((ggm_u32x4 *)Wl, p.Wdx, C / 2, tid, blockDim.x);
+        } else {
+            const float4 *src = (const float4 *)p.Wdx;
+            for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
+        }
         for (int c = tid; c < C; c += blockDim.x) {
             const float sc = p.scale[c];
             cst[c] = sc;
@@ -326,6 +440,21 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             float4 z[4], g[4], a[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) { z[q] = *(const float4 *)(zr + k0 + 4 * q); g[q] = ldg(k0 + 4 * q); }
+            if constexpr (BF16) {
+                // dZ formed and packed group by group (its five constants per channel quad would
+                // otherwise all be live at once)
+                const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    const float4 d0 = dz4(z[2 * gq], g[2 * gq], k0 + 8 * gq);
+                    const float4 d1 = dz4(z[2 * gq + 1], g[2 * gq + 1], k0 + 8 * gq + 4);
+                    const ggm_u32x4 a8 = {gg_pk_bf16(d0.x, d0.y), gg_pk_bf16(d0.z, d0.w),
+                                          gg_pk_bf16(d1.x, d1.y), gg_pk_bf16(d1.z, d1.w)};
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = gg_mfma_bf16(a8, W16[((2 * c + gq) * 64 + lane) * NTV + t], acc[t]);
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) a[q] = dz4(z[q], g[q], k0 + 4 * q);
 #pragma unroll
@@ -339,10 +468,32 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
                     s++;
                 }
+            }
         }
         if (ktail) {
             const int nq = ktail >> 3;
             const int k0 = nfull * 32 + h * 4 * nq;
+            if constexpr (BF16) {
+                const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
+                float4 at[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    at[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q < nq)
+                        at[q] = dz4(*(const float4 *)(zr + k0 + 4 * q), ldg(k0 + 4 * q), k0 + 4 * q);
+                }
+#pragma unroll
+                for (int gq = 0; gq < 2; gq++) {
+                    if (2 * gq < nq) {
+                        const ggm_u32x4 a8 = {gg_pk_bf16(at[2 * gq].x, at[2 * gq].y), gg_pk_bf16(at[2 * gq].z, at[2 * gq].w),
+                                              gg_pk_bf16(at[2 * gq + 1].x, at[2 * gq + 1].y),
+                                              gg_pk_bf16(at[2 * gq + 1].z, at[2 * gq + 1].w)};
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = gg_mfma_bf16(a8, W16[((2 * nfull + gq) * 64 + lane) * NTV + t], acc[t]);
+                    }
+                }
+            } else {
             for (int q = 0; q < nq; q++) {
                 const float4 a = dz4(*(const float4 *)(zr + k0 + 4 * q), ldg(k0 + 4 * q), k0 + 4 * q);
 #pragma unroll
@@ -354,6 +505,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
                     s++;
                 }
+            }
             }
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
@@ -425,14 +577,17 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
     // (768 threads = 3 waves per SIMD at 168 registers was measured: no gain, 59 spills)
     // narrow outputs (NT <= 2) use ~150-170 registers = 3 waves per SIMD: workgroups of 4 waves so
     // that three of them fit a CU (with 8-wave workgroups only one did)
     const int threads = NT <= 2 ? 256 : 512, nw = threads / 64;
-    size_t lds = ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
+    const bool bf16 = g_mlp_bf16 != 0;
+    size_t lds = bf16 ? (size_t)((p.C / 2 + 7) / 8) * 64 * NTV * 16 + 5 * (size_t)p.C * 4
+                      : ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     if (lds < rbytes) lds = rbytes;
     if (lds > 156 * 1024) return 1;
@@ -441,7 +596,8 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
     if (nb > 256 * per_cu) nb = 256 * per_cu;
-    gg_k_linear_dx_direct<NT><<<(int)nb, threads, lds, st>>>(p);
+    if (bf16) gg_k_linear_dx_direct<NT, true><<<(int)nb, threads, lds, st>>>(p);
+    else gg_k_linear_dx_direct<NT, false><<<(int)nb, threads, lds, st>>>(p);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -475,7 +631,7 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 // m-groups of a workgroup walk the SAME rows (the B rows hit L1/L2), RS row streams fill the rest.
 // No LDS, no barriers; two register sets keep the next step's loads in flight.  Partials go to the
 // workspace as [wave][tile][reg][lane]; gg_k_dw_reduce_direct sums them into the framework layout.
-template <int MT, int NQ, int NP, int NS>
+template <int MT, int NQ, int NP, int NS, bool BF16 = false>
 __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int MG, int RS,
                                                                  long long rows_per_wg)
 {
@@ -585,8 +741,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
 #pragma unroll
     for (int i = 0; i < MT; i++) ggm_zero<NJ>(acc[i]);
 
-    auto compute = [&](const Regs &R) {
-        float dz[MT], xa[NJ];
+    auto values = [&](const Regs &R, float (&dz)[MT], float (&xa)[NJ]) {
 #pragma unroll
         for (int i = 0; i < MT; i++) {
             float g = R.g[i];
@@ -602,6 +757,10 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             if (NS && j == NJ - 1 && !sok) x = 0.f;
             xa[j] = x;
         }
+    };
+    auto compute = [&](const Regs &R) {
+        float dz[MT], xa[NJ];
+        values(R, dz, xa);
 #pragma unroll
         for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -611,12 +770,41 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
 
     const long long nsteps = (rb - ra + 1) >> 1;
     Regs A, B;
+    if constexpr (BF16) {
+        // eight steps (16 rows) per v_mfma_f32_32x32x16_bf16: element j of a lane's operands =
+        // step 8g + j, packed two steps per register as they are formed
+        for (long long s = 0; s < nsteps; s += 8) {
+            unsigned dzp[MT][4], xap[NJ][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                float d0[MT], x0[NJ], d1[MT], x1[NJ];
+                load(A, s + 2 * jj);          // past the end: ok = false, clamped addresses
+                load(B, s + 2 * jj + 1);
+                values(A, d0, x0);
+                values(B, d1, x1);
+#pragma unroll
+                for (int i = 0; i < MT; i++) dzp[i][jj] = gg_pk_bf16(d0[i], d1[i]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) xap[j][jj] = gg_pk_bf16(x0[j], x1[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                const ggm_u32x4 a8 = {dzp[i][0], dzp[i][1], dzp[i][2], dzp[i][3]};
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const ggm_u32x4 b8 = {xap[j][0], xap[j][1], xap[j][2], xap[j][3]};
+                    acc[i][j] = gg_mfma_bf16(a8, b8, acc[i][j]);
+                }
+            }
+        }
+    } else {
     if (nsteps > 0) load(A, 0);
     for (long long s = 0; s < nsteps; s += 2) {
         load(B, s + 1);          // past the end: ok = false, clamped addresses
         compute(A);
         load(A, s + 2);
         if (s + 1 < nsteps) compute(B);
+    }
     }
 
     // partial: [wave_global][i*NJ + j][reg][lane]
@@ -714,7 +902,10 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C)
 template <int MT, int NQ, int NP, int NS>
 static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
 {
-    gg_k_linear_dw_direct<MT, NQ, NP, NS><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+    if (g_mlp_bf16)
+        gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+    else
+        gg_k_linear_dw_direct<MT, NQ, NP, NS, false><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -66,3 +66,8 @@ int gg_bn_bwd_reduce(const float *dY, const float *Z, const float *scale, const 
 int gg_bn_bwd_elemt(const float *dY, const float *Z, const float *scale, const float *shift,
                     const float *mean, const float *rstd, const float *m1, const float *m2,
                     long long E, int C, float *dZ, hipStream_t st);
+
+// process-wide switch of the register-direct GEMM kernels: 0 = exact fp32 MFMA, 1 = bf16 MFMA with
+// fp32 operands in memory, fp32 accumulation and statistics (gridgcn_direct.hip)
+void gg_set_mlp_bf16(int on);
+int gg_get_mlp_bf16();

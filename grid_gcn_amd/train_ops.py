@@ -50,6 +50,20 @@ SPARSE_L0 = os.environ.get("GG_SORTED_L0", "0") != "1"
 
 
 
+
+def set_mlp_precision(mode):
+    """'fp32' (default): exact fp32 MFMA, the parity path.  'bf16': the register-direct GEMM kernels
+    (forward, dX, dW of every conv of the training path) round their operands to bf16 in registers
+    and use v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm statistics
+    and all epilogues stay fp32 (BASELINE configs[2]: 'bf16 MLP / fp32 indices').  Process-wide,
+    read when a kernel is launched (include/gridgcn.h: gridgcn_set_mlp_precision)."""
+    assert mode in ("fp32", "bf16")
+    _lib.check(_lib.load().gridgcn_set_mlp_precision(1 if mode == "bf16" else 0), "set_mlp_precision")
+
+
+def get_mlp_precision():
+    return "bf16" if _lib.load().gridgcn_get_mlp_precision() else "fp32"
+
 def _momentum(bn):
     """BatchNorm momentum handed to gg_k_bn_finalize.  momentum=None (torch's cumulative moving
     average) has no counterpart in the reference (mx.sym.BatchNorm(momentum=bn_decay)) nor in the

@@ -68,6 +68,15 @@ const char *gridgcn_strerror(int code);
 /* library/ABI version, bumped on any signature change */
 int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev */
 
+/* Precision of the contraction inside the training GEMM kernels (gridgcn_linear_fwd_direct,
+ * gridgcn_linear_dx, the direct dW kernel behind gridgcn_linear_bwd): 0 (default) = exact fp32
+ * (v_mfma_f32_32x32x2_f32), the parity path; 1 = bf16 operands (v_mfma_f32_32x32x16_bf16, round to
+ * nearest even at the register level) with fp32 accumulation -- tensors in memory, BatchNorm
+ * statistics and every epilogue stay fp32.  BASELINE configs[2] "bf16 MLP / fp32 indices".
+ * PROCESS-WIDE and read at launch time: set it before enqueuing the kernels it should affect. */
+int gridgcn_set_mlp_precision(int bf16);
+int gridgcn_get_mlp_precision(void);
+
 /* ---- Gridify : replaces GridifyForward<gpu>, gridify.cu:294-413 -------------------------------
  * in : data[B,N,4] f32 (x,y,z,w)   actual_numpoints[B] i32
  * out: nebidx[B,O,P] i32  nebidxmsk[B,O,P] f32  cent[B,O,4] f32  centmsk[B,O] f32

@@ -411,3 +411,38 @@ def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
     # dW and the sums: different summation order over the rows
     assert float((w0 - w1).abs().max()) <= 2e-5 * max(1.0, float(w0.abs().max()))
     assert float((s0 - s1).abs().max()) <= 1e-5 * max(1.0, float(s0.abs().max()))
+
+
+def test_bf16_mlp_precision_mode_close_to_fp32():
+    """gridgcn_set_mlp_precision(1): bf16 MFMA operands, fp32 storage / accumulation / statistics.
+    Tolerance of the variant (NOT the parity path, which stays fp32): output of a 3-layer
+    conv+BN+ReLU stack within 2e-2 * max|y| of the fp32 kernels, input and weight gradients within
+    1e-1 in relative L2 norm (measured: 6e-2 on the input gradient); and the switch really changes the arithmetic (the outputs differ)."""
+    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.gridconv import mlp
+    torch.manual_seed(11)
+    layers = mlp(136, [128, 128, 256]).to(DEV).train()
+    x = torch.randn(40000, 136, device=DEV)
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            train_ops.set_mlp_precision(mode)
+            assert train_ops.get_mlp_precision() == mode
+            for l in layers:
+                l.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = train_ops.mlp_bn_relu_train(xi, list(layers))
+            (y * y).sum().backward()
+            res[mode] = (y.detach().clone(), xi.grad.clone(),
+                         [l.lin.weight.grad.clone() for l in layers])
+    finally:
+        train_ops.set_mlp_precision("fp32")
+    y32, y16 = res["fp32"][0], res["bf16"][0]
+    assert float((y32 - y16).abs().max()) > 0.0
+    assert float((y32 - y16).abs().max()) <= 2e-2 * float(y32.abs().max())
+    # gradients through three BatchNorm+ReLU layers: a ReLU that flips under the rounded operands
+    # moves single elements by much more than the rounding itself -- bound the error in norm
+    rel = lambda a, b: float((a - b).norm() / b.norm())  # noqa: E731
+    assert rel(res["bf16"][1], res["fp32"][1]) <= 1e-1
+    for a, b in zip(res["fp32"][2], res["bf16"][2]):
+        assert rel(b, a) <= 1e-1
