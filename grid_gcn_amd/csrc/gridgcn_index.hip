@@ -628,6 +628,10 @@ static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
         if (!grow && !shrink) break;
         KB++;
     }
+    if (const char *e = getenv("GG_TUNE_KB")) {  // tuning experiments only: shift log2(nslab)
+        KB += atoi(e);
+        KB = KB < 0 ? 0 : (KB > MB ? MB : KB);
+    }
     if (forced || KB > 10 || MB - KB + GG_XRB > GG_MAX_SB) return false;
     w->KB = KB;
     w->MB = MB;
@@ -643,6 +647,10 @@ static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
     while (CH < GG_CHUNK_MAX &&
            ((long long)B * ((N + CH - 1) / CH) > 512 || (N + CH - 1) / CH > GG_MAX_CHUNKS))
         CH *= 2;
+    if (const char *e = getenv("GG_TUNE_CH")) {  // tuning experiments only
+        const int v = atoi(e);
+        if ((v == 1024 || v == 2048 || v == 4096) && (N + v - 1) / v <= GG_MAX_CHUNKS) CH = v;
+    }
     w->CH = CH;
     w->nblk = (N + CH - 1) / CH;
     if (w->nblk > GG_MAX_CHUNKS) return false;

@@ -8,6 +8,7 @@
 // evaluate their reservoir draw and the S0 outcome "the last writer of a slot wins" is an LDS
 // atomicMax on the item number; outputs leave as coalesced rows.
 #include "gridgcn_index.h"
+#include <stdlib.h>
 
 struct GGQueryPtrs {
     const int2 *vtab;  // .x = segment start, .y = population
@@ -568,6 +569,10 @@ int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, c
     // centres per wave: more loads in flight per wave once there are more centres than wave slots
     int NC = 1;
     if (gp.k3 <= 64) NC = ncent > 65536 ? 4 : (ncent > 16384 ? 2 : 1);
+    if (const char *e = getenv("GG_TUNE_QNC")) {  // tuning experiments only
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4) && (gp.k3 <= 64 || v == 1)) NC = v;
+    }
     const int per = GG_QW * NC;
     const unsigned grid = (unsigned)B * (unsigned)((gp.O + per - 1) / per);
     const size_t lds = gg_query_lds(NC, gp.k3, gp.P);
