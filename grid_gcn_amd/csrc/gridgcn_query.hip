@@ -456,19 +456,14 @@ GG_PROF_SETTER(gridgcn_prof_set_query)
 // r = pick(seed + threadindex, n+1) with threadindex = (b*Nd + id)*k^3 + nei (gridify_up.cu:121-167).
 // That bucket is rebuilt here on the fly for the up point's voxel only, from the down points'
 // own-voxel sorted segments: rank n of a candidate = number of candidates with a smaller id.
-__global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ updata,
-                                                    const int *__restrict__ up_np, int Nd,
-                                                    GGGrid gp, GGQueryPtrs q,
-                                                    int *__restrict__ nebidx,
-                                                    float *__restrict__ nebmsk)
+// one wave, one up point (general k, P): lanes enumerate the candidates
+__device__ __forceinline__ void gg_query_up_wave(int index, const float4 *__restrict__ updata,
+                                                 const int *__restrict__ up_np, int Nd,
+                                                 const GGGrid &gp, const GGQueryPtrs &q,
+                                                 int *__restrict__ nebidx, float *__restrict__ nebmsk,
+                                                 int *s_excl, int *s_off, int *s_cnt, int *s_slot)
 {
-    __shared__ int s_excl[GG_K3MAX + 1];
-    __shared__ int s_off[GG_K3MAX];
-    __shared__ int s_cnt[GG_K3MAX];
-    __shared__ int s_slot[GG_PMAX];
-
-    const int lane = threadIdx.x;
-    const int index = blockIdx.x;
+    const int lane = threadIdx.x & 63;
     const int b = index / gp.O;
     const int o = index - b * gp.O;
     const int P = gp.P, k = gp.k, k3 = gp.k3;
@@ -507,7 +502,7 @@ __global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ u
     }
     if (lane == 0) s_excl[k3] = M;
     for (int s = lane; s < P; s += 64) s_slot[s] = -1;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
     for (int g0 = lane; g0 < M; g0 += 64) {
         // locate the item
@@ -539,11 +534,126 @@ __global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ u
         }
         if (s < P) atomicMax(&s_slot[s], id);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     const int first = M > 0 ? s_slot[0] : 0;  // reference: uninitialised initID when M == 0
     for (int s = lane; s < P; s += 64) {
         row[s] = s < M ? s_slot[s] : first;
         mrow[s] = s < M ? 1.0f : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ updata,
+                                                    const int *__restrict__ up_np, int Nd,
+                                                    GGGrid gp, GGQueryPtrs q,
+                                                    int *__restrict__ nebidx,
+                                                    float *__restrict__ nebmsk)
+{
+    __shared__ int s_excl[GG_K3MAX + 1];
+    __shared__ int s_off[GG_K3MAX];
+    __shared__ int s_cnt[GG_K3MAX];
+    __shared__ int s_slot[GG_PMAX];
+    gg_query_up_wave(blockIdx.x, updata, up_np, Nd, gp, q, nebidx, nebmsk, s_excl, s_off, s_cnt,
+                     s_slot);
+}
+
+// The shipped shapes (k = 3, P = 5: segmentation/configs/configs.yaml:99-104): ONE LANE per up point.
+// The down points are sparse in the up grid (0.4-2 candidates per up point on average), so a wave
+// per point leaves 60 lanes idle through three dependent lookups.  Here a lane loads its point,
+// the 27 (start, population) entries of its neighbourhood (all in flight), its <= 16 candidates
+// into a private LDS strip, ranks them by counting (rank = number of candidates with a smaller id)
+// and resolves the reservoir in registers (P <= 8).  Points with more than 16 candidates (dense
+// corners) fall to the wave-per-point routine above, one after the other, inside the same launch.
+#define GG_UP_MAXC 16
+template <int K>
+__global__ __launch_bounds__(256) void gg_k_query_up_lanes(const float4 *__restrict__ updata,
+                                                           const int *__restrict__ up_np, int Nd,
+                                                           GGGrid gp, GGQueryPtrs q, int total,
+                                                           int *__restrict__ nebidx,
+                                                           float *__restrict__ nebmsk)
+{
+    constexpr int K3 = K * K * K, HK = (K - 1) / 2;
+    __shared__ int s_cand[256 * GG_UP_MAXC];
+    __shared__ unsigned char s_cnei[256 * GG_UP_MAXC];
+    __shared__ int s_wave[4][K3 + 1 + K3 + K3 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int index = blockIdx.x * 256 + tid;
+    const int P = gp.P;
+    bool heavy = false;
+    if (index < total) {
+        const int b = index / gp.O;
+        const int o = index - b * gp.O;
+        int *row = nebidx + (size_t)index * P;
+        float *mrow = nebmsk + (size_t)index * P;
+        int c3[3] = {0, 0, 0};
+        int vq = -1;
+        if (o < up_np[b]) {
+            const float4 p = updata[index];
+            vq = gg_voxel_of(p.x, p.y, p.z, gp, c3);
+        }
+        if (vq < 0) {  // gridify_up-inl.h:111-112 fill values
+            for (int s = 0; s < P; s++) { row[s] = 0; mrow[s] = 0.0f; }
+        } else {
+            int2 vt[K3];
+            int M = 0;
+#pragma unroll
+            for (int nei = 0; nei < K3; nei++) {
+                const int d = nei / (K * K) - HK + c3[2];
+                const int h = (nei % (K * K)) / K - HK + c3[1];
+                const int w = nei % K - HK + c3[0];
+                vt[nei] = make_int2(0, 0);
+                if (d >= 0 && d < gp.g[2] && h >= 0 && h < gp.g[1] && w >= 0 && w < gp.g[0])
+                    vt[nei] = q.vtab[(size_t)b * gp.G + (size_t)d * gp.gxy + h * gp.g[0] + w];
+            }
+#pragma unroll
+            for (int nei = 0; nei < K3; nei++) M += vt[nei].y;
+            if (M > GG_UP_MAXC) {
+                heavy = true;
+            } else {
+                int *cand = s_cand + tid * GG_UP_MAXC;
+                unsigned char *cnei = s_cnei + tid * GG_UP_MAXC;
+                int pos = 0;
+#pragma unroll
+                for (int nei = 0; nei < K3; nei++)
+                    for (int j = 0; j < vt[nei].y; j++) {
+                        cand[pos] = q.sorted[vt[nei].x + j];
+                        cnei[pos] = (unsigned char)nei;
+                        pos++;
+                    }
+                int slot[8];
+#pragma unroll
+                for (int s = 0; s < 8; s++) slot[s] = -1;
+                for (int i = 0; i < M; i++) {
+                    const int id = cand[i];
+                    int n = 0;
+                    for (int j = 0; j < M; j++) n += cand[j] < id;
+                    int sl = n;
+                    if (n >= P) {
+                        const long long threadindex = ((long long)b * Nd + id) * K3 + (K3 - 1 - cnei[i]);
+                        sl = gg_reservoir_pick(gg_seed(gp) + (unsigned long long)threadindex, n + 1);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; s++)
+                        if (s == sl) slot[s] = slot[s] > id ? slot[s] : id;   // sl < P <= 8 or no hit
+                }
+                const int first = M > 0 ? slot[0] : 0;  // reference: uninitialised initID when M == 0
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+                    if (s < P) {
+                        row[s] = s < M ? slot[s] : first;
+                        mrow[s] = s < M ? 1.0f : 0.0f;
+                    }
+            }
+        }
+    }
+    unsigned long long hm = __ballot(heavy);
+    int *wl = s_wave[wave];
+    while (hm) {
+        const int l = __builtin_ctzll(hm);
+        hm &= hm - 1;
+        const int idx = __shfl(index, l, 64);
+        gg_query_up_wave(idx, updata, up_np, Nd, gp, q, nebidx, nebmsk, wl, wl + K3 + 1,
+                         wl + 2 * K3 + 1, wl + 3 * K3 + 1);
     }
 }
 
@@ -596,7 +706,18 @@ int gg_launch_query_up(const float *updata, const int *up_np, int B, int Nd, con
     GGQueryPtrs q = {};
     q.vtab = (const int2 *)(wsbase + w.o_vtab);
     q.sorted = (const int *)(wsbase + w.o_sorted);
-    gg_k_query_up<<<B * gp.O, 64, 0, st>>>((const float4 *)updata, up_np, Nd, gp, q, nebidx,
-                                           nebmsk);
+    const long long total = (long long)B * gp.O;
+    if (gp.P <= 8 && (gp.k == 3 || gp.k == 1) && !getenv("GG_UP_WAVE")) {
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        if (gp.k == 3)
+            gg_k_query_up_lanes<3><<<grid, 256, 0, st>>>((const float4 *)updata, up_np, Nd, gp, q,
+                                                         (int)total, nebidx, nebmsk);
+        else
+            gg_k_query_up_lanes<1><<<grid, 256, 0, st>>>((const float4 *)updata, up_np, Nd, gp, q,
+                                                         (int)total, nebidx, nebmsk);
+    } else {
+        gg_k_query_up<<<B * gp.O, 64, 0, st>>>((const float4 *)updata, up_np, Nd, gp, q, nebidx,
+                                               nebmsk);
+    }
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
