@@ -16,13 +16,30 @@
 
 #define GG_AF_TS 68    // LDS row stride (floats) of the staged half tile: 64 channels + 4
 
+// bf16 contraction mode (gridgcn_direct.hip: gg_set_mlp_bf16): eight fp32 MFMA steps = one
+// v_mfma_f32_32x32x16_bf16, operands rounded in registers (compiler-made conversion, see there)
+typedef __bf16 ggaf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ggaf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ggaf_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ggaf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ggaf_pk(float lo, float hi)
+{
+    const ggaf_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ggaf_bf16x2));
+}
+__device__ __forceinline__ ggm_f32x16 ggaf_mfma(const ggaf_u32x4 a, const ggaf_u32x4 b, ggm_f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ggaf_bf16x8, a),
+                                                   __builtin_bit_cast(ggaf_bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float gg_af_f4(const float4 &v, int i)
 {
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
 // NJ = C / 32 (2 or 4).  cin == ndx in {16, 32}, previous layer's BatchNorm given, C % 64 == 0.
-template <int NJ>
+template <int NJ, bool BF16 = false>
 __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -35,8 +52,21 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
     float *cst = lds + C * 32;                         // scale, shift, mean, bz, cz  [5][C]
     float *T = cst + 5 * C + wave * (32 * GG_AF_TS);   // this wave's dZ half tile [32][TS]
     {
-        const float4 *src = (const float4 *)p.Wdx;
-        for (int i = tid; i < C * 8; i += 256) ((float4 *)Wl)[i] = src[i];
+        if (BF16) {
+            // [C/16 groups of 8 steps][64 lanes] x 8 bf16 in the first half of the Wl area
+            for (int e = tid; e < (C / 16) * 64; e += 256) {
+                const int ln = e & 63, g8 = e >> 6;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = p.Wdx[(size_t)(g8 * 8 + j) * 64 + ln];
+                const ggaf_u32x4 o = {ggaf_pk(v[0], v[1]), ggaf_pk(v[2], v[3]), ggaf_pk(v[4], v[5]),
+                                      ggaf_pk(v[6], v[7])};
+                ((ggaf_u32x4 *)Wl)[e] = o;
+            }
+        } else {
+            const float4 *src = (const float4 *)p.Wdx;
+            for (int i = tid; i < C * 8; i += 256) ((float4 *)Wl)[i] = src[i];
+        }
         for (int c = tid; c < C; c += 256) {
             const float sc = p.scale[c];
             cst[c] = sc;
@@ -108,6 +138,17 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
         ggm_f32x16 accx;
 #pragma unroll
         for (int r = 0; r < 16; r++) accx[r] = 0.f;
+        ggaf_u32x4 av8[2];
+        if constexpr (BF16) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) av[j] = fmaxf(zpv[hf * 8 + j] * ps + psh, 0.f);
+                av8[hf] = ggaf_u32x4{ggaf_pk(av[0], av[1]), ggaf_pk(av[2], av[3]), ggaf_pk(av[4], av[5]),
+                                     ggaf_pk(av[6], av[7])};
+            }
+        }
         int s = 0;
 #pragma unroll
         for (int hc = 0; hc < NJ / 2; hc++) {
@@ -123,6 +164,15 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
                     if (!rowok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     *(float4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = a[q];
                 }
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        const ggaf_u32x4 a8 = {ggaf_pk(a[2 * g].x, a[2 * g].y), ggaf_pk(a[2 * g].z, a[2 * g].w),
+                                               ggaf_pk(a[2 * g + 1].x, a[2 * g + 1].y),
+                                               ggaf_pk(a[2 * g + 1].z, a[2 * g + 1].w)};
+                        accx = ggaf_mfma(a8, ((const ggaf_u32x4 *)Wl)[(2 * (2 * hc + cc) + g) * 64 + lane], accx);
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -131,10 +181,27 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
                                                                     accx, 0, 0, 0);
                         s++;
                     }
+                }
             }
             // the tile belongs to this wave alone: its LDS writes only have to land before its reads
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (BF16) {
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        float tv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int r = hf * 8 + j;
+                            tv[j] = T[((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31 + jj * 32];
+                        }
+                        const ggaf_u32x4 b8 = {ggaf_pk(tv[0], tv[1]), ggaf_pk(tv[2], tv[3]),
+                                               ggaf_pk(tv[4], tv[5]), ggaf_pk(tv[6], tv[7])};
+                        accw[2 * hc + jj] = ggaf_mfma(av8[hf], b8, accw[2 * hc + jj]);
+                    }
+            } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
@@ -144,6 +211,7 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
                 for (int jj = 0; jj < 2; jj++)
                     accw[2 * hc + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, trow[jj * 32],
                                                                              accw[2 * hc + jj], 0, 0, 0);
+            }
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -250,13 +318,15 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_fused<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_fused<NJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_fused<NJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
     const int C = NJ * 32;
     const size_t lds = ((size_t)C * 32 + 5 * C + 4 * 32 * GG_AF_TS) * sizeof(float);
     const int grid = gg_att_fused_grid(p.E);
-    gg_k_att_bwd_fused<NJ><<<grid, 256, lds, st>>>(p);
+    if (gg_get_mlp_bf16()) gg_k_att_bwd_fused<NJ, true><<<grid, 256, lds, st>>>(p);
+    else gg_k_att_bwd_fused<NJ, false><<<grid, 256, lds, st>>>(p);
     if (hipGetLastError() != hipSuccess) return 3;
     gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.cin, p.dW);
     return hipGetLastError() == hipSuccess ? 0 : 3;

@@ -304,7 +304,9 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
     if (nb > 256) nb = 256;
     const bool exact = q.cout == NT * 32;
     const size_t w16 = (size_t)((q.K / 2 + 7) / 8) * 64 * NT * 16;
-    if (g_mlp_bf16 && w16 + sbytes <= 156 * 1024) {
+    // bf16 only behind a BatchNorm+ReLU (q.scale): the FIRST conv of a stack sees raw coordinates /
+    // geometric features (|mean| / sigma ~ 30 for the attention inputs), which 8 mantissa bits destroy
+    if (g_mlp_bf16 && q.scale && w16 + sbytes <= 156 * 1024) {
         static bool attr16 = false;
         if (!attr16) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -902,7 +904,7 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C)
 template <int MT, int NQ, int NP, int NS>
 static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
 {
-    if (g_mlp_bf16)
+    if (g_mlp_bf16 && p.pscale)   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
         gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
     else
         gg_k_linear_dw_direct<MT, NQ, NP, NS, false><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
