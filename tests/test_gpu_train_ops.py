@@ -455,7 +455,7 @@ def test_bf16_mode_whole_model_loss_and_gradient_direction():
     0.4 % perturbation of the pair features flips the arg-max of the neighbour max-pool in a fraction
     of the (centre, channel) pairs, which re-routes their gradient to another edge."""
     import copy
-    from grid_gcn_amd import model, train_ops
+    from grid_gcn_amd import model, synth, train_ops
     torch.manual_seed(3)
     cfg = dict(model.SEG_81920, dropout=0.0)
     net = model.GGCNSeg(cfg, fixed_seed=True).to(DEV).train()
