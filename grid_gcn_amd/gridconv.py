@@ -59,6 +59,22 @@ def mlp(cin, dims, bn_decay=0.9):
     return nn.Sequential(*layers)
 
 
+_warned_shapes = set()
+
+
+def _warn_stock_fallback(layers, x):
+    """The MFMA training kernels take stacks of <= 256 output / <= 384 input channels (fp32,
+    contiguous rows); anything else runs on the stock PyTorch modules -- several times slower.  Say
+    so once per shape instead of silently ("silent perf cliff")."""
+    key = (tuple((l.lin.in_features, l.lin.out_features) for l in layers), str(x.dtype))
+    if key not in _warned_shapes:
+        _warned_shapes.add(key)
+        import warnings
+        warnings.warn("grid_gcn_amd: conv+BN+ReLU stack %s (%s) is outside the hand-written training "
+                      "kernels' domain; running it on the stock PyTorch modules" % (key[0], key[1]),
+                      RuntimeWarning, stacklevel=3)
+
+
 def run_mlp(layers, x, mfma=True):
     """A stack of ConvBNReLU layers.  Training on the GPU: one autograd op over the hand-written
     kernels (train_ops.mlp_bn_relu_train); otherwise the stock PyTorch modules."""
@@ -66,6 +82,7 @@ def run_mlp(layers, x, mfma=True):
         from . import train_ops
         if train_ops.supported(layers, x):
             return train_ops.mlp_bn_relu_train(x, layers)
+        _warn_stock_fallback(layers, x)
     if mfma and x.is_cuda and layers and not layers[0].training and not torch.is_grad_enabled():
         from . import train_ops
         if train_ops.supported(layers, x) and all(l.lin.in_features <= 1024 for l in layers):
