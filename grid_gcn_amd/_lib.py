@@ -31,6 +31,8 @@ EXPORTS = [
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
+    "gridgcn_linear_fwd_direct2", "gridgcn_ctx_max", "gridgcn_ctx_max_backward",
+    "gridgcn_bn_dz_segsum", "gridgcn_sparse_add",
 ]
 
 
@@ -136,6 +138,17 @@ def load():
     lib.gridgcn_take_backward_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_fwd_direct.restype = ci
     lib.gridgcn_linear_fwd_direct.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_linear_fwd_direct2.restype = ci
+    lib.gridgcn_linear_fwd_direct2.argtypes = [vp, ci, ci, vp, ci, ci, ll, vp, vp, vp, ci, ci, ci,
+                                               vp, vp, vp, vp, vp]
+    lib.gridgcn_ctx_max.restype = ci
+    lib.gridgcn_ctx_max.argtypes = [vp, vp, vp] + [ci] * 6 + [vp, vp, vp]
+    lib.gridgcn_ctx_max_backward.restype = ci
+    lib.gridgcn_ctx_max_backward.argtypes = [vp, vp, ll, ci, ci, vp, vp]
+    lib.gridgcn_bn_dz_segsum.restype = ci
+    lib.gridgcn_bn_dz_segsum.argtypes = [vp] * 8 + [ll, ci, ci, vp, vp]
+    lib.gridgcn_sparse_add.restype = ci
+    lib.gridgcn_sparse_add.argtypes = [vp, vp, ll, ci, ci, vp, vp]
     cf = ctypes.c_float
     lib.gridgcn_bn_finalize.restype = ci
     lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp]

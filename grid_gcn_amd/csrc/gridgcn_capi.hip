@@ -8,6 +8,7 @@
 #include "gridgcn_csr.h"
 #include "gridgcn_edgelin.h"
 #include "gridgcn_atteval.h"
+#include "gridgcn_clsblock.h"
 
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
@@ -459,6 +460,60 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
     p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.dbg = 0;
     int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_linear_fwd_direct2(const float *X1, int ld1, int K1, const float *X2, int ld2, int K2,
+                               long long E, const float *Wq, const float *b, const float *rowbias,
+                               int P, int ldw, int cout, const float *scale, const float *shift,
+                               float *Z, double *sums, void *stream)
+{
+    if (!X1 || !X2 || !Wq || !Z || (!b && !rowbias) || cout < 1 || cout > ldw ||
+        (scale && !shift) || K1 < 32 || (K1 & 31) || K2 < 8 || (K2 & 7) || ld1 < K1 || ld2 < K2 ||
+        ((ld1 | ld2) & 3) || (((uintptr_t)X1 | (uintptr_t)X2) & 15))
+        return GRIDGCN_EINVAL;
+    if (rowbias && (P < 32 || (P & 31) || E % P)) return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X1; p.W = Wq; p.b = b ? b : rowbias; p.scale = scale; p.shift = shift; p.Z = Z;
+    p.sums = sums; p.E = E; p.cin = K1 + K2; p.K = K1 + K2; p.ldw = ldw; p.cout = cout;
+    p.lda = ld1; p.dbg = 0;
+    p.X2 = X2; p.K1 = K1; p.lda2 = ld2; p.rowbias = rowbias; p.P = P;
+    int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_ctx_max(const float *src, const int32_t *nebidx, const float *cent, int cent_stride,
+                    int B, int Nsrc, int Cs, int O, int P, float *ctx, int32_t *cidx, void *stream)
+{
+    if (!src || !nebidx || !cent || !ctx || B < 1 || Nsrc < 1 || O < 1 || P < 1 || cent_stride < 3)
+        return GRIDGCN_EINVAL;
+    int rc = gg_ctx_max(src, nebidx, cent, cent_stride, B, Nsrc, Cs, O, P, ctx, cidx,
+                        (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_ctx_max_backward(const float *dctx, const int32_t *cidx, long long ncent, int Cf, int Cs,
+                             float *dsrc, void *stream)
+{
+    if (!dctx || !cidx || !dsrc || ncent < 1 || Cf < 0 || Cs != Cf + 4) return GRIDGCN_EINVAL;
+    return gg_ctx_scatter(dctx, cidx, ncent, Cf, Cs, dsrc, (hipStream_t)stream);
+}
+
+int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, const float *shift,
+                         const float *mean, const float *rstd, const float *m1, const float *m2,
+                         long long ncent, int P, int C, float *out, void *stream)
+{
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !out || ncent < 1 || P < 1)
+        return GRIDGCN_EINVAL;
+    int rc = gg_dz_segsum(dY, Z, scale, shift, mean, rstd, m1, m2, ncent, P, C, out,
+                          (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_sparse_add(const int32_t *amax, const float *gval, long long ncent, int P, int C,
+                       float *dX, void *stream)
+{
+    if (!amax || !gval || !dX || ncent < 1 || P < 1 || C < 1) return GRIDGCN_EINVAL;
+    return gg_sparse_add(amax, gval, ncent, P, C, dX, (hipStream_t)stream);
 }
 
 int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,

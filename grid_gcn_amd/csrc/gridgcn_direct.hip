@@ -138,14 +138,18 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
         long long row = r0 + (lane & 31);
         if (row >= p.E) row = p.E - 1;
         const float *xr = p.X + row * p.lda;          // lda = row stride of X (>= K)
+        // two-source rows (p.X2): columns [0, K1) come from X, [K1, K) from X2 -- the concatenation
+        // the classification attention MLP consumes is never written (K1 % 32 == 0)
+        const float *xr2 = p.X2 ? p.X2 + row * p.lda2 - p.K1 : xr;
         ggm_f32x16 acc[NT];
         ggm_zero<NT>(acc);
         int s = 0;
         for (int c = 0; c < nfull; c++) {
             const int k0 = c * 32 + h * 16;
+            const float *xc = (c * 32 < p.K1) ? xr : xr2;
             float4 a[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) a[q] = *(const float4 *)(xr + k0 + 4 * q);
+            for (int q = 0; q < 4; q++) a[q] = *(const float4 *)(xc + k0 + 4 * q);
             if (p.scale) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
                 for (int q = 0; q < 4; q++) {
                     at[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (q < nq) {
-                        at[q] = *(const float4 *)(xr + k0 + 4 * q);
+                        at[q] = *(const float4 *)(xr2 + k0 + 4 * q);
                         if (p.scale)
                             at[q] = gg_bnrelu4(at[q], *(const float4 *)(scl + k0 + 4 * q),
                                                *(const float4 *)(scl + K + k0 + 4 * q));
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
                 }
             } else {
             for (int q = 0; q < nq; q++) {
-                float4 a = *(const float4 *)(xr + k0 + 4 * q);
+                float4 a = *(const float4 *)(xr2 + k0 + 4 * q);
                 if (p.scale)
                     a = gg_bnrelu4(a, *(const float4 *)(scl + k0 + 4 * q),
                                    *(const float4 *)(scl + K + k0 + 4 * q));
@@ -225,6 +229,16 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
         const int ldz = EXACT ? NT * 32 : p.cout;
+        if (p.rowbias) {
+            // bias per group of P rows (P % 32 == 0: one group per tile): the contribution of the
+            // per-centre context vector, constant over a centre's neighbours
+            const float *rb = p.rowbias + (r0 / p.P) * p.cout;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int col = t * 32 + (lane & 31);
+                bias[t] = col < p.cout ? rb[col] : 0.f;
+            }
+        }
         float *zp = p.Z + (r0 + 4 * h) * ldz + (lane & 31);
         if (nrows == 32) {
 #pragma unroll
@@ -369,8 +383,10 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         if (BF16) {
             gg_stage_w_bf16<NTV>((ggm_u32x4 *)Wl, p.Wdx, C / 2, tid, blockDim.x);
         } else {
-            const float4 *src = (const float4 *)p.Wdx;
-            for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
+            // (column-half mode, NT == 4 of a layout packed for 8 tiles: every second float4)
+            const float4 *src = (const float4 *)p.Wdx + (p.dx_col0 ? 1 : 0);
+            const int ws = p.dx_wstride;
+            for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[(size_t)i * ws];
         }
         for (int c = tid; c < C; c += blockDim.x) {
             const float sc = p.scale[c];
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         a1[t] = 0.f; a2[t] = 0.f;
-        const int col = t * 32 + (lane & 31);
+        const int col = p.dx_col0 + t * 32 + (lane & 31);
         const bool ok = prevbn && col < p.ndx;
         ps[t] = ok ? p.pscale[col] : 0.f; psh[t] = ok ? p.pshift[col] : 0.f;
         pm[t] = ok ? p.pmean[col] : 0.f;  pr[t] = ok ? p.prstd[col] : 0.f;
@@ -511,12 +527,12 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             }
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        const long long base = (r0 + 4 * h) * ldx + (lane & 31);
+        const long long base = (r0 + 4 * h) * ldx + p.dx_col0 + (lane & 31);
         float *xp = p.dX + base;
         const float *ap = p.Aprev + base;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            if (t * 32 + (lane & 31) < p.ndx) {
+            if (p.dx_col0 + t * 32 + (lane & 31) < p.ndx) {
                 float s1 = 0.f, s2 = 0.f;
                 // all 16 loads of the previous layer's raw output first: dX and Aprev may alias as
                 // far as the compiler knows, so loads placed between the stores were serialised
@@ -566,10 +582,10 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
     __syncthreads();
     for (int i = tid; i < 2 * NT * 32; i += blockDim.x) {
         const int which = i / (NT * 32), col = i - which * NT * 32;
-        if (col >= p.ndx) continue;
+        if (p.dx_col0 + col >= p.ndx) continue;
         float v = 0.f;
         for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
-        atomicAdd(&p.psums[which * p.cin + col], (double)v);
+        atomicAdd(&p.psums[which * p.cin + p.dx_col0 + col], (double)v);
     }
 }
 
@@ -592,7 +608,18 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
                       : ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     if (lds < rbytes) lds = rbytes;
-    if (lds > 156 * 1024) return 1;
+    if (lds > 156 * 1024) {
+        // fp32 operand of 5..8 column tiles too large for LDS (C > 151): two passes of 4 tiles over
+        // the same packed operand (each stages every second float4 of it)
+        if (NT <= 4 || bf16 || p.dx_wstride != 1) return 1;
+        GGLinBwd q = p;
+        q.dx_wstride = 2;
+        q.dx_col0 = 0;
+        const int rc = launch_dx_direct<4>(q, st);
+        if (rc) return rc;
+        q.dx_col0 = 128;
+        return launch_dx_direct<4>(q, st);
+    }
     int per_cu = NT <= 2 ? 3 : 2;
     while (per_cu > 1 && per_cu * lds > 152 * 1024) per_cu--;
     const long long ntile = (p.E + 31) >> 5;

@@ -13,6 +13,12 @@ struct GGLinFwd {
     long long E;
     int cin, K, ldw, cout, lda;
     int dbg;              // ablation switches (GG_DBG env): 1 no Z store, 2 stage once, 4 no MFMA
+    // register-direct kernel only: second row source for columns [K1, K) (nullptr: X holds all K),
+    // and a bias per group of P consecutive rows [E/P][cout] replacing b (nullptr: b)
+    const float *X2 = nullptr;
+    int K1 = 0, lda2 = 0;
+    const float *rowbias = nullptr;
+    int P = 0;
 };
 
 struct GGLinBwd {
@@ -42,6 +48,8 @@ struct GGLinBwd {
     const unsigned long long *drop_dev;    // optional device scalar added to the dropout seed
     unsigned drop_thr, drop_lo, drop_hi;   // register-direct dX only: dX *= dropout mask of the
     float drop_scale;                      // [E][cin] input activation (gg_drop_keep), thr 0 = off
+    int dx_col0 = 0;      // register-direct dX: first output column of this launch (0 / 128) and
+    int dx_wstride = 1;   //   float4 stride while staging Wdx (2: one half of an 8-tile layout)
     int rt;               // rows per workgroup tile of gg_k_linear_dw (32/64/96/128)
     unsigned t1[4];       // per wave: up to 3 GEMM1 column tiles, one byte each, 0xff = none
     unsigned t2[4][3];    // per wave: up to 12 GEMM2 (m,n) pair ids, one byte each, 0xff = none

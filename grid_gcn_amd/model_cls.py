@@ -44,6 +44,30 @@ class SubGUpdateCls(nn.Module):
 
     mfma_train = True
 
+    def forward_src(self, cent, src, nebidx, center_masks=None):
+        """On the GPU from the un-gathered source points: the whole edge block on the hand-written
+        kernels (train_ops._EdgeBlockClsTrain; evaluation under no_grad: edge_block_cls_eval with
+        the running statistics) -- no gathered [E, 4+C] tensor, no concat, no tiled context.  None when the shapes are outside the kernels' domain (the caller
+        then gathers and uses forward())."""
+        from . import train_ops
+        train = self.training and torch.is_grad_enabled()
+        infer = not self.training and not torch.is_grad_enabled()
+        if not (self.mfma_train and src.is_cuda and (train or infer)):
+            return None
+        if self.has_feats and self.localfdim == 0:
+            return None
+        pt, a1, a2 = list(self.pt_mlp), list(self.att1), list(self.att2)
+        if not train_ops.edge_block_cls_supported(pt, a1, a2, src, nebidx.shape[2]):
+            return None
+        if train:
+            agg = train_ops.edge_block_cls_train(src, nebidx, cent, pt, a1, a2)
+        else:
+            agg = train_ops.edge_block_cls_eval(src, nebidx, cent, pt, a1, a2)
+        # (relu of a product of two relu outputs is the identity: gcn_module_g.py's relu=True)
+        if center_masks is not None:
+            agg = agg * center_masks[..., None]
+        return agg
+
     def forward(self, centers_xyz, neighbors, center_masks=None):
         nbr_xyz = neighbors[..., 0:3]
         geo_vec = nbr_xyz - centers_xyz[:, :, None, :]
@@ -117,8 +141,10 @@ class GGCNCls(nn.Module):
             nebidx, nebidxmsk, cent, centmsk, num = ix.Gridify(
                 data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed), **sd)
             data_loc = cent
-            neighbors = ix.batch_take_g(data.contiguous(), nebidx, **self._take_kw)  # :94
-            cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104
+            cf = layer.forward_src(cent, data, nebidx, centmsk) if self._take_kw else None
+            if cf is None:
+                neighbors = ix.batch_take_g(data.contiguous(), nebidx, **self._take_kw)  # :94
+                cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104
             data = torch.cat([cent, cf], dim=2)                                   # :106
         net = cf.reshape(cf.shape[0], -1)                                         # flatten=True
         return self.fc3(self.fc2(self.fc1(net)))

@@ -301,6 +301,36 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream);
 /* (ldx = row stride of X in floats, >= K, a multiple of 4, X 16-byte aligned; sums may be NULL.) */
+/* ---- classification edge block (classification/models/gcn_module_g.py:64-114 verts_pair_func
+ *      with att_full='next'; :212-223 contextvec_func) -----------------------------------------
+ * The classifier's attention MLP reads concat(att1(att_vec), pt_mlp(nf), context) per edge; the
+ * concatenation is never written:
+ * gridgcn_linear_fwd_direct2: as gridgcn_linear_fwd_direct with the K1 + K2 input columns taken from
+ *   two tensors (X1[E][ld1] columns [0,K1), K1 % 32 == 0; X2[E][ld2] columns [0,K2), K2 % 8 == 0;
+ *   Wq / scale / shift indexed by the concatenated column) and, when rowbias != NULL, a bias per
+ *   group of P consecutive rows rowbias[E/P][cout] instead of b (P % 32 == 0): the context term
+ *   ctx[centre] Wc^T + b, constant over a centre's neighbours.
+ * gridgcn_ctx_max: ctx[B*O][3 + Cf] = max over the P neighbours of (xyz_nbr - xyz_centre | features
+ *   of the neighbour) read from src[B][Nsrc][Cs = 4 + Cf] through nebidx (take mode 'clip');
+ *   cidx[B*O][Cf] (may be NULL) = flat source row of the arg-max of every feature column.
+ * gridgcn_ctx_max_backward: dsrc[cidx[c][j]][4 + j] += dctx[c][3 + j] (atomic; dsrc [B*Nsrc][Cs]).
+ * gridgcn_bn_dz_segsum: out[c][:] = sum over the P rows of centre c of dZ, dZ = the BatchNorm+ReLU
+ *   backward of (dY, Z) as in gridgcn_linear_bwd: the gradient of the per-centre bias.
+ * gridgcn_sparse_add: dX[c*P + amax[c][ch]][ch] += gval[c][ch]: the sparse product/max gradient
+ *   (gridgcn_pairmax_bwd) folded into a dense gradient of the same tensor. */
+int gridgcn_linear_fwd_direct2(const float *X1, int ld1, int K1, const float *X2, int ld2, int K2,
+                               long long E, const float *Wq, const float *b, const float *rowbias,
+                               int P, int ldw, int cout, const float *scale, const float *shift,
+                               float *Z, double *sums, void *stream);
+int gridgcn_ctx_max(const float *src, const int32_t *nebidx, const float *cent, int cent_stride,
+                    int B, int Nsrc, int Cs, int O, int P, float *ctx, int32_t *cidx, void *stream);
+int gridgcn_ctx_max_backward(const float *dctx, const int32_t *cidx, long long ncent, int Cf, int Cs,
+                             float *dsrc, void *stream);
+int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, const float *shift,
+                         const float *mean, const float *rstd, const float *m1, const float *m2,
+                         long long ncent, int P, int C, float *out, void *stream);
+int gridgcn_sparse_add(const int32_t *amax, const float *gval, long long ncent, int P, int C,
+                       float *dX, void *stream);
 /* gridgcn_pack_linear: W[C][cin_w] (framework layout, C <= 256), b[C]; the kernels see `cin` >=
  *   cin_w input channels: kernel column k = framework column k + rot (k < cin_w - rot), k - (cin_w -
  *   rot) (k < cin_w), zero (k >= cin_w) -- i.e. the first `rot` columns moved behind the others and
