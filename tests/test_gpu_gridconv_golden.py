@@ -41,11 +41,11 @@ def run_hip(case, m, train):
             return m.forward_src(cent, src, idx, cm, center_ori_feats=cof)
         with torch.no_grad():
             return m.forward_fused(cent, src, idx, cm, center_ori_feats=cof)
-    nb = ops.batch_take_g(src, idx, neighbour_index=True)
-    if train:
-        return m(cent[..., 0:3], nb, cm)
-    with torch.no_grad():
-        return m(cent[..., 0:3], nb, cm)
+    # classification block: the kernels of train_ops._EdgeBlockClsTrain / edge_block_cls_eval
+    with (torch.enable_grad() if train else torch.no_grad()):
+        out = m.forward_src(cent, src, idx, cm)
+    assert out is not None, "classification edge block fell back to the stock modules"
+    return out
 
 
 def run_stock_gpu(case, m, train):
@@ -93,9 +93,11 @@ def test_hip_train_not_worse_than_stock_fp32(name):
     assert e_hip <= max(2.0 * e_stock, 1e-5 * scale), (name, e_hip, e_stock)
 
 
-@pytest.mark.parametrize("name", ["gridconv_seg_L1", "gridconv_up2"])
+@pytest.mark.parametrize("name", ["gridconv_seg_L1", "gridconv_up2", "gridconv_cls_L0"])
 def test_hip_gradients_bounded_by_stock_fp32(name):
     case = gc.CASES[name]()
+    seg = case["kind"] == "seg"
+    kw = (lambda cof: dict(center_ori_feats=cof)) if seg else (lambda cof: {})
     rng = np.random.default_rng(7)
     B, O = case["nebidx"].shape[0], case["nebidx"].shape[1]
 
@@ -105,7 +107,9 @@ def test_hip_gradients_bounded_by_stock_fp32(name):
         out = fwd(m, src)
         G = torch.from_numpy(rng_cot[:, :, :out.shape[2]]).to(dev).to(dtype)
         (out * G).sum().backward()
-        gs = {"src": src.grad[..., 4:].detach().double().cpu().numpy()}
+        gs = {}
+        if src.shape[2] > 4:
+            gs["src"] = src.grad[..., 4:].detach().double().cpu().numpy()
         for n_, p in m.named_parameters():
             if p.grad is not None:
                 gs[n_] = p.grad.detach().double().cpu().numpy()
@@ -123,7 +127,7 @@ def test_hip_gradients_bounded_by_stock_fp32(name):
         cm = None if case["centmsk"] is None else torch.from_numpy(case["centmsk"]).to(src.dtype)
         cof = None if case["center_ori_feats"] is None else \
             torch.from_numpy(case["center_ori_feats"]).to(src.dtype)
-        return m(cent[..., 0:3], nb, cm, center_ori_feats=cof)
+        return m(cent[..., 0:3], nb, cm, **kw(cof))
 
     def fwd_stock_gpu(m, src):
         cent, idx = T(case["cent"]), T(case["nebidx"])
@@ -132,13 +136,15 @@ def test_hip_gradients_bounded_by_stock_fp32(name):
         m.mfma_train = False
         Bn, N, C = src.shape
         flat = (idx.long() + (torch.arange(Bn, device=DEV) * N).view(Bn, 1, 1)).clamp(0, Bn * N - 1)
-        return m(cent[..., 0:3], src.reshape(Bn * N, C)[flat], cm, center_ori_feats=cof)
+        return m(cent[..., 0:3], src.reshape(Bn * N, C)[flat], cm, **kw(cof))
 
     def fwd_hip(m, src):
         cent, idx = T(case["cent"]), T(case["nebidx"])
         cm = None if case["centmsk"] is None else T(case["centmsk"])
         cof = None if case["center_ori_feats"] is None else T(case["center_ori_feats"])
-        return m.forward_src(cent, src, idx, cm, center_ori_feats=cof)
+        out = m.forward_src(cent, src, idx, cm, **kw(cof))
+        assert out is not None
+        return out
 
     g64 = grads(m64, fwd_cpu, torch.float64, "cpu")
     g_stock = grads(gc.build_module(case).to(DEV), fwd_stock_gpu, torch.float32, DEV)
