@@ -13,6 +13,7 @@ EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",
     "gridgcn_get_mlp_precision",
     "gridgcn_gridify_workspace_bytes", "gridgcn_gridify", "gridgcn_gridify_timed",
+    "gridgcn_gridify_occaware_workspace_bytes", "gridgcn_gridify_occaware",
     "gridgcn_gridify_knn_workspace_bytes", "gridgcn_gridify_knn",
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
@@ -76,7 +77,7 @@ def load():
     lib.gridgcn_set_mlp_precision.argtypes = [ci]
     lib.gridgcn_get_mlp_precision.restype = ci
     for name in ("gridgcn_gridify_workspace_bytes", "gridgcn_gridify_knn_workspace_bytes",
-                 "gridgcn_gridify_up_workspace_bytes"):
+                 "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_occaware_workspace_bytes"):
         f = getattr(lib, name)
         f.restype = ci
         f.argtypes = [ci, ci, pp, ctypes.POINTER(cs)]
@@ -84,6 +85,9 @@ def load():
         f = getattr(lib, name)
         f.restype = ci
         f.argtypes = [vp, vp, ci, ci, pp, vp, vp, vp, vp, vp, vp, cs, vp]
+    lib.gridgcn_gridify_occaware.restype = ci
+    lib.gridgcn_gridify_occaware.argtypes = [vp, vp, ci, ci, pp, ctypes.c_float, vp, vp, vp, vp, vp,
+                                             vp, cs, vp]
     lib.gridgcn_gridify_timed.restype = ci
     lib.gridgcn_gridify_timed.argtypes = [vp, vp, ci, ci, pp, vp, vp, vp, vp, vp, vp, cs, vp, ci,
                                           ctypes.POINTER(ctypes.c_float)]

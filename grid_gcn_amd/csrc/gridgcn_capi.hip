@@ -130,10 +130,13 @@ int gridgcn_gridify_workspace_bytes(int B, int N, const gridgcn_grid_params *p, 
     return GRIDGCN_OK;
 }
 
+static size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// cas_beta < 0: random voxel sampling (the reference's source); >= 0: coverage-aware refinement
 static int gridify_common(bool knn, const float *data, const int32_t *np, int B, int N,
                           const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk,
                           float *cent, float *centmsk, int32_t *centnum, void *ws,
-                          size_t ws_bytes, void *stream)
+                          size_t ws_bytes, void *stream, float cas_beta = -1.0f)
 {
     GGGrid gp;
     int rc = fill_grid(p, B, N, false, &gp);
@@ -141,11 +144,18 @@ static int gridify_common(bool knn, const float *data, const int32_t *np, int B,
     if (!data || !np || !nebidx || !nebmsk || !cent || !centmsk || !centnum) return GRIDGCN_EINVAL;
     GGIndexWs w;
     size_t need = gg_index_workspace_bytes(B, N, gp, true, &w);
+    const size_t cas_off = ws_align(need);
+    if (cas_beta >= 0.0f) need = cas_off + gg_cas_workspace_bytes(B, N, gp);
     if (!ws || ws_bytes < need) return GRIDGCN_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (ensure_init()) return GRIDGCN_ELAUNCH;
     rc = gg_index_build(data, np, B, N, gp, true, centnum, (char *)ws, w, st);
     if (rc) return rc;
+    if (cas_beta >= 0.0f) {
+        rc = gg_cas_refine(data, np, B, N, gp, cas_beta, (int *)((char *)ws + w.o_slotfirst1),
+                           centnum, (char *)ws + cas_off, st);
+        if (rc) return rc;
+    }
     if (knn)
         return gg_launch_query_knn(data, B, N, gp, (char *)ws, w, nebidx, nebmsk, cent, centmsk,
                                    centnum, st);
@@ -159,6 +169,28 @@ int gridgcn_gridify(const float *data, const int32_t *np, int B, int N,
 {
     return gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
                           ws_bytes, stream);
+}
+
+int gridgcn_gridify_occaware_workspace_bytes(int B, int N, const gridgcn_grid_params *p,
+                                             size_t *bytes)
+{
+    GGGrid gp;
+    int rc = fill_grid(p, B, N, false, &gp);
+    if (rc || !bytes) return rc ? rc : GRIDGCN_EINVAL;
+    *bytes = ws_align(gg_index_workspace_bytes(B, N, gp, true, nullptr)) +
+             gg_cas_workspace_bytes(B, N, gp);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_gridify_occaware(const float *data, const int32_t *np, int B, int N,
+                             const gridgcn_grid_params *p, float beta, int32_t *nebidx,
+                             float *nebmsk, float *cent, float *centmsk, int32_t *centnum, void *ws,
+                             size_t ws_bytes, void *stream)
+{
+    if (!(beta >= 0.0f)) return GRIDGCN_EINVAL;
+    if (p && p->max_o_grid > 16384) return GRIDGCN_EINVAL;
+    return gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
+                          ws_bytes, stream, beta);
 }
 
 int gridgcn_gridify_timed(const float *data, const int32_t *np, int B, int N,

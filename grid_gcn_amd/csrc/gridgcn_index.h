@@ -63,3 +63,8 @@ int gg_index_legacy_build(const float *data, const int *np, int B, int N, const 
                           bool with_centres, int *centnum, char *wsbase, const GGIndexWs &w,
                           hipStream_t st);
 int gg_index_legacy_init();
+
+// gridgcn_cas.hip: coverage-aware refinement of the centre slots (parity unpinned, see there)
+size_t gg_cas_workspace_bytes(int B, int N, const GGGrid &gp);
+int gg_cas_refine(const float *data, const int *np, int B, int N, const GGGrid &gp, float beta,
+                  int *slotfirst1, const int *centnum, char *ws, hipStream_t st);

@@ -97,7 +97,7 @@ def _workspace(nbytes, device):
 
 
 def _gridify_like(fn_name, data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, stride,
-                  loc, coord_shift, voxel_size, grid_size, seed, seed_dev=None):
+                  loc, coord_shift, voxel_size, grid_size, seed, seed_dev=None, extra=()):
     lib = _lib.load()
     _chk(data, "data", 3, torch.float32, 4)
     B, N, _ = data.shape
@@ -117,7 +117,7 @@ def _gridify_like(fn_name, data, actual_numpoints, max_p_grid, max_o_grid, kerne
         cent = torch.empty((B, O, 4), dtype=torch.float32, device=dev)
         centmsk = torch.empty((B, O), dtype=torch.float32, device=dev)
         actual_centnum = torch.empty((B, 1), dtype=torch.int32, device=dev)
-        rc = getattr(lib, fn_name)(_ptr(data), _ptr(actual_numpoints), B, N, ctypes.byref(p),
+        rc = getattr(lib, fn_name)(_ptr(data), _ptr(actual_numpoints), B, N, ctypes.byref(p), *extra,
                                    _ptr(nebidx), _ptr(nebidxmsk), _ptr(cent), _ptr(centmsk),
                                    _ptr(actual_centnum), _ptr(ws), nbytes.value, _stream(data))
     _lib.check(rc, fn_name)
@@ -136,6 +136,20 @@ def Gridify(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stri
     return _gridify_like("gridgcn_gridify", data, actual_numpoints, max_p_grid, max_o_grid,
                          kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed,
                          seed_dev)
+
+
+@torch.no_grad()
+def Gridify_occaware(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
+                     coord_shift, voxel_size, grid_size, seed=0, seed_dev=None, beta=1.0):
+    """Gridify with Coverage-Aware Sampling of the centre voxels (the paper's CAS; the reference
+    registers it as `Gridify_occaware` but ships no source for it: gridifyop/additional.so).
+    PARITY UNPINNED -- our own restatement of the paper's section 3.2 (include/gridgcn.h,
+    oracle/gridgcn_oracle.c: gridgcn_oracle_gridify_occaware) is what this is checked against.
+    Same signature and outputs as Gridify; beta >= 0 weighs the over-coverage penalty of eq. 3."""
+    _require(float(beta) >= 0.0, "beta must be >= 0")
+    return _gridify_like("gridgcn_gridify_occaware", data, actual_numpoints, max_p_grid, max_o_grid,
+                         kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed,
+                         seed_dev, extra=(ctypes.c_float(float(beta)),))
 
 
 @torch.no_grad()

@@ -11,6 +11,8 @@ torch.compile / export:
                               stride=, loc=, coord_shift=, voxel_size=, grid_size=, seed=0)
         -> (nebidx, nebidxmsk, cent, centmsk, actual_centnum)
     torch.ops.gridgcn.gridify_knn(...)            same
+    torch.ops.gridgcn.gridify_occaware(..., beta=1.0)   same + coverage-aware sampling (parity
+                                                  unpinned: binary-only in the reference)
     torch.ops.gridgcn.gridify_up(downdata, updata, down_actual_numpoints, up_actual_numpoints,
                                  max_p_grid=, max_o_grid=, kernel_size=, coord_shift=, voxel_size=,
                                  grid_size=, seed=0) -> (nebidx, nebidxmsk)
@@ -63,8 +65,28 @@ def _gridify_fake(data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, s
             data.new_empty((B, 1), dtype=torch.int32))
 
 
+@_lib_def("gridgcn::gridify_occaware", mutates_args=(), device_types="cuda")
+def gridify_occaware(data: Tensor, actual_numpoints: Tensor, max_p_grid: int, max_o_grid: int,
+                     kernel_size: int, stride: int, loc: int, coord_shift: List[float],
+                     voxel_size: List[float], grid_size: List[int], seed: int = 0,
+                     beta: float = 1.0) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """`Gridify_occaware` (coverage-aware sampling; the reference ships it as a binary only --
+    parity unpinned, see ops.Gridify_occaware)."""
+    return ops.Gridify_occaware(data, actual_numpoints, max_p_grid=max_p_grid,
+                                max_o_grid=max_o_grid, kernel_size=kernel_size, stride=stride,
+                                loc=loc, coord_shift=coord_shift, voxel_size=voxel_size,
+                                grid_size=grid_size, seed=seed, beta=beta)
+
+
 gridify.register_fake(_gridify_fake)
 gridify_knn.register_fake(_gridify_fake)
+
+
+@gridify_occaware.register_fake
+def _(data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift,
+      voxel_size, grid_size, seed=0, beta=1.0):
+    return _gridify_fake(data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, stride, loc,
+                         coord_shift, voxel_size, grid_size, seed)
 
 
 @_lib_def("gridgcn::gridify_up", mutates_args=(), device_types="cuda")

@@ -88,6 +88,22 @@ int gridgcn_gridify(const float *data, const int32_t *actual_numpoints, int B, i
                     int32_t *actual_centnum,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Gridify_occaware: Gridify with Coverage-Aware Sampling (CAS) of the centre voxels ---------
+ * PARITY UNPINNED: the reference holds this operator only as a binary (gridifyop/additional.so,
+ * symbols GridifyOp_occaware*, gridify_occaware_sampling; no source, no caller).  Implemented from
+ * the paper (Grid-GCN, CVPR 2020, section 3.2 eq. 3-4) under the schedule written down in
+ * oracle/gridgcn_oracle.c: the RVS sample of gridgcn_gridify gives the incumbents; every other
+ * occupied voxel, in order of first appearance, challenges one random incumbent and replaces it
+ * when H_add > H_rmv (beta >= 0 weighs the over-coverage penalty; beta = 0: pure coverage).
+ * Same inputs / outputs / attributes as gridgcn_gridify; max_o_grid <= 16384. */
+int gridgcn_gridify_occaware_workspace_bytes(int B, int N, const gridgcn_grid_params *p,
+                                             size_t *bytes);
+int gridgcn_gridify_occaware(const float *data, const int32_t *actual_numpoints, int B, int N,
+                             const gridgcn_grid_params *p, float beta,
+                             int32_t *nebidx, float *nebidxmsk, float *cent, float *centmsk,
+                             int32_t *actual_centnum,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* Measurement helper: `iters` back-to-back gridgcn_gridify calls on `stream`, bracketed by HIP
  * events recorded on that stream; *ms_per_call = average device time of one call (all of its
  * launches, no host work in between except the launches themselves).  Synchronises the stream. */

@@ -111,6 +111,8 @@ static inline int voxel_of(const float *p, const float *shift, const float *vs,
 }
 
 typedef struct {
+    int *order_vox;  /* optional: voxel of first-appearance rank t        [G] (CAS only) */
+    int *order_idx;  /* optional: global index of that voxel's first point [G] (CAS only) */
     int *cnt;        /* coor_counter         [G]   */
     int *bucket;     /* coor_to_pntidx       [G*P] */
     float *sums;     /* coor_to_locxyzw      [G*4] */
@@ -148,6 +150,7 @@ static int build_index_cloud(const float *data, int b, int N, int np, int P, int
         if (!T->touched[v]) {                                  /* :165-172 */
             T->touched[v] = 1;
             int t = centcount++;                               /* :176 */
+            if (T->order_vox) { T->order_vox[t] = v; T->order_idx[t] = index; }
             if (t < O) {
                 T->slot2vox[t] = v;                            /* :179 */
                 centmsk[t] = 1.0f;                             /* :180 */
@@ -162,6 +165,8 @@ static int build_index_cloud(const float *data, int b, int N, int np, int P, int
 
 static void alloc_tables(build_tables *T, int G, int P, int O)
 {
+    T->order_vox = NULL;
+    T->order_idx = NULL;
     T->cnt = (int *)calloc((size_t)G, sizeof(int));
     T->bucket = (int *)malloc((size_t)G * P * sizeof(int));
     T->sums = (float *)calloc((size_t)G * 4, sizeof(float));
@@ -170,6 +175,7 @@ static void alloc_tables(build_tables *T, int G, int P, int O)
 }
 static void free_tables(build_tables *T)
 {
+    free(T->order_vox); free(T->order_idx);
     free(T->cnt); free(T->bucket); free(T->sums); free(T->touched); free(T->slot2vox);
 }
 
@@ -187,12 +193,110 @@ static void init_outputs_cloud(int O, int P, int *nebidx, float *nebmsk, float *
 /* ------------------------------ Gridify -------------------------------------- */
 /* data[B,N,4] f32, actual_numpoints[B] i32 -> nebidx[B,O,P] i32, nebidxmsk[B,O,P] f32,
  * cent[B,O,4] f32, centmsk[B,O] f32, actual_centnum[B] i32   (gridify-inl.h:190-195) */
+/* ---- Coverage-Aware Sampling (CAS) of the centre voxels: OUR specification ---------------------
+ * PARITY UNPINNED.  The reference has no source for it (gridifyop/additional.so: Gridify_occaware*,
+ * SURVEY F3); this is the greedy algorithm of the paper (Grid-GCN, CVPR 2020, section 3.2):
+ *   incumbents  = the RVS sample of the build above: slots 0..M-1, M = min(#occupied, O)
+ *   challengers = the occupied voxels that are NOT incumbents after the build, in order of first
+ *                 appearance (rank t of gridify.cu:176); a voxel that loses its slot later is not
+ *                 re-entered
+ *   a challenger Vc meets ONE random incumbent: slot s = ceil(u*M) - 1, u = XORWOW(index + 3*seed),
+ *                 index = global index of Vc's first point (the seed pattern of gridify.cu:182)
+ *   H_add = sum_{V in win(Vc), occupied} [C_V == 0] - beta * C_V / lambda            (eq. 3)
+ *   H_rmv = sum_{V in win(Vi), occupied} [C_V == 1]                                  (eq. 4)
+ *   C_V = number of incumbents whose k^3 window (the query's window, gridify.cu:240-246) holds V,
+ *   lambda = k^3.  H_add > H_rmv  <=>  lambda*(n0 - n1) > beta * sum C_V  (integer sums, one fp32
+ *   multiply): Vc takes slot s, C is decremented over win(Vi) and incremented over win(Vc). */
+static int cas_neighbour(int v, int nei, int ksz, const int *grid)
+{
+    const int gxy = grid[0] * grid[1];
+    int c2 = v / gxy, c1 = (v - c2 * gxy) / grid[0], c0 = v - c2 * gxy - c1 * grid[0];
+    int d = nei / (ksz * ksz) - (ksz - 1) / 2 + c2;
+    int h = (nei % (ksz * ksz)) / ksz - (ksz - 1) / 2 + c1;
+    int w = nei % ksz - (ksz - 1) / 2 + c0;
+    if (d < 0 || d >= grid[2] || h < 0 || h >= grid[1] || w < 0 || w >= grid[0]) return -1;
+    return d * gxy + h * grid[0] + w;
+}
+
+static void cas_refine_cloud(build_tables *T, int centcount, int O, int ksz, const int *grid,
+                             uint64_t seed, float beta)
+{
+    if (centcount <= O) return;                    /* every occupied voxel already is a centre */
+    const int G = grid[0] * grid[1] * grid[2], size = ksz * ksz * ksz, M = O;
+    int *cov = (int *)calloc((size_t)G, sizeof(int));
+    unsigned char *picked = (unsigned char *)calloc((size_t)G, 1);
+    for (int s = 0; s < M; s++) {
+        int v = T->slot2vox[s];
+        picked[v] = 1;
+        for (int nei = 0; nei < size; nei++) {
+            int u = cas_neighbour(v, nei, ksz, grid);
+            if (u >= 0 && T->touched[u]) cov[u]++;
+        }
+    }
+    for (int t = 0; t < centcount; t++) {
+        int vc = T->order_vox[t];
+        if (picked[vc]) continue;                  /* incumbent of the initial sample */
+        int s = reservoir_pick((uint64_t)(int64_t)T->order_idx[t] + 3 * seed, M);
+        int vi = T->slot2vox[s];
+        int n0 = 0, n1 = 0, sc = 0;
+        for (int nei = 0; nei < size; nei++) {
+            int uc = cas_neighbour(vc, nei, ksz, grid), ui = cas_neighbour(vi, nei, ksz, grid);
+            if (uc >= 0 && T->touched[uc]) { n0 += (cov[uc] == 0); sc += cov[uc]; }
+            if (ui >= 0 && T->touched[ui]) n1 += (cov[ui] == 1);
+        }
+        float lhs = (float)(size * (n0 - n1)), rhs = beta * (float)sc;
+        if (lhs > rhs) {
+            for (int nei = 0; nei < size; nei++) {
+                int ui = cas_neighbour(vi, nei, ksz, grid);
+                if (ui >= 0 && T->touched[ui]) cov[ui]--;
+            }
+            for (int nei = 0; nei < size; nei++) {
+                int uc = cas_neighbour(vc, nei, ksz, grid);
+                if (uc >= 0 && T->touched[uc]) cov[uc]++;
+            }
+            T->slot2vox[s] = vc;
+        }
+    }
+    free(cov); free(picked);
+}
+
+static int gridify_impl(const float *data, const int *actual_numpoints, int B, int N,
+                        int P, int O, int ksz, int stride, int loc,
+                        const float *shift, const float *vs, const int *grid,
+                        uint64_t seed, float cas_beta,
+                        int *nebidx, float *nebmsk, float *cent, float *centmsk,
+                        int *actual_centnum);
+
 int gridgcn_oracle_gridify(const float *data, const int *actual_numpoints, int B, int N,
                            int P, int O, int ksz, int stride, int loc,
                            const float *shift, const float *vs, const int *grid,
                            uint64_t seed,
                            int *nebidx, float *nebmsk, float *cent, float *centmsk,
                            int *actual_centnum)
+{
+    return gridify_impl(data, actual_numpoints, B, N, P, O, ksz, stride, loc, shift, vs, grid, seed,
+                        -1.0f, nebidx, nebmsk, cent, centmsk, actual_centnum);
+}
+
+/* Gridify with CAS (cas_refine_cloud above) between the build and the query; beta >= 0 */
+int gridgcn_oracle_gridify_occaware(const float *data, const int *actual_numpoints, int B, int N,
+                                    int P, int O, int ksz, int stride, int loc,
+                                    const float *shift, const float *vs, const int *grid,
+                                    uint64_t seed, float beta,
+                                    int *nebidx, float *nebmsk, float *cent, float *centmsk,
+                                    int *actual_centnum)
+{
+    if (!(beta >= 0.0f)) return 1;
+    return gridify_impl(data, actual_numpoints, B, N, P, O, ksz, stride, loc, shift, vs, grid, seed,
+                        beta, nebidx, nebmsk, cent, centmsk, actual_centnum);
+}
+
+static int gridify_impl(const float *data, const int *actual_numpoints, int B, int N,
+                        int P, int O, int ksz, int stride, int loc,
+                        const float *shift, const float *vs, const int *grid,
+                        uint64_t seed, float cas_beta,
+                        int *nebidx, float *nebmsk, float *cent, float *centmsk,
+                        int *actual_centnum)
 {
     (void)stride; /* accepted and ignored by the kernels */
     const int G = grid[0] * grid[1] * grid[2];
@@ -209,8 +313,13 @@ int gridgcn_oracle_gridify(const float *data, const int *actual_numpoints, int B
         init_outputs_cloud(O, P, o_idx, o_msk, o_cent, o_cmsk, &actual_centnum[b]);
         build_tables T;
         alloc_tables(&T, G, P, O);
+        if (cas_beta >= 0.0f) {
+            T.order_vox = (int *)malloc((size_t)G * sizeof(int));
+            T.order_idx = (int *)malloc((size_t)G * sizeof(int));
+        }
         int cc = build_index_cloud(data, b, N, actual_numpoints[b], P, O, loc, shift, vs, grid,
                                    seed, &T, o_cmsk);
+        if (cas_beta >= 0.0f) cas_refine_cloud(&T, cc, O, ksz, grid, seed, cas_beta);
         int cn = cc > O ? O : cc;                               /* gridify.cu:222-224 */
         actual_centnum[b] = cn;
         /* gridify_kernel_query_neighs under S0, gridify.cu:218-290 */

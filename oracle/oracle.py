@@ -63,7 +63,7 @@ def xorwow_uniform(seed):
 
 
 def _gridify_like(fn, data, actual_numpoints, max_p_grid, max_o_grid, kernel_size, stride, loc,
-                  coord_shift, voxel_size, grid_size, seed):
+                  coord_shift, voxel_size, grid_size, seed, extra=()):
     data = np.ascontiguousarray(data, dtype=np.float32)
     anp = np.ascontiguousarray(np.asarray(actual_numpoints, dtype=np.int32).reshape(-1))
     B, N, C = data.shape
@@ -76,7 +76,7 @@ def _gridify_like(fn, data, actual_numpoints, max_p_grid, max_o_grid, kernel_siz
     centmsk = np.empty((B, O), np.float32)
     centnum = np.empty((B, 1), np.int32)
     rc = fn(_p(data), _p(anp), B, N, P, O, int(kernel_size), int(stride), int(loc),
-            _p(sh), _p(vs), _p(gs), ctypes.c_uint64(int(seed)),
+            _p(sh), _p(vs), _p(gs), ctypes.c_uint64(int(seed)), *extra,
             _p(nebidx), _p(nebmsk), _p(cent), _p(centmsk), _p(centnum))
     if rc != 0:
         raise RuntimeError("oracle returned %d" % rc)
@@ -89,6 +89,15 @@ def gridify(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stri
     return _gridify_like(_load().gridgcn_oracle_gridify, data, actual_numpoints, max_p_grid,
                          max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size,
                          seed)
+
+
+def gridify_occaware(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1,
+                     loc=0, coord_shift, voxel_size, grid_size, seed=0, beta=1.0):
+    """Gridify with Coverage-Aware Sampling.  PARITY UNPINNED: our sequential statement of the
+    paper's section 3.2 (gridgcn_oracle.c: cas_refine_cloud); the reference has no source for it."""
+    return _gridify_like(_load().gridgcn_oracle_gridify_occaware, data, actual_numpoints,
+                         max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size,
+                         grid_size, seed, extra=(ctypes.c_float(float(beta)),))
 
 
 def gridify_knn(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
