@@ -3,9 +3,9 @@
 // PARITY UNPINNED.  The reference ships CAS only inside a prebuilt binary (gridifyop/additional.so:
 // ops Gridify_occaware / Gridify_occaware_s); there is no source to restate.  What is
 // implemented here is the algorithm of the Grid-GCN paper (CVPR 2020, section 3.2, eq. 3-4) under a
-// schedule of OUR choosing, stated in full in oracle/gridgcn_oracle.c (gridgcn_oracle_gridify_occaware)
-// and checked bit for bit against that restatement -- it pins this kernel to our specification, not
-// to the reference's binary.
+// schedule of OUR choosing, stated in full in the tests' sequential C checker (tests/test_cas.py)
+// and verified bit for bit against it -- that pins this kernel to our specification, not to the
+// reference's binary.
 //
 //   incumbents  = the RVS sample of gridify (gridify.cu:165-189): M = min(#occupied, O) voxels
 //   challengers = every occupied voxel that is not an incumbent, in order of first appearance

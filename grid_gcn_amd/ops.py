@@ -143,8 +143,8 @@ def Gridify_occaware(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_s
                      coord_shift, voxel_size, grid_size, seed=0, seed_dev=None, beta=1.0):
     """Gridify with Coverage-Aware Sampling of the centre voxels (the paper's CAS; the reference
     registers it as `Gridify_occaware` but ships no source for it: gridifyop/additional.so).
-    PARITY UNPINNED -- our own restatement of the paper's section 3.2 (include/gridgcn.h,
-    oracle/gridgcn_oracle.c: gridgcn_oracle_gridify_occaware) is what this is checked against.
+    PARITY UNPINNED -- our own sequential restatement of the paper's section 3.2 (stated in
+    include/gridgcn.h and in the tests' C checker, tests/test_cas.py) is what this is checked against.
     Same signature and outputs as Gridify; beta >= 0 weighs the over-coverage penalty of eq. 3."""
     _require(float(beta) >= 0.0, "beta must be >= 0")
     return _gridify_like("gridgcn_gridify_occaware", data, actual_numpoints, max_p_grid, max_o_grid,
