@@ -189,6 +189,8 @@ int gridgcn_gridify_occaware(const float *data, const int32_t *np, int B, int N,
 {
     if (!(beta >= 0.0f)) return GRIDGCN_EINVAL;
     if (p && p->max_o_grid > 16384) return GRIDGCN_EINVAL;
+    if (p && (p->grid_size[0] > 1023 || p->grid_size[1] > 1023 || p->grid_size[2] > 1023))
+        return GRIDGCN_EINVAL;   // the sweep packs voxel coordinates into 10 bits each
     return gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
                           ws_bytes, stream, beta);
 }

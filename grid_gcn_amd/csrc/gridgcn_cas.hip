@@ -144,6 +144,24 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     // ---- the sweep (wave 0) ----
     if (wave == 0) {
         const unsigned long long seed3 = 3ull * gg_seed(gp);
+        // window offsets of this lane (nei = lane + 64*i), decoded once
+        const int kk = gp.k, rr = (kk - 1) / 2;
+        constexpr int NI = (GG_K3MAX + 63) / 64;
+        int od[NI], oh[NI], ow[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int nei = lane + 64 * i;
+            od[i] = nei / (kk * kk) - rr;
+            oh[i] = (nei % (kk * kk)) / kk - rr;
+            ow[i] = nei % kk - rr;
+        }
+        const int ni = (k3 + 63) >> 6;
+        auto nbv = [&](int c0, int c1, int c2, int i) -> int {
+            const int d = od[i] + c2, h = oh[i] + c1, w = ow[i] + c0;
+            const bool in = lane + 64 * i < k3 && d >= 0 && d < gp.g[2] && h >= 0 && h < gp.g[1] &&
+                            w >= 0 && w < gp.g[0];
+            return in ? d * gp.gxy + h * gp.g[0] + w : -1;
+        };
         for (int j0 = 0; j0 < nchal; j0 += 64) {
             const int j = j0 + lane;
             int cid = 0, cvx = 0, csl = 0;
@@ -153,35 +171,43 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
                 const long long gi = (long long)b * N + cid;
                 csl = gg_reservoir_pick((unsigned long long)gi + seed3, M);
             }
+            // coordinates of the batch's challenger voxels, decoded lane-parallel
+            const int cz = cvx / gp.gxy, cy = (cvx - cz * gp.gxy) / gp.g[0];
+            const int cxyz = (cvx - cz * gp.gxy - cy * gp.g[0]) | (cy << 10) | (cz << 20);
             const int nb = nchal - j0 < 64 ? nchal - j0 : 64;
             for (int q = 0; q < nb; q++) {
                 const int vc = __builtin_amdgcn_readlane(cvx, q);
+                const int pc = __builtin_amdgcn_readlane(cxyz, q);
                 const int s = __builtin_amdgcn_readlane(csl, q);
                 const int vi = slotvox[s];
-                const int a2 = vc / gp.gxy, a1 = (vc - a2 * gp.gxy) / gp.g[0], a0 = vc - a2 * gp.gxy - a1 * gp.g[0];
+                const int a0 = pc & 1023, a1 = (pc >> 10) & 1023, a2 = pc >> 20;
                 const int i2 = vi / gp.gxy, i1 = (vi - i2 * gp.gxy) / gp.g[0], i0 = vi - i2 * gp.gxy - i1 * gp.g[0];
                 int n0 = 0, n1 = 0, sc = 0;
-                for (int nei = lane; nei < k3; nei += 64) {
-                    const int uc = gg_cas_nb(a0, a1, a2, nei, gp);
-                    const int ui = gg_cas_nb(i0, i1, i2, nei, gp);
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    if (i >= ni) break;
+                    const int uc = nbv(a0, a1, a2, i), ui = nbv(i0, i1, i2, i);
                     const unsigned ec = uc >= 0 ? cov[uc] : 0u;
                     const unsigned ei = ui >= 0 ? cov[ui] : 0u;
-                    if (ec & 0x8000u) { n0 += (ec == 0x8000u); sc += (int)(ec & 0x7fffu); }
-                    n1 += (ei == 0x8001u);
+                    n0 += __popcll(__ballot(ec == 0x8000u));
+                    n1 += __popcll(__ballot(ei == 0x8001u));
+                    sc += (ec & 0x8000u) ? (int)(ec & 0x7fffu) : 0;
                 }
-                n0 = gg_wave_sum(n0);
-                n1 = gg_wave_sum(n1);
                 sc = gg_wave_sum(sc);
                 if ((float)(k3 * (n0 - n1)) > __fmul_rn(a.beta, (float)sc)) {
                     // (the two windows may overlap, and the next challenger reads what is written
                     // here through other lanes: fences keep the wave's accesses in program order)
-                    for (int nei = lane; nei < k3; nei += 64) {
-                        const int ui = gg_cas_nb(i0, i1, i2, nei, gp);
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        if (i >= ni) break;
+                        const int ui = nbv(i0, i1, i2, i);
                         if (ui >= 0 && (cov[ui] & 0x8000)) cov[ui] -= 1;
                     }
                     __threadfence_block();
-                    for (int nei = lane; nei < k3; nei += 64) {
-                        const int uc = gg_cas_nb(a0, a1, a2, nei, gp);
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        if (i >= ni) break;
+                        const int uc = nbv(a0, a1, a2, i);
                         if (uc >= 0 && (cov[uc] & 0x8000)) cov[uc] += 1;
                     }
                     const int lead = __builtin_amdgcn_readlane(cid, q);

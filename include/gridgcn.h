@@ -95,7 +95,7 @@ int gridgcn_gridify(const float *data, const int32_t *actual_numpoints, int B, i
  * oracle/gridgcn_oracle.c: the RVS sample of gridgcn_gridify gives the incumbents; every other
  * occupied voxel, in order of first appearance, challenges one random incumbent and replaces it
  * when H_add > H_rmv (beta >= 0 weighs the over-coverage penalty; beta = 0: pure coverage).
- * Same inputs / outputs / attributes as gridgcn_gridify; max_o_grid <= 16384. */
+ * Same inputs / outputs / attributes as gridgcn_gridify; max_o_grid <= 16384, grid_size[j] <= 1023. */
 int gridgcn_gridify_occaware_workspace_bytes(int B, int N, const gridgcn_grid_params *p,
                                              size_t *bytes);
 int gridgcn_gridify_occaware(const float *data, const int32_t *actual_numpoints, int B, int N,
