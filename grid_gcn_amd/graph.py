@@ -12,18 +12,27 @@ kernels is `seed + *seed_dev` (include/gridgcn.h: gridgcn_grid_params.seed_dev, 
 the captured graph starts with `seed_dev += golden ratio`: each replay redraws the voxel sampling,
 the neighbour reservoirs and the dropout mask.
 
-Data parallelism: with world_size > 1 the step is two graphs -- forward/backward, then the
-optimizer -- around the ONE flat RCCL all-reduce of dp.FlatGradAllReduce, which stays eager (a
-collective captured into a graph is the only part of this that cannot be exercised here).
+Data parallelism: with world_size > 1 the ONE graph also holds the gather of the gradients into
+dp.FlatGradAllReduce's flat bucket, the RCCL all-reduce (a collective is capturable: it is a kernel
+on the capture stream) and the averaging, in front of the optimizer.  An earlier arrangement -- a
+forward/backward graph, the all-reduce eager, an optimizer graph -- was dropped: on this ROCm
+version eager kernels that consume the output of a just-launched graph (and graphs that follow
+eager kernels) are not reliably ordered on the stream; its single-rank emulation trained along a
+different trajectory from run to run.  Back-to-back replays of one graph are.
+tests/test_gpu_gridconv.py captures the collective on one rank over a real RCCL group (more ranks
+need more GPUs) and checks the trajectory against the graph without it.  If the capture fails,
+bench.py falls back to the eager step and says so (`step_mode`).
 """
 import torch
+
+from . import train_ops
 
 _GOLDEN = 0x9E3779B97F4A7C15 - (1 << 64)   # as a signed int64 increment
 
 
 class GraphedTrainStep:
     """step() == zero_grad(set_to_none) ; loss = loss_fn(net(*inputs), target) ; backward ;
-    all-reduce (world > 1) ; opt.step() -- replayed from captured graphs.
+    all-reduce (world > 1) ; opt.step() -- replayed from one captured graph.
 
     net       a GGCNSeg / GGCNCls / GGCNSynth in train() mode on the GPU
     opt       torch.optim.Adam(..., fused=True, capturable=True) (any capturable optimizer)
@@ -32,11 +41,15 @@ class GraphedTrainStep:
     sync      dp.FlatGradAllReduce or None
     """
 
-    def __init__(self, net, opt, loss_fn, inputs, target, sync=None, warmup=3):
+    def __init__(self, net, opt, loss_fn, inputs, target, sync=None, warmup=3, split=None):
         self.net, self.opt, self.loss_fn = net, opt, loss_fn
         self.inputs, self.target, self.sync = tuple(inputs), target, sync
         dev = self.inputs[0].device
         self.world = sync.world if sync is not None else 1
+        # gradient gather + all-reduce inside the graph (default: whenever there is more than one
+        # rank; split=True forces it on a single rank, for tests)
+        self.split = (self.world > 1) if split is None else bool(split)
+        assert not self.split or sync is not None
         net.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.params = [p for p in net.parameters() if p.requires_grad]
 
@@ -53,30 +66,34 @@ class GraphedTrainStep:
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 fwd_bwd()
-                if self.world > 1:
-                    sync()
+                if self.split:
+                    self._sync_eager()
                 opt.step()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
 
         self.g1 = torch.cuda.CUDAGraph()
-        self.g2 = None
-        if self.world == 1:
-            with torch.cuda.graph(self.g1):
-                self.loss = fwd_bwd()
-                opt.step()
-        else:
-            pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(self.g1, pool=pool):
-                self.loss = fwd_bwd()
-            # the gradients the captured backward writes (graph-owned storage)
-            self.static_grads = [p.grad for p in self.params]
-            assert all(g is not None for g in self.static_grads)
-            self._allreduce()                      # p.grad become views of the flat bucket
-            self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, pool=pool):
-                opt.step()
+        # scratch carved out of a shared zero chunk must not cross a capture boundary
+        train_ops.reset_zero_arena()
+        with torch.cuda.graph(self.g1):
+            self.loss = fwd_bwd()
+            if self.split:
+                # the flat gather, the RCCL all-reduce and the averaging are graph nodes too
+                self.static_grads = [p.grad for p in self.params]
+                assert all(g is not None for g in self.static_grads)
+                self._allreduce()                  # p.grad become views of the flat bucket
+            opt.step()
+        train_ops.reset_zero_arena()
         torch.cuda.synchronize(dev)
+
+    def _sync_eager(self):
+        """warm-up steps: the plain FlatGradAllReduce call (a no-op on one rank, where the forced
+        split still has to leave .grad as views of the flat bucket)"""
+        if self.sync.world > 1:
+            self.sync()
+        else:
+            self.static_grads = [p.grad for p in self.params]
+            self._allreduce()
 
     def _allreduce(self):
         sync = self.sync
@@ -93,7 +110,4 @@ class GraphedTrainStep:
 
     def __call__(self):
         self.g1.replay()
-        if self.g2 is not None:
-            self._allreduce()
-            self.g2.replay()
         return self.loss

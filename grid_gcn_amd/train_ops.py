@@ -302,6 +302,14 @@ class _ZeroArena:
     def __init__(self):
         self.chunk, self.off = {}, {}
 
+    def reset(self):
+        """Forget the current chunks (live slices keep theirs alive).  A chunk allocated while a
+        hipGraph is being captured lives in THAT graph's memory pool and is only re-zeroed by
+        that graph's replay: nothing captured or run later may carve slices out of it
+        (graph.GraphedTrainStep calls this around every capture)."""
+        self.chunk.clear()
+        self.off.clear()
+
     def zeros(self, shape, dtype, dev):
         if isinstance(shape, int):
             shape = (shape,)
@@ -333,6 +341,7 @@ SRC_EVAL = os.environ.get("GG_NO_SRC_EVAL", "0") != "1"
 ATT_MAX_EVAL = os.environ.get("GG_NO_ATT_MAX_EVAL", "0") != "1"
 _ARENA = _ZeroArena()
 _zeros = _ARENA.zeros
+reset_zero_arena = _ARENA.reset
 _ZEROS = {}
 
 

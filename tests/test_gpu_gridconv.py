@@ -449,3 +449,66 @@ def test_graphed_train_step_equals_eager_step():
     assert len(set(lg)) == 3                 # fresh draws per replay
     for a, b in zip(le, lg):
         assert abs(a - b) < 2e-3 * abs(a), (le, lg)
+
+
+def test_graphed_step_split_around_rccl_all_reduce_single_rank():
+    """The N > 1 arrangement of graph.GraphedTrainStep -- the gather into dp.FlatGradAllReduce's
+    flat bucket, the RCCL all-reduce and the averaging captured INSIDE the step's graph -- forced on
+    one rank with a real 'nccl' (= RCCL) process group: its replays must follow the trajectory of
+    the graph without the collective.  Each arrangement runs in its own process, as in production.
+    (More than one rank needs more than one GPU; tests/test_model_cpu.py covers world_size 2 over
+    gloo.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from grid_gcn_amd import dp, graph, model, synth
+split = sys.argv[1] == "split"
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+DEV = "cuda:0"
+torch.manual_seed(5)
+net = model.GGCNSeg(model.SEG_8192, fixed_seed=True).to(DEV).train()
+data, npn = synth.make_batch(2, 8192, "planes", first_id=70)
+x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+n = torch.from_numpy(npn).to(DEV)
+lab = torch.randint(0, 21, (2, 8192), device=DEV)
+opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=True)
+sync = dp.FlatGradAllReduce(net)
+sync.broadcast_parameters()
+gs = graph.GraphedTrainStep(net, opt, model.seg_loss, (x, n), lab, sync, warmup=2, split=split)
+assert gs.split == split
+losses = [float(gs()) for _ in range(4)]
+torch.cuda.synchronize()
+finite = all(bool(torch.isfinite(p).all()) for p in net.parameters())
+norm = float(torch.cat([p.detach().reshape(-1) for p in net.parameters()]).double().norm())
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(dict(losses=losses, finite=finite, norm=norm)))
+"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    import socket
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return str(sk.getsockname()[1])
+
+    for mode in ("one", "split"):
+        r = subprocess.run([sys.executable, "-c", code, mode, free_port()], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert r.returncode == 0 and line, (mode, r.stdout[-2000:], r.stderr[-3000:])
+        res[mode] = json.loads(line[-1][7:])
+    a, b = res["one"], res["split"]
+    assert a["finite"] and b["finite"]
+    assert a["losses"][0] > a["losses"][-1]                      # it trains
+    for u, v in zip(a["losses"], b["losses"]):
+        assert abs(u - v) < 2e-3 * abs(u), (a, b)
+    assert abs(a["norm"] - b["norm"]) < 1e-4 * a["norm"], (a, b)
