@@ -81,8 +81,64 @@ def cpu_baseline(cfg, B, points, kind, sample_clouds):
                            "(%d threads), mean of 3 calls" % (B, cagq_threads)}
 
 
+_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", rank=rank, world_size=world)
+x = torch.full((1 << 16,), float(rank + 1), device="cuda")
+y = torch.zeros_like(x)
+dist.all_reduce(y)                                   # communicator set up outside the capture
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    y.copy_(x)
+    dist.all_reduce(y)
+    y.div_(world)
+for _ in range(3):
+    g.replay()
+torch.cuda.synchronize()
+want = sum(range(1, world + 1)) / world
+ok = bool((y == want).all())
+dist.barrier()
+dist.destroy_process_group()
+print("PROBE_OK" if ok else "PROBE_WRONG")
+"""
+
+
+def rccl_capture_probe(world, rank, local, dev):
+    """Can an RCCL all-reduce be captured into a hipGraph and replayed on this node?  Asked in a
+    throw-away process per rank (its own process group on port MASTER_PORT + 17): a failed stream
+    capture poisons the HIP context of the process it happens in, so the real step must only try
+    what is known to work.  The ranks agree on the answer (MIN over ranks)."""
+    import subprocess
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
+               MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+    for k in list(env):
+        if k.startswith("TORCHELASTIC") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE",
+                                                  "ROLE_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+            env.pop(k)
+    try:
+        r = subprocess.run([sys.executable, "-c", _PROBE], env=env, capture_output=True, text=True,
+                           timeout=240)
+        ok = r.returncode == 0 and "PROBE_OK" in r.stdout
+        if not ok and rank == 0:
+            sys.stderr.write("RCCL capture probe failed (rc %d): %s\n" % (r.returncode, r.stderr[-400:]))
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        if rank == 0:
+            sys.stderr.write("RCCL capture probe failed (%s)\n" % e)
+    if world > 1 and dist.is_initialized():
+        t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t.item()))
+    return ok
+
+
 def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
-    """The timed step.  Default: one captured hipGraph (two around the all-reduce for N > 1) --
+    """The timed step.  Default: one captured hipGraph (for N > 1 with the flat RCCL all-reduce
+    inside, when rccl_capture_probe says a captured collective replays correctly here) --
     grid_gcn_amd/graph.py -- so that the result does not depend on how fast the host enqueues ~350
     launches; the GPU work of a replay is that of the eager step, launch for launch, with the
     random draws still fresh per step (device-side seed).  Falls back to the eager step when the
@@ -95,6 +151,14 @@ def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
         opt.step()
         return loss
 
+    if use_graph and sync is not None and sync.world > 1:
+        # N > 1: the graph holds the RCCL all-reduce (graph.py); only attempted where a throw-away
+        # process has shown that such a capture replays correctly
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if dist.get_backend() != "nccl" or not rccl_capture_probe(
+                sync.world, dist.get_rank(), local, inputs[0].device):
+            use_graph = False
+            sys.stderr.write("N > 1 without a capturable collective: timing the eager step\n")
     if use_graph:
         try:
             return graph.GraphedTrainStep(net, opt, loss_fn, inputs, target, sync), "hipgraph"

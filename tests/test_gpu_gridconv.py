@@ -512,3 +512,25 @@ print("RESULT " + json.dumps(dict(losses=losses, finite=finite, norm=norm)))
     for u, v in zip(a["losses"], b["losses"]):
         assert abs(u - v) < 2e-3 * abs(u), (a, b)
     assert abs(a["norm"] - b["norm"]) < 1e-4 * a["norm"], (a, b)
+
+
+def test_bench_rccl_capture_probe_runs():
+    """bench.py only puts the all-reduce into the step's graph where a throw-away process has shown
+    that a captured RCCL collective replays with the right result; the probe itself must work (one
+    rank here)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="24811")
+    try:
+        assert bench.rccl_capture_probe(1, 0, 0, torch.device(DEV)) is True
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
