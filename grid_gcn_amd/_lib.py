@@ -14,6 +14,7 @@ EXPORTS = [
     "gridgcn_get_mlp_precision",
     "gridgcn_gridify_workspace_bytes", "gridgcn_gridify", "gridgcn_gridify_timed",
     "gridgcn_gridify_occaware_workspace_bytes", "gridgcn_gridify_occaware",
+    "gridgcn_gridify_fast_rand_workspace_bytes", "gridgcn_gridify_fast_rand",
     "gridgcn_gridify_knn_workspace_bytes", "gridgcn_gridify_knn",
     "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_up",
     "gridgcn_ball_knn", "gridgcn_knn",
@@ -77,11 +78,12 @@ def load():
     lib.gridgcn_set_mlp_precision.argtypes = [ci]
     lib.gridgcn_get_mlp_precision.restype = ci
     for name in ("gridgcn_gridify_workspace_bytes", "gridgcn_gridify_knn_workspace_bytes",
-                 "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_occaware_workspace_bytes"):
+                 "gridgcn_gridify_up_workspace_bytes", "gridgcn_gridify_occaware_workspace_bytes",
+                 "gridgcn_gridify_fast_rand_workspace_bytes"):
         f = getattr(lib, name)
         f.restype = ci
         f.argtypes = [ci, ci, pp, ctypes.POINTER(cs)]
-    for name in ("gridgcn_gridify", "gridgcn_gridify_knn"):
+    for name in ("gridgcn_gridify", "gridgcn_gridify_knn", "gridgcn_gridify_fast_rand"):
         f = getattr(lib, name)
         f.restype = ci
         f.argtypes = [vp, vp, ci, ci, pp, vp, vp, vp, vp, vp, vp, cs, vp]

@@ -195,6 +195,33 @@ int gridgcn_gridify_occaware(const float *data, const int32_t *np, int B, int N,
                           ws_bytes, stream, beta);
 }
 
+int gridgcn_gridify_fast_rand_workspace_bytes(int B, int N, const gridgcn_grid_params *p,
+                                              size_t *bytes)
+{
+    return gridgcn_gridify_occaware_workspace_bytes(B, N, p, bytes);
+}
+
+int gridgcn_gridify_fast_rand(const float *data, const int32_t *np, int B, int N,
+                              const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk,
+                              float *cent, float *centmsk, int32_t *centnum, void *ws,
+                              size_t ws_bytes, void *stream)
+{
+    GGGrid gp;
+    int rc = fill_grid(p, B, N, true, &gp);      // (B*N*k^3 < 2^31: the variant's int thread index)
+    if (rc) return rc;
+    if (!data || !np || !nebidx || !nebmsk || !cent || !centmsk || !centnum) return GRIDGCN_EINVAL;
+    GGIndexWs w;
+    const size_t need0 = gg_index_workspace_bytes(B, N, gp, true, &w);
+    const size_t off = ws_align(need0);
+    if (!ws || ws_bytes < off + gg_cas_workspace_bytes(B, N, gp)) return GRIDGCN_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (ensure_init()) return GRIDGCN_ELAUNCH;
+    rc = gg_index_build(data, np, B, N, gp, true, centnum, (char *)ws, w, st);
+    if (rc) return rc;
+    return gg_fastrand_query(data, np, B, N, gp, (char *)ws, w, (char *)ws + off, nebidx, nebmsk,
+                             cent, centmsk, centnum, st);
+}
+
 int gridgcn_gridify_timed(const float *data, const int32_t *np, int B, int N,
                           const gridgcn_grid_params *p, int32_t *nebidx, float *nebmsk, float *cent,
                           float *centmsk, int32_t *centnum, void *ws, size_t ws_bytes, void *stream,

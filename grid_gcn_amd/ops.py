@@ -153,6 +153,17 @@ def Gridify_occaware(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_s
 
 
 @torch.no_grad()
+def Gridify_fast_rand(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1,
+                      loc=0, coord_shift, voxel_size, grid_size, seed=0):
+    """The `fast_rand` build of Gridify (gridifyop/fast_rand/gridify.cu): scatter-to-k^3 buckets
+    with a thread-index-seeded reservoir, the first max_o_grid occupied voxels as centres, own-voxel
+    query.  Same signature and outputs as Gridify (`seed` is not used by this variant)."""
+    return _gridify_like("gridgcn_gridify_fast_rand", data, actual_numpoints, max_p_grid,
+                         max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size,
+                         seed)
+
+
+@torch.no_grad()
 def gridify_timed(data, actual_numpoints, iters=50, *, max_p_grid, max_o_grid, kernel_size,
                   stride=1, loc=0, coord_shift, voxel_size, grid_size, seed=0):
     """Average device time (ms) of one Gridify call: `iters` back-to-back calls inside the

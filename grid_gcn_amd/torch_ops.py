@@ -11,6 +11,7 @@ torch.compile / export:
                               stride=, loc=, coord_shift=, voxel_size=, grid_size=, seed=0)
         -> (nebidx, nebidxmsk, cent, centmsk, actual_centnum)
     torch.ops.gridgcn.gridify_knn(...)            same
+    torch.ops.gridgcn.gridify_fast_rand(...)      same (the fast_rand build variant)
     torch.ops.gridgcn.gridify_occaware(..., beta=1.0)   same + coverage-aware sampling (parity
                                                   unpinned: binary-only in the reference)
     torch.ops.gridgcn.gridify_up(downdata, updata, down_actual_numpoints, up_actual_numpoints,
@@ -78,8 +79,21 @@ def gridify_occaware(data: Tensor, actual_numpoints: Tensor, max_p_grid: int, ma
                                 grid_size=grid_size, seed=seed, beta=beta)
 
 
+@_lib_def("gridgcn::gridify_fast_rand", mutates_args=(), device_types="cuda")
+def gridify_fast_rand(data: Tensor, actual_numpoints: Tensor, max_p_grid: int, max_o_grid: int,
+                      kernel_size: int, stride: int, loc: int, coord_shift: List[float],
+                      voxel_size: List[float], grid_size: List[int],
+                      seed: int = 0) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """the `fast_rand` build of Gridify (gridifyop/fast_rand/): same operator, other sampling"""
+    return ops.Gridify_fast_rand(data, actual_numpoints, max_p_grid=max_p_grid,
+                                 max_o_grid=max_o_grid, kernel_size=kernel_size, stride=stride,
+                                 loc=loc, coord_shift=coord_shift, voxel_size=voxel_size,
+                                 grid_size=grid_size, seed=seed)
+
+
 gridify.register_fake(_gridify_fake)
 gridify_knn.register_fake(_gridify_fake)
+gridify_fast_rand.register_fake(_gridify_fake)
 
 
 @gridify_occaware.register_fake

@@ -104,6 +104,20 @@ int gridgcn_gridify_occaware(const float *data, const int32_t *actual_numpoints,
                              int32_t *actual_centnum,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Gridify, `fast_rand` build variant (gridifyop/fast_rand/gridify.cu:126-272) ---------------
+ * Same operator, different sampling: every point enters the bucket of all k^3 voxels around its
+ * own (reservoir past P seeded with the reference's thread index, so `seed` is not used), the
+ * centres are the first max_o_grid occupied voxels in order of first appearance, a centre reads the
+ * bucket of its own voxel only; loc == 0: centre = weighted mean of the picked points.  Results
+ * are those of the reference's kernels under the canonical schedule S0; B*N*k^3 < 2^31. */
+int gridgcn_gridify_fast_rand_workspace_bytes(int B, int N, const gridgcn_grid_params *p,
+                                              size_t *bytes);
+int gridgcn_gridify_fast_rand(const float *data, const int32_t *actual_numpoints, int B, int N,
+                              const gridgcn_grid_params *p,
+                              int32_t *nebidx, float *nebidxmsk, float *cent, float *centmsk,
+                              int32_t *actual_centnum,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
 /* Measurement helper: `iters` back-to-back gridgcn_gridify calls on `stream`, bracketed by HIP
  * events recorded on that stream; *ms_per_call = average device time of one call (all of its
  * launches, no host work in between except the launches themselves).  Synchronises the stream. */

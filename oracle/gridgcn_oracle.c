@@ -383,6 +383,127 @@ static int gridify_impl(const float *data, const int *actual_numpoints, int B, i
     return 0;
 }
 
+/* ------------------------------ Gridify, fast_rand build --------------------- */
+/* gridifyop/fast_rand/gridify.cu under S0 (threads in ascending threadindex = index*size + j).
+ * build :126-200: the thread of (point index, j) has nei_idx = (threadindex + size/2) % size and
+ * appends the point to the bucket of the voxel at that offset from the point's own voxel (reservoir
+ * past P seeded with curand_init(threadindex), :149-153); the thread at the zero offset also adds the
+ * point to its voxel's weighted sums (loc == 1, :168-174) and claims a centre slot for a voxel seen
+ * for the first time while fewer than max_o are taken (:175-197; no reservoir over the centres).
+ * query :232-272: the centre reads the bucket of its own voxel only. */
+int gridgcn_oracle_gridify_fast_rand(const float *data, const int *actual_numpoints, int B, int N,
+                                     int P, int O, int ksz, int stride, int loc,
+                                     const float *shift, const float *vs, const int *grid,
+                                     int *nebidx, float *nebmsk, float *cent, float *centmsk,
+                                     int *actual_centnum)
+{
+    (void)stride;
+    const int G = grid[0] * grid[1] * grid[2];
+    const int size = ksz * ksz * ksz;
+    const int gxy = grid[0] * grid[1];
+    if ((long long)B * N * size >= (1ll << 31)) return 1;       /* int threadindex (:126) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_threads(B))
+    for (int b = 0; b < B; b++) {
+        int *o_idx = nebidx + (size_t)b * O * P;
+        float *o_msk = nebmsk + (size_t)b * O * P;
+        float *o_cent = cent + (size_t)b * O * 4;
+        float *o_cmsk = centmsk + (size_t)b * O;
+        init_outputs_cloud(O, P, o_idx, o_msk, o_cent, o_cmsk, &actual_centnum[b]);
+        int *counter = (int *)calloc((size_t)G, sizeof(int));
+        int *bucket = (int *)malloc((size_t)G * P * sizeof(int));
+        float *sums = (float *)calloc((size_t)G * 4, sizeof(float));
+        int *vox2idx = (int *)malloc((size_t)G * sizeof(int));
+        int *slotcoor = (int *)calloc((size_t)(O > 0 ? O : 1) * 3, sizeof(int));
+        for (int v = 0; v < G; v++) vox2idx[v] = -1;
+        int centnum = 0;
+        const float *cloud = data + (size_t)b * N * DATA_NDIM;
+        for (int i = 0; i < N; i++) {
+            if (!(i < actual_numpoints[b])) continue;           /* :132 */
+            const float *p = cloud + (size_t)i * DATA_NDIM;
+            int coor[3], inside = 1;
+            for (int j = 0; j < 3; j++) {                       /* :136-142 */
+                /* (the test is made on the float, as in the main build: a NaN coordinate, which
+                 * CUDA's float->int conversion would turn into 0, is dropped here) */
+                float f = floorf((p[j] + shift[j]) / vs[j]);
+                if (!(f >= 0.0f) || !(f < (float)grid[j])) { inside = 0; break; }
+                coor[j] = (int)f;
+            }
+            if (!inside) continue;
+            for (int j = 0; j < size; j++) {
+                int threadindex = (b * N + i) * size + j;       /* :126 */
+                int nei_idx = (threadindex + size / 2) % size;  /* :127 */
+                int d = nei_idx / (ksz * ksz) - (ksz - 1) / 2 + coor[2];       /* :144-146 */
+                int h = (nei_idx % (ksz * ksz)) / ksz - (ksz - 1) / 2 + coor[1];
+                int w = nei_idx % ksz - (ksz - 1) / 2 + coor[0];
+                if (!(d >= 0 && d < grid[2] && h >= 0 && h < grid[1] && w >= 0 && w < grid[0]))
+                    continue;
+                int v = d * gxy + h * grid[0] + w;
+                int c = counter[v]++;                           /* :152 */
+                if (c < P) {
+                    bucket[(size_t)v * P + c] = i;
+                } else {                                        /* :156-160 */
+                    int r = reservoir_pick((uint64_t)(int64_t)threadindex, c + 1);
+                    if (r < P) bucket[(size_t)v * P + r] = i;
+                }
+                if (size - 1 == nei_idx * 2) {                  /* :163 the point's own voxel */
+                    if (loc == 1) {                             /* :164-171 */
+                        float wgt = p[3];
+                        sums[v * 4 + 0] += p[0] * wgt;
+                        sums[v * 4 + 1] += p[1] * wgt;
+                        sums[v * 4 + 2] += p[2] * wgt;
+                        sums[v * 4 + 3] += wgt;
+                    }
+                    if (centnum < O && vox2idx[v] == -1) {      /* :172-192 */
+                        vox2idx[v] = 0;
+                        int tmp = centnum++;
+                        slotcoor[tmp * 3 + 0] = coor[0];
+                        slotcoor[tmp * 3 + 1] = coor[1];
+                        slotcoor[tmp * 3 + 2] = coor[2];
+                        o_cmsk[tmp] = 1.0f;
+                    }
+                }
+            }
+        }
+        actual_centnum[b] = centnum;
+        for (int o = 0; o < centnum; o++) {                     /* :232-272 */
+            int v = slotcoor[o * 3 + 2] * gxy + slotcoor[o * 3 + 1] * grid[0] + slotcoor[o * 3 + 0];
+            int countlimit = counter[v], initID = 0;
+            float xsum = 0.0f, ysum = 0.0f, zsum = 0.0f, weightsum = 0.0f, countweightsum = 0.0f;
+            int *row = o_idx + (size_t)o * P;
+            float *mrow = o_msk + (size_t)o * P;
+            for (int j = 0; j < P; j++) {
+                if (j < countlimit) {
+                    int idx = bucket[(size_t)v * P + j];
+                    const float *q = cloud + (size_t)idx * DATA_NDIM;
+                    if (j == 0) initID = idx;
+                    row[j] = idx;
+                    mrow[j] = 1.0f;
+                    int ew = (int)q[3];                         /* :255 int in_data_eleweight */
+                    if (loc == 0) {
+                        xsum += q[0] * (float)ew;
+                        ysum += q[1] * (float)ew;
+                        zsum += q[2] * (float)ew;
+                        countweightsum += (float)ew;
+                    }
+                    weightsum += (float)ew;
+                } else {
+                    row[j] = initID;
+                }
+            }
+            if (loc == 1) {
+                xsum = sums[v * 4 + 0]; ysum = sums[v * 4 + 1]; zsum = sums[v * 4 + 2];
+                countweightsum = sums[v * 4 + 3];
+            }
+            o_cent[o * 4 + 0] = xsum / countweightsum;
+            o_cent[o * 4 + 1] = ysum / countweightsum;
+            o_cent[o * 4 + 2] = zsum / countweightsum;
+            o_cent[o * 4 + 3] = weightsum;
+        }
+        free(counter); free(bucket); free(sums); free(vox2idx); free(slotcoor);
+    }
+    return 0;
+}
+
 /* ------------------------------ GridifyKNN ----------------------------------- */
 /* same build; query = gridifyKNN_kernel_query_neighs, gridifyknn.cu:231-332 */
 int gridgcn_oracle_gridify_knn(const float *data, const int *actual_numpoints, int B, int N,

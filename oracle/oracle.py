@@ -100,6 +100,29 @@ def gridify_occaware(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_s
                          grid_size, seed, extra=(ctypes.c_float(float(beta)),))
 
 
+def gridify_fast_rand(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1,
+                      loc=0, coord_shift, voxel_size, grid_size, seed=0):
+    """S0 restatement of the fast_rand build of Gridify (gridifyop/fast_rand/gridify.cu:126-272);
+    its draws are seeded with the thread index only, `seed` is accepted and ignored."""
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    anp = np.ascontiguousarray(np.asarray(actual_numpoints, dtype=np.int32).reshape(-1))
+    B, N, C = data.shape
+    assert C == 4 and anp.shape[0] == B
+    P, O = int(max_p_grid), int(max_o_grid)
+    sh, vs, gs = _f3(coord_shift), _f3(voxel_size), _i3(grid_size)
+    nebidx = np.empty((B, O, P), np.int32)
+    nebmsk = np.empty((B, O, P), np.float32)
+    cent = np.empty((B, O, 4), np.float32)
+    centmsk = np.empty((B, O), np.float32)
+    centnum = np.empty((B, 1), np.int32)
+    rc = _load().gridgcn_oracle_gridify_fast_rand(
+        _p(data), _p(anp), B, N, P, O, int(kernel_size), int(stride), int(loc), _p(sh), _p(vs),
+        _p(gs), _p(nebidx), _p(nebmsk), _p(cent), _p(centmsk), _p(centnum))
+    if rc != 0:
+        raise RuntimeError("oracle returned %d" % rc)
+    return nebidx, nebmsk, cent, centmsk, centnum
+
+
 def gridify_knn(data, actual_numpoints, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0,
                 coord_shift, voxel_size, grid_size, seed=0):
     """S0 restatement of mx.sym.GridifyKNN (gridifyknn.cu:115-204, 231-332)."""

@@ -162,3 +162,31 @@ def knn_cases():
         return (un, kn, np.array([[3]], np.int32), np.array([[64]], np.int32)), dict(k=6, radius=5.0)
     cases.append(("ball_knn_few", few))
     return cases
+
+
+def gridify_variant_cases():
+    """(name, build) of the two operator variants: `occaware_*` = Gridify_occaware (coverage-aware
+    sampling, OUR specification -- parity unpinned), `fastrand_*` = the fast_rand build of Gridify."""
+    cases = []
+
+    def occ(beta, O, kind):
+        def build():
+            data, npnts = synth.make_batch(2, 8192, kind, first_id=30)
+            kw = synth.gridify_kwargs(synth.SEG_SCANNET_8192, 0, 7)
+            kw.update(max_o_grid=O, beta=beta)
+            return (data, npnts), kw
+        return build
+    cases.append(("occaware_scan8k_b1", occ(1.0, 256, "planes")))
+    cases.append(("occaware_scan8k_b0", occ(0.0, 100, "ball")))
+
+    def fr(layer, over):
+        def build():
+            data, npnts = synth.make_batch(2, 8192, "planes", first_id=40)
+            kw = synth.gridify_kwargs(synth.SEG_SCANNET_8192, layer)
+            kw.update(over)
+            return (data, npnts), kw
+        return build
+    cases.append(("fastrand_scan8k_L0", fr(0, {})))
+    cases.append(("fastrand_scan8k_overfull", fr(1, dict(max_p_grid=8, max_o_grid=300))))
+    cases.append(("fastrand_scan8k_loc0", fr(0, dict(loc=0, max_p_grid=16))))
+    return cases

@@ -44,6 +44,11 @@ def all_cases():
         out.append((name, build, lambda a, kw: orc.gridify_knn(*a, **kw)))
     for name, build in cases.gridify_up_cases(orc.gridify):
         out.append((name, build, lambda a, kw: orc.gridify_up(*a, **kw)))
+    for name, build in cases.gridify_variant_cases():
+        if name.startswith("occaware"):
+            out.append((name, build, lambda a, kw: orc.gridify_occaware(*a, **kw)))
+        else:
+            out.append((name, build, lambda a, kw: orc.gridify_fast_rand(*a, **kw)))
     for name, build in cases.knn_cases():
         out.append((name, build, lambda a, kw: (orc.ball_knn(*a, **kw),)))
         out.append((name.replace("ball_knn", "knn"), build,

@@ -27,6 +27,10 @@ def NP(ts):
 
 def run_hip(name, args, kw):
     targs = [T(a) for a in args]
+    if name.startswith("occaware"):
+        return NP(ops.Gridify_occaware(*targs, **kw))
+    if name.startswith("fastrand"):
+        return NP(ops.Gridify_fast_rand(*targs, **kw))
     if name.startswith("gridify_knn"):
         return NP(ops.GridifyKNN(*targs, **kw))
     if name.startswith("gridify_up"):
