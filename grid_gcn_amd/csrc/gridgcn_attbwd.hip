@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
         if (row >= p.E) row = p.E - 1;
         const float *zr = p.Z + row * C;
         const float *gr;
-        const int *ar = nullptr;
+        const gg_amax_t *ar = nullptr;
         int pp = 0;
         if (sparse) {
             const long long cen = row / p.P;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
         auto ldg = [&](int k) -> float4 {
             float4 g = *(const float4 *)(gr + k);
             if (sparse) {
-                const int4 am = *(const int4 *)(ar + k);
+                const int4 am = gg_amax4(ar + k);
                 g.x = am.x == pp ? g.x : 0.f; g.y = am.y == pp ? g.y : 0.f;
                 g.z = am.z == pp ? g.z : 0.f; g.w = am.w == pp ? g.w : 0.f;
             }

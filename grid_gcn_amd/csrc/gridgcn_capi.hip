@@ -43,15 +43,16 @@ size_t gg_take_bwd_sorted_workspace(int B, int N, int M);
 int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, int, int, void *,
                        hipStream_t);
 int gg_pairmax_fwd(const float *, const float *, const float *, const float *, const float *,
-                   const float *, long long, int, int, float *, int, int *, float *, hipStream_t);
+                   const float *, long long, int, int, float *, int, unsigned char *, float *,
+                   hipStream_t);
 int gg_pairmax_fwd_src(const float *, const int *, const float *, const float *, const float *, int,
                        int, int, const float *, const float *, const float *, const float *,
-                       const float *, long long, int, int, float *, int, int *, float *,
+                       const float *, long long, int, int, float *, int, unsigned char *, float *,
                        hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
-                   const float *, const int *, long long, int, int, int, float *, float *, double *,
-                   double *, const float *, hipStream_t);
+                   const float *, const unsigned char *, long long, int, int, int, float *, float *,
+                   double *, double *, const float *, hipStream_t);
 
 int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
                    float *, float *, float *, float *, hipStream_t);
@@ -111,7 +112,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 2; }
+int gridgcn_abi_version(void) { return 3; }
 
 int gridgcn_set_mlp_precision(int bf16)
 {
@@ -365,7 +366,7 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *Wdx, int ndx, long long E,
                        int C, int cin, int cin_w, int rot, int ldy, float *dX, float *dW,
                        double *psums,
-                       const int32_t *amax, const float *gval, int P, void *workspace,
+                       const uint8_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream)
 {
     if (amax && (!gval || P < 1 || E % P != 0)) return GRIDGCN_EINVAL;
@@ -428,9 +429,10 @@ int gridgcn_bn_relu_dropout_apply(const float *Z, const float *scale, const floa
 
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *scale_a, const float *shift_a,
-                        long long ncent, int P, int C, float *agg, int ld_agg, int32_t *amax,
+                        long long ncent, int P, int C, float *agg, int ld_agg, uint8_t *amax,
                         float *zsel, void *stream)
 {
+    if (P > 256) return GRIDGCN_EINVAL;   // one-byte arg max
     if (!Zp || !Za || !scale_p || !shift_p || !scale_a || !shift_a || !agg || !amax || ncent < 1 ||
         P < 1 || C < 1 || ld_agg < C)
         return GRIDGCN_EINVAL;
@@ -442,7 +444,7 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             const float *Wg, const float *b, int B, int Nsrc, int O,
                             const float *Za, const float *scale_p, const float *shift_p,
                             const float *scale_a, const float *shift_a, long long ncent, int P,
-                            int C, float *agg, int ld_agg, int32_t *amax, float *zsel,
+                            int C, float *agg, int ld_agg, uint8_t *amax, float *zsel,
                             void *stream)
 {
     if ((!Ysrc && !Wg) || !nebidx || !att16 || !b || !Za || !scale_p || !shift_p || !scale_a ||
@@ -458,7 +460,7 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
 int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *mean_p, const float *rstd_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
-                        const float *rstd_a, const float *dagg, const int32_t *amax,
+                        const float *rstd_a, const float *dagg, const uint8_t *amax,
                         long long ncent, int P, int C, int ld_dagg, float *gp, float *ga,
                         double *sums_p, double *sums_a, const float *zsel, void *stream)
 {
@@ -570,7 +572,7 @@ int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, co
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
-int gridgcn_sparse_add(const int32_t *amax, const float *gval, long long ncent, int P, int C,
+int gridgcn_sparse_add(const uint8_t *amax, const float *gval, long long ncent, int P, int C,
                        float *dX, void *stream)
 {
     if (!amax || !gval || !dX || ncent < 1 || P < 1 || C < 1) return GRIDGCN_EINVAL;
@@ -678,7 +680,7 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
 }
 
 int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
-                               const float *dY, const int32_t *amax,
+                               const float *dY, const uint8_t *amax,
                                const float *gval, const float *scale, const float *shift,
                                const float *mean, const float *rstd, const float *m1,
                                const float *m2, const float *att16, const int32_t *nebidx, int B,
@@ -707,7 +709,7 @@ int gridgcn_edge_lin0_backward_sparse_workspace_bytes(int B, int Nsrc, int C0, s
 }
 
 int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
-                                      const int32_t *amax, const float *gval, const float *zsel,
+                                      const uint8_t *amax, const float *gval, const float *zsel,
                                       const float *Ysrc, const float *Wg, const float *b,
                                       const float *scale, const float *shift, const float *mean,
                                       const float *rstd, const float *m1, const float *m2, int B,

@@ -9,5 +9,5 @@ int gg_ctx_scatter(const float *dctx, const int *cidx, long long ncent, int Cf, 
 int gg_dz_segsum(const float *dY, const float *Z, const float *scale, const float *shift,
                  const float *mean, const float *rstd, const float *m1, const float *m2,
                  long long ncent, int P, int C, float *out, hipStream_t st);
-int gg_sparse_add(const int *amax, const float *gval, long long ncent, int P, int C, float *dX,
+int gg_sparse_add(const unsigned char *amax, const float *gval, long long ncent, int P, int C, float *dX,
                   hipStream_t st);

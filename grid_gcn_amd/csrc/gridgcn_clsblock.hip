@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gg_k_dz_segsum(const float *__restrict__ 
 }
 
 // dX[(centre*P + amax[centre][c])][c] += gval[centre][c]   (every destination distinct: plain RMW)
-__global__ __launch_bounds__(256) void gg_k_sparse_add(const int *__restrict__ amax,
+__global__ __launch_bounds__(256) void gg_k_sparse_add(const unsigned char *__restrict__ amax,
                                                        const float *__restrict__ gval,
                                                        long long total, int P, int C,
                                                        float *__restrict__ dX)
@@ -159,7 +159,7 @@ int gg_dz_segsum(const float *dY, const float *Z, const float *scale, const floa
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-int gg_sparse_add(const int *amax, const float *gval, long long ncent, int P, int C, float *dX,
+int gg_sparse_add(const unsigned char *amax, const float *gval, long long ncent, int P, int C, float *dX,
                   hipStream_t st)
 {
     gg_k_sparse_add<<<gg_grid(ncent * C, 256, 16384), 256, 0, st>>>(amax, gval, ncent * C, P, C, dX);

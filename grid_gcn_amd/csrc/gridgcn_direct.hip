@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         if (row >= p.E) row = p.E - 1;
         const float *zr = p.Z + row * C;
         const float *gr;
-        const int *ar = nullptr;
+        const gg_amax_t *ar = nullptr;
         int pp = 0;
         if (sparse) {
             const long long cen = row / p.P;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         auto ldg = [&](int k) -> float4 {
             float4 g = *(const float4 *)(gr + k);
             if (sparse) {
-                const int4 am = *(const int4 *)(ar + k);
+                const int4 am = gg_amax4(ar + k);
                 g.x = am.x == pp ? g.x : 0.f; g.y = am.y == pp ? g.y : 0.f;
                 g.z = am.z == pp ? g.z : 0.f; g.w = am.w == pp ? g.w : 0.f;
             }
@@ -736,8 +736,8 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
         if (sparse) {
             const long long cc = R.ok ? cen : 0;
             gr = p.gval + cc * C + chl;
-            const int *ar = p.amax + cc * C + chl;
-            if constexpr (MT == 2) { const int2 t = *(const int2 *)ar; R.am[0] = t.x; R.am[1] = t.y; }
+            const gg_amax_t *ar = p.amax + cc * C + chl;
+            if constexpr (MT == 2) { const unsigned short t = *(const unsigned short *)ar; R.am[0] = t & 255; R.am[1] = t >> 8; }
             else R.am[0] = ar[0];
             R.pp = pp;
             pp += 2;

@@ -19,7 +19,7 @@ struct GGEdgeLin0Bwd {
     const float *Z;       // [E][C0], or nullptr: recomputed from (Ysrc, Wg, b) as in the forward
     const float *Ysrc, *Wg, *b;
     const float *dY;      // dense upstream gradient [E][C0] (nullptr: sparse)
-    const int *amax;      // sparse: [B*O][C0] arg-max neighbour, value
+    const unsigned char *amax;   // sparse: [B*O][C0] arg-max neighbour (one byte), value
     const float *gval;
     const float *scale, *shift, *mean, *rstd, *m1, *m2;   // [C0]
     const float *att16;   // [E][16] (geo_vec at columns 1..3)
@@ -31,7 +31,7 @@ struct GGEdgeLin0Bwd {
 };
 
 size_t gg_edge_lin0_sparse_workspace(int B, int N, int C);
-int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *amax,
+int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigned char *amax,
                             const float *gval, const float *zsel, const float *Ysrc,
                             const float *Wg, const float *bias, const float *scale,
                             const float *shift, const float *mean, const float *rstd,

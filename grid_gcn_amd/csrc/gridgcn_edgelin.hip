@@ -342,7 +342,7 @@ int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st)
 struct GGEdgeSparse {
     const int *nebidx;       // [B][O*P]
     const float *att16;      // [E][16]
-    const int *amax;         // [B*O][C]
+    const unsigned char *amax;   // [B*O][C]
     const float *gval, *zsel;   // [B*O][C]: gradient w.r.t. relu(bn(z0)) and z0 at the arg max
     const float *sc, *sh;    // [C] BatchNorm scale / shift of the layer
     float *part;             // [B][nsplit][N+1][C]
@@ -536,7 +536,7 @@ int gg_edge_lin0_sparse_nsplit(int B, int C)
 }
 
 // 1 = shape not supported.  wgs[3*C] and gg[12] (fp64) must be zero-filled by the caller.
-int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const int *amax,
+int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigned char *amax,
                             const float *gval, const float *zsel, const float *Ysrc,
                             const float *Wg, const float *bias, const float *scale,
                             const float *shift, const float *mean, const float *rstd,

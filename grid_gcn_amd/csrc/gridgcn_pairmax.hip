@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
                                                         const float *__restrict__ sha,
                                                         long long ncent, int P, int C,
                                                         float *__restrict__ agg,
-                                                        int *__restrict__ amax,
+                                                        unsigned char *__restrict__ amax,
                                                         float *__restrict__ zsel, int lda)
 {
     const long long total = ncent * C;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict_
             if (v > best) { best = v; bi = p; zps = z1; zas = z2; }
         }
         agg[o * lda + c] = best;
-        amax[t] = bi;
+        amax[t] = (unsigned char)bi;
         if (zsel) {              // the two pre-activations at the arg max: backward needs no gather
             zsel[t] = zps;
             zsel[total + t] = zas;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
                                                              const float *__restrict__ sha,
                                                              long long ncent, int P, int C,
                                                              float *__restrict__ agg,
-                                                             int *__restrict__ amax,
+                                                             unsigned char *__restrict__ amax,
                                                              float *__restrict__ zsel, int lda)
 {
     const int C4 = C >> 2;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
         }
         const long long e = o * C + c;
         *(float4 *)(agg + o * lda + c) = make_float4(best[0], best[1], best[2], best[3]);
-        *(int4 *)(amax + e) = make_int4(bi4[0], bi4[1], bi4[2], bi4[3]);
+        *(unsigned *)(amax + e) = (unsigned)bi4[0] | ((unsigned)bi4[1] << 8) | ((unsigned)bi4[2] << 16) | ((unsigned)bi4[3] << 24);
         if (zsel) {
             *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
             *(float4 *)(zsel + ncent * C + e) = make_float4(zas[0], zas[1], zas[2], zas[3]);
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict
                                                          const float *__restrict__ sha,
                                                          long long ncent, int P, int C,
                                                          float *__restrict__ agg,
-                                                         int *__restrict__ amax,
+                                                         unsigned char *__restrict__ amax,
                                                          float *__restrict__ zsel, int lda)
 {
     const int C4 = C >> 2;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict
         }
         const long long e = o * C + c;
         *(float4 *)(agg + o * lda + c) = make_float4(best[0], best[1], best[2], best[3]);
-        *(int4 *)(amax + e) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+        *(unsigned *)(amax + e) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
         if (zsel) {
             *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
             *(float4 *)(zsel + ncent * C + e) = make_float4(zas[0], zas[1], zas[2], zas[3]);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     const float *__restrict__ Zp, const float *__restrict__ Za, const float *__restrict__ scp,
     const float *__restrict__ shp, const float *__restrict__ mup, const float *__restrict__ rsp,
     const float *__restrict__ sca, const float *__restrict__ sha, const float *__restrict__ mua,
-    const float *__restrict__ rsa, const float *__restrict__ dagg, const int *__restrict__ amax,
+    const float *__restrict__ rsa, const float *__restrict__ dagg, const unsigned char *__restrict__ amax,
     long long ncent, int P, int C, float *__restrict__ gp, float *__restrict__ ga,
     double *__restrict__ sums_p, double *__restrict__ sums_a, const float *__restrict__ zsel,
     int ldd)
@@ -401,7 +401,7 @@ int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float 
 int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16, const float *Wg,
                        const float *b, int B, int Nsrc, int O, const float *Za, const float *scp,
                        const float *shp, const float *sca, const float *sha, long long ncent, int P,
-                       int C, float *agg, int lda, int *amax, float *zsel, hipStream_t st)
+                       int C, float *agg, int lda, unsigned char *amax, float *zsel, hipStream_t st)
 {
     if ((C & 3) || (lda & 3)) return 1;
     GGPtRecompute r;
@@ -416,7 +416,7 @@ int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16,
 
 int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *sca, const float *sha, long long ncent, int P, int C, float *agg,
-                   int lda, int *amax, float *zsel, hipStream_t st)
+                   int lda, unsigned char *amax, float *zsel, hipStream_t st)
 {
     if ((C & 3) == 0 && (lda & 3) == 0) {
         long long nb = (ncent * (C / 4) + 255) / 256;
@@ -434,7 +434,7 @@ int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const flo
 
 int gg_pairmax_bwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *mup, const float *rsp, const float *sca, const float *sha,
-                   const float *mua, const float *rsa, const float *dagg, const int *amax,
+                   const float *mua, const float *rsa, const float *dagg, const unsigned char *amax,
                    long long ncent, int P, int C, int ldd, float *gp, float *ga, double *sums_p,
                    double *sums_a, const float *zsel, hipStream_t st)
 {

@@ -2,6 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// arg-max neighbour of a (centre, channel) pair: one byte (P <= 128 neighbours per centre)
+typedef unsigned char gg_amax_t;
+// four consecutive arg-max entries with ONE 32-bit load (address a multiple of 4)
+__device__ __forceinline__ int4 gg_amax4(const gg_amax_t *p)
+{
+    const unsigned v = *(const unsigned *)p;
+    return make_int4((int)(v & 255u), (int)((v >> 8) & 255u), (int)((v >> 16) & 255u), (int)(v >> 24));
+}
+
 struct GGLinFwd {
     const float *X;       // [E][cin] row-major
     const float *W;       // packed [groups][K][32][NT] (see gridgcn.h)
@@ -42,7 +51,7 @@ struct GGLinBwd {
     double *psums;        // [2][cin] BN-backward sums of the previous layer (zeroed by caller)
     long long E;
     int C, cin, ldd, lda;
-    const int *amax;      // sparse upstream gradient (nullptr: dense dY): arg-max neighbour [E/P][C]
+    const gg_amax_t *amax;  // sparse upstream gradient (nullptr: dense dY): arg-max neighbour [E/P][C]
     const float *gval;    //   and its value [E/P][C]; row e = centre e/P, neighbour e%P
     int P, ncen_max;
     const unsigned long long *drop_dev;    // optional device scalar added to the dropout seed

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_bwd(GGLinBwd p)
             const long long o0 = r0 / p.P;
             rem0 = (int)(r0 - o0 * p.P);
             const int ncen = (rem0 + nrows - 1) / p.P + 1;
-            const int *am = p.amax + o0 * C;
+            const gg_amax_t *am = p.amax + o0 * C;
             const float *gv = p.gval + o0 * C;
             for (int i = tid; i < ncen * C; i += 256) { s_am[i] = am[i]; s_gv[i] = gv[i]; }
             __syncthreads();
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void gg_k_linear_dw(GGLinBwd p)
                             const int oc = (int)(((float)t + 0.5f) * invP);
                             const int pp = t - oc * p.P;
                             const long long idx = (o0 + oc) * C + c;
-                            const int4 am = *(const int4 *)(p.amax + idx);
+                            const int4 am = gg_amax4(p.amax + idx);
                             const float4 gv = *(const float4 *)(p.gval + idx);
                             g[u].x = am.x == pp ? gv.x : 0.f; g[u].y = am.y == pp ? gv.y : 0.f;
                             g[u].z = am.z == pp ? gv.z : 0.f; g[u].w = am.w == pp ? gv.w : 0.f;
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void gg_k_linear_dx(GGLinBwd p)
                             const int oc = (int)(((float)t + 0.5f) * invP);
                             const int pp = t - oc * p.P;
                             const long long idx = (o0 + oc) * C + c;
-                            const int4 am = *(const int4 *)(p.amax + idx);
+                            const int4 am = gg_amax4(p.amax + idx);
                             const float4 gv = *(const float4 *)(p.gval + idx);
                             g[u].x = am.x == pp ? gv.x : 0.f; g[u].y = am.y == pp ? gv.y : 0.f;
                             g[u].z = am.z == pp ? gv.z : 0.f; g[u].w = am.w == pp ? gv.w : 0.f;

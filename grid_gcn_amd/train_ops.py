@@ -535,7 +535,7 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim, out=
             _lib.check(rc, "gridgcn_att_max_eval")
             return agg if out is not None else agg.view(B, O, C)
         Za, sc_a, sh_a = _chain_eval_raw(lib, att16, att_layers)
-        amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+        amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
         rc = lib.gridgcn_pairmax_fwd_src(
             _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None, _ptr(wgb[3]), B,
             Nsrc, O, _ptr(Za), _ptr(sc_p), _ptr(sh_p), _ptr(sc_a), _ptr(sh_a), ncent, P, C,
@@ -629,7 +629,7 @@ class _EdgeBlockTrain(torch.autograd.Function):
             sa = _chain_forward(lib, att_vec, params[4 * Lp:], bns_a, eps)
             C = sp.Z[-1].shape[1]
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
-            amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             rc = lib.gridgcn_pairmax_fwd(_ptr(sp.Z[-1]), _ptr(sa.Z[-1]), _ptr(sp.scale[-1]),
                                          _ptr(sp.shift[-1]), _ptr(sa.scale[-1]), _ptr(sa.shift[-1]),
@@ -737,7 +737,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             agg = out if out is not None else torch.empty((ncent, C), dtype=torch.float32,
                                                            device=dev)
             lda = agg.stride(0)
-            amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             if noz:
                 rc = lib.gridgcn_pairmax_fwd_src(
@@ -938,7 +938,7 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=
     scale, shift = rnd(C).abs() + 0.5, rnd(C) * 0.1
     mean, rstd = rnd(C) * 0.1, rnd(C).abs() + 0.5
     m1, m2 = rnd(C) * 1e-3, rnd(C) * 1e-3
-    amax = torch.randint(0, P, (ncent, C), device=device, dtype=torch.int32, generator=g)
+    amax = torch.randint(0, P, (ncent, C), device=device, dtype=torch.int32, generator=g).to(torch.uint8)
     gval = rnd(ncent, C)
     Wt = rnd(C, cin)
     Wb, Wg = pack_tiles(Wt), pack_groups(Wt)
@@ -1120,7 +1120,7 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
             sa = _chain_forward(lib, Z20, pa2[4:], bns_a2[1:], eps, 0, N0,
                                 prev_bn=(vecA[0], vecA[1]))
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
-            amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+            amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
             rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
                                          _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
@@ -1332,7 +1332,7 @@ def edge_block_cls_eval(src, nebidx, cent, pt_layers, att1_layers, att2_layers):
         _lib.check(rc, "gridgcn_linear_fwd_direct2")
         Za, sca, sha = _chain_eval_raw(lib, Z20, att2_layers[1:], _bn_eval_vectors(a20.bn))
         agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)
-        amax = torch.empty((ncent, C), dtype=torch.int32, device=dev)
+        amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
         rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(Za), _ptr(scl), _ptr(shl), _ptr(sca), _ptr(sha),
                                      ncent, P, C, _ptr(agg), C, _ptr(amax), None, st)
         _lib.check(rc, "gridgcn_pairmax_fwd")

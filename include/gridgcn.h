@@ -66,7 +66,7 @@ typedef struct gridgcn_grid_params {
 
 const char *gridgcn_strerror(int code);
 /* library/ABI version, bumped on any signature change */
-int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev */
+int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors */
 
 /* Precision of the contraction inside the training GEMM kernels (gridgcn_linear_fwd_direct,
  * gridgcn_linear_dx, the direct dW kernel behind gridgcn_linear_bwd): 0 (default) = exact fp32
@@ -247,7 +247,7 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             const float *Wg, const float *b, int B, int Nsrc, int O,
                             const float *Za, const float *scale_p, const float *shift_p,
                             const float *scale_a, const float *shift_a, long long ncent, int P,
-                            int C, float *agg, int ld_agg, int32_t *amax, float *zsel,
+                            int C, float *agg, int ld_agg, uint8_t *amax, float *zsel,
                             void *stream);
 /* Evaluation-mode tail of the edge block in one kernel (csrc/gridgcn_atteval.hip): with every
  * BatchNorm a fixed affine map (scale = gamma*rsqrt(running_var+eps), shift = beta - mean*scale),
@@ -262,7 +262,7 @@ int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shif
                          const float *shift_p, int B, int Nsrc, int O, int P, int C, float *agg,
                          int ld_agg, void *stream);
 int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
-                               const float *dY, const int32_t *amax,
+                               const float *dY, const uint8_t *amax,
                                const float *gval, const float *scale, const float *shift,
                                const float *mean, const float *rstd, const float *m1,
                                const float *m2, const float *att16, const int32_t *nebidx, int B,
@@ -279,7 +279,7 @@ int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *
  * bz = -scale*rstd*m2, cz = -scale*m1. */
 int gridgcn_edge_lin0_backward_sparse_workspace_bytes(int B, int Nsrc, int C0, size_t *bytes);
 int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
-                                      const int32_t *amax, const float *gval, const float *zsel,
+                                      const uint8_t *amax, const float *gval, const float *zsel,
                                       const float *Ysrc, const float *Wg, const float *b,
                                       const float *scale, const float *shift, const float *mean,
                                       const float *rstd, const float *m1, const float *m2, int B,
@@ -359,7 +359,7 @@ int gridgcn_ctx_max_backward(const float *dctx, const int32_t *cidx, long long n
 int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, const float *shift,
                          const float *mean, const float *rstd, const float *m1, const float *m2,
                          long long ncent, int P, int C, float *out, void *stream);
-int gridgcn_sparse_add(const int32_t *amax, const float *gval, long long ncent, int P, int C,
+int gridgcn_sparse_add(const uint8_t *amax, const float *gval, long long ncent, int P, int C,
                        float *dX, void *stream);
 /* gridgcn_pack_linear: W[C][cin_w] (framework layout, C <= 256), b[C]; the kernels see `cin` >=
  *   cin_w input channels: kernel column k = framework column k + rot (k < cin_w - rot), k - (cin_w -
@@ -390,7 +390,7 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const float *Wdx, int ndx, long long E,
                        int C, int cin, int cin_w, int rot, int ldy, float *dX, float *dW,
                        double *psums,
-                       const int32_t *amax, const float *gval, int P, void *workspace,
+                       const uint8_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream);
 /* (cin = row length of Aprev / dX as the kernels see it; dW is written in the FRAMEWORK layout
  *  [C][cin_w]: zero-padding columns dropped and the `rot` columns moved back in front, the inverse
@@ -402,12 +402,13 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
  *
  * gridgcn_pairmax_fwd: agg[o,c] = max_p relu(Zp*scale_p+shift_p) * relu(Za*scale_a+shift_a) over the
  *   P rows of centre o (Zp, Za [ncent*P, C] pre-BatchNorm outputs of the last pt / att layer;
- *   gcn_module_g_att.py:167 and :57-59), amax = first arg max.
+ *   gcn_module_g_att.py:167 and :57-59), amax = first arg max, ONE BYTE per (centre, channel)
+ *   (P <= 256; the arg-max tensors are read three to five times per step).
  * gridgcn_pairmax_bwd: gp/ga[o,c] = gradient w.r.t. the two post-ReLU activations at the arg-max
  *   edge, and the BatchNorm-backward sums (as gridgcn_bn_relu_bwd_reduce) of both layers. */
 int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *scale_a, const float *shift_a,
-                        long long ncent, int P, int C, float *agg, int ld_agg, int32_t *amax,
+                        long long ncent, int P, int C, float *agg, int ld_agg, uint8_t *amax,
                         float *zsel, void *stream);
 /* ld_agg / ldy (gridgcn_bn_relu_apply): row stride in floats of the output, >= C -- lets the two
  * halves of update_func's concat (gcn_module_g_att.py:31-36) be written in place, no concat pass. */
@@ -416,7 +417,7 @@ int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
 int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         const float *shift_p, const float *mean_p, const float *rstd_p,
                         const float *scale_a, const float *shift_a, const float *mean_a,
-                        const float *rstd_a, const float *dagg, const int32_t *amax,
+                        const float *rstd_a, const float *dagg, const uint8_t *amax,
                         long long ncent, int P, int C, int ld_dagg, float *gp, float *ga,
                         double *sums_p,
                         double *sums_a, const float *zsel, void *stream);

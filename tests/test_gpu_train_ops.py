@@ -378,6 +378,7 @@ def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
     m1, m2 = rnd(C) * 1e-2, rnd(C) * 1e-2
     pv = [rnd(cin).abs() + 0.5, rnd(cin) * 0.3, rnd(cin) * 0.1, rnd(cin).abs() + 0.5]
     amax = torch.randint(0, P, (ncent, C), device=DEV, dtype=torch.int32, generator=g)
+    amax8 = amax.to(torch.uint8)                # the kernels' one-byte arg max
     gval = rnd(ncent, C)
     dY = rnd(E, C)
     W = rnd(C, cin)
@@ -398,7 +399,7 @@ def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
             None if sparse else _ptr(dY), _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
             _ptr(m1), _ptr(m2), _ptr(X), _ptr(pv[0]), _ptr(pv[1]), _ptr(pv[2]), _ptr(pv[3]),
             _ptr(Wb), None, _ptr(Wdx), cin, E, C, cin, cin, 0, 0, _ptr(dX), _ptr(dW), _ptr(psums),
-            _ptr(amax) if sparse else None, _ptr(gval) if sparse else None, P if sparse else 0,
+            _ptr(amax8) if sparse else None, _ptr(gval) if sparse else None, P if sparse else 0,
             _ptr(ws), nbytes.value, _stream(Z))
         _lib.check(rc, "gridgcn_linear_bwd")
         torch.cuda.synchronize()
