@@ -34,7 +34,7 @@ EXPORTS = [
     "gridgcn_bn_relu_bwd_elemt",
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
     "gridgcn_linear_fwd_direct2", "gridgcn_ctx_max", "gridgcn_ctx_max_backward",
-    "gridgcn_bn_dz_segsum", "gridgcn_sparse_add",
+    "gridgcn_bn_dz_segsum", "gridgcn_sparse_add", "gridgcn_bn_stats",
 ]
 
 
@@ -153,6 +153,8 @@ def load():
     lib.gridgcn_ctx_max_backward.argtypes = [vp, vp, ll, ci, ci, vp, vp]
     lib.gridgcn_bn_dz_segsum.restype = ci
     lib.gridgcn_bn_dz_segsum.argtypes = [vp] * 8 + [ll, ci, ci, vp, vp]
+    lib.gridgcn_bn_stats.restype = ci
+    lib.gridgcn_bn_stats.argtypes = [vp, ll, ci, ci, vp, vp]
     lib.gridgcn_sparse_add.restype = ci
     lib.gridgcn_sparse_add.argtypes = [vp, vp, ll, ci, ci, vp, vp]
     cf = ctypes.c_float

@@ -572,6 +572,12 @@ int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, co
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_bn_stats(const float *Z, long long E, int C, int ld, double *sums, void *stream)
+{
+    if (!Z || !sums || E < 1 || C < 1 || ld < C) return GRIDGCN_EINVAL;
+    return gg_bn_stats(Z, E, C, ld, sums, (hipStream_t)stream);
+}
+
 int gridgcn_sparse_add(const uint8_t *amax, const float *gval, long long ncent, int P, int C,
                        float *dX, void *stream)
 {

@@ -11,3 +11,4 @@ int gg_dz_segsum(const float *dY, const float *Z, const float *scale, const floa
                  long long ncent, int P, int C, float *out, hipStream_t st);
 int gg_sparse_add(const unsigned char *amax, const float *gval, long long ncent, int P, int C, float *dX,
                   hipStream_t st);
+int gg_bn_stats(const float *Z, long long E, int C, int ld, double *sums, hipStream_t st);

@@ -127,6 +127,34 @@ __global__ __launch_bounds__(256) void gg_k_sparse_add(const unsigned char *__re
     }
 }
 
+// sums[c] += sum_e Z[e][c], sums[C + c] += sum_e Z[e][c]^2 over E rows of ld floats: the batch
+// statistics of a layer whose GEMM ran outside the MFMA kernels (their epilogues do this for free).
+// block = 256 threads = 256/Cb row streams x Cb columns (Cb = min(C, 256) columns per block column).
+__global__ __launch_bounds__(256) void gg_k_bn_stats(const float *__restrict__ Z, long long E, int C,
+                                                     int ld, double *__restrict__ sums)
+{
+    __shared__ float sh1[256], sh2[256];
+    const int tid = threadIdx.x;
+    const int Cb = C < 256 ? C : 256;
+    const int rs = 256 / Cb;
+    const int c = blockIdx.y * 256 + tid % Cb, rr = tid / Cb;
+    float a1 = 0.f, a2 = 0.f;
+    const bool ok = c < C && rr < rs;
+    if (ok)
+        for (long long r = (long long)blockIdx.x * rs + rr; r < E; r += (long long)gridDim.x * rs) {
+            const float z = Z[r * ld + c];
+            a1 += z;
+            a2 += z * z;
+        }
+    sh1[tid] = a1; sh2[tid] = a2;
+    __syncthreads();
+    if (ok && rr == 0) {
+        for (int j = 1; j < rs; j++) { a1 += sh1[tid + j * Cb]; a2 += sh2[tid + j * Cb]; }
+        atomicAdd(&sums[c], (double)a1);
+        atomicAdd(&sums[C + c], (double)a2);
+    }
+}
+
 static int gg_grid(long long work, int per_block, int cap)
 {
     long long nb = (work + per_block - 1) / per_block;
@@ -163,5 +191,13 @@ int gg_sparse_add(const unsigned char *amax, const float *gval, long long ncent,
                   hipStream_t st)
 {
     gg_k_sparse_add<<<gg_grid(ncent * C, 256, 16384), 256, 0, st>>>(amax, gval, ncent * C, P, C, dX);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_bn_stats(const float *Z, long long E, int C, int ld, double *sums, hipStream_t st)
+{
+    const int Cb = C < 256 ? C : 256, rs = 256 / Cb;
+    dim3 grid((unsigned)gg_grid(E, rs * 32, 2048), (unsigned)((C + 255) / 256));
+    gg_k_bn_stats<<<grid, 256, 0, st>>>(Z, E, C, ld, sums);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

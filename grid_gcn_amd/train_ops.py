@@ -80,7 +80,12 @@ def supported(layers, x):
         c = l.lin.out_features
         if l.bn is None or not l.use_relu or c > 256 or 256 % c != 0:
             return False
-        if l.lin.in_features > 384:          # <= 12 column tiles in gg_k_linear_bwd
+        cin = l.lin.in_features
+        if cin > 384:                        # <= 12 column tiles in gg_k_linear_bwd
+            return False
+        # input widths the register-direct dW kernel does not take go to the LDS-staged backward,
+        # which holds at most 48 (input tile, output tile) pairs
+        if not _dw_direct_ok(c, cin) and ((cin + 31) // 32) * ((c + 31) // 32) > 48:
             return False
     return True
 
@@ -408,6 +413,7 @@ class _MLPTrain(torch.autograd.Function):
             _lib.check(rc, "gridgcn_bn_relu_apply")
         ctx.L = L
         ctx.ndx = st.ndx
+        ctx.cin_w0 = params[0].shape[1]          # x may carry zero-padded columns beyond it
         ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg,
                               *st.Wdx)
         return Y
@@ -439,8 +445,112 @@ class _MLPTrain(torch.autograd.Function):
                                                 E, C, dY.stride(0), _ptr(sums), _stream(x))
             _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
             dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
-                                        ctx.ndx, sums, dY, None, ctx.needs_input_grad[0])
+                                        ctx.ndx, sums, dY, None, ctx.needs_input_grad[0],
+                                        ctx.cin_w0, 0)
         return (dX, None) + tuple(grads)
+
+
+class _WideLayerTrain(torch.autograd.Function):
+    """conv + BatchNorm(batch statistics) + ReLU of a layer BEYOND the MFMA kernels' widths
+    (> 256 output or > 384 input channels: the last layer of the classifier and of the 200k-point
+    workload).  The GEMMs go to rocBLAS; the BatchNorm work -- statistics, apply, backward sums,
+    dZ -- to this library's elementwise kernels (the framework's channels-last BatchNorm kernels
+    ran at 0.5-0.8 TB/s on these [131 k, 512] tensors and were 20 % of cfg5's step)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, bn):
+        lib = _lib.load()
+        x = x.contiguous()
+        E, C = x.shape[0], W.shape[0]
+        dev = x.device
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            Z = torch.addmm(b.detach(), x.detach(), W.detach().t())
+            sums = _zeros(2 * C, torch.float64, dev)
+            _lib.check(lib.gridgcn_bn_stats(_ptr(Z), E, C, C, _ptr(sums), st), "gridgcn_bn_stats")
+            vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+            track = bn.track_running_stats
+            rc = lib.gridgcn_bn_finalize(
+                _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, bn.eps,
+                _momentum(bn) if track else 0.0, C, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
+                _ptr(bn.running_var) if track else None,
+                _ptr(bn.num_batches_tracked) if track else None, st)
+            _lib.check(rc, "gridgcn_bn_finalize")
+            Y = torch.empty_like(Z)
+            rc = lib.gridgcn_bn_relu_apply(_ptr(Z), _ptr(vec[0]), _ptr(vec[1]), _ptr(Y), E, C, C, st)
+            _lib.check(rc, "gridgcn_bn_relu_apply")
+        ctx.save_for_backward(x, W, Z, vec)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _lib.load()
+        x, W, Z, vec = ctx.saved_tensors
+        E, C = Z.shape
+        dev = x.device
+        dY = dY.contiguous()
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            sums = _zeros(2 * C, torch.float64, dev)
+            rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Z), _ptr(vec[0]), _ptr(vec[1]),
+                                                _ptr(vec[2]), _ptr(vec[3]), E, C, C, _ptr(sums), st)
+            _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
+            v = torch.empty((4, C), dtype=torch.float32, device=dev)
+            rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums), E, C, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]),
+                                             _ptr(v[3]), st)
+            _lib.check(rc, "gridgcn_bn_bwd_finalize")
+            dZ = torch.empty_like(Z)
+            rc = lib.gridgcn_bn_relu_bwd_elemt(_ptr(dY), _ptr(Z), _ptr(vec[0]), _ptr(vec[1]),
+                                               _ptr(vec[2]), _ptr(vec[3]), _ptr(v[0]), _ptr(v[1]),
+                                               E, C, _ptr(dZ), st)
+            _lib.check(rc, "gridgcn_bn_relu_bwd_elemt")
+            dX = torch.matmul(dZ, W.detach()) if ctx.needs_input_grad[0] else None
+            dW = _tn_matmul(dZ, x.detach())
+            db = _zeros(C, torch.float32, dev)      # bias in front of a BatchNorm: sum(dZ) == 0
+        return dX, dW, db, v[2], v[3], None
+
+
+def wide_supported(layers, x):
+    """any stack of conv + BatchNorm + ReLU on fp32 GPU rows (the fallback behind supported())"""
+    # (the BatchNorm kernels: a divisor of 256 or a multiple of 256 channels)
+    return (x.is_cuda and x.dtype == torch.float32 and
+            all(l.bn is not None and l.use_relu and
+                (l.lin.out_features % 256 == 0 or 256 % l.lin.out_features == 0) for l in layers))
+
+
+def _padded_supported(layer, x):
+    """a single layer whose input, zero-padded to a multiple of 8 columns, fits the MFMA kernels"""
+    c, cin8 = layer.lin.out_features, (layer.lin.in_features + 7) & ~7
+    return (layer.bn is not None and layer.use_relu and c <= 256 and 256 % c == 0 and cin8 <= 320
+            and _dw_direct_ok(c, cin8) and c % 8 == 0)
+
+
+def mlp_wide_train(x, layers):
+    """x [..., cin] through `layers` in training mode: rocBLAS GEMMs + this library's BatchNorm
+    kernels (_WideLayerTrain); layers the MFMA kernels take still go through them."""
+    shp = x.shape
+    y = x.reshape(-1, shp[-1])
+    i = 0
+    while i < len(layers):
+        # longest run of layers the MFMA chain takes, else one wide layer
+        j = i
+        while j < len(layers) and supported(layers[i:j + 1], y):
+            j += 1
+        if j > i:
+            y = mlp_bn_relu_train(y, layers[i:j])
+            i = j
+        elif y.shape[1] % 8 and supported(layers[i:i + 1], y) is False and \
+                _padded_supported(layers[i], y):
+            # e.g. 259 -> 256: zero-padded to 264 columns the register-direct kernels take it
+            y = torch.nn.functional.pad(y, (0, 8 - y.shape[1] % 8))
+            y = mlp_bn_relu_train(y, layers[i:i + 1])
+            i += 1
+        else:
+            l = layers[i]
+            y = _WideLayerTrain.apply(y, l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias, l.bn)
+            i += 1
+    return y.reshape(shp[:-1] + (y.shape[-1],))
 
 
 def _bn_eval_vectors(bn):

@@ -359,6 +359,10 @@ int gridgcn_ctx_max_backward(const float *dctx, const int32_t *cidx, long long n
 int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, const float *shift,
                          const float *mean, const float *rstd, const float *m1, const float *m2,
                          long long ncent, int P, int C, float *out, void *stream);
+/* gridgcn_bn_stats: sums[c] += sum_e Z[e][c], sums[C+c] += sum_e Z[e][c]^2 (input of
+ *   gridgcn_bn_finalize) for a layer whose GEMM ran elsewhere (the "wide" fallback: stacks beyond
+ *   the MFMA kernels' 256 output / 384 input channels use rocBLAS + these BatchNorm kernels). */
+int gridgcn_bn_stats(const float *Z, long long E, int C, int ld, double *sums, void *stream);
 int gridgcn_sparse_add(const uint8_t *amax, const float *gval, long long ncent, int P, int C,
                        float *dX, void *stream);
 /* gridgcn_pack_linear: W[C][cin_w] (framework layout, C <= 256), b[C]; the kernels see `cin` >=

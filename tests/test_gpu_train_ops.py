@@ -248,11 +248,56 @@ def test_mlp_eval_matches_modules(E, cin, dims):
 
 
 def test_unsupported_width_falls_to_modules():
-    m = mlp(8, [48]).to(DEV).train()
+    """stacks outside every kernel path (no BatchNorm; a width below 256 that does not divide
+    256): stock modules, with a warning"""
+    from grid_gcn_amd.gridconv import ConvBNReLU, run_mlp
     x = torch.randn(10, 8, device=DEV)
-    assert not train_ops.supported(list(m), x)      # 256 % 48 != 0
+    for m in (torch.nn.Sequential(ConvBNReLU(8, 64, use_bn=False)), mlp(8, [48])):
+        m = m.to(DEV).train()
+        assert not train_ops.supported(list(m), x) and not train_ops.wide_supported(list(m), x)
+        import grid_gcn_amd.gridconv as gcv
+        gcv._warned_shapes.clear()
+        with pytest.warns(RuntimeWarning):
+            assert run_mlp(list(m), x).shape[0] == 10
+
+
+@pytest.mark.parametrize("E,cin,dims", [(3000, 259, [256, 256, 512]), (1500, 1027, [512, 512]),
+                                        (700, 8, [768]), (2000, 128, [512])])
+def test_wide_stack_rocblas_plus_bn_kernels_matches_stock(E, cin, dims):
+    """stacks beyond the MFMA kernels' widths (the 512-wide last layer of the classifier and of the
+    200k-point workload): rocBLAS GEMMs + this library's BatchNorm kernels (train_ops.mlp_wide_train,
+    with the supported sub-runs still on the MFMA chain) == the stock modules: forward, input and
+    parameter gradients, running statistics."""
+    import copy
     from grid_gcn_amd.gridconv import run_mlp
-    assert run_mlp(list(m), x).shape == (10, 48)
+    torch.manual_seed(E + cin)
+    ref = mlp(cin, dims).to(DEV).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    new = copy.deepcopy(ref)
+    assert not train_ops.supported(list(new), torch.empty(1, cin, device=DEV))
+    x1 = (torch.randn(E, cin, device=DEV) * 1.5).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1 = ref(x1)
+    y2 = run_mlp(list(new), x2)
+    assert float((y1 - y2).abs().max()) <= 5e-5 * max(1.0, float(y1.abs().max()))
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+
+    def close(a, b, tol=1e-3):
+        s_ = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * s_, (float((a - b).abs().max()), s_)
+    close(x2.grad, x1.grad)
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), new.named_parameters()):
+        if n1.endswith("lin.bias"):
+            continue
+        close(p2.grad, p1.grad)
+    for (n1, b1), (n2, b2) in zip(ref.named_buffers(), new.named_buffers()):
+        if "num_batches" not in n1:
+            close(b2, b1, 1e-5)
 
 
 @pytest.mark.parametrize("E,cin,dims,C2,p", [(5000, 256, [128, 128], 21, 0.5), (70001, 128, [128], 21, 0.5),
