@@ -107,6 +107,17 @@ def geo_features(neighbors, centers_xyz):
     return geo_vec, geo_dist, att_vec
 
 
+class Tail:
+    """What directly follows a GridConv block in the CALLER (the segmentation head behind the last
+    up layer): conv+BN+ReLU `layers` that may join the block's update chain, and optionally the
+    Dropout + class-score Linear behind them, head = (p, nn.Linear, seed_dev | None).  A per-call
+    request object: finish() reports in `done` what it absorbed (0 nothing, 1 the layers, 2 the
+    head as well) -- the module itself keeps no per-call state."""
+
+    def __init__(self, layers=(), head=None):
+        self.layers, self.head, self.done = tuple(layers), head, 0
+
+
 class SubGUpdate(nn.Module):
     """sub_g_update for aggtype='gcn', pool 'max_pooling', attfdim=10 (the shipped seg configs).
 
@@ -135,9 +146,6 @@ class SubGUpdate(nn.Module):
         self.out_channels = out_dim[-1] if len(out_dim) else agg_c
 
     mfma_train = True   # training on the GPU: MLPs through csrc/gridgcn_train.hip
-    tail_layers = ()    # ConvBNReLU layers of the caller that directly follow update_mlp (not owned)
-    tail_done = False   # set by finish(): the tail layers were applied (2: the tail head as well)
-    tail_head = None    # (dropout p, nn.Linear) of the caller that follows the tail layers
 
     def edge_inputs(self, neighbors, centers_xyz):
         geo_vec, _, att_vec = geo_features(neighbors, centers_xyz)
@@ -149,15 +157,15 @@ class SubGUpdate(nn.Module):
             nf = neighbors[..., 4:]
         return nf, att_vec
 
-    def forward(self, centers_xyz, neighbors, center_masks=None, center_ori_feats=None):
+    def forward(self, centers_xyz, neighbors, center_masks=None, center_ori_feats=None, tail=None):
         """centers_xyz [B,O,3], neighbors [B,O,P,4+C] (already gathered), center_masks [B,O]|None,
         center_ori_feats [B,O,Cc]|None  ->  [B,O,out_channels]."""
         nf, att_vec = self.edge_inputs(neighbors, centers_xyz)
         pair = self.att2(self.att1(att_vec)) * self.pt_mlp(nf)             # :135-167
         agg = pair.max(dim=2).values                                       # :57-59 (unmasked, F10)
-        return self.finish(agg, center_masks, center_ori_feats)
+        return self.finish(agg, center_masks, center_ori_feats, tail=tail)
 
-    def forward_src(self, cent, src, nebidx, center_masks=None, center_ori_feats=None):
+    def forward_src(self, cent, src, nebidx, center_masks=None, center_ori_feats=None, tail=None):
         """Training path on the GPU: the edge inputs (gather + geo features + concat) come from
         one HIP kernel (ops.edge_inputs, scatter-add backward); the MLPs with batch-statistics
         BatchNorm are stock PyTorch ops."""
@@ -180,7 +188,7 @@ class SubGUpdate(nn.Module):
                     out = train_ops.alias_columns(buf, ccf, C)
                 agg = train_ops.edge_block_src_train(src, nebidx, cent.contiguous(), pt_layers,
                                                      att_layers, self.localfdim, out=out)
-                return self.finish(agg, center_masks, center_ori_feats, buf=buf)
+                return self.finish(agg, center_masks, center_ori_feats, buf=buf, tail=tail)
             if train_ops.edge_block_supported(pt_layers, att_layers, src) and \
                     ops.edge_inputs_rows_supported(src, self.has_feats):
                 # rows laid out for the MFMA kernels (features | geo_vec | zero padding)
@@ -188,18 +196,18 @@ class SubGUpdate(nn.Module):
                                                       has_feats=self.has_feats,
                                                       localfdim=self.localfdim)
                 agg = train_ops.edge_block_train(nf, att16, pt_layers, att_layers, rot)
-                return self.finish(agg, center_masks, center_ori_feats)
+                return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         nf, att_vec = ops.edge_inputs(src, nebidx, cent.contiguous(),
                                       has_feats=self.has_feats, localfdim=self.localfdim)
         if self.mfma_train and self.training and torch.is_grad_enabled():
             from . import train_ops
             if train_ops.edge_block_supported(pt_layers, att_layers, nf):
                 agg = train_ops.edge_block_train(nf, att_vec, pt_layers, att_layers)
-                return self.finish(agg, center_masks, center_ori_feats)
+                return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         pair = run_mlp(att_layers, att_vec, self.mfma_train) * \
             run_mlp(pt_layers, nf, self.mfma_train)
         agg = pair.max(dim=2).values
-        return self.finish(agg, center_masks, center_ori_feats)
+        return self.finish(agg, center_masks, center_ori_feats, tail=tail)
 
     def packed_layers(self):
         """BatchNorm-folded, padded weights for the fused kernel (cached; eval mode only)."""
@@ -227,7 +235,7 @@ class SubGUpdate(nn.Module):
             self._packed_key = key
         return self._packed
 
-    def forward_fused(self, cent, src, nebidx, center_masks=None, center_ori_feats=None):
+    def forward_fused(self, cent, src, nebidx, center_masks=None, center_ori_feats=None, tail=None):
         """Inference path through the hand-written gfx950 kernel (csrc/gridgcn_conv.hip):
         src [B,Nsrc,4+C] (NOT gathered), nebidx [B,O,P], cent [B,O,>=3]."""
         from . import ops
@@ -249,16 +257,16 @@ class SubGUpdate(nn.Module):
                                               out=train_ops.alias_columns(buf, ccf, C))
                 train_ops.mlp_bn_relu_eval(center_ori_feats, list(self.center_mlp),
                                            out=train_ops.alias_columns(buf, 0, ccf))
-                return self.finish(buf.view(B, O, ccf + C), center_masks, None)
+                return self.finish(buf.view(B, O, ccf + C), center_masks, None, tail=tail)
             agg = train_ops.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
                                                 att_layers, self.localfdim)
-            return self.finish(agg, center_masks, center_ori_feats)
+            return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         pt, att = self.packed_layers()
         agg = ops.gridconv_forward(src.contiguous(), nebidx, cent.contiguous(), pt, att,
                                    has_feats=self.has_feats, localfdim=self.localfdim)
-        return self.finish(agg, center_masks, center_ori_feats)
+        return self.finish(agg, center_masks, center_ori_feats, tail=tail)
 
-    def finish(self, agg, center_masks, center_ori_feats, buf=None):
+    def finish(self, agg, center_masks, center_ori_feats, buf=None, tail=None):
         if center_ori_feats is not None and buf is not None:
             # `agg` already sits in the right half of buf; the centre MLP writes the left half
             from . import train_ops
@@ -273,30 +281,29 @@ class SubGUpdate(nn.Module):
             agg = torch.cat([cf, agg], dim=-1)                             # up_center_inte=concat
         if self.relu:
             agg = F.relu(agg)                                              # update_func :31-32
-        self.tail_done = False
         if self.update_mlp is not None:
             layers = list(self.update_mlp)
-            if self.tail_layers and center_masks is None:
+            if tail is not None and tail.layers and center_masks is None:
                 # conv+BN+ReLU layers that directly follow this block (the head's fc1 after the last
                 # up layer) join the same chain: one activation pass and one reduce pass less
-                layers += list(self.tail_layers)
-                self.tail_done = True
-                if self.tail_head is not None and self.mfma_train and agg.is_cuda and \
+                layers += list(tail.layers)
+                tail.done = 1
+                if tail.head is not None and self.mfma_train and agg.is_cuda and \
                         self.training and torch.is_grad_enabled():
                     from . import train_ops
-                    p, lin = self.tail_head[:2]
+                    p, lin = tail.head[:2]
                     if train_ops.head_supported(agg, layers, lin):
                         # ... and the Dropout + class-score Linear behind them (train_ops._HeadTrain)
-                        self.tail_done = 2
-                        seed_dev = self.tail_head[2] if len(self.tail_head) > 2 else None
+                        tail.done = 2
+                        seed_dev = tail.head[2] if len(tail.head) > 2 else None
                         return train_ops.head_train(agg, layers, p, lin, seed_dev=seed_dev)
-                if self.tail_head is not None and self.mfma_train and agg.is_cuda and \
+                if tail.head is not None and self.mfma_train and agg.is_cuda and \
                         not self.training and not torch.is_grad_enabled():
                     from . import train_ops
-                    p, lin = self.tail_head[:2]
+                    p, lin = tail.head[:2]
                     if train_ops.head_supported(agg, layers, lin) and \
                             all(l.lin.in_features <= 1024 for l in layers):
-                        self.tail_done = 2              # evaluation: dropout is the identity
+                        tail.done = 2                   # evaluation: dropout is the identity
                         return train_ops.head_eval(agg, layers, lin)
             agg = run_mlp(layers, agg, self.mfma_train)
         if center_masks is not None:

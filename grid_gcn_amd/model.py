@@ -94,7 +94,6 @@ class GGCNSeg(nn.Module):
         # get_seg_head (:30-43)
         self.fc1 = ConvBNReLU(last_c, 128, cfg["bn_decay"])
         # fc1 directly follows the last up layer's update MLP: one conv+BN+ReLU chain (see finish())
-        object.__setattr__(self.up[-1], "tail_layers", (self.fc1,))
         self.fc2 = nn.Linear(128, cfg["num_classes"])
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
@@ -149,8 +148,9 @@ class GGCNSeg(nn.Module):
             locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
         f_last = feats[-1]
         nup = len(self.up)
-        object.__setattr__(self.up[-1], "tail_head",
-                           (cfg["dropout"], self.fc2, self.seed_dev) if self.fused_head else None)
+        # what follows the last up layer (fc1, dropout, fc2): offered to that layer's chain per call
+        from .gridconv import Tail
+        tail = Tail((self.fc1,), (cfg["dropout"], self.fc2, self.seed_dev) if self.fused_head else None)
         for i, layer in enumerate(self.up):
             down, upl = locs[-i - 1], locs[-i - 2]
             downnum, upnum = nums[-i - 1], nums[-i - 2]
@@ -170,17 +170,21 @@ class GGCNSeg(nn.Module):
             if self.use_fused():
                 if self.jobs is not None:
                     self.jobs.append(("up%d" % i, layer, upl, f_last, nebidx))
-                cf = layer.forward_fused(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
+                cf = layer.forward_fused(upl, f_last, nebidx, cmask, center_ori_feats=f_this,
+                                         tail=tail if i == nup - 1 else None)
             elif _is_hip(self.ix) and self.edge_kernel:
-                cf = layer.forward_src(upl, f_last, nebidx, cmask, center_ori_feats=f_this)
+                cf = layer.forward_src(upl, f_last, nebidx, cmask, center_ori_feats=f_this,
+                                       tail=tail if i == nup - 1 else None)
             else:
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx, **self._take_kw)  # :217-218
-                cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this)  # :229
+                cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this,
+                           tail=tail if i == nup - 1 else None)                       # :229
             if i != nup - 1:                      # (the last layer's features go to the head only)
                 f_last = torch.cat([upl, cf], dim=2)                                # :231
-        if self.up[-1].tail_done == 2:            # fc1, dropout and fc2 ran inside the last up layer
+        self.last_tail_done = tail.done           # (introspection only: which head path ran)
+        if tail.done == 2:                        # fc1, dropout and fc2 ran inside the last up layer
             return cf
-        net = cf if self.up[-1].tail_done else run_mlp([self.fc1], cf)
+        net = cf if tail.done else run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
         if HEAD_KERNELS and self.training and torch.is_grad_enabled() and _is_hip(self.ix):
             from . import train_ops

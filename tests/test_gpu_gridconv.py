@@ -210,13 +210,13 @@ def test_full_model_eval_fused_vs_torch():
     with torch.no_grad():
         net.fused = True
         a = net(x, n)
-        assert net.up[-1].tail_done == 2             # head through the hand-written kernels too
+        assert net.last_tail_done == 2             # head through the hand-written kernels too
         # reference: stock PyTorch modules everywhere (index ops shared)
         net.fused = False
         for l in list(net.down) + list(net.up):
             l.mfma_train = False
         b = net(x, n)
-        assert net.up[-1].tail_done != 2
+        assert net.last_tail_done != 2
     scale = max(1.0, float(b.abs().max()))
     assert float((a - b).abs().max()) <= 2e-4 * scale   # 12 stacked layers of fp32 round-off
 
@@ -249,7 +249,7 @@ def test_seg_model_with_gridify_knn_matches_cpu_oracle_model():
     loss_cpu = model.seg_loss(net_cpu(x, n), lab)
     loss_gpu = model.seg_loss(net_gpu(x.to(DEV), n.to(DEV)), lab.to(DEV))
     loss_gpu.backward()
-    assert net_gpu.up[-1].tail_done == 2                      # the HIP training path ran
+    assert net_gpu.last_tail_done == 2                      # the HIP training path ran
     assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu)))
 
 

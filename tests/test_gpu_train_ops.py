@@ -372,7 +372,7 @@ def test_head_in_model_matches_unfused_head_without_dropout():
         net.zero_grad(set_to_none=True)
         net.fused_head = fused
         logits = net(x, n)
-        assert (net.up[-1].tail_done == 2) == fused
+        assert (net.last_tail_done == 2) == fused
         loss = model.seg_loss(logits, lab)
         loss.backward()
         out.append((logits.detach().clone(), float(loss),
