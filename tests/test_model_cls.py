@@ -68,7 +68,7 @@ def test_cls_training_step_mfma_kernels_match_stock_modules():
     assert abs(res[0][0] - res[1][0]) < 1e-4 * max(1.0, abs(res[1][0]))
     # this net is discretely sensitive at fp32 round-off (max-pool arg-max over 128 padded
     # neighbours, BatchNorm over 8 rows in the head): perturbing the INPUT of the stock path by 1e-7
-    # already moves single weight gradients by ~1e-2 of their scale (tools/dbg_cls.py), so the
+    # already moves single weight gradients by ~1e-2 of their scale, so the
     # two paths are compared as vectors
     a, b = res[0][1].double(), res[1][1].double()
     cos = float((a * b).sum() / (a.norm() * b.norm()))
