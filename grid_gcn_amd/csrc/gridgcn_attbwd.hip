@@ -39,8 +39,11 @@ __device__ __forceinline__ float gg_af_f4(const float4 &v, int i)
 }
 
 // NJ = C / 32 (2 or 4).  cin == ndx in {16, 32}, previous layer's BatchNorm given, C % 64 == 0.
-template <int NJ, bool BF16 = false>
-__global__ __launch_bounds__(256) void gg_k_att_bwd_fused(GGLinBwd p)
+// (second launch bound = waves per SIMD: the 64-channel form fits three -- 167 registers, no spills,
+//  1.63 -> 1.23 ms on 8.4 M edges; the 128-channel form needs 247 registers and stays at two: forced
+//  to three it spills 66 and gains nothing)
+template <int NJ, bool BF16>
+__global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLinBwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,11 +296,12 @@ __global__ __launch_bounds__(1024) void gg_k_att_dw_reduce(const float *__restri
     }
 }
 
-static int gg_att_fused_grid(long long E)
+static int gg_att_fused_grid(long long E, int C = 128)
 {
     const long long ntile = (E + 31) >> 5;
     long long nb = (ntile + 3) / 4;
-    if (nb > 256 * 3) nb = 256 * 3;
+    const int per_cu = 3;
+    if (nb > 256 * per_cu) nb = 256 * per_cu;
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -310,7 +314,7 @@ bool gg_att_bwd_fused_ok(long long E, int cin, int C)
 size_t gg_att_bwd_fused_workspace(long long E, int cin, int C)
 {
     if (!gg_att_bwd_fused_ok(E, cin, C)) return 0;
-    return (size_t)gg_att_fused_grid(E) * (C / 32) * 1024 * sizeof(float);
+    return (size_t)gg_att_fused_grid(E, C) * (C / 32) * 1024 * sizeof(float);
 }
 
 template <int NJ>
@@ -324,7 +328,7 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
     }
     const int C = NJ * 32;
     const size_t lds = ((size_t)C * 32 + 5 * C + 4 * 32 * GG_AF_TS) * sizeof(float);
-    const int grid = gg_att_fused_grid(p.E);
+    const int grid = gg_att_fused_grid(p.E, C);
     if (gg_get_mlp_bf16()) gg_k_att_bwd_fused<NJ, true><<<grid, 256, lds, st>>>(p);
     else gg_k_att_bwd_fused<NJ, false><<<grid, 256, lds, st>>>(p);
     if (hipGetLastError() != hipSuccess) return 3;
