@@ -379,6 +379,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
     float *Wl = lds;                              // [C/2 steps][64][NTV]
     const int ng8 = (C / 2 + 7) >> 3;             // bf16: groups of 8 steps, 16 bytes per entry
     float *cst = lds + (BF16 ? ng8 * 64 * NTV * 4 : C * 32 * NTV);   // scale, shift, mean, bz, cz  [5][C]
+    float *pcs = cst + 5 * C;          // previous layer: scale, shift, mean, rstd  [4][NT*32] (0 beyond ndx)
     {
         if (BF16) {
             gg_stage_w_bf16<NTV>((ggm_u32x4 *)Wl, p.Wdx, C / 2, tid, blockDim.x);
@@ -396,18 +397,22 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             cst[3 * C + c] = -(sc * p.rstd[c]) * p.m2[c];
             cst[4 * C + c] = -(sc * p.m1[c]);
         }
+        // (kept in LDS, not in 4*NT registers per lane: the 8-tile form spilled 70 of them)
+        const bool pb = p.pscale != nullptr;
+        for (int c = tid; c < NT * 32; c += blockDim.x) {
+            const int col = p.dx_col0 + c;
+            const bool ok = pb && col < p.ndx;
+            pcs[c] = ok ? p.pscale[col] : 0.f;
+            pcs[NT * 32 + c] = ok ? p.pshift[col] : 0.f;
+            pcs[2 * NT * 32 + c] = ok ? p.pmean[col] : 0.f;
+            pcs[3 * NT * 32 + c] = ok ? p.prstd[col] : 0.f;
+        }
     }
     __syncthreads();
     const bool prevbn = p.pscale != nullptr;
-    float a1[NT], a2[NT], ps[NT], psh[NT], pm[NT], pr[NT];
+    float a1[NT], a2[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        a1[t] = 0.f; a2[t] = 0.f;
-        const int col = p.dx_col0 + t * 32 + (lane & 31);
-        const bool ok = prevbn && col < p.ndx;
-        ps[t] = ok ? p.pscale[col] : 0.f; psh[t] = ok ? p.pshift[col] : 0.f;
-        pm[t] = ok ? p.pmean[col] : 0.f;  pr[t] = ok ? p.prstd[col] : 0.f;
-    }
+    for (int t = 0; t < NT; t++) { a1[t] = 0.f; a2[t] = 0.f; }
     const long long ntile = (p.E + 31) >> 5;
     const int nfull = C >> 5, ktail = C & 31;
     const bool sparse = p.amax != nullptr;
@@ -534,6 +539,9 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         for (int t = 0; t < NT; t++) {
             if (p.dx_col0 + t * 32 + (lane & 31) < p.ndx) {
                 float s1 = 0.f, s2 = 0.f;
+                const int pc = t * 32 + (lane & 31);
+                const float ps_t = pcs[pc], psh_t = pcs[NT * 32 + pc], pm_t = pcs[2 * NT * 32 + pc],
+                            pr_t = pcs[3 * NT * 32 + pc];
                 // all 16 loads of the previous layer's raw output first: dX and Aprev may alias as
                 // far as the compiler knows, so loads placed between the stores were serialised
                 float zpv[16];
@@ -556,9 +564,9 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                         xp[off] = dx;
                         if (prevbn) {
                             const float zp = zpv[r];
-                            const float d = (zp * ps[t] + psh[t] > 0.f) ? dx : 0.f;
+                            const float d = (zp * ps_t + psh_t > 0.f) ? dx : 0.f;
                             s1 += d;
-                            s2 += d * ((zp - pm[t]) * pr[t]);
+                            s2 += d * ((zp - pm_t) * pr_t);
                         }
                     }
                 }
@@ -604,8 +612,8 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     // that three of them fit a CU (with 8-wave workgroups only one did)
     const int threads = NT <= 2 ? 256 : 512, nw = threads / 64;
     const bool bf16 = g_mlp_bf16 != 0;
-    size_t lds = bf16 ? (size_t)((p.C / 2 + 7) / 8) * 64 * NTV * 16 + 5 * (size_t)p.C * 4
-                      : ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4;
+    size_t lds = (bf16 ? (size_t)((p.C / 2 + 7) / 8) * 64 * NTV * 16 + 5 * (size_t)p.C * 4
+                       : ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4) + (size_t)4 * NT * 32 * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     if (lds < rbytes) lds = rbytes;
     if (lds > 156 * 1024) {
