@@ -45,7 +45,7 @@ def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step):
         workload = ("BASELINE configs[1]: ModelNet40 %d-pt classifier (3 Gridify + GridConv layers, "
                     "FC head), batch %d per GPU, Adam, fp32" % (N, B))
         metric = "point-clouds/sec fwd+bwd (ModelNet40 1024-pt classifier)"
-        flops = None
+        flops = 3.0 * model_cls.cls_forward_flops(net, B)
     elif a.config in ("cfg3", "cfg3up"):
         B, N = a.batch or 16, a.points or 8192
         cfg = dict(model.SEG_8192, up_neigh_fetch=(a.config == "cfg3"))

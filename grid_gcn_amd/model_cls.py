@@ -157,3 +157,21 @@ def cls_loss(logits, label, weights=None):
         logits = WeightedGradient.apply(logits, torch.as_tensor(weights, dtype=logits.dtype,
                                                                 device=logits.device))
     return F.cross_entropy(logits, label.long(), reduction="mean")
+
+
+def cls_forward_flops(net, B):
+    """Algorithmic flops of one forward of GGCNCls on B clouds: 2 * edges *
+    sum(Cin*Cout) over the pt / att1 / att2 convs of every layer (the att2 input counts its full
+    concat width, as the reference computes it) + the FC head."""
+    g = net.cfg["grid"]
+    fl = 0.0
+    for i, layer in enumerate(net.layers):
+        L = g["down"][i]
+        e = B * L["max_o_grid"] * L["max_p_grid"]
+        macs = sum(m.lin.in_features * m.lin.out_features
+                   for seq in (layer.pt_mlp, layer.att1, layer.att2) for m in seq)
+        fl += 2.0 * e * macs
+    head = (net.fc1.l.lin.in_features * net.fc1.l.lin.out_features +
+            net.fc2.l.lin.in_features * net.fc2.l.lin.out_features +
+            net.fc3.in_features * net.fc3.out_features)
+    return fl + 2.0 * B * head
