@@ -35,6 +35,7 @@ EXPORTS = [
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
     "gridgcn_linear_fwd_direct2", "gridgcn_ctx_max", "gridgcn_ctx_max_backward",
     "gridgcn_bn_dz_segsum", "gridgcn_sparse_add", "gridgcn_bn_stats",
+    "gridgcn_att_max_train", "gridgcn_att_bwd_recomp",
 ]
 
 
@@ -153,6 +154,11 @@ def load():
     lib.gridgcn_ctx_max_backward.argtypes = [vp, vp, ll, ci, ci, vp, vp]
     lib.gridgcn_bn_dz_segsum.restype = ci
     lib.gridgcn_bn_dz_segsum.argtypes = [vp] * 8 + [ll, ci, ci, vp, vp]
+    lib.gridgcn_att_max_train.restype = ci
+    lib.gridgcn_att_max_train.argtypes = [vp] * 14 + [ci] * 6 + [vp, ci, vp, vp, vp]
+    lib.gridgcn_att_bwd_recomp.restype = ci
+    lib.gridgcn_att_bwd_recomp.argtypes = [vp] * 15 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, cs,
+                                           vp]
     lib.gridgcn_bn_stats.restype = ci
     lib.gridgcn_bn_stats.argtypes = [vp, ll, ci, ci, vp, vp]
     lib.gridgcn_sparse_add.restype = ci

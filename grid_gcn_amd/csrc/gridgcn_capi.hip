@@ -393,6 +393,31 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_att_bwd_recomp(const float *dY, const float *scale, const float *shift, const float *mean,
+                           const float *rstd, const float *m1, const float *m2, const float *Z1,
+                           const float *pscale, const float *pshift, const float *pmean,
+                           const float *prstd, const float *W2, const float *b2, const float *Wdx,
+                           long long E, int C, int cin, int ldy, float *dX, float *dW,
+                           double *psums, const uint8_t *amax, const float *gval, int P,
+                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (amax && (!gval || P < 1 || E % P != 0)) return GRIDGCN_EINVAL;
+    if ((!dY && !amax) || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Z1 || !pscale ||
+        !pshift || !pmean || !prstd || !W2 || !b2 || !Wdx || !dX || !dW || !psums)
+        return GRIDGCN_EINVAL;
+    const size_t need = gg_att_bwd_fused_workspace(E, cin, C);
+    if (!need) return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < need) return GRIDGCN_EWORKSPACE;
+    GGLinBwd p = {};
+    p.dY = dY; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.m1 = m1; p.m2 = m2;
+    p.Aprev = Z1; p.pscale = pscale; p.pshift = pshift; p.pmean = pmean; p.prstd = prstd;
+    p.Wdx = Wdx; p.ndx = cin; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW; p.psums = psums;
+    p.E = E; p.C = C; p.cin = cin; p.cin_w = cin; p.rot = 0; p.amax = amax; p.gval = gval;
+    p.P = P > 0 ? P : 1; p.ldy = (dY && !amax && ldy > 0) ? ldy : C;
+    const int rc = gg_att_bwd_recomp(p, W2, b2, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const float *shift,
                       const float *mean, const float *rstd, const float *m1, const float *m2,
                       const float *Aprev, const float *pscale, const float *pshift,
@@ -515,7 +540,7 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream)
 {
-    if (!X || !Wq || !b || !Z || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
+    if (!X || !Wq || !b || (!Z && !sums) || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
         (ldx & 3) || ((uintptr_t)X & 15))
         return GRIDGCN_EINVAL;
     GGLinFwd p;
@@ -764,6 +789,26 @@ int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shif
     p.hp = shift_p; p.out = agg; p.E = (long long)B * O * P; p.P = P; p.O = O; p.Nsrc = Nsrc;
     p.B = B; p.ldo = ld_agg;
     const int rc = gg_att_max_eval(p, C, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_att_max_train(const float *Z1, const float *scale1, const float *shift1, const float *W2,
+                          const float *b2, const float *scale_a, const float *shift_a,
+                          const float *Ysrc, const int32_t *nebidx, const float *att16,
+                          const float *Wg, const float *b, const float *scale_p,
+                          const float *shift_p, int B, int Nsrc, int O, int P, int C, int cin,
+                          float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream)
+{
+    if (!Z1 || !scale1 || !shift1 || !W2 || !b2 || !scale_a || !shift_a || !Ysrc || !nebidx ||
+        !att16 || !b || !scale_p || !shift_p || !agg || !amax || !zsel || B < 1 || Nsrc < 1 ||
+        O < 1 || P < 1 || ld_agg < C)
+        return GRIDGCN_EINVAL;
+    GGAttEval p;
+    p.Z1 = Z1; p.s1 = scale1; p.h1 = shift1; p.W2 = W2; p.b2 = b2; p.sa = scale_a; p.ha = shift_a;
+    p.Ysrc = Ysrc; p.nebidx = nebidx; p.att16 = att16; p.Wg = Wg; p.bp = b; p.sp = scale_p;
+    p.hp = shift_p; p.out = agg; p.E = (long long)B * O * P; p.P = P; p.O = O; p.Nsrc = Nsrc;
+    p.B = B; p.ldo = ld_agg;
+    const int rc = gg_att_max_train(p, C, cin, amax, zsel, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

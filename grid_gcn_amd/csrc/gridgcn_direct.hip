@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const float z = acc[t][r] + bias[t];
-                        zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;
+                        if (p.Z) zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;   // (nullptr: statistics only)
                         sm += z;
                         sq += z * z;
                     }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(G
                 for (int r = 0; r < 16; r++) {
                     const float z = acc[t][r] + bias[t];
                     if ((EXACT || t * 32 + (lane & 31) < p.cout) && ggm_row(r, lane) < nrows) {
-                        zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;
+                        if (p.Z) zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;
                         sm += z;
                         sq += z * z;
                     }

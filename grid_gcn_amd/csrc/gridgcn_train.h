@@ -71,6 +71,8 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st);
 size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shape not supported
 int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st);       // gridgcn_attbwd.hip; 1 = other shape
 size_t gg_att_bwd_fused_workspace(long long E, int cin, int C);
+// the same backward with the layer's pre-activation recomputed from Aprev (Z is not read)
+int gg_att_bwd_recomp(const GGLinBwd &p, const float *W2, const float *b2, hipStream_t st);
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,

@@ -47,6 +47,12 @@ SRC_FIRST_CONV = os.environ.get("GG_EDGE_GEMM", "0") != "1"
 NO_Z0 = os.environ.get("GG_STORE_Z0", "0") != "1"
 # ... and its backward reduced to the sparse arg-max entries (gg_k_edge_lin0_bwd_sparse)
 SPARSE_L0 = os.environ.get("GG_SORTED_L0", "0") != "1"
+# ... optionally (GG_NO_Z2=1) with the [E, C] pre-activation of the second attention conv never
+# written either: the forward folds that conv into the max kernel (gg_k_att_max_train), the backward
+# recomputes it (gg_k_att_bwd_recomp).  Correct (tests run both), 1.7 GB less traffic per step at
+# cfg4 -- and slower: 0.32 + 1.92 + 1.94 ms against 0.50 + 0.74 + 1.30 ms for the stored form (DESIGN
+# section 3.5, dead ends), so the stored form is the default.
+NO_Z2 = os.environ.get("GG_NO_Z2", "0") == "1"
 
 
 
@@ -841,15 +847,60 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             else:
                 sp = _Chain()
                 Zl, scl, shl = Z0, vec0[0], vec0[1]
-            sa = _chain_forward(lib, att16, params[4 * Lp:], bns_a, eps)
-            C = sa.Z[-1].shape[1]
+            pa = params[4 * Lp:]
+            C = pa[4 * (La - 1)].shape[0]
+            A0 = pa[0].shape[0]
             ncent = B * O
             agg = out if out is not None else torch.empty((ncent, C), dtype=torch.float32,
                                                            device=dev)
             lda = agg.stride(0)
             amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
-            if noz:
+            noz2 = (noz and NO_Z2 and La == 2 and A0 in (16, 32) and C in (64, 128) and P <= 255
+                    and lda % 4 == 0 and not lib.gridgcn_get_mlp_precision())
+            if noz2:
+                # second attention conv: statistics from a store-less pass of the forward kernel,
+                # the conv itself inside the max kernel -- its [E, C] output is never written
+                sa = _chain_forward(lib, att16, pa[:4], bns_a[:1], eps)
+                Z1 = sa.Z[0]
+                W2, b2, g2, be2 = pa[4:8]
+                W2c, b2c = W2.detach().contiguous(), b2.detach().contiguous()
+                _, ldw, _, _ = packed_sizes(C, A0)
+                pk2 = torch.empty(ldw + A0 * ldw + C * 32, dtype=torch.float32, device=dev)
+                Bp2, Wq2, Wdx2 = pk2[:ldw], pk2[ldw:ldw + A0 * ldw], pk2[ldw + A0 * ldw:]
+                rc = lib.gridgcn_pack_linear(_ptr(W2c), _ptr(b2c), C, A0, 0, A0, A0, None, _ptr(Bp2),
+                                             None, None, _ptr(Wq2), _ptr(Wdx2), st)
+                _lib.check(rc, "gridgcn_pack_linear")
+                sums2 = _zeros(2 * C, torch.float64, dev)
+                rc = lib.gridgcn_linear_fwd_direct(_ptr(Z1), E, A0, A0, _ptr(Wq2), _ptr(Bp2), ldw, C,
+                                                   _ptr(sa.scale[0]), _ptr(sa.shift[0]), None,
+                                                   _ptr(sums2), st)
+                _lib.check(rc, "gridgcn_linear_fwd_direct")
+                vec2 = torch.empty((4, C), dtype=torch.float32, device=dev)
+                bn = bns_a[1]
+                track = bn.track_running_stats
+                rc = lib.gridgcn_bn_finalize(
+                    _ptr(sums2), _ptr(g2.detach()), _ptr(be2.detach()), E, eps,
+                    _momentum(bn) if track else 0.0, C, _ptr(vec2[0]), _ptr(vec2[1]), _ptr(vec2[2]),
+                    _ptr(vec2[3]), _ptr(bn.running_mean) if track else None,
+                    _ptr(bn.running_var) if track else None,
+                    _ptr(bn.num_batches_tracked) if track else None, st)
+                _lib.check(rc, "gridgcn_bn_finalize")
+                rc = lib.gridgcn_att_max_train(
+                    _ptr(Z1), _ptr(sa.scale[0]), _ptr(sa.shift[0]), _ptr(W2c), _ptr(b2c),
+                    _ptr(vec2[0]), _ptr(vec2[1]), _ptr(Ysrc), _ptr(nebidx), _ptr(att16),
+                    _ptr(Wg) if geo else None, _ptr(wgb[3]), _ptr(scl), _ptr(shl), B, Nsrc, O, P, C,
+                    A0, _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
+                _lib.check(rc, "gridgcn_att_max_train")
+                # the backward's view of the attention chain: layer 0 as usual, layer 1 Z-less
+                sa.Z.append(W2c); sa.scale.append(vec2[0]); sa.shift.append(vec2[1])
+                sa.mean.append(vec2[2]); sa.rstd.append(vec2[3])
+                sa.Wb.append(b2c); sa.Wg.append(b2c); sa.Wdx.append(Wdx2); sa.ndx.append(A0)
+            else:
+                sa = _chain_forward(lib, att16, pa, bns_a, eps)
+            if noz2:
+                pass
+            elif noz:
                 rc = lib.gridgcn_pairmax_fwd_src(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
                     B, Nsrc, O, _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl), _ptr(sa.scale[-1]),
@@ -859,6 +910,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                                              _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
                                              _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_fwd")
+        ctx.noz2 = noz2
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.save_for_backward(
@@ -887,7 +939,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         Zl = pZ[-1] if L1 else Z0
         lS, lH, lM, lR = (pS[-1], pH[-1], pM[-1], pR[-1]) if L1 else (vec0[0], vec0[1], vec0[2],
                                                                         vec0[3])
-        C = aZ[-1].shape[1]
+        C = amax.shape[1]
         if not (dagg.dim() == 2 and dagg.stride(1) == 1):       # (a concat half: used in place)
             dagg = dagg.contiguous().reshape(ncent, C)
         with torch.cuda.device(dev):
@@ -897,15 +949,41 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             sums_pa = _zeros((2, 2 * C), torch.float64, dev)
             sums_p, sums_a = sums_pa[0], sums_pa[1]
             # (the arg-max pre-activations come from zsel: Zl may not exist)
-            rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None, _ptr(aZ[-1]),
+            rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None,
+                                         None if ctx.noz2 else _ptr(aZ[-1]),
                                          _ptr(lS), _ptr(lH), _ptr(lM),
                                          _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
                                          _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C,
                                          dagg.stride(0), _ptr(gp),
                                          _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_bwd")
-            _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1],
-                                         sums_a, None, (amax, ga, P), False, cwa, 0)
+            if ctx.noz2:
+                # second attention conv without its stored output: aZ[1] holds W2, aWb[1] b2
+                Z1, W2c, b2c, Wdx2 = aZ[0], aZ[1], aWb[1], aWx[1]
+                A0 = Z1.shape[1]
+                v2 = torch.empty((4, C), dtype=torch.float32, device=dev)
+                rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums_a), E, C, _ptr(v2[0]), _ptr(v2[1]),
+                                                 _ptr(v2[2]), _ptr(v2[3]), st)
+                _lib.check(rc, "gridgcn_bn_bwd_finalize")
+                dX1 = torch.empty((E, A0), dtype=torch.float32, device=dev)
+                dW2 = torch.empty((C, A0), dtype=torch.float32, device=dev)
+                ps1 = _zeros(2 * A0, torch.float64, dev)
+                nbytes = ctypes.c_size_t(0)
+                lib.gridgcn_linear_bwd_workspace_bytes(E, A0, C, ctypes.byref(nbytes))
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                rc = lib.gridgcn_att_bwd_recomp(
+                    None, _ptr(aS[1]), _ptr(aH[1]), _ptr(aM[1]), _ptr(aR[1]), _ptr(v2[0]),
+                    _ptr(v2[1]), _ptr(Z1), _ptr(aS[0]), _ptr(aH[0]), _ptr(aM[0]), _ptr(aR[0]),
+                    _ptr(W2c), _ptr(b2c), _ptr(Wdx2), E, C, A0, 0, _ptr(dX1), _ptr(dW2), _ptr(ps1),
+                    _ptr(amax), _ptr(ga), P, _ptr(ws), nbytes.value, st)
+                _lib.check(rc, "gridgcn_att_bwd_recomp")
+                _, g1 = _chain_backward(lib, att16, aZ[:1], aS[:1], aH[:1], aM[:1], aR[:1], aWb[:1],
+                                        aWg[:1], aWx[:1], ctx.ndx[1][:1], ps1, dX1, None, False, cwa,
+                                        0)
+                grads_a = list(g1) + [dW2, _zeros(C, torch.float32, dev), v2[2], v2[3]]
+            else:
+                _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx,
+                                             ctx.ndx[1], sums_a, None, (amax, ga, P), False, cwa, 0)
             if L1:
                 dY0, grads_rest, sums0 = _chain_backward(
                     lib, Z0, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0], sums_p, None,

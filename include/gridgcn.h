@@ -255,6 +255,30 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
  *                  * relu((W2[c,:] . relu(Z1[e,:]*scale1 + shift1) + b2[c]) * scale_a[c] + shift_a[c])
  * Z1[E,32] = raw output of the first attention conv, W2[C][32] (torch layout) / b2 the second one;
  * C = 64 or 128, P <= 8, agg[B*O][ld_agg].  The [E, C] attention tensor is never materialised. */
+/* Training form of the up layers' attention tail WITHOUT the [E, C] pre-activation of the second
+ * attention conv in memory (1.7 GB at cfg4's last up layer, formerly written once and read twice):
+ * gridgcn_att_max_train: as gridgcn_att_max_eval with batch-statistics BatchNorm vectors (those of
+ *   the second conv from a statistics-only gridgcn_linear_fwd_direct pass, Z = NULL); also writes the
+ *   arg-max neighbour amax[B*O][C] (one byte) and the two pre-activations at the arg max
+ *   zsel[2][B*O][C] (point branch, attention branch) for gridgcn_pairmax_bwd; Z1 rows of cin = 16
+ *   or 32 floats, W2 [C][cin].
+ * gridgcn_att_bwd_recomp: backward of that conv (dX [E][cin], dW [C][cin], BatchNorm-backward sums
+ *   psums of the first attention conv) with its pre-activation recomputed tile by tile from Z1 --
+ *   the arguments of gridgcn_linear_bwd minus Z, plus the conv's W2 [C][cin] / b2 [C]; cin in {16,
+ *   32}, C in {64, 128}; workspace as gridgcn_linear_bwd_workspace_bytes(E, cin, C). */
+int gridgcn_att_max_train(const float *Z1, const float *scale1, const float *shift1, const float *W2,
+                          const float *b2, const float *scale_a, const float *shift_a,
+                          const float *Ysrc, const int32_t *nebidx, const float *att16,
+                          const float *Wg, const float *b, const float *scale_p,
+                          const float *shift_p, int B, int Nsrc, int O, int P, int C, int cin,
+                          float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream);
+int gridgcn_att_bwd_recomp(const float *dY, const float *scale, const float *shift, const float *mean,
+                           const float *rstd, const float *m1, const float *m2, const float *Z1,
+                           const float *pscale, const float *pshift, const float *pmean,
+                           const float *prstd, const float *W2, const float *b2, const float *Wdx,
+                           long long E, int C, int cin, int ldy, float *dX, float *dW,
+                           double *psums, const uint8_t *amax, const float *gval, int P,
+                           void *workspace, size_t workspace_bytes, void *stream);
 int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shift1, const float *W2,
                          const float *b2, const float *scale_a, const float *shift_a,
                          const float *Ysrc, const int32_t *nebidx, const float *att16,
@@ -330,7 +354,8 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
 int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream);
-/* (ldx = row stride of X in floats, >= K, a multiple of 4, X 16-byte aligned; sums may be NULL.) */
+/* (ldx = row stride of X in floats, >= K, a multiple of 4, X 16-byte aligned; sums may be NULL;
+ *  Z may be NULL when sums is given: a statistics-only pass that stores nothing.) */
 /* ---- classification edge block (classification/models/gcn_module_g.py:64-114 verts_pair_func
  *      with att_full='next'; :212-223 contextvec_func) -----------------------------------------
  * The classifier's attention MLP reads concat(att1(att_vec), pt_mlp(nf), context) per edge; the

@@ -135,12 +135,17 @@ def test_edge_inputs_rows_layout(cin, lfd):
 
 @pytest.mark.parametrize("cin,lfd,dims,O,P", [(128, 3, [128], 700, 5), (64, 3, [64, 64, 128], 90, 12),
                                               (64, 0, [32, 64], 200, 7), (256, 3, [128], 300, 6),
-                                              (32, 3, [256], 64, 33)])
-def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P):
+                                              (32, 3, [256], 64, 33), (64, 3, [64], 100, 9),
+                                              (128, 0, [128], 2000, 5)])
+@pytest.mark.parametrize("no_z2", [False, True])
+def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P, no_z2, monkeypatch):
     """GridConv training forward/backward with the first pt conv applied to the SOURCE points and
-    gathered (train_ops.edge_block_src_train) == the stock modules on the gathered tensor."""
+    gathered (train_ops.edge_block_src_train) == the stock modules on the gathered tensor.
+    no_z2: the optional form that never writes the second attention conv's output
+    (gg_k_att_max_train / gg_k_att_bwd_recomp; taken by the single-layer 64- / 128-channel cases)."""
     import copy
     from grid_gcn_amd import train_ops
+    monkeypatch.setattr(train_ops, "NO_Z2", no_z2)
     torch.manual_seed(cin + lfd + O)
     gen = torch.Generator().manual_seed(cin + P)
     B, Nsrc = 3, 150
