@@ -549,7 +549,7 @@ static int gg_att_fused_grid(long long E, int C = 128)
 {
     const long long ntile = (E + 31) >> 5;
     long long nb = (ntile + 3) / 4;
-    const int per_cu = 3;
+    const int per_cu = C == 128 ? 2 : 3;   // resident workgroups per CU (registers): no late third wave of them
     if (nb > 256 * per_cu) nb = 256 * per_cu;
     return (int)(nb < 1 ? 1 : nb);
 }

@@ -300,7 +300,7 @@ int gg_att_max_eval(const GGAttEval &p, int C, hipStream_t st)
     if ((C != 64 && C != 128) || p.P < 1 || p.E < 1 || (p.E % p.P) || (p.ldo & 3)) return 1;
     const long long ntile = (p.E / p.P + 31) >> 5;
     long long nb = (ntile + 3) / 4;
-    if (nb > 256 * 8) nb = 256 * 8;
+    if (nb > 256 * 2) nb = 256 * 2;   // resident workgroups per CU at 216 / 236 registers
     if (C == 64) gg_k_att_max_eval<2><<<(int)nb, 256, 0, st>>>(p);
     else gg_k_att_max_eval<4><<<(int)nb, 256, 0, st>>>(p);
     return hipGetLastError() == hipSuccess ? 0 : 3;

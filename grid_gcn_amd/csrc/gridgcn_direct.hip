@@ -104,7 +104,7 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 // Z[E, cout] = act(X[E, K]) * W + b, batch statistics of Z in the epilogue.  K % 8 == 0, X row
 // stride K.  NT = ldw / 32 column tiles per wave (all of them: the wave owns full rows of Z).
 template <int NT, bool WLDS, bool EXACT, bool BF16 = false>
-__global__ __launch_bounds__(NT == 8 ? 512 : 1024) void gg_k_linear_fwd_direct(GGLinFwd p)
+__global__ __launch_bounds__(NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -310,7 +310,7 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
             if (hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
-    const int threads = NT == 8 ? 512 : 1024, nw = threads / 64;
+    const int threads = NT == 8 ? 512 : (NT == 4 ? 768 : 1024), nw = threads / 64;
     const size_t wbytes = (size_t)q.K * 32 * NT * 4, sbytes = (size_t)2 * q.K * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     const long long ntile = (q.E + 31) >> 5;
@@ -628,7 +628,10 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
         q.dx_col0 = 128;
         return launch_dx_direct<4>(q, st);
     }
-    int per_cu = NT <= 2 ? 3 : 2;
+    // workgroups that are RESIDENT per CU (registers: 162 at NT = 1 -> three 4-wave groups; 182 at
+    // NT = 2 -> two; > 128 for the 8-wave groups of NT >= 3 -> one): a grid beyond that runs a second,
+    // partly filled round (measured on the fused attention backward: 1.30 -> 1.06 ms)
+    int per_cu = NT == 1 ? 3 : (NT == 2 ? 2 : 1);
     while (per_cu > 1 && per_cu * lds > 152 * 1024) per_cu--;
     const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
