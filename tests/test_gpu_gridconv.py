@@ -539,3 +539,39 @@ def test_bench_rccl_capture_probe_runs():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver reads (metric, value, unit,
+    n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config)
+    plus roofline / cpu_baseline; value = clouds per second of the timed steps; traffic comes from
+    profiles/traffic.json or is null.  Run at the real cfg4 shape with few steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4",
+                        "--warmup", "2"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline", "roofline_step", "roofline_cagq", "ms_per_cagq_layer", "step_mode"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert "81920" in d["metric"] and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    tr = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert d["roofline_cagq"]["traffic"] in (None, tr.get("gridify_N81920_B8"))
