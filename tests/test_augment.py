@@ -76,3 +76,25 @@ def test_levels_keep_the_contract():
     ratio = (d9 / d0.clamp_min(1e-9))[:, 0, 1:]
     assert (ratio.max(dim=1).values - ratio.min(dim=1).values).max() < 1e-4
     assert ((ratio[:, 0] >= 0.8 - 1e-5) & (ratio[:, 0] <= 1.25 + 1e-5)).all()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_augmentation_runs_on_the_device():
+    """the whole pipeline on HBM-resident clouds: no host round trip, deterministic per generator"""
+    dev = "cuda:0"
+    x = torch.cat([T(PC), torch.ones(B, N, 1)], dim=2).to(dev)
+    outs = []
+    for _ in range(2):
+        g = torch.Generator(device=dev).manual_seed(3)
+        y = x
+        for level in (1, 3, 7):
+            y = augment.augment_batch(y, level=level, dropout_ratio=0.3, gen=g)
+        assert y.device.type == "cuda" and y.shape == x.shape and torch.isfinite(y).all()
+        assert torch.equal(y[..., 3], x[..., 3])              # the weight column is untouched
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    y = augment.shuffle_points(x, gen=torch.Generator(device=dev).manual_seed(1))
+    assert torch.equal(y.sort(dim=1).values, x.sort(dim=1).values)
