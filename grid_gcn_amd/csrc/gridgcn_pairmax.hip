@@ -60,6 +60,10 @@ struct GGPtRecompute {
     int Nsrc, O, B;
 };
 
+// PF > 0: the number of neighbours is the compile-time constant PF (the up layers: 5) and the loop
+// over them is unrolled, so that the index -> source row chains of ALL neighbours are in flight
+// together instead of one after the other
+template <int PF>
 __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
                                                              const float *__restrict__ Za,
                                                              const float *__restrict__ scp,
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
             w1 = *(const float4 *)(r.Wg + C + c);
             w2 = *(const float4 *)(r.Wg + 2 * C + c);
         }
-        const float *za = Za + (o * P) * C + c;
+        const float *za = Za + (o * (PF > 0 ? PF : P)) * C + c;
         float best[4], zps[4], zas[4];
         int bi4[4];
         const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
@@ -97,8 +101,10 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
         const float w2v[4] = {w2.x, w2.y, w2.z, w2.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) { best[i] = -__builtin_inff(); bi4[i] = 0; zps[i] = 0.f; zas[i] = 0.f; }
-        for (int p = 0; p < P; p++) {
-            const long long e = o * P + p;
+        const int PN = PF > 0 ? PF : P;
+#pragma unroll
+        for (int p = 0; p < PN; p++) {
+            const long long e = o * PN + p;
             long long flat = (long long)r.nebidx[e] + (long long)bi * r.Nsrc;
             flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
             const float4 g = *(const float4 *)(r.att16 + e * 16);       // (dist, gx, gy, gz)
@@ -409,8 +415,12 @@ int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16,
     r.Nsrc = Nsrc; r.O = O; r.B = B;
     long long nb = (ncent * (C / 4) + 255) / 256;
     int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
-    gg_k_pairmax_fwd4_src<<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,
-                                                zsel, lda);
+    if (P == 5)
+        gg_k_pairmax_fwd4_src<5><<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg,
+                                                       amax, zsel, lda);
+    else
+        gg_k_pairmax_fwd4_src<0><<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg,
+                                                       amax, zsel, lda);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
