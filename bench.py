@@ -165,6 +165,11 @@ def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("graph capture failed (%s: %s); timing the eager step\n" % (type(e).__name__, e))
             net.seed_dev = None
+            if (sync is None or sync.world == 1) and "--eager" not in sys.argv:
+                # a failed stream capture leaves the HIP context of this process unusable
+                # ("operation failed due to a previous error during capture"): start over, eager
+                sys.stderr.flush()
+                os.execv(sys.executable, [sys.executable] + sys.argv + ["--eager"])
     return eager, "eager"
 
 
