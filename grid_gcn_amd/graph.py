@@ -23,6 +23,8 @@ tests/test_gpu_gridconv.py captures the collective on one rank over a real RCCL 
 need more GPUs) and checks the trajectory against the graph without it.  If the capture fails,
 bench.py falls back to the eager step and says so (`step_mode`).
 """
+import os
+
 import torch
 
 from . import train_ops
@@ -76,6 +78,8 @@ class GraphedTrainStep:
         # scratch carved out of a shared zero chunk must not cross a capture boundary
         train_ops.reset_zero_arena()
         with torch.cuda.graph(self.g1):
+            if os.environ.get("GG_TEST_CAPTURE_FAIL") == "1":
+                torch.cuda.synchronize(dev)        # test hook: an illegal call invalidates the capture
             self.loss = fwd_bwd()
             if self.split:
                 # the flat gather, the RCCL all-reduce and the averaging are graph nodes too

@@ -575,3 +575,21 @@ def test_bench_line_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     tr = json.load(open(os.path.join(root, "profiles", "traffic.json")))
     assert d["roofline_cagq"]["traffic"] in (None, tr.get("gridify_N81920_B8"))
+
+
+def test_bench_survives_a_failed_capture():
+    """An invalidated stream capture poisons the process's HIP context; bench.py then restarts itself
+    with --eager (one GPU) and still delivers its line, step_mode 'eager'."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GG_TEST_CAPTURE_FAIL="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg3", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "graph capture failed" in r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["step_mode"] == "eager" and d["value"] > 0
