@@ -102,3 +102,37 @@ def test_gridify_up_and_knn_random(seed):
     want = orc.knn(up[..., :3], data[..., :3], dn, upn, k=k)
     got = ops.KNN(T(up[..., :3].copy()), T(data[..., :3].copy()), T(dn), T(upn), k=k)
     same((want,), (got,), ("knn", seed, k))
+
+
+BIG = [
+    # B, N, grid, k, P, O   -- chunk sizes 1024..4096, slab splits, the legacy build beyond 2^22 voxels
+    (8, 81920, [40, 40, 40], 3, 128, 1024),
+    (3, 200000, [64, 64, 64], 3, 64, 16384),
+    (2, 120000, [100, 100, 100], 3, 32, 4096),
+    (2, 50000, [200, 200, 200], 3, 16, 2048),          # 8 M voxels: legacy index build
+    (5, 30000, [31, 17, 5], 5, 64, 300),
+    (1, 131072, [8, 8, 8], 7, 128, 512),               # every voxel over-full
+    (16, 8192, [15, 15, 15], 3, 32, 256),
+]
+
+
+@pytest.mark.parametrize("case", BIG, ids=["%dx%d_g%d" % (c[0], c[1], c[2][0]) for c in BIG])
+def test_gridify_large_random(case):
+    B, N, g, k, P, O = case
+    rng = np.random.default_rng(B * 7 + N)
+    xyz = rng.uniform(-1.02, 1.02, (B, N, 3))
+    xyz[:, : N // 3, 2] = 0.3 * xyz[:, : N // 3, 0] + rng.normal(0, 0.002, (B, N // 3))   # a wall
+    data = np.concatenate([xyz, rng.integers(1, 3, (B, N, 1))], 2).astype(np.float32)
+    npn = rng.integers(N // 2, N + 1, (B, 1)).astype(np.int32)
+    kw = dict(max_p_grid=P, max_o_grid=O, kernel_size=k, stride=1, loc=1, coord_shift=[1.0, 1.0, 1.0],
+              voxel_size=[float(np.float32(2.0 / gi)) for gi in g], grid_size=g, seed=99)
+    d, n = T(data), T(npn)
+    same(orc.gridify(data, npn, **kw), ops.Gridify(d, n, **kw), ("gridify", case))
+    if k == 3:
+        M = min(N, 20000)
+        up = data[:, :M].copy()
+        ku = dict(max_p_grid=5, max_o_grid=M, kernel_size=3, coord_shift=kw["coord_shift"],
+                  voxel_size=kw["voxel_size"], grid_size=g, seed=5)
+        upn = np.minimum(npn, M).astype(np.int32)
+        same(orc.gridify_up(data, up, npn, upn, **ku), ops.GridifyUp(d, T(up), n, T(upn), **ku),
+             ("gridify_up", case))
