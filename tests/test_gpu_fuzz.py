@@ -136,3 +136,130 @@ def test_gridify_large_random(case):
         upn = np.minimum(npn, M).astype(np.int32)
         same(orc.gridify_up(data, up, npn, upn, **ku), ops.GridifyUp(d, T(up), n, T(upn), **ku),
              ("gridify_up", case))
+
+
+@pytest.mark.parametrize("seed", range(max(NFUZZ * 2 // 3, 1)))
+def test_gridconv_training_block_random_shapes(seed):
+    """Random GridConv shapes (feature widths incl. odd ones, 1-3 pt layers, widths 16..512, P, O,
+    localfdim, up-layer centre/update MLPs): whichever kernel path the dispatcher picks -- source-side
+    first conv, row layout, wide fallback, stock -- must agree with the stock modules evaluated in
+    FLOAT64 on the CPU: forward, parameter and source gradients, 1e-4 of each tensor's scale.
+    (float64 because an fp32 reference has the near-tie problem below on its own side as well:
+    tools/dbg_fuzz3.py 189 shows the stock fp32 GPU ops 2 % off where the kernels are at 6e-7.)
+
+    Near-ties: the neighbour max routes each (centre, channel) gradient to ONE edge, so two distinct
+    edges whose float64 products differ by < 5e-6 relative can be ordered the other way in fp32 and
+    move a whole gradient column (observed: one such entry in 16384 -> 1.5 % on d_src, seeds 11 and
+    20).  The reference is therefore evaluated for every routing of those few entries (at most 2^3
+    runs) and the kernels must match ONE of them to 1e-4; exact ties between duplicate neighbours
+    route to identical inputs and need nothing."""
+    import copy
+    from grid_gcn_amd.gridconv import SubGUpdate
+    rng = np.random.default_rng(3000 + seed)
+    torch.manual_seed(seed)
+    cin = int(rng.choice([0, 4, 16, 33, 64, 128, 260]))
+    L = int(rng.integers(1, 4))
+    dims = [int(rng.choice([16, 32, 64, 128, 256])) for _ in range(L)]
+    if rng.random() < 0.2:
+        dims[-1] = 512
+    lfd = int(rng.choice([0, 3]))
+    P = int(rng.choice([1, 5, 8, 32, 64]))
+    O = int(rng.choice([7, 64, 300]))
+    B, Nsrc = int(rng.integers(1, 4)), int(rng.choice([50, 400]))
+    up = cin > 0 and rng.random() < 0.4
+    kwargs = dict(center_in=4 + 32, center_dim=[64], out_dim=[64]) if up else {}
+    ref = SubGUpdate(cin, dims, localfdim=lfd, **kwargs).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    gen = torch.Generator().manual_seed(seed)
+    src = torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1
+    nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32)
+    cent = torch.rand(B, O, 4, generator=gen) * 2 - 1
+    cof = (torch.rand(B, O, 36, generator=gen) * 2 - 1) if up else None
+    msk = (torch.rand(B, O, generator=gen) > 0.2).float() if rng.random() < 0.5 else None
+    cot = torch.randn(B, O, ref.out_channels, generator=gen)
+
+    def run(dev, dtype, kernel, bump=None):
+        m = copy.deepcopy(ref).to(dev).to(dtype).train()
+        s = src.to(dev).to(dtype).requires_grad_(cin > 0)
+        c, ix = cent.to(dev).to(dtype), nebidx.to(dev)
+        cf = None if cof is None else cof.to(dev).to(dtype)
+        mk = None if msk is None else msk.to(dev).to(dtype)
+        if kernel:
+            y = m.forward_src(c, s, ix, mk, center_ori_feats=cf)
+        else:
+            Bn, N, C = s.shape                               # take(mode='clip') on the flat batch
+            flat = (ix.long() + (torch.arange(Bn, device=dev) * N).view(Bn, 1, 1)).clamp(0, Bn * N - 1)
+            nf, att_vec = m.edge_inputs(s.reshape(Bn * N, C)[flat], c[..., 0:3])
+            pair = m.att2(m.att1(att_vec)) * m.pt_mlp(nf)
+            if bump is None:
+                agg = pair.max(dim=2).values
+            else:                                            # same values, chosen routing
+                agg = pair.gather(2, (pair.detach() + bump).argmax(2, keepdim=True)).squeeze(2)
+            y = m.finish(agg, mk, cf)
+        y.backward(cot.to(dev).to(dtype))
+        out = {"y": y.detach().double().cpu()}
+        if cin:
+            out["src"] = s.grad[..., 4:].double().cpu()
+        for n_, p_ in m.named_parameters():
+            if p_.grad is not None and not n_.endswith("lin.bias"):   # conv biases sit in front of a BatchNorm
+                out[n_] = p_.grad.double().cpu()
+        if not kernel and bump is None:
+            out["_pair"] = pair.detach()
+        return out
+
+    def off(want, got, keys):
+        """keys whose tensors differ by more than 1e-4 of the float64 tensor's scale"""
+        return [k for k in keys if float((got[k] - want[k]).abs().max()) > 1e-4 * scale[k]]
+
+    want, got = run("cpu", torch.float64, False), run(DEV, torch.float32, True)
+    pair = want.pop("_pair")
+    assert set(want) == set(got)
+    scale = {k: max(float(want[k].abs().max()), 1e-3) for k in want}
+    bad = off(want, got, list(want))
+    if not bad:
+        return
+    # A ReLU input within fp32 rounding of zero flips its mask in ANY fp32 evaluation (seed 49: the
+    # stock fp32 ops and the kernels are both 4.7e-4 from float64 and 1e-6 from each other), so a
+    # tensor may also be vouched for by the stock ops in fp32 on the GPU.
+    stock = run(DEV, torch.float32, False)
+    stock.pop("_pair")
+    bad = off(stock, got, bad)
+    if not bad:
+        return
+    # Other routings of the near-tied entries.  The backward is linear in the routing, so each
+    # candidate's effect D_t = grads(flip t) - grads(reference) is measured on its own and the
+    # difference kernels - reference must be a sum of some of them.
+    assert P > 1, str((seed, bad, cin, dims, lfd, P, O, B, up))
+    K = min(P, 8)                                             # runner-up = best edge of ANOTHER source row
+    top = pair.topk(K, dim=2)                                 # (duplicate neighbours tie harmlessly)
+    Bn, N = src.shape[:2]
+    flat = (nebidx.long() + (torch.arange(Bn) * N).view(Bn, 1, 1)).clamp(0, Bn * N - 1)
+    ids = flat.unsqueeze(-1).expand_as(pair).gather(2, top.indices)
+    other = ids != ids[:, :, 0:1]
+    jj = other.float().argmax(2, keepdim=True)
+    v0, v1 = top.values[:, :, 0], top.values.gather(2, jj).squeeze(2)
+    e1 = top.indices.gather(2, jj).squeeze(2)
+    gapn = (v0 - v1) / pair.abs().amax(dim=(0, 1, 2)).clamp_min(1e-30)     # in units of the channel's range
+    gapn = torch.where(other.any(2) & (v0 != 0), gapn, torch.full_like(gapn, 1.0))
+    order = gapn.flatten().argsort()[:12]
+    cands = [(int(i), float(gapn.flatten()[i])) for i in order if float(gapn.flatten()[i]) < 2e-5]
+    assert cands, str((seed, bad, cin, dims, lfd, P, O, B, up, "no near-ties", float(gapn.min())))
+    C = pair.shape[3]
+    big = float(pair.abs().max()) * 4 + 1
+    resid = {k: (got[k] - want[k]) / scale[k] for k in want}
+    norm = lambda r: float(sum((v ** 2).sum() for v in r.values()))
+    used = []
+    for i, g_ in cands:
+        b, o, ch = i // (O * C), i // C % O, i % C
+        bump = torch.zeros_like(pair)
+        bump[b, o, int(e1[b, o, ch]), ch] = big
+        alt = run("cpu", torch.float64, False, bump)
+        trial = {k: resid[k] - (alt[k] - want[k]) / scale[k] for k in want}
+        if norm(trial) < norm(resid):
+            resid, used = trial, used + [(b, o, ch, g_)]
+    left = [k for k in bad if float(resid[k].abs().max()) > 1e-4]
+    assert not left, str((seed, cin, dims, lfd, P, O, B, up, "after routings", used, "of", cands, "left",
+                          [(k, float(resid[k].abs().max())) for k in left]))
