@@ -1,5 +1,5 @@
 """Run the kernels bench.py's `roofline` object times (backward of the 32->128 attention conv of
-layer up2: gg_k_linear_dx_direct + gg_k_linear_dw_direct + reduce) a few times, for rocprofv3:
+layer up2: gg_k_att_bwd_fused + gg_k_att_dw_reduce) a few times, for rocprofv3:
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out1 -- python tools/prof_att_bwd.py
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out2 -- python tools/prof_att_bwd.py
@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--summarise":
 
 from grid_gcn_amd import train_ops  # noqa: E402
 
-ms = train_ops.time_linear_bwd(655360, 5, 32, 128, iters=3, device="cuda:0")
+ms = train_ops.time_linear_bwd(655360, 5, 32, 128, iters=3, device="cuda:0", ndx=32, prev_bn=True)   # bench.py's call
 print("ms per call", ms)
 ms = train_ops.time_linear_fwd(655360, 256, 128, iters=3, device="cuda:0")
 print("fwd ms per call", ms)
