@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         if (row >= p.E) row = p.E - 1;
         const float *zr = p.Z + row * C;
         const float *gr;
-        const gg_amax_t *ar = nullptr;
+        const gg_amax_t *ar = (const gg_amax_t *)zr;   // dense: harmless bytes, never used
         int pp = 0;
         if (sparse) {
             const long long cen = row / p.P;
@@ -446,24 +446,25 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         } else {
             gr = p.dY + row * p.ldy;
         }
+        // no branch around the arg-max load: a conditional load made the compiler wait for ALL
+        // outstanding loads (s_waitcnt vmcnt(0)) after every quad of the sparse form
         auto ldg = [&](int k) -> float4 {
             float4 g = *(const float4 *)(gr + k);
-            if (sparse) {
-                const int4 am = gg_amax4(ar + k);
-                g.x = am.x == pp ? g.x : 0.f; g.y = am.y == pp ? g.y : 0.f;
-                g.z = am.z == pp ? g.z : 0.f; g.w = am.w == pp ? g.w : 0.f;
-            }
+            const int4 am = gg_amax4(ar + k);
+            g.x = (!sparse || am.x == pp) ? g.x : 0.f; g.y = (!sparse || am.y == pp) ? g.y : 0.f;
+            g.z = (!sparse || am.z == pp) ? g.z : 0.f; g.w = (!sparse || am.w == pp) ? g.w : 0.f;
             return g;
         };
         ggm_f32x16 acc[NT];
         ggm_zero<NT>(acc);
         int s = 0;
+        if constexpr (BF16) {
         for (int c = 0; c < nfull; c++) {
             const int k0 = c * 32 + h * 16;
-            float4 z[4], g[4], a[4];
+            float4 z[4], g[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) { z[q] = *(const float4 *)(zr + k0 + 4 * q); g[q] = ldg(k0 + 4 * q); }
-            if constexpr (BF16) {
+            {
                 // dZ formed and packed group by group (its five constants per channel quad would
                 // otherwise all be live at once)
                 const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
@@ -477,21 +478,46 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                     for (int t = 0; t < NT; t++)
                         acc[t] = gg_mfma_bf16(a8, W16[((2 * c + gq) * 64 + lane) * NTV + t], acc[t]);
                 }
-            } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) a[q] = dz4(z[q], g[q], k0 + 4 * q);
-#pragma unroll
-            for (int q = 0; q < 4; q++)
+            }
+        }
+        } else {
+            // One quad (4 channels per lane = 4 MFMA steps x NT tiles) at a time, the NEXT quad's
+            // loads issued before this quad's MFMAs: the chunk form (all 16 channels loaded, then
+            // 16 steps) needed 48 registers for the loaded values, and at NT = 8 the compiler fell
+            // back to load -> s_waitcnt vmcnt(0) -> 32 MFMAs per quad, i.e. a full memory round
+            // trip in front of every 2048 MFMA cycles.  The arg-max mask is applied at use, not at
+            // load (a select right behind the load is a wait).
+            const int nquad = nfull * 4;
+            float4 zc = make_float4(0.f, 0.f, 0.f, 0.f), gc = zc;
+            unsigned amc = 0;
+            if (nquad > 0) {
+                zc = *(const float4 *)(zr + h * 16);
+                gc = *(const float4 *)(gr + h * 16);
+                amc = *(const unsigned *)(ar + h * 16);
+            }
+            for (int qi = 0; qi < nquad; qi++) {
+                const int qn = qi + 1 < nquad ? qi + 1 : qi;      // (last quad: a harmless re-read)
+                const int kn = (qn >> 2) * 32 + h * 16 + (qn & 3) * 4;
+                const float4 zn = *(const float4 *)(zr + kn), gn = *(const float4 *)(gr + kn);
+                const unsigned amn = *(const unsigned *)(ar + kn);
+                const int k0 = (qi >> 2) * 32 + h * 16 + (qi & 3) * 4;
+                float4 g = gc;
+                g.x = (!sparse || (int)(amc & 255u) == pp) ? g.x : 0.f;
+                g.y = (!sparse || (int)((amc >> 8) & 255u) == pp) ? g.y : 0.f;
+                g.z = (!sparse || (int)((amc >> 16) & 255u) == pp) ? g.z : 0.f;
+                g.w = (!sparse || (int)(amc >> 24) == pp) ? g.w : 0.f;
+                const float4 a = dz4(zc, g, k0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     float b[NTV];
-                    gg_ldb<NTV>(Wl, s * 64 + lane, b);
+                    gg_ldb<NTV>(Wl, (qi * 4 + i) * 64 + lane, b);
 #pragma unroll
                     for (int t = 0; t < NT; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
-                    s++;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
                 }
+                zc = zn; gc = gn; amc = amn;
             }
+            s = nquad * 4;
         }
         if (ktail) {
             const int nq = ktail >> 3;
@@ -547,9 +573,10 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                 float zpv[16];
                 if (prevbn) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
+                    for (int r = 0; r < 16; r++) {          // (rows past the end: any valid address)
                         const int rr = (r & 3) + 8 * (r >> 2);
-                        zpv[r] = (nrows == 32 || rr + 4 * h < nrows) ? ap[rr * ldx + t * 32] : 0.f;
+                        const float *a = (nrows == 32 || rr + 4 * h < nrows) ? ap + rr * ldx + t * 32 : p.Aprev;
+                        zpv[r] = *a;
                     }
                 }
 #pragma unroll
@@ -628,10 +655,11 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
         q.dx_col0 = 128;
         return launch_dx_direct<4>(q, st);
     }
-    // workgroups that are RESIDENT per CU (registers: 162 at NT = 1 -> three 4-wave groups; 182 at
-    // NT = 2 -> two; > 128 for the 8-wave groups of NT >= 3 -> one): a grid beyond that runs a second,
-    // partly filled round (measured on the fused attention backward: 1.30 -> 1.06 ms)
-    int per_cu = NT == 1 ? 3 : (NT == 2 ? 2 : 1);
+    // workgroups that are RESIDENT per CU (registers, fp32 form: 127 at NT = 1 -> four 4-wave groups;
+    // 154 at NT = 2 -> three; > 128 for the 8-wave groups of NT >= 3 -> one; the bf16 form, 213 / 235,
+    // two): a grid beyond that runs a second, partly filled round (measured on the fused
+    // attention backward: 1.30 -> 1.06 ms)
+    int per_cu = NT == 1 ? (bf16 ? 2 : 4) : (NT == 2 ? (bf16 ? 2 : 3) : 1);
     while (per_cu > 1 && per_cu * lds > 152 * 1024) per_cu--;
     const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
@@ -738,24 +766,25 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
         cen = r / p.P;
         pp = (int)(r - cen * p.P);
     }
+    // Branch-free on purpose: with a branch (sparse or dense, the centre-counter loop) in the body
+    // the compiler closed every step with s_waitcnt vmcnt(0) and the register sets below never
+    // overlapped (dW of 256 -> 128 at 41 % of the MFMA rate).
+    const int Pq = sparse ? p.P : (1 << 30);
     auto load = [&](Regs &R, long long s) {
         const long long row = ra + 2 * s + h;
         R.ok = row < rb;
         const long long rw = R.ok ? row : (p.E - 1);
         const float *zr = p.Z + rw * C + chl;
-        const float *gr;
-        if (sparse) {
-            const long long cc = R.ok ? cen : 0;
-            gr = p.gval + cc * C + chl;
-            const gg_amax_t *ar = p.amax + cc * C + chl;
-            if constexpr (MT == 2) { const unsigned short t = *(const unsigned short *)ar; R.am[0] = t & 255; R.am[1] = t >> 8; }
-            else R.am[0] = ar[0];
-            R.pp = pp;
-            pp += 2;
-            while (pp >= p.P) { pp -= p.P; cen++; }
-        } else {
-            gr = p.dY + rw * p.ldy + chl;
-        }
+        const long long cc = R.ok ? cen : 0;
+        const float *gr = sparse ? p.gval + cc * C + chl : p.dY + rw * p.ldy + chl;
+        // dense: a harmless byte of Z, never used
+        const gg_amax_t *ar = sparse ? p.amax + cc * C + chl : (const gg_amax_t *)zr;
+        if constexpr (MT == 2) { const unsigned short t = *(const unsigned short *)ar; R.am[0] = t & 255; R.am[1] = t >> 8; }
+        else R.am[0] = ar[0];
+        R.pp = pp;
+        pp += 2;                                   // two rows on: at most two centres further (P >= 1)
+        { const bool t = pp >= Pq; pp -= t ? Pq : 0; cen += t ? 1 : 0; }
+        { const bool t = pp >= Pq; pp -= t ? Pq : 0; cen += t ? 1 : 0; }
         if constexpr (MT == 2) {
             const float2 t = *(const float2 *)zr, u = *(const float2 *)gr;
             R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y;
@@ -784,8 +813,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
     auto values = [&](const Regs &R, float (&dz)[MT], float (&xa)[NJ]) {
 #pragma unroll
         for (int i = 0; i < MT; i++) {
-            float g = R.g[i];
-            if (sparse) g = R.am[i] == R.pp ? g : 0.f;
+            const float g = (!sparse || R.am[i] == R.pp) ? R.g[i] : 0.f;
             const float d = sc[i] * ((R.z[i] * sc[i] + sh[i] > 0.f) ? g : 0.f) +
                             ((R.z[i] - mu[i]) * bz[i] + cz[i]);
             dz[i] = (R.ok && chok) ? d : 0.f;
@@ -838,12 +866,87 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             }
         }
     } else {
-    if (nsteps > 0) load(A, 0);
-    for (long long s = 0; s < nsteps; s += 2) {
-        load(B, s + 1);          // past the end: ok = false, clamped addresses
-        compute(A);
-        load(A, s + 2);
-        if (s + 1 < nsteps) compute(B);
+    // D register sets rotate: the loads of step s + D - 1 are issued before step s is consumed.  One
+    // step is only MT*NJ MFMAs (64 cycles each) and a wave has at most one partner on its SIMD, so
+    // a distance of one step (the first form of this loop) covered < 0.5 us of the 1-2 us a load
+    // takes under traffic.  (load() past the end: ok = false, clamped addresses; called once per
+    // step in ascending order, as the sparse centre counter requires.)
+    // D per instantiation, from the compiler's register report: as deep as fits the occupancy the
+    // launcher counts on (gg_dw_direct_cfg: 4 / 3 / 2 waves per SIMD for <= 2 / <= 4 / more tiles,
+    // i.e. 128 / 168 / 256 registers) without spilling.
+    constexpr int TILES = MT * NJ;
+    constexpr int D = TILES == 1 ? 8
+                      : TILES == 2 ? (MT == 2 ? 4 : 6)
+                      : TILES <= 4 ? (MT == 2 ? 4 : (TILES == 3 ? 4 : 6))
+                      : TILES == 5 ? 5
+                      : TILES <= 7 ? (MT == 2 ? 6 : (TILES == 7 ? 4 : 6))
+                      : TILES == 8 ? 5
+                      : TILES == 9 ? 3 : 2;
+    Regs R[D];
+#pragma unroll
+    for (int d = 0; d < D - 1; d++) load(R[d], d);
+    long long s = 0;
+    {
+        // Rounds whose loads (steps up to s + 2D - 2) all lie inside the wave's rows: per-lane
+        // pointers advance by constants.  (The general load() forms every address from the step
+        // number -- clamping, four 64-bit products -- and its ~90 VALU instructions per step
+        // competed with the 8 MFMAs of the step for the issue slots.)
+        const long long nin = (rb - ra) >> 1;      // steps with both rows valid
+        const long long r1 = ra + 2 * (D - 1) + h; // row of the next step to load
+        const float *zp = p.Z + r1 * C + chl;
+        const float *xp = p.Aprev + r1 * cin;
+        const float *gp = sparse ? p.gval + cen * C + chl : p.dY + r1 * p.ldy + chl;
+        const gg_amax_t *ap = sparse ? p.amax + cen * C + chl : (const gg_amax_t *)p.Z;
+        const int ginc = sparse ? 0 : 2 * p.ldy, Cs = sparse ? C : 0;
+        auto load_in = [&](Regs &R) {
+            R.ok = true;
+            if constexpr (MT == 2) { const unsigned short t = *(const unsigned short *)ap; R.am[0] = t & 255; R.am[1] = t >> 8; }
+            else R.am[0] = ap[0];
+            R.pp = pp;
+            if constexpr (MT == 2) {
+                const float2 t = *(const float2 *)zp, u = *(const float2 *)gp;
+                R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y;
+            } else {
+                R.z[0] = zp[0]; R.g[0] = gp[0];
+            }
+            int j = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const float4 t = *(const float4 *)(xp + q * 128 + 4 * cq);
+                R.x[j++] = t.x; R.x[j++] = t.y; R.x[j++] = t.z; R.x[j++] = t.w;
+            }
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                const float2 t = *(const float2 *)(xp + NQ * 128 + 2 * cq);
+                R.x[j++] = t.x; R.x[j++] = t.y;
+            }
+            if (NS) R.x[j++] = xp[scol];
+            pp += 2;
+            const bool t1 = pp >= Pq;
+            pp -= t1 ? Pq : 0;
+            const bool t2 = pp >= Pq;
+            pp -= t2 ? Pq : 0;
+            const int adv = (t1 ? 1 : 0) + (t2 ? 1 : 0);
+            cen += adv;
+            gp += ginc + adv * Cs;
+            ap += adv * Cs;
+            zp += 2 * C;
+            xp += 2 * cin;
+        };
+        for (; s + 2 * D - 1 <= nin; s += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                load_in(R[(d + D - 1) % D]);
+                compute(R[d]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; d++)                // the sets still hold steps s .. s + D - 2
+        if (s + d < nsteps) compute(R[d]);
+    for (s += D - 1; s < nsteps; s++) {            // < 2D steps at the end of the wave's rows, one by one
+        load(R[0], s);
+        compute(R[0]);
     }
     }
 
@@ -920,7 +1023,7 @@ static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
     c->MT = MT; c->NQ = NQ; c->NP = NP; c->NS = NS; c->MG = MG; c->RS = RS;
     c->threads = 64 * MG * RS;
     // waves per SIMD the register footprint allows (small tiles are latency bound: more waves)
-    const int wps = MT * NJ <= 2 ? 4 : (MT * NJ <= 5 ? 3 : 2);
+    const int wps = MT * NJ <= 2 ? 4 : (MT * NJ <= 4 ? 3 : 2);
     int nwg = 1024 * wps / (MG * RS);
     long long maxwg = (E + 64LL * RS - 1) / (64LL * RS);
     if (nwg > maxwg) nwg = (int)maxwg;
