@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLin
         if (row >= p.E) row = p.E - 1;
         const float *zr = p.Z + row * C;
         const float *gr;
-        const gg_amax_t *ar = nullptr;
+        const gg_amax_t *ar = (const gg_amax_t *)zr;   // dense: harmless bytes, never used
         int pp = 0;
         if (sparse) {
             const long long cen = row / p.P;
@@ -119,13 +119,14 @@ __global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLin
         } else {
             gr = p.dY + row * p.ldy;
         }
-        auto ldg = [&](int k) -> float4 {
-            float4 g = *(const float4 *)(gr + k);
-            if (sparse) {
-                const int4 am = gg_amax4(ar + k);
-                g.x = am.x == pp ? g.x : 0.f; g.y = am.y == pp ? g.y : 0.f;
-                g.z = am.z == pp ? g.z : 0.f; g.w = am.w == pp ? g.w : 0.f;
-            }
+        // The arg-max bytes are loaded unconditionally and applied where the gradient is used: with
+        // the load inside `if (sparse)` (and the select right behind it) the compiler closed every
+        // quad with s_waitcnt vmcnt(0) -- four memory round trips per 32 channels instead of one.
+        auto gmask = [&](float4 g, unsigned am) -> float4 {
+            g.x = (!sparse || (int)(am & 255u) == pp) ? g.x : 0.f;
+            g.y = (!sparse || (int)((am >> 8) & 255u) == pp) ? g.y : 0.f;
+            g.z = (!sparse || (int)((am >> 16) & 255u) == pp) ? g.z : 0.f;
+            g.w = (!sparse || (int)(am >> 24) == pp) ? g.w : 0.f;
             return g;
         };
         // the previous layer's raw outputs in the C/D row order (rows (r&3) + 8(r>>2) + 4h, column
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLin
         for (int r = 0; r < 16; r++) {
             const int rr = (r & 3) + 8 * (r >> 2);
             const bool ok = colok && (nrows == 32 || rr + 4 * h < nrows);
-            zpv[r] = ok ? p.Aprev[base + rr * cin] : 0.f;
+            const float v = *(ok ? p.Aprev + base + rr * cin : p.Aprev);   // (no branch around the load)
+            zpv[r] = ok ? v : 0.f;
         }
         ggm_f32x16 accx;
 #pragma unroll
@@ -159,11 +161,16 @@ __global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLin
             for (int cc = 0; cc < 2; cc++) {
                 const int k0 = (2 * hc + cc) * 32 + h * 16;
                 float4 z[4], g[4], a[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { z[q] = *(const float4 *)(zr + k0 + 4 * q); g[q] = ldg(k0 + 4 * q); }
+                unsigned am[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    a[q] = dz4(z[q], g[q], k0 + 4 * q);
+                    z[q] = *(const float4 *)(zr + k0 + 4 * q);
+                    g[q] = *(const float4 *)(gr + k0 + 4 * q);
+                    am[q] = *(const unsigned *)(ar + k0 + 4 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    a[q] = dz4(z[q], gmask(g[q], am[q]), k0 + 4 * q);
                     if (!rowok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     *(float4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = a[q];
                 }
