@@ -102,15 +102,13 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
 #pragma unroll
         for (int i = 0; i < 4; i++) { best[i] = -__builtin_inff(); bi4[i] = 0; zps[i] = 0.f; zas[i] = 0.f; }
         const int PN = PF > 0 ? PF : P;
-#pragma unroll
-        for (int p = 0; p < PN; p++) {
-            const long long e = o * PN + p;
-            long long flat = (long long)r.nebidx[e] + (long long)bi * r.Nsrc;
-            flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
-            const float4 g = *(const float4 *)(r.att16 + e * 16);       // (dist, gx, gy, gz)
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r.Ysrc) y = *(const float4 *)(r.Ysrc + flat * C + c);
-            const float4 z2 = *(const float4 *)(za + (size_t)p * C);
+        // (no branch around the dependent row load: a conditional load made the compiler wait for
+        //  every outstanding load -- s_waitcnt vmcnt(0) -- once per neighbour)
+        const bool hasY = r.Ysrc != nullptr;
+        const float *ysrc = hasY ? r.Ysrc + c : r.b;            // no source term: any valid address
+        const long long ystride = hasY ? C : 0;
+        auto fold = [&](int p, const float4 g, const float4 yy, const float4 z2) {
+            const float4 y = hasY ? yy : make_float4(0.f, 0.f, 0.f, 0.f);
             const float yv[4] = {y.x, y.y, y.z, y.w}, z2v[4] = {z2.x, z2.y, z2.z, z2.w};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -125,6 +123,36 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
                 const bool upd = v > best[i];
                 if (upd || p == 0) { zps[i] = z1; zas[i] = z2v[i]; }
                 if (upd) { best[i] = v; bi4[i] = p; }
+            }
+        };
+        if constexpr (PF > 0) {
+            // all PF indices, then every independent load, then the PF dependent rows together
+            int nb[PF];
+            float4 gq[PF], zq[PF], yq[PF];
+#pragma unroll
+            for (int p = 0; p < PF; p++) nb[p] = r.nebidx[o * PF + p];
+#pragma unroll
+            for (int p = 0; p < PF; p++) {
+                gq[p] = *(const float4 *)(r.att16 + (o * PF + p) * 16);       // (dist, gx, gy, gz)
+                zq[p] = *(const float4 *)(za + (size_t)p * C);
+            }
+#pragma unroll
+            for (int p = 0; p < PF; p++) {
+                long long flat = (long long)nb[p] + (long long)bi * r.Nsrc;
+                flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+                yq[p] = *(const float4 *)(ysrc + flat * ystride);
+            }
+#pragma unroll
+            for (int p = 0; p < PF; p++) fold(p, gq[p], yq[p], zq[p]);
+        } else {
+            for (int p = 0; p < PN; p++) {
+                const long long e = o * PN + p;
+                long long flat = (long long)r.nebidx[e] + (long long)bi * r.Nsrc;
+                flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+                const float4 g = *(const float4 *)(r.att16 + e * 16);       // (dist, gx, gy, gz)
+                const float4 y = *(const float4 *)(ysrc + flat * ystride);
+                const float4 z2 = *(const float4 *)(za + (size_t)p * C);
+                fold(p, g, y, z2);
             }
         }
         const long long e = o * C + c;
