@@ -104,7 +104,7 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 // Z[E, cout] = act(X[E, K]) * W + b, batch statistics of Z in the epilogue.  K % 8 == 0, X row
 // stride K.  NT = ldw / 32 column tiles per wave (all of them: the wave owns full rows of Z).
 template <int NT, bool WLDS, bool EXACT, bool BF16 = false>
-__global__ __launch_bounds__(NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) void gg_k_linear_fwd_direct(GGLinFwd p)
+__global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024))) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -132,6 +132,26 @@ __global__ __launch_bounds__(NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) void gg_k_l
     }
     const long long ntile = (p.E + 31) >> 5;
     const int nfull = K >> 5, ktail = K & 31;
+    // fp32 form: the NEXT chunk (32 columns: four float4 per lane, issued together so that a row's
+    // 64-byte piece is fetched once) is loaded while the current one runs its 16 * NT MFMAs -- the
+    // next tile's first chunk during the last chunk and the epilogue.  xa = the chunk about to be
+    // consumed.
+    float4 xa[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) xa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto rowptrs = [&](long long tl, const float *&r1, const float *&r2) {
+        long long rw = (tl << 5) + (lane & 31);
+        if (rw >= p.E) rw = p.E - 1;
+        r1 = p.X + rw * p.lda;
+        r2 = p.X2 ? p.X2 + rw * p.lda2 - p.K1 : r1;
+    };
+    if (!BF16 && nfull > 0 && (long long)blockIdx.x * nw + wave < ntile) {
+        const float *r1, *r2;
+        rowptrs((long long)blockIdx.x * nw + wave, r1, r2);
+        const float *x0 = (0 < p.K1) ? r1 : r2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) xa[q] = *(const float4 *)(x0 + h * 16 + 4 * q);
+    }
     for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
          tile += (long long)gridDim.x * nw) {
         const long long r0 = tile << 5;
@@ -144,6 +164,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) void gg_k_l
         ggm_f32x16 acc[NT];
         ggm_zero<NT>(acc);
         int s = 0;
+        if constexpr (BF16) {
         for (int c = 0; c < nfull; c++) {
             const int k0 = c * 32 + h * 16;
             const float *xc = (c * 32 < p.K1) ? xr : xr2;
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) void gg_k_l
                     a[q] = gg_bnrelu4(a[q], *(const float4 *)(scl + k0 + 4 * q),
                                       *(const float4 *)(scl + K + k0 + 4 * q));
             }
-            if constexpr (BF16) {
+            {
                 const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
@@ -167,19 +188,45 @@ __global__ __launch_bounds__(NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) void gg_k_l
                     for (int t = 0; t < NT; t++)
                         acc[t] = gg_mfma_bf16(a8, W16[((2 * c + g) * 64 + lane) * NT + t], acc[t]);
                 }
-            } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float b[NT];
-                    gg_ldb<NT>(Wb, s * 64 + lane, b);
-#pragma unroll
-                    for (int t = 0; t < NT; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
-                    s++;
-                }
             }
+        }
+        } else {
+            const float *n1 = xr, *n2 = xr2;             // rows of the wave's next tile (or this one again)
+            {
+                const long long tn = tile + (long long)gridDim.x * nw;
+                if (tn < ntile) rowptrs(tn, n1, n2);
+            }
+            for (int c = 0; c < nfull; c++) {
+                const int k0 = c * 32 + h * 16;
+                const bool last = c + 1 == nfull;
+                const int cn = last ? 0 : c + 1;
+                const float *xn = (cn * 32 < p.K1) ? (last ? n1 : xr) : (last ? n2 : xr2);
+                float4 xb[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) xb[q] = *(const float4 *)(xn + cn * 32 + h * 16 + 4 * q);
+                float4 a[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[q] = xa[q];
+                if (p.scale) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        a[q] = gg_bnrelu4(a[q], *(const float4 *)(scl + k0 + 4 * q),
+                                          *(const float4 *)(scl + K + k0 + 4 * q));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float b[NT];
+                        gg_ldb<NT>(Wb, s * 64 + lane, b);
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
+                        s++;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) xa[q] = xb[q];
             }
         }
         if (ktail) {
@@ -310,7 +357,10 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
             if (hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
-    const int threads = NT == 8 ? 512 : (NT == 4 ? 768 : 1024), nw = threads / 64;
+    // fp32 form (next chunk prefetched: 16 more registers): 2 waves per SIMD at NT >= 4, 3 at NT = 2
+    const bool use16 = g_mlp_bf16 && q.scale && (size_t)((q.K / 2 + 7) / 8) * 64 * NT * 16 + (size_t)2 * q.K * 4 <= 156 * 1024;
+    const int threads = use16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024));
+    const int nw = threads / 64;
     const size_t wbytes = (size_t)q.K * 32 * NT * 4, sbytes = (size_t)2 * q.K * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
     const long long ntile = (q.E + 31) >> 5;
