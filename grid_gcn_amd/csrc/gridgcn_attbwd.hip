@@ -43,7 +43,7 @@ __device__ __forceinline__ float gg_af_f4(const float4 &v, int i)
 //  1.63 -> 1.23 ms on 8.4 M edges; the 128-channel form needs 247 registers and stays at two: forced
 //  to three it spills 66 and gains nothing)
 template <int NJ, bool BF16>
-__global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLinBwd p)
+__global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_fused(GGLinBwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,24 +100,59 @@ __global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLin
         return d;
     };
 
+    // row pointers of a tile: Z row, upstream-gradient row, arg-max row (dense: harmless bytes of Z,
+    // never used), neighbour number of the row within its centre
+    auto tileptrs = [&](long long tl, const float *&zr_, const float *&gr_, const gg_amax_t *&ar_, int &pp_) {
+        long long rw = (tl << 5) + l31;
+        if (rw >= p.E) rw = p.E - 1;
+        zr_ = p.Z + rw * C;
+        ar_ = (const gg_amax_t *)zr_;
+        pp_ = 0;
+        if (sparse) {
+            const long long cen = rw / p.P;
+            pp_ = (int)(rw - cen * p.P);
+            gr_ = p.gval + cen * C;
+            ar_ = p.amax + cen * C;
+        } else {
+            gr_ = p.dY + rw * p.ldy;
+        }
+    };
+    // The 32 channels a lane consumes next (z, upstream gradient, arg-max bytes) are loaded one chunk
+    // AHEAD: right after a chunk's dZ is formed its registers are free again, so the next chunk's
+    // loads (the next tile's first chunk at the end of a tile) fly during the dX and dW MFMAs.
+    float4 z[4], g[4];
+    unsigned am[4];
+    auto issue = [&](const float *zr_, const float *gr_, const gg_amax_t *ar_, int ci) {
+        const int k0 = ci * 32 + h * 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            z[q] = *(const float4 *)(zr_ + k0 + 4 * q);
+            g[q] = *(const float4 *)(gr_ + k0 + 4 * q);
+            am[q] = *(const unsigned *)(ar_ + k0 + 4 * q);
+        }
+    };
+    if ((long long)blockIdx.x * 4 + wave < ntile) {
+        const float *z0, *g0;
+        const gg_amax_t *a0;
+        int p0;
+        tileptrs((long long)blockIdx.x * 4 + wave, z0, g0, a0, p0);
+        issue(z0, g0, a0, 0);
+    }
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile;
          tile += (long long)gridDim.x * 4) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
         const bool rowok = l31 < nrows;               // rows past E are clamped copies: no weight
-        long long row = r0 + l31;
-        if (row >= p.E) row = p.E - 1;
-        const float *zr = p.Z + row * C;
-        const float *gr;
-        const gg_amax_t *ar = (const gg_amax_t *)zr;   // dense: harmless bytes, never used
-        int pp = 0;
-        if (sparse) {
-            const long long cen = row / p.P;
-            pp = (int)(row - cen * p.P);
-            gr = p.gval + cen * C;
-            ar = p.amax + cen * C;
-        } else {
-            gr = p.dY + row * p.ldy;
+        const float *zr, *gr;
+        const gg_amax_t *ar;
+        int pp;
+        tileptrs(tile, zr, gr, ar, pp);
+        const float *nzr = zr, *ngr = gr;              // the wave's next tile (or this one again)
+        const gg_amax_t *nar = ar;
+        {
+            const long long tn = tile + (long long)gridDim.x * 4;
+            int pn;
+            if (tn < ntile) tileptrs(tn, nzr, ngr, nar, pn);
         }
         // The arg-max bytes are loaded unconditionally and applied where the gradient is used: with
         // the load inside `if (sparse)` (and the select right behind it) the compiler closed every
@@ -160,20 +195,18 @@ __global__ __launch_bounds__(256, NJ == 2 ? 3 : 2) void gg_k_att_bwd_fused(GGLin
 #pragma unroll
             for (int cc = 0; cc < 2; cc++) {
                 const int k0 = (2 * hc + cc) * 32 + h * 16;
-                float4 z[4], g[4], a[4];
-                unsigned am[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    z[q] = *(const float4 *)(zr + k0 + 4 * q);
-                    g[q] = *(const float4 *)(gr + k0 + 4 * q);
-                    am[q] = *(const unsigned *)(ar + k0 + 4 * q);
-                }
+                float4 a[4];
+                __builtin_amdgcn_sched_barrier(0);     // (and the uses of the loaded chunk below the previous phase)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     a[q] = dz4(z[q], gmask(g[q], am[q]), k0 + 4 * q);
                     if (!rowok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                     *(float4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = a[q];
                 }
+                if (2 * hc + cc + 1 < NJ) issue(zr, gr, ar, 2 * hc + cc + 1);
+                else issue(nzr, ngr, nar, 0);
+                // (keep the loads HERE: left alone, the scheduler sinks them to their first use)
+                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (BF16) {
 #pragma unroll
                     for (int g = 0; g < 2; g++) {
@@ -584,7 +617,8 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
     }
     const int C = NJ * 32;
     const size_t lds = ((size_t)C * 32 + 5 * C + 4 * 32 * GG_AF_TS) * sizeof(float);
-    const int grid = gg_att_fused_grid(p.E, C);
+    int grid = gg_att_fused_grid(p.E, C);
+    if (gg_get_mlp_bf16() && grid > 512) grid = 512;   // the bf16 form holds two workgroups per CU at either width
     if (gg_get_mlp_bf16()) gg_k_att_bwd_fused<NJ, true><<<grid, 256, lds, st>>>(p);
     else gg_k_att_bwd_fused<NJ, false><<<grid, 256, lds, st>>>(p);
     if (hipGetLastError() != hipSuccess) return 3;
