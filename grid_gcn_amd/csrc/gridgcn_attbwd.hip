@@ -189,6 +189,35 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                                      ggaf_pk(av[6], av[7])};
             }
         }
+        // dW^T tile j += act(Aprev)^T * dZ(columns cc*32.. of the LDS tile).  The tile belongs to this
+        // wave alone: its LDS writes only have to land before its reads; the columns read here are
+        // overwritten two chunks later, behind another of these barriers.
+        auto dwphase = [&](int j, int cc) {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (BF16) {
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    float tv[8];
+#pragma unroll
+                    for (int jx = 0; jx < 8; jx++) {
+                        const int r = hf * 8 + jx;
+                        tv[jx] = T[((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31 + cc * 32];
+                    }
+                    const ggaf_u32x4 b8 = {ggaf_pk(tv[0], tv[1]), ggaf_pk(tv[2], tv[3]),
+                                           ggaf_pk(tv[4], tv[5]), ggaf_pk(tv[6], tv[7])};
+                    accw[j] = ggaf_mfma(av8[hf], b8, accw[j]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
+                    // (rows past E: their dZ rows in T are zero, whatever act() makes of the padding)
+                    const float av = fmaxf(zpv[r] * ps + psh, 0.f);      // 0 in the idle columns
+                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, trow[cc * 32], accw[j], 0, 0, 0);
+                }
+            }
+        };
         int s = 0;
 #pragma unroll
         for (int hc = 0; hc < NJ / 2; hc++) {
@@ -225,39 +254,13 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                         s++;
                     }
                 }
+                // NJ = 4: dW of THIS chunk's 32 channels right away (not of both chunks after the second):
+                // every chunk then has its dX and its dW MFMAs between the issue of the next chunk's
+                // loads and their use.  (At NJ = 2 the same split spilled 59 registers under the
+                // three-waves bound; that form keeps the two-chunk phase.)
+                if constexpr (NJ == 4) dwphase(2 * hc + cc, cc);
             }
-            // the tile belongs to this wave alone: its LDS writes only have to land before its reads
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (BF16) {
-#pragma unroll
-                for (int hf = 0; hf < 2; hf++)
-#pragma unroll
-                    for (int jj = 0; jj < 2; jj++) {
-                        float tv[8];
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const int r = hf * 8 + j;
-                            tv[j] = T[((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31 + jj * 32];
-                        }
-                        const ggaf_u32x4 b8 = {ggaf_pk(tv[0], tv[1]), ggaf_pk(tv[2], tv[3]),
-                                               ggaf_pk(tv[4], tv[5]), ggaf_pk(tv[6], tv[7])};
-                        accw[2 * hc + jj] = ggaf_mfma(av8[hf], b8, accw[2 * hc + jj]);
-                    }
-            } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
-                // (rows past E: their dZ rows in T are zero, whatever act() makes of the padding)
-                const float av = fmaxf(zpv[r] * ps + psh, 0.f);      // 0 in the idle columns
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-                    accw[2 * hc + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, trow[jj * 32],
-                                                                             accw[2 * hc + jj], 0, 0, 0);
-            }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (NJ != 4) { dwphase(2 * hc, 0); dwphase(2 * hc + 1, 1); }
         }
         // dX tile + BatchNorm-backward sums of the previous layer
         float *xp = p.dX + base;
