@@ -4,6 +4,8 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/$1
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
+cp profiles/traffic.json $OUT/traffic.json        # other keys (att_bwd_fused: tools/r2_pmc_attbwd.sh) stay
+if [ -z "$SKIP_PMC" ]; then
 cd /tmp && export TMPDIR=/tmp
 for cfg in seg80k synth200k; do
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -14,6 +16,8 @@ cd $R
 python tools/pmc_traffic.py --fetch $OUT/pmc_seg80k_FETCH_SIZE --write $OUT/pmc_seg80k_WRITE_SIZE --key gridify_N81920_B8 --kernels gg_k_chunk_split:327680,gg_k_slab_build:524288,gg_k_centre_slots:163840,gg_k_query_gridify:524288 --out $OUT/traffic.json
 python tools/pmc_traffic.py --fetch $OUT/pmc_synth200k_FETCH_SIZE --write $OUT/pmc_synth200k_WRITE_SIZE --key gridify_N200000_B8 --kernels gg_k_chunk_split:401408,gg_k_slab_build:524288,gg_k_centre_slots:401408,gg_k_query_gridify:2097152 --out $OUT/traffic.json
 cp $OUT/traffic.json profiles/traffic.json
+fi
+cd $R
 for cfg in cfg4 cfg1 cfg2 cfg3 cfg3up cfg5; do
   st=50; [ $cfg = cfg5 ] && st=10
   timeout 900 python bench.py --config $cfg --steps $st --warmup 5 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
