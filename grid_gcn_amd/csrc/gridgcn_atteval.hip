@@ -88,6 +88,14 @@ __global__ __launch_bounds__(256) void gg_k_att_max_eval(GGAttEval p)
             flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
             const float4 ge = *(const float4 *)(p.att16 + e * 16);    // (dist, gx, gy, gz)
             const float *yrow = p.Ysrc + flat * C;
+            // the neighbour's source row (this lane's 4 x NJ pieces) is requested BEFORE the MFMAs:
+            // loaded piece by piece in the epilogue, each piece was a full L2 round trip in front of
+            // 16 results (4 x NJ round trips per neighbour against 16 x NJ MFMAs)
+            float4 yq[NJ * 4];
+#pragma unroll
+            for (int t = 0; t < NJ; t++)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) yq[t * 4 + qq] = *(const float4 *)(yrow + 32 * t + 8 * qq + 4 * h);
             ggm_f32x16 acc[NJ];
             ggm_zero<NJ>(acc);
 #pragma unroll
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void gg_k_att_max_eval(GGAttEval p)
                     const float4 w0 = *(const float4 *)(cst + 2 * C + c), w1 = *(const float4 *)(cst + 3 * C + c);
                     const float4 w2 = *(const float4 *)(cst + 4 * C + c), bp = *(const float4 *)(cst + 5 * C + c);
                     const float4 sp = *(const float4 *)(cst + 6 * C + c), hp = *(const float4 *)(cst + 7 * C + c);
-                    const float4 y = *(const float4 *)(yrow + c);
+                    const float4 y = yq[t * 4 + qq];
                     const float sav[4] = {sa.x, sa.y, sa.z, sa.w}, hav[4] = {ha.x, ha.y, ha.z, ha.w};
                     const float w0v[4] = {w0.x, w0.y, w0.z, w0.w}, w1v[4] = {w1.x, w1.y, w1.z, w1.w};
                     const float w2v[4] = {w2.x, w2.y, w2.z, w2.w}, bpv[4] = {bp.x, bp.y, bp.z, bp.w};

@@ -165,6 +165,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
         ndx = cin if l > 0 else ndx0
         if not (DIRECT_DX and cout % 8 == 0 and 0 < ndx <= 256):
             ndx = 0
+        if ndx and str((ndx + 31) // 32) in os.environ.get("GG_DX_LEGACY_NT", "").split(","):   # debugging aid
+            ndx = 0
         nt = (ndx + 31) // 32
         nwdx = cout * 32 * (1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8) if ndx else 0
         pk = torch.empty(nwp + ldw + 2 * nwb + nwq + nwdx, dtype=torch.float32, device=dev)
@@ -441,7 +443,7 @@ class _MLPTrain(torch.autograd.Function):
         # register-direct kernels take this layer; otherwise it is packed first
         if not (dY.dim() == 2 and dY.stride(1) == 1 and dY.stride(0) % 4 == 0
                 and dY.storage_offset() % 4 == 0 and _dw_direct_ok(C, cin_last)
-                and DIRECT_DX and not os.environ.get("GG_DW_LDS")
+                and DIRECT_DX and not os.environ.get("GG_DW_LDS") and not os.environ.get("GG_PACK_DY")
                 and (not need_dx_last or ctx.ndx[-1] > 0)):
             dY = dY.contiguous()
         with torch.cuda.device(dev):
@@ -1560,7 +1562,7 @@ def _identity_consts(Cp, dev):
 def linear_plain_supported(x, lin):
     return (x.is_cuda and x.dtype == torch.float32 and DIRECT_FWD and DIRECT_DX
             and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and lin.out_features <= 32
-            and lin.bias is not None)
+            and lin.bias is not None and not os.environ.get("GG_NO_PLAIN"))
 
 
 class _LinearPlain(torch.autograd.Function):
@@ -1729,7 +1731,7 @@ class _HeadTrain(torch.autograd.Function):
 def head_supported(x, layers, lin):
     C = layers[-1].lin.out_features
     return (supported(layers, x) and DIRECT_FWD and DIRECT_DX and lin.bias is not None
-            and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
+            and not os.environ.get("GG_NO_HEAD") and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
 
 
 def head_train(x, layers, p, lin, seed=None, seed_dev=None):
