@@ -537,7 +537,34 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             // back to load -> s_waitcnt vmcnt(0) -> 32 MFMAs per quad, i.e. a full memory round
             // trip in front of every 2048 MFMA cycles.  The arg-max mask is applied at use, not at
             // load (a select right behind the load is a wait).
-            const int nquad = nfull * 4;
+            const int nquad = sparse ? nfull * 4 : 0;
+            if (!sparse) {
+                // dense upstream gradient: nothing conditional to load, and the chunk form (a row's
+                // 64-byte piece fetched by four back-to-back loads) measured 4 % faster than the quad
+                // pipeline here (591 -> 569 us on 655 360 x 128 -> 256)
+                for (int c = 0; c < nfull; c++) {
+                    const int k0 = c * 32 + h * 16;
+                    float4 z[4], g[4], a[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        z[q] = *(const float4 *)(zr + k0 + 4 * q);
+                        g[q] = *(const float4 *)(gr + k0 + 4 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) a[q] = dz4(z[q], g[q], k0 + 4 * q);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            float b[NTV];
+                            gg_ldb<NTV>(Wl, s * 64 + lane, b);
+#pragma unroll
+                            for (int t = 0; t < NT; t++)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
+                            s++;
+                        }
+                }
+            }
             float4 zc = make_float4(0.f, 0.f, 0.f, 0.f), gc = zc;
             unsigned amc = 0;
             if (nquad > 0) {
@@ -567,7 +594,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                 }
                 zc = zn; gc = gn; amc = amn;
             }
-            s = nquad * 4;
+            if (sparse) s = nquad * 4;
         }
         if (ktail) {
             const int nq = ktail >> 3;
@@ -705,11 +732,11 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
         q.dx_col0 = 128;
         return launch_dx_direct<4>(q, st);
     }
-    // workgroups that are RESIDENT per CU (registers, fp32 form: 127 at NT = 1 -> four 4-wave groups;
-    // 154 at NT = 2 -> three; > 128 for the 8-wave groups of NT >= 3 -> one; the bf16 form, 213 / 235,
-    // two): a grid beyond that runs a second, partly filled round (measured on the fused
-    // attention backward: 1.30 -> 1.06 ms)
-    int per_cu = NT == 1 ? (bf16 ? 2 : 4) : (NT == 2 ? (bf16 ? 2 : 3) : 1);
+    // workgroups that are RESIDENT per CU (registers: 167 at NT = 1 -> three 4-wave groups; 170 at
+    // NT = 2 -> two, as the bf16 form at either; > 128 for the 8-wave groups of NT >= 3 -> one): a grid
+    // beyond that runs a second, partly filled round (measured on the fused attention backward:
+    // 1.30 -> 1.06 ms)
+    int per_cu = NT == 1 ? (bf16 ? 2 : 3) : (NT == 2 ? 2 : 1);
     while (per_cu > 1 && per_cu * lds > 152 * 1024) per_cu--;
     const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
