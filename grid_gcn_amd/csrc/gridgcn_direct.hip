@@ -542,13 +542,33 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                 // dense upstream gradient: nothing conditional to load, and the chunk form (a row's
                 // 64-byte piece fetched by four back-to-back loads) measured 4 % faster than the quad
                 // pipeline here (591 -> 569 us on 655 360 x 128 -> 256)
-                for (int c = 0; c < nfull; c++) {
-                    const int k0 = c * 32 + h * 16;
-                    float4 z[4], g[4], a[4];
+                // 2-4 column tiles: registers for the NEXT chunk's eight float4 as well (requested
+                // before this chunk's 16 * NT MFMAs)
+                constexpr bool DB = NT >= 2 && NT <= 4;
+                float4 z[4], g[4], zn[4], gn[4];
+                if (DB && nfull > 0) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        z[q] = *(const float4 *)(zr + k0 + 4 * q);
-                        g[q] = *(const float4 *)(gr + k0 + 4 * q);
+                        z[q] = *(const float4 *)(zr + h * 16 + 4 * q);
+                        g[q] = *(const float4 *)(gr + h * 16 + 4 * q);
+                    }
+                }
+                for (int c = 0; c < nfull; c++) {
+                    const int k0 = c * 32 + h * 16;
+                    float4 a[4];
+                    if constexpr (DB) {
+                        const int kn = (c + 1 < nfull ? c + 1 : c) * 32 + h * 16;   // (last: a harmless re-read)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            zn[q] = *(const float4 *)(zr + kn + 4 * q);
+                            gn[q] = *(const float4 *)(gr + kn + 4 * q);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            z[q] = *(const float4 *)(zr + k0 + 4 * q);
+                            g[q] = *(const float4 *)(gr + k0 + 4 * q);
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < 4; q++) a[q] = dz4(z[q], g[q], k0 + 4 * q);
@@ -563,6 +583,10 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
                             s++;
                         }
+                    if constexpr (DB) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { z[q] = zn[q]; g[q] = gn[q]; }
+                    }
                 }
             }
             float4 zc = make_float4(0.f, 0.f, 0.f, 0.f), gc = zc;
