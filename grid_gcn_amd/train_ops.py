@@ -41,6 +41,12 @@ import os  # noqa: E402
 # register-direct forward kernel (csrc/gridgcn_direct.hip) for inputs whose width is a multiple of 8
 DIRECT_FWD = os.environ.get("GG_FWD_LDS", "0") != "1"
 DIRECT_DX = os.environ.get("GG_DX_LDS", "0") != "1"
+# bisecting aids (tools/dbg_step_parity.py): legacy dX for given column-tile counts, packed (not strided)
+# upstream gradients, no plain-Linear kernel path, no fused head
+_DX_LEGACY_NT = set(os.environ.get("GG_DX_LEGACY_NT", "").split(",")) - {""}
+_PACK_DY = bool(os.environ.get("GG_PACK_DY"))
+_NO_PLAIN = bool(os.environ.get("GG_NO_PLAIN"))
+_NO_HEAD = bool(os.environ.get("GG_NO_HEAD"))
 # first conv of the point MLP applied to the source points and gathered (csrc/gridgcn_edgelin.hip)
 SRC_FIRST_CONV = os.environ.get("GG_EDGE_GEMM", "0") != "1"
 # ... and, for single-layer point MLPs, recomputed by its consumers instead of stored
@@ -165,7 +171,7 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
         ndx = cin if l > 0 else ndx0
         if not (DIRECT_DX and cout % 8 == 0 and 0 < ndx <= 256):
             ndx = 0
-        if ndx and str((ndx + 31) // 32) in os.environ.get("GG_DX_LEGACY_NT", "").split(","):   # debugging aid
+        if ndx and str((ndx + 31) // 32) in _DX_LEGACY_NT:
             ndx = 0
         nt = (ndx + 31) // 32
         nwdx = cout * 32 * (1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8) if ndx else 0
@@ -443,7 +449,7 @@ class _MLPTrain(torch.autograd.Function):
         # register-direct kernels take this layer; otherwise it is packed first
         if not (dY.dim() == 2 and dY.stride(1) == 1 and dY.stride(0) % 4 == 0
                 and dY.storage_offset() % 4 == 0 and _dw_direct_ok(C, cin_last)
-                and DIRECT_DX and not os.environ.get("GG_DW_LDS") and not os.environ.get("GG_PACK_DY")
+                and DIRECT_DX and not os.environ.get("GG_DW_LDS") and not _PACK_DY
                 and (not need_dx_last or ctx.ndx[-1] > 0)):
             dY = dY.contiguous()
         with torch.cuda.device(dev):
@@ -1562,7 +1568,7 @@ def _identity_consts(Cp, dev):
 def linear_plain_supported(x, lin):
     return (x.is_cuda and x.dtype == torch.float32 and DIRECT_FWD and DIRECT_DX
             and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and lin.out_features <= 32
-            and lin.bias is not None and not os.environ.get("GG_NO_PLAIN"))
+            and lin.bias is not None and not _NO_PLAIN)
 
 
 class _LinearPlain(torch.autograd.Function):
@@ -1731,7 +1737,7 @@ class _HeadTrain(torch.autograd.Function):
 def head_supported(x, layers, lin):
     C = layers[-1].lin.out_features
     return (supported(layers, x) and DIRECT_FWD and DIRECT_DX and lin.bias is not None
-            and not os.environ.get("GG_NO_HEAD") and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
+            and not _NO_HEAD and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
 
 
 def head_train(x, layers, p, lin, seed=None, seed_dev=None):
