@@ -1062,6 +1062,191 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             for (int r = 0; r < 16; r++) out[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
 }
 
+// ------------------------------------------------------------------------------------------
+// EXPERIMENTAL -- selected with GG_DW_SHARED=1, off by default: the dW kernel with its B operand staged
+// ONCE per row stream through LDS.  Motive (profiles/r2_pmc_bwd_gemm.txt): in gg_k_linear_dw_direct
+// the MG m-group waves of a stream each load the same input rows (2 KB per 8 MFMAs at cin = 256) and
+// apply the previous layer's BatchNorm+ReLU to them again; a wave waits 69 % of its life and issues
+// 9 VALU instructions per MFMA.  Here the MG waves of a stream copy a block of 32 rows x cin
+// (activation applied once, while copying) into one of two LDS buffers while they consume the other;
+// the B operands of a step are then one or two ds_read_b128 per lane.  Z / upstream-gradient values
+// (the A operand: distinct channels per wave) stay per-step register loads, D sets deep.  Same partial
+// layout as gg_k_linear_dw_direct (gg_k_dw_reduce_direct finishes).  cin in {64, 128, 256}, MG >= 2.
+// Status at the end of round 2: passes tests/test_gpu_train_ops.py; 547 us against 540-578 us for the
+// register form on 655 360 x 256 -> 128, 277 against 264-271 us on 128 -> 128 -- the redundant reads
+// of the input rows were NOT what the waves wait for.  What is left per step are the three 4-byte-per-
+// lane loads of the A operand (z, gradient, arg max: 256 useful bytes per instruction), four steps
+// deep with no registers for more: the next form stages those through LDS as well, both operands by
+// global_load ... lds several blocks ahead.
+template <int MT, int NQ, int NP, bool PT8>
+__global__ __launch_bounds__(512, 1) void gg_k_linear_dw_shared(GGLinBwd p, int MG, int RS,
+                                                                 long long rows_per_wg)
+{
+    constexpr int NJ = 4 * NQ + 2 * NP;
+    constexpr int RB = 32, PT = PT8 ? 8 : 4;     // rows per block (16 MFMA steps); float4 pieces per thread
+    constexpr int D = 4;                         // register sets of the A-operand loads (divides 16)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cq = lane & 31, h = lane >> 5;
+    const int mg = wave % MG, rs = wave / MG;
+    const int C = p.C, cin = p.cin;
+    const bool prevbn = p.pscale != nullptr, sparse = p.amax != nullptr;
+
+    const long long wa = (long long)blockIdx.x * rows_per_wg;
+    const long long wb = wa + rows_per_wg < p.E ? wa + rows_per_wg : p.E;
+    const long long per = ((wb - wa + RS - 1) / RS + 1) & ~1ll;
+    long long ra = wa + rs * per;
+    const long long rb = ra + per < wb ? ra + per : wb;
+    if (ra > rb) ra = rb;
+    const int nrows = (int)(rb - ra);                     // rows of this stream
+    const int nblk = (int)((per + RB - 1) / RB);          // the same for every stream of the workgroup
+
+    // ---- staging map: the stream's 64*MG threads copy RB x cin floats as float4 pieces; piece k of
+    //      a thread = row srow + rstep*k, columns scol..scol+3 (the column is fixed per thread)
+    float *L0 = lds + (size_t)rs * 2 * RB * cin;
+    const int ts = 64 * MG, tl = mg * 64 + lane, Q = cin >> 2;
+    const int srow = tl / Q, scol = (tl - srow * Q) * 4, rstep = ts / Q;
+    float4 psc4 = make_float4(0.f, 0.f, 0.f, 0.f), psh4 = psc4;
+    if (prevbn) { psc4 = *(const float4 *)(p.pscale + scol); psh4 = *(const float4 *)(p.pshift + scol); }
+    const float *alast = p.Aprev + (p.E - 1) * cin + scol;
+    auto stage_load = [&](float4 (&st)[PT], int b) {
+        const long long r0 = ra + (long long)b * RB + srow;
+        const float *a = p.Aprev + r0 * cin + scol;
+#pragma unroll
+        for (int k = 0; k < PT; k++) {                    // (rows past the end of X: its last row, unused)
+            const bool in = r0 + rstep * k < p.E;
+            st[k] = *(const float4 *)(in ? a + (size_t)rstep * k * cin : alast);
+        }
+    };
+    auto stage_store = [&](const float4 (&st)[PT], float *Lb) {
+#pragma unroll
+        for (int k = 0; k < PT; k++) {
+            float4 v = st[k];
+            if (prevbn) {
+                v.x = fmaxf(v.x * psc4.x + psh4.x, 0.f); v.y = fmaxf(v.y * psc4.y + psh4.y, 0.f);
+                v.z = fmaxf(v.z * psc4.z + psh4.z, 0.f); v.w = fmaxf(v.w * psc4.w + psh4.w, 0.f);
+            }
+            *(float4 *)(Lb + (srow + rstep * k) * cin + scol) = v;
+        }
+    };
+
+    // ---- A operand: per-lane constants and pointers (as gg_k_linear_dw_direct)
+    const int chA = mg * 32 * MT + MT * cq;
+    float sc[MT], sh[MT], mu[MT], bz[MT], cz[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int c = chA + i;
+        const bool ok = c < C;
+        const float s = ok ? p.scale[c] : 0.f;
+        sc[i] = s; sh[i] = ok ? p.shift[c] : 0.f; mu[i] = ok ? p.mean[c] : 0.f;
+        bz[i] = ok ? -(s * p.rstd[c]) * p.m2[c] : 0.f;
+        cz[i] = ok ? -(s * p.m1[c]) : 0.f;
+    }
+    const bool chok = chA + MT - 1 < C;
+    const int chl = chok ? chA : 0;
+    const int Pq = sparse ? p.P : (1 << 30);
+    long long cen = 0;
+    int pp = 0;
+    if (sparse) {
+        const long long r = ra + h;
+        cen = r / p.P;
+        pp = (int)(r - cen * p.P);
+    }
+    const float *zp = p.Z + (ra + h) * C + chl;
+    const float *zlast = p.Z + (p.E - 1) * C + chl;
+    const float *gp = sparse ? p.gval + cen * C + chl : p.dY + (ra + h) * p.ldy + chl;
+    const float *glast = sparse ? p.gval + chl : p.dY + (p.E - 1) * p.ldy + chl;
+    const gg_amax_t *ap = sparse ? p.amax + cen * C + chl : (const gg_amax_t *)p.Z;
+    const gg_amax_t *aplast = sparse ? p.amax + chl : (const gg_amax_t *)p.Z;
+    const int ginc = sparse ? 0 : 2 * p.ldy, Cs = sparse ? C : 0;
+    struct Regs { float z[MT], g[MT]; int am[MT], pp; bool ok; };
+    int srows = h;                                        // 2*step + h of the next step to load
+    auto load_zg = [&](Regs &R) {                         // one call per step, ascending
+        const bool ok = srows < nrows;
+        const float *zq = ok ? zp : zlast, *gq = ok ? gp : glast;
+        const gg_amax_t *aq = ok ? ap : aplast;
+        if constexpr (MT == 2) {
+            const float2 t = *(const float2 *)zq, u = *(const float2 *)gq;
+            const unsigned short a2 = *(const unsigned short *)aq;
+            R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y; R.am[0] = a2 & 255; R.am[1] = a2 >> 8;
+        } else {
+            R.z[0] = zq[0]; R.g[0] = gq[0]; R.am[0] = aq[0];
+        }
+        R.pp = pp;
+        R.ok = ok;
+        srows += 2;
+        zp += 2 * C;
+        pp += 2;
+        const bool t1 = pp >= Pq;
+        pp -= t1 ? Pq : 0;
+        const bool t2 = pp >= Pq;
+        pp -= t2 ? Pq : 0;
+        const int adv = (t1 ? 1 : 0) + (t2 ? 1 : 0);
+        gp += ginc + adv * Cs;
+        ap += adv * Cs;
+    };
+
+    ggm_f32x16 acc[MT][NJ];
+#pragma unroll
+    for (int i = 0; i < MT; i++) ggm_zero<NJ>(acc[i]);
+    auto compute = [&](const Regs &R, const float *Lb, int d) {
+        float dz[MT], xa[NJ];
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const float g = (!sparse || R.am[i] == R.pp) ? R.g[i] : 0.f;
+            const float dv = sc[i] * ((R.z[i] * sc[i] + sh[i] > 0.f) ? g : 0.f) +
+                             ((R.z[i] - mu[i]) * bz[i] + cz[i]);
+            dz[i] = (R.ok && chok) ? dv : 0.f;
+        }
+        const float *lr = Lb + (2 * d + h) * cin;
+        int j = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const float4 t = *(const float4 *)(lr + q * 128 + 4 * cq);
+            xa[j++] = t.x; xa[j++] = t.y; xa[j++] = t.z; xa[j++] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const float2 t = *(const float2 *)(lr + NQ * 128 + 2 * cq);
+            xa[j++] = t.x; xa[j++] = t.y;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int jj = 0; jj < NJ; jj++)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[i], xa[jj], acc[i][jj], 0, 0, 0);
+    };
+
+    Regs R[D];
+    float4 st[PT];
+    stage_load(st, 0);
+#pragma unroll
+    for (int d = 0; d < D - 1; d++) load_zg(R[d]);        // steps 0 .. D-2
+    stage_store(st, L0);
+    __syncthreads();
+    for (int b = 0; b < nblk; b++) {
+        const float *Lb = L0 + (b & 1) * RB * cin;
+        stage_load(st, b + 1 < nblk ? b + 1 : b);         // (last block: a harmless re-read)
+#pragma unroll
+        for (int d = 0; d < 16; d++) {
+            load_zg(R[(d + D - 1) % D]);                  // step 16b + d + D - 1
+            compute(R[d % D], Lb, d);
+        }
+        // the other buffer was last read in block b - 1, which every wave has left (barrier below)
+        stage_store(st, L0 + ((b + 1) & 1) * RB * cin);
+        __syncthreads();
+    }
+
+    const long long wg = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    float *out = p.dWpart + wg * (MT * NJ * 1024) + lane;
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) out[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
+}
+
 // dW[c][framework col] = sum over the waves of m-group mg(c) of their partial element.
 // thread = one partial element (tile, reg, lane) of one m-group; block = 64 elements x 16 wave
 // slices (the partials are a few tens of MB: enough loads in flight to stream them at HBM speed).
@@ -1143,9 +1328,36 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C)
     return (size_t)c.nwg * (c.threads / 64) * c.MT * (4 * c.NQ + 2 * c.NP + c.NS) * 1024 * sizeof(float);
 }
 
+// GG_DW_SHARED=1: shapes the experimental LDS-staged form takes (see gg_k_linear_dw_shared)
+template <int MT, int NQ, int NP>
+static int launch_dw_shared(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
+{
+    const int ts = 64 * c.MG, Q = p.cin / 4;
+    const int pt = 32 * Q / ts;
+    const size_t lds = (size_t)c.RS * 2 * 32 * p.cin * sizeof(float);
+    if (c.MG < 2 || ts % Q || (pt != 4 && pt != 8) || lds > 64 * 1024) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_linear_dw_shared<MT, NQ, NP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)gg_k_linear_dw_shared<MT, NQ, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            return 3;
+        attr_done = true;
+    }
+    if (pt == 8) gg_k_linear_dw_shared<MT, NQ, NP, true><<<c.nwg, c.threads, lds, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+    else gg_k_linear_dw_shared<MT, NQ, NP, false><<<c.nwg, c.threads, lds, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 template <int MT, int NQ, int NP, int NS>
 static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
 {
+    static const bool shared_form = [] { const char *e = getenv("GG_DW_SHARED"); return e && e[0] == '1'; }();
+    if constexpr (NS == 0 && ((NQ == 2 && NP == 0) || (NQ == 1 && NP == 0) || (NQ == 0 && NP == 1))) {
+        if (shared_form && !(g_mlp_bf16 && p.pscale)) {
+            const int rc = launch_dw_shared<MT, NQ, NP>(p, c, st);
+            if (rc != 1) return rc;                       // 1: not its shape -> the register form below
+        }
+    }
     if (g_mlp_bf16 && p.pscale)   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
         gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
     else
