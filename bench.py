@@ -249,8 +249,12 @@ def main():
         import bench_configs
         out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step)
         if rank == 0:
-            print(json.dumps(out))
+            print(json.dumps(out), flush=True)
         if world > 1:
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -461,8 +465,14 @@ def main():
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, B, points, kind, a.cpu_sample)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        # teardown order: the step's graph (it holds the captured all-reduce) before the communicator
+        del step
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -9,9 +9,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GG_HIP_LIB: profiling variant of the same library (lib/libgridgcn_hip_prof.so, tools/prof_phases.py)
 LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
+ABI_VERSION = 4                 # include/gridgcn.h: gridgcn_abi_version()
+OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
+
 EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",
-    "gridgcn_get_mlp_precision",
+    "gridgcn_get_mlp_precision", "gridgcn_set_option", "gridgcn_get_option",
     "gridgcn_gridify_workspace_bytes", "gridgcn_gridify", "gridgcn_gridify_timed",
     "gridgcn_gridify_occaware_workspace_bytes", "gridgcn_gridify_occaware",
     "gridgcn_gridify_fast_rand_workspace_bytes", "gridgcn_gridify_fast_rand",
@@ -35,7 +38,6 @@ EXPORTS = [
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
     "gridgcn_linear_fwd_direct2", "gridgcn_ctx_max", "gridgcn_ctx_max_backward",
     "gridgcn_bn_dz_segsum", "gridgcn_sparse_add", "gridgcn_bn_stats",
-    "gridgcn_att_max_train", "gridgcn_att_bwd_recomp",
 ]
 
 
@@ -75,6 +77,14 @@ def load():
     lib.gridgcn_strerror.restype = ctypes.c_char_p
     lib.gridgcn_strerror.argtypes = [ci]
     lib.gridgcn_abi_version.restype = ci
+    if lib.gridgcn_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s is ABI v%d, this package needs v%d: rebuild it "
+                           "(python -m grid_gcn_amd.build --force)"
+                           % (LIB_PATH, lib.gridgcn_abi_version(), ABI_VERSION))
+    lib.gridgcn_set_option.restype = ci
+    lib.gridgcn_set_option.argtypes = [ci, ci]
+    lib.gridgcn_get_option.restype = ci
+    lib.gridgcn_get_option.argtypes = [ci]
     lib.gridgcn_set_mlp_precision.restype = ci
     lib.gridgcn_set_mlp_precision.argtypes = [ci]
     lib.gridgcn_get_mlp_precision.restype = ci
@@ -154,11 +164,6 @@ def load():
     lib.gridgcn_ctx_max_backward.argtypes = [vp, vp, ll, ci, ci, vp, vp]
     lib.gridgcn_bn_dz_segsum.restype = ci
     lib.gridgcn_bn_dz_segsum.argtypes = [vp] * 8 + [ll, ci, ci, vp, vp]
-    lib.gridgcn_att_max_train.restype = ci
-    lib.gridgcn_att_max_train.argtypes = [vp] * 14 + [ci] * 6 + [vp, ci, vp, vp, vp]
-    lib.gridgcn_att_bwd_recomp.restype = ci
-    lib.gridgcn_att_bwd_recomp.argtypes = [vp] * 15 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, cs,
-                                           vp]
     lib.gridgcn_bn_stats.restype = ci
     lib.gridgcn_bn_stats.argtypes = [vp, ll, ci, ci, vp, vp]
     lib.gridgcn_sparse_add.restype = ci

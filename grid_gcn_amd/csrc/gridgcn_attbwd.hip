@@ -318,255 +318,6 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// The same backward WITHOUT the layer's pre-activation Z in memory: the training forward of the up
-// layers never writes the [E, C] attention tensor (gg_k_att_max_train), so it is recomputed here,
-// tile by tile, from the previous layer's raw output Z1 [E, cin] (which both the dW product and the
-// epilogue read anyway).  Per 32-row tile a wave
-//   1. loads Z1 twice -- once row-wise (A operand of the recompute GEMM: lane = row, cin/2
-//      consecutive k's of its half), once in the C/D order (lane = input channel, 16 rows) --
-//   2. Z2 = act(Z1) W2^T on cin/2 MFMA steps per column tile: the result is in the C/D order, lane =
-//      OUTPUT channel, so the BatchNorm/ReLU backward runs with per-lane constants and the sparse
-//      upstream gradient is one (amax, gval) pair per (row, lane),
-//   3. dW^T += act(Z1)^T dZ straight from registers (A = the C/D-order Z1 tile, B = the C/D-order dZ
-//      tile: both index the contraction by the same (register, half) -> row map),
-//   4. transposes dZ through its LDS half tile (written column-wise, read row-wise) for the dX GEMM
-//      (contraction over the channels), then the usual epilogue.
-// 3 x 16 x NJ MFMAs per tile instead of 2 x, about a third of the bytes.
-template <int NJ>
-__global__ __launch_bounds__(256, 2) void gg_k_att_bwd_recomp(GGLinBwd p, const float *__restrict__ W2,
-                                                             const float *__restrict__ b2)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int C = NJ * 32;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int cin = p.cin, kh = cin >> 1;              // k's per lane half: 16 or 8
-    const bool colok = l31 < cin;
-    float *Wl = lds;                                   // Wdx: [C/2 steps][64]
-    float *Wr = lds + C * 32;                          // recompute operand [kh steps][64][NJ]
-    float *pb1 = Wr + 16 * 64 * NJ;                    // previous BatchNorm: scale, shift  [2][32]
-    float *T = pb1 + 64 + wave * (32 * GG_AF_TS);
-    {
-        const float4 *src = (const float4 *)p.Wdx;
-        for (int i = tid; i < C * 8; i += 256) ((float4 *)Wl)[i] = src[i];
-        if (tid < 64) pb1[tid] = (tid & 31) < cin ? (tid < 32 ? p.pscale[tid] : p.pshift[tid - 32]) : 0.f;
-        for (int i = tid; i < kh * 64 * NJ; i += 256) {
-            const int t = i % NJ, ln = (i / NJ) & 63, s_ = i / (NJ * 64);
-            Wr[i] = W2[(32 * t + (ln & 31)) * cin + kh * (ln >> 5) + s_];
-        }
-    }
-    __syncthreads();
-    // this lane's output channels: 32t + l31
-    float sc[NJ], sh[NJ], mu[NJ], bz[NJ], cz[NJ], bb[NJ];
-#pragma unroll
-    for (int t = 0; t < NJ; t++) {
-        const int c = 32 * t + l31;
-        sc[t] = p.scale[c]; sh[t] = p.shift[c]; mu[t] = p.mean[c];
-        bz[t] = -(sc[t] * p.rstd[c]) * p.m2[c];
-        cz[t] = -(sc[t] * p.m1[c]);
-        bb[t] = b2[c];
-    }
-    const float ps = colok ? p.pscale[l31] : 0.f, psh = colok ? p.pshift[l31] : 0.f;
-    const float pm = colok ? p.pmean[l31] : 0.f, pr = colok ? p.prstd[l31] : 0.f;
-    float a1 = 0.f, a2 = 0.f;
-    ggm_f32x16 accw[NJ];
-    ggm_zero<NJ>(accw);
-    const long long ntile = (p.E + 31) >> 5;
-    const bool sparse = p.amax != nullptr;
-
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile;
-         tile += (long long)gridDim.x * 4) {
-        const long long r0 = tile << 5;
-        const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        long long row = r0 + l31;
-        if (row >= p.E) row = p.E - 1;
-        // ---- Z1, row-wise: A operand of the recompute ----
-        float hv[16];
-        {
-            const float *zr = p.Aprev + row * cin + kh * h;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (4 * q < kh) {
-                    const float4 z = *(const float4 *)(zr + 4 * q);
-                    const float4 rs = *(const float4 *)(pb1 + kh * h + 4 * q);
-                    const float4 rh = *(const float4 *)(pb1 + 32 + kh * h + 4 * q);
-                    hv[4 * q + 0] = fmaxf(z.x * rs.x + rh.x, 0.f);
-                    hv[4 * q + 1] = fmaxf(z.y * rs.y + rh.y, 0.f);
-                    hv[4 * q + 2] = fmaxf(z.z * rs.z + rh.z, 0.f);
-                    hv[4 * q + 3] = fmaxf(z.w * rs.w + rh.w, 0.f);
-                } else {
-                    hv[4 * q + 0] = 0.f; hv[4 * q + 1] = 0.f; hv[4 * q + 2] = 0.f; hv[4 * q + 3] = 0.f;
-                }
-            }
-        }
-        // ---- Z1 in the C/D order: rows (r&3) + 8(r>>2) + 4h, column l31 ----
-        const long long base = (r0 + 4 * h) * cin + l31;
-        float zpv[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            const bool ok = colok && (nrows == 32 || rr + 4 * h < nrows);
-            zpv[r] = ok ? p.Aprev[base + rr * cin] : 0.f;
-        }
-        // ---- Z2 tile, then dZ in place ----
-        ggm_f32x16 dz[NJ];
-        ggm_zero<NJ>(dz);
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            if (s < kh) {
-                float w[NJ];
-                if constexpr (NJ == 4) {
-                    const float4 t4 = *(const float4 *)(Wr + (s * 64 + lane) * 4);
-                    w[0] = t4.x; w[1] = t4.y; w[2] = t4.z; w[3] = t4.w;
-                } else {
-                    const float2 t2 = *(const float2 *)(Wr + (s * 64 + lane) * 2);
-                    w[0] = t2.x; w[1] = t2.y;
-                }
-#pragma unroll
-                for (int t = 0; t < NJ; t++)
-                    dz[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(hv[s], w[t], dz[t], 0, 0, 0);
-            }
-        }
-        // (one 64-bit division per tile; the rows' centres follow with 32-bit arithmetic)
-        const long long cen0 = sparse ? r0 / p.P : 0;
-        const int rem0 = sparse ? (int)(r0 - cen0 * p.P) : 0;
-        const float invP = 1.0f / (float)p.P;
-        // the (gval, amax) rows of the tile's centres, staged in this wave's LDS tile (free until the
-        // transposition below) with a few wide loads: per (row, channel) reads then cost LDS latency
-        const int ncen = sparse ? (rem0 + nrows - 1) / p.P + 1 : 0;
-        const bool stg = sparse && ncen * C * 5 <= 32 * GG_AF_TS * 4;
-        float *sgv = T;
-        gg_amax_t *sam = (gg_amax_t *)(T + ncen * C);
-        if (stg) {
-            const float4 *g4 = (const float4 *)(p.gval + cen0 * C);
-            for (int i = lane; i < ncen * (C / 4); i += 64) ((float4 *)sgv)[i] = g4[i];
-            const unsigned *a4 = (const unsigned *)(p.amax + cen0 * C);
-            for (int i = lane; i < ncen * (C / 4); i += 64) ((unsigned *)sam)[i] = a4[i];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool rok = rr < nrows;
-            const int ro = rok ? rr : 0;
-            const int tq = rem0 + ro;
-            const int oc = (int)(((float)tq + 0.5f) * invP);        // exact for tq < 2^22
-            const int pp = tq - oc * p.P;
-            const float *gvr = stg ? sgv + oc * C + l31 : p.gval + (cen0 + oc) * C + l31;
-            const gg_amax_t *amr = stg ? sam + oc * C + l31 : p.amax + (cen0 + oc) * C + l31;
-            const float *dyr = p.dY + (r0 + ro) * p.ldy + l31;
-#pragma unroll
-            for (int t = 0; t < NJ; t++) {
-                float g;
-                if (sparse) {
-                    const float gv = gvr[32 * t];
-                    g = ((int)amr[32 * t] == pp) ? gv : 0.f;
-                } else {
-                    g = dyr[32 * t];
-                }
-                const float z = dz[t][r] + bb[t];
-                const float d = sc[t] * ((z * sc[t] + sh[t] > 0.f) ? g : 0.f) + ((z - mu[t]) * bz[t] + cz[t]);
-                dz[t][r] = rok ? d : 0.f;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- dW^T += act(Z1)^T dZ (registers only) ----
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float av = fmaxf(zpv[r] * ps + psh, 0.f);    // 0 in the idle columns / rows past E
-#pragma unroll
-            for (int t = 0; t < NJ; t++)
-                accw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dz[t][r], accw[t], 0, 0, 0);
-        }
-        // ---- dX = dZ W2: dZ transposed through LDS, 64 channels at a time ----
-        ggm_f32x16 accx;
-#pragma unroll
-        for (int r = 0; r < 16; r++) accx[r] = 0.f;
-        int s = 0;
-#pragma unroll
-        for (int hc = 0; hc < NJ / 2; hc++) {
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    T[((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + cc * 32 + l31] = dz[2 * hc + cc][r];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-                float4 a[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) a[q] = *(const float4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q);
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_af_f4(a[q], i), Wl[s * 64 + lane],
-                                                                    accx, 0, 0, 0);
-                        s++;
-                    }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        // ---- dX tile + BatchNorm-backward sums of the previous layer ----
-        float *xp = p.dX + base;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            if (colok && (nrows == 32 || rr + 4 * h < nrows)) {
-                const float dx = accx[r];
-                xp[rr * cin] = dx;
-                const float d = (zpv[r] * ps + psh > 0.f) ? dx : 0.f;
-                s1 += d;
-                s2 += d * ((zpv[r] - pm) * pr);
-            }
-        }
-        a1 += s1;
-        a2 += s2;
-    }
-    // dW^T partials: as gg_k_att_bwd_fused
-    {
-        float *blk = Wr;                               // NJ*1024 floats over the recompute operand
-        __syncthreads();
-        for (int w = 0; w < 4; w++) {
-            if (wave == w) {
-#pragma unroll
-                for (int j = 0; j < NJ; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int idx = (j * 16 + r) * 64 + lane;
-                        blk[idx] = (w == 0 ? 0.f : blk[idx]) + accw[j][r];
-                    }
-            }
-            __syncthreads();
-        }
-        float *part = p.dWpart + (size_t)blockIdx.x * NJ * 1024;
-        for (int i = tid; i < NJ * 1024; i += 256) part[i] = blk[i];
-    }
-    __syncthreads();
-    float *red = lds;
-    {
-        const float t1 = a1 + __shfl_xor(a1, 32, 64);
-        const float t2 = a2 + __shfl_xor(a2, 32, 64);
-        if (lane < 32) {
-            red[(wave * 2 + 0) * 32 + lane] = t1;
-            red[(wave * 2 + 1) * 32 + lane] = t2;
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const int which = tid >> 5, col = tid & 31;
-        float v = 0.f;
-        for (int w = 0; w < 4; w++) v += red[(w * 2 + which) * 32 + col];
-        if (col < cin) atomicAdd(&p.psums[which * cin + col], (double)v);
-    }
-}
-
 // dW[ch][i] = sum over workgroups of the partial D tiles: tile j, lane l, reg r hold dW^T[i][ch] with
 // ch = 32j + (l & 31), i = (r & 3) + 8(r >> 2) + 4(l >> 5).  One 1024-thread workgroup per (j, r):
 // 16 groups of 64 lanes each sum a slice of the waves, LDS adds the groups (deterministic order).
@@ -637,29 +388,4 @@ int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st)
     if (p.cin_w != p.cin || p.rot != 0 || p.drop_thr) return 1;
     if (!p.amax && (p.ldy & 3)) return 1;
     return p.C == 64 ? launch_att_fused<2>(p, st) : launch_att_fused<4>(p, st);
-}
-
-// Z-less form (gg_k_att_bwd_recomp): W2 [C][cin] torch layout, b2 [C].  1 = other shape.
-int gg_att_bwd_recomp(const GGLinBwd &p, const float *W2, const float *b2, hipStream_t st)
-{
-    if (!gg_att_bwd_fused_ok(p.E, p.cin, p.C) || gg_get_mlp_bf16()) return 1;
-    if (!W2 || !b2 || !p.Wdx || p.ndx != p.cin || !p.dX || !p.dW || !p.dWpart || !p.pscale ||
-        !p.psums || !p.Aprev)
-        return 1;
-    if (p.cin_w != p.cin || p.rot != 0 || p.drop_thr || (!p.amax && !p.dY)) return 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_recomp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)gg_k_att_bwd_recomp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-            return 3;
-        attr_done = true;
-    }
-    const int NJ = p.C / 32;
-    const size_t lds = ((size_t)p.C * 32 + (size_t)16 * 64 * NJ + 64 + 4 * 32 * GG_AF_TS) * sizeof(float);
-    const int grid = gg_att_fused_grid(p.E, p.C);
-    if (NJ == 2) gg_k_att_bwd_recomp<2><<<grid, 256, lds, st>>>(p, W2, b2);
-    else gg_k_att_bwd_recomp<4><<<grid, 256, lds, st>>>(p, W2, b2);
-    if (hipGetLastError() != hipSuccess) return 3;
-    gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.cin, p.dW);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
 }

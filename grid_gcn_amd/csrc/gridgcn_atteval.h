@@ -19,8 +19,3 @@ struct GGAttEval {
 };
 
 int gg_att_max_eval(const GGAttEval &p, int C, hipStream_t st);   // 1 = shape not supported
-// training form: batch-statistics vectors in s1/h1/sa/ha/sp/hp, + arg max (one byte) and the two
-// pre-activations at the arg max, zsel[2][E/P][C]
-// (Z1 rows of cin = 16 or 32 floats, W2 [C][cin])
-int gg_att_max_train(const GGAttEval &p, int C, int cin, unsigned char *amax, float *zsel,
-                     hipStream_t st);

@@ -154,155 +154,6 @@ __global__ __launch_bounds__(256) void gg_k_att_max_eval(GGAttEval p)
     }
 }
 
-// ---- training form -------------------------------------------------------------------------
-// The same transposed product with batch-statistics BatchNorm vectors (the statistics of the second
-// attention conv come from a store-less pass of the forward GEMM kernel), plus what the backward
-// needs: the arg-max neighbour (one byte) and the two pre-activations at the arg max.  The [E, C]
-// attention tensor is not written in training either.  A wave handles 32 channels at a time (C/32
-// passes over its 32 centres: running max, arg max and two pre-activations of one column tile are
-// 16 + 4 + 16 + 16 registers, which keeps three waves per SIMD), re-reading the centres' Z1 rows
-// from L1/L2.  Update rule of gg_k_pairmax_fwd4_src: first maximum wins.
-__global__ __launch_bounds__(256, 3) void gg_k_att_max_train(GGAttEval p, int C, int cin,
-                                                             unsigned char *__restrict__ amax,
-                                                             float *__restrict__ zsel)
-{
-    extern __shared__ __attribute__((aligned(16))) float atl[];
-    const int NJ = C >> 5, kh = cin >> 1;              // k's per lane half: 16 or 8
-    float *Wz = atl;                       // [16 steps][64 lanes][NJ]
-    float *cst = atl + 16 * 64 * NJ;       // sa, ha, b2, w0, w1, w2, bp, sp, hp  [9][C]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, l31 = lane & 31;
-    for (int i = tid; i < kh * 64 * NJ; i += 256) {
-        const int t = i % NJ, ln = (i / NJ) & 63, s = i / (NJ * 64);
-        Wz[i] = p.W2[(32 * t + (ln & 31)) * cin + kh * (ln >> 5) + s];
-    }
-    for (int c = tid; c < C; c += 256) {
-        cst[c] = p.sa[c];
-        cst[C + c] = p.ha[c];
-        cst[2 * C + c] = p.b2[c];
-        cst[3 * C + c] = p.Wg ? p.Wg[c] : 0.f;
-        cst[4 * C + c] = p.Wg ? p.Wg[C + c] : 0.f;
-        cst[5 * C + c] = p.Wg ? p.Wg[2 * C + c] : 0.f;
-        cst[6 * C + c] = p.bp[c];
-        cst[7 * C + c] = p.sp[c];
-        cst[8 * C + c] = p.hp[c];
-    }
-    __syncthreads();
-    const int P = p.P;
-    const long long ncent = p.E / P;
-    const long long ntile = (ncent + 31) >> 5;
-    const long long rows = (long long)p.B * p.Nsrc;
-    float4 s1v[4], h1v[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const bool ok = 4 * q < kh;
-        s1v[q] = ok ? *(const float4 *)(p.s1 + kh * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        h1v[q] = ok ? *(const float4 *)(p.h1 + kh * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile;
-         tile += (long long)gridDim.x * 4) {
-        long long o = (tile << 5) + l31;
-        const bool live = o < ncent;
-        if (!live) o = ncent - 1;
-        const int bi = (int)(o / p.O);
-        for (int t0 = 0; t0 < NJ; t0++) {                    // 32 channels per pass
-            ggm_f32x16 best, zps, zas;
-            unsigned bq[4];                                  // arg max, one byte per channel
-#pragma unroll
-            for (int r = 0; r < 16; r++) { best[r] = -__builtin_inff(); zps[r] = 0.f; zas[r] = 0.f; }
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) bq[qq] = 0u;
-            for (int pp = 0; pp < P; pp++) {
-                asm volatile("" ::: "memory");               // per-channel constants stay in LDS
-                const long long e = o * P + pp;
-                float hv[16];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (4 * q < kh) z = *(const float4 *)(p.Z1 + e * cin + kh * h + 4 * q);
-                    hv[4 * q + 0] = fmaxf(z.x * s1v[q].x + h1v[q].x, 0.f);
-                    hv[4 * q + 1] = fmaxf(z.y * s1v[q].y + h1v[q].y, 0.f);
-                    hv[4 * q + 2] = fmaxf(z.z * s1v[q].z + h1v[q].z, 0.f);
-                    hv[4 * q + 3] = fmaxf(z.w * s1v[q].w + h1v[q].w, 0.f);
-                }
-                long long flat = (long long)p.nebidx[e] + (long long)bi * p.Nsrc;
-                flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
-                const float4 ge = *(const float4 *)(p.att16 + e * 16);
-                const float *yrow = p.Ysrc + flat * C;
-                ggm_f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; s++)
-                    if (s < kh)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Wz[(s * 64 + lane) * NJ + t0], hv[s], acc, 0, 0, 0);
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const int c = 32 * t0 + 8 * qq + 4 * h;
-                    const float4 sa = *(const float4 *)(cst + c), ha = *(const float4 *)(cst + C + c);
-                    const float4 b2 = *(const float4 *)(cst + 2 * C + c);
-                    const float4 w0 = *(const float4 *)(cst + 3 * C + c), w1 = *(const float4 *)(cst + 4 * C + c);
-                    const float4 w2 = *(const float4 *)(cst + 5 * C + c), bp = *(const float4 *)(cst + 6 * C + c);
-                    const float4 sp = *(const float4 *)(cst + 7 * C + c), hp = *(const float4 *)(cst + 8 * C + c);
-                    const float4 y = *(const float4 *)(yrow + c);
-                    const float sav[4] = {sa.x, sa.y, sa.z, sa.w}, hav[4] = {ha.x, ha.y, ha.z, ha.w};
-                    const float b2v[4] = {b2.x, b2.y, b2.z, b2.w};
-                    const float w0v[4] = {w0.x, w0.y, w0.z, w0.w}, w1v[4] = {w1.x, w1.y, w1.z, w1.w};
-                    const float w2v[4] = {w2.x, w2.y, w2.z, w2.w}, bpv[4] = {bp.x, bp.y, bp.z, bp.w};
-                    const float spv[4] = {sp.x, sp.y, sp.z, sp.w}, hpv[4] = {hp.x, hp.y, hp.z, hp.w};
-                    const float yv[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int r = 4 * qq + i;
-                        const float z2 = acc[r] + b2v[i];
-                        const float y2 = fmaxf(z2 * sav[i] + hav[i], 0.f);
-                        float z1 = yv[i];
-                        z1 = fmaf(ge.y, w0v[i], z1);
-                        z1 = fmaf(ge.z, w1v[i], z1);
-                        z1 = fmaf(ge.w, w2v[i], z1);
-                        z1 += bpv[i];
-                        const float y1 = fmaxf(z1 * spv[i] + hpv[i], 0.f);
-                        const float v = y1 * y2;
-                        const bool upd = v > best[r];
-                        if (upd || pp == 0) { zps[r] = z1; zas[r] = z2; }
-                        if (upd) {
-                            best[r] = v;
-                            bq[qq] = (bq[qq] & ~(255u << (8 * i))) | ((unsigned)pp << (8 * i));
-                        }
-                    }
-                }
-            }
-            if (live) {
-                const long long nc = ncent * C;
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const int c = 32 * t0 + 8 * qq + 4 * h;
-                    *(float4 *)(p.out + o * p.ldo + c) = make_float4(
-                        best[4 * qq], best[4 * qq + 1], best[4 * qq + 2], best[4 * qq + 3]);
-                    *(unsigned *)(amax + o * C + c) = bq[qq];
-                    *(float4 *)(zsel + o * C + c) = make_float4(
-                        zps[4 * qq], zps[4 * qq + 1], zps[4 * qq + 2], zps[4 * qq + 3]);
-                    *(float4 *)(zsel + nc + o * C + c) = make_float4(
-                        zas[4 * qq], zas[4 * qq + 1], zas[4 * qq + 2], zas[4 * qq + 3]);
-                }
-            }
-        }
-    }
-}
-
-int gg_att_max_train(const GGAttEval &p, int C, int cin, unsigned char *amax, float *zsel,
-                     hipStream_t st)
-{
-    if ((cin != 16 && cin != 32) || (C != 64 && C != 128) || p.P < 1 || p.P > 255 || p.E < 1 || (p.E % p.P) || (p.ldo & 3))
-        return 1;
-    const long long ntile = (p.E / p.P + 31) >> 5;
-    long long nb = (ntile + 3) / 4;
-    if (nb > 256 * 8) nb = 256 * 8;
-    const size_t lds = ((size_t)16 * 64 * (C / 32) + 9 * (size_t)C) * sizeof(float);
-    gg_k_att_max_train<<<(int)nb, 256, lds, st>>>(p, C, cin, amax, zsel);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
 int gg_att_max_eval(const GGAttEval &p, int C, hipStream_t st)
 {
     if ((C != 64 && C != 128) || p.P < 1 || p.E < 1 || (p.E % p.P) || (p.ldo & 3)) return 1;

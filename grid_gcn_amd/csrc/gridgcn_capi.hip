@@ -112,7 +112,19 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 3; }
+int gridgcn_abi_version(void) { return 4; }
+
+int gridgcn_set_option(int option, int value)
+{
+    if (option == GRIDGCN_OPT_ATT_BWD_FUSED) { gg_set_att_bwd_fused(value); return GRIDGCN_OK; }
+    return GRIDGCN_EINVAL;
+}
+
+int gridgcn_get_option(int option)
+{
+    if (option == GRIDGCN_OPT_ATT_BWD_FUSED) return gg_get_att_bwd_fused();
+    return -1;
+}
 
 int gridgcn_set_mlp_precision(int bf16)
 {
@@ -230,24 +242,25 @@ int gridgcn_gridify_timed(const float *data, const int32_t *np, int B, int N,
 {
     if (iters < 1 || !ms_per_call) return GRIDGCN_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-        return GRIDGCN_ELAUNCH;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) return GRIDGCN_ELAUNCH;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return GRIDGCN_ELAUNCH; }
     int rc = GRIDGCN_OK;
     for (int w = 0; w < 3 && !rc; w++)
         rc = gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
                             ws_bytes, stream);
-    hipEventRecord(e0, st);
+    if (!rc && hipEventRecord(e0, st) != hipSuccess) rc = GRIDGCN_ELAUNCH;
     for (int i = 0; i < iters && !rc; i++)
         rc = gridify_common(false, data, np, B, N, p, nebidx, nebmsk, cent, centmsk, centnum, ws,
                             ws_bytes, stream);
-    hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess) rc = rc ? rc : GRIDGCN_ELAUNCH;
+    if (!rc && hipEventRecord(e1, st) != hipSuccess) rc = GRIDGCN_ELAUNCH;
+    // (the stream is drained even after an error so that the events can be destroyed)
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = GRIDGCN_ELAUNCH;
     float ms = 0.0f;
-    hipEventElapsedTime(&ms, e0, e1);
-    *ms_per_call = ms / (float)iters;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = GRIDGCN_ELAUNCH;
+    *ms_per_call = rc ? 0.0f : ms / (float)iters;
+    if (hipEventDestroy(e0) != hipSuccess && !rc) rc = GRIDGCN_ELAUNCH;
+    if (hipEventDestroy(e1) != hipSuccess && !rc) rc = GRIDGCN_ELAUNCH;
     return rc;
 }
 
@@ -369,7 +382,7 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const uint8_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream)
 {
-    if (amax && (!gval || P < 1 || E % P != 0)) return GRIDGCN_EINVAL;
+    if (amax && (!gval || P < 1 || P > 256 || E % P != 0)) return GRIDGCN_EINVAL;   // one-byte arg max
     if (Wdx && (ndx < 1 || ndx > cin)) return GRIDGCN_EINVAL;
     if (cin_w < 1 || cin_w > cin || rot < 0 || rot > cin_w) return GRIDGCN_EINVAL;
     if (!dY && amax) dY = Z;     // unused in sparse mode
@@ -390,31 +403,6 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     p.ldy = (dY && !amax && ldy > 0) ? ldy : C;
     if (p.ldy < C) return GRIDGCN_EINVAL;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
-}
-
-int gridgcn_att_bwd_recomp(const float *dY, const float *scale, const float *shift, const float *mean,
-                           const float *rstd, const float *m1, const float *m2, const float *Z1,
-                           const float *pscale, const float *pshift, const float *pmean,
-                           const float *prstd, const float *W2, const float *b2, const float *Wdx,
-                           long long E, int C, int cin, int ldy, float *dX, float *dW,
-                           double *psums, const uint8_t *amax, const float *gval, int P,
-                           void *workspace, size_t workspace_bytes, void *stream)
-{
-    if (amax && (!gval || P < 1 || E % P != 0)) return GRIDGCN_EINVAL;
-    if ((!dY && !amax) || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Z1 || !pscale ||
-        !pshift || !pmean || !prstd || !W2 || !b2 || !Wdx || !dX || !dW || !psums)
-        return GRIDGCN_EINVAL;
-    const size_t need = gg_att_bwd_fused_workspace(E, cin, C);
-    if (!need) return GRIDGCN_EINVAL;
-    if (!workspace || workspace_bytes < need) return GRIDGCN_EWORKSPACE;
-    GGLinBwd p = {};
-    p.dY = dY; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.m1 = m1; p.m2 = m2;
-    p.Aprev = Z1; p.pscale = pscale; p.pshift = pshift; p.pmean = pmean; p.prstd = prstd;
-    p.Wdx = Wdx; p.ndx = cin; p.dX = dX; p.dWpart = (float *)workspace; p.dW = dW; p.psums = psums;
-    p.E = E; p.C = C; p.cin = cin; p.cin_w = cin; p.rot = 0; p.amax = amax; p.gval = gval;
-    p.P = P > 0 ? P : 1; p.ldy = (dY && !amax && ldy > 0) ? ldy : C;
-    const int rc = gg_att_bwd_recomp(p, W2, b2, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
@@ -473,7 +461,7 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             void *stream)
 {
     if ((!Ysrc && !Wg) || !nebidx || !att16 || !b || !Za || !scale_p || !shift_p || !scale_a ||
-        !shift_a || !agg || !amax || ncent < 1 || P < 1 || C < 1 || B < 1 || Nsrc < 1 || O < 1 ||
+        !shift_a || !agg || !amax || ncent < 1 || P < 1 || P > 256 || C < 1 || B < 1 || Nsrc < 1 || O < 1 ||
         ncent != (long long)B * O || ld_agg < C)
         return GRIDGCN_EINVAL;
     const int rc = gg_pairmax_fwd_src(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Za, scale_p, shift_p,
@@ -490,7 +478,7 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         double *sums_p, double *sums_a, const float *zsel, void *stream)
 {
     if (((!Zp || !Za) && !zsel) || !dagg || !amax || !gp || !ga || !sums_p || !sums_a ||
-        ncent < 1 || P < 1 || ld_dagg < C)
+        ncent < 1 || P < 1 || P > 256 || ld_dagg < C)
         return GRIDGCN_EINVAL;
     int rc = gg_pairmax_bwd(Zp, Za, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
                             rstd_a, dagg, amax, ncent, P, C, ld_dagg, gp, ga, sums_p, sums_a, zsel,
@@ -545,7 +533,7 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
         return GRIDGCN_EINVAL;
     GGLinFwd p;
     p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
-    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.dbg = 0;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx;
     int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -563,7 +551,7 @@ int gridgcn_linear_fwd_direct2(const float *X1, int ld1, int K1, const float *X2
     GGLinFwd p;
     p.X = X1; p.W = Wq; p.b = b ? b : rowbias; p.scale = scale; p.shift = shift; p.Z = Z;
     p.sums = sums; p.E = E; p.cin = K1 + K2; p.K = K1 + K2; p.ldw = ldw; p.cout = cout;
-    p.lda = ld1; p.dbg = 0;
+    p.lda = ld1;
     p.X2 = X2; p.K1 = K1; p.lda2 = ld2; p.rowbias = rowbias; p.P = P;
     int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
@@ -606,7 +594,7 @@ int gridgcn_bn_stats(const float *Z, long long E, int C, int ld, double *sums, v
 int gridgcn_sparse_add(const uint8_t *amax, const float *gval, long long ncent, int P, int C,
                        float *dX, void *stream)
 {
-    if (!amax || !gval || !dX || ncent < 1 || P < 1 || C < 1) return GRIDGCN_EINVAL;
+    if (!amax || !gval || !dX || ncent < 1 || P < 1 || P > 256 || C < 1) return GRIDGCN_EINVAL;
     return gg_sparse_add(amax, gval, ncent, P, C, dX, (hipStream_t)stream);
 }
 
@@ -720,7 +708,7 @@ int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *
 {
     if ((!Z0 && (!b || (!Ysrc && !Wg))) || (!dY && (!amax || !gval)) || !scale || !shift || !mean ||
         !rstd || !m1 || !m2 || !att16 || !nebidx || !dYsrc || B < 1 || Nsrc < 1 || O < 1 || P < 1 ||
-        C0 < 1)
+        (amax && P > 256) || C0 < 1)
         return GRIDGCN_EINVAL;
     if (!workspace || workspace_bytes < gg_csr_workspace(B, Nsrc, O * P)) return GRIDGCN_EWORKSPACE;
     GGEdgeLin0Bwd p;
@@ -750,7 +738,7 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
 {
     if (!nebidx || !att16 || !amax || !gval || !zsel || (!Ysrc && !Wg) || !b || !scale || !shift ||
         !mean || !rstd || !m1 || !m2 || !dYsrc || !Gsum || !wgs || !gg || B < 1 || Nsrc < 1 ||
-        O < 1 || P < 1 || C0 < 1)
+        O < 1 || P < 1 || P > 256 || C0 < 1)
         return GRIDGCN_EINVAL;
     if (!workspace || workspace_bytes < gg_edge_lin0_sparse_workspace(B, Nsrc, C0))
         return GRIDGCN_EWORKSPACE;
@@ -789,26 +777,6 @@ int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shif
     p.hp = shift_p; p.out = agg; p.E = (long long)B * O * P; p.P = P; p.O = O; p.Nsrc = Nsrc;
     p.B = B; p.ldo = ld_agg;
     const int rc = gg_att_max_eval(p, C, (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
-}
-
-int gridgcn_att_max_train(const float *Z1, const float *scale1, const float *shift1, const float *W2,
-                          const float *b2, const float *scale_a, const float *shift_a,
-                          const float *Ysrc, const int32_t *nebidx, const float *att16,
-                          const float *Wg, const float *b, const float *scale_p,
-                          const float *shift_p, int B, int Nsrc, int O, int P, int C, int cin,
-                          float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream)
-{
-    if (!Z1 || !scale1 || !shift1 || !W2 || !b2 || !scale_a || !shift_a || !Ysrc || !nebidx ||
-        !att16 || !b || !scale_p || !shift_p || !agg || !amax || !zsel || B < 1 || Nsrc < 1 ||
-        O < 1 || P < 1 || ld_agg < C)
-        return GRIDGCN_EINVAL;
-    GGAttEval p;
-    p.Z1 = Z1; p.s1 = scale1; p.h1 = shift1; p.W2 = W2; p.b2 = b2; p.sa = scale_a; p.ha = shift_a;
-    p.Ysrc = Ysrc; p.nebidx = nebidx; p.att16 = att16; p.Wg = Wg; p.bp = b; p.sp = scale_p;
-    p.hp = shift_p; p.out = agg; p.E = (long long)B * O * P; p.P = P; p.O = O; p.Nsrc = Nsrc;
-    p.B = B; p.ldo = ld_agg;
-    const int rc = gg_att_max_train(p, C, cin, amax, zsel, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

@@ -1062,333 +1062,6 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             for (int r = 0; r < 16; r++) out[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
 }
 
-// ------------------------------------------------------------------------------------------
-// EXPERIMENTAL -- selected with GG_DW_SHARED=1, off by default: the dW kernel with its B operand staged
-// ONCE per row stream through LDS.  Motive (profiles/r2_pmc_bwd_gemm.txt): in gg_k_linear_dw_direct
-// the MG m-group waves of a stream each load the same input rows (2 KB per 8 MFMAs at cin = 256) and
-// apply the previous layer's BatchNorm+ReLU to them again; a wave waits 69 % of its life and issues
-// 9 VALU instructions per MFMA.  Here the MG waves of a stream copy a block of 32 rows x cin
-// (activation applied once, while copying) into one of two LDS buffers while they consume the other;
-// the B operands of a step are then one or two ds_read_b128 per lane.  Z / upstream-gradient values
-// (the A operand: distinct channels per wave) stay per-step register loads, D sets deep.  Same partial
-// layout as gg_k_linear_dw_direct (gg_k_dw_reduce_direct finishes).  cin in {64, 128, 256}, MG >= 2.
-// Status at the end of round 2: passes tests/test_gpu_train_ops.py; 547 us against 540-578 us for the
-// register form on 655 360 x 256 -> 128, 277 against 264-271 us on 128 -> 128 -- the redundant reads
-// of the input rows were NOT what the waves wait for.  What is left per step are the three 4-byte-per-
-// lane loads of the A operand (z, gradient, arg max: 256 useful bytes per instruction), four steps
-// deep with no registers for more: the next form stages those through LDS as well, both operands by
-// global_load ... lds several blocks ahead.
-template <int MT, int NQ, int NP, bool PT8>
-__global__ __launch_bounds__(512, 1) void gg_k_linear_dw_shared(GGLinBwd p, int MG, int RS,
-                                                                 long long rows_per_wg)
-{
-    constexpr int NJ = 4 * NQ + 2 * NP;
-    constexpr int RB = 32, PT = PT8 ? 8 : 4;     // rows per block (16 MFMA steps); float4 pieces per thread
-    constexpr int D = 4;                         // register sets of the A-operand loads (divides 16)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cq = lane & 31, h = lane >> 5;
-    const int mg = wave % MG, rs = wave / MG;
-    const int C = p.C, cin = p.cin;
-    const bool prevbn = p.pscale != nullptr, sparse = p.amax != nullptr;
-
-    const long long wa = (long long)blockIdx.x * rows_per_wg;
-    const long long wb = wa + rows_per_wg < p.E ? wa + rows_per_wg : p.E;
-    const long long per = ((wb - wa + RS - 1) / RS + 1) & ~1ll;
-    long long ra = wa + rs * per;
-    const long long rb = ra + per < wb ? ra + per : wb;
-    if (ra > rb) ra = rb;
-    const int nrows = (int)(rb - ra);                     // rows of this stream
-    const int nblk = (int)((per + RB - 1) / RB);          // the same for every stream of the workgroup
-
-    // ---- staging map: the stream's 64*MG threads copy RB x cin floats as float4 pieces; piece k of
-    //      a thread = row srow + rstep*k, columns scol..scol+3 (the column is fixed per thread)
-    float *L0 = lds + (size_t)rs * 2 * RB * cin;
-    const int ts = 64 * MG, tl = mg * 64 + lane, Q = cin >> 2;
-    const int srow = tl / Q, scol = (tl - srow * Q) * 4, rstep = ts / Q;
-    float4 psc4 = make_float4(0.f, 0.f, 0.f, 0.f), psh4 = psc4;
-    if (prevbn) { psc4 = *(const float4 *)(p.pscale + scol); psh4 = *(const float4 *)(p.pshift + scol); }
-    const float *alast = p.Aprev + (p.E - 1) * cin + scol;
-    auto stage_load = [&](float4 (&st)[PT], int b) {
-        const long long r0 = ra + (long long)b * RB + srow;
-        const float *a = p.Aprev + r0 * cin + scol;
-#pragma unroll
-        for (int k = 0; k < PT; k++) {                    // (rows past the end of X: its last row, unused)
-            const bool in = r0 + rstep * k < p.E;
-            st[k] = *(const float4 *)(in ? a + (size_t)rstep * k * cin : alast);
-        }
-    };
-    auto stage_store = [&](const float4 (&st)[PT], float *Lb) {
-#pragma unroll
-        for (int k = 0; k < PT; k++) {
-            float4 v = st[k];
-            if (prevbn) {
-                v.x = fmaxf(v.x * psc4.x + psh4.x, 0.f); v.y = fmaxf(v.y * psc4.y + psh4.y, 0.f);
-                v.z = fmaxf(v.z * psc4.z + psh4.z, 0.f); v.w = fmaxf(v.w * psc4.w + psh4.w, 0.f);
-            }
-            *(float4 *)(Lb + (srow + rstep * k) * cin + scol) = v;
-        }
-    };
-
-    // ---- A operand: per-lane constants and pointers (as gg_k_linear_dw_direct)
-    const int chA = mg * 32 * MT + MT * cq;
-    float sc[MT], sh[MT], mu[MT], bz[MT], cz[MT];
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-        const int c = chA + i;
-        const bool ok = c < C;
-        const float s = ok ? p.scale[c] : 0.f;
-        sc[i] = s; sh[i] = ok ? p.shift[c] : 0.f; mu[i] = ok ? p.mean[c] : 0.f;
-        bz[i] = ok ? -(s * p.rstd[c]) * p.m2[c] : 0.f;
-        cz[i] = ok ? -(s * p.m1[c]) : 0.f;
-    }
-    const bool chok = chA + MT - 1 < C;
-    const int chl = chok ? chA : 0;
-    const int Pq = sparse ? p.P : (1 << 30);
-    long long cen = 0;
-    int pp = 0;
-    if (sparse) {
-        const long long r = ra + h;
-        cen = r / p.P;
-        pp = (int)(r - cen * p.P);
-    }
-    const float *zp = p.Z + (ra + h) * C + chl;
-    const float *zlast = p.Z + (p.E - 1) * C + chl;
-    const float *gp = sparse ? p.gval + cen * C + chl : p.dY + (ra + h) * p.ldy + chl;
-    const float *glast = sparse ? p.gval + chl : p.dY + (p.E - 1) * p.ldy + chl;
-    const gg_amax_t *ap = sparse ? p.amax + cen * C + chl : (const gg_amax_t *)p.Z;
-    const gg_amax_t *aplast = sparse ? p.amax + chl : (const gg_amax_t *)p.Z;
-    const int ginc = sparse ? 0 : 2 * p.ldy, Cs = sparse ? C : 0;
-    struct Regs { float z[MT], g[MT]; int am[MT], pp; bool ok; };
-    int srows = h;                                        // 2*step + h of the next step to load
-    auto load_zg = [&](Regs &R) {                         // one call per step, ascending
-        const bool ok = srows < nrows;
-        const float *zq = ok ? zp : zlast, *gq = ok ? gp : glast;
-        const gg_amax_t *aq = ok ? ap : aplast;
-        if constexpr (MT == 2) {
-            const float2 t = *(const float2 *)zq, u = *(const float2 *)gq;
-            const unsigned short a2 = *(const unsigned short *)aq;
-            R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y; R.am[0] = a2 & 255; R.am[1] = a2 >> 8;
-        } else {
-            R.z[0] = zq[0]; R.g[0] = gq[0]; R.am[0] = aq[0];
-        }
-        R.pp = pp;
-        R.ok = ok;
-        srows += 2;
-        zp += 2 * C;
-        pp += 2;
-        const bool t1 = pp >= Pq;
-        pp -= t1 ? Pq : 0;
-        const bool t2 = pp >= Pq;
-        pp -= t2 ? Pq : 0;
-        const int adv = (t1 ? 1 : 0) + (t2 ? 1 : 0);
-        gp += ginc + adv * Cs;
-        ap += adv * Cs;
-    };
-
-    ggm_f32x16 acc[MT][NJ];
-#pragma unroll
-    for (int i = 0; i < MT; i++) ggm_zero<NJ>(acc[i]);
-    auto compute = [&](const Regs &R, const float *Lb, int d) {
-        float dz[MT], xa[NJ];
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-            const float g = (!sparse || R.am[i] == R.pp) ? R.g[i] : 0.f;
-            const float dv = sc[i] * ((R.z[i] * sc[i] + sh[i] > 0.f) ? g : 0.f) +
-                             ((R.z[i] - mu[i]) * bz[i] + cz[i]);
-            dz[i] = (R.ok && chok) ? dv : 0.f;
-        }
-        const float *lr = Lb + (2 * d + h) * cin;
-        int j = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const float4 t = *(const float4 *)(lr + q * 128 + 4 * cq);
-            xa[j++] = t.x; xa[j++] = t.y; xa[j++] = t.z; xa[j++] = t.w;
-        }
-#pragma unroll
-        for (int q = 0; q < NP; q++) {
-            const float2 t = *(const float2 *)(lr + NQ * 128 + 2 * cq);
-            xa[j++] = t.x; xa[j++] = t.y;
-        }
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-            for (int jj = 0; jj < NJ; jj++)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[i], xa[jj], acc[i][jj], 0, 0, 0);
-    };
-
-    Regs R[D];
-    float4 st[PT];
-    stage_load(st, 0);
-#pragma unroll
-    for (int d = 0; d < D - 1; d++) load_zg(R[d]);        // steps 0 .. D-2
-    stage_store(st, L0);
-    __syncthreads();
-    for (int b = 0; b < nblk; b++) {
-        const float *Lb = L0 + (b & 1) * RB * cin;
-        stage_load(st, b + 1 < nblk ? b + 1 : b);         // (last block: a harmless re-read)
-#pragma unroll
-        for (int d = 0; d < 16; d++) {
-            load_zg(R[(d + D - 1) % D]);                  // step 16b + d + D - 1
-            compute(R[d % D], Lb, d);
-        }
-        // the other buffer was last read in block b - 1, which every wave has left (barrier below)
-        stage_store(st, L0 + ((b + 1) & 1) * RB * cin);
-        __syncthreads();
-    }
-
-    const long long wg = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
-    float *out = p.dWpart + wg * (MT * NJ * 1024) + lane;
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) out[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
-}
-
-// ------------------------------------------------------------------------------------------
-// EXPERIMENTAL -- GG_DW_ASYNC=1, off by default, written after the last GPU minute of round 2 was spent:
-// NOT yet run on hardware.  dW for a DENSE upstream gradient with every operand moved global -> LDS by
-// global_load_lds_dwordx4 (no registers in between), RING blocks of 16 rows deep.  What the register
-// forms above cannot do: keep the three 4-byte-per-lane loads of the A operand (z, dY) more than four
-// steps ahead.  A workgroup = the MG = C/32 m-group waves of ONE row stream (1 wave per SIMD at C =
-// 128: the memory pipeline, not occupancy, hides the latency here); a ring slot holds
-//     x [16][cin] | z [16][C] | dY [16][C]            (dense rows, 16-byte pieces in row-major order)
-// and is filled by (16 (cin + 2C) / 256) instructions of 64 pieces, dealt round-robin to the waves
-// (NPER each).  Per block: wait for the own loads of that block (vmcnt counts in order), one
-// workgroup barrier (all loads of the block have landed, everybody has left the previous block),
-// refill the slot just vacated, 8 MFMA steps from LDS (2 ds_read_b32 + cin/128 ds_read_b128 per
-// lane and step, the previous layer's BatchNorm+ReLU applied on the B operand as it is read).
-// The loads are inline asm on purpose: behind __builtin_amdgcn_global_load_lds the compiler puts
-// s_waitcnt vmcnt(0) in front of every LDS read (it cannot tell the ring slots apart).
-// Assumes the LDS address of lane l = M0 + 16 l with the full byte address in M0 (what hipcc itself
-// emits for the builtin on gfx950).  Partial layout: that of gg_k_linear_dw_direct<1, NJ/4, NJ==2, 0>.
-__device__ __forceinline__ void gg_gl2lds16(const void *g, unsigned lds_byte_base)
-{
-    // (m0 is not declared clobbered: hipcc reserves it and uses it for nothing else in these kernels)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte_base) : "memory");
-}
-
-template <int N> __device__ __forceinline__ void gg_wait_vm()
-{
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int NJ, int MG, int RING>
-__global__ __launch_bounds__(64 * MG) void gg_k_linear_dw_async(GGLinBwd p, long long rows_per_wg)
-{
-    constexpr int RBK = 16, CIN = NJ * 32, Q = CIN / 4;   // rows per block; pieces per x row
-    constexpr int C = 32 * MG, NPER = 2 * NJ / MG + 4;    // channels; load instructions per wave and block
-    constexpr int lgC4 = MG == 2 ? 4 : (MG == 4 ? 5 : 6); // log2(C / 4)
-    static_assert((2 * NJ) % MG == 0 && (MG == 2 || MG == 4 || MG == 8), "shape");
-    constexpr int NQ = NJ / 4, NP = NJ == 2 ? 1 : 0;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // wave = m-group
-    const int cq = lane & 31, h = lane >> 5;
-    const bool prevbn = p.pscale != nullptr;
-    const long long ra = (long long)blockIdx.x * rows_per_wg;
-    const long long rb = ra + rows_per_wg < p.E ? ra + rows_per_wg : p.E;
-    const int nrows = rb > ra ? (int)(rb - ra) : 0;
-    const int nblk = (nrows + RBK - 1) / RBK;
-    constexpr int slotf = RBK * (CIN + 2 * C);                        // floats per ring slot
-    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
-
-    // ---- the wave's NPER load instructions of a block: instruction i = wave + MG k covers pieces
-    //      64 i .. 64 i + 63 of the slot; per lane a global pointer that advances by 16 rows per block
-    constexpr int nx = RBK * Q, nz = RBK << lgC4;                     // pieces of the x / z regions
-    const char *gp[NPER];
-    const char *glast[NPER];
-    long long gstep[NPER];
-    int growk[NPER];                                                  // row of the piece inside its block
-#pragma unroll
-    for (int k = 0; k < NPER; k++) {
-        const int pid0 = 64 * (wave + MG * k), pid = pid0 + lane;     // (an instruction never straddles two regions)
-        int row, col4;
-        const float *base;
-        long long ld;
-        if (pid0 < nx) { row = pid / Q; col4 = pid - row * Q; base = p.Aprev; ld = CIN; }
-        else if (pid0 < nx + nz) { const int q = pid - nx; row = q >> lgC4; col4 = q - (row << lgC4); base = p.Z; ld = C; }
-        else { const int q = pid - nx - nz; row = q >> lgC4; col4 = q - (row << lgC4); base = p.dY; ld = p.ldy; }
-        growk[k] = row;
-        gp[k] = (const char *)(base + (ra + row) * ld + 4 * col4);
-        glast[k] = (const char *)(base + (p.E - 1) * ld + 4 * col4);
-        gstep[k] = (long long)RBK * ld * 4;
-    }
-    long long next_r0 = ra;                                           // first row of the next block to issue
-    int islot = 0;
-    auto issue = [&]() {
-        const unsigned sbase = lbase + (unsigned)(islot * slotf) * 4u;
-#pragma unroll
-        for (int k = 0; k < NPER; k++) {
-            const bool in = next_r0 + growk[k] < p.E;                 // (rows past the end of the arrays: their last row)
-            gg_gl2lds16(in ? gp[k] : glast[k], __builtin_amdgcn_readfirstlane(sbase + 1024u * (unsigned)(wave + MG * k)));
-            gp[k] += gstep[k];
-        }
-        next_r0 += RBK;
-        islot = islot + 1 == RING ? 0 : islot + 1;
-    };
-
-    // ---- per-lane constants of the two operands
-    const int ch = wave * 32 + cq;                                    // this lane's output channel (A operand)
-    const float scv = p.scale[ch], shv = p.shift[ch], muv = p.mean[ch];
-    const float bzv = -(scv * p.rstd[ch]) * p.m2[ch], czv = -(scv * p.m1[ch]);
-    float psc[NJ], psh[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const int col = NP ? 2 * cq + j : (j >> 2) * 128 + 4 * cq + (j & 3);
-        psc[j] = prevbn ? p.pscale[col] : 1.f;                         // no previous BatchNorm: x * 1 + 0,
-        psh[j] = prevbn ? p.pshift[col] : 0.f;                         // clamped at -FLT_MAX = x itself
-    }
-    const float xlo = prevbn ? 0.f : -3.402823466e+38f;
-    ggm_f32x16 acc[NJ];
-    ggm_zero<NJ>(acc);
-
-#pragma unroll
-    for (int b = 0; b < RING - 1; b++) issue();                        // blocks 0 .. RING-2
-    int cslot = 0;
-    for (int b = 0; b < nblk; b++) {
-        gg_wait_vm<(RING - 2) * NPER>();                               // own loads of block b have landed
-        __syncthreads();                                               // ... everybody's; block b-1 is vacated
-        issue();                                                       // block b + RING - 1 into the slot of block b - 1
-        const float *Lx = lds + cslot * slotf, *Lz = Lx + RBK * CIN, *Ld = Lz + RBK * C;
-#pragma unroll
-        for (int s = 0; s < RBK / 2; s++) {
-            const int rl = 2 * s + h;
-            const float z = Lz[rl * C + ch], g = Ld[rl * C + ch];
-            const float dv = scv * ((z * scv + shv > 0.f) ? g : 0.f) + ((z - muv) * bzv + czv);
-            const float dz = (b * RBK + rl < nrows) ? dv : 0.f;
-            float xa[NJ];
-            const float *lr = Lx + rl * CIN;
-            if constexpr (NP) {
-                const float2 t = *(const float2 *)(lr + 2 * cq);
-                xa[0] = t.x; xa[1] = t.y;
-            } else {
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const float4 t = *(const float4 *)(lr + q * 128 + 4 * cq);
-                    xa[4 * q] = t.x; xa[4 * q + 1] = t.y; xa[4 * q + 2] = t.z; xa[4 * q + 3] = t.w;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                const float x = fmaxf(xa[j] * psc[j] + psh[j], xlo);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, x, acc[j], 0, 0, 0);
-            }
-        }
-        cslot = cslot + 1 == RING ? 0 : cslot + 1;
-    }
-    gg_wait_vm<0>();                                                   // nothing may land in LDS after the wave has gone
-
-    const long long wg = (long long)blockIdx.x * MG + wave;
-    float *out = p.dWpart + wg * (NJ * 1024) + lane;
-#pragma unroll
-    for (int j = 0; j < NJ; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) out[(j * 16 + r) * 64] = acc[j][r];
-}
-
 // dW[c][framework col] = sum over the waves of m-group mg(c) of their partial element.
 // thread = one partial element (tile, reg, lane) of one m-group; block = 64 elements x 16 wave
 // slices (the partials are a few tens of MB: enough loads in flight to stream them at HBM speed).
@@ -1470,36 +1143,9 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C)
     return (size_t)c.nwg * (c.threads / 64) * c.MT * (4 * c.NQ + 2 * c.NP + c.NS) * 1024 * sizeof(float);
 }
 
-// GG_DW_SHARED=1: shapes the experimental LDS-staged form takes (see gg_k_linear_dw_shared)
-template <int MT, int NQ, int NP>
-static int launch_dw_shared(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
-{
-    const int ts = 64 * c.MG, Q = p.cin / 4;
-    const int pt = 32 * Q / ts;
-    const size_t lds = (size_t)c.RS * 2 * 32 * p.cin * sizeof(float);
-    if (c.MG < 2 || ts % Q || (pt != 4 && pt != 8) || lds > 64 * 1024) return 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gg_k_linear_dw_shared<MT, NQ, NP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)gg_k_linear_dw_shared<MT, NQ, NP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
-            return 3;
-        attr_done = true;
-    }
-    if (pt == 8) gg_k_linear_dw_shared<MT, NQ, NP, true><<<c.nwg, c.threads, lds, st>>>(p, c.MG, c.RS, c.rows_per_wg);
-    else gg_k_linear_dw_shared<MT, NQ, NP, false><<<c.nwg, c.threads, lds, st>>>(p, c.MG, c.RS, c.rows_per_wg);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
 template <int MT, int NQ, int NP, int NS>
 static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
 {
-    static const bool shared_form = [] { const char *e = getenv("GG_DW_SHARED"); return e && e[0] == '1'; }();
-    if constexpr (NS == 0 && ((NQ == 2 && NP == 0) || (NQ == 1 && NP == 0) || (NQ == 0 && NP == 1))) {
-        if (shared_form && !(g_mlp_bf16 && p.pscale)) {
-            const int rc = launch_dw_shared<MT, NQ, NP>(p, c, st);
-            if (rc != 1) return rc;                       // 1: not its shape -> the register form below
-        }
-    }
     if (g_mlp_bf16 && p.pscale)   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
         gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
     else
@@ -1508,58 +1154,11 @@ static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
 }
 
 // dW in the framework layout [C][cin_w] (columns rotated back by p.rot).  1 = unsupported.
-// GG_DW_ASYNC=1: the experimental global -> LDS form (gg_k_linear_dw_async); 1 = not its shape
-template <int NJ, int MG, int RING>
-static int launch_dw_async_t(const GGLinBwd &p, int nwg, long long rows_per_wg, size_t lds, hipStream_t st)
-{
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gg_k_linear_dw_async<NJ, MG, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
-        attr_done = true;
-    }
-    gg_k_linear_dw_async<NJ, MG, RING><<<nwg, 64 * MG, lds, st>>>(p, rows_per_wg);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
-static int launch_dw_async(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
-{
-    const int C = p.C, cin = p.cin;
-    if (p.amax || !p.dY || g_mlp_bf16 || (C & 31) || (cin != 64 && cin != 128 && cin != 256)) return 1;
-    if ((p.ldy & 3) || (((size_t)p.dY | (size_t)p.Z | (size_t)p.Aprev) & 15) || p.E < 16384) return 1;
-    const int MG = C / 32, NJ = cin / 32;
-    const size_t slot = (size_t)16 * (cin + 2 * C) * sizeof(float);
-    const int ring = 4 * slot <= 150 * 1024 ? 4 : 3;
-    // workgroups: one per CU, never more partial blocks than the workspace sized for the register form holds
-    const long long units = (long long)c.nwg * (c.threads / 64) * c.MT * (4 * c.NQ + 2 * c.NP + c.NS);
-    long long nwg = 256;
-    if (nwg > (p.E + 15) / 16) nwg = (p.E + 15) / 16;
-    if (nwg > units / ((long long)MG * NJ)) nwg = units / ((long long)MG * NJ);
-    if (nwg < 1) return 1;
-    long long rp = (p.E + nwg - 1) / nwg;
-    rp = (rp + 15) & ~15ll;
-    nwg = (p.E + rp - 1) / rp;
-    int rc = 1;
-#define GG_DWA(nj, mg, rg)                                                                       \
-    if (NJ == nj && MG == mg && ring == rg) rc = launch_dw_async_t<nj, mg, rg>(p, (int)nwg, rp, ring * slot, st);
-    GG_DWA(8, 4, 4) GG_DWA(4, 4, 4) GG_DWA(8, 8, 3) GG_DWA(2, 2, 4) GG_DWA(4, 2, 4) GG_DWA(4, 8, 3) GG_DWA(2, 4, 4)
-#undef GG_DWA
-    if (rc) return rc;
-    const int per = NJ * 1024;
-    gg_k_dw_reduce_direct<<<dim3((per + 63) / 64, MG), 1024, 0, st>>>(
-        p.dWpart, (int)nwg * MG, MG, 1, NJ / 4, NJ == 2 ? 1 : 0, 0, p.C, p.cin, p.cin_w, p.rot, p.dW);
-    return hipGetLastError() == hipSuccess ? 0 : 3;
-}
-
 int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
 {
     GGDwCfg c;
     if (!gg_dw_direct_cfg(p.E, p.C, p.cin, &c)) return 1;
     if (p.C % c.MT) return 1;
-    static const bool async_form = [] { const char *e = getenv("GG_DW_ASYNC"); return e && e[0] == '1'; }();
-    if (async_form) {
-        const int rc = launch_dw_async(p, c, st);
-        if (rc != 1) return rc;                            // 1: not its shape -> the register form
-    }
     int rc = 1;
 #define GG_DWD(mt, nq, np, ns)                                                                   \
     if (c.MT == mt && c.NQ == nq && c.NP == np && c.NS == ns) rc = launch_dw_direct<mt, nq, np, ns>(p, c, st);

@@ -28,7 +28,6 @@
 // counters, so the result does not depend on any arrival order: the output is bit-identical from
 // run to run and equal to schedule S0 of the reference.
 #include "gridgcn_index.h"
-#include <stdlib.h>
 
 #define GG_NT1 1024
 #define GG_NW1 16
@@ -609,10 +608,6 @@ static unsigned gg_inv_odd(unsigned a)  // inverse of an odd number mod 2^32 (Ne
 
 static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
 {
-    static const bool forced = [] {
-        const char *e = getenv("GG_INDEX_LEGACY");
-        return e && e[0] == '1';
-    }();
     const long long nruns = ((long long)gp.G + (1 << GG_XRB) - 1) >> GG_XRB;
     int MB = 0;
     while ((1ll << MB) < nruns) MB++;
@@ -628,11 +623,7 @@ static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
         if (!grow && !shrink) break;
         KB++;
     }
-    if (const char *e = getenv("GG_TUNE_KB")) {  // tuning experiments only: shift log2(nslab)
-        KB += atoi(e);
-        KB = KB < 0 ? 0 : (KB > MB ? MB : KB);
-    }
-    if (forced || KB > 10 || MB - KB + GG_XRB > GG_MAX_SB) return false;
+    if (KB > 10 || MB - KB + GG_XRB > GG_MAX_SB) return false;
     w->KB = KB;
     w->MB = MB;
     w->SB = MB - KB + GG_XRB;
@@ -647,10 +638,6 @@ static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
     while (CH < GG_CHUNK_MAX &&
            ((long long)B * ((N + CH - 1) / CH) > 512 || (N + CH - 1) / CH > GG_MAX_CHUNKS))
         CH *= 2;
-    if (const char *e = getenv("GG_TUNE_CH")) {  // tuning experiments only
-        const int v = atoi(e);
-        if ((v == 1024 || v == 2048 || v == 4096) && (N + v - 1) / v <= GG_MAX_CHUNKS) CH = v;
-    }
     w->CH = CH;
     w->nblk = (N + CH - 1) / CH;
     if (w->nblk > GG_MAX_CHUNKS) return false;

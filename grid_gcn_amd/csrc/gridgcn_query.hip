@@ -8,7 +8,6 @@
 // evaluate their reservoir draw and the S0 outcome "the last writer of a slot wins" is an LDS
 // atomicMax on the item number; outputs leave as coalesced rows.
 #include "gridgcn_index.h"
-#include <stdlib.h>
 
 struct GGQueryPtrs {
     const int2 *vtab;  // .x = segment start, .y = population
@@ -679,10 +678,6 @@ int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, c
     // centres per wave: more loads in flight per wave once there are more centres than wave slots
     int NC = 1;
     if (gp.k3 <= 64) NC = ncent > 65536 ? 4 : (ncent > 16384 ? 2 : 1);
-    if (const char *e = getenv("GG_TUNE_QNC")) {  // tuning experiments only
-        const int v = atoi(e);
-        if ((v == 1 || v == 2 || v == 4) && (gp.k3 <= 64 || v == 1)) NC = v;
-    }
     const int per = GG_QW * NC;
     const unsigned grid = (unsigned)B * (unsigned)((gp.O + per - 1) / per);
     const size_t lds = gg_query_lds(NC, gp.k3, gp.P);
@@ -707,7 +702,7 @@ int gg_launch_query_up(const float *updata, const int *up_np, int B, int Nd, con
     q.vtab = (const int2 *)(wsbase + w.o_vtab);
     q.sorted = (const int *)(wsbase + w.o_sorted);
     const long long total = (long long)B * gp.O;
-    if (gp.P <= 8 && (gp.k == 3 || gp.k == 1) && !getenv("GG_UP_WAVE")) {
+    if (gp.P <= 8 && (gp.k == 3 || gp.k == 1)) {
         const unsigned grid = (unsigned)((total + 255) / 256);
         if (gp.k == 3)
             gg_k_query_up_lanes<3><<<grid, 256, 0, st>>>((const float4 *)updata, up_np, Nd, gp, q,

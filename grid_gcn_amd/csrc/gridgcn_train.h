@@ -21,7 +21,6 @@ struct GGLinFwd {
     double *sums;         // [2][cout]: sum z, sum z^2 (accumulated; zeroed by the caller)
     long long E;
     int cin, K, ldw, cout, lda;
-    int dbg;              // ablation switches (GG_DBG env): 1 no Z store, 2 stage once, 4 no MFMA
     // register-direct kernel only: second row source for columns [K1, K) (nullptr: X holds all K),
     // and a bias per group of P consecutive rows [E/P][cout] replacing b (nullptr: b)
     const float *X2 = nullptr;
@@ -71,8 +70,6 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st);
 size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shape not supported
 int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st);       // gridgcn_attbwd.hip; 1 = other shape
 size_t gg_att_bwd_fused_workspace(long long E, int cin, int C);
-// the same backward with the layer's pre-activation recomputed from Aprev (Z is not read)
-int gg_att_bwd_recomp(const GGLinBwd &p, const float *W2, const float *b2, hipStream_t st);
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);
 int gg_bn_apply(const float *Z, const float *scale, const float *shift, float *Y, long long E,
@@ -88,5 +85,7 @@ int gg_bn_bwd_elemt(const float *dY, const float *Z, const float *scale, const f
 
 // process-wide switch of the register-direct GEMM kernels: 0 = exact fp32 MFMA, 1 = bf16 MFMA with
 // fp32 operands in memory, fp32 accumulation and statistics (gridgcn_direct.hip)
+void gg_set_att_bwd_fused(int on);   // gridgcn_train.hip (GRIDGCN_OPT_ATT_BWD_FUSED)
+int gg_get_att_bwd_fused();
 void gg_set_mlp_bf16(int on);
 int gg_get_mlp_bf16();

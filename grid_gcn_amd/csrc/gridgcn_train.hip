@@ -21,6 +21,12 @@
 #include "gridgcn_mma.h"
 #include "gridgcn_train.h"
 
+// kernel-selection option (include/gridgcn.h: gridgcn_set_option): the one-pass backward of the
+// attention conv (gridgcn_attbwd.hip) on by default; 0 = the separate dX / dW kernels (A/B tests)
+static int g_opt_att_bwd_fused = 1;
+void gg_set_att_bwd_fused(int on) { g_opt_att_bwd_fused = on ? 1 : 0; }
+int gg_get_att_bwd_fused() { return g_opt_att_bwd_fused; }
+
 // ------------------------------------------------------------------------------------------
 // copy a [nrows x cin] row-major chunk (contiguous in global memory) into an LDS tile with row
 // stride ld, optionally through x -> relu(x*scale[c] + shift[c]); zero the K padding / missing rows.
@@ -259,10 +265,8 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_fwd(GGLinFwd p)
             if (g >= ngroup) continue;
             ggm_f32x16 acc[NT];
             ggm_zero<NT>(acc);
-            if (!(p.dbg & 4)) {
             if (WLDS) ggm_mma_lds<NT>(Aw, lda, Wl + (size_t)p.K * g * 32 * NT, p.K, acc);
             else ggm_mma<NT>(Aw, lda, p.W + (size_t)p.K * g * 32 * NT, p.K, acc);
-            }
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 const int col = (g * NT + nt) * 32 + (lane & 31);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_fwd(GGLinFwd p)
                     const int row = ggm_row(r, lane);
                     const float z = acc[nt][r] + bias;
                     if (cok && row < nrows) {
-                        if (!(p.dbg & 1)) p.Z[(r0 + row) * p.cout + col] = z;
+                        p.Z[(r0 + row) * p.cout + col] = z;
                         s += z;
                         q += z * z;
                     }
@@ -338,7 +342,6 @@ int gg_linear_fwd(const GGLinFwd &p, hipStream_t st)
     if (p.ldw != 32 && p.ldw != 64 && p.ldw != 128 && p.ldw != 256) return 1;
     GGLinFwd q = p;
     q.lda = p.K | 1;
-    q.dbg = getenv("GG_DBG") ? atoi(getenv("GG_DBG")) : 0;
     if (p.ldw == 32) return launch_fwd<1>(q, st);
     if (p.ldw == 64) return launch_fwd<2>(q, st);
     return launch_fwd<4>(q, st);
@@ -948,13 +951,12 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
     // ---- 32 -> 64/128 layer behind a BatchNorm'd layer: dX, sums and dW in one pass over Z ----
-    const char *nf = getenv("GG_NO_ATT_FUSED");
-    if (p.dX && p.Wdx && !(nf && nf[0] && nf[0] != '0')) {
+    if (p.dX && p.Wdx && g_opt_att_bwd_fused) {
         const int rc = gg_att_bwd_fused(p, st);
         if (rc != 1) return rc;
     }
     // ---- register-direct dX (gridgcn_direct.hip) when the operand was packed for it ----
-    if (p.dX && p.Wdx && !getenv("GG_DX_LDS")) {
+    if (p.dX && p.Wdx) {
         const int rc = gg_linear_dx_direct(p, st);
         if (rc == 0) p.dX = nullptr;
         else if (rc != 1) return rc;
@@ -962,7 +964,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     // a strided dense dY is only understood by the register-direct kernels
     if (p.dX && !p.amax && p.ldy != p.C) return 1;
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
-    if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0 && !getenv("GG_BWD_MONO")) {
+    if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0) {
         static bool attr_dx = false;
         if (!attr_dx) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_dx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -982,7 +984,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         }
     }
     // ---- register-direct dW (gridgcn_direct.hip) once dX is out of the way ----
-    if (!p.dX && !getenv("GG_DW_LDS")) {
+    if (!p.dX) {
         const int rc = gg_linear_dw_direct(p, st);
         if (rc != 1) return rc;
     }
@@ -1022,7 +1024,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     const size_t wbytes = (size_t)ntm * C4 * 32 * sizeof(float);
     // weights resident in LDS only when that still leaves room for >= 2 workgroups per CU: with a
     // single workgroup per CU nothing overlaps the staging round trips of a tile
-    const size_t wcap = getenv("GG_BWD_WCAP") ? (size_t)atoi(getenv("GG_BWD_WCAP")) * 1024 : 158 * 1024;
+    const size_t wcap = 158 * 1024;
     const bool wlds = p.dX && (base + wbytes <= wcap);
     const size_t lds = base + (wlds ? wbytes : 0);
     if (lds > 158 * 1024) return 1;
@@ -1035,7 +1037,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     }
     int rc;
     // ---- dW-only kernel with large row tiles (split mode, or no input gradient needed) ----
-    if (!p.dX && p.C >= 4 && (p.C & (p.C - 1)) == 0 && !getenv("GG_BWD_MONO")) {
+    if (!p.dX && p.C >= 4 && (p.C & (p.C - 1)) == 0) {
         const size_t cbytes = ((size_t)6 * p.C + 2 * p.cin) * sizeof(float);
         int rt = 0;
         const int cands[4] = {128, 96, 64, 32};

@@ -110,12 +110,52 @@ def geo_features(neighbors, centers_xyz):
 class Tail:
     """What directly follows a GridConv block in the CALLER (the segmentation head behind the last
     up layer): conv+BN+ReLU `layers` that may join the block's update chain, and optionally the
-    Dropout + class-score Linear behind them, head = (p, nn.Linear, seed_dev | None).  A per-call
+    Dropout + class-score Linear behind them, head = (p, nn.Linear, seed_dev | None[, host seed |
+    None]).  A per-call
     request object: finish() reports in `done` what it absorbed (0 nothing, 1 the layers, 2 the
     head as well) -- the module itself keeps no per-call state."""
 
     def __init__(self, layers=(), head=None):
         self.layers, self.head, self.done = tuple(layers), head, 0
+
+
+# Branches of the reference's sub_g_update that are restated here.  Everything else in its
+# signature / `configs` (segmentation/models/gcn_module_g_att.py:172-287,
+# classification/models/gcn_module_g.py:116-209) is used by none of the shipped yaml files and is
+# REFUSED rather than silently ignored.
+_SHIPPED = {
+    "segmentation": dict(attfdim=(10,), localfdim=(0, 3), aggtype=("gcn",),
+                         pool_type=("max", "max_pooling"), att_full=("",),
+                         up_center_inte=("concat",)),
+    "classification": dict(attfdim=(4,), localfdim=(0, 3), aggtype=("gcn",),
+                           pool_type=("max", "max_pooling"), att_full=("next",),
+                           up_center_inte=("concat",)),
+}
+_BRANCH_REF = dict(
+    attfdim="gcn_module_g_att.py:196-216 (attfdim 5/11/12 add point-density features)",
+    localfdim="gcn_module_g_att.py:220-233 (localfdim 4/5/10/11/12 geo_feats)",
+    aggtype="gcn_module_g_att.py:262-264 (agg_gcn: pooling before the MLP)",
+    pool_type="gcn_module_g_att.py:45-79 (aggregation_func: only max pooling is restated)",
+    att_full="gcn_module_g_att.py:143-148 ('last' / 'next' concat in front of the second attention conv)",
+    up_center_inte="gcn_module_g_att.py:279-282 ('add' instead of concat)",
+    elevation="gcn_module_g_att.py:243-247 (elevation MLP on the geometric features of a first layer)",
+    cntxt_mlp="gcn_module_g_att.py:253-255 (context MLP; only the classifier's empty one is restated)")
+
+
+def check_shipped_branches(family, elevation=(), cntxt_mlp=None, **opts):
+    """NotImplementedError for an option value outside what this package restates."""
+    ok = _SHIPPED[family]
+    for k, v in opts.items():
+        if v not in ok[k]:
+            raise NotImplementedError(
+                "%s sub_g_update with %s=%r is not restated here (supported: %s); reference branch: %s"
+                % (family, k, v, list(ok[k]), _BRANCH_REF[k]))
+    if elevation is not None and len(elevation) > 0:
+        raise NotImplementedError("sub_g_update with an elevation MLP %r is not restated here; "
+                                  "reference branch: %s" % (list(elevation), _BRANCH_REF["elevation"]))
+    if cntxt_mlp is not None and (family != "classification" or len(cntxt_mlp) > 0):
+        raise NotImplementedError("sub_g_update with cntxt_mlp=%r is not restated here; reference "
+                                  "branch: %s" % (cntxt_mlp, _BRANCH_REF["cntxt_mlp"]))
 
 
 class SubGUpdate(nn.Module):
@@ -129,8 +169,13 @@ class SubGUpdate(nn.Module):
     """
 
     def __init__(self, in_feats, pt_mlp, localfdim=0, relu=True, center_in=None, center_dim=(),
-                 out_dim=(), bn_decay=0.9):
+                 out_dim=(), bn_decay=0.9, attfdim=10, aggtype="gcn", pool_type="max_pooling",
+                 att_full="", elevation=(), up_center_inte="concat", cntxt_mlp=None):
         super().__init__()
+        check_shipped_branches("segmentation", attfdim=attfdim, localfdim=localfdim,
+                               aggtype=aggtype, pool_type=pool_type, att_full=att_full,
+                               elevation=elevation, up_center_inte=up_center_inte,
+                               cntxt_mlp=cntxt_mlp)
         self.has_feats = in_feats > 0
         self.localfdim = localfdim
         self.relu = relu
@@ -174,7 +219,8 @@ class SubGUpdate(nn.Module):
         src = src.contiguous()
         if self.mfma_train and self.training and torch.is_grad_enabled():
             from . import train_ops
-            if train_ops.edge_block_src_supported(pt_layers, att_layers, src, self.has_feats):
+            if train_ops.edge_block_src_supported(pt_layers, att_layers, src, self.has_feats,
+                                                  nebidx.shape[2]):
                 # first conv on the source points, gathered afterwards: no [E, 3+Cf] tensor at all
                 buf, out = None, None
                 if center_ori_feats is not None and self.center_mlp is not None and \
@@ -189,7 +235,7 @@ class SubGUpdate(nn.Module):
                 agg = train_ops.edge_block_src_train(src, nebidx, cent.contiguous(), pt_layers,
                                                      att_layers, self.localfdim, out=out)
                 return self.finish(agg, center_masks, center_ori_feats, buf=buf, tail=tail)
-            if train_ops.edge_block_supported(pt_layers, att_layers, src) and \
+            if train_ops.edge_block_supported(pt_layers, att_layers, src, nebidx.shape[2]) and \
                     ops.edge_inputs_rows_supported(src, self.has_feats):
                 # rows laid out for the MFMA kernels (features | geo_vec | zero padding)
                 nf, att16, rot = ops.edge_inputs_rows(src, nebidx, cent.contiguous(),
@@ -201,7 +247,7 @@ class SubGUpdate(nn.Module):
                                       has_feats=self.has_feats, localfdim=self.localfdim)
         if self.mfma_train and self.training and torch.is_grad_enabled():
             from . import train_ops
-            if train_ops.edge_block_supported(pt_layers, att_layers, nf):
+            if train_ops.edge_block_supported(pt_layers, att_layers, nf, nebidx.shape[2]):
                 agg = train_ops.edge_block_train(nf, att_vec, pt_layers, att_layers)
                 return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         pair = run_mlp(att_layers, att_vec, self.mfma_train) * \
@@ -296,7 +342,9 @@ class SubGUpdate(nn.Module):
                         # ... and the Dropout + class-score Linear behind them (train_ops._HeadTrain)
                         tail.done = 2
                         seed_dev = tail.head[2] if len(tail.head) > 2 else None
-                        return train_ops.head_train(agg, layers, p, lin, seed_dev=seed_dev)
+                        seed = tail.head[3] if len(tail.head) > 3 else None
+                        return train_ops.head_train(agg, layers, p, lin, seed=seed,
+                                                    seed_dev=seed_dev)
                 if tail.head is not None and self.mfma_train and agg.is_cuda and \
                         not self.training and not torch.is_grad_enabled():
                     from . import train_ops

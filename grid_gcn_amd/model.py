@@ -5,7 +5,6 @@ data_layer = concat(cent, feats), up path BallKNN | GridifyUp -> gather -> sub_g
 
 Shape contract = segmentation/configs/configs.yaml:71-111 (8192-pt) and :144-189 (81920-pt).
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -15,9 +14,9 @@ from . import ops, synth
 from .gridconv import ConvBNReLU, SubGUpdate, run_mlp
 
 # last linear layer + softmax cross-entropy on the hand-written kernels (GPU, float32)
-HEAD_KERNELS = os.environ.get("GG_HEAD_TORCH", "0") != "1"
+HEAD_KERNELS = True
 # fc1 -> dropout -> fc2 as one op with the dropout folded into the neighbouring kernels
-FUSED_HEAD = os.environ.get("GG_HEAD_UNFUSED", "0") != "1"
+FUSED_HEAD = True
 
 SEG_8192 = dict(
     grid=synth.SEG_SCANNET_8192, inputDim=[0, 64, 128], pt_ele_dim=[[32, 32, 64], [64, 64, 128],
@@ -117,6 +116,12 @@ class GGCNSeg(nn.Module):
             return self.seed
         return call_seed(self.seed, forward_no, call_no)
 
+    def _seed_dev(self):
+        """The device-side seed increment (graph.GraphedTrainStep) only applies where a fresh draw
+        per call is the contract: training mode without fixed_seed.  Evaluation and fixed_seed nets
+        sample with `seed` itself whatever was replayed before."""
+        return self.seed_dev if (self.training and not self.fixed_seed) else None
+
     def forward(self, data_xyz, actual_centnum):
         """data_xyz [B,N,3] f32, actual_centnum [B,1] i32 -> logits [B,N,num_classes]."""
         cfg, g, ix = self.cfg, self.cfg["grid"], self.ix
@@ -129,7 +134,8 @@ class GGCNSeg(nn.Module):
         fwd_no = self.forward_no
         if self.training:
             self.forward_no += 1
-        sd = dict(seed_dev=self.seed_dev) if (self.seed_dev is not None and _is_hip(ix)) else {}
+        seed_dev = self._seed_dev()
+        sd = dict(seed_dev=seed_dev) if (seed_dev is not None and _is_hip(ix)) else {}
         for i, layer in enumerate(self.down):
             kw = dict(synth.gridify_kwargs(g, i, self._seed(fwd_no, i)), **sd)
             nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
@@ -150,7 +156,11 @@ class GGCNSeg(nn.Module):
         nup = len(self.up)
         # what follows the last up layer (fc1, dropout, fc2): offered to that layer's chain per call
         from .gridconv import Tail
-        tail = Tail((self.fc1,), (cfg["dropout"], self.fc2, self.seed_dev) if self.fused_head else None)
+        # dropout seed of the fused head: with a device-side increment the host part is a constant of
+        # the MODEL seed (ranks / model instances built with different seeds drop different masks)
+        tail = Tail((self.fc1,), (cfg["dropout"], self.fc2, seed_dev,
+                                  call_seed(self.seed, 0, 63) if seed_dev is not None else None)
+                    if self.fused_head else None)
         for i, layer in enumerate(self.up):
             down, upl = locs[-i - 1], locs[-i - 2]
             downnum, upnum = nums[-i - 1], nums[-i - 2]

@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import synth
-from .gridconv import ConvBNReLU, mlp, run_mlp
+from .gridconv import ConvBNReLU, check_shipped_branches, mlp, run_mlp
 from .model import HipIndexOps, WeightedGradient, call_seed
 
 CLS_MN40 = dict(
@@ -27,8 +27,14 @@ class SubGUpdateCls(nn.Module):
     """classification sub_g_update: pt-MLP, attention MLP fed with
     concat(att1(att_vec), pt-MLP output, context) (att_full='next' + contextvec), product, max."""
 
-    def __init__(self, in_feats, pt_mlp, att_ele, localfdim=3, relu=True, bn_decay=0.9):
+    def __init__(self, in_feats, pt_mlp, att_ele, localfdim=3, relu=True, bn_decay=0.9, attfdim=4,
+                 aggtype="gcn", pool_type="max_pooling", att_full="next", elevation=(),
+                 up_center_inte="concat", cntxt_mlp=()):
         super().__init__()
+        check_shipped_branches("classification", attfdim=attfdim, localfdim=localfdim,
+                               aggtype=aggtype, pool_type=pool_type, att_full=att_full,
+                               elevation=elevation, up_center_inte=up_center_inte,
+                               cntxt_mlp=cntxt_mlp)
         self.has_feats = in_feats > 0
         self.localfdim = localfdim
         self.relu = relu
@@ -137,7 +143,8 @@ class GGCNCls(nn.Module):
         for i, layer in enumerate(self.layers):
             seed = self.seed if (self.fixed_seed or not self.training) else \
                 call_seed(self.seed, fwd_no, i)
-            sd = dict(seed_dev=self.seed_dev) if (self.seed_dev is not None and self._take_kw) else {}
+            seed_dev = self.seed_dev if (self.training and not self.fixed_seed) else None
+            sd = dict(seed_dev=seed_dev) if (seed_dev is not None and self._take_kw) else {}
             nebidx, nebidxmsk, cent, centmsk, num = ix.Gridify(
                 data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed), **sd)
             data_loc = cent

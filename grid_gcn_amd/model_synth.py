@@ -50,7 +50,8 @@ class GGCNSynth(nn.Module):
         for i, layer in enumerate(self.down):
             seed = self.seed if (self.fixed_seed or not self.training) else \
                 call_seed(self.seed, fwd_no, i)
-            sd = dict(seed_dev=self.seed_dev) if (self.seed_dev is not None and _is_hip(ix)) else {}
+            seed_dev = self.seed_dev if (self.training and not self.fixed_seed) else None
+            sd = dict(seed_dev=seed_dev) if (seed_dev is not None and _is_hip(ix)) else {}
             nebidx, _, cent, centmsk, num = ix.Gridify(
                 data_loc.detach().contiguous(), num, **synth.gridify_kwargs(g, i, seed), **sd)
             data_loc = cent

@@ -25,16 +25,15 @@ path: the reference has none either for the grid ops (gridify.cc:28-39 LOG(FATAL
 All index ops are non-differentiable (gridify-inl.h:227-231, ball_k_nn.cc:60).
 """
 import ctypes
-import os
 
 import torch
 
 from . import _lib
 
 # backward of the neighbour gather as a sorted segmented sum (csrc/gridgcn_scatter.hip)
-SORTED_TAKE_BWD = os.environ.get("GG_TAKE_BWD_ATOMIC", "0") != "1"
+SORTED_TAKE_BWD = True
 # BallKNN through a cell grid over the known points instead of the all-pairs scan
-BALL_GRID = os.environ.get("GG_BALL_SCAN", "0") != "1"
+BALL_GRID = True
 
 def _require(cond, msg):
     if not cond:

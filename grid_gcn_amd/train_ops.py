@@ -36,29 +36,17 @@ from . import _lib
 from .ops import _ptr, _stream
 
 
-import os  # noqa: E402
-
-# register-direct forward kernel (csrc/gridgcn_direct.hip) for inputs whose width is a multiple of 8
-DIRECT_FWD = os.environ.get("GG_FWD_LDS", "0") != "1"
-DIRECT_DX = os.environ.get("GG_DX_LDS", "0") != "1"
-# bisecting aids (tools/dbg_step_parity.py): legacy dX for given column-tile counts, packed (not strided)
-# upstream gradients, no plain-Linear kernel path, no fused head
-_DX_LEGACY_NT = set(os.environ.get("GG_DX_LEGACY_NT", "").split(",")) - {""}
-_PACK_DY = bool(os.environ.get("GG_PACK_DY"))
-_NO_PLAIN = bool(os.environ.get("GG_NO_PLAIN"))
-_NO_HEAD = bool(os.environ.get("GG_NO_HEAD"))
+# Path switches.  Plain module constants (tests flip them with monkeypatch to compare two paths on
+# the same inputs); nothing here, and nothing in the C library, reads the process environment.
+# register-direct forward / dX kernels (csrc/gridgcn_direct.hip) for row widths that are a multiple of 8
+DIRECT_FWD = True
+DIRECT_DX = True
 # first conv of the point MLP applied to the source points and gathered (csrc/gridgcn_edgelin.hip)
-SRC_FIRST_CONV = os.environ.get("GG_EDGE_GEMM", "0") != "1"
+SRC_FIRST_CONV = True
 # ... and, for single-layer point MLPs, recomputed by its consumers instead of stored
-NO_Z0 = os.environ.get("GG_STORE_Z0", "0") != "1"
+NO_Z0 = True
 # ... and its backward reduced to the sparse arg-max entries (gg_k_edge_lin0_bwd_sparse)
-SPARSE_L0 = os.environ.get("GG_SORTED_L0", "0") != "1"
-# ... optionally (GG_NO_Z2=1) with the [E, C] pre-activation of the second attention conv never
-# written either: the forward folds that conv into the max kernel (gg_k_att_max_train), the backward
-# recomputes it (gg_k_att_bwd_recomp).  Correct (tests run both), 1.7 GB less traffic per step at
-# cfg4 -- and slower: 0.32 + 1.92 + 1.94 ms against 0.50 + 0.74 + 1.30 ms for the stored form (DESIGN
-# section 3.5, dead ends), so the stored form is the default.
-NO_Z2 = os.environ.get("GG_NO_Z2", "0") == "1"
+SPARSE_L0 = True
 
 
 
@@ -170,8 +158,6 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
         # input gradient: all columns of a hidden layer, the first ndx0 of the chain input
         ndx = cin if l > 0 else ndx0
         if not (DIRECT_DX and cout % 8 == 0 and 0 < ndx <= 256):
-            ndx = 0
-        if ndx and str((ndx + 31) // 32) in _DX_LEGACY_NT:
             ndx = 0
         nt = (ndx + 31) // 32
         nwdx = cout * 32 * (1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8) if ndx else 0
@@ -354,10 +340,10 @@ class _ZeroArena:
             self.chunk[key].untyped_storage(), o // item, tuple(shape), tuple(reversed(strides)))
 
 
-ZERO_ARENA = os.environ.get("GG_NO_ZERO_ARENA", "0") != "1"
+ZERO_ARENA = True
 # evaluation of single-layer-pt edge blocks (the up layers) through the source-side kernels
-SRC_EVAL = os.environ.get("GG_NO_SRC_EVAL", "0") != "1"
-ATT_MAX_EVAL = os.environ.get("GG_NO_ATT_MAX_EVAL", "0") != "1"
+SRC_EVAL = True
+ATT_MAX_EVAL = True
 _ARENA = _ZeroArena()
 _zeros = _ARENA.zeros
 reset_zero_arena = _ARENA.reset
@@ -449,7 +435,7 @@ class _MLPTrain(torch.autograd.Function):
         # register-direct kernels take this layer; otherwise it is packed first
         if not (dY.dim() == 2 and dY.stride(1) == 1 and dY.stride(0) % 4 == 0
                 and dY.storage_offset() % 4 == 0 and _dw_direct_ok(C, cin_last)
-                and DIRECT_DX and not os.environ.get("GG_DW_LDS") and not _PACK_DY
+                and DIRECT_DX
                 and (not need_dx_last or ctx.ndx[-1] > 0)):
             dY = dY.contiguous()
         with torch.cuda.device(dev):
@@ -600,12 +586,12 @@ def _chain_eval_raw(lib, prev, layers, prev_bn=None):
     return prev, sc, sh
 
 
-def edge_block_src_eval_supported(pt_layers, att_layers, src, has_feats):
+def edge_block_src_eval_supported(pt_layers, att_layers, src, has_feats, P=None):
     """single-layer point MLP on neighbour features (every up layer): evaluation through the
     training path's forward kernels with running statistics"""
     if len(pt_layers) != 1 or not SRC_EVAL:
         return False
-    if not edge_block_src_supported(pt_layers, att_layers, src, has_feats):
+    if not edge_block_src_supported(pt_layers, att_layers, src, has_feats, P):
         return False
     return all(l.lin.out_features % 8 == 0 and l.lin.out_features <= 256 for l in att_layers)
 
@@ -864,51 +850,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             lda = agg.stride(0)
             amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
-            noz2 = (noz and NO_Z2 and La == 2 and A0 in (16, 32) and C in (64, 128) and P <= 255
-                    and lda % 4 == 0 and not lib.gridgcn_get_mlp_precision())
-            if noz2:
-                # second attention conv: statistics from a store-less pass of the forward kernel,
-                # the conv itself inside the max kernel -- its [E, C] output is never written
-                sa = _chain_forward(lib, att16, pa[:4], bns_a[:1], eps)
-                Z1 = sa.Z[0]
-                W2, b2, g2, be2 = pa[4:8]
-                W2c, b2c = W2.detach().contiguous(), b2.detach().contiguous()
-                _, ldw, _, _ = packed_sizes(C, A0)
-                pk2 = torch.empty(ldw + A0 * ldw + C * 32, dtype=torch.float32, device=dev)
-                Bp2, Wq2, Wdx2 = pk2[:ldw], pk2[ldw:ldw + A0 * ldw], pk2[ldw + A0 * ldw:]
-                rc = lib.gridgcn_pack_linear(_ptr(W2c), _ptr(b2c), C, A0, 0, A0, A0, None, _ptr(Bp2),
-                                             None, None, _ptr(Wq2), _ptr(Wdx2), st)
-                _lib.check(rc, "gridgcn_pack_linear")
-                sums2 = _zeros(2 * C, torch.float64, dev)
-                rc = lib.gridgcn_linear_fwd_direct(_ptr(Z1), E, A0, A0, _ptr(Wq2), _ptr(Bp2), ldw, C,
-                                                   _ptr(sa.scale[0]), _ptr(sa.shift[0]), None,
-                                                   _ptr(sums2), st)
-                _lib.check(rc, "gridgcn_linear_fwd_direct")
-                vec2 = torch.empty((4, C), dtype=torch.float32, device=dev)
-                bn = bns_a[1]
-                track = bn.track_running_stats
-                rc = lib.gridgcn_bn_finalize(
-                    _ptr(sums2), _ptr(g2.detach()), _ptr(be2.detach()), E, eps,
-                    _momentum(bn) if track else 0.0, C, _ptr(vec2[0]), _ptr(vec2[1]), _ptr(vec2[2]),
-                    _ptr(vec2[3]), _ptr(bn.running_mean) if track else None,
-                    _ptr(bn.running_var) if track else None,
-                    _ptr(bn.num_batches_tracked) if track else None, st)
-                _lib.check(rc, "gridgcn_bn_finalize")
-                rc = lib.gridgcn_att_max_train(
-                    _ptr(Z1), _ptr(sa.scale[0]), _ptr(sa.shift[0]), _ptr(W2c), _ptr(b2c),
-                    _ptr(vec2[0]), _ptr(vec2[1]), _ptr(Ysrc), _ptr(nebidx), _ptr(att16),
-                    _ptr(Wg) if geo else None, _ptr(wgb[3]), _ptr(scl), _ptr(shl), B, Nsrc, O, P, C,
-                    A0, _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
-                _lib.check(rc, "gridgcn_att_max_train")
-                # the backward's view of the attention chain: layer 0 as usual, layer 1 Z-less
-                sa.Z.append(W2c); sa.scale.append(vec2[0]); sa.shift.append(vec2[1])
-                sa.mean.append(vec2[2]); sa.rstd.append(vec2[3])
-                sa.Wb.append(b2c); sa.Wg.append(b2c); sa.Wdx.append(Wdx2); sa.ndx.append(A0)
-            else:
-                sa = _chain_forward(lib, att16, pa, bns_a, eps)
-            if noz2:
-                pass
-            elif noz:
+            sa = _chain_forward(lib, att16, pa, bns_a, eps)
+            if noz:
                 rc = lib.gridgcn_pairmax_fwd_src(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
                     B, Nsrc, O, _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl), _ptr(sa.scale[-1]),
@@ -918,7 +861,6 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                                              _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
                                              _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_fwd")
-        ctx.noz2 = noz2
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.save_for_backward(
@@ -958,40 +900,15 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             sums_p, sums_a = sums_pa[0], sums_pa[1]
             # (the arg-max pre-activations come from zsel: Zl may not exist)
             rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None,
-                                         None if ctx.noz2 else _ptr(aZ[-1]),
+                                         _ptr(aZ[-1]),
                                          _ptr(lS), _ptr(lH), _ptr(lM),
                                          _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
                                          _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C,
                                          dagg.stride(0), _ptr(gp),
                                          _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_bwd")
-            if ctx.noz2:
-                # second attention conv without its stored output: aZ[1] holds W2, aWb[1] b2
-                Z1, W2c, b2c, Wdx2 = aZ[0], aZ[1], aWb[1], aWx[1]
-                A0 = Z1.shape[1]
-                v2 = torch.empty((4, C), dtype=torch.float32, device=dev)
-                rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums_a), E, C, _ptr(v2[0]), _ptr(v2[1]),
-                                                 _ptr(v2[2]), _ptr(v2[3]), st)
-                _lib.check(rc, "gridgcn_bn_bwd_finalize")
-                dX1 = torch.empty((E, A0), dtype=torch.float32, device=dev)
-                dW2 = torch.empty((C, A0), dtype=torch.float32, device=dev)
-                ps1 = _zeros(2 * A0, torch.float64, dev)
-                nbytes = ctypes.c_size_t(0)
-                lib.gridgcn_linear_bwd_workspace_bytes(E, A0, C, ctypes.byref(nbytes))
-                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-                rc = lib.gridgcn_att_bwd_recomp(
-                    None, _ptr(aS[1]), _ptr(aH[1]), _ptr(aM[1]), _ptr(aR[1]), _ptr(v2[0]),
-                    _ptr(v2[1]), _ptr(Z1), _ptr(aS[0]), _ptr(aH[0]), _ptr(aM[0]), _ptr(aR[0]),
-                    _ptr(W2c), _ptr(b2c), _ptr(Wdx2), E, C, A0, 0, _ptr(dX1), _ptr(dW2), _ptr(ps1),
-                    _ptr(amax), _ptr(ga), P, _ptr(ws), nbytes.value, st)
-                _lib.check(rc, "gridgcn_att_bwd_recomp")
-                _, g1 = _chain_backward(lib, att16, aZ[:1], aS[:1], aH[:1], aM[:1], aR[:1], aWb[:1],
-                                        aWg[:1], aWx[:1], ctx.ndx[1][:1], ps1, dX1, None, False, cwa,
-                                        0)
-                grads_a = list(g1) + [dW2, _zeros(C, torch.float32, dev), v2[2], v2[3]]
-            else:
-                _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx,
-                                             ctx.ndx[1], sums_a, None, (amax, ga, P), False, cwa, 0)
+            _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx,
+                                         ctx.ndx[1], sums_a, None, (amax, ga, P), False, cwa, 0)
             if L1:
                 dY0, grads_rest, sums0 = _chain_backward(
                     lib, Z0, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0], sums_p, None,
@@ -1063,14 +980,14 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         return (gsrc, None, None, None) + tuple(grads0) + tuple(grads_rest) + tuple(grads_a)
 
 
-def edge_block_src_supported(pt_layers, att_layers, src, has_feats):
+def edge_block_src_supported(pt_layers, att_layers, src, has_feats, P=None):
     """the source-side first conv needs neighbour features with a width the kernels can vector-load"""
     if not (has_feats and src.is_cuda and src.dtype == torch.float32 and SRC_FIRST_CONV):
         return False
     C0 = pt_layers[0].lin.out_features
     if C0 % 4 or C0 > 256 or (src.shape[2] % 4):
         return False
-    return edge_block_supported(pt_layers, att_layers, src)
+    return edge_block_supported(pt_layers, att_layers, src, P)
 
 
 def edge_block_src_train(src, nebidx, cent, pt_layers, att_layers, localfdim, out=None):
@@ -1119,13 +1036,14 @@ def time_linear_fwd(E, cin, C, iters=10, device="cuda:0"):
     return e0.elapsed_time(e1) / iters
 
 
-def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=False):
+def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=False, dense=False):
     """Time one gridgcn_linear_bwd call (dX kernel + dW kernel + dW reduce) on synthetic tensors
     shaped like the last pt layer of a GridConv edge block (sparse upstream gradient, input gradient
     for the first `ndx` columns; cin = padded row length).  Used by bench.py for the roofline of the
     dominant kernels of the training step.  prev_bn: the layer's input is the raw output of a
     BatchNorm'd layer (as the second attention conv's is): its BatchNorm+ReLU is applied on the fly
-    and its BatchNorm-backward sums are accumulated.  Returns ms/call."""
+    and its BatchNorm-backward sums are accumulated.  dense: a dense upstream gradient [E, C]
+    instead of the max-pool's sparse one (the per-point layers of the head).  Returns ms/call."""
     lib = _lib.load()
     E = ncent * P
     g = torch.Generator(device=device).manual_seed(0)
@@ -1136,6 +1054,7 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=
     m1, m2 = rnd(C) * 1e-3, rnd(C) * 1e-3
     amax = torch.randint(0, P, (ncent, C), device=device, dtype=torch.int32, generator=g).to(torch.uint8)
     gval = rnd(ncent, C)
+    dY = rnd(E, C) if dense else None
     Wt = rnd(C, cin)
     Wb, Wg = pack_tiles(Wt), pack_groups(Wt)
     ndx = (ndx or min(cin, 256)) if (DIRECT_DX and C % 8 == 0) else 0
@@ -1153,11 +1072,11 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=
     psums = torch.zeros(2 * cin, dtype=torch.float64, device=device)
 
     def call():
-        rc = lib.gridgcn_linear_bwd(None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
+        rc = lib.gridgcn_linear_bwd(_ptr(dY) if dense else None, _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd),
                                     _ptr(m1), _ptr(m2), _ptr(X), pb[0], pb[1], pb[2], pb[3], _ptr(Wb),
-                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin, cin, 0, 0,
-                                    _ptr(dX), _ptr(dW), _ptr(psums) if prev_bn else None, _ptr(amax),
-                                    _ptr(gval), P,
+                                    _ptr(Wg), _ptr(Wdx) if ndx else None, ndx, E, C, cin, cin, 0, C if dense else 0,
+                                    _ptr(dX), _ptr(dW), _ptr(psums) if prev_bn else None,
+                                    None if dense else _ptr(amax), None if dense else _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))
         _lib.check(rc, "gridgcn_linear_bwd")
     with torch.cuda.device(device):
@@ -1173,7 +1092,12 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=
     return e0.elapsed_time(e1) / iters
 
 
-def edge_block_supported(pt_layers, att_layers, nf):
+def edge_block_supported(pt_layers, att_layers, nf, P=None):
+    """P: neighbours per centre.  The arg max of the neighbour max-pool is stored in ONE byte
+    (uint8 amax, four of them per 32-bit store), so the kernels take P <= 256 (include/gridgcn.h);
+    wider neighbour lists run on the stock modules."""
+    if P is not None and P > 256:
+        return False
     C = pt_layers[-1].lin.out_features
     return (supported(pt_layers, nf) and supported(att_layers, nf)
             and att_layers[-1].lin.out_features == C)
@@ -1568,7 +1492,7 @@ def _identity_consts(Cp, dev):
 def linear_plain_supported(x, lin):
     return (x.is_cuda and x.dtype == torch.float32 and DIRECT_FWD and DIRECT_DX
             and x.shape[-1] % 8 == 0 and x.shape[-1] <= 256 and lin.out_features <= 32
-            and lin.bias is not None and not _NO_PLAIN)
+            and lin.bias is not None)
 
 
 class _LinearPlain(torch.autograd.Function):
@@ -1737,7 +1661,7 @@ class _HeadTrain(torch.autograd.Function):
 def head_supported(x, layers, lin):
     C = layers[-1].lin.out_features
     return (supported(layers, x) and DIRECT_FWD and DIRECT_DX and lin.bias is not None
-            and not _NO_HEAD and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
+            and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
 
 
 def head_train(x, layers, p, lin, seed=None, seed_dev=None):

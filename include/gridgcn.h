@@ -66,7 +66,17 @@ typedef struct gridgcn_grid_params {
 
 const char *gridgcn_strerror(int code);
 /* library/ABI version, bumped on any signature change */
-int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors */
+int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors;
+                                 * 4: gridgcn_set_option, Z-less attention pair removed, the library
+                                 *    reads nothing from the process environment */
+
+/* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
+ * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
+#define GRIDGCN_OPT_ATT_BWD_FUSED 0  /* [1] one-pass backward of the attention conv (dX, previous
+                                      *     layer's BN sums and dW from one read of Z); 0 = the
+                                      *     separate dX and dW kernels */
+int gridgcn_set_option(int option, int value);
+int gridgcn_get_option(int option);
 
 /* Precision of the contraction inside the training GEMM kernels (gridgcn_linear_fwd_direct,
  * gridgcn_linear_dx, the direct dW kernel behind gridgcn_linear_bwd): 0 (default) = exact fp32
@@ -255,30 +265,6 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
  *                  * relu((W2[c,:] . relu(Z1[e,:]*scale1 + shift1) + b2[c]) * scale_a[c] + shift_a[c])
  * Z1[E,32] = raw output of the first attention conv, W2[C][32] (torch layout) / b2 the second one;
  * C = 64 or 128, P <= 8, agg[B*O][ld_agg].  The [E, C] attention tensor is never materialised. */
-/* Training form of the up layers' attention tail WITHOUT the [E, C] pre-activation of the second
- * attention conv in memory (1.7 GB at cfg4's last up layer, formerly written once and read twice):
- * gridgcn_att_max_train: as gridgcn_att_max_eval with batch-statistics BatchNorm vectors (those of
- *   the second conv from a statistics-only gridgcn_linear_fwd_direct pass, Z = NULL); also writes the
- *   arg-max neighbour amax[B*O][C] (one byte) and the two pre-activations at the arg max
- *   zsel[2][B*O][C] (point branch, attention branch) for gridgcn_pairmax_bwd; Z1 rows of cin = 16
- *   or 32 floats, W2 [C][cin].
- * gridgcn_att_bwd_recomp: backward of that conv (dX [E][cin], dW [C][cin], BatchNorm-backward sums
- *   psums of the first attention conv) with its pre-activation recomputed tile by tile from Z1 --
- *   the arguments of gridgcn_linear_bwd minus Z, plus the conv's W2 [C][cin] / b2 [C]; cin in {16,
- *   32}, C in {64, 128}; workspace as gridgcn_linear_bwd_workspace_bytes(E, cin, C). */
-int gridgcn_att_max_train(const float *Z1, const float *scale1, const float *shift1, const float *W2,
-                          const float *b2, const float *scale_a, const float *shift_a,
-                          const float *Ysrc, const int32_t *nebidx, const float *att16,
-                          const float *Wg, const float *b, const float *scale_p,
-                          const float *shift_p, int B, int Nsrc, int O, int P, int C, int cin,
-                          float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream);
-int gridgcn_att_bwd_recomp(const float *dY, const float *scale, const float *shift, const float *mean,
-                           const float *rstd, const float *m1, const float *m2, const float *Z1,
-                           const float *pscale, const float *pshift, const float *pmean,
-                           const float *prstd, const float *W2, const float *b2, const float *Wdx,
-                           long long E, int C, int cin, int ldy, float *dX, float *dW,
-                           double *psums, const uint8_t *amax, const float *gval, int P,
-                           void *workspace, size_t workspace_bytes, void *stream);
 int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shift1, const float *W2,
                          const float *b2, const float *scale_a, const float *shift_a,
                          const float *Ysrc, const int32_t *nebidx, const float *att16,

@@ -32,7 +32,14 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.gridgcn_abi_version() >= 1
+    from grid_gcn_amd import _lib
+    assert lib.gridgcn_abi_version() == _lib.ABI_VERSION == 4
+    # kernel-selection options: explicit API, no environment variables (tests/test_guards.py)
+    assert lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 1
+    assert lib.gridgcn_set_option(_lib.OPT_ATT_BWD_FUSED, 0) == 0
+    assert lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 0
+    assert lib.gridgcn_set_option(_lib.OPT_ATT_BWD_FUSED, 1) == 0
+    assert lib.gridgcn_set_option(12345, 1) == 1 and lib.gridgcn_get_option(12345) == -1
     assert lib.gridgcn_strerror(0) == b"ok"
     assert b"workspace" in lib.gridgcn_strerror(2)
 

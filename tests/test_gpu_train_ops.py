@@ -408,9 +408,8 @@ def test_softmax_ce_class_weights_match_weighted_gradient_op():
                                                   (4099, 1, 32, 64, False), (20000, 5, 32, 128, False)])
 def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
     """gg_k_att_bwd_fused (one pass over Z: dX, previous layer's BN-backward sums, dW) against the
-    separate register-direct dX and dW kernels on the same inputs (GG_NO_ATT_FUSED=1)."""
+    separate register-direct dX and dW kernels on the same inputs (GRIDGCN_OPT_ATT_BWD_FUSED = 0)."""
     import ctypes
-    import os
     from grid_gcn_amd import _lib
     from grid_gcn_amd.ops import _ptr, _stream
     lib = _lib.load()
@@ -434,8 +433,8 @@ def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
     nbytes = ctypes.c_size_t(0)
     lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
     res = []
-    for nofused in ("1", "0"):
-        os.environ["GG_NO_ATT_FUSED"] = nofused
+    for fused in (0, 1):
+        _lib.check(lib.gridgcn_set_option(_lib.OPT_ATT_BWD_FUSED, fused), "gridgcn_set_option")
         dX = torch.full((E, cin), float("nan"), device=DEV)
         dW = torch.full((C, cin), float("nan"), device=DEV)
         psums = torch.zeros(2 * cin, dtype=torch.float64, device=DEV)
@@ -449,7 +448,7 @@ def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
         _lib.check(rc, "gridgcn_linear_bwd")
         torch.cuda.synchronize()
         res.append((dX, dW, psums))
-    os.environ.pop("GG_NO_ATT_FUSED")
+    assert lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 1      # (left at its default)
     (x0, w0, s0), (x1, w1, s1) = res
     assert torch.isfinite(x1).all() and torch.isfinite(w1).all()
     # dX: the same MFMA chain over the channels in both kernels
