@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgc
 
 ABI_VERSION = 4                 # include/gridgcn.h: gridgcn_abi_version()
 OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
+OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
+OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK
 
 EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",

@@ -117,12 +117,24 @@ int gridgcn_abi_version(void) { return 4; }
 int gridgcn_set_option(int option, int value)
 {
     if (option == GRIDGCN_OPT_ATT_BWD_FUSED) { gg_set_att_bwd_fused(value); return GRIDGCN_OK; }
+    if (option == GRIDGCN_OPT_INDEX_SLAB_SHIFT) {
+        if (value < -4 || value > 4) return GRIDGCN_EINVAL;
+        gg_index_set_tuning(0, value);
+        return GRIDGCN_OK;
+    }
+    if (option == GRIDGCN_OPT_INDEX_CHUNK) {
+        if (value != 0 && value != 1024 && value != 2048 && value != 4096) return GRIDGCN_EINVAL;
+        gg_index_set_tuning(1, value);
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
 int gridgcn_get_option(int option)
 {
     if (option == GRIDGCN_OPT_ATT_BWD_FUSED) return gg_get_att_bwd_fused();
+    if (option == GRIDGCN_OPT_INDEX_SLAB_SHIFT) return gg_index_get_tuning(0);
+    if (option == GRIDGCN_OPT_INDEX_CHUNK) return gg_index_get_tuning(1);
     return -1;
 }
 

@@ -73,9 +73,13 @@ __device__ __forceinline__ int gg_voxel_of(float x, float y, float z, const GGGr
 static __device__ unsigned long long *gg_prof_buf = nullptr;
 #define GG_STAMP(kid, wg, k)                                                                   \
     do {                                                                                       \
-        if (threadIdx.x == 0 && gg_prof_buf)                                                   \
-            gg_prof_buf[((size_t)(kid) * 4096 + ((unsigned)(wg) & 4095u)) * 16 + (k)] =        \
-                wall_clock64();                                                                \
+        if (threadIdx.x == 0 && gg_prof_buf) {                                                 \
+            unsigned long long *gg_pb_ =                                                       \
+                gg_prof_buf + ((size_t)(kid) * 4096 + ((unsigned)(wg) & 4095u)) * 16;          \
+            gg_pb_[(k)] = wall_clock64();                                                      \
+            if ((k) == 0) gg_pb_[14] = clock64();   /* shader clock at the first stamp ... */  \
+            gg_pb_[15] = clock64();                 /* ... and at the last one so far */       \
+        }                                                                                      \
     } while (0)
 #define GG_PROF_SETTER(name)                                                                   \
     extern "C" int name(void *buf)                                                             \
@@ -88,6 +92,23 @@ static __device__ unsigned long long *gg_prof_buf = nullptr;
 #endif
 
 __device__ __forceinline__ int gg_lane() { return (int)(threadIdx.x & 63); }
+
+// Workgroup number -> (cloud, item of the cloud) for a 1-D launch of B * per_cloud workgroups.
+// Workgroup w is dispatched to XCD w % 8 (observed, MI355X_MICROARCH "Workgroup dispatch"; only
+// speed depends on it): with B a multiple of 8 every kernel of a call sends the workgroups of
+// cloud b to XCD b % 8, so what one kernel of the call leaves in that XCD's 4 MB L2 (the cloud's
+// split runs, sorted ids, voxel table: ~3 MB at 81920 points) is what the next one reads.
+__device__ __forceinline__ void gg_cloud_item(int wg, int per_cloud, int B, int &b, int &item)
+{
+    if ((B & 7) == 0) {
+        const int xcd = wg & 7, j = wg >> 3;
+        b = (j / per_cloud) * 8 + xcd;
+        item = j % per_cloud;
+    } else {
+        b = wg / per_cloud;
+        item = wg % per_cloud;
+    }
+}
 
 // inclusive prefix sum across the 64 lanes of a wave
 __device__ __forceinline__ int gg_wave_incl_scan(int v)

@@ -27,11 +27,8 @@ struct GGIndexWs {
     size_t o_part;        // u32 [B*N]   chunk-local split by slab: (voxel number inside the slab) << 12
                           //             | local point number
     size_t o_ctab;        // int [B*nchunk*(nslab+1)] chunk-local exclusive slab offsets
-    size_t o_lead;        // int [B*N]   first point id of every occupied voxel: slab s keeps its
-                          //             leaders at [base_s, base_s + occupied_s), grouped by the
-                          //             point range (id >> RSB) they fall in
-    size_t o_ltab;        // int [B*nslab*(R+1)] start of range r's group inside o_lead (absolute
-                          //             within the cloud); entry R = end of the slab's leaders
+    size_t o_lbm;         // u32 [B*ceil(N/32)] leader bitmap: bit i of cloud b = point i is the first
+                          //             point of its voxel (zeroed by the first kernel of the call)
     size_t o_cursor;      // legacy: int [B] bump allocator of segment space
     size_t o_wsum;        // u64 [B*nblk] per-chunk sum |w| of in-grid points, bit 63 = non-integer
                           //             seen, bit 62 = weight != 1.0 seen
@@ -47,7 +44,6 @@ struct GGIndexWs {
     unsigned HA, HAinv;   // split: odd multiplier of the run-number hash and its inverse mod 2^MB
     int NW2;              // split: waves per workgroup of the slab kernel
     int CH;               // split: points per chunk
-    int R, RSB;           // split: point ranges per cloud in the centre kernel, log2(points per range)
     int legacy;           // 1: built by the legacy generation
 };
 
@@ -56,6 +52,10 @@ int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid 
                    bool with_centres, int *centnum, char *wsbase, const GGIndexWs &w,
                    hipStream_t st);
 int gg_index_init();
+// plan overrides for measurements: which = 0: shift of log2(slabs per cloud), 1: points per chunk
+// (1024 / 2048 / 4096, 0 = automatic)
+void gg_index_set_tuning(int which, int value);
+int gg_index_get_tuning(int which);
 
 size_t gg_index_legacy_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres,
                                        GGIndexWs *ws);

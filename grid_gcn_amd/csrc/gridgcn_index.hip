@@ -14,14 +14,16 @@
 //      voxel grid, see GGSplit) in LDS; the chunk's items leave as one coalesced run per slab, 4
 //      bytes per point: (voxel number inside the slab) << 12 | local point number; the
 //      chunk-local exclusive slab offsets go to a small table.  Also zeroes the centre-slot array
-//      and reduces the weight statistics.
+//      and the leader bitmap, and reduces the weight statistics.
 //   K2 gg_k_slab_build   (slab, cloud): gathers the slab's runs of every chunk (they are in
 //      ascending point id by construction), stable split by voxel -> the sorted segment of every
 //      voxel, the (start, population) table of the slab's voxels (dense, 128-byte lines, no
-//      memset), the stage-1 bucket reservoir of over-full voxels (gridify.cu:145-154) and the first
-//      point of every occupied voxel ("leader"), grouped by point range for K3.
-//   K3 gg_k_centre_slots (point range, cloud): rank of a leader among the cloud's leaders = the
-//      voxel's order of first appearance; RVS reservoir over the centre slots (gridify.cu:165-189).
+//      memset), the stage-1 bucket reservoir of over-full voxels (gridify.cu:145-154); the first
+//      point of every occupied voxel ("leader") becomes a bit of the cloud's leader bitmap.
+//   K3 gg_k_centre_slots (4096 consecutive points of a cloud, a word of the cloud's leader bitmap
+//      per lane): rank of a leader among the cloud's leaders = the voxel's order of first
+//      appearance = number of bitmap bits below it; RVS reservoir over the centre slots
+//      (gridify.cu:165-189).  Bitmap words in, atomics out: no dependent global load.
 //
 // The stable split of 64 items inside a wave finds, for every lane, the set of lanes with the same
 // key by one ballot per key bit; waves own contiguous ranges of the item list and keep private
@@ -32,8 +34,6 @@
 #define GG_NT1 1024
 #define GG_NW1 16
 #define GG_GS 8       // lanes that copy one run together
-#define GG_NT3 1024
-#define GG_MAX_R 64   // point ranges per cloud in K3
 
 // Slab assignment.  Voxels are taken in runs of 16 consecutive ids (128 bytes of the voxel table,
 // x-neighbours mostly together); the run number u < 2^MB is scrambled by an odd multiplier (a
@@ -46,7 +46,7 @@ struct GGSplit {
     int LB;       // MB - KB: bits of the run number inside a slab
     int SB;       // LB + 4: log2 of voxels per slab
     int KB;       // log2(nslab)
-    int nslab, nchunk, CH, R, RSB;
+    int nslab, nchunk, CH;
 };
 
 __device__ __forceinline__ void gg_slab_of(int v, const GGSplit &sp, int &slab, int &vl)
@@ -119,7 +119,7 @@ __device__ __forceinline__ unsigned long long gg_wave_peers(bool valid, unsigned
 // (wave, iteration, lane) = ascending point id, which the split preserves inside every slab.
 template <int IPT>
 __global__ __launch_bounds__(GG_NT1) void gg_k_chunk_split(
-    const float4 *__restrict__ data, const int *__restrict__ np, int N, GGGrid gp, GGSplit sp,
+    const float4 *__restrict__ data, const int *__restrict__ np, int N, int B, GGGrid gp, GGSplit sp,
     unsigned *__restrict__ part, int *__restrict__ ctab, unsigned long long *__restrict__ wsum_blk,
     int *__restrict__ zero_base, int zero_words)
 {
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(GG_NT1) void gg_k_chunk_split(
     __shared__ int s_w[GG_NW1];
     __shared__ long long s_sum[GG_NW1];
     __shared__ int s_flag[GG_NW1];
-    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int nchunk = sp.nchunk;
+    int b, chunk;
+    gg_cloud_item(blockIdx.x, nchunk, B, b, chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wgid = b * nchunk + chunk;
     GG_STAMP(0, wgid, 0);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(GG_NT1) void gg_k_chunk_split(
     nvalid = nvalid < N ? nvalid : N;
     for (int j = tid; j < GG_NW1 * nslab; j += GG_NT1) wc[j] = 0;
     if (zero_words > 0) {  // centre slots, zeroed for K3 (stream order)
-        const int nwg = nchunk * gridDim.y;
+        const int nwg = nchunk * B;
         const int per = (zero_words + nwg - 1) / nwg;
         const int z0 = wgid * per, z1 = (z0 + per < zero_words) ? z0 + per : zero_words;
         for (int j = z0 + tid; j < z1; j += GG_NT1) zero_base[j] = 0;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(GG_NT1) void gg_k_chunk_split(
 
 // ------------------------------------------------------------------------------------------
 // K2.  grid (nslab, B), block 64*NW, dynamic LDS:
-//   wc[NW][S] | voff[S+1] | ltmp[S] | roff[nchunk+1] | rsrc[nchunk] | hist[65] | lid[NW][CAPW] |
+//   wc[NW][S] | voff[S+1] | ltmp[S] | roff[nchunk+1] | rsrc[nchunk] | lid[NW][CAPW] |
 //   lvl[NW][CAPW] (u16)
 // The slab's item list = its runs in ascending chunk order (ascending point id).  Wave w owns the
 // runs of the chunks [nchunk*w/NW, nchunk*(w+1)/NW) and streams that part of the list through its
@@ -247,14 +249,15 @@ struct GGSlabArgs {
     const unsigned *part;
     const int *ctab;
     int2 *vtab;
-    int *sorted, *bkt, *lead, *ltab;
+    int *sorted, *bkt;
+    unsigned *lbm;   // leader bitmap [B][ceil(N/32)]: bit i = point i is the first point of its voxel
     int N;
 };
 
 template <int NW> struct GGCapW { static constexpr int value = NW >= 8 ? 256 : 512; };
 
 template <bool WITH_CENTRES, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void gg_k_slab_build(GGSlabArgs a, GGGrid gp, GGSplit sp)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void gg_k_slab_build(GGSlabArgs a, int B, GGGrid gp, GGSplit sp)
 {
     constexpr int NT = 64 * NW;
     constexpr int CAPW = GGCapW<NW>::value;
@@ -265,12 +268,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
     int *ltmp = voff + S + 1;            // [S]
     int *roff = ltmp + S;                // [nchunk+1]
     int *rsrc = roff + nchunk + 1;       // [nchunk]
-    int *hist = rsrc + nchunk;           // [GG_MAX_R+1]
-    int *lid = hist + GG_MAX_R + 1;      // [NW][CAPW]
+    int *lid = rsrc + nchunk;            // [NW][CAPW]
     unsigned short *lvl = (unsigned short *)(lid + NW * CAPW);
     __shared__ int s_w[2 * NW];
     __shared__ int s_dense;
-    const int b = blockIdx.y, s = blockIdx.x;
+    int b, s;
+    gg_cloud_item(blockIdx.x, sp.nslab, B, b, s);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wgid = b * sp.nslab + s;
     GG_STAMP(1, wgid, 0);
@@ -287,7 +290,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
         }
         if (c0 == 0) {  // overlapped with the table loads
             for (int j = tid; j < NW * S; j += NT) wc[j] = 0;
-            for (int j = tid; j <= GG_MAX_R; j += NT) hist[j] = 0;
             if (tid == 0) s_dense = 0;
         }
         int tl;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
             wc[w * S + j] = run;
             run += cw;
         }
-        ltmp[j] = run;  // population, replaced by the leader id in pass 2
+        ltmp[j] = run;  // population
         mine += run;
     }
     int tot_chk;
@@ -429,7 +431,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
                     const int vo = voff[vl];
                     const int n = pos - vo;            // rank of the point inside its voxel
                     const int cv = voff[vl + 1] - vo;  // population of the voxel
-                    if (n == 0) ltmp[vl] = id;
+                    if (n == 0)   // first point of its voxel: a leader of the cloud
+                        atomicOr(&a.lbm[(size_t)b * ((N + 31) >> 5) + (id >> 5)], 1u << (id & 31));
                     if (cv > gp.P) {
                         // S0: item n < P sits in slot n; item n >= P overwrites slot r(n) if
                         // r(n) < P (gridify.cu:146-153).  Last writer = largest n = largest id.
@@ -447,154 +450,114 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
         __builtin_amdgcn_wave_barrier();
     }
     GG_STAMP(1, wgid, 5);
-    if (!WITH_CENTRES) return;
-    __syncthreads();
-    // ---- leaders of the slab (first point of every occupied voxel), grouped by the point range
-    //      id >> RSB they fall in (any order inside a group: K3 only needs the set) ----
-    for (int j = tid; j < S; j += NT)
-        if (voff[j + 1] - voff[j] > 0) atomicAdd(&hist[ltmp[j] >> sp.RSB], 1);
-    __syncthreads();
-    if (wave == 0) {
-        const int h = lane < sp.R ? hist[lane] : 0;  // R <= 64
-        const int incl = gg_wave_incl_scan(h);
-        int *row = a.ltab + ((size_t)b * sp.nslab + s) * (sp.R + 1);
-        if (lane < sp.R) {
-            hist[lane] = incl - h;
-            row[lane] = base_s + incl - h;
-        }
-        if (lane == 63) row[sp.R] = base_s + incl;
-    }
-    __syncthreads();
-    int *ldst = a.lead + gbase;
-    for (int j = tid; j < S; j += NT)
-        if (voff[j + 1] - voff[j] > 0) {
-            const int id = ltmp[j];
-            ldst[atomicAdd(&hist[id >> sp.RSB], 1)] = id;
-        }
-    GG_STAMP(1, wgid, 6);
 }
 
 // ------------------------------------------------------------------------------------------
-// K3.  grid (R, B), block 256, dynamic LDS = 2*(2^RSB/32) + 2*(nslab+1) ints.  Centre slots = RVS
-// reservoir over the occupied voxels in order of first appearance (gridify.cu:165-189): t = rank
-// of the voxel's first point among all first points.  A workgroup owns the point range
-// [r << RSB, (r+1) << RSB): from every slab's table row it takes the number of leaders below its
-// range and the position of the slab's leaders inside it, marks those in an LDS bitmap; a prefix
-// popcount gives t.  slotfirst1[b,O] holds (first point id of the chosen voxel) + 1, 0 = empty;
-// "last writer wins" of S0 = largest t = largest id -> atomicMax.
+// K3.  grid = B * ceil(nw32 / 128) workgroups of 128 threads; a thread owns ONE word of the cloud's
+// leader bitmap (32 points).  Centre slots = RVS reservoir over the occupied voxels in order of
+// first appearance (gridify.cu:165-189): t = rank of the voxel's first point among all first
+// points = number of bitmap bits below it.  Voxel t < O sits in slot t; voxel t >= O overwrites
+// slot r(t) if r(t) < O; "last writer wins" of S0 = largest t = largest first point -> atomicMax on
+// (first point id + 1), 0 = empty.
+// Per wave: the set bits are compacted into an LDS list (position = rank), then the list is walked
+// 64 leaders at a time with every lane busy.  No dependent global load anywhere: bitmap words in,
+// atomics out.  (A form that also fetched the landing leaders' points to record the voxel id in the
+// slot -- one dependent load less in the query -- cost the first workgroup of every cloud, where all
+// ~950 leaders land, 8 us for its scattered loads: dropped.)
+#define GG_NT3 128
 __global__ __launch_bounds__(GG_NT3) void gg_k_centre_slots(
-    int N, GGGrid gp, GGSplit sp, const int *__restrict__ lead, const int *__restrict__ ltab,
+    int N, int B, GGGrid gp, int nchunk, const unsigned *__restrict__ lbm,
     const unsigned long long *__restrict__ wsum_blk, int *__restrict__ slotfirst1,
     int *__restrict__ centnum, int *__restrict__ exact)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned lds3[];
-    const int nslab = sp.nslab, R = sp.R, RSB = sp.RSB;
-    const int nw = (1 << RSB) >> 5;
-    unsigned *bm = lds3;                    // [nw]   leaders of this range
-    int *pre = (int *)(bm + nw);            // [nw]   exclusive prefix popcount
-    int *rpos = pre + nw;                   // [nslab+1] list offset of the slab's run
-    int *rsrc = rpos + nslab + 1;           // [nslab]   its position in lead[] minus the offset
-    __shared__ int s_w[2 * (GG_NT3 / 64)];
-    const int b = blockIdx.y, r = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lo = r << RSB;
-    const int wgid = b * gridDim.x + r;
-    GG_STAMP(2, wgid, 0);
-    for (int j = tid; j < nw; j += GG_NT3) bm[j] = 0u;
-    const int *lb = lead + (size_t)b * N;
-    int before = 0, nlead = 0, nown = 0;
-    for (int s0 = 0; s0 < nslab; s0 += GG_NT3) {
-        const int s = s0 + tid;
-        int a0 = 0, len = 0;
-        if (s < nslab) {
-            const int *row = ltab + ((size_t)b * nslab + s) * (R + 1);
-            const int t0 = row[0], tR = row[R];
-            a0 = row[r];
-            len = row[r + 1] - a0;
-            before += a0 - t0;
-            nlead += tR - t0;
-        }
-        int tl;
-        const int ex = gg_block_excl_scan<GG_NT3 / 64>(len, s_w, &tl);
-        if (s < nslab) {
-            rpos[s] = nown + ex;
-            rsrc[s] = a0 - (nown + ex);
-        }
-        nown += tl;
-    }
-    if (tid == 0) rpos[nslab] = nown;
-    gg_block_sum2<GG_NT3 / 64>(before, nlead, s_w);  // + barriers: rpos/rsrc/bm visible
-    GG_STAMP(2, wgid, 1);
-    // the range's own leaders, flat over the runs: four loads in flight per thread
-    for (int p0 = tid; p0 < nown; p0 += 4 * GG_NT3) {
-        int id[4];
+    constexpr int NW = GG_NT3 / 64;
+    __shared__ int s_before[NW], s_wtot[NW];
+    __shared__ int s_list[NW][2048];       // leader ids of a wave's 64 words
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw32 = (N + 31) >> 5;
+    const int nwg = (nw32 + GG_NT3 - 1) / GG_NT3;
+    int b, r;
+    gg_cloud_item(blockIdx.x, nwg, B, b, r);
+    const unsigned *bm = lbm + (size_t)b * nw32;
+    const int w_first = r * GG_NT3;
+    GG_STAMP(2, blockIdx.x, 0);
+    // ---- leaders below this workgroup's words (unconditional loads from clamped addresses, the
+    //      select applied at use: eight in flight per thread) ----
+    const int wi = w_first + tid;
+    const unsigned word = bm[wi < nw32 ? wi : nw32 - 1] & (wi < nw32 ? ~0u : 0u);
+    int before = 0;
+    for (int j0 = tid; j0 < w_first; j0 += 8 * GG_NT3) {
+        unsigned x[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int p = p0 + u * GG_NT3;
-            id[u] = -1;
-            if (p < nown) {
-                int l = 0, h = nslab;  // rpos[l] <= p < rpos[h]
-                while (h - l > 1) {
-                    const int mid = (l + h) >> 1;
-                    if (rpos[mid] <= p) l = mid; else h = mid;
-                }
-                id[u] = lb[rsrc[l] + p];
-            }
+        for (int u = 0; u < 8; u++) {
+            const int j = j0 + u * GG_NT3;
+            x[u] = bm[j < w_first ? j : 0];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (id[u] >= 0) {
-                const unsigned d = (unsigned)(id[u] - lo);
-                atomicOr(&bm[d >> 5], 1u << (d & 31u));
-            }
+        for (int u = 0; u < 8; u++) before += j0 + u * GG_NT3 < w_first ? __popc(x[u]) : 0;
     }
+    before = gg_wave_sum(before);
+    const int pc = __popc(word);
+    const int incl = gg_wave_incl_scan(pc);
+    const int wtot = __shfl(incl, 63, 64);
+    if (lane == 0) { s_before[wave] = before; s_wtot[wave] = wtot; }
     __syncthreads();
-    GG_STAMP(2, wgid, 2);
-    int nbefore = before;
-    for (int w0 = 0; w0 < nw; w0 += GG_NT3) {
-        const int wi = w0 + tid;
-        const int pc = wi < nw ? __popc(bm[wi]) : 0;
-        int tot;
-        const int ex = gg_block_excl_scan<GG_NT3 / 64>(pc, s_w, &tot);
-        if (wi < nw) pre[wi] = nbefore + ex;
-        nbefore += tot;
+    int nbefore = 0, below_waves = 0, wg_total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        nbefore += s_before[w];
+        if (w < wave) below_waves += s_wtot[w];
+        wg_total += s_wtot[w];
     }
-    __syncthreads();
-    // one bit position per thread and step: the picks spread evenly over the block
-    for (int q = tid; q < (1 << RSB); q += GG_NT3) {
-        const unsigned word = bm[q >> 5];
-        if ((word >> (q & 31)) & 1u) {
-            const int t = pre[q >> 5] + __popc(word & ((1u << (q & 31)) - 1u));
-            const int id = lo + q;
-            int sl = t;
-            if (t >= gp.O) {
-                const int gi = (int)((long long)b * N + id);
-                sl = gg_reservoir_pick((unsigned long long)(long long)gi + 2ull * gg_seed(gp), t + 1);
-            }
-            if (sl < gp.O) atomicMax(&slotfirst1[(size_t)b * gp.O + sl], id + 1);
+    const int t_wave = nbefore + below_waves;   // rank of this wave's first leader
+    GG_STAMP(2, blockIdx.x, 1);
+    // ---- compact this wave's leaders: list position = rank - t_wave ----
+    {
+        int q = incl - pc;
+        unsigned m = word;
+        const int id0 = wi << 5;
+        while (m) {
+            s_list[wave][q++] = id0 + __builtin_ctz(m);
+            m &= m - 1u;
         }
     }
-    GG_STAMP(2, wgid, 3);
-    if (r == 0 && tid < 64) {
-        // weights of the cloud are integers and sum(|w|) < 2^23: every partial sum of S0's
-        // total_weight accumulation is exact, so it may be evaluated in any order
+    __builtin_amdgcn_wave_barrier();
+    GG_STAMP(2, blockIdx.x, 2);
+    const int O = gp.O;
+    const unsigned long long seed2 = 2ull * gg_seed(gp);
+    int *slots = slotfirst1 + (size_t)b * O;
+    for (int i = lane; i < wtot; i += 64) {
+        const int id = s_list[wave][i];
+        const int t = t_wave + i;
+        int sl = t;
+        if (t >= O) {
+            const int gi = (int)((long long)b * N + id);
+            sl = gg_reservoir_pick((unsigned long long)(long long)gi + seed2, t + 1);
+        }
+        if (sl < O) atomicMax(&slots[sl], id + 1);
+    }
+    GG_STAMP(2, blockIdx.x, 3);
+    if (r == nwg - 1 && wave == 0) {
+        // the cloud's last words: all leaders counted.  Weights of the cloud are integers and
+        // sum(|w|) < 2^23: every partial sum of S0's total_weight accumulation is exact, so it may
+        // be evaluated in any order
+        const int nlead = nbefore + wg_total;
         long long ws = 0;
         int fl = 0;
-        for (int j = tid; j < sp.nchunk; j += 64) {
-            const unsigned long long x = wsum_blk[(size_t)b * sp.nchunk + j];
+        for (int j = lane; j < nchunk; j += 64) {
+            const unsigned long long x = wsum_blk[(size_t)b * nchunk + j];
             fl |= (int)(x >> 62);
             ws += (long long)(x & ~(3ull << 62));
         }
         ws = gg_wave_sum_ll(ws);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) fl |= __shfl_xor(fl, d, 64);
-        if (tid == 0) {
-            centnum[b] = nlead < gp.O ? nlead : gp.O;
+        if (lane == 0) {
+            centnum[b] = nlead < O ? nlead : O;
             const int ex = (!(fl & 2) && ws < (1ll << 23)) ? 1 : 0;
             exact[b] = ex | ((ex && !(fl & 1)) ? 2 : 0);
         }
     }
-    GG_STAMP(2, wgid, 4);
 }
 GG_PROF_SETTER(gridgcn_prof_set_index)
 
@@ -605,6 +568,16 @@ static unsigned gg_inv_odd(unsigned a)  // inverse of an odd number mod 2^32 (Ne
     for (int i = 0; i < 5; i++) x *= 2u - a * x;
     return x;
 }
+
+// plan overrides for measurements (include/gridgcn.h: gridgcn_set_option): shift of log2(slabs per
+// cloud), points per chunk (0 = automatic)
+static int g_opt_kb_shift = 0, g_opt_chunk = 0;
+void gg_index_set_tuning(int which, int value)
+{
+    if (which == 0) g_opt_kb_shift = value;
+    else g_opt_chunk = value;
+}
+int gg_index_get_tuning(int which) { return which == 0 ? g_opt_kb_shift : g_opt_chunk; }
 
 static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
 {
@@ -623,6 +596,8 @@ static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
         if (!grow && !shrink) break;
         KB++;
     }
+    KB += g_opt_kb_shift;
+    KB = KB < 0 ? 0 : (KB > MB ? MB : KB);
     if (KB > 10 || MB - KB + GG_XRB > GG_MAX_SB) return false;
     w->KB = KB;
     w->MB = MB;
@@ -638,14 +613,12 @@ static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
     while (CH < GG_CHUNK_MAX &&
            ((long long)B * ((N + CH - 1) / CH) > 512 || (N + CH - 1) / CH > GG_MAX_CHUNKS))
         CH *= 2;
+    if ((g_opt_chunk == 1024 || g_opt_chunk == 2048 || g_opt_chunk == 4096) &&
+        (N + g_opt_chunk - 1) / g_opt_chunk <= GG_MAX_CHUNKS)
+        CH = g_opt_chunk;
     w->CH = CH;
     w->nblk = (N + CH - 1) / CH;
     if (w->nblk > GG_MAX_CHUNKS) return false;
-    // centre kernel: ranges of 2^RSB >= 4096 points, at most GG_MAX_R per cloud
-    int RSB = 12;
-    while ((((long long)N + (1ll << RSB) - 1) >> RSB) > GG_MAX_R) RSB++;
-    w->RSB = RSB;
-    w->R = (int)(((long long)N + (1ll << RSB) - 1) >> RSB);
     return true;
 }
 
@@ -661,8 +634,6 @@ static GGSplit gg_split_of(const GGIndexWs &w)
     sp.nslab = w.nslab;
     sp.nchunk = w.nblk;
     sp.CH = w.CH;
-    sp.R = w.R;
-    sp.RSB = w.RSB;
     return sp;
 }
 
@@ -671,12 +642,7 @@ static size_t gg_k2_lds(int SB, int nchunk, int NW)
 {
     const size_t S = (size_t)1 << SB;
     const size_t capw = NW >= 8 ? 256 : 512;
-    return (NW * S + (S + 1) + S + (nchunk + 1) + nchunk + (GG_MAX_R + 1) + NW * capw) * 4 +
-           NW * capw * 2;
-}
-static size_t gg_k3_lds(int RSB, int nslab)
-{
-    return (size_t)(2 * ((1 << RSB) >> 5) + 2 * (nslab + 1)) * 4;
+    return (NW * S + (S + 1) + S + (nchunk + 1) + nchunk + NW * capw) * 4 + NW * capw * 2;
 }
 
 size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres, GGIndexWs *ws)
@@ -689,6 +655,7 @@ size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centre
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     // ---- zeroed by K1 ----
     w.o_slotfirst1 = take(with_centres ? (size_t)B * gp.O * 4 : 0);
+    w.o_lbm = take(with_centres ? (size_t)B * ((N + 31) / 32) * 4 : 0);
     w.zero_bytes = o;
     // ---- written before read ----
     w.o_vtab = take(BG * 8);
@@ -697,8 +664,6 @@ size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centre
     w.o_exact = take((size_t)B * 4);
     w.o_part = take(BN * 4);
     w.o_ctab = take((size_t)B * w.nblk * (w.nslab + 1) * 4);
-    w.o_lead = take(with_centres ? BN * 4 : 0);
-    w.o_ltab = take(with_centres ? (size_t)B * w.nslab * (w.R + 1) * 4 : 0);
     w.o_wsum = take((size_t)B * w.nblk * 8);
     w.total = o;
     w.legacy = 0;
@@ -710,8 +675,8 @@ template <bool WC, int NW>
 static void gg_launch_k2(const GGSlabArgs &a, const GGGrid &gp, const GGSplit &sp, int B,
                          hipStream_t st)
 {
-    gg_k_slab_build<WC, NW><<<dim3(sp.nslab, B), 64 * NW, gg_k2_lds(sp.SB, sp.nchunk, NW), st>>>(
-        a, gp, sp);
+    gg_k_slab_build<WC, NW><<<sp.nslab * B, 64 * NW, gg_k2_lds(sp.SB, sp.nchunk, NW), st>>>(
+        a, B, gp, sp);
 }
 
 int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid &gp,
@@ -724,32 +689,32 @@ int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid 
     unsigned *part = (unsigned *)(wsbase + w.o_part);
     int *ctab = (int *)(wsbase + w.o_ctab);
     unsigned long long *wsum = (unsigned long long *)(wsbase + w.o_wsum);
-    const dim3 g1(sp.nchunk, B);
+    const int g1 = sp.nchunk * B;
     const size_t l1 = gg_k1_lds(sp.nslab, sp.CH);
     const float4 *d4 = (const float4 *)data;
     int *zb = (int *)wsbase;
     const int zw = (int)(w.zero_bytes / 4);
     if (sp.CH == 1024)
-        gg_k_chunk_split<1><<<g1, GG_NT1, l1, st>>>(d4, np, N, gp, sp, part, ctab, wsum, zb, zw);
+        gg_k_chunk_split<1><<<g1, GG_NT1, l1, st>>>(d4, np, N, B, gp, sp, part, ctab, wsum, zb, zw);
     else if (sp.CH == 2048)
-        gg_k_chunk_split<2><<<g1, GG_NT1, l1, st>>>(d4, np, N, gp, sp, part, ctab, wsum, zb, zw);
+        gg_k_chunk_split<2><<<g1, GG_NT1, l1, st>>>(d4, np, N, B, gp, sp, part, ctab, wsum, zb, zw);
     else
-        gg_k_chunk_split<4><<<g1, GG_NT1, l1, st>>>(d4, np, N, gp, sp, part, ctab, wsum, zb, zw);
+        gg_k_chunk_split<4><<<g1, GG_NT1, l1, st>>>(d4, np, N, B, gp, sp, part, ctab, wsum, zb, zw);
     GGSlabArgs a;
     a.part = part;
     a.ctab = ctab;
     a.vtab = (int2 *)(wsbase + w.o_vtab);
     a.sorted = (int *)(wsbase + w.o_sorted);
     a.bkt = with_centres ? (int *)(wsbase + w.o_bkt) : nullptr;
-    a.lead = with_centres ? (int *)(wsbase + w.o_lead) : nullptr;
-    a.ltab = with_centres ? (int *)(wsbase + w.o_ltab) : nullptr;
+    a.lbm = with_centres ? (unsigned *)(wsbase + w.o_lbm) : nullptr;
     a.N = N;
     if (with_centres) {
         if (w.NW2 == 8) gg_launch_k2<true, 8>(a, gp, sp, B, st);
         else if (w.NW2 == 4) gg_launch_k2<true, 4>(a, gp, sp, B, st);
         else gg_launch_k2<true, 2>(a, gp, sp, B, st);
-        gg_k_centre_slots<<<dim3(sp.R, B), GG_NT3, gg_k3_lds(sp.RSB, sp.nslab), st>>>(
-            N, gp, sp, a.lead, a.ltab, wsum, (int *)(wsbase + w.o_slotfirst1), centnum,
+        const int nw32 = (N + 31) / 32;
+        gg_k_centre_slots<<<B * ((nw32 + GG_NT3 - 1) / GG_NT3), GG_NT3, 0, st>>>(
+            N, B, gp, sp.nchunk, a.lbm, wsum, (int *)(wsbase + w.o_slotfirst1), centnum,
             (int *)(wsbase + w.o_exact));
     } else {
         if (w.NW2 == 8) gg_launch_k2<false, 8>(a, gp, sp, B, st);
@@ -777,8 +742,5 @@ int gg_index_init()
         if (hipFuncSetAttribute(k2[i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)gg_k2_lds(sb2[i], GG_MAX_CHUNKS, nw2[i])) != hipSuccess)
             return 3;
-    if (hipFuncSetAttribute((const void *)gg_k_centre_slots,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess)
-        return 3;
     return gg_index_legacy_init();
 }

@@ -75,6 +75,10 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
 #define GRIDGCN_OPT_ATT_BWD_FUSED 0  /* [1] one-pass backward of the attention conv (dX, previous
                                       *     layer's BN sums and dW from one read of Z); 0 = the
                                       *     separate dX and dW kernels */
+#define GRIDGCN_OPT_INDEX_SLAB_SHIFT 1 /* [0] voxel-index build: added to log2(slabs per cloud), -4..4  */
+#define GRIDGCN_OPT_INDEX_CHUNK 2      /* [0 = automatic] voxel-index build: points per chunk, 1024 / 2048 /
+                                        *     4096.  Both only move work between the build's kernels;
+                                        *     results are identical for every setting. */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 

@@ -55,7 +55,10 @@ for k in range(NK):
     used = t[k][:, 0] > 0
     if not used.any():
         continue
-    tk = t[k][used]
+    tk = t[k][used].copy()
+    # slots 14 / 15: shader clock (s_memtime) at the first / latest stamp of the workgroup
+    sclk = (tk[:, 15] - tk[:, 14]) / 0.01           # undo the 100 MHz scaling: raw cycles
+    tk[:, 14:] = 0
     nst = int((tk > 0).all(axis=0).sum())
     start, end = tk[:, 0].min(), tk[:, :nst].max()
     if t0 is None:
@@ -69,3 +72,15 @@ for k in range(NK):
     tot = tk[:, nst - 1] - tk[:, 0]
     print("    WG total : median %6.2f  p95 %6.2f  max %6.2f us" % (
         np.median(tot), np.percentile(tot, 95), tot.max()))
+    last = np.array([row[:14][row[:14] > 0].max() for row in tk])
+    mhz = sclk / np.maximum(last - tk[:, 0], 1e-3)
+    print("    shader clock over the workgroups' lives: median %.0f MHz (min %.0f, max %.0f)" % (
+        np.median(mhz), mhz.min(), mhz.max()))
+    if k == 1 and nst < NS and (tk[:, nst + 1] > 0).any():
+        # centre pass: only the last slab workgroup of each cloud stamps nst (ticket drawn) and nst+1
+        cp = tk[tk[:, nst + 1] > 0]
+        d = cp[:, nst + 1] - cp[:, nst]
+        print("    centre pass (%d workgroups): median %.2f  max %.2f us; starts %.2f .. %.2f us after the "
+              "kernel's start, kernel ends at +%.2f us" % (len(cp), np.median(d), d.max(),
+                                                           cp[:, nst].min() - start, cp[:, nst].max() - start,
+                                                           cp[:, nst + 1].max() - start))
