@@ -66,15 +66,21 @@ def cpu_baseline(cfg, B, points, kind, sample_clouds):
     x = torch.from_numpy(data[:S, :, :3].copy())
     n = torch.from_numpy(npn[:S])
     lab = torch.randint(0, cfg["num_classes"], (S, points))
-    t0 = time.perf_counter()
-    loss = model.seg_loss(m(x, n), lab)
-    loss.backward()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(2):            # the first pass pays thread-pool start-up, page faults, oneDNN set-up
+        for prm in m.parameters():
+            prm.grad = None
+        t0 = time.perf_counter()
+        loss = model.seg_loss(m(x, n), lab)
+        loss.backward()
+        dts.append(time.perf_counter() - t0)
+    dt = dts[1]
     return {"value": S / dt, "unit": "point-clouds/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": "%d of the %d clouds x %d pts, one fwd+bwd: S0 oracle (C, OpenMP across clouds) for "
-                      "Gridify/BallKNN + PyTorch-CPU (%d threads) for gather/GridConv" % (
-                          S, B, points, torch.get_num_threads()),
+            "sample": "%d of the %d clouds x %d pts, fwd+bwd twice, the SECOND pass reported (first: "
+                      "%.2f s): S0 oracle (C, OpenMP across clouds) for Gridify/BallKNN + PyTorch-CPU "
+                      "(%d threads) for gather/GridConv" % (S, B, points, dts[0],
+                                                            torch.get_num_threads()),
             "ms_per_cagq_layer": dt_g * 1e3,
             "cagq_threads": cagq_threads,
             "cagq_sample": "Gridify down layer 0 on the same %d-cloud batch, OpenMP across clouds "
@@ -197,14 +203,14 @@ def time_training(step, steps, warmup, world, dev):
     return dt, t_enq
 
 
-def cagq_roofline(d4, n, kw, B, N, traffic, key):
-    ms, _ = ops.gridify_timed(d4, n, 100, **kw)
+def cagq_roofline(d4, n, kw, B, N, traffic, key, iters=100):
+    ms, _ = ops.gridify_timed(d4, n, iters, **kw)
     alg = B * synth.gridify_algorithmic_bytes(N, kw["max_o_grid"], kw["max_p_grid"])
     ach = alg / (ms * 1e-3) / 1e9
     return ms, {"bound": "hbm",
                 "kernel": "gridgcn_gridify (gg_k_chunk_split + gg_k_slab_build + gg_k_centre_slots "
-                          "+ gg_k_query_gridify; 100 back-to-back calls between two HIP events on "
-                          "the launch stream)",
+                          "+ gg_k_query_gridify; %d back-to-back calls between two HIP events on "
+                          "the launch stream)" % iters,
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic.get(key), "traffic_key": key,
                 "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
@@ -222,6 +228,11 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="points per cloud (0: the config's own)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="clouds of the CPU fwd+bwd sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--micro-iters", type=int, default=50,
+                    help="launches per micro-benchmark (median reported); the PMC passes use 3")
+    ap.add_argument("--no-micro", action="store_true",
+                    help="only the timed step: no per-kernel rooflines, no inference, no CPU baseline "
+                         "(what the PMC passes of tools/r3_pmc_step.sh run)")
     ap.add_argument("--eager", action="store_true", help="time the eager step instead of the hipGraph replay")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="contraction precision of the training GEMM kernels: f32 = exact fp32 MFMA "
@@ -305,17 +316,25 @@ def main():
                           "achieved": tf_step, "peak": MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0,
                           "unit": "TFLOP/s",
                           "frac": tf_step / (MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0),
-                          "traffic": None,
+                          "traffic": None, "mfma_busy": None,
                           "algorithmic_flops_per_step": step_flops,
                           "edge_flops_fwd": fe, "per_point_flops_fwd": fr},
     }
 
-    if rank == 0 and world == 1:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # whole-step HBM bytes and MFMA-pipe utilisation from the PMC passes over one eager step
+    # (tools/r3_pmc_step.sh -> profiles/traffic.json), f32 only
+    if a.dtype == "f32" and points == 81920 and B == 8:
+        out["roofline_step"]["traffic"] = traffic.get("step_cfg4")
+        out["roofline_step"]["mfma_busy"] = traffic.get("step_cfg4_mfma_busy")
+        out["roofline_step"]["traffic_key"] = "step_cfg4"
+    if rank == 0 and world == 1 and not a.no_micro:
+        from grid_gcn_amd.train_ops import median_ms
         # ---- ms per CAGQ layer: Gridify of down layer 0 on the same batch ----
         kw = synth.gridify_kwargs(cfg["grid"], 0)
         d4 = torch.from_numpy(data).to(dev)
-        ms, rc = cagq_roofline(d4, n, kw, B, points, traffic, "gridify_N%d_B%d" % (points, B))
+        mi = a.micro_iters
+        ms, rc = cagq_roofline(d4, n, kw, B, points, traffic, "gridify_N%d_B%d" % (points, B),
+                               iters=2 * mi)
         out["ms_per_cagq_layer"] = ms
         out["roofline_cagq"] = rc
         # ---- inference forward through the fused GridConv kernels (the reference's own speed
@@ -326,30 +345,14 @@ def main():
             net.jobs = []
             net(x, n)
             jobs, net.jobs = net.jobs, None
-            for _ in range(2):
-                net(x, n)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(10):
-                net(x, n)
-            e1.record()
-            torch.cuda.synchronize()
-            ms_inf = e0.elapsed_time(e1) / 10
+            ms_inf = median_ms(lambda: net(x, n), max(3, mi // 2), 3, dev)
             name, layer, cent_, src_, idx_ = max(jobs, key=lambda j: j[4].numel() * j[1].cin)
             pt, att = layer.packed_layers()
             src_ = src_.contiguous()
             call = lambda: ops.gridconv_forward(src_, idx_, cent_, pt, att,  # noqa: E731
                                                 has_feats=layer.has_feats,
                                                 localfdim=layer.localfdim)
-            for _ in range(3):
-                call()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(20):
-                call()
-            e1.record()
-            torch.cuda.synchronize()
-            ms_k = e0.elapsed_time(e1) / 20
+            ms_k = median_ms(call, mi, 5, dev)
             # the path evaluation actually takes for this layer (one point conv: source-side)
             ms_src = None
             from grid_gcn_amd import train_ops as _to
@@ -357,15 +360,7 @@ def main():
             if _to.edge_block_src_eval_supported(ptl, attl, src_, layer.has_feats):
                 call2 = lambda: _to.edge_block_src_eval(src_, idx_, cent_.contiguous(), ptl[0],  # noqa: E731
                                                         attl, layer.localfdim)
-                for _ in range(3):
-                    call2()
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(20):
-                    call2()
-                e1.record()
-                torch.cuda.synchronize()
-                ms_src = e0.elapsed_time(e1) / 20
+                ms_src = median_ms(call2, mi, 5, dev)
         macs = sum(l.lin.in_features * l.lin.out_features
                    for seq in (layer.pt_mlp, layer.att1, layer.att2) for l in seq)
         flops = 2.0 * idx_.numel() * macs
@@ -374,7 +369,9 @@ def main():
             "bound": "mfma", "kernel": "gg_k_gridconv (GridConv %s: gather + per-edge MLPs + att "
             "product + max, one launch, inference-mode BatchNorm)" % name,
             "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+            "frac": tf / MFMA_F32_PEAK_TF,
+            "traffic": traffic.get("gridconv_%s_E%d" % (name, idx_.numel())),
+            "traffic_key": "gridconv_%s_E%d" % (name, idx_.numel()),
             "algorithmic_flops_per_launch": flops, "ms_per_launch": ms_k,
             "dtype": "f32 (v_mfma_f32_32x32x2_f32)",
             # evaluation runs this layer through the source-side kernels instead (first conv once
@@ -393,12 +390,13 @@ def main():
         cin_b = layer.att2[0].lin.in_features
         c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
-        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=10, device=dev,
+        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev,
                                          ndx=cin_b, prev_bn=True)
         e_b = float(ncent_b * p_b)
         # algorithmic bytes of the operation: read Z [E,C] once, the sparse upstream gradient
-        # (amax, gval) [ncent,C], the previous layer's raw output [E,cin]; write dX [E,cin]
-        bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 8.0 * ncent_b * c_b
+        # (one-byte amax + fp32 gval) [ncent,C], the previous layer's raw output [E,cin]; write
+        # dX [E,cin]
+        bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 5.0 * ncent_b * c_b
         gbs_b = bytes_b / (ms_b * 1e-3) / 1e9
         key_b = "att_bwd_fused_E%d_%dto%d" % (int(e_b), cin_b, c_b)
         out["roofline"] = {"bound": "hbm", "kernel": "gg_k_att_bwd_fused + gg_k_att_dw_reduce "
@@ -415,12 +413,14 @@ def main():
         # the largest MFMA-bound kernel of the step: forward of the 256->128 update conv over
         # all B*N points (previous BatchNorm+ReLU applied while loading, statistics epilogue)
         e_f, cin_f, c_f = B * points, 256, 128
-        ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=10, device=dev)
+        ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=mi, device=dev)
         tf_f = 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12
         out["roofline_mfma"] = {"bound": "mfma", "kernel": "gg_k_linear_fwd_direct (%d->%d conv + "
                                 "BN/ReLU prologue + statistics over %d rows)" % (cin_f, c_f, e_f),
                                 "achieved": tf_f, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": tf_f / MFMA_F32_PEAK_TF, "traffic": None,
+                                "frac": tf_f / MFMA_F32_PEAK_TF,
+                                "traffic": traffic.get("linear_fwd_E%d_%dto%d" % (e_f, cin_f, c_f)),
+                                "traffic_key": "linear_fwd_E%d_%dto%d" % (e_f, cin_f, c_f),
                                 "algorithmic_flops_per_launch": 2.0 * e_f * cin_f * c_f,
                                 "ms_per_launch": ms_f, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         # ---- the materialising neighbour gather as an operator (SURVEY §8(d) algorithmic bytes):
@@ -428,32 +428,18 @@ def main():
         with torch.no_grad():
             gsrc = src_.contiguous()
             tk = lambda: ops.batch_take_g(gsrc, idx_, neighbour_index=True)  # noqa: E731
-            for _ in range(3):
-                tk()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(20):
-                tk()
-            e1.record()
-            torch.cuda.synchronize()
-            ms_g = e0.elapsed_time(e1) / 20
+            ms_g = median_ms(tk, mi, 5, dev)
             gout = tk()
             tb = lambda: ops.batch_take_g_backward(gout, idx_, gsrc.shape[1], True)  # noqa: E731
-            for _ in range(3):
-                tb()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(20):
-                tb()
-            e1.record()
-            torch.cuda.synchronize()
-            ms_gb = e0.elapsed_time(e1) / 20
+            ms_gb = median_ms(tb, mi, 5, dev)
         alg_g = 4.0 * gsrc.numel() + 4.0 * idx_.numel() + 4.0 * idx_.numel() * gsrc.shape[2]
         out["roofline_gather"] = {
             "bound": "hbm", "kernel": "gridgcn_batch_take (batch_take_g of GridConv %s: src %s, "
             "index %s)" % (name, list(gsrc.shape), list(idx_.shape)),
             "achieved": alg_g / (ms_g * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": alg_g / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": alg_g / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic.get("batch_take_%s_E%d" % (name, idx_.numel())),
+            "traffic_key": "batch_take_%s_E%d" % (name, idx_.numel()),
             "algorithmic_bytes_per_launch": alg_g, "ms_per_launch": ms_g,
             "backward_sorted_ms": ms_gb,
             "backward_sorted_GBps": alg_g / (ms_gb * 1e-3) / 1e9}

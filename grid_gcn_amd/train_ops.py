@@ -1002,9 +1002,28 @@ def edge_block_src_train(src, nebidx, cent, pt_layers, att_layers, localfdim, ou
     return _EdgeBlockSrcTrain.apply(src, nebidx, cent, meta, *params)
 
 
-def time_linear_fwd(E, cin, C, iters=10, device="cuda:0"):
+def median_ms(call, iters=50, warm=5, device="cuda:0"):
+    """Median device time of `call()` over `iters` launches, each bracketed by its own pair of events
+    on the current stream (a mean over a handful of back-to-back launches moved by 10-15 % from box
+    to box and with the clock state the previous benchmark left behind)."""
+    with torch.cuda.device(device):
+        for _ in range(warm):
+            call()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(iters)]
+        for e0, e1 in ev:
+            e0.record()
+            call()
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return ts[len(ts) // 2]
+
+
+def time_linear_fwd(E, cin, C, iters=50, device="cuda:0"):
     """Time one gridgcn_linear_fwd_direct launch (previous layer's BatchNorm+ReLU applied on the fly,
-    statistics epilogue) on synthetic tensors.  Returns ms/launch."""
+    statistics epilogue) on synthetic tensors.  Returns the median ms/launch."""
     lib = _lib.load()
     g = torch.Generator(device=device).manual_seed(0)
     X = torch.randn(E, cin, device=device, generator=g)
@@ -1023,27 +1042,18 @@ def time_linear_fwd(E, cin, C, iters=10, device="cuda:0"):
         _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(X), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, C,
                                                  _ptr(sc), _ptr(sh), _ptr(Z), _ptr(sums),
                                                  _stream(X)), "gridgcn_linear_fwd_direct")
-    with torch.cuda.device(device):
-        for _ in range(3):
-            call()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            call()
-        e1.record()
-        torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return median_ms(call, iters, device=device)
 
 
-def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=False, dense=False):
+def time_linear_bwd(ncent, P, cin, C, iters=50, device="cuda:0", ndx=0, prev_bn=False, dense=False):
     """Time one gridgcn_linear_bwd call (dX kernel + dW kernel + dW reduce) on synthetic tensors
     shaped like the last pt layer of a GridConv edge block (sparse upstream gradient, input gradient
     for the first `ndx` columns; cin = padded row length).  Used by bench.py for the roofline of the
     dominant kernels of the training step.  prev_bn: the layer's input is the raw output of a
     BatchNorm'd layer (as the second attention conv's is): its BatchNorm+ReLU is applied on the fly
     and its BatchNorm-backward sums are accumulated.  dense: a dense upstream gradient [E, C]
-    instead of the max-pool's sparse one (the per-point layers of the head).  Returns ms/call."""
+    instead of the max-pool's sparse one (the per-point layers of the head).  Returns the median
+    ms/call."""
     lib = _lib.load()
     E = ncent * P
     g = torch.Generator(device=device).manual_seed(0)
@@ -1079,17 +1089,7 @@ def time_linear_bwd(ncent, P, cin, C, iters=10, device="cuda:0", ndx=0, prev_bn=
                                     None if dense else _ptr(amax), None if dense else _ptr(gval), P,
                                     _ptr(ws), nbytes.value, _stream(Z))
         _lib.check(rc, "gridgcn_linear_bwd")
-    with torch.cuda.device(device):
-        for _ in range(3):
-            call()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            call()
-        e1.record()
-        torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return median_ms(call, iters, device=device)
 
 
 def edge_block_supported(pt_layers, att_layers, nf, P=None):

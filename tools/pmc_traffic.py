@@ -30,6 +30,12 @@ ap.add_argument("--kernels", required=True,
                      "the dispatch, to tell the layers of a network apart)")
 ap.add_argument("--wide", default="gg_k_chunk_split", help="kernels whose FETCH_SIZE gets the x2")
 ap.add_argument("--grid-min", type=int, default=0, help="only dispatches with at least this grid size")
+ap.add_argument("--last", type=int, default=0,
+                help="per kernel name keep only the last N dispatches of the pass (bench.py runs its "
+                     "micro-benchmarks after the training steps: their launches are the last ones)")
+ap.add_argument("--largest", action="store_true",
+                help="per kernel name keep only the dispatches with the LARGEST grid (the micro-benchmarked "
+                     "shape when the same kernel also runs at smaller shapes in the step)")
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                               "profiles", "traffic.json"))
 a = ap.parse_args()
@@ -54,8 +60,16 @@ def per_kernel(dirname, counter):
                 continue
             for k in kernels:
                 if k in name and (k not in grids or grids[k] == grid):
-                    acc[k].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items() if v}
+                    acc[k].append((grid, float(row["Counter_Value"]), int(row["Start_Timestamp"])))
+    out = {}
+    for k, v in acc.items():
+        if a.last:
+            v = sorted(v, key=lambda x: x[2])[-a.last:]
+        if a.largest:
+            g = max(x[0] for x in v)
+            v = [x for x in v if x[0] == g]
+        out[k] = sum(x[1] for x in v) / len(v)
+    return out
 
 
 fe, wr = per_kernel(a.fetch, "FETCH_SIZE"), per_kernel(a.write, "WRITE_SIZE")

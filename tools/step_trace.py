@@ -18,7 +18,7 @@ for r in seq:
     k = r["Kernel_Name"][:60]
     agg[k][0] += 1
     agg[k][1] += d
-    if d > minus and ("gg_k" in k):
+    if d > minus:
         print("%9.1f us %-46s grid=%-9s wg=%s lds=%s" % (d, k[:46], r["Grid_Size_X"], r["Workgroup_Size_X"],
                                                       r.get("LDS_Block_Size", "")))
 print("---- by kernel")
