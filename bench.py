@@ -157,14 +157,20 @@ def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
         opt.step()
         return loss
 
+    make_step.probe = None
     if use_graph and sync is not None and sync.world > 1:
         # N > 1: the graph holds the RCCL all-reduce (graph.py); only attempted where a throw-away
         # process has shown that such a capture replays correctly
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if dist.get_backend() != "nccl" or not rccl_capture_probe(
-                sync.world, dist.get_rank(), local, inputs[0].device):
+        if dist.get_backend() != "nccl":
+            make_step.probe = "not asked (backend %s)" % dist.get_backend()
             use_graph = False
-            sys.stderr.write("N > 1 without a capturable collective: timing the eager step\n")
+        else:
+            ok = rccl_capture_probe(sync.world, dist.get_rank(), local, inputs[0].device)
+            make_step.probe = "ok" if ok else "failed"
+            use_graph = ok
+        sys.stderr.write("[rank %d] RCCL capture probe: %s -> %s step\n" % (
+            dist.get_rank(), make_step.probe, "hipgraph" if use_graph else "eager"))
     if use_graph:
         try:
             return graph.GraphedTrainStep(net, opt, loss_fn, inputs, target, sync), "hipgraph"
@@ -298,6 +304,7 @@ def main():
         "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "step_mode": step_mode,
+        "rccl_capture_probe": getattr(make_step, "probe", None),
         "config": {"workload": "BASELINE configs[3]: ScanNet %d-pt segmentation, batch %d per GPU, "
                                "3 Gridify down + 3 BallKNN up layers, Adam, fp32" % (points, B),
                    "global_batch": world * B, "points_per_cloud": points,

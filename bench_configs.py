@@ -19,6 +19,9 @@ def _line(metric, value, unit, a, world, ms_step, workload, extra):
            "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": unit != "ms",
            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
            "config": {"workload": workload, "parallelism": "dp%d" % world}}
+    cx = extra.pop("config_extra", None)
+    if cx:
+        out["config"].update(cx)
     out.update(extra)
     return out
 
@@ -81,7 +84,8 @@ def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step):
 
     dt, t_enq = time_training(step, a.steps, a.warmup, world, dev)
     ms_step = dt / a.steps * 1e3
-    extra = {"host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "step_mode": step_mode}
+    extra = {"host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "step_mode": step_mode,
+             "rccl_capture_probe": getattr(make_step, "probe", None)}
     extra["config_extra"] = {"global_batch": world * B, "points_per_cloud": N}
     if flops is not None:
         tf = flops / (ms_step * 1e-3) / 1e12
