@@ -33,6 +33,7 @@ EXPORTS = [
     "gridgcn_edge_lin0_dwg", "gridgcn_att_max_eval",
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
+    "gridgcn_linear_fwd_ld", "gridgcn_linear_fwd_direct_ld", "gridgcn_linear_bwd_ld",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
@@ -126,6 +127,13 @@ def load():
     ll = ctypes.c_longlong
     lib.gridgcn_linear_fwd.restype = ci
     lib.gridgcn_linear_fwd.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_linear_fwd_ld.restype = ci
+    lib.gridgcn_linear_fwd_ld.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
+    lib.gridgcn_linear_fwd_direct_ld.restype = ci
+    lib.gridgcn_linear_fwd_direct_ld.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp]
+    lib.gridgcn_linear_bwd_ld.restype = ci
+    lib.gridgcn_linear_bwd_ld.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp,
+                                                      ci, vp, cs, vp]
     lib.gridgcn_linear_bwd_workspace_bytes.restype = ci
     lib.gridgcn_linear_bwd_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_bwd.restype = ci

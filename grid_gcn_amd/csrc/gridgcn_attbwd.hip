@@ -387,5 +387,6 @@ int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st)
     if (!p.Wdx || p.ndx != p.cin || !p.dX || !p.dW || !p.dWpart || !p.pscale || !p.psums) return 1;
     if (p.cin_w != p.cin || p.rot != 0 || p.drop_thr) return 1;
     if (!p.amax && (p.ldy & 3)) return 1;
+    if (p.ldz && p.ldz != p.C) return 1;
     return p.C == 64 ? launch_att_fused<2>(p, st) : launch_att_fused<4>(p, st);
 }

@@ -365,17 +365,25 @@ int gridgcn_batch_take_backward_sorted(const float *grad_out, const int32_t *ind
                                   (hipStream_t)stream);
 }
 
+int gridgcn_linear_fwd_ld(const float *X, long long E, int cin, const float *W, const float *b, int K,
+                          int ldw, int cout, const float *scale, const float *shift, float *Z,
+                          double *sums, int ldz, void *stream)
+{
+    if (!X || !W || !b || !Z || !sums || E < 1 || cin < 1 || cout < 1 || cout > ldw ||
+        (ldz && ldz < cout))
+        return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X; p.W = W; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
+    p.E = E; p.cin = cin; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = 0; p.ldz = ldz;
+    int rc = gg_linear_fwd(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, const float *b, int K,
                        int ldw, int cout, const float *scale, const float *shift, float *Z,
                        double *sums, void *stream)
 {
-    if (!X || !W || !b || !Z || !sums || E < 1 || cin < 1 || cout < 1 || cout > ldw)
-        return GRIDGCN_EINVAL;
-    GGLinFwd p;
-    p.X = X; p.W = W; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
-    p.E = E; p.cin = cin; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = 0;
-    int rc = gg_linear_fwd(p, (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
+    return gridgcn_linear_fwd_ld(X, E, cin, W, b, K, ldw, cout, scale, shift, Z, sums, 0, stream);
 }
 
 int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *bytes)
@@ -394,6 +402,22 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        const uint8_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream)
 {
+    return gridgcn_linear_bwd_ld(dY, Z, scale, shift, mean, rstd, m1, m2, Aprev, pscale, pshift, pmean,
+                                 prstd, Wb, Wg, Wdx, ndx, E, C, cin, cin_w, rot, ldy, 0, 0, dX, dW, psums,
+                                 amax, gval, P, workspace, workspace_bytes, stream);
+}
+
+int gridgcn_linear_bwd_ld(const float *dY, const float *Z, const float *scale, const float *shift,
+                          const float *mean, const float *rstd, const float *m1, const float *m2,
+                          const float *Aprev, const float *pscale, const float *pshift,
+                          const float *pmean, const float *prstd, const float *Wb, const float *Wg,
+                          const float *Wdx, int ndx, long long E,
+                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, float *dX,
+                          float *dW, double *psums,
+                          const uint8_t *amax, const float *gval, int P, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    if ((ldz && ldz < C) || nbn < 0 || nbn > cin || (nbn & 31)) return GRIDGCN_EINVAL;
     if (amax && (!gval || P < 1 || P > 256 || E % P != 0)) return GRIDGCN_EINVAL;   // one-byte arg max
     if (Wdx && (ndx < 1 || ndx > cin)) return GRIDGCN_EINVAL;
     if (cin_w < 1 || cin_w > cin || rot < 0 || rot > cin_w) return GRIDGCN_EINVAL;
@@ -414,6 +438,8 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
     p.cin_w = cin_w; p.rot = rot;
     p.ldy = (dY && !amax && ldy > 0) ? ldy : C;
     if (p.ldy < C) return GRIDGCN_EINVAL;
+    p.ldz = ldz;
+    p.nbn = nbn;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -536,18 +562,25 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, const float *Wq,
+                                 const float *b, int ldw, int cout, const float *scale,
+                                 const float *shift, float *Z, double *sums, int ldz, void *stream)
+{
+    if (!X || !Wq || !b || (!Z && !sums) || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
+        (ldx & 3) || ((uintptr_t)X & 15) || (ldz && ldz < cout))
+        return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.ldz = ldz;
+    int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream)
 {
-    if (!X || !Wq || !b || (!Z && !sums) || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
-        (ldx & 3) || ((uintptr_t)X & 15))
-        return GRIDGCN_EINVAL;
-    GGLinFwd p;
-    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
-    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx;
-    int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
+    return gridgcn_linear_fwd_direct_ld(X, E, K, ldx, Wq, b, ldw, cout, scale, shift, Z, sums, 0, stream);
 }
 
 int gridgcn_linear_fwd_direct2(const float *X1, int ld1, int K1, const float *X2, int ld2, int K2,

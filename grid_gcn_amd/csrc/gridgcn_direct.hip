@@ -275,7 +275,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
             }
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        const int ldz = EXACT ? NT * 32 : p.cout;
+        const int ldz = p.ldz ? p.ldz : (EXACT ? NT * 32 : p.cout);
         if (p.rowbias) {
             // bias per group of P rows (P % 32 == 0: one group per tile): the contribution of the
             // per-centre context vector, constant over a centre's neighbours
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         const long long r0 = tile << 5;
         long long row = r0 + (lane & 31);
         if (row >= p.E) row = p.E - 1;
-        const float *zr = p.Z + row * C;
+        const float *zr = p.Z + row * (p.ldz ? p.ldz : C);
         const float *gr;
         const gg_amax_t *ar = (const gg_amax_t *)zr;   // dense: harmless bytes, never used
         int pp = 0;
@@ -672,7 +672,8 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                 // all 16 loads of the previous layer's raw output first: dX and Aprev may alias as
                 // far as the compiler knows, so loads placed between the stores were serialised
                 float zpv[16];
-                if (prevbn) {
+                const bool tbn = prevbn && (p.nbn == 0 || p.dx_col0 + t * 32 < p.nbn);
+                if (tbn) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {          // (rows past the end: any valid address)
                         const int rr = (r & 3) + 8 * (r >> 2);
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                             dx = gg_drop_keep((unsigned long long)(base + off), drop_lo, drop_hi,
                                               p.drop_thr) ? dx * p.drop_scale : 0.f;
                         xp[off] = dx;
-                        if (prevbn) {
+                        if (tbn) {
                             const float zp = zpv[r];
                             const float d = (zp * ps_t + psh_t > 0.f) ? dx : 0.f;
                             s1 += d;
@@ -802,13 +803,17 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 // workspace as [wave][tile][reg][lane]; gg_k_dw_reduce_direct sums them into the framework layout.
 template <int MT, int NQ, int NP, int NS, bool BF16 = false>
 __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int MG, int RS,
-                                                                 long long rows_per_wg)
+                                                                 long long rows_per_wg,
+                                                                 int *__restrict__ tick, int ntick)
 {
     constexpr int NJ = 4 * NQ + 2 * NP + NS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0)   // tickets of the reduce kernel behind this one (stream order)
+        for (int t = threadIdx.x; t < ntick; t += blockDim.x) tick[t] = 0;
     const int cq = lane & 31, h = lane >> 5;
     const int mg = wave % MG, rs = wave / MG;
     const int C = p.C, cin = p.cin;
+    const int ldz = p.ldz ? p.ldz : C;
     const bool prevbn = p.pscale != nullptr, sparse = p.amax != nullptr;
 
     // row range of this wave
@@ -875,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
         const long long row = ra + 2 * s + h;
         R.ok = row < rb;
         const long long rw = R.ok ? row : (p.E - 1);
-        const float *zr = p.Z + rw * C + chl;
+        const float *zr = p.Z + rw * ldz + chl;
         const long long cc = R.ok ? cen : 0;
         const float *gr = sparse ? p.gval + cc * C + chl : p.dY + rw * p.ldy + chl;
         // dense: a harmless byte of Z, never used
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
         // competed with the 8 MFMAs of the step for the issue slots.)
         const long long nin = (rb - ra) >> 1;      // steps with both rows valid
         const long long r1 = ra + 2 * (D - 1) + h; // row of the next step to load
-        const float *zp = p.Z + r1 * C + chl;
+        const float *zp = p.Z + r1 * ldz + chl;
         const float *xp = p.Aprev + r1 * cin;
         const float *gp = sparse ? p.gval + cen * C + chl : p.dY + r1 * p.ldy + chl;
         const gg_amax_t *ap = sparse ? p.amax + cen * C + chl : (const gg_amax_t *)p.Z;
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             cen += adv;
             gp += ginc + adv * Cs;
             ap += adv * Cs;
-            zp += 2 * C;
+            zp += 2 * ldz;
             xp += 2 * cin;
         };
         for (; s + 2 * D - 1 <= nin; s += D) {
@@ -1062,36 +1067,71 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
             for (int r = 0; r < 16; r++) out[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
 }
 
-// dW[c][framework col] = sum over the waves of m-group mg(c) of their partial element.
-// thread = one partial element (tile, reg, lane) of one m-group; block = 64 elements x 16 wave
-// slices (the partials are a few tens of MB: enough loads in flight to stream them at HBM speed).
-__global__ __launch_bounds__(1024) void gg_k_dw_reduce_direct(const float *__restrict__ part,
-                                                              int nwaves, int MG, int MT, int NQ,
-                                                              int NP, int NS, int C, int cin,
-                                                              int cin_w, int rot,
-                                                              float *__restrict__ dW)
+// dW[c][framework col] = sum over the waves of m-group mg(c) of their partial element, in a FIXED
+// order (bit-reproducible), in one launch on the whole chip: grid (per/64, MG, S).  Block (x, mg, z)
+// sums the z-th of S contiguous slices of the m-group's wave list for its 64 elements -- 4 thread
+// slices, each walking its waves with eight loads in flight -- and, for S > 1, leaves the result in
+// part2[z][mg][e]; the block that draws the last ticket of its (x, mg) column adds the S slices in
+// the order z = 0 .. S-1 and writes dW.  The round-2 form gave 64 blocks of 16 slices one m-group's
+// 1024 partial tiles each: 42-48 us for 16 MB.  Tickets are zeroed by the dW kernel in front.
+#define GG_DWR_SL 4
+__global__ __launch_bounds__(64 * GG_DWR_SL) void gg_k_dw_reduce_direct(
+    const float *__restrict__ part, int nwaves, int MG, int MT, int NQ, int NP, int NS, int C, int cin,
+    int cin_w, int rot, float *__restrict__ part2, int *__restrict__ tick, float *__restrict__ dW)
 {
-    __shared__ float sh[1024];
+    __shared__ float sh[64 * GG_DWR_SL];
+    __shared__ int s_last;
     const int NJ = 4 * NQ + 2 * NP + NS;
     const int per = MT * NJ * 1024;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;          // element of the partial
-    const int mg = blockIdx.y;
-    float s0 = 0.f, s1 = 0.f;
-    if (e < per) {
-        int w = mg + sl * MG;
-        for (; w + 16 * MG < nwaves; w += 32 * MG) {
-            s0 += part[(size_t)w * per + e];
-            s1 += part[(size_t)(w + 16 * MG) * per + e];
-        }
-        if (w < nwaves) s0 += part[(size_t)w * per + e];
-    }
-    sh[threadIdx.x] = s0 + s1;
-    __syncthreads();
-    if (sl != 0 || e >= per) return;
-    float s = 0.f;
+    const int mg = blockIdx.y, z = blockIdx.z, S = gridDim.z;
+    const int nwm = nwaves / MG;                 // waves of one m-group: w = mg + i * MG
+    const int chunk = (nwm + S - 1) / S;
+    const int i0 = z * chunk, i1 = i0 + chunk < nwm ? i0 + chunk : nwm;
+    float acc[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) s += sh[k * 64 + el];
+    for (int u = 0; u < 8; u++) acc[u] = 0.f;
+    if (e < per) {
+        const float *src = part + (size_t)mg * per + e;
+        const size_t stride = (size_t)MG * per;
+        int i = i0 + sl;
+        for (; i + 7 * GG_DWR_SL < i1; i += 8 * GG_DWR_SL) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] += src[(size_t)(i + u * GG_DWR_SL) * stride];
+        }
+        for (int u = 0; i < i1; i += GG_DWR_SL, u++) acc[u & 7] += src[(size_t)i * stride];
+    }
+    sh[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    float s = 0.f;
+    if (sl == 0) {
+#pragma unroll
+        for (int k = 0; k < GG_DWR_SL; k++) s += sh[k * 64 + el];
+    }
+    if (S > 1) {
+        // hand-off without an L2 write-back: the slice sums travel as device-scope (sc1, write-through)
+        // stores and are read back with device-scope loads -- "sc1 stores and loads on both sides" of
+        // MI355X_MICROARCH's inter-workgroup section; a release fence per block (buffer_wbl2) made
+        // this kernel 45 us with 1024 blocks in flight
+        if (sl == 0 && e < per)
+            __hip_atomic_store(&part2[((size_t)z * MG + mg) * per + e], s, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_last = __hip_atomic_fetch_add(&tick[mg * gridDim.x + blockIdx.x], 1, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (sl == 0 && e < per) {
+            s = 0.f;
+            for (int zz = 0; zz < S; zz++)
+                s += __hip_atomic_load(&part2[((size_t)zz * MG + mg) * per + e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (sl != 0 || e >= per) return;
     const int lane = e & 63, r = (e >> 6) & 15, tile = e >> 10;
     const int i = tile / NJ, j = tile - i * NJ;
     const int cq = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nq = lane & 31;
@@ -1136,20 +1176,42 @@ static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
     return true;
 }
 
+// slices of the reduce's wave list (grid.z), and where its scratch sits behind the partials
+struct GGDwRed { int S, gx; size_t part_floats, part2_floats; };
+static GGDwRed gg_dw_reduce_cfg(const GGDwCfg &c)
+{
+    GGDwRed r;
+    const int NJ = 4 * c.NQ + 2 * c.NP + c.NS;
+    const int per = c.MT * NJ * 1024;
+    const int nwm = c.nwg * (c.threads / 64) / c.MG;
+    r.gx = (per + 63) / 64;
+    int S = 2048 / (r.gx * c.MG);
+    S = S > 16 ? 16 : S;
+    while (S > 1 && nwm / S < 8) S >>= 1;          // at least 8 waves per slice
+    r.S = S < 1 ? 1 : S;
+    r.part_floats = (size_t)c.nwg * (c.threads / 64) * per;
+    r.part2_floats = r.S > 1 ? (size_t)r.S * c.MG * per : 0;
+    return r;
+}
+
 size_t gg_linear_dw_direct_workspace(long long E, int cin, int C)
 {
     GGDwCfg c;
     if (!gg_dw_direct_cfg(E, C, cin, &c)) return 0;
-    return (size_t)c.nwg * (c.threads / 64) * c.MT * (4 * c.NQ + 2 * c.NP + c.NS) * 1024 * sizeof(float);
+    const GGDwRed r = gg_dw_reduce_cfg(c);
+    return (r.part_floats + r.part2_floats) * sizeof(float) + (size_t)r.gx * c.MG * sizeof(int) + 256;
 }
 
 template <int MT, int NQ, int NP, int NS>
 static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
 {
+    const GGDwRed r = gg_dw_reduce_cfg(c);
+    int *tick = (int *)(p.dWpart + r.part_floats + r.part2_floats);
+    const int ntick = r.S > 1 ? r.gx * c.MG : 0;
     if (g_mlp_bf16 && p.pscale)   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
-        gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+        gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick);
     else
-        gg_k_linear_dw_direct<MT, NQ, NP, NS, false><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg);
+        gg_k_linear_dw_direct<MT, NQ, NP, NS, false><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -1167,10 +1229,11 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
     GG_DWD(2, 0, 0, 1) GG_DWD(2, 0, 1, 0) GG_DWD(2, 0, 1, 1) GG_DWD(2, 1, 0, 0) GG_DWD(2, 1, 0, 1)
 #undef GG_DWD
     if (rc) return rc;
-    const int NJ = 4 * c.NQ + 2 * c.NP + c.NS;
-    const int per = c.MT * NJ * 1024;
     const int nwaves = c.nwg * (c.threads / 64);
-    gg_k_dw_reduce_direct<<<dim3((per + 63) / 64, c.MG), 1024, 0, st>>>(
-        p.dWpart, nwaves, c.MG, c.MT, c.NQ, c.NP, c.NS, p.C, p.cin, p.cin_w, p.rot, p.dW);
+    const GGDwRed r = gg_dw_reduce_cfg(c);
+    float *part2 = p.dWpart + r.part_floats;
+    int *tick = (int *)(part2 + r.part2_floats);
+    gg_k_dw_reduce_direct<<<dim3(r.gx, c.MG, r.S), 64 * GG_DWR_SL, 0, st>>>(
+        p.dWpart, nwaves, c.MG, c.MT, c.NQ, c.NP, c.NS, p.C, p.cin, p.cin_w, p.rot, part2, tick, p.dW);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -27,6 +27,7 @@ struct GGLinFwd {
     int K1 = 0, lda2 = 0;
     const float *rowbias = nullptr;
     int P = 0;
+    int ldz = 0;          // row stride of Z (0: cout) -- Z may be the left columns of a wider buffer
 };
 
 struct GGLinBwd {
@@ -56,6 +57,9 @@ struct GGLinBwd {
     const unsigned long long *drop_dev;    // optional device scalar added to the dropout seed
     unsigned drop_thr, drop_lo, drop_hi;   // register-direct dX only: dX *= dropout mask of the
     float drop_scale;                      // [E][cin] input activation (gg_drop_keep), thr 0 = off
+    int ldz = 0;          // row stride of Z (0: C); register-direct dX / dW kernels only
+    int nbn = 0;          // leading input columns that carry the previous layer's BatchNorm (0: all
+                          // cin); beyond them the dX epilogue neither reads Aprev nor sums
     int dx_col0 = 0;      // register-direct dX: first output column of this launch (0 / 128) and
     int dx_wstride = 1;   //   float4 stride while staging Wdx (2: one half of an 8-tile layout)
     int rt;               // rows per workgroup tile of gg_k_linear_dw (32/64/96/128)

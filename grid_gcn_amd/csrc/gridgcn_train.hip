@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_fwd(GGLinFwd p)
                     const int row = ggm_row(r, lane);
                     const float z = acc[nt][r] + bias;
                     if (cok && row < nrows) {
-                        p.Z[(r0 + row) * p.cout + col] = z;
+                        p.Z[(r0 + row) * (p.ldz ? p.ldz : p.cout) + col] = z;
                         s += z;
                         q += z * z;
                     }
@@ -961,8 +961,9 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         if (rc == 0) p.dX = nullptr;
         else if (rc != 1) return rc;
     }
-    // a strided dense dY is only understood by the register-direct kernels
+    // a strided dense dY / a strided Z is only understood by the register-direct kernels
     if (p.dX && !p.amax && p.ldy != p.C) return 1;
+    if (p.dX && p.ldz && p.ldz != p.C) return 1;
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
     if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0) {
         static bool attr_dx = false;
@@ -989,6 +990,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         if (rc != 1) return rc;
     }
     if (!p.amax && p.ldy != p.C) return 1;
+    if (p.ldz && p.ldz != p.C) return 1;
     const int npairs = ntm * ntn2;
     if (npairs > 48) return 1;
     // ---- balance GEMM1 column tiles (cost C4/2 MFMAs) and GEMM2 pairs (16 MFMAs) over 4 waves ----

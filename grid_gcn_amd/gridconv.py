@@ -313,19 +313,28 @@ class SubGUpdate(nn.Module):
         return self.finish(agg, center_masks, center_ori_feats, tail=tail)
 
     def finish(self, agg, center_masks, center_ori_feats, buf=None, tail=None):
+        link = None
+        nonneg = False   # both halves of the concat are >= 0: update_func's ReLU is the identity
         if center_ori_feats is not None and buf is not None:
             # `agg` already sits in the right half of buf; the centre MLP writes the left half
             from . import train_ops
             B, O = center_ori_feats.shape[0], center_ori_feats.shape[1]
             ccf = self.center_mlp[-1].lin.out_features
+            nonneg = True
+            if self._raw_link_ok(center_ori_feats, buf, tail, center_masks):
+                # ... as the RAW output of its last conv: the update MLP applies that layer's
+                # BatchNorm+ReLU while it loads the concat, and its input-gradient kernel accumulates
+                # the layer's BatchNorm-backward sums (train_ops.RawLink): one activation pass and one
+                # reduce pass over [B*O, ccf] less
+                link = train_ops.RawLink(ccf, buf.shape[1], buf.device)
             cf = train_ops.mlp_bn_relu_train(center_ori_feats, list(self.center_mlp),
-                                             out=train_ops.alias_columns(buf, 0, ccf))
+                                             out=train_ops.alias_columns(buf, 0, ccf), link=link)
             agg = train_ops._Cat2.apply(cf, agg, buf).reshape(B, O, buf.shape[1])
         elif center_ori_feats is not None:
             cf = (run_mlp(list(self.center_mlp), center_ori_feats, self.mfma_train)
                   if self.center_mlp is not None else center_ori_feats)
             agg = torch.cat([cf, agg], dim=-1)                             # up_center_inte=concat
-        if self.relu:
+        if self.relu and not nonneg:
             agg = F.relu(agg)                                              # update_func :31-32
         if self.update_mlp is not None:
             layers = list(self.update_mlp)
@@ -344,7 +353,7 @@ class SubGUpdate(nn.Module):
                         seed_dev = tail.head[2] if len(tail.head) > 2 else None
                         seed = tail.head[3] if len(tail.head) > 3 else None
                         return train_ops.head_train(agg, layers, p, lin, seed=seed,
-                                                    seed_dev=seed_dev)
+                                                    seed_dev=seed_dev, prev=link)
                 if tail.head is not None and self.mfma_train and agg.is_cuda and \
                         not self.training and not torch.is_grad_enabled():
                     from . import train_ops
@@ -353,7 +362,32 @@ class SubGUpdate(nn.Module):
                             all(l.lin.in_features <= 1024 for l in layers):
                         tail.done = 2                   # evaluation: dropout is the identity
                         return train_ops.head_eval(agg, layers, lin)
-            agg = run_mlp(layers, agg, self.mfma_train)
+            if link is not None:
+                from . import train_ops
+                agg = train_ops.mlp_bn_relu_train(agg, layers, prev=link)
+            else:
+                agg = run_mlp(layers, agg, self.mfma_train)
         if center_masks is not None:
             agg = agg * center_masks[..., None]                            # :284-285
         return agg
+
+    raw_link = True   # training: centre MLP output handed to the update MLP raw (train_ops.RawLink)
+
+    def _raw_link_ok(self, center_ori_feats, buf, tail, center_masks):
+        """the update MLP (with the tail layers it absorbs) and the centre MLP's last layer are all
+        shapes of the register-direct kernels, which alone read a row-strided Z"""
+        from . import train_ops
+        if not (self.raw_link and self.mfma_train and self.training and torch.is_grad_enabled()
+                and self.update_mlp is not None and buf.is_cuda):
+            return False
+        layers = list(self.update_mlp)
+        if tail is not None and tail.layers and center_masks is None:
+            layers += list(tail.layers)
+        cm = list(self.center_mlp)
+        C = cm[-1].lin.out_features
+        cin_last = cm[-2].lin.out_features if len(cm) > 1 else center_ori_feats.shape[-1]
+        cin_last = (cin_last + 3) & ~3
+        need_dx = len(cm) > 1 or center_ori_feats.requires_grad
+        return (train_ops.supported(layers, buf) and buf.shape[1] % 8 == 0 and buf.shape[1] <= 256
+                and train_ops._dw_direct_ok(C, cin_last) and C % 8 == 0
+                and (not need_dx or cin_last <= 256))

@@ -131,12 +131,48 @@ def packed_sizes(C, cin):
     return K, ldw, K * ldw, ((cin + 31) // 32) * ((C + 3) & ~3) * 32
 
 
-def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
+_LINK_TEMPLATES = {}
+
+
+class RawLink:
+    """Hand-off between the PRODUCER of a raw (pre-BatchNorm) layer output written into the left `n`
+    columns of a wider [E, total] buffer and the chain that CONSUMES the buffer (update_func's
+    concat(centre features, aggregate), gcn_module_g_att.py:279-283): the consumer applies the
+    producer's BatchNorm+ReLU while it loads (columns >= n: scale 1, shift 0 -- the aggregate is a max
+    of products of ReLU outputs, so the ReLU is the identity there) and accumulates the producer's
+    BatchNorm-backward sums in the epilogue of its input-gradient kernel.  Neither the activated copy
+    of the producer's output nor a separate reduce pass over its gradient exists.
+    vec [4, total]: scale, shift, mean, rstd per column (left part written by the producer's
+    BatchNorm bookkeeping); sums: fp64 [2, total], left by the consumer's backward."""
+
+    def __init__(self, n, total, device):
+        key = (n, total, str(device))
+        if key not in _LINK_TEMPLATES:
+            t = torch.zeros((4, total), dtype=torch.float32, device=device)
+            t[0, n:] = 1.0
+            _LINK_TEMPLATES[key] = t
+        self.n, self.total = n, total
+        self.vec = _LINK_TEMPLATES[key].clone()
+        self.sums = None
+
+    def prev_bn(self):
+        return (self.vec[0], self.vec[1], self.vec[2], self.vec[3])
+
+    def nbn(self):
+        """input columns of the consumer that carry the producer's BatchNorm, as the dX kernel wants
+        them (whole 32-column tiles; 0 = all)"""
+        return self.n if self.n % 32 == 0 else 0
+
+
+def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_raw=None, last_vec=None):
     """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer.  Per layer three launches:
     pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping.
     x may be wider than the first layer's weight (zero padded columns) and hold the layer's first
     `rot` input channels behind the others (ops.edge_inputs_rows).  prev_bn = (scale, shift): x is
-    the raw (pre-BatchNorm) output of an earlier layer whose BatchNorm+ReLU is applied on the fly."""
+    the raw (pre-BatchNorm) output of an earlier layer whose BatchNorm+ReLU is applied on the fly.
+    out_raw: [E, cout_last] destination of the LAST layer's raw output (row stride >= cout_last: the
+    left columns of a wider buffer), last_vec: [4, >= cout_last] destination of its BatchNorm vectors
+    (RawLink)."""
     L = len(params) // 4
     E, dev = x.shape[0], x.device
     st = _Chain()
@@ -176,19 +212,28 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
         _lib.check(rc, "gridgcn_pack_linear")
         st.Wdx.append(Wdx if ndx else Wb)
         st.ndx.append(ndx)
-        Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
+        last = l == L - 1
+        if last and out_raw is not None:
+            Z = out_raw
+            assert Z.shape == (E, cout) and Z.stride(1) == 1
+        else:
+            Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
+        ldz = Z.stride(0) if Z.stride(0) != cout else 0
         sums = allsums[so:so + 2 * cout]
         so += 2 * cout
         ps = _ptr(pscale) if pscale is not None else None
         ph = _ptr(pshift) if pshift is not None else None
         if direct:
-            rc = lib.gridgcn_linear_fwd_direct(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
-                                               cout, ps, ph, _ptr(Z), _ptr(sums), stream)
+            rc = lib.gridgcn_linear_fwd_direct_ld(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
+                                                  cout, ps, ph, _ptr(Z), _ptr(sums), ldz, stream)
         else:
-            rc = lib.gridgcn_linear_fwd(_ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
-                                        ps, ph, _ptr(Z), _ptr(sums), stream)
+            rc = lib.gridgcn_linear_fwd_ld(_ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
+                                           ps, ph, _ptr(Z), _ptr(sums), ldz, stream)
         _lib.check(rc, "gridgcn_linear_fwd")
-        vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
+        if last and last_vec is not None:
+            vec = last_vec[:, :cout]            # rows of the link's [4, total] table
+        else:
+            vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
         bn = bns[l]
         track = bn is not None and bn.track_running_stats
         rc = lib.gridgcn_bn_finalize(
@@ -206,7 +251,7 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None):
 
 
 def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, ndxs, sums, dY, sparse,
-                    need_dx, cin_w0=None, rot=0, prev_bn=None):
+                    need_dx, cin_w0=None, rot=0, prev_bn=None, nbn=0):
     """backward through a chain.  `sums` [2*C_L] fp64 = BatchNorm-backward sums of the LAST layer;
     upstream gradient either dense dY [E,C_L] or sparse = (amax, gval, P).  Returns (dX, grads)
     with grads = [dW, db, dgamma, dbeta] * L.  cin_w0 / rot: width of the first layer's weight and
@@ -265,12 +310,13 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         else:
             sp = (None, None, 0)
             dyp = _ptr(dY)
-        rc = lib.gridgcn_linear_bwd(
+        rc = lib.gridgcn_linear_bwd_ld(
             dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
             _ptr(m1), _ptr(m2), _ptr(prev), pbn[0], pbn[1], pbn[2], pbn[3],
             _ptr(Wb), _ptr(Wg) if Wg is not None else None,
             _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin, cw, rt,
             dY.stride(0) if (sparse is None and dY is not None) else 0,
+            Z.stride(0) if Z.stride(0) != C else 0, nbn if l == 0 else 0,
             _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
@@ -397,20 +443,29 @@ def _dw_direct_ok(C, cin):
 class _MLPTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *params):
-        """x [E,cin]; params = (W, b, gamma, beta) per layer; meta = (eps, [bn modules], out):
-        out = None or a [E, C_last] tensor (row stride >= C_last) that receives the result."""
+        """x [E,cin]; params = (W, b, gamma, beta) per layer; meta = (eps, [bn modules], out, link,
+        prev): out = None or a [E, C_last] tensor (row stride >= C_last) that receives the result;
+        link (RawLink, with out): the result is the RAW output of the last layer -- its BatchNorm+ReLU
+        is the consumer's business; prev (RawLink): x is such a buffer."""
         lib = _lib.load()
-        eps, bns, out = meta
+        eps, bns, out, link, prev = (tuple(meta) + (None, None))[:5]
         L = len(params) // 4
         x = x.contiguous()
         E = x.shape[0]
         with torch.cuda.device(x.device):
             st = _chain_forward(lib, x, params, bns, eps, 0,
-                                x.shape[1] if ctx.needs_input_grad[0] else 0)
-            Y = out if out is not None else torch.empty_like(st.Z[-1])
-            rc = lib.gridgcn_bn_relu_apply(_ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]),
-                                           _ptr(Y), E, Y.shape[1], Y.stride(0), _stream(x))
-            _lib.check(rc, "gridgcn_bn_relu_apply")
+                                x.shape[1] if ctx.needs_input_grad[0] else 0,
+                                prev_bn=prev.prev_bn()[:2] if prev is not None else None,
+                                out_raw=out if link is not None else None,
+                                last_vec=link.vec if link is not None else None)
+            if link is not None:
+                Y = out
+            else:
+                Y = out if out is not None else torch.empty_like(st.Z[-1])
+                rc = lib.gridgcn_bn_relu_apply(_ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]),
+                                               _ptr(Y), E, Y.shape[1], Y.stride(0), _stream(x))
+                _lib.check(rc, "gridgcn_bn_relu_apply")
+        ctx.link, ctx.prev = link, prev
         ctx.L = L
         ctx.ndx = st.ndx
         ctx.cin_w0 = params[0].shape[1]          # x may carry zero-padded columns beyond it
@@ -438,15 +493,25 @@ class _MLPTrain(torch.autograd.Function):
                 and DIRECT_DX
                 and (not need_dx_last or ctx.ndx[-1] > 0)):
             dY = dY.contiguous()
+        link, prev = ctx.link, ctx.prev
         with torch.cuda.device(dev):
-            sums = _zeros((2, C), torch.float64, dev)
-            rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Zs[-1]), _ptr(scales[-1]),
-                                                _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
-                                                E, C, dY.stride(0), _ptr(sums), _stream(x))
-            _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
-            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
-                                        ctx.ndx, sums, dY, None, ctx.needs_input_grad[0],
-                                        ctx.cin_w0, 0)
+            if link is not None and link.sums is not None:
+                # the consumer's input-gradient kernel has accumulated this layer's sums
+                sums = link.sums[:, :C].contiguous()
+            else:
+                assert link is None, "RawLink: the consumer's backward has not run"
+                sums = _zeros((2, C), torch.float64, dev)
+                rc = lib.gridgcn_bn_relu_bwd_reduce(_ptr(dY), _ptr(Zs[-1]), _ptr(scales[-1]),
+                                                    _ptr(shifts[-1]), _ptr(means[-1]), _ptr(rstds[-1]),
+                                                    E, C, dY.stride(0), _ptr(sums), _stream(x))
+                _lib.check(rc, "gridgcn_bn_relu_bwd_reduce")
+            r = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
+                                ctx.ndx, sums, dY, None, ctx.needs_input_grad[0],
+                                ctx.cin_w0, 0, prev_bn=prev.prev_bn() if prev is not None else None,
+                                nbn=prev.nbn() if prev is not None else 0)
+            dX, grads = r[0], r[1]
+            if prev is not None:
+                prev.sums = r[2].view(2, x.shape[1])
         return (dX, None) + tuple(grads)
 
 
@@ -706,16 +771,17 @@ def head_eval(x, layers, lin):
     return Y[:, :C].reshape(shp[:-1] + (C,))
 
 
-def mlp_bn_relu_train(x, layers, out=None):
+def mlp_bn_relu_train(x, layers, out=None, link=None, prev=None):
     """x [..., cin] -> [..., cout_last] through `layers` (gridconv.ConvBNReLU modules, training
     mode).  Callers check supported() first.  out: optional [E, cout_last] destination
-    (alias_columns); the 2-D result is then returned as is."""
+    (alias_columns); the 2-D result is then returned as is.  link / prev: RawLink roles (producer of
+    a raw output into `out` / consumer of such a buffer)."""
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
     params = []
     for l in layers:
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
-    y = _MLPTrain.apply(x2, (layers[0].bn.eps, [l.bn for l in layers], out), *params)
+    y = _MLPTrain.apply(x2, (layers[0].bn.eps, [l.bn for l in layers], out, link, prev), *params)
     if out is not None:
         return y
     return y.reshape(shp[:-1] + (y.shape[-1],))
@@ -1574,7 +1640,7 @@ class _HeadTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *params):
         lib = _lib.load()
-        eps, bns, p, seed, seed_dev = meta
+        eps, bns, p, seed, seed_dev, prev = (tuple(meta) + (None,))[:6]
         L = (len(params) - 2) // 4
         W2, b2 = params[4 * L], params[4 * L + 1]
         x = x.contiguous()
@@ -1584,7 +1650,8 @@ class _HeadTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = _stream(x)
             st = _chain_forward(lib, x, params[:4 * L], bns, eps, 0,
-                                x.shape[1] if ctx.needs_input_grad[0] else 0)
+                                x.shape[1] if ctx.needs_input_grad[0] else 0,
+                                prev_bn=prev.prev_bn()[:2] if prev is not None else None)
             C = st.Z[-1].shape[1]
             Hd = torch.empty((E, C), dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_bn_relu_dropout_apply(
@@ -1604,6 +1671,7 @@ class _HeadTrain(torch.autograd.Function):
                                                      Cp, None, None, _ptr(Z2), None, stream),
                        "gridgcn_linear_fwd_direct")
         ctx.L = L
+        ctx.prev = prev
         ctx.ndx = st.ndx
         ctx.drop = (float(p), int(seed), seed_dev)
         ctx.dims = (C2, Cp)
@@ -1653,8 +1721,14 @@ class _HeadTrain(torch.autograd.Function):
                 None, 0, E, Cp, C, C, 0, 0, None, _ptr(dW2), None, None, None, 0, _ptr(ws),
                 nbytes.value, st), "gridgcn_linear_bwd")
             _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C2, _ptr(db64), st), "gridgcn_colsum")
-            dX, grads = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
-                                        ctx.ndx, sums, dH, None, ctx.needs_input_grad[0])
+            prev = ctx.prev
+            r = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
+                                ctx.ndx, sums, dH, None, ctx.needs_input_grad[0],
+                                prev_bn=prev.prev_bn() if prev is not None else None,
+                                nbn=prev.nbn() if prev is not None else 0)
+            dX, grads = r[0], r[1]
+            if prev is not None:
+                prev.sums = r[2].view(2, x.shape[1])
         return (dX, None) + tuple(grads) + (dW2[:C2], db64[:C2].float())
 
 
@@ -1664,7 +1738,7 @@ def head_supported(x, layers, lin):
             and lin.out_features <= 32 and lin.in_features == C and C % 32 == 0 and C <= 256)
 
 
-def head_train(x, layers, p, lin, seed=None, seed_dev=None):
+def head_train(x, layers, p, lin, seed=None, seed_dev=None, prev=None):
     """x [..., cin] -> class scores [..., lin.out_features] through `layers` (ConvBNReLU modules in
     training mode), Dropout(p) and the Linear `lin`.  seed: dropout seed (None: drawn from torch's
     CPU generator, i.e. reproducible under torch.manual_seed).  seed_dev: optional int64 GPU scalar
@@ -1679,7 +1753,7 @@ def head_train(x, layers, p, lin, seed=None, seed_dev=None):
         params += [l.lin.weight, l.lin.bias, l.bn.weight, l.bn.bias]
     params += [lin.weight, lin.bias]
     y = _HeadTrain.apply(x.reshape(-1, shp[-1]), (layers[0].bn.eps, [l.bn for l in layers],
-                                                  float(p), seed, seed_dev), *params)
+                                                  float(p), seed, seed_dev, prev), *params)
     return y.reshape(shp[:-1] + (y.shape[-1],))
 
 

@@ -320,6 +320,16 @@ int gridgcn_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, c
 int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, const float *b, int K,
                        int ldw, int cout, const float *scale, const float *shift, float *Z,
                        double *sums, void *stream);
+/* *_ld variants: Z with a row stride ldz >= cout (0 = cout): the layer's raw output is written into /
+ * read from the left columns of a wider row-major buffer -- update_func's concat(centre features,
+ * aggregate), whose consumer applies the BatchNorm+ReLU while loading, so that neither the activated
+ * copy nor a separate BatchNorm-backward reduce pass exists (gridgcn_linear_bwd_ld: the
+ * register-direct dX / dW kernels only; other shapes return GRIDGCN_EINVAL;
+ * nbn: only the first nbn input columns (a multiple of 32; 0 = all) carry a previous BatchNorm -- the
+ * dX epilogue reads Aprev and accumulates psums for those alone). */
+int gridgcn_linear_fwd_ld(const float *X, long long E, int cin, const float *W, const float *b, int K,
+                          int ldw, int cout, const float *scale, const float *shift, float *Z,
+                          double *sums, int ldz, void *stream);
 /* gridgcn_linear_bwd: backward of one (linear -> BatchNorm(batch stats) -> ReLU) layer in ONE pass
  *   over the edges: dZ = scale*(dyr - m1 - zhat*m2) is formed while staging (dyr, zhat as above),
  *   dX[E,cin] = dZ * W (gradient w.r.t. this layer's input activation; NULL = not needed),
@@ -344,6 +354,9 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
 int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream);
+int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, const float *Wq,
+                                 const float *b, int ldw, int cout, const float *scale,
+                                 const float *shift, float *Z, double *sums, int ldz, void *stream);
 /* (ldx = row stride of X in floats, >= K, a multiple of 4, X 16-byte aligned; sums may be NULL;
  *  Z may be NULL when sums is given: a statistics-only pass that stores nothing.) */
 /* ---- classification edge block (classification/models/gcn_module_g.py:64-114 verts_pair_func
@@ -411,6 +424,15 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        double *psums,
                        const uint8_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream);
+int gridgcn_linear_bwd_ld(const float *dY, const float *Z, const float *scale, const float *shift,
+                          const float *mean, const float *rstd, const float *m1, const float *m2,
+                          const float *Aprev, const float *pscale, const float *pshift,
+                          const float *pmean, const float *prstd, const float *Wb, const float *Wg,
+                          const float *Wdx, int ndx, long long E,
+                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, float *dX,
+                          float *dW, double *psums,
+                          const uint8_t *amax, const float *gval, int P, void *workspace,
+                          size_t workspace_bytes, void *stream);
 /* (cin = row length of Aprev / dX as the kernels see it; dW is written in the FRAMEWORK layout
  *  [C][cin_w]: zero-padding columns dropped and the `rot` columns moved back in front, the inverse
  *  of gridgcn_pack_linear's mapping.  cin_w = cin, rot = 0 for an ordinary layer.) */
