@@ -34,6 +34,7 @@ EXPORTS = [
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_linear_fwd_ld", "gridgcn_linear_fwd_direct_ld", "gridgcn_linear_bwd_ld",
+    "gridgcn_pairmax_fwd_src_z",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
@@ -130,9 +131,9 @@ def load():
     lib.gridgcn_linear_fwd_ld.restype = ci
     lib.gridgcn_linear_fwd_ld.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     lib.gridgcn_linear_fwd_direct_ld.restype = ci
-    lib.gridgcn_linear_fwd_direct_ld.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp]
+    lib.gridgcn_linear_fwd_direct_ld.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, vp]
     lib.gridgcn_linear_bwd_ld.restype = ci
-    lib.gridgcn_linear_bwd_ld.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp,
+    lib.gridgcn_linear_bwd_ld.argtypes = [vp] * 16 + [ci, ll, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp,
                                                       ci, vp, cs, vp]
     lib.gridgcn_linear_bwd_workspace_bytes.restype = ci
     lib.gridgcn_linear_bwd_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
@@ -187,6 +188,9 @@ def load():
     lib.gridgcn_edge_lin0_forward.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp] * 6
     lib.gridgcn_edge_lin0_backward.restype = ci
     lib.gridgcn_edge_lin0_backward.argtypes = [vp] * 15 + [ci] * 5 + [vp, vp, vp, cs, vp]
+    lib.gridgcn_pairmax_fwd_src_z.restype = ci
+    lib.gridgcn_pairmax_fwd_src_z.argtypes = [vp] * 5 + [ci, ci, ci] + [vp, ci] + [vp] * 4 + [ll, ci, ci, vp,
+                                                                                       ci, vp, vp, vp]
     lib.gridgcn_pairmax_fwd_src.restype = ci
     lib.gridgcn_pairmax_fwd_src.argtypes = [vp] * 5 + [ci, ci, ci] + [vp] * 5 + [ll, ci, ci, vp, ci,
                                                                               vp, vp, vp]

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
     ggm_zero<NJ>(accw);
     const long long ntile = (p.E + 31) >> 5;
     const bool sparse = p.amax != nullptr;
+    const bool z16 = p.zfmt != 0;          // Z stored as bf16
 
     auto dz4 = [&](const float4 z, const float4 g, int k) -> float4 {
         const float4 sc = *(const float4 *)(cst + k), sh = *(const float4 *)(cst + C + k);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
     auto tileptrs = [&](long long tl, const float *&zr_, const float *&gr_, const gg_amax_t *&ar_, int &pp_) {
         long long rw = (tl << 5) + l31;
         if (rw >= p.E) rw = p.E - 1;
-        zr_ = p.Z + rw * C;
+        zr_ = z16 ? (const float *)((const unsigned short *)p.Z + rw * C) : p.Z + rw * C;
         ar_ = (const gg_amax_t *)zr_;
         pp_ = 0;
         if (sparse) {
@@ -122,14 +123,31 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
     // loads (the next tile's first chunk at the end of a tile) fly during the dX and dW MFMAs.
     float4 z[4], g[4];
     unsigned am[4];
+    // (Z as bf16: a lane's 16 channels are two 16-byte loads; z[] then holds raw bits until zcvt())
     auto issue = [&](const float *zr_, const float *gr_, const gg_amax_t *ar_, int ci) {
         const int k0 = ci * 32 + h * 16;
+        if (z16) {
+            const unsigned short *zb = (const unsigned short *)zr_ + k0;
+            z[0] = *(const float4 *)zb;
+            z[1] = *(const float4 *)(zb + 8);
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            z[q] = *(const float4 *)(zr_ + k0 + 4 * q);
+            if (!z16) z[q] = *(const float4 *)(zr_ + k0 + 4 * q);
             g[q] = *(const float4 *)(gr_ + k0 + 4 * q);
             am[q] = *(const unsigned *)(ar_ + k0 + 4 * q);
         }
+    };
+    auto zcvt = [&]() {     // bf16 pairs (low half first) -> four float4
+        if (!z16) return;
+        const unsigned u[8] = {__float_as_uint(z[0].x), __float_as_uint(z[0].y), __float_as_uint(z[0].z),
+                               __float_as_uint(z[0].w), __float_as_uint(z[1].x), __float_as_uint(z[1].y),
+                               __float_as_uint(z[1].z), __float_as_uint(z[1].w)};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            z[q] = make_float4(__uint_as_float(u[2 * q] << 16), __uint_as_float(u[2 * q] & 0xffff0000u),
+                               __uint_as_float(u[2 * q + 1] << 16),
+                               __uint_as_float(u[2 * q + 1] & 0xffff0000u));
     };
     if ((long long)blockIdx.x * 4 + wave < ntile) {
         const float *z0, *g0;
@@ -226,6 +244,7 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                 const int k0 = (2 * hc + cc) * 32 + h * 16;
                 float4 a[4];
                 __builtin_amdgcn_sched_barrier(0);     // (and the uses of the loaded chunk below the previous phase)
+                zcvt();
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     a[q] = dz4(z[q], gmask(g[q], am[q]), k0 + 4 * q);
@@ -388,5 +407,6 @@ int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st)
     if (p.cin_w != p.cin || p.rot != 0 || p.drop_thr) return 1;
     if (!p.amax && (p.ldy & 3)) return 1;
     if (p.ldz && p.ldz != p.C) return 1;
+    if (p.zfmt && (p.C & 7)) return 1;
     return p.C == 64 ? launch_att_fused<2>(p, st) : launch_att_fused<4>(p, st);
 }

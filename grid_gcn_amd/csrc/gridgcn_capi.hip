@@ -48,7 +48,7 @@ int gg_pairmax_fwd(const float *, const float *, const float *, const float *, c
 int gg_pairmax_fwd_src(const float *, const int *, const float *, const float *, const float *, int,
                        int, int, const float *, const float *, const float *, const float *,
                        const float *, long long, int, int, float *, int, unsigned char *, float *,
-                       hipStream_t);
+                       int, hipStream_t);
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
                    const float *, const unsigned char *, long long, int, int, int, float *, float *,
@@ -403,21 +403,23 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        size_t workspace_bytes, void *stream)
 {
     return gridgcn_linear_bwd_ld(dY, Z, scale, shift, mean, rstd, m1, m2, Aprev, pscale, pshift, pmean,
-                                 prstd, Wb, Wg, Wdx, ndx, E, C, cin, cin_w, rot, ldy, 0, 0, dX, dW, psums,
+                                 prstd, Wb, Wg, Wdx, ndx, E, C, cin, cin_w, rot, ldy, 0, 0, 0, dX, dW, psums,
                                  amax, gval, P, workspace, workspace_bytes, stream);
 }
 
-int gridgcn_linear_bwd_ld(const float *dY, const float *Z, const float *scale, const float *shift,
+int gridgcn_linear_bwd_ld(const float *dY, const void *Z_, const float *scale, const float *shift,
                           const float *mean, const float *rstd, const float *m1, const float *m2,
                           const float *Aprev, const float *pscale, const float *pshift,
                           const float *pmean, const float *prstd, const float *Wb, const float *Wg,
                           const float *Wdx, int ndx, long long E,
-                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, float *dX,
-                          float *dW, double *psums,
+                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, int zfmt,
+                          float *dX, float *dW, double *psums,
                           const uint8_t *amax, const float *gval, int P, void *workspace,
                           size_t workspace_bytes, void *stream)
 {
-    if ((ldz && ldz < C) || nbn < 0 || nbn > cin || (nbn & 31)) return GRIDGCN_EINVAL;
+    const float *Z = (const float *)Z_;
+    if ((ldz && ldz < C) || nbn < 0 || nbn > cin || (nbn & 31) || (zfmt != 0 && zfmt != 1))
+        return GRIDGCN_EINVAL;
     if (amax && (!gval || P < 1 || P > 256 || E % P != 0)) return GRIDGCN_EINVAL;   // one-byte arg max
     if (Wdx && (ndx < 1 || ndx > cin)) return GRIDGCN_EINVAL;
     if (cin_w < 1 || cin_w > cin || rot < 0 || rot > cin_w) return GRIDGCN_EINVAL;
@@ -440,6 +442,7 @@ int gridgcn_linear_bwd_ld(const float *dY, const float *Z, const float *scale, c
     if (p.ldy < C) return GRIDGCN_EINVAL;
     p.ldz = ldz;
     p.nbn = nbn;
+    p.zfmt = zfmt;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -491,6 +494,23 @@ int gridgcn_pairmax_fwd(const float *Zp, const float *Za, const float *scale_p,
                           amax, zsel, (hipStream_t)stream);
 }
 
+int gridgcn_pairmax_fwd_src_z(const float *Ysrc, const int32_t *nebidx, const float *att16,
+                              const float *Wg, const float *b, int B, int Nsrc, int O,
+                              const void *Za, int za_bf16, const float *scale_p, const float *shift_p,
+                              const float *scale_a, const float *shift_a, long long ncent, int P,
+                              int C, float *agg, int ld_agg, uint8_t *amax, float *zsel,
+                              void *stream)
+{
+    if ((!Ysrc && !Wg) || !nebidx || !att16 || !b || !Za || !scale_p || !shift_p || !scale_a ||
+        !shift_a || !agg || !amax || ncent < 1 || P < 1 || P > 256 || C < 1 || B < 1 || Nsrc < 1 || O < 1 ||
+        ncent != (long long)B * O || ld_agg < C)
+        return GRIDGCN_EINVAL;
+    const int rc = gg_pairmax_fwd_src(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, (const float *)Za, scale_p,
+                                      shift_p, scale_a, shift_a, ncent, P, C, agg, ld_agg, amax, zsel,
+                                      za_bf16 ? 1 : 0, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const float *att16,
                             const float *Wg, const float *b, int B, int Nsrc, int O,
                             const float *Za, const float *scale_p, const float *shift_p,
@@ -498,14 +518,8 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             int C, float *agg, int ld_agg, uint8_t *amax, float *zsel,
                             void *stream)
 {
-    if ((!Ysrc && !Wg) || !nebidx || !att16 || !b || !Za || !scale_p || !shift_p || !scale_a ||
-        !shift_a || !agg || !amax || ncent < 1 || P < 1 || P > 256 || C < 1 || B < 1 || Nsrc < 1 || O < 1 ||
-        ncent != (long long)B * O || ld_agg < C)
-        return GRIDGCN_EINVAL;
-    const int rc = gg_pairmax_fwd_src(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Za, scale_p, shift_p,
-                                      scale_a, shift_a, ncent, P, C, agg, ld_agg, amax, zsel,
-                                      (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
+    return gridgcn_pairmax_fwd_src_z(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Za, 0, scale_p, shift_p,
+                                     scale_a, shift_a, ncent, P, C, agg, ld_agg, amax, zsel, stream);
 }
 
 int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
@@ -564,14 +578,15 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
 
 int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, const float *Wq,
                                  const float *b, int ldw, int cout, const float *scale,
-                                 const float *shift, float *Z, double *sums, int ldz, void *stream)
+                                 const float *shift, void *Z, double *sums, int ldz, int zfmt,
+                                 void *stream)
 {
     if (!X || !Wq || !b || (!Z && !sums) || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
-        (ldx & 3) || ((uintptr_t)X & 15) || (ldz && ldz < cout))
+        (ldx & 3) || ((uintptr_t)X & 15) || (ldz && ldz < cout) || (zfmt != 0 && zfmt != 1))
         return GRIDGCN_EINVAL;
     GGLinFwd p;
-    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = sums;
-    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.ldz = ldz;
+    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = (float *)Z; p.sums = sums;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.ldz = ldz; p.zfmt = zfmt;
     int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -580,7 +595,8 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream)
 {
-    return gridgcn_linear_fwd_direct_ld(X, E, K, ldx, Wq, b, ldw, cout, scale, shift, Z, sums, 0, stream);
+    return gridgcn_linear_fwd_direct_ld(X, E, K, ldx, Wq, b, ldw, cout, scale, shift, Z, sums, 0, 0,
+                                        stream);
 }
 
 int gridgcn_linear_fwd_direct2(const float *X1, int ld1, int K1, const float *X2, int ld2, int K2,

@@ -287,6 +287,12 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
             }
         }
         float *zp = p.Z + (r0 + 4 * h) * ldz + (lane & 31);
+        unsigned short *zh = (unsigned short *)p.Z + (r0 + 4 * h) * ldz + (lane & 31);   // zfmt 1
+        const bool z16 = p.zfmt != 0;
+        auto zst = [&](int off, float z) {
+            if (z16) zh[off] = (unsigned short)(gg_pk_bf16(z, 0.f) & 0xffffu);
+            else zp[off] = z;
+        };
         if (nrows == 32) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const float z = acc[t][r] + bias[t];
-                        if (p.Z) zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;   // (nullptr: statistics only)
+                        if (p.Z) zst(((r & 3) + 8 * (r >> 2)) * ldz + t * 32, z);   // (nullptr: statistics only)
                         sm += z;
                         sq += z * z;
                     }
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
                 for (int r = 0; r < 16; r++) {
                     const float z = acc[t][r] + bias[t];
                     if ((EXACT || t * 32 + (lane & 31) < p.cout) && ggm_row(r, lane) < nrows) {
-                        if (p.Z) zp[((r & 3) + 8 * (r >> 2)) * ldz + t * 32] = z;
+                        if (p.Z) zst(((r & 3) + 8 * (r >> 2)) * ldz + t * 32, z);
                         sm += z;
                         sq += z * z;
                     }

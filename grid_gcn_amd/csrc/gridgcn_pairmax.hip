@@ -63,7 +63,15 @@ struct GGPtRecompute {
 // PF > 0: the number of neighbours is the compile-time constant PF (the up layers: 5) and the loop
 // over them is unrolled, so that the index -> source row chains of ALL neighbours are in flight
 // together instead of one after the other
-template <int PF>
+// ZB: Za holds bf16 values (gridgcn_linear_fwd_direct_ld zfmt 1)
+__device__ __forceinline__ float4 gg_ld4_bf16(const void *p)
+{
+    const uint2 u = *(const uint2 *)p;
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <int PF, bool ZB = false>
 __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
                                                              const float *__restrict__ Za,
                                                              const float *__restrict__ scp,
@@ -93,6 +101,11 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
             w2 = *(const float4 *)(r.Wg + 2 * C + c);
         }
         const float *za = Za + (o * (PF > 0 ? PF : P)) * C + c;
+        const unsigned short *zah = (const unsigned short *)Za + (o * (PF > 0 ? PF : P)) * C + c;
+        auto ldza = [&](int p) -> float4 {
+            if constexpr (ZB) return gg_ld4_bf16(zah + (size_t)p * C);
+            else return *(const float4 *)(za + (size_t)p * C);
+        };
         float best[4], zps[4], zas[4];
         int bi4[4];
         const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
 #pragma unroll
             for (int p = 0; p < PF; p++) {
                 gq[p] = *(const float4 *)(r.att16 + (o * PF + p) * 16);       // (dist, gx, gy, gz)
-                zq[p] = *(const float4 *)(za + (size_t)p * C);
+                zq[p] = ldza(p);
             }
 #pragma unroll
             for (int p = 0; p < PF; p++) {
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_src(GGPtRecompute r,
                 flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
                 const float4 g = *(const float4 *)(r.att16 + e * 16);       // (dist, gx, gy, gz)
                 const float4 y = *(const float4 *)(ysrc + flat * ystride);
-                const float4 z2 = *(const float4 *)(za + (size_t)p * C);
+                const float4 z2 = ldza(p);
                 fold(p, g, y, z2);
             }
         }
@@ -435,7 +448,8 @@ int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float 
 int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16, const float *Wg,
                        const float *b, int B, int Nsrc, int O, const float *Za, const float *scp,
                        const float *shp, const float *sca, const float *sha, long long ncent, int P,
-                       int C, float *agg, int lda, unsigned char *amax, float *zsel, hipStream_t st)
+                       int C, float *agg, int lda, unsigned char *amax, float *zsel, int za_bf16,
+                       hipStream_t st)
 {
     if ((C & 3) || (lda & 3)) return 1;
     GGPtRecompute r;
@@ -443,7 +457,13 @@ int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16,
     r.Nsrc = Nsrc; r.O = O; r.B = B;
     long long nb = (ncent * (C / 4) + 255) / 256;
     int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
-    if (P == 5)
+    if (P == 5 && za_bf16)
+        gg_k_pairmax_fwd4_src<5, true><<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg,
+                                                             amax, zsel, lda);
+    else if (za_bf16)
+        gg_k_pairmax_fwd4_src<0, true><<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg,
+                                                             amax, zsel, lda);
+    else if (P == 5)
         gg_k_pairmax_fwd4_src<5><<<grid, 256, 0, st>>>(r, Za, scp, shp, sca, sha, ncent, P, C, agg,
                                                        amax, zsel, lda);
     else

@@ -28,6 +28,8 @@ struct GGLinFwd {
     const float *rowbias = nullptr;
     int P = 0;
     int ldz = 0;          // row stride of Z (0: cout) -- Z may be the left columns of a wider buffer
+    int zfmt = 0;         // 0: Z is fp32; 1: Z is bf16 (round to nearest even; ldz in elements) -- the
+                          // register-direct kernel only; the statistics are those of the fp32 values
 };
 
 struct GGLinBwd {
@@ -58,6 +60,7 @@ struct GGLinBwd {
     unsigned drop_thr, drop_lo, drop_hi;   // register-direct dX only: dX *= dropout mask of the
     float drop_scale;                      // [E][cin] input activation (gg_drop_keep), thr 0 = off
     int ldz = 0;          // row stride of Z (0: C); register-direct dX / dW kernels only
+    int zfmt = 0;         // 0: Z is fp32; 1: Z is bf16 (gg_k_att_bwd_fused only)
     int nbn = 0;          // leading input columns that carry the previous layer's BatchNorm (0: all
                           // cin); beyond them the dX epilogue neither reads Aprev nor sums
     int dx_col0 = 0;      // register-direct dX: first output column of this launch (0 / 128) and

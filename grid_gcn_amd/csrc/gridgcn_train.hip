@@ -955,6 +955,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         const int rc = gg_att_bwd_fused(p, st);
         if (rc != 1) return rc;
     }
+    if (p.zfmt) return 1;   // a bf16 Z is only read by the fused attention backward
     // ---- register-direct dX (gridgcn_direct.hip) when the operand was packed for it ----
     if (p.dX && p.Wdx) {
         const int rc = gg_linear_dx_direct(p, st);

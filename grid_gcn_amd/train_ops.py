@@ -47,6 +47,8 @@ SRC_FIRST_CONV = True
 NO_Z0 = True
 # ... and its backward reduced to the sparse arg-max entries (gg_k_edge_lin0_bwd_sparse)
 SPARSE_L0 = True
+# bf16 mode (set_mlp_precision("bf16")): bf16 STORAGE of the attention pre-activation of the up layers
+Z16_STORAGE = True
 
 
 
@@ -164,7 +166,8 @@ class RawLink:
         return self.n if self.n % 32 == 0 else 0
 
 
-def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_raw=None, last_vec=None):
+def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_raw=None, last_vec=None,
+                   z16_last=False):
     """x [E,cin] contiguous; params = (W, b, gamma, beta) per layer.  Per layer three launches:
     pack the operand layouts of W, the MFMA kernel, the BatchNorm bookkeeping.
     x may be wider than the first layer's weight (zero padded columns) and hold the layer's first
@@ -172,7 +175,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
     the raw (pre-BatchNorm) output of an earlier layer whose BatchNorm+ReLU is applied on the fly.
     out_raw: [E, cout_last] destination of the LAST layer's raw output (row stride >= cout_last: the
     left columns of a wider buffer), last_vec: [4, >= cout_last] destination of its BatchNorm vectors
-    (RawLink)."""
+    (RawLink).  z16_last: the last layer's raw output is stored as bf16 (callers check that every
+    reader of it takes that: Z16_STORAGE)."""
     L = len(params) // 4
     E, dev = x.shape[0], x.device
     st = _Chain()
@@ -217,7 +221,10 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
             Z = out_raw
             assert Z.shape == (E, cout) and Z.stride(1) == 1
         else:
-            Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
+            Z = torch.empty((E, cout), dtype=torch.bfloat16 if (last and z16_last) else torch.float32,
+                            device=dev)
+        zfmt = 1 if Z.dtype == torch.bfloat16 else 0
+        assert not zfmt or direct
         ldz = Z.stride(0) if Z.stride(0) != cout else 0
         sums = allsums[so:so + 2 * cout]
         so += 2 * cout
@@ -225,7 +232,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         ph = _ptr(pshift) if pshift is not None else None
         if direct:
             rc = lib.gridgcn_linear_fwd_direct_ld(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
-                                                  cout, ps, ph, _ptr(Z), _ptr(sums), ldz, stream)
+                                                  cout, ps, ph, _ptr(Z), _ptr(sums), ldz, zfmt,
+                                                  stream)
         else:
             rc = lib.gridgcn_linear_fwd_ld(_ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
                                            ps, ph, _ptr(Z), _ptr(sums), ldz, stream)
@@ -317,6 +325,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
             _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin, cw, rt,
             dY.stride(0) if (sparse is None and dY is not None) else 0,
             Z.stride(0) if Z.stride(0) != C else 0, nbn if l == 0 else 0,
+            1 if Z.dtype == torch.bfloat16 else 0,
             _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
@@ -916,12 +925,20 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             lda = agg.stride(0)
             amax = torch.empty((ncent, C), dtype=torch.uint8, device=dev)
             zsel = torch.empty((2, ncent, C), dtype=torch.float32, device=dev)
-            sa = _chain_forward(lib, att16, pa, bns_a, eps)
+            # bf16 mode: the [E, C] pre-activation of the second attention conv -- the largest tensor of
+            # the step, written once and read twice -- is STORED as bf16 (its writer's fp32
+            # accumulators are rounded once; BatchNorm statistics from the fp32 values).  Only where
+            # both readers take it: the source-side max kernel and the fused attention backward.
+            z16 = (Z16_STORAGE and noz and La == 2 and A0 in (16, 32) and C in (64, 128)
+                   and lib.gridgcn_get_mlp_precision() == 1
+                   and lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 1)
+            sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)
             if noz:
-                rc = lib.gridgcn_pairmax_fwd_src(
+                rc = lib.gridgcn_pairmax_fwd_src_z(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
-                    B, Nsrc, O, _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl), _ptr(sa.scale[-1]),
-                    _ptr(sa.shift[-1]), ncent, P, C, _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
+                    B, Nsrc, O, _ptr(sa.Z[-1]), 1 if z16 else 0, _ptr(scl), _ptr(shl),
+                    _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C, _ptr(agg), lda, _ptr(amax),
+                    _ptr(zsel), st)
             else:
                 rc = lib.gridgcn_pairmax_fwd(_ptr(Zl), _ptr(sa.Z[-1]), _ptr(scl), _ptr(shl),
                                              _ptr(sa.scale[-1]), _ptr(sa.shift[-1]), ncent, P, C,
@@ -966,7 +983,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             sums_p, sums_a = sums_pa[0], sums_pa[1]
             # (the arg-max pre-activations come from zsel: Zl may not exist)
             rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None,
-                                         _ptr(aZ[-1]),
+                                         # (a bf16-stored attention tensor: the values at the arg
+                                         #  max come from zsel)
+                                         _ptr(aZ[-1]) if aZ[-1].dtype == torch.float32 else None,
                                          _ptr(lS), _ptr(lH), _ptr(lM),
                                          _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
                                          _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C,

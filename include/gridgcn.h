@@ -263,6 +263,12 @@ int gridgcn_pairmax_fwd_src(const float *Ysrc, const int32_t *nebidx, const floa
                             const float *scale_a, const float *shift_a, long long ncent, int P,
                             int C, float *agg, int ld_agg, uint8_t *amax, float *zsel,
                             void *stream);
+int gridgcn_pairmax_fwd_src_z(const float *Ysrc, const int32_t *nebidx, const float *att16,
+                              const float *Wg, const float *b, int B, int Nsrc, int O,
+                              const void *Za, int za_bf16, const float *scale_p, const float *shift_p,
+                              const float *scale_a, const float *shift_a, long long ncent, int P,
+                              int C, float *agg, int ld_agg, uint8_t *amax, float *zsel,
+                              void *stream);
 /* Evaluation-mode tail of the edge block in one kernel (csrc/gridgcn_atteval.hip): with every
  * BatchNorm a fixed affine map (scale = gamma*rsqrt(running_var+eps), shift = beta - mean*scale),
  *   agg[o,c] = max_p relu((Ysrc[src(e)][c] + Wg[:,c].geo(e) + b[c]) * scale_p[c] + shift_p[c])
@@ -356,7 +362,12 @@ int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const
                               const float *shift, float *Z, double *sums, void *stream);
 int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, const float *Wq,
                                  const float *b, int ldw, int cout, const float *scale,
-                                 const float *shift, float *Z, double *sums, int ldz, void *stream);
+                                 const float *shift, void *Z, double *sums, int ldz, int zfmt,
+                                 void *stream);
+/* (zfmt 1: Z is written as bf16, round to nearest even, ldz in elements -- "bf16 storage" of a large
+ *  per-edge pre-activation in the bf16 mode of BASELINE configs[2]; the BatchNorm statistics are those
+ *  of the fp32 values.  Its readers: gridgcn_pairmax_fwd_src_z (za_bf16) and gridgcn_linear_bwd_ld
+ *  (zfmt 1, shapes of the fused attention backward only).) */
 /* (ldx = row stride of X in floats, >= K, a multiple of 4, X 16-byte aligned; sums may be NULL;
  *  Z may be NULL when sums is given: a statistics-only pass that stores nothing.) */
 /* ---- classification edge block (classification/models/gcn_module_g.py:64-114 verts_pair_func
@@ -424,13 +435,13 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                        double *psums,
                        const uint8_t *amax, const float *gval, int P, void *workspace,
                        size_t workspace_bytes, void *stream);
-int gridgcn_linear_bwd_ld(const float *dY, const float *Z, const float *scale, const float *shift,
+int gridgcn_linear_bwd_ld(const float *dY, const void *Z, const float *scale, const float *shift,
                           const float *mean, const float *rstd, const float *m1, const float *m2,
                           const float *Aprev, const float *pscale, const float *pshift,
                           const float *pmean, const float *prstd, const float *Wb, const float *Wg,
                           const float *Wdx, int ndx, long long E,
-                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, float *dX,
-                          float *dW, double *psums,
+                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, int zfmt,
+                          float *dX, float *dW, double *psums,
                           const uint8_t *amax, const float *gval, int P, void *workspace,
                           size_t workspace_bytes, void *stream);
 /* (cin = row length of Aprev / dX as the kernels see it; dW is written in the FRAMEWORK layout

@@ -525,3 +525,42 @@ def test_bf16_mode_whole_model_loss_and_gradient_direction():
     assert abs(a[0] - b[0]) < 1e-3 * abs(a[0])
     assert not torch.isnan(b[1]).any()
     assert float((a[1] * b[1]).sum() / (a[1].norm() * b[1].norm())) > 0.9
+
+
+def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
+    """bf16 mode with the [E, C] pre-activation of the second attention conv STORED as bf16
+    (train_ops.Z16_STORAGE: written by gridgcn_linear_fwd_direct_ld zfmt 1, read by
+    gridgcn_pairmax_fwd_src_z and the fused attention backward) against the same mode with fp32
+    storage.  Stated tolerance of the variant: aggregate within 1e-2 * max|y| (one bf16 rounding of a
+    pre-activation whose BatchNorm+ReLU+product follow), every gradient within 5e-2 in relative L2
+    norm (a few arg-max flips re-route single entries)."""
+    import copy
+    from grid_gcn_amd import ops, train_ops
+    from grid_gcn_amd.gridconv import SubGUpdate
+    torch.manual_seed(21)
+    gen = torch.Generator().manual_seed(5)
+    B, Nsrc, O, P, cin = 2, 300, 4000, 5, 128
+    ref = SubGUpdate(cin, [128], localfdim=3).to(DEV).train()
+    new = copy.deepcopy(ref)
+    src1 = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV).requires_grad_(True)
+    src2 = src1.detach().clone().requires_grad_(True)
+    nebidx = torch.randint(0, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    g = torch.randn(B, O, 128, generator=gen).to(DEV)
+    outs = []
+    try:
+        train_ops.set_mlp_precision("bf16")
+        for net, src, z16 in ((ref, src1, False), (new, src2, True)):
+            monkeypatch.setattr(train_ops, "Z16_STORAGE", z16)
+            y = net.forward_src(cent, src, nebidx, None)
+            y.backward(g)
+            outs.append((y.detach(), src.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+    finally:
+        train_ops.set_mlp_precision("fp32")
+    (y0, s0, p0), (y1, s1, p1) = outs
+    assert float((y0 - y1).abs().max()) > 0.0                       # the storage really changed
+    assert float((y0 - y1).abs().max()) <= 1e-2 * float(y0.abs().max())
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    assert rel(s1[..., 4:], s0[..., 4:]) <= 5e-2
+    for a, b in zip(p1, p0):
+        assert rel(a, b) <= 5e-2, (rel(a, b), a.shape)
