@@ -175,6 +175,8 @@ def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
         try:
             return graph.GraphedTrainStep(net, opt, loss_fn, inputs, target, sync), "hipgraph"
         except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
             sys.stderr.write("graph capture failed (%s: %s); timing the eager step\n" % (type(e).__name__, e))
             net.seed_dev = None
             if (sync is None or sync.world == 1) and "--eager" not in sys.argv:

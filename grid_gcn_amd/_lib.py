@@ -34,7 +34,7 @@ EXPORTS = [
     "gridgcn_softmax_ce_fwd", "gridgcn_softmax_ce_bwd", "gridgcn_colsum",
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_linear_fwd_ld", "gridgcn_linear_fwd_direct_ld", "gridgcn_linear_bwd_ld",
-    "gridgcn_pairmax_fwd_src_z",
+    "gridgcn_pairmax_fwd_src_z", "gridgcn_pack_desc_fill", "gridgcn_pack_linear_batch",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
@@ -52,6 +52,12 @@ class GridParams(ctypes.Structure):
                 ("loc", ctypes.c_int32), ("coord_shift", ctypes.c_float * 3),
                 ("voxel_size", ctypes.c_float * 3), ("grid_size", ctypes.c_int32 * 3),
                 ("seed", ctypes.c_uint64), ("seed_dev", ctypes.c_void_p)]
+
+
+class PackDesc(ctypes.Structure):
+    """struct gridgcn_pack_desc (include/gridgcn.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("W", "b", "Wp", "Bp", "Wb", "Wg", "Wq", "Wdx")] + \
+               [(n, ctypes.c_int32) for n in ("C", "cin_w", "rot", "cin", "ndx", "K", "ldw", "n")]
 
 
 class ConvLayer(ctypes.Structure):
@@ -188,6 +194,10 @@ def load():
     lib.gridgcn_edge_lin0_forward.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp] * 6
     lib.gridgcn_edge_lin0_backward.restype = ci
     lib.gridgcn_edge_lin0_backward.argtypes = [vp] * 15 + [ci] * 5 + [vp, vp, vp, cs, vp]
+    lib.gridgcn_pack_desc_fill.restype = ci
+    lib.gridgcn_pack_desc_fill.argtypes = [ctypes.POINTER(PackDesc)]
+    lib.gridgcn_pack_linear_batch.restype = ci
+    lib.gridgcn_pack_linear_batch.argtypes = [vp, ci, ci, vp]
     lib.gridgcn_pairmax_fwd_src_z.restype = ci
     lib.gridgcn_pairmax_fwd_src_z.argtypes = [vp] * 5 + [ci, ci, ci] + [vp, ci] + [vp] * 4 + [ll, ci, ci, vp,
                                                                                        ci, vp, vp, vp]

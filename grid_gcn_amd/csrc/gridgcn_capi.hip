@@ -61,6 +61,9 @@ int gg_bn_finalize(const double *, const float *, const float *, long long, floa
 int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
                        hipStream_t);
 
+int gg_pack_desc_fill(gridgcn_pack_desc *e);
+int gg_pack_linear_batch(const gridgcn_pack_desc *dev, int nlayers, int max_n, hipStream_t st);
+
 static int ensure_init()
 {
     static int rc = gg_index_init();  // thread-safe one-time init (C++11 static)
@@ -564,6 +567,17 @@ int gridgcn_bn_relu_bwd_elemt(const float *dY, const float *Z, const float *scal
     if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !dZ || E < 1 || C < 1)
         return GRIDGCN_EINVAL;
     return gg_bn_bwd_elemt(dY, Z, scale, shift, mean, rstd, m1, m2, E, C, dZ, (hipStream_t)stream);
+}
+
+int gridgcn_pack_desc_fill(gridgcn_pack_desc *desc_host)
+{
+    return gg_pack_desc_fill(desc_host) ? GRIDGCN_EINVAL : GRIDGCN_OK;
+}
+
+int gridgcn_pack_linear_batch(const gridgcn_pack_desc *descs_dev, int nlayers, int max_n, void *stream)
+{
+    const int rc = gg_pack_linear_batch(descs_dev, nlayers, max_n, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
 int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, int cin, int ndx,

@@ -11,6 +11,7 @@
 // The dense gradient is never materialised: gg_k_linear_bwd rebuilds it from (amax, gval) while
 // staging its tile.
 #include <hip/hip_runtime.h>
+#include "../../include/gridgcn.h"
 
 __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict__ Zp,
                                                         const float *__restrict__ Za,
@@ -344,13 +345,13 @@ struct GGPackW {
     }
 };
 
-__global__ void gg_k_pack_linear(const float *__restrict__ W_, const float *__restrict__ b, int C,
-                                 int cin_w, int rot, int cin, int K, int ldw, int ndx,
-                                 float *__restrict__ Wp, float *__restrict__ Bp,
-                                 float *__restrict__ Wb, float *__restrict__ Wg,
-                                 float *__restrict__ Wq, float *__restrict__ Wdx)
+__device__ __forceinline__ void gg_pack_linear_body(int t, const float *__restrict__ W_,
+                                                    const float *__restrict__ b, int C, int cin_w,
+                                                    int rot, int cin, int K, int ldw, int ndx,
+                                                    float *__restrict__ Wp, float *__restrict__ Bp,
+                                                    float *__restrict__ Wb, float *__restrict__ Wg,
+                                                    float *__restrict__ Wq, float *__restrict__ Wdx)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int K8 = (cin + 7) & ~7;
     const GGPackW W{W_, cin_w, rot};
     if (Wdx && ndx > 0) {
@@ -408,6 +409,59 @@ __global__ void gg_k_pack_linear(const float *__restrict__ W_, const float *__re
             Wg[t] = (kc < C && col < cin) ? W.at(kc, col) : 0.f;
         }
     }
+}
+
+__global__ void gg_k_pack_linear(const float *__restrict__ W_, const float *__restrict__ b, int C,
+                                 int cin_w, int rot, int cin, int K, int ldw, int ndx,
+                                 float *__restrict__ Wp, float *__restrict__ Bp,
+                                 float *__restrict__ Wb, float *__restrict__ Wg,
+                                 float *__restrict__ Wq, float *__restrict__ Wdx)
+{
+    gg_pack_linear_body(blockIdx.x * blockDim.x + threadIdx.x, W_, b, C, cin_w, rot, cin, K, ldw, ndx,
+                        Wp, Bp, Wb, Wg, Wq, Wdx);
+}
+
+// every layer of a network in ONE launch: blockIdx.y = layer, its descriptor read from device memory
+// (the weights change once per optimizer step; 27 pack launches per training step were ~110 us of
+// 4-us kernels and their boundaries)
+__global__ void gg_k_pack_linear_batch(const gridgcn_pack_desc *__restrict__ d)
+{
+    const gridgcn_pack_desc e = d[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= e.n) return;
+    gg_pack_linear_body(t, e.W, e.b, e.C, e.cin_w, e.rot, e.cin, e.K, e.ldw, e.ndx, e.Wp, e.Bp, e.Wb,
+                        e.Wg, e.Wq, e.Wdx);
+}
+
+// threads one layer's pack needs (the largest of its layouts)
+static int gg_pack_threads(int C, int cin, bool wdx)
+{
+    const int K8 = (cin + 7) & ~7;
+    const int ldw = C <= 32 ? 32 : (C <= 64 ? 64 : (C <= 128 ? 128 : 256));
+    const int C4 = (C + 3) & ~3, ntile = (cin + 31) / 32;
+    int n = K8 * ldw;
+    if (ntile * C4 * 32 > n) n = ntile * C4 * 32;
+    const int C8 = (C + 7) & ~7;
+    if (C8 * 32 * 8 > n && wdx) n = C8 * 32 * 8;
+    return n;
+}
+
+int gg_pack_desc_fill(gridgcn_pack_desc *e)
+{
+    if (!e || !e->W || (e->Bp && !e->b) || e->C < 1 || e->C > 256 || e->cin_w < 1 || e->cin < e->cin_w ||
+        e->rot < 0 || e->rot > e->cin_w || e->ndx < 0 || e->ndx > 256)
+        return 1;
+    e->K = (e->cin + 3) & ~3;
+    e->ldw = e->C <= 32 ? 32 : (e->C <= 64 ? 64 : (e->C <= 128 ? 128 : 256));
+    e->n = gg_pack_threads(e->C, e->cin, e->Wdx != nullptr);
+    return 0;
+}
+
+int gg_pack_linear_batch(const gridgcn_pack_desc *dev, int nlayers, int max_n, hipStream_t st)
+{
+    if (!dev || nlayers < 1 || max_n < 1) return 1;
+    gg_k_pack_linear_batch<<<dim3((max_n + 255) / 256, nlayers), 256, 0, st>>>(dev);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 int gg_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, int cin, int ndx,

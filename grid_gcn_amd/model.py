@@ -69,6 +69,7 @@ class GGCNSeg(nn.Module):
         self.seed = seed
         self.fixed_seed = fixed_seed
         self.forward_no = 0
+        self.register_forward_hook(release_packs)
         # int64 GPU scalar added to every sampling / dropout seed inside the kernels (None: off).
         # graph.GraphedTrainStep sets and bumps it so that replays of ONE captured step still redraw
         self.seed_dev = None
@@ -134,6 +135,9 @@ class GGCNSeg(nn.Module):
         fwd_no = self.forward_no
         if self.training:
             self.forward_no += 1
+            if data_xyz.is_cuda and torch.is_grad_enabled():
+                from . import train_ops
+                train_ops.PACKS.prepack(self)   # all weight layouts of the step, one launch
         seed_dev = self._seed_dev()
         sd = dict(seed_dev=seed_dev) if (seed_dev is not None and _is_hip(ix)) else {}
         for i, layer in enumerate(self.down):
@@ -228,6 +232,12 @@ def seg_forward_flops(net, B, N):
         rows += 2.0 * B * m * (_mlp_macs(layer.center_mlp) + _mlp_macs(layer.update_mlp))
     rows += 2.0 * B * N * (_mlp_macs([net.fc1]) + net.fc2.in_features * net.fc2.out_features)
     return edge, rows
+
+
+def release_packs(module, _inputs, _output):
+    """forward hook of the three nets: see train_ops._PackCache.release"""
+    from . import train_ops
+    train_ops.PACKS.release(module)
 
 
 class WeightedGradient(torch.autograd.Function):

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import synth
 from .gridconv import ConvBNReLU, check_shipped_branches, mlp, run_mlp
-from .model import HipIndexOps, WeightedGradient, call_seed
+from .model import HipIndexOps, WeightedGradient, call_seed, release_packs
 
 CLS_MN40 = dict(
     grid=synth.CLS_MODELNET40, inputDim=[0, 128, 256],
@@ -118,6 +118,7 @@ class GGCNCls(nn.Module):
         self.cfg, self.ix, self.seed = cfg, index_ops, seed
         self.fixed_seed = fixed_seed
         self.forward_no = 0
+        self.register_forward_hook(release_packs)
         self.seed_dev = None      # see GGCNSeg
         self._take_kw = (dict(neighbour_index=True)
                          if isinstance(index_ops, type) and issubclass(index_ops, HipIndexOps) else {})
@@ -140,6 +141,9 @@ class GGCNCls(nn.Module):
         fwd_no = self.forward_no
         if self.training:
             self.forward_no += 1
+            if data_xyz.is_cuda and torch.is_grad_enabled():
+                from . import train_ops
+                train_ops.PACKS.prepack(self)   # all weight layouts of the step, one launch
         for i, layer in enumerate(self.layers):
             seed = self.seed if (self.fixed_seed or not self.training) else \
                 call_seed(self.seed, fwd_no, i)

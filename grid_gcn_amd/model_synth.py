@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import synth
 from .gridconv import SubGUpdate
-from .model import HipIndexOps, call_seed, _is_hip, _mlp_macs
+from .model import HipIndexOps, call_seed, _is_hip, _mlp_macs, release_packs
 
 SYNTH_200K = dict(
     grid=synth.SYNTH_200K, inputDim=[0, 64, 128, 256],
@@ -27,6 +27,7 @@ class GGCNSynth(nn.Module):
         super().__init__()
         self.cfg, self.ix, self.seed, self.fixed_seed = cfg, index_ops, seed, fixed_seed
         self.forward_no = 0
+        self.register_forward_hook(release_packs)
         self.seed_dev = None      # see GGCNSeg
         self.down = nn.ModuleList(
             SubGUpdate(cfg["inputDim"][i], cfg["pt_ele_dim"][i], cfg["localfdim"], cfg["relu"],
@@ -45,6 +46,9 @@ class GGCNSynth(nn.Module):
         fwd_no = self.forward_no
         if self.training:
             self.forward_no += 1
+            if data_xyz.is_cuda and torch.is_grad_enabled():
+                from . import train_ops
+                train_ops.PACKS.prepack(self)   # all weight layouts of the step, one launch
         data_loc, data_layer, num = data, data, actual_centnum
         outs = []
         for i, layer in enumerate(self.down):

@@ -29,6 +29,7 @@ Numerics follow torch.nn.BatchNorm1d(eps, momentum) exactly as used by gridconv.
 variance for normalisation, unbiased for the running estimate).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -133,6 +134,114 @@ def packed_sizes(C, cin):
     return K, ldw, K * ldw, ((cin + 31) // 32) * ((C + 3) & ~3) * 32
 
 
+class _PackCache:
+    """Operand layouts of every conv layer (gridgcn_pack_linear) in persistent buffers, one entry per
+    (weight Parameter, layout request).  prepack(module) -- called by the models at the start of a
+    training forward -- rebuilds the layouts of ALL of the module's entries in ONE launch
+    (gridgcn_pack_linear_batch over a device-side descriptor table), and each entry then serves
+    exactly one lookup without a launch of its own: the ~27 pack launches of a step become one.
+    Any other lookup (no prepack before it, a second use in the same forward, a weight whose
+    version counter has moved since) packs its layer alone, as before.  (Freshness cannot be read
+    off Tensor._version alone: the fused optimizers update weights without moving it.)"""
+
+    def __init__(self):
+        self.entries = {}          # key -> dict(W, b, pk, bufs, fresh, ver, desc)
+        self.tables = {}           # id(module) -> (weakref(module), keys, device table, max_n)
+
+    def _drop(self, key):
+        self.entries.pop(key, None)
+        for m in [m for m, t in self.tables.items() if key in t[1]]:
+            del self.tables[m]
+
+    def get(self, lib, W, b, cout, cin_w, rot, cin, ndx, direct, sizes, stream):
+        if not (isinstance(W, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter)):
+            # a temporary (a slice, a product): nothing to key a cache entry on -- packed per call
+            bufs = self._alloc(W.device, direct, ndx, sizes)[1]
+            self._pack_one(lib, W, b, cout, cin_w, rot, cin, ndx, bufs, stream)
+            return bufs
+        key = (id(W), id(b), cout, cin_w, rot, cin, ndx, direct, W.data_ptr(), b.data_ptr())
+        e = self.entries.get(key)
+        if e is not None and (e["W"]() is not W or e["b"]() is not b):
+            self._drop(key)        # the id was recycled by another tensor
+            e = None
+        if e is None:
+            pk, bufs = self._alloc(W.device, direct, ndx, sizes)
+            d = _lib.PackDesc()
+            d.W, d.b = W.data_ptr(), b.data_ptr()
+            for name, t in zip(("Wp", "Bp", "Wb", "Wg", "Wq", "Wdx"), bufs):
+                setattr(d, name, t.data_ptr() if t is not None else None)
+            d.C, d.cin_w, d.rot, d.cin, d.ndx = cout, cin_w, rot, cin, ndx
+            _lib.check(lib.gridgcn_pack_desc_fill(ctypes.byref(d)), "gridgcn_pack_desc_fill")
+            e = dict(W=weakref.ref(W, lambda _r, k=key: self._drop(k)), b=weakref.ref(b), pk=pk,
+                     bufs=bufs, fresh=False, ver=None, desc=d)
+            self.entries[key] = e
+            self.tables.clear()
+        if not (e["fresh"] and e["ver"] == (W._version, b._version)):
+            self._pack_one(lib, W, b, cout, cin_w, rot, cin, ndx, e["bufs"], stream)
+        e["fresh"] = False
+        return e["bufs"]
+
+    @staticmethod
+    def _alloc(dev, direct, ndx, sizes):
+        nwp, ldw, nwb, nwq, nwdx = sizes
+        pk = torch.empty(nwp + ldw + 2 * nwb + nwq + nwdx, dtype=torch.float32, device=dev)
+        o = nwp + ldw
+        return pk, (None if direct else pk[:nwp], pk[nwp:nwp + ldw], pk[o:o + nwb],
+                    pk[o + nwb:o + 2 * nwb], pk[o + 2 * nwb:o + 2 * nwb + nwq] if direct else None,
+                    pk[o + 2 * nwb + nwq:] if ndx else None)
+
+    @staticmethod
+    def _pack_one(lib, W, b, cout, cin_w, rot, cin, ndx, bufs, stream):
+        p = lambda t: _ptr(t) if t is not None else None   # noqa: E731
+        rc = lib.gridgcn_pack_linear(_ptr(W.detach()), _ptr(b.detach()), cout, cin_w, rot, cin, ndx,
+                                     *[p(t) for t in bufs], stream)
+        _lib.check(rc, "gridgcn_pack_linear")
+
+    def prepack(self, module):
+        """one launch for the layouts of every entry that belongs to `module`'s parameters"""
+        t = self.tables.get(id(module))
+        if t is not None and t[0]() is not module:
+            t = None
+        if t is None:
+            ids = {id(p) for p in module.parameters()}
+            keys = [k for k, e in self.entries.items()
+                    if k[0] in ids and k[1] in ids and e["W"]() is not None and e["b"]() is not None]
+            if len(keys) < 2:
+                return
+            if torch.cuda.is_current_stream_capturing():
+                return             # (a host-to-device copy; the lookups pack per layer instead)
+            arr = (_lib.PackDesc * len(keys))(*[self.entries[k]["desc"] for k in keys])
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = self.entries[keys[0]]["pk"].device
+            assert all(self.entries[k]["pk"].device == dev for k in keys)
+            t = (weakref.ref(module), keys, raw.to(dev),
+                 max(self.entries[k]["desc"].n for k in keys))
+            self.tables[id(module)] = t
+        _, keys, table, max_n = t
+        with torch.cuda.device(table.device):
+            rc = _lib.load().gridgcn_pack_linear_batch(
+                table.data_ptr(), len(keys), max_n, torch.cuda.current_stream(table.device).cuda_stream)
+        _lib.check(rc, "gridgcn_pack_linear_batch")
+        for k in keys:
+            e = self.entries[k]
+            e["fresh"], e["ver"] = True, (e["W"]()._version, e["b"]()._version)
+
+
+    def release(self, module):
+        """end of the module's forward: layouts that no layer looked up do not stay marked fresh"""
+        t = self.tables.get(id(module))
+        if t is not None:
+            for k in t[1]:
+                e = self.entries.get(k)
+                if e is not None:
+                    e["fresh"] = False
+
+
+PACKS = _PackCache()
+
+
+def release_packs_hook(module, _inputs, _output):
+    PACKS.release(module)
 _LINK_TEMPLATES = {}
 
 
@@ -201,19 +310,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
             ndx = 0
         nt = (ndx + 31) // 32
         nwdx = cout * 32 * (1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8) if ndx else 0
-        pk = torch.empty(nwp + ldw + 2 * nwb + nwq + nwdx, dtype=torch.float32, device=dev)
-        Wp, Bp = pk[:nwp], pk[nwp:nwp + ldw]
-        o = nwp + ldw
-        Wb, Wg = pk[o:o + nwb], pk[o + nwb:o + 2 * nwb]
-        o += 2 * nwb
-        Wq = pk[o:o + nwq] if direct else None
-        Wdx = pk[o + nwq:] if ndx else None
-        rc = lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), cout, cin_w,
-                                     rot if l == 0 else 0, cin, ndx,
-                                     None if direct else _ptr(Wp), _ptr(Bp), _ptr(Wb), _ptr(Wg),
-                                     _ptr(Wq) if direct else None, _ptr(Wdx) if ndx else None,
-                                     stream)
-        _lib.check(rc, "gridgcn_pack_linear")
+        Wp, Bp, Wb, Wg, Wq, Wdx = PACKS.get(lib, W, b, cout, cin_w, rot if l == 0 else 0, cin, ndx,
+                                            direct, (nwp, ldw, nwb, nwq, nwdx), stream)
         st.Wdx.append(Wdx if ndx else Wb)
         st.ndx.append(ndx)
         last = l == L - 1
@@ -1593,14 +1691,12 @@ class _LinearPlain(torch.autograd.Function):
         nt = (ndx + 31) // 32
         ntv = 1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8
         K, ldw, nwp, nwb = packed_sizes(C, cin)
-        pk = torch.empty(ldw + nwb + cin * ldw + Cp * 32 * ntv, dtype=torch.float32, device=dev)
-        Bp, Wb, Wq = pk[:ldw], pk[ldw:ldw + nwb], pk[ldw + nwb:ldw + nwb + cin * ldw]
-        Wdx = pk[ldw + nwb + cin * ldw:]
         with torch.cuda.device(dev):
             st = _stream(x)
-            _lib.check(lib.gridgcn_pack_linear(_ptr(W.detach().contiguous()), _ptr(b.detach()), C,
-                                               cin, 0, cin, ndx, None, _ptr(Bp), _ptr(Wb), None,
-                                               _ptr(Wq), _ptr(Wdx) if ndx else None, st), "pack")
+            _, Bp, Wb, _, Wq, Wdx = PACKS.get(lib, W, b, C, cin, 0, cin, ndx, True,
+                                              (0, ldw, nwb, cin * ldw, Cp * 32 * ntv if ndx else 0), st)
+            if Wdx is None:
+                Wdx = Wb
             Z = torch.empty((E, Cp), dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(x), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
                                                      Cp, None, None, _ptr(Z), None, st),
@@ -1679,12 +1775,8 @@ class _HeadTrain(torch.autograd.Function):
                 "gridgcn_bn_relu_dropout_apply")
             K, ldw, nwp, nwb = packed_sizes(C2, C)
             ntv = next(v for v in (1, 2, 4, 8) if v * 32 >= C)
-            pk = torch.empty(ldw + nwb + C * ldw + Cp * 32 * ntv, dtype=torch.float32, device=dev)
-            Bp, Wb, Wq = pk[:ldw], pk[ldw:ldw + nwb], pk[ldw + nwb:ldw + nwb + C * ldw]
-            Wdx = pk[ldw + nwb + C * ldw:]
-            _lib.check(lib.gridgcn_pack_linear(_ptr(W2.detach().contiguous()), _ptr(b2.detach()),
-                                               C2, C, 0, C, C, None, _ptr(Bp), _ptr(Wb), None,
-                                               _ptr(Wq), _ptr(Wdx), stream), "pack")
+            _, Bp, Wb, _, Wq, Wdx = PACKS.get(lib, W2, b2, C2, C, 0, C, C, True,
+                                              (0, ldw, nwb, C * ldw, Cp * 32 * ntv), stream)
             Z2 = torch.empty((E, Cp), dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(Hd), E, C, C, _ptr(Wq), _ptr(Bp), ldw,
                                                      Cp, None, None, _ptr(Z2), None, stream),

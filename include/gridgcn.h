@@ -351,6 +351,19 @@ int gridgcn_linear_fwd_ld(const float *X, long long E, int cin, const float *W, 
 int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, int cin, int ndx,
                         float *Wp, float *Bp, float *Wb, float *Wg, float *Wq, float *Wdx,
                         void *stream);
+/* The same for MANY layers in one launch (the weights of a network change once per optimizer step).
+ * The caller keeps an array of descriptors in DEVICE memory: fill each one on the host (pointers and
+ * C, cin_w, rot, cin, ndx as for gridgcn_pack_linear; NULL for a layout that is not wanted), let
+ * gridgcn_pack_desc_fill() complete K / ldw / n, copy the array to the device once, and call
+ * gridgcn_pack_linear_batch(device array, layers, max over the layers' n) every step. */
+typedef struct gridgcn_pack_desc {
+    const float *W, *b;
+    float *Wp, *Bp, *Wb, *Wg, *Wq, *Wdx;
+    int32_t C, cin_w, rot, cin, ndx;
+    int32_t K, ldw, n;          /* written by gridgcn_pack_desc_fill */
+} gridgcn_pack_desc;
+int gridgcn_pack_desc_fill(gridgcn_pack_desc *desc_host);
+int gridgcn_pack_linear_batch(const gridgcn_pack_desc *descs_dev, int nlayers, int max_n, void *stream);
 /* gridgcn_linear_fwd_direct: as gridgcn_linear_fwd for X[E][K] with K % 8 == 0 (zero-padded input
  *   channels), weights in the "Wq" order: each lane reads 16 consecutive floats of its row straight
  *   into registers and consumes them over 16 MFMA steps -- step (c, q, i) of lane l multiplies

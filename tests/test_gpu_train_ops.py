@@ -166,6 +166,79 @@ def test_pack_linear_layouts(C, cin):
             assert torch.equal(o, r)
 
 
+def test_pack_cache_batch_launch_equals_single_packs():
+    """train_ops.PACKS: the one-launch rebuild of every layout of a module
+    (gridgcn_pack_linear_batch) writes, bit for bit, what the per-layer gridgcn_pack_linear writes;
+    after it each entry serves ONE lookup without a launch, every other lookup packs on its own."""
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _stream
+    lib = _lib.load()
+    torch.manual_seed(5)
+    cache = train_ops._PackCache()
+    shapes = [(32, 11, 3, 16, 0), (64, 32, 0, 32, 32), (128, 131, 3, 136, 131),
+              (256, 128, 0, 128, 128), (13, 128, 0, 128, 128), (128, 256, 0, 256, 256)]
+    holder = torch.nn.Module()
+    calls = []
+    for i, (C, cin_w, rot, cin, ndx) in enumerate(shapes):
+        W = torch.nn.Parameter(torch.randn(C, cin_w, device=DEV))
+        b = torch.nn.Parameter(torch.randn(C, device=DEV))
+        holder.register_parameter("w%d" % i, W)
+        holder.register_parameter("b%d" % i, b)
+        K, ldw, nwp, nwb = train_ops.packed_sizes(C, cin)
+        Cp = (C + 7) & ~7
+        nt = (ndx + 31) // 32
+        ntv = 1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8
+        sizes = (nwp, ldw, nwb, cin * ldw, Cp * 32 * ntv if ndx else 0)
+        calls.append((lib, W, b, C, cin_w, rot, cin, ndx, True, sizes, _stream(W)))
+        cache.get(*calls[-1])
+    assert len(cache.entries) == len(shapes)
+    ent = list(cache.entries.values())
+
+    def fill():
+        for e in ent:
+            e["pk"].fill_(7.0)
+
+    def untouched():
+        torch.cuda.synchronize()
+        return [bool((e["pk"] == 7.0).all()) for e in ent]
+
+    fill()
+    for c in calls:
+        cache.get(*c)                         # no prepack before it: the per-layer launch
+    assert not any(untouched())
+    singles = [e["pk"].clone() for e in ent]
+    fill()
+    cache.prepack(holder)                     # one launch for all six
+    torch.cuda.synchronize()
+    for e, ref in zip(ent, singles):
+        assert torch.equal(e["pk"], ref)
+    fill()
+    for c in calls:
+        cache.get(*c)                         # served from the batch: nothing is launched
+    assert all(untouched())
+    for c in calls[:2]:
+        cache.get(*c)                         # second lookup in the same forward: packs again
+    assert untouched() == [False, False, True, True, True, True]
+    # a weight whose version moved after the batch launch is not served from it
+    fill()
+    cache.prepack(holder)
+    with torch.no_grad():
+        calls[3][1].add_(1.0)
+    fill()
+    cache.get(*calls[3])
+    cache.get(*calls[4])
+    assert untouched() == [True, True, True, False, True, True]
+    # release(): what no layer looked up does not stay fresh
+    cache.release(holder)
+    cache.get(*calls[5])
+    assert untouched()[5] is False
+    # a dead weight drops its entry (and the module's table with it)
+    del holder._parameters["w5"], calls[5], c, W
+    import gc
+    gc.collect()
+    assert len(cache.entries) == len(shapes) - 1 and not cache.tables
+
+
 @pytest.mark.parametrize("E,C", [(1000, 21), (70001, 21), (257, 8), (5000, 32), (300, 3)])
 def test_softmax_ce_matches_torch(E, C):
     """gridgcn_softmax_ce_fwd/bwd == F.cross_entropy(ignore_index=0, reduction='mean')
