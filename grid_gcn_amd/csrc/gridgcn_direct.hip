@@ -487,7 +487,9 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
 
     for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
          tile += (long long)gridDim.x * nw) {
-        const long long r0 = tile << 5;
+        // (the tile number is the same in all lanes: say so, and everything derived from it --
+        //  the row block's base addresses -- is scalar)
+        const long long r0 = (long long)__builtin_amdgcn_readfirstlane((int)tile) << 5;
         long long row = r0 + (lane & 31);
         if (row >= p.E) row = p.E - 1;
         const float *zr = p.Z + row * (p.ldz ? p.ldz : C);
@@ -665,6 +667,48 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             }
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        if (nrows == 32 && !p.drop_thr) {
+            // Full row block, no Dropout (every call of the conv stacks but the last block and the
+            // head): straight-line stores.  The row/column-tile part of every address is wave
+            // uniform (r0 comes from a readfirstlane'd tile number) and lives in scalar registers,
+            // a lane adds its constant (4h rows + its column): no per-element address arithmetic,
+            // no per-row branches.  (The general form below cost ~30 VALU instructions per element:
+            // 7.9 VALU per MFMA at 8 column tiles, profiles/r2_pmc_bwd_gemm.txt.)
+            const gg_rsrc xs = gg_make_rsrc(p.dX + (r0 * ldx + p.dx_col0));
+            const gg_rsrc as = gg_make_rsrc(p.Aprev + (r0 * ldx + p.dx_col0));
+            const unsigned lo = (unsigned)(4 * h * ldx + (lane & 31)) * 4u;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (p.dx_col0 + t * 32 + (lane & 31) < p.ndx) {
+                    const bool tbn = prevbn && (p.nbn == 0 || p.dx_col0 + t * 32 < p.nbn);
+                    if (tbn) {
+                        const int pc = t * 32 + (lane & 31);
+                        const float ps_t = pcs[pc], psh_t = pcs[NT * 32 + pc], pm_t = pcs[2 * NT * 32 + pc],
+                                    pr_t = pcs[3 * NT * 32 + pc];
+                        float zpv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            zpv[r] = gg_buf_ld(as, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldx) * 4u);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float dx = acc[t][r];
+                            gg_buf_st(dx, xs, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldx) * 4u);
+                            const float d = (zpv[r] * ps_t + psh_t > 0.f) ? dx : 0.f;
+                            s1 += d;
+                            s2 += d * ((zpv[r] - pm_t) * pr_t);
+                        }
+                        a1[t] += s1;
+                        a2[t] += s2;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++)
+                            gg_buf_st(acc[t][r], xs, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldx) * 4u);
+                    }
+                }
+            }
+            continue;
+        }
         const long long base = (r0 + 4 * h) * ldx + p.dx_col0 + (lane & 31);
         float *xp = p.dX + base;
         const float *ap = p.Aprev + base;
@@ -807,20 +851,24 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 // m-groups of a workgroup walk the SAME rows (the B rows hit L1/L2), RS row streams fill the rest.
 // No LDS, no barriers; two register sets keep the next step's loads in flight.  Partials go to the
 // workspace as [wave][tile][reg][lane]; gg_k_dw_reduce_direct sums them into the framework layout.
-template <int MT, int NQ, int NP, int NS, bool BF16 = false>
-__global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int MG, int RS,
-                                                                 long long rows_per_wg,
-                                                                 int *__restrict__ tick, int ntick)
+#define GG_DW_D16 8      // register sets of the 16-tile form (one wave per SIMD: depth instead of partners)
+template <int MT, int NQ, int NP, int NS, bool BF16 = false, bool SP = false>
+__global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) void gg_k_linear_dw_direct(
+    GGLinBwd p, int MG, int RS, long long rows_per_wg, int *__restrict__ tick, int ntick)
 {
     constexpr int NJ = 4 * NQ + 2 * NP + NS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // (the wave number is the same in all lanes: everything derived from it -- the wave's row range,
+    //  its m-group -- lives in scalar registers)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (blockIdx.x == 0)   // tickets of the reduce kernel behind this one (stream order)
         for (int t = threadIdx.x; t < ntick; t += blockDim.x) tick[t] = 0;
     const int cq = lane & 31, h = lane >> 5;
     const int mg = wave % MG, rs = wave / MG;
     const int C = p.C, cin = p.cin;
     const int ldz = p.ldz ? p.ldz : C;
-    const bool prevbn = p.pscale != nullptr, sparse = p.amax != nullptr;
+    const bool prevbn = p.pscale != nullptr;
+    constexpr bool sparse = SP;
 
     // row range of this wave
     long long wa = (long long)blockIdx.x * rows_per_wg;
@@ -829,7 +877,9 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
     long long ra = wa + rs * per, rb = ra + per < wb ? ra + per : wb;
     if (ra > rb) ra = rb;
 
-    // per-lane constants
+    // per-lane constants.  A channel outside the layer (chok false) gets all-zero constants: its dz
+    // is then 0 without a select.
+    //   dz = sc * (mask ? g : 0) + ((z - mu) * bz + cz),   mask = z * sc + sh > 0  [and arg-max == p]
     const int chA = mg * 32 * MT + MT * cq;
     float sc[MT], sh[MT], mu[MT], bz[MT], cz[MT];
 #pragma unroll
@@ -844,7 +894,10 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
     const bool chok = chA + MT - 1 < C;               // C % MT == 0: all or none of the MT channels
     const int chl = chok ? chA : 0;
     int col[NJ];
+    // B operand = max(x * psc + psh, lo): the previous layer's BatchNorm + ReLU (lo = 0), or x itself
+    // (psc = 1, psh = 0, lo = -inf); a column outside the layer: psc = psh = 0
     float psc[NJ], psh[NJ];
+    const float lo = prevbn ? 0.f : -__builtin_inff();
     {
         int j = 0;
 #pragma unroll
@@ -859,9 +912,9 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
     }
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-        const bool ok = prevbn && col[j] < cin;
-        psc[j] = ok ? p.pscale[col[j]] : 0.f;
-        psh[j] = ok ? p.pshift[col[j]] : 0.f;
+        const bool ok = col[j] < cin;
+        psc[j] = ok ? (prevbn ? p.pscale[col[j]] : 1.f) : 0.f;
+        psh[j] = (ok && prevbn) ? p.pshift[col[j]] : 0.f;
     }
     const bool sok = NS ? (col[NJ - 1] < cin) : false;
     const int scol = sok ? col[NJ - 1] : 0;
@@ -922,30 +975,43 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
 #pragma unroll
     for (int i = 0; i < MT; i++) ggm_zero<NJ>(acc[i]);
 
+    // Every instruction a wave issues takes ~5 cycles away from the MFMA pipe of its SIMD
+    // (tools/micro/mfma_valu.hip: fp32 MFMA and VALU do not overlap on gfx950), so the operand
+    // formulas are written for instruction count: explicit FMAs, the B operand two columns at a time
+    // (v_pk_fma_f32), no selects that constants can absorb.
     auto values = [&](const Regs &R, float (&dz)[MT], float (&xa)[NJ]) {
 #pragma unroll
         for (int i = 0; i < MT; i++) {
-            const float g = (!sparse || R.am[i] == R.pp) ? R.g[i] : 0.f;
-            const float d = sc[i] * ((R.z[i] * sc[i] + sh[i] > 0.f) ? g : 0.f) +
-                            ((R.z[i] - mu[i]) * bz[i] + cz[i]);
-            dz[i] = (R.ok && chok) ? d : 0.f;
+            const float t = __builtin_fmaf(R.z[i] - mu[i], bz[i], cz[i]);
+            bool m = __builtin_fmaf(R.z[i], sc[i], sh[i]) > 0.f;
+            if (sparse) m = m && (R.am[i] == R.pp);
+            const float d = __builtin_fmaf(sc[i], m ? R.g[i] : 0.f, t);
+            dz[i] = R.ok ? d : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            float x = R.x[j];
-            if (prevbn) x = fmaxf(x * psc[j] + psh[j], 0.f);
-            if (NS && j == NJ - 1 && !sok) x = 0.f;
-            xa[j] = x;
+        for (int j = 0; j + 1 < NJ; j += 2) {
+            const v2f y = __builtin_elementwise_fma((v2f){R.x[j], R.x[j + 1]}, (v2f){psc[j], psc[j + 1]},
+                                                    (v2f){psh[j], psh[j + 1]});
+            xa[j] = fmaxf(y.x, lo);
+            xa[j + 1] = fmaxf(y.y, lo);
         }
+        if (NJ & 1) xa[NJ - 1] = fmaxf(__builtin_fmaf(R.x[NJ - 1], psc[NJ - 1], psh[NJ - 1]), lo);
     };
     auto compute = [&](const Regs &R) {
         float dz[MT], xa[NJ];
         values(R, dz, xa);
+#if defined(GG_DW_ABLATE) && (GG_DW_ABLATE & 1)      // no MFMA: operands kept alive, nothing else
+#pragma unroll
+        for (int i = 0; i < MT; i++) asm volatile("" ::"v"(dz[i]));
+#pragma unroll
+        for (int j = 0; j < NJ; j++) asm volatile("" ::"v"(xa[j]));
+#else
 #pragma unroll
         for (int i = 0; i < MT; i++)
 #pragma unroll
             for (int j = 0; j < NJ; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[i], xa[j], acc[i][j], 0, 0, 0);
+#endif
     };
 
     const long long nsteps = (rb - ra + 1) >> 1;
@@ -984,8 +1050,8 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
     // takes under traffic.  (load() past the end: ok = false, clamped addresses; called once per
     // step in ascending order, as the sparse centre counter requires.)
     // D per instantiation, from the compiler's register report: as deep as fits the occupancy the
-    // launcher counts on (gg_dw_direct_cfg: 4 / 3 / 2 waves per SIMD for <= 2 / <= 4 / more tiles,
-    // i.e. 128 / 168 / 256 registers) without spilling.
+    // launcher counts on (gg_dw_direct_cfg: 4 / 3 / 2 / 1 waves per SIMD for <= 2 / <= 4 / <= 10 /
+    // 16 tiles, i.e. 128 / 168 / 256 / 512 registers) without spilling.
     constexpr int TILES = MT * NJ;
     constexpr int D = TILES == 1 ? 8
                       : TILES == 2 ? (MT == 2 ? 4 : 6)
@@ -993,57 +1059,72 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
                       : TILES == 5 ? 5
                       : TILES <= 7 ? (MT == 2 ? 6 : (TILES == 7 ? 4 : 6))
                       : TILES == 8 ? 5
-                      : TILES == 9 ? 3 : 2;
+                      : TILES == 9 ? 3 : (TILES == 16 ? GG_DW_D16 : 2);
     Regs R[D];
 #pragma unroll
     for (int d = 0; d < D - 1; d++) load(R[d], d);
     long long s = 0;
     {
-        // Rounds whose loads (steps up to s + 2D - 2) all lie inside the wave's rows: per-lane
-        // pointers advance by constants.  (The general load() forms every address from the step
-        // number -- clamping, four 64-bit products -- and its ~90 VALU instructions per step
-        // competed with the 8 MFMAs of the step for the issue slots.)
+        // Rounds whose loads (steps up to s + 2D - 2) all lie inside the wave's rows.  The row base
+        // of each stream sits in a buffer descriptor (scalar), a lane contributes one constant byte
+        // offset, the step is a scalar offset: a load is one instruction, no address arithmetic.
+        // The sparse gradient's centre moves per lane (rows 2s and 2s+1 may belong to different
+        // centres): its offset is a vector register advanced by select.
         const long long nin = (rb - ra) >> 1;      // steps with both rows valid
-        const long long r1 = ra + 2 * (D - 1) + h; // row of the next step to load
-        const float *zp = p.Z + r1 * ldz + chl;
-        const float *xp = p.Aprev + r1 * cin;
-        const float *gp = sparse ? p.gval + cen * C + chl : p.dY + r1 * p.ldy + chl;
-        const gg_amax_t *ap = sparse ? p.amax + cen * C + chl : (const gg_amax_t *)p.Z;
-        const int ginc = sparse ? 0 : 2 * p.ldy, Cs = sparse ? C : 0;
+        const long long r1 = ra + 2 * (D - 1);     // first row of the next step to load
+        const gg_rsrc rz = gg_make_rsrc(p.Z + r1 * ldz);
+        const gg_rsrc rx = gg_make_rsrc(p.Aprev + r1 * cin);
+        const gg_rsrc rg = gg_make_rsrc(sparse ? p.gval : p.dY + r1 * p.ldy);
+        const gg_rsrc rm = gg_make_rsrc(sparse ? (const void *)p.amax : (const void *)p.Z);
+        const unsigned vz = (unsigned)(h * ldz + chl) * 4u;
+        const unsigned vxq = (unsigned)(h * cin + 4 * cq) * 4u;
+        const unsigned vxp = (unsigned)(h * cin + NQ * 128 + 2 * cq) * 4u;
+        const unsigned vxs = (unsigned)(h * cin + scol) * 4u;
+        unsigned vg = sparse ? (unsigned)(cen * C + chl) * 4u : (unsigned)(h * p.ldy + chl) * 4u;
+        unsigned va = (unsigned)(cen * C + chl);
+        unsigned sz = 0, sx = 0, sg = 0;           // scalar byte offsets of the next step
+        const unsigned dz_ = 2u * ldz * 4u, dx_ = 2u * cin * 4u, dg_ = sparse ? 0u : 2u * p.ldy * 4u;
+        const unsigned Cb = (unsigned)C;
         auto load_in = [&](Regs &R) {
             R.ok = true;
-            if constexpr (MT == 2) { const unsigned short t = *(const unsigned short *)ap; R.am[0] = t & 255; R.am[1] = t >> 8; }
-            else R.am[0] = ap[0];
+#if defined(GG_DW_ABLATE) && (GG_DW_ABLATE & 2)      // no loads in the main rounds (operands: whatever the sets hold)
+            asm volatile("" : "+v"(R.z[0]), "+v"(R.g[0]), "+v"(R.x[0]), "+v"(R.x[NJ - 1]));
+            return;
+#endif
+            if (sparse) {
+                if constexpr (MT == 2) { const unsigned t = gg_buf_ld_u16(rm, va, 0); R.am[0] = t & 255; R.am[1] = t >> 8; }
+                else R.am[0] = gg_buf_ld_u8(rm, va, 0);
+            }
             R.pp = pp;
             if constexpr (MT == 2) {
-                const float2 t = *(const float2 *)zp, u = *(const float2 *)gp;
+                const gg_f32x2 t = gg_buf_ld2(rz, vz, sz), u = gg_buf_ld2(rg, vg, sg);
                 R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y;
             } else {
-                R.z[0] = zp[0]; R.g[0] = gp[0];
+                R.z[0] = gg_buf_ld(rz, vz, sz); R.g[0] = gg_buf_ld(rg, vg, sg);
             }
             int j = 0;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                const float4 t = *(const float4 *)(xp + q * 128 + 4 * cq);
+                const gg_f32x4 t = gg_buf_ld4(rx, vxq + q * 512u, sx);
                 R.x[j++] = t.x; R.x[j++] = t.y; R.x[j++] = t.z; R.x[j++] = t.w;
             }
 #pragma unroll
             for (int q = 0; q < NP; q++) {
-                const float2 t = *(const float2 *)(xp + NQ * 128 + 2 * cq);
+                const gg_f32x2 t = gg_buf_ld2(rx, vxp, sx);
                 R.x[j++] = t.x; R.x[j++] = t.y;
             }
-            if (NS) R.x[j++] = xp[scol];
-            pp += 2;
-            const bool t1 = pp >= Pq;
-            pp -= t1 ? Pq : 0;
-            const bool t2 = pp >= Pq;
-            pp -= t2 ? Pq : 0;
-            const int adv = (t1 ? 1 : 0) + (t2 ? 1 : 0);
-            cen += adv;
-            gp += ginc + adv * Cs;
-            ap += adv * Cs;
-            zp += 2 * ldz;
-            xp += 2 * cin;
+            if (NS) R.x[j++] = gg_buf_ld(rx, vxs, sx);
+            sz += dz_; sx += dx_; sg += dg_;
+            if (sparse) {
+                pp += 2;
+                const bool t1 = pp >= Pq;
+                pp -= t1 ? Pq : 0;
+                const bool t2 = pp >= Pq;          // (P == 1: two centres per step)
+                pp -= t2 ? Pq : 0;
+                const unsigned adv = (t1 ? Cb : 0u) + (t2 ? Cb : 0u);
+                va += adv;
+                vg += adv * 4u;
+            }
         };
         for (; s + 2 * D - 1 <= nin; s += D) {
 #pragma unroll
@@ -1052,6 +1133,7 @@ __global__ __launch_bounds__(512, 1) void gg_k_linear_dw_direct(GGLinBwd p, int 
                 compute(R[d]);
             }
         }
+        if (sparse) cen = (long long)((va - (unsigned)chl) / Cb);   // the generic steps below continue from here
     }
 #pragma unroll
     for (int d = 0; d < D - 1; d++)                // the sets still hold steps s .. s + D - 2
@@ -1163,14 +1245,18 @@ static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
     int NS = rem > 0 ? 1 : 0;
     const int NJ = 4 * NQ + 2 * NP + NS;
     int MT = (C >= 64 && NJ <= 5) ? 2 : 1;
-    if (MT * NJ > 10 || NQ > 2) return false;
+    // 256 input columns, many rows: 2 x 8 tiles per wave, one wave per SIMD with the accumulators in
+    // the AGPR half of its 512 registers -- an operand value formed by the VALU then feeds twice the
+    // MFMAs (1.5 instead of 3+ VALU instructions per MFMA)
+    if (NQ == 2 && NP == 0 && NS == 0 && C >= 64 && (C & 63) == 0 && E >= 65536) MT = 2;
+    if ((MT * NJ > 10 && MT * NJ != 16) || NQ > 2) return false;
     const int MG = (C + 32 * MT - 1) / (32 * MT);
     if (MG > 8) return false;
     const int RS = MG >= 4 ? 1 : 4 / MG;
     c->MT = MT; c->NQ = NQ; c->NP = NP; c->NS = NS; c->MG = MG; c->RS = RS;
     c->threads = 64 * MG * RS;
     // waves per SIMD the register footprint allows (small tiles are latency bound: more waves)
-    const int wps = MT * NJ <= 2 ? 4 : (MT * NJ <= 4 ? 3 : 2);
+    const int wps = MT * NJ <= 2 ? 4 : (MT * NJ <= 4 ? 3 : (MT * NJ <= 10 ? 2 : 1));
     int nwg = 1024 * wps / (MG * RS);
     long long maxwg = (E + 64LL * RS - 1) / (64LL * RS);
     if (nwg > maxwg) nwg = (int)maxwg;
@@ -1214,10 +1300,19 @@ static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
     const GGDwRed r = gg_dw_reduce_cfg(c);
     int *tick = (int *)(p.dWpart + r.part_floats + r.part2_floats);
     const int ntick = r.S > 1 ? r.gx * c.MG : 0;
-    if (g_mlp_bf16 && p.pscale)   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
-        gg_k_linear_dw_direct<MT, NQ, NP, NS, true><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick);
-    else
-        gg_k_linear_dw_direct<MT, NQ, NP, NS, false><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick);
+    // (32-bit byte offsets inside a wave's row range and inside the sparse gradient)
+    const long long wmax = p.ldz > p.cin ? p.ldz : p.cin;
+    if (c.rows_per_wg * (wmax > p.ldy ? wmax : p.ldy) * 4 >= (1ll << 31)) return 1;
+    const bool sp = p.amax != nullptr;
+    if (sp && ((p.E + p.P - 1) / p.P) * (long long)p.C * 4 >= (1ll << 31)) return 1;
+    const bool bf = g_mlp_bf16 && p.pscale;   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
+#define GG_DWL(BF, SPV)                                                                           \
+    gg_k_linear_dw_direct<MT, NQ, NP, NS, BF, SPV><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick)
+    if (bf && sp) GG_DWL(true, true);
+    else if (bf) GG_DWL(true, false);
+    else if (sp) GG_DWL(false, true);
+    else GG_DWL(false, false);
+#undef GG_DWL
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -1233,6 +1328,7 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
     GG_DWD(1, 0, 0, 1) GG_DWD(1, 0, 1, 0) GG_DWD(1, 0, 1, 1) GG_DWD(1, 1, 0, 0) GG_DWD(1, 1, 0, 1)
     GG_DWD(1, 1, 1, 0) GG_DWD(1, 1, 1, 1) GG_DWD(1, 2, 0, 0) GG_DWD(1, 2, 0, 1) GG_DWD(1, 2, 1, 0)
     GG_DWD(2, 0, 0, 1) GG_DWD(2, 0, 1, 0) GG_DWD(2, 0, 1, 1) GG_DWD(2, 1, 0, 0) GG_DWD(2, 1, 0, 1)
+    GG_DWD(2, 2, 0, 0)
 #undef GG_DWD
     if (rc) return rc;
     const int nwaves = c.nwg * (c.threads / 64);

@@ -101,3 +101,33 @@ __device__ __forceinline__ void ggm_mma(const float *A, int lda, const float *__
         if (s + 3 < nk) { a1 = ap[2 * (s + 3)]; b1 = wp[(size_t)(2 * (s + 3)) * 32]; }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Buffer addressing for loops that walk a row block: the descriptor (four scalar registers) holds a
+// wave-uniform base, a lane supplies ONE constant byte offset, the row / column-tile step is a
+// scalar offset -- a load or store is one instruction with no per-element address arithmetic
+// (global_load/store with 64-bit per-lane pointers costs a v_lshl_add_u64 each, and every
+// instruction a wave issues takes ~5 cycles from the MFMA pipe: tools/micro/mfma_valu.hip).
+// Raw buffer (stride 0), 32-bit data format, range check off (num_records = 2^32 - 1).
+// The LLVM intrinsics are declared directly: clang's __builtin_amdgcn_raw_buffer_load_b64/_b128 of
+// this toolchain return the first dword in every element.
+typedef int gg_rsrc __attribute__((ext_vector_type(4)));
+typedef float gg_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
+__device__ gg_f32x4 gg_buf_ld4(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ gg_f32x2 gg_buf_ld2(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ float gg_buf_ld(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ unsigned char gg_buf_ld_u8(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.i8");
+__device__ unsigned short gg_buf_ld_u16(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.i16");
+__device__ unsigned gg_buf_ld_u32(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ void gg_buf_st(float v, gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ __forceinline__ gg_rsrc gg_make_rsrc(const void *uniform_base)
+{
+    const unsigned long long a = (unsigned long long)uniform_base;
+    gg_rsrc r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));   // (stride 0: bits 48..61 clear)
+    r.z = -1;
+    r.w = 0x00020000;
+    return r;
+}
