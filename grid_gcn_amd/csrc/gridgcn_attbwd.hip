@@ -89,18 +89,6 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
     const bool sparse = p.amax != nullptr;
     const bool z16 = p.zfmt != 0;          // Z stored as bf16
 
-    auto dz4 = [&](const float4 z, const float4 g, int k) -> float4 {
-        const float4 sc = *(const float4 *)(cst + k), sh = *(const float4 *)(cst + C + k);
-        const float4 mu = *(const float4 *)(cst + 2 * C + k), bz = *(const float4 *)(cst + 3 * C + k);
-        const float4 cz = *(const float4 *)(cst + 4 * C + k);
-        float4 d;
-        d.x = sc.x * ((z.x * sc.x + sh.x > 0.f) ? g.x : 0.f) + ((z.x - mu.x) * bz.x + cz.x);
-        d.y = sc.y * ((z.y * sc.y + sh.y > 0.f) ? g.y : 0.f) + ((z.y - mu.y) * bz.y + cz.y);
-        d.z = sc.z * ((z.z * sc.z + sh.z > 0.f) ? g.z : 0.f) + ((z.z - mu.z) * bz.z + cz.z);
-        d.w = sc.w * ((z.w * sc.w + sh.w > 0.f) ? g.w : 0.f) + ((z.w - mu.w) * bz.w + cz.w);
-        return d;
-    };
-
     // row pointers of a tile: Z row, upstream-gradient row, arg-max row (dense: harmless bytes of Z,
     // never used), neighbour number of the row within its centre
     auto tileptrs = [&](long long tl, const float *&zr_, const float *&gr_, const gg_amax_t *&ar_, int &pp_) {
@@ -160,7 +148,6 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
          tile += (long long)gridDim.x * 4) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        const bool rowok = l31 < nrows;               // rows past E are clamped copies: no weight
         const float *zr, *gr;
         const gg_amax_t *ar;
         int pp;
@@ -172,27 +159,31 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
             int pn;
             if (tn < ntile) tileptrs(tn, nzr, ngr, nar, pn);
         }
-        // The arg-max bytes are loaded unconditionally and applied where the gradient is used: with
-        // the load inside `if (sparse)` (and the select right behind it) the compiler closed every
-        // quad with s_waitcnt vmcnt(0) -- four memory round trips per 32 channels instead of one.
-        auto gmask = [&](float4 g, unsigned am) -> float4 {
-            g.x = (!sparse || (int)(am & 255u) == pp) ? g.x : 0.f;
-            g.y = (!sparse || (int)((am >> 8) & 255u) == pp) ? g.y : 0.f;
-            g.z = (!sparse || (int)((am >> 16) & 255u) == pp) ? g.z : 0.f;
-            g.w = (!sparse || (int)(am >> 24) == pp) ? g.w : 0.f;
-            return g;
-        };
+        // (The arg-max bytes are loaded unconditionally and applied where the gradient is used: with
+        //  the load inside `if (sparse)` the compiler closed every quad with s_waitcnt vmcnt(0).)
         // the previous layer's raw outputs in the C/D row order (rows (r&3) + 8(r>>2) + 4h, column
         // l31): A operand of the dW product and input of the epilogue's BatchNorm-backward sums
         const long long base = (r0 + 4 * h) * cin + l31;
+        // zpv = NaN where the lane has no element (idle column of a 16-wide layer, row past E): the
+        // activation av = max(NaN * ps + psh, 0) is then 0, so such a row adds nothing to dW whatever
+        // its dZ -- no per-element row select on dZ
         float zpv[16];
+        // (a second, predicate-free form of this block and of the epilogue for full tiles spilled 24-59
+        //  registers and ran 10 % slower than this one)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rr = (r & 3) + 8 * (r >> 2);
             const bool ok = colok && (nrows == 32 || rr + 4 * h < nrows);
             const float v = *(ok ? p.Aprev + base + rr * cin : p.Aprev);   // (no branch around the load)
-            zpv[r] = ok ? v : 0.f;
+            zpv[r] = ok ? v : __builtin_nanf("");
         }
+        // (recomputed where it is used -- two FMA-and-max per pair of rows: sixteen more registers for
+        //  a stored copy spilled at both widths)
+        auto act2 = [&](int r) -> gg_f32x2 {
+            const gg_f32x2 y = __builtin_elementwise_fma((gg_f32x2){zpv[r], zpv[r + 1]}, (gg_f32x2){ps, ps},
+                                                         (gg_f32x2){psh, psh});
+            return (gg_f32x2){fmaxf(y.x, 0.f), fmaxf(y.y, 0.f)};
+        };
         ggm_f32x16 accx;
 #pragma unroll
         for (int r = 0; r < 16; r++) accx[r] = 0.f;
@@ -200,11 +191,11 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
         if constexpr (BF16) {
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
-                float av[8];
+                float av_[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) av[j] = fmaxf(zpv[hf * 8 + j] * ps + psh, 0.f);
-                av8[hf] = ggaf_u32x4{ggaf_pk(av[0], av[1]), ggaf_pk(av[2], av[3]), ggaf_pk(av[4], av[5]),
-                                     ggaf_pk(av[6], av[7])};
+                for (int j = 0; j < 8; j += 2) { const gg_f32x2 t = act2(hf * 8 + j); av_[j] = t.x; av_[j + 1] = t.y; }
+                av8[hf] = ggaf_u32x4{ggaf_pk(av_[0], av_[1]), ggaf_pk(av_[2], av_[3]), ggaf_pk(av_[4], av_[5]),
+                                     ggaf_pk(av_[6], av_[7])};
             }
         }
         // dW^T tile j += act(Aprev)^T * dZ(columns cc*32.. of the LDS tile).  The tile belongs to this
@@ -230,9 +221,8 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
-                    // (rows past E: their dZ rows in T are zero, whatever act() makes of the padding)
-                    const float av = fmaxf(zpv[r] * ps + psh, 0.f);      // 0 in the idle columns
-                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, trow[cc * 32], accw[j], 0, 0, 0);
+                    const float avr = fmaxf(__builtin_fmaf(zpv[r], ps, psh), 0.f);      // 0 where zpv is NaN
+                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr, trow[cc * 32], accw[j], 0, 0, 0);
                 }
             }
         };
@@ -247,9 +237,11 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                 zcvt();
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    a[q] = dz4(z[q], gmask(g[q], am[q]), k0 + 4 * q);
-                    if (!rowok) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *(float4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = a[q];
+                    const gg_f32x4 d = gg_dz4v(__builtin_bit_cast(gg_f32x4, z[q]), __builtin_bit_cast(gg_f32x4, g[q]),
+                                               am[q], pp, sparse, cst, C, k0 + 4 * q);
+                    a[q] = __builtin_bit_cast(float4, d);
+                    *(gg_f32x4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = d;
+                    __builtin_amdgcn_sched_barrier(0);   // (one quad's constants live at a time)
                 }
                 if (2 * hc + cc + 1 < NJ) issue(zr, gr, ar, 2 * hc + cc + 1);
                 else issue(nzr, ngr, nar, 0);
@@ -282,17 +274,21 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
             if constexpr (NJ != 4) { dwphase(2 * hc, 0); dwphase(2 * hc + 1, 1); }
         }
         // dX tile + BatchNorm-backward sums of the previous layer
-        float *xp = p.dX + base;
         float s1 = 0.f, s2 = 0.f;
+        const float pc = -(pm * pr);                   // zhat = zp * pr + pc
+        // (plain stores: with buffer stores and scalar row offsets this kernel spilled 30-80 registers)
+        {
+            float *xp = p.dX + base;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            if (colok && (nrows == 32 || rr + 4 * h < nrows)) {
-                const float dx = accx[r];
-                xp[rr * cin] = dx;
-                const float d = (zpv[r] * ps + psh > 0.f) ? dx : 0.f;
-                s1 += d;
-                s2 += d * ((zpv[r] - pm) * pr);
+            for (int r = 0; r < 16; r++) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (colok && (nrows == 32 || rr + 4 * h < nrows)) {
+                    const float dx = accx[r];
+                    xp[rr * cin] = dx;
+                    const float d = __builtin_fmaf(zpv[r], ps, psh) > 0.f ? dx : 0.f;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, __builtin_fmaf(zpv[r], pr, pc), s2);
+                }
             }
         }
         a1 += s1;

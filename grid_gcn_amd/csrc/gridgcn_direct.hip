@@ -92,13 +92,11 @@ __device__ __forceinline__ float gg_f4(const float4 &v, int i)
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// (one FMA + one max per channel, the FMAs two channels at a time: gridgcn_mma.h)
 __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const float4 sh)
 {
-    a.x = fmaxf(a.x * sc.x + sh.x, 0.f);
-    a.y = fmaxf(a.y * sc.y + sh.y, 0.f);
-    a.z = fmaxf(a.z * sc.z + sh.z, 0.f);
-    a.w = fmaxf(a.w * sc.w + sh.w, 0.f);
-    return a;
+    return __builtin_bit_cast(float4, gg_bnrelu4v(__builtin_bit_cast(gg_f32x4, a), __builtin_bit_cast(gg_f32x4, sc),
+                                                   __builtin_bit_cast(gg_f32x4, sh)));
 }
 
 // Z[E, cout] = act(X[E, K]) * W + b, batch statistics of Z in the epilogue.  K % 8 == 0, X row
@@ -154,7 +152,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
     }
     for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
          tile += (long long)gridDim.x * nw) {
-        const long long r0 = tile << 5;
+        const long long r0 = (long long)__builtin_amdgcn_readfirstlane((int)tile) << 5;   // (wave uniform)
         long long row = r0 + (lane & 31);
         if (row >= p.E) row = p.E - 1;
         const float *xr = p.X + row * p.lda;          // lda = row stride of X (>= K)
@@ -293,7 +291,34 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
             if (z16) zh[off] = (unsigned short)(gg_pk_bf16(z, 0.f) & 0xffffu);
             else zp[off] = z;
         };
-        if (nrows == 32) {
+        if (NT <= 4 && nrows == 32 && !z16) {       // (8 column tiles: this form spilled 80 registers)
+            // Full row block, fp32 Z: written for instruction count (every instruction costs the MFMA
+            // pipe ~5 cycles).  The block's base address is wave uniform (buffer descriptor), a lane
+            // adds one constant, rows step by a scalar offset, column tiles by the immediate offset;
+            // bias and statistics two rows per instruction (v_pk_add_f32 / v_pk_fma_f32).
+            const gg_rsrc zs = gg_make_rsrc(p.Z ? p.Z + r0 * ldz : (float *)p.sums);
+            const unsigned lo = (unsigned)(4 * h * ldz + (lane & 31)) * 4u;
+            const bool wr = p.Z != nullptr;            // (nullptr: statistics only)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (EXACT || t * 32 + (lane & 31) < p.cout) {
+                    gg_f32x2 sm = {0.f, 0.f}, sq = {0.f, 0.f};
+                    const gg_f32x2 b2 = {bias[t], bias[t]};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const gg_f32x2 z = (gg_f32x2){acc[t][r], acc[t][r + 1]} + b2;
+                        if (wr) {
+                            gg_buf_st(z.x, zs, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldz) * 4u);
+                            gg_buf_st(z.y, zs, lo + t * 128u, (unsigned)((((r + 1) & 3) + 8 * ((r + 1) >> 2)) * ldz) * 4u);
+                        }
+                        sm += z;
+                        sq = __builtin_elementwise_fma(z, z, sq);
+                    }
+                    ssum[t] += sm.x + sm.y;
+                    ssq[t] += sq.x + sq.y;
+                }
+            }
+        } else if (nrows == 32) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 if (EXACT || t * 32 + (lane & 31) < p.cout) {
@@ -473,16 +498,15 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
     const int nfull = C >> 5, ktail = C & 31;
     const bool sparse = p.amax != nullptr;
 
+    // (gridgcn_mma.h: explicit FMAs, two channels per instruction; the arg-max mask of the sparse
+    //  gradient is applied by the same select as the ReLU mask)
     auto dz4 = [&](const float4 z, const float4 g, int k) -> float4 {
-        const float4 sc = *(const float4 *)(cst + k), sh = *(const float4 *)(cst + C + k);
-        const float4 mu = *(const float4 *)(cst + 2 * C + k), bz = *(const float4 *)(cst + 3 * C + k);
-        const float4 cz = *(const float4 *)(cst + 4 * C + k);
-        float4 d;
-        d.x = sc.x * ((z.x * sc.x + sh.x > 0.f) ? g.x : 0.f) + ((z.x - mu.x) * bz.x + cz.x);
-        d.y = sc.y * ((z.y * sc.y + sh.y > 0.f) ? g.y : 0.f) + ((z.y - mu.y) * bz.y + cz.y);
-        d.z = sc.z * ((z.z * sc.z + sh.z > 0.f) ? g.z : 0.f) + ((z.z - mu.z) * bz.z + cz.z);
-        d.w = sc.w * ((z.w * sc.w + sh.w > 0.f) ? g.w : 0.f) + ((z.w - mu.w) * bz.w + cz.w);
-        return d;
+        return __builtin_bit_cast(float4, gg_dz4v(__builtin_bit_cast(gg_f32x4, z), __builtin_bit_cast(gg_f32x4, g),
+                                                   0u, 0, false, cst, C, k));
+    };
+    auto dz4m = [&](const float4 z, const float4 g, unsigned am, int pp_, int k) -> float4 {
+        return __builtin_bit_cast(float4, gg_dz4v(__builtin_bit_cast(gg_f32x4, z), __builtin_bit_cast(gg_f32x4, g),
+                                                   am, pp_, sparse, cst, C, k));
     };
 
     for (long long tile = (long long)blockIdx.x * nw + wave; tile < ntile;
@@ -610,12 +634,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                 const float4 zn = *(const float4 *)(zr + kn), gn = *(const float4 *)(gr + kn);
                 const unsigned amn = *(const unsigned *)(ar + kn);
                 const int k0 = (qi >> 2) * 32 + h * 16 + (qi & 3) * 4;
-                float4 g = gc;
-                g.x = (!sparse || (int)(amc & 255u) == pp) ? g.x : 0.f;
-                g.y = (!sparse || (int)((amc >> 8) & 255u) == pp) ? g.y : 0.f;
-                g.z = (!sparse || (int)((amc >> 16) & 255u) == pp) ? g.z : 0.f;
-                g.w = (!sparse || (int)(amc >> 24) == pp) ? g.w : 0.f;
-                const float4 a = dz4(zc, g, k0);
+                const float4 a = dz4m(zc, gc, amc, pp, k0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     float b[NTV];
@@ -689,17 +708,24 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
 #pragma unroll
                         for (int r = 0; r < 16; r++)
                             zpv[r] = gg_buf_ld(as, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldx) * 4u);
-                        float s1 = 0.f, s2 = 0.f;
+                        // two rows per instruction: d = relu'(zp * ps + psh) * dx,  s1 += d,
+                        // s2 += d * zhat with zhat = zp * pr + pc
+                        gg_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+                        const gg_f32x2 ps2 = {ps_t, ps_t}, psh2 = {psh_t, psh_t}, pr2 = {pr_t, pr_t};
+                        const float pcz = -(pm_t * pr_t);
+                        const gg_f32x2 pc2 = {pcz, pcz};
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const float dx = acc[t][r];
-                            gg_buf_st(dx, xs, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldx) * 4u);
-                            const float d = (zpv[r] * ps_t + psh_t > 0.f) ? dx : 0.f;
+                        for (int r = 0; r < 16; r += 2) {
+                            const gg_f32x2 dx = {acc[t][r], acc[t][r + 1]}, zp = {zpv[r], zpv[r + 1]};
+                            gg_buf_st(dx.x, xs, lo + t * 128u, (unsigned)(((r & 3) + 8 * (r >> 2)) * ldx) * 4u);
+                            gg_buf_st(dx.y, xs, lo + t * 128u, (unsigned)((((r + 1) & 3) + 8 * ((r + 1) >> 2)) * ldx) * 4u);
+                            const gg_f32x2 y = __builtin_elementwise_fma(zp, ps2, psh2);
+                            const gg_f32x2 d = {y.x > 0.f ? dx.x : 0.f, y.y > 0.f ? dx.y : 0.f};
                             s1 += d;
-                            s2 += d * ((zpv[r] - pm_t) * pr_t);
+                            s2 = __builtin_elementwise_fma(d, __builtin_elementwise_fma(zp, pr2, pc2), s2);
                         }
-                        a1[t] += s1;
-                        a2[t] += s2;
+                        a1[t] += s1.x + s1.y;
+                        a2[t] += s2.x + s2.y;
                     } else {
 #pragma unroll
                         for (int r = 0; r < 16; r++)

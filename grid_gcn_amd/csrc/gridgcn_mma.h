@@ -131,3 +131,37 @@ __device__ __forceinline__ gg_rsrc gg_make_rsrc(const void *uniform_base)
     r.w = 0x00020000;
     return r;
 }
+
+// ------------------------------------------------------------------------------------------
+// Operand formulas of the training kernels, written for instruction count (every VALU instruction
+// costs the SIMD ~5 cycles of MFMA time): explicit FMAs on float4 values, which the compiler issues
+// as v_pk_fma_f32 / v_pk_add_f32 (two channels per instruction).
+__device__ __forceinline__ gg_f32x4 gg_ld_f4(const float *p) { return *(const gg_f32x4 *)p; }
+
+// BatchNorm + ReLU of four consecutive channels: max(x * sc + sh, 0)
+__device__ __forceinline__ gg_f32x4 gg_bnrelu4v(gg_f32x4 x, gg_f32x4 sc, gg_f32x4 sh)
+{
+    const gg_f32x4 y = __builtin_elementwise_fma(x, sc, sh);
+    return __builtin_elementwise_max(y, (gg_f32x4)(0.f));
+}
+
+// dZ of four consecutive channels k .. k+3 of one row (BatchNorm + ReLU backward):
+//   dz = sc * (mask ? g : 0) + ((z - mu) * bz + cz),   mask = z * sc + sh > 0  [and arg-max byte == pp]
+// cst = [5][C]: sc, sh, mu, bz, cz (bz = -sc*rstd*m2, cz = -sc*m1).  am = the four arg-max bytes of the
+// sparse upstream gradient (gridgcn_pairmax_bwd), consulted only when `sparse`.
+__device__ __forceinline__ gg_f32x4 gg_dz4v(gg_f32x4 z, gg_f32x4 g, unsigned am, int pp, bool sparse,
+                                            const float *cst, int C, int k)
+{
+    const gg_f32x4 sc = gg_ld_f4(cst + k), sh = gg_ld_f4(cst + C + k), mu = gg_ld_f4(cst + 2 * C + k);
+    const gg_f32x4 bz = gg_ld_f4(cst + 3 * C + k), cz = gg_ld_f4(cst + 4 * C + k);
+    const gg_f32x4 y = __builtin_elementwise_fma(z, sc, sh);
+    const gg_f32x4 t = __builtin_elementwise_fma(z - mu, bz, cz);
+    // (bit-wise & | on purpose: && || made a branch per element)
+    const bool ns = !sparse;
+    gg_f32x4 gm;
+    gm.x = ((y.x > 0.f) & (ns | ((int)(am & 255u) == pp))) ? g.x : 0.f;
+    gm.y = ((y.y > 0.f) & (ns | ((int)((am >> 8) & 255u) == pp))) ? g.y : 0.f;
+    gm.z = ((y.z > 0.f) & (ns | ((int)((am >> 16) & 255u) == pp))) ? g.z : 0.f;
+    gm.w = ((y.w > 0.f) & (ns | ((int)(am >> 24) == pp))) ? g.w : 0.f;
+    return __builtin_elementwise_fma(sc, gm, t);
+}
