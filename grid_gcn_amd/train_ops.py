@@ -342,6 +342,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
             vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
         bn = bns[l]
         track = bn is not None and bn.track_running_stats
+        # (a separate launch on purpose: folded into the forward kernel's last workgroup -- returning
+        #  fp64 atomics, ticket, device-scope read-back -- the step was 0.1 ms SLOWER over 31 layers)
         rc = lib.gridgcn_bn_finalize(
             _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
             _momentum(bn) if track else 0.0, cout, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
@@ -558,10 +560,17 @@ class _MLPTrain(torch.autograd.Function):
         eps, bns, out, link, prev = (tuple(meta) + (None, None))[:5]
         L = len(params) // 4
         x = x.contiguous()
-        E = x.shape[0]
+        E, cin0 = x.shape
+        if DIRECT_FWD and cin0 % 8 and prev is None:
+            # rows padded with zero columns to a multiple of 8 floats: the register-direct kernels
+            # then take the layer (a [E, 4] or [E, 4 + C] centre tensor of the up path; the LDS-staged
+            # forward kernel these widths used to fall to ran at 4 % of the MFMA rate)
+            xp = x.new_zeros((E, (cin0 + 7) & ~7))
+            xp[:, :cin0] = x
+            x = xp
         with torch.cuda.device(x.device):
             st = _chain_forward(lib, x, params, bns, eps, 0,
-                                x.shape[1] if ctx.needs_input_grad[0] else 0,
+                                cin0 if ctx.needs_input_grad[0] else 0,
                                 prev_bn=prev.prev_bn()[:2] if prev is not None else None,
                                 out_raw=out if link is not None else None,
                                 last_vec=link.vec if link is not None else None)
@@ -576,6 +585,7 @@ class _MLPTrain(torch.autograd.Function):
         ctx.L = L
         ctx.ndx = st.ndx
         ctx.cin_w0 = params[0].shape[1]          # x may carry zero-padded columns beyond it
+        ctx.cin0 = cin0
         ctx.save_for_backward(x, *st.Z, *st.scale, *st.shift, *st.mean, *st.rstd, *st.Wb, *st.Wg,
                               *st.Wdx)
         return Y
@@ -619,6 +629,8 @@ class _MLPTrain(torch.autograd.Function):
             dX, grads = r[0], r[1]
             if prev is not None:
                 prev.sums = r[2].view(2, x.shape[1])
+            if dX is not None and ctx.cin0 != x.shape[1]:
+                dX = dX[:, :ctx.cin0]
         return (dX, None) + tuple(grads)
 
 
