@@ -544,16 +544,21 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         for (int c = 0; c < nfull; c++) {
             const int k0 = c * 32 + h * 16;
             float4 z[4], g[4];
+            unsigned amq[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { z[q] = *(const float4 *)(zr + k0 + 4 * q); g[q] = ldg(k0 + 4 * q); }
+            for (int q = 0; q < 4; q++) {
+                z[q] = *(const float4 *)(zr + k0 + 4 * q);
+                g[q] = *(const float4 *)(gr + k0 + 4 * q);
+                amq[q] = *(const unsigned *)(ar + k0 + 4 * q);    // (dense: harmless bytes, never used)
+            }
             {
                 // dZ formed and packed group by group (its five constants per channel quad would
                 // otherwise all be live at once)
                 const ggm_u32x4 *W16 = (const ggm_u32x4 *)Wl;
 #pragma unroll
                 for (int gq = 0; gq < 2; gq++) {
-                    const float4 d0 = dz4(z[2 * gq], g[2 * gq], k0 + 8 * gq);
-                    const float4 d1 = dz4(z[2 * gq + 1], g[2 * gq + 1], k0 + 8 * gq + 4);
+                    const float4 d0 = dz4m(z[2 * gq], g[2 * gq], amq[2 * gq], pp, k0 + 8 * gq);
+                    const float4 d1 = dz4m(z[2 * gq + 1], g[2 * gq + 1], amq[2 * gq + 1], pp, k0 + 8 * gq + 4);
                     const ggm_u32x4 a8 = {gg_pk_bf16(d0.x, d0.y), gg_pk_bf16(d0.z, d0.w),
                                           gg_pk_bf16(d1.x, d1.y), gg_pk_bf16(d1.z, d1.w)};
 #pragma unroll
@@ -1040,18 +1045,92 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
 #endif
     };
 
+    // Streams of the main rounds (steps whose rows all lie inside the wave's range): the row base of
+    // each stream sits in a buffer descriptor (scalar), a lane contributes one constant byte offset,
+    // the step is a scalar offset -- a load is one instruction, no address arithmetic.  The sparse
+    // gradient's centre moves per lane (rows 2s and 2s+1 may belong to different centres): its offset
+    // is a vector register advanced by select.  stream_init(r1): r1 = first row of the next step.
+    gg_rsrc rz, rx, rg, rm;
+    const unsigned vz = (unsigned)(h * ldz + chl) * 4u;
+    const unsigned vxq = (unsigned)(h * cin + 4 * cq) * 4u;
+    const unsigned vxp = (unsigned)(h * cin + NQ * 128 + 2 * cq) * 4u;
+    const unsigned vxs = (unsigned)(h * cin + scol) * 4u;
+    unsigned vg = 0, va = 0, sz = 0, sx = 0, sg = 0;   // (s*: scalar byte offsets of the next step)
+    const unsigned dz_ = 2u * ldz * 4u, dx_ = 2u * cin * 4u, dg_ = sparse ? 0u : 2u * p.ldy * 4u;
+    const unsigned Cb = (unsigned)C;
+    auto stream_init = [&](long long r1) {
+        rz = gg_make_rsrc(p.Z + r1 * ldz);
+        rx = gg_make_rsrc(p.Aprev + r1 * cin);
+        rg = gg_make_rsrc(sparse ? p.gval : p.dY + r1 * p.ldy);
+        rm = gg_make_rsrc(sparse ? (const void *)p.amax : (const void *)p.Z);
+        vg = sparse ? (unsigned)(cen * C + chl) * 4u : (unsigned)(h * p.ldy + chl) * 4u;
+        va = (unsigned)(cen * C + chl);
+        sz = 0; sx = 0; sg = 0;
+    };
+    auto stream_done = [&]() {                     // the generic steps continue from here
+        if (sparse) cen = (long long)((va - (unsigned)chl) / Cb);
+    };
+    auto load_in = [&](Regs &R) {
+        R.ok = true;
+#if defined(GG_DW_ABLATE) && (GG_DW_ABLATE & 2)      // no loads in the main rounds (operands: whatever the sets hold)
+        asm volatile("" : "+v"(R.z[0]), "+v"(R.g[0]), "+v"(R.x[0]), "+v"(R.x[NJ - 1]));
+        return;
+#endif
+        if (sparse) {
+            if constexpr (MT == 2) { const unsigned t = gg_buf_ld_u16(rm, va, 0); R.am[0] = t & 255; R.am[1] = t >> 8; }
+            else R.am[0] = gg_buf_ld_u8(rm, va, 0);
+        }
+        R.pp = pp;
+        if constexpr (MT == 2) {
+            const gg_f32x2 t = gg_buf_ld2(rz, vz, sz), u = gg_buf_ld2(rg, vg, sg);
+            R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y;
+        } else {
+            R.z[0] = gg_buf_ld(rz, vz, sz); R.g[0] = gg_buf_ld(rg, vg, sg);
+        }
+        int j = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const gg_f32x4 t = gg_buf_ld4(rx, vxq + q * 512u, sx);
+            R.x[j++] = t.x; R.x[j++] = t.y; R.x[j++] = t.z; R.x[j++] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const gg_f32x2 t = gg_buf_ld2(rx, vxp, sx);
+            R.x[j++] = t.x; R.x[j++] = t.y;
+        }
+        if (NS) R.x[j++] = gg_buf_ld(rx, vxs, sx);
+        sz += dz_; sx += dx_; sg += dg_;
+        if (sparse) {
+            pp += 2;
+            const bool t1 = pp >= Pq;
+            pp -= t1 ? Pq : 0;
+            const bool t2 = pp >= Pq;          // (P == 1: two centres per step)
+            pp -= t2 ? Pq : 0;
+            const unsigned adv = (t1 ? Cb : 0u) + (t2 ? Cb : 0u);
+            va += adv;
+            vg += adv * 4u;
+        }
+    };
+
     const long long nsteps = (rb - ra + 1) >> 1;
     Regs A, B;
     if constexpr (BF16) {
         // eight steps (16 rows) per v_mfma_f32_32x32x16_bf16: element j of a lane's operands =
         // step 8g + j, packed two steps per register as they are formed
+        const long long nin = (rb - ra) >> 1;      // steps with both rows valid
+        stream_init(ra);
         for (long long s = 0; s < nsteps; s += 8) {
             unsigned dzp[MT][4], xap[NJ][4];
+            const bool inside = s + 8 <= nin;      // (wave uniform) all 16 rows valid: the cheap loads
+            if (!inside && s > 0 && s - 8 + 8 <= nin) stream_done();
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 float d0[MT], x0[NJ], d1[MT], x1[NJ];
-                load(A, s + 2 * jj);          // past the end: ok = false, clamped addresses
-                load(B, s + 2 * jj + 1);
+                if (inside) { load_in(A); load_in(B); }
+                else {
+                    load(A, s + 2 * jj);      // past the end: ok = false, clamped addresses
+                    load(B, s + 2 * jj + 1);
+                }
                 values(A, d0, x0);
                 values(B, d1, x1);
 #pragma unroll
@@ -1097,61 +1176,7 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
         // The sparse gradient's centre moves per lane (rows 2s and 2s+1 may belong to different
         // centres): its offset is a vector register advanced by select.
         const long long nin = (rb - ra) >> 1;      // steps with both rows valid
-        const long long r1 = ra + 2 * (D - 1);     // first row of the next step to load
-        const gg_rsrc rz = gg_make_rsrc(p.Z + r1 * ldz);
-        const gg_rsrc rx = gg_make_rsrc(p.Aprev + r1 * cin);
-        const gg_rsrc rg = gg_make_rsrc(sparse ? p.gval : p.dY + r1 * p.ldy);
-        const gg_rsrc rm = gg_make_rsrc(sparse ? (const void *)p.amax : (const void *)p.Z);
-        const unsigned vz = (unsigned)(h * ldz + chl) * 4u;
-        const unsigned vxq = (unsigned)(h * cin + 4 * cq) * 4u;
-        const unsigned vxp = (unsigned)(h * cin + NQ * 128 + 2 * cq) * 4u;
-        const unsigned vxs = (unsigned)(h * cin + scol) * 4u;
-        unsigned vg = sparse ? (unsigned)(cen * C + chl) * 4u : (unsigned)(h * p.ldy + chl) * 4u;
-        unsigned va = (unsigned)(cen * C + chl);
-        unsigned sz = 0, sx = 0, sg = 0;           // scalar byte offsets of the next step
-        const unsigned dz_ = 2u * ldz * 4u, dx_ = 2u * cin * 4u, dg_ = sparse ? 0u : 2u * p.ldy * 4u;
-        const unsigned Cb = (unsigned)C;
-        auto load_in = [&](Regs &R) {
-            R.ok = true;
-#if defined(GG_DW_ABLATE) && (GG_DW_ABLATE & 2)      // no loads in the main rounds (operands: whatever the sets hold)
-            asm volatile("" : "+v"(R.z[0]), "+v"(R.g[0]), "+v"(R.x[0]), "+v"(R.x[NJ - 1]));
-            return;
-#endif
-            if (sparse) {
-                if constexpr (MT == 2) { const unsigned t = gg_buf_ld_u16(rm, va, 0); R.am[0] = t & 255; R.am[1] = t >> 8; }
-                else R.am[0] = gg_buf_ld_u8(rm, va, 0);
-            }
-            R.pp = pp;
-            if constexpr (MT == 2) {
-                const gg_f32x2 t = gg_buf_ld2(rz, vz, sz), u = gg_buf_ld2(rg, vg, sg);
-                R.z[0] = t.x; R.z[1] = t.y; R.g[0] = u.x; R.g[1] = u.y;
-            } else {
-                R.z[0] = gg_buf_ld(rz, vz, sz); R.g[0] = gg_buf_ld(rg, vg, sg);
-            }
-            int j = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const gg_f32x4 t = gg_buf_ld4(rx, vxq + q * 512u, sx);
-                R.x[j++] = t.x; R.x[j++] = t.y; R.x[j++] = t.z; R.x[j++] = t.w;
-            }
-#pragma unroll
-            for (int q = 0; q < NP; q++) {
-                const gg_f32x2 t = gg_buf_ld2(rx, vxp, sx);
-                R.x[j++] = t.x; R.x[j++] = t.y;
-            }
-            if (NS) R.x[j++] = gg_buf_ld(rx, vxs, sx);
-            sz += dz_; sx += dx_; sg += dg_;
-            if (sparse) {
-                pp += 2;
-                const bool t1 = pp >= Pq;
-                pp -= t1 ? Pq : 0;
-                const bool t2 = pp >= Pq;          // (P == 1: two centres per step)
-                pp -= t2 ? Pq : 0;
-                const unsigned adv = (t1 ? Cb : 0u) + (t2 ? Cb : 0u);
-                va += adv;
-                vg += adv * 4u;
-            }
-        };
+        stream_init(ra + 2 * (D - 1));
         for (; s + 2 * D - 1 <= nin; s += D) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
@@ -1159,7 +1184,7 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
                 compute(R[d]);
             }
         }
-        if (sparse) cen = (long long)((va - (unsigned)chl) / Cb);   // the generic steps below continue from here
+        stream_done();
     }
 #pragma unroll
     for (int d = 0; d < D - 1; d++)                // the sets still hold steps s .. s + D - 2
