@@ -885,7 +885,7 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 #define GG_DW_D16 8      // register sets of the 16-tile form (one wave per SIMD: depth instead of partners)
 template <int MT, int NQ, int NP, int NS, bool BF16 = false, bool SP = false>
 __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) void gg_k_linear_dw_direct(
-    GGLinBwd p, int MG, int RS, long long rows_per_wg, int *__restrict__ tick, int ntick)
+    GGLinBwd p, int MG, int RS, long long rows_per_wg, int *__restrict__ tick, int ntick, int lds_red)
 {
     constexpr int NJ = 4 * NQ + 2 * NP + NS;
     typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1195,8 +1195,38 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
     }
     }
 
-    // partial: [wave_global][i*NJ + j][reg][lane]
-    const long long wg = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    // The RS row streams of an m-group add up inside the workgroup first (LDS, fixed order rs = 1,
+    // 2, ...), so that ONE partial per (workgroup, m-group) goes to the workspace: RS times fewer
+    // bytes written here and read by gg_k_dw_reduce_direct (at RS = 2..4 the partials of a step were
+    // ~1 GB each way).  lds_red = 0: the tiles of MG m-groups do not fit LDS -- every wave stores.
+    extern __shared__ __attribute__((aligned(16))) float dwred[];
+    if (lds_red && RS > 1) {
+        float *slot = dwred + (size_t)mg * (MT * NJ * 1024) + lane;
+        for (int r_ = 1; r_ < RS; r_++) {
+            if (rs == r_) {
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) slot[((i * NJ + j) * 16 + r) * 64] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (rs == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[i][j][r] += slot[((i * NJ + j) * 16 + r) * 64];
+            }
+            __syncthreads();
+        }
+        if (rs != 0) return;
+    }
+    // partial: [slot][i*NJ + j][reg][lane], slot = workgroup * MG + m-group (or the global wave number)
+    const long long wg = lds_red ? (long long)blockIdx.x * MG + mg
+                                 : (long long)blockIdx.x * (blockDim.x >> 6) + wave;
     float *out = p.dWpart + wg * (MT * NJ * 1024) + lane;
 #pragma unroll
     for (int i = 0; i < MT; i++)
@@ -1284,7 +1314,7 @@ __global__ __launch_bounds__(64 * GG_DWR_SL) void gg_k_dw_reduce_direct(
     dW[(size_t)c * cin_w + f] = s;
 }
 
-struct GGDwCfg { int MT, NQ, NP, NS, MG, RS, threads, nwg; long long rows_per_wg; };
+struct GGDwCfg { int MT, NQ, NP, NS, MG, RS, threads, nwg; long long rows_per_wg; int lds_red, slots; };
 
 static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
 {
@@ -1316,6 +1346,9 @@ static bool gg_dw_direct_cfg(long long E, int C, int cin, GGDwCfg *c)
     rp = (rp + 1) & ~1ll;
     c->rows_per_wg = rp;
     c->nwg = (int)((E + rp - 1) / rp);
+    // row streams of an m-group summed in LDS before the store (one tile set per m-group must fit)
+    c->lds_red = (RS > 1 && (size_t)MG * MT * NJ * 4096 <= 152 * 1024) ? 1 : 0;
+    c->slots = c->lds_red ? c->nwg * MG : c->nwg * (c->threads / 64);   // partial tile sets in the workspace
     return true;
 }
 
@@ -1326,13 +1359,13 @@ static GGDwRed gg_dw_reduce_cfg(const GGDwCfg &c)
     GGDwRed r;
     const int NJ = 4 * c.NQ + 2 * c.NP + c.NS;
     const int per = c.MT * NJ * 1024;
-    const int nwm = c.nwg * (c.threads / 64) / c.MG;
+    const int nwm = c.slots / c.MG;
     r.gx = (per + 63) / 64;
     int S = 2048 / (r.gx * c.MG);
     S = S > 16 ? 16 : S;
     while (S > 1 && nwm / S < 8) S >>= 1;          // at least 8 waves per slice
     r.S = S < 1 ? 1 : S;
-    r.part_floats = (size_t)c.nwg * (c.threads / 64) * per;
+    r.part_floats = (size_t)c.slots * per;
     r.part2_floats = r.S > 1 ? (size_t)r.S * c.MG * per : 0;
     return r;
 }
@@ -1357,8 +1390,21 @@ static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
     const bool sp = p.amax != nullptr;
     if (sp && ((p.E + p.P - 1) / p.P) * (long long)p.C * 4 >= (1ll << 31)) return 1;
     const bool bf = g_mlp_bf16 && p.pscale;   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
+    const size_t ldsb = c.lds_red ? (size_t)c.MG * MT * (4 * NQ + 2 * NP + NS) * 4096 : 0;
+    if (ldsb > 64 * 1024) {
+        static bool attr_done[4] = {false, false, false, false};
+        const int vi = (bf ? 2 : 0) + (sp ? 1 : 0);
+        if (!attr_done[vi]) {
+            const void *f = bf ? (sp ? (const void *)gg_k_linear_dw_direct<MT, NQ, NP, NS, true, true>
+                                     : (const void *)gg_k_linear_dw_direct<MT, NQ, NP, NS, true, false>)
+                               : (sp ? (const void *)gg_k_linear_dw_direct<MT, NQ, NP, NS, false, true>
+                                     : (const void *)gg_k_linear_dw_direct<MT, NQ, NP, NS, false, false>);
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+            attr_done[vi] = true;
+        }
+    }
 #define GG_DWL(BF, SPV)                                                                           \
-    gg_k_linear_dw_direct<MT, NQ, NP, NS, BF, SPV><<<c.nwg, c.threads, 0, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick)
+    gg_k_linear_dw_direct<MT, NQ, NP, NS, BF, SPV><<<c.nwg, c.threads, ldsb, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick, c.lds_red)
     if (bf && sp) GG_DWL(true, true);
     else if (bf) GG_DWL(true, false);
     else if (sp) GG_DWL(false, true);
@@ -1382,7 +1428,7 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
     GG_DWD(2, 2, 0, 0)
 #undef GG_DWD
     if (rc) return rc;
-    const int nwaves = c.nwg * (c.threads / 64);
+    const int nwaves = c.slots;
     const GGDwRed r = gg_dw_reduce_cfg(c);
     float *part2 = p.dWpart + r.part_floats;
     int *tick = (int *)(part2 + r.part2_floats);
