@@ -565,9 +565,7 @@ class _MLPTrain(torch.autograd.Function):
             # rows padded with zero columns to a multiple of 8 floats: the register-direct kernels
             # then take the layer (a [E, 4] or [E, 4 + C] centre tensor of the up path; the LDS-staged
             # forward kernel these widths used to fall to ran at 4 % of the MFMA rate)
-            xp = x.new_zeros((E, (cin0 + 7) & ~7))
-            xp[:, :cin0] = x
-            x = xp
+            x = torch.nn.functional.pad(x, (0, -cin0 % 8))        # (one launch)
         with torch.cuda.device(x.device):
             st = _chain_forward(lib, x, params, bns, eps, 0,
                                 cin0 if ctx.needs_input_grad[0] else 0,

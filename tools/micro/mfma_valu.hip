@@ -79,7 +79,6 @@ int main()
     run<4, 2>(2); run<8, 2>(2);
     run<4, 3>(2); run<8, 3>(2);
     run<2, 4>(2); run<4, 4>(2);
-    run<4, 5>(2); run<8, 5>(2); run<16, 5>(2);
     run<4, 6>(2); run<8, 6>(2);
     run<4, 7>(2); run<8, 7>(2);
     return 0;
