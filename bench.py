@@ -97,7 +97,7 @@ y = torch.zeros_like(x)
 dist.all_reduce(y)                                   # communicator set up outside the capture
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
     y.copy_(x)
     dist.all_reduce(y)
     y.div_(world)

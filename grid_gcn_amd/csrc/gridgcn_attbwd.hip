@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
             cst[c] = sc;
             cst[C + c] = p.shift[c];
             cst[2 * C + c] = p.mean[c];
-            cst[3 * C + c] = -(sc * p.rstd[c]) * p.m2[c];
-            cst[4 * C + c] = -(sc * p.m1[c]);
+            cst[3 * C + c] = -(sc * p.rstd[c]) * gg_bn_m2(p, c);
+            cst[4 * C + c] = -(sc * gg_bn_m1(p, c));
         }
     }
     __syncthreads();
@@ -337,9 +337,14 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
 // ch = 32j + (l & 31), i = (r & 3) + 8(r >> 2) + 4(l >> 5).  One 1024-thread workgroup per (j, r):
 // 16 groups of 64 lanes each sum a slice of the waves, LDS adds the groups (deterministic order).
 __global__ __launch_bounds__(1024) void gg_k_att_dw_reduce(const float *__restrict__ part, int nwaves,
-                                                           int NJ, int cin, float *__restrict__ dW)
+                                                           int NJ, int cin, float *__restrict__ dW,
+                                                           const double *__restrict__ bsums, long long E,
+                                                           float *__restrict__ fm1, float *__restrict__ fm2,
+                                                           float *__restrict__ fdg, float *__restrict__ fdb)
 {
     __shared__ float sh[16][64];
+    if (bsums && blockIdx.x == 0)       // (GGLinBwd.bsums: the BatchNorm-backward vectors of the layer)
+        for (int c = threadIdx.x; c < NJ * 32; c += blockDim.x) gg_bn_bwd_fin_write(bsums, E, NJ * 32, c, fm1, fm2, fdg, fdb);
     const int j = blockIdx.x >> 4, r = blockIdx.x & 15;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     float v = 0.f;
@@ -391,7 +396,8 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
     if (gg_get_mlp_bf16()) gg_k_att_bwd_fused<NJ, true><<<grid, 256, lds, st>>>(p);
     else gg_k_att_bwd_fused<NJ, false><<<grid, 256, lds, st>>>(p);
     if (hipGetLastError() != hipSuccess) return 3;
-    gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.cin, p.dW);
+    gg_k_att_dw_reduce<<<NJ * 16, 1024, 0, st>>>(p.dWpart, grid, NJ, p.cin, p.dW, p.bsums, p.E, p.fin_m1,
+                                                 p.fin_m2, p.fin_dgamma, p.fin_dbeta);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

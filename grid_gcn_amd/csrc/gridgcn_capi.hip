@@ -410,7 +410,8 @@ int gridgcn_linear_bwd(const float *dY, const float *Z, const float *scale, cons
                                  amax, gval, P, workspace, workspace_bytes, stream);
 }
 
-int gridgcn_linear_bwd_ld(const float *dY, const void *Z_, const float *scale, const float *shift,
+static int linear_bwd_common(const double *bsums, float *dgamma, float *dbeta, float *m1w, float *m2w,
+                             const float *dY, const void *Z_, const float *scale, const float *shift,
                           const float *mean, const float *rstd, const float *m1, const float *m2,
                           const float *Aprev, const float *pscale, const float *pshift,
                           const float *pmean, const float *prstd, const float *Wb, const float *Wg,
@@ -427,8 +428,8 @@ int gridgcn_linear_bwd_ld(const float *dY, const void *Z_, const float *scale, c
     if (Wdx && (ndx < 1 || ndx > cin)) return GRIDGCN_EINVAL;
     if (cin_w < 1 || cin_w > cin || rot < 0 || rot > cin_w) return GRIDGCN_EINVAL;
     if (!dY && amax) dY = Z;     // unused in sparse mode
-    if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Aprev || !Wb || !dW)
-        return GRIDGCN_EINVAL;
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !Aprev || !Wb || !dW) return GRIDGCN_EINVAL;
+    if (bsums ? (!m1w || !m2w || !dgamma || !dbeta) : (!m1 || !m2)) return GRIDGCN_EINVAL;
     if (pscale && (!pshift || !pmean || !prstd || (dX && !psums))) return GRIDGCN_EINVAL;
     size_t need = 0;
     gg_linear_bwd_workspace(E, cin, C, &need, nullptr);
@@ -446,8 +447,43 @@ int gridgcn_linear_bwd_ld(const float *dY, const void *Z_, const float *scale, c
     p.ldz = ldz;
     p.nbn = nbn;
     p.zfmt = zfmt;
+    p.bsums = bsums; p.fin_m1 = m1w; p.fin_m2 = m2w; p.fin_dgamma = dgamma; p.fin_dbeta = dbeta;
     int rc = gg_linear_bwd(p, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_linear_bwd_ld(const float *dY, const void *Z_, const float *scale, const float *shift,
+                          const float *mean, const float *rstd, const float *m1, const float *m2,
+                          const float *Aprev, const float *pscale, const float *pshift,
+                          const float *pmean, const float *prstd, const float *Wb, const float *Wg,
+                          const float *Wdx, int ndx, long long E,
+                          int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, int zfmt,
+                          float *dX, float *dW, double *psums,
+                          const uint8_t *amax, const float *gval, int P, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    return linear_bwd_common(nullptr, nullptr, nullptr, nullptr, nullptr, dY, Z_, scale, shift, mean, rstd, m1,
+                             m2, Aprev, pscale, pshift, pmean, prstd, Wb, Wg, Wdx, ndx, E, C, cin, cin_w, rot,
+                             ldy, ldz, nbn, zfmt, dX, dW, psums, amax, gval, P, workspace, workspace_bytes,
+                             stream);
+}
+
+int gridgcn_linear_bwd_fin(const float *dY, const void *Z_, const float *scale, const float *shift,
+                           const float *mean, const float *rstd, const double *sums, float *m1, float *m2,
+                           float *dgamma, float *dbeta,
+                           const float *Aprev, const float *pscale, const float *pshift,
+                           const float *pmean, const float *prstd, const float *Wb, const float *Wg,
+                           const float *Wdx, int ndx, long long E,
+                           int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, int zfmt,
+                           float *dX, float *dW, double *psums,
+                           const uint8_t *amax, const float *gval, int P, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    if (!sums) return GRIDGCN_EINVAL;
+    return linear_bwd_common(sums, dgamma, dbeta, m1, m2, dY, Z_, scale, shift, mean, rstd, nullptr, nullptr,
+                             Aprev, pscale, pshift, pmean, prstd, Wb, Wg, Wdx, ndx, E, C, cin, cin_w, rot,
+                             ldy, ldz, nbn, zfmt, dX, dW, psums, amax, gval, P, workspace, workspace_bytes,
+                             stream);
 }
 
 int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const float *shift,

@@ -475,8 +475,8 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             cst[c] = sc;
             cst[C + c] = p.shift[c];
             cst[2 * C + c] = p.mean[c];
-            cst[3 * C + c] = -(sc * p.rstd[c]) * p.m2[c];
-            cst[4 * C + c] = -(sc * p.m1[c]);
+            cst[3 * C + c] = -(sc * p.rstd[c]) * gg_bn_m2(p, c);
+            cst[4 * C + c] = -(sc * gg_bn_m1(p, c));
         }
         // (kept in LDS, not in 4*NT registers per lane: the 8-tile form spilled 70 of them)
         const bool pb = p.pscale != nullptr;
@@ -919,8 +919,8 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
         const bool ok = c < C;
         const float s = ok ? p.scale[c] : 0.f;
         sc[i] = s; sh[i] = ok ? p.shift[c] : 0.f; mu[i] = ok ? p.mean[c] : 0.f;
-        bz[i] = ok ? -(s * p.rstd[c]) * p.m2[c] : 0.f;
-        cz[i] = ok ? -(s * p.m1[c]) : 0.f;
+        bz[i] = ok ? -(s * p.rstd[c]) * gg_bn_m2(p, c) : 0.f;
+        cz[i] = ok ? -(s * gg_bn_m1(p, c)) : 0.f;
     }
     const bool chok = chA + MT - 1 < C;               // C % MT == 0: all or none of the MT channels
     const int chl = chok ? chA : 0;
@@ -1246,9 +1246,14 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
 #define GG_DWR_SL 4
 __global__ __launch_bounds__(64 * GG_DWR_SL) void gg_k_dw_reduce_direct(
     const float *__restrict__ part, int nwaves, int MG, int MT, int NQ, int NP, int NS, int C, int cin,
-    int cin_w, int rot, float *__restrict__ part2, int *__restrict__ tick, float *__restrict__ dW)
+    int cin_w, int rot, float *__restrict__ part2, int *__restrict__ tick, float *__restrict__ dW,
+    const double *__restrict__ bsums, long long E, float *__restrict__ fm1, float *__restrict__ fm2,
+    float *__restrict__ fdg, float *__restrict__ fdb)
 {
     __shared__ float sh[64 * GG_DWR_SL];
+    // (BatchNorm-backward vectors of the layer, when no launch of their own wrote them: GGLinBwd.bsums)
+    if (bsums && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) gg_bn_bwd_fin_write(bsums, E, C, c, fm1, fm2, fdg, fdb);
     __shared__ int s_last;
     const int NJ = 4 * NQ + 2 * NP + NS;
     const int per = MT * NJ * 1024;
@@ -1433,6 +1438,7 @@ int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st)
     float *part2 = p.dWpart + r.part_floats;
     int *tick = (int *)(part2 + r.part2_floats);
     gg_k_dw_reduce_direct<<<dim3(r.gx, c.MG, r.S), 64 * GG_DWR_SL, 0, st>>>(
-        p.dWpart, nwaves, c.MG, c.MT, c.NQ, c.NP, c.NS, p.C, p.cin, p.cin_w, p.rot, part2, tick, p.dW);
+        p.dWpart, nwaves, c.MG, c.MT, c.NQ, c.NP, c.NS, p.C, p.cin, p.cin_w, p.rot, part2, tick, p.dW,
+        p.bsums, p.E, p.fin_m1, p.fin_m2, p.fin_dgamma, p.fin_dbeta);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

@@ -63,6 +63,12 @@ struct GGLinBwd {
     int zfmt = 0;         // 0: Z is fp32; 1: Z is bf16 (gg_k_att_bwd_fused only)
     int nbn = 0;          // leading input columns that carry the previous layer's BatchNorm (0: all
                           // cin); beyond them the dX epilogue neither reads Aprev nor sums
+    // BatchNorm-backward finalisation without a launch of its own: bsums = (s1, s2) [2][C] fp64 as
+    // gridgcn_bn_relu_bwd_reduce / a dX epilogue left them.  The register-direct kernels form m1 = s1/E,
+    // m2 = s2/E themselves (gg_bn_m1 / gg_bn_m2) and their dW reduce kernel writes dgamma = s2,
+    // dbeta = s1 (and m1, m2); a legacy kernel on the path gets them from gg_k_bn_bwd_finalize first.
+    const double *bsums = nullptr;
+    float *fin_m1 = nullptr, *fin_m2 = nullptr, *fin_dgamma = nullptr, *fin_dbeta = nullptr;
     int dx_col0 = 0;      // register-direct dX: first output column of this launch (0 / 128) and
     int dx_wstride = 1;   //   float4 stride while staging Wdx (2: one half of an 8-tile layout)
     int rt;               // rows per workgroup tile of gg_k_linear_dw (32/64/96/128)
@@ -70,6 +76,29 @@ struct GGLinBwd {
     unsigned t2[4][3];    // per wave: up to 12 GEMM2 (m,n) pair ids, one byte each, 0xff = none
 };
 
+#ifdef __HIPCC__
+__device__ __forceinline__ float gg_bn_m1(const GGLinBwd &p, int c)
+{
+    return p.bsums ? (float)(p.bsums[c] / (double)p.E) : p.m1[c];
+}
+__device__ __forceinline__ float gg_bn_m2(const GGLinBwd &p, int c)
+{
+    return p.bsums ? (float)(p.bsums[p.C + c] / (double)p.E) : p.m2[c];
+}
+// tail of a dW reduce kernel (one thread per channel): the vectors gg_k_bn_bwd_finalize would write
+__device__ __forceinline__ void gg_bn_bwd_fin_write(const double *bsums, long long E, int C, int c, float *m1,
+                                                    float *m2, float *dgamma, float *dbeta)
+{
+    const double s1 = bsums[c], s2 = bsums[C + c];
+    m1[c] = (float)(s1 / (double)E);
+    m2[c] = (float)(s2 / (double)E);
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+}
+#endif
+
+int gg_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2, float *dgamma,
+                       float *dbeta, hipStream_t st);       // gridgcn_pairmax.hip
 int gg_linear_fwd(const GGLinFwd &p, hipStream_t st);
 int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st);   // gridgcn_direct.hip
 int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st);    // 1 = shape not supported

@@ -964,9 +964,18 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     }
     // a strided dense dY / a strided Z is only understood by the register-direct kernels
     if (p.dX && !p.amax && p.ldy != p.C) return 1;
+    // from here on a kernel that reads the m1 / m2 ARRAYS may run: GGLinBwd.bsums -> the vectors first
+    auto finalize_now = [&]() -> int {
+        if (!p.bsums) return 0;
+        const int rc = gg_bn_bwd_finalize(p.bsums, p.E, p.C, p.fin_m1, p.fin_m2, p.fin_dgamma, p.fin_dbeta, st);
+        p.m1 = p.fin_m1; p.m2 = p.fin_m2;
+        p.bsums = nullptr;
+        return rc;
+    };
     if (p.dX && p.ldz && p.ldz != p.C) return 1;
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
     if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0) {
+        if (finalize_now()) return 3;
         static bool attr_dx = false;
         if (!attr_dx) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_dx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -992,6 +1001,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     }
     if (!p.amax && p.ldy != p.C) return 1;
     if (p.ldz && p.ldz != p.C) return 1;
+    if (finalize_now()) return 3;
     const int npairs = ntm * ntn2;
     if (npairs > 48) return 1;
     // ---- balance GEMM1 column tiles (cost C4/2 MFMAs) and GEMM2 pairs (16 MFMAs) over 4 waves ----

@@ -77,7 +77,11 @@ class GraphedTrainStep:
         self.g1 = torch.cuda.CUDAGraph()
         # scratch carved out of a shared zero chunk must not cross a capture boundary
         train_ops.reset_zero_arena()
-        with torch.cuda.graph(self.g1):
+        # capture_error_mode "thread_local": the RCCL watchdog thread polls its events with
+        # hipEventQuery while this thread captures; under the default "global" mode such a call from
+        # ANY thread invalidates the capture ("operation not permitted when stream is capturing": seen
+        # in about one of three single-rank runs, whenever a poll fell inside the ~1 s capture)
+        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
             if os.environ.get("GG_TEST_CAPTURE_FAIL") == "1":
                 torch.cuda.synchronize(dev)        # test hook: an illegal call invalidates the capture
             self.loss = fwd_bwd()

@@ -381,11 +381,10 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     po, bo = 0, 0
     for l in range(L - 1, -1, -1):
         Z, C, cin = Zs[l], Cs[l], cins[l]
+        # m1, m2, dgamma, dbeta: written by the layer's own backward kernels from `sums`
+        # (gridgcn_linear_bwd_fin: no finalisation launch)
         v = torch.empty((4, C), dtype=torch.float32, device=dev)
         m1, m2 = v[0], v[1]
-        rc = lib.gridgcn_bn_bwd_finalize(_ptr(sums), E, C, _ptr(m1), _ptr(m2), _ptr(v[2]),
-                                         _ptr(v[3]), _stream(x))
-        _lib.check(rc, "gridgcn_bn_bwd_finalize")
         grads[4 * l + 2] = v[2]                             # d gamma
         grads[4 * l + 3] = v[3]                             # d beta
         # the conv bias feeds a BatchNorm: its gradient is sum(dZ) == 0 analytically
@@ -418,9 +417,10 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         else:
             sp = (None, None, 0)
             dyp = _ptr(dY)
-        rc = lib.gridgcn_linear_bwd_ld(
+        rc = lib.gridgcn_linear_bwd_fin(
             dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
-            _ptr(m1), _ptr(m2), _ptr(prev), pbn[0], pbn[1], pbn[2], pbn[3],
+            _ptr(sums), _ptr(m1), _ptr(m2), _ptr(v[2]), _ptr(v[3]),
+            _ptr(prev), pbn[0], pbn[1], pbn[2], pbn[3],
             _ptr(Wb), _ptr(Wg) if Wg is not None else None,
             _ptr(Wdxs[l]) if (want_dx and ndxs[l]) else None, ndxs[l], E, C, cin, cw, rt,
             dY.stride(0) if (sparse is None and dY is not None) else 0,

@@ -457,6 +457,21 @@ int gridgcn_linear_bwd_ld(const float *dY, const void *Z, const float *scale, co
                           float *dX, float *dW, double *psums,
                           const uint8_t *amax, const float *gval, int P, void *workspace,
                           size_t workspace_bytes, void *stream);
+/* gridgcn_linear_bwd_fin = gridgcn_bn_bwd_finalize + gridgcn_linear_bwd_ld without the finalisation
+ *   launch: `sums` [2][C] fp64 (s1, s2) as gridgcn_bn_relu_bwd_reduce or a dX epilogue (psums) left
+ *   them.  The register-direct kernels divide by E themselves; m1, m2, dgamma, dbeta [C] are OUTPUTS
+ *   (written by the dW reduce kernel, or by gridgcn_bn_bwd_finalize's kernel when a legacy kernel
+ *   is on the path). */
+int gridgcn_linear_bwd_fin(const float *dY, const void *Z, const float *scale, const float *shift,
+                           const float *mean, const float *rstd, const double *sums, float *m1, float *m2,
+                           float *dgamma, float *dbeta,
+                           const float *Aprev, const float *pscale, const float *pshift,
+                           const float *pmean, const float *prstd, const float *Wb, const float *Wg,
+                           const float *Wdx, int ndx, long long E,
+                           int C, int cin, int cin_w, int rot, int ldy, int ldz, int nbn, int zfmt,
+                           float *dX, float *dW, double *psums,
+                           const uint8_t *amax, const float *gval, int P, void *workspace,
+                           size_t workspace_bytes, void *stream);
 /* (cin = row length of Aprev / dX as the kernels see it; dW is written in the FRAMEWORK layout
  *  [C][cin_w]: zero-padding columns dropped and the `rot` columns moved back in front, the inverse
  *  of gridgcn_pack_linear's mapping.  cin_w = cin, rot = 0 for an ordinary layer.) */
