@@ -16,12 +16,14 @@
 //     counters move) when H_add > H_rmv, evaluated as  lambda*(n0 - n1) > beta * sum C_V  with
 //     integer sums (one fp32 multiply, one compare: the same result on every machine).
 //
-// The sweep is inherently sequential (each replacement changes the counters the next challenger
+// The sweep is sequential by definition (each replacement changes the counters the next challenger
 // reads), so one workgroup owns a cloud: its 1024 threads build the tables in parallel -- first
 // point per voxel, occupancy + coverage counters (16 bits per voxel, in LDS whenever the grid fits:
-// 40^3 voxels = 128 KB of the CU's 160 KB), incumbent slots, the compacted challenger list -- then
-// wave 0 walks the challengers 64 at a time (ids, voxels and random slots of a batch are loaded /
-// drawn lane-parallel) and evaluates each one with a lane per window voxel: LDS latency only.
+// 40^3 voxels = 128 KB of the CU's 160 KB), incumbent slots, the compacted challenger list with the
+// drawn incumbent slot of every challenger -- and then walk the challengers in batches of 64: all 16
+// waves evaluate the batch speculatively (a lane per window voxel: LDS latency only), wave 0 commits
+// the verdicts in order and re-evaluates the few whose inputs an earlier replacement of the same
+// batch has touched (see "the sweep" below): same verdicts as the one-by-one walk, ~10x its speed.
 #include "gridgcn_index.h"
 
 #define GG_CAS_NT 1024
@@ -33,7 +35,7 @@ struct GGCasArgs {
     const int *centnum;     // [B]
     int *first;             // [B][G]
     unsigned *bm;           // [B][2][W]  leader bitmap, incumbent bitmap
-    int *chal;              // [B][2][N]  challenger first point, challenger voxel
+    int *chal;              // [B][3][N]  challenger first point, challenger voxel, drawn incumbent slot
     unsigned short *cov_g;  // [B][Gp]  (Gp = G rounded up to 2) when the counters do not fit LDS
     int *slot_g;            // [B][2][O] when the slot arrays do not fit LDS
     int N, W, Gp;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     const float4 *cloud = a.data + (size_t)b * N;
     int *first = a.first + (size_t)b * G;
     unsigned *lbm = a.bm + (size_t)b * 2 * W, *pbm = lbm + W;
-    int *chal_id = a.chal + (size_t)b * 2 * N, *chal_vox = chal_id + N;
+    int *chal_id = a.chal + (size_t)b * 3 * N, *chal_vox = chal_id + N;
     unsigned short *cov = a.cov_lds >= 0 ? (unsigned short *)(lds_cas + a.cov_lds)
                                          : a.cov_g + (size_t)b * a.Gp;
     int *slotvox = a.slot_lds >= 0 ? (int *)(lds_cas + a.slot_lds) : a.slot_g + (size_t)b * 2 * O;
@@ -141,9 +143,22 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     for (int j = tid; j < nchal; j += GG_CAS_NT) chal_vox[j] = gg_cas_voxel(cloud, chal_id[j], gp);
     __syncthreads();
 
-    // ---- the sweep (wave 0) ----
-    if (wave == 0) {
-        const unsigned long long seed3 = 3ull * gg_seed(gp);
+    // ---- the sweep: batches of 64 challengers, evaluated speculatively by all 16 waves ----
+    // The sweep is sequential by definition (an accepted challenger changes the counters the next one
+    // reads), but only ~7 % are accepted and a replacement touches two k^3 windows of a 40^3 .. 64^3 grid.
+    // Phase A: every wave evaluates four challengers of the batch against the state at the START of
+    // the batch.  Phase B: wave 0 walks the batch in order; a challenger whose read set -- the windows
+    // of its voxel and of its incumbent, its slot -- was not touched by a replacement accepted earlier
+    // in the batch keeps its speculative verdict (same inputs, same arithmetic: bit-identical to the
+    // sequential sweep), any other one is evaluated again on the spot.  Window overlap is tested on
+    // the centres: |d|_inf <= k - 1 (clipping at the grid border only shrinks windows).
+    const unsigned long long seed3 = 3ull * gg_seed(gp);
+    for (int j = tid; j < nchal; j += GG_CAS_NT)
+        a.chal[(size_t)b * 3 * N + 2 * N + j] =
+            gg_reservoir_pick((unsigned long long)((long long)b * N + chal_id[j]) + seed3, M);
+    __shared__ int sb_vx[64], sb_xyz[64], sb_sl[64], sb_id[64], sb_dec[64], sb_vixyz[64];
+    const int *chal_sl = a.chal + (size_t)b * 3 * N + 2 * N;
+    {
         // window offsets of this lane (nei = lane + 64*i), decoded once
         const int kk = gp.k, rr = (kk - 1) / 2;
         constexpr int NI = (GG_K3MAX + 63) / 64;
@@ -162,62 +177,137 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
                             w >= 0 && w < gp.g[0];
             return in ? d * gp.gxy + h * gp.g[0] + w : -1;
         };
+        // H_add > H_rmv for challenger voxel (a0,a1,a2) against incumbent voxel (i0,i1,i2): wave-wide
+        auto accept = [&](int a0, int a1, int a2, int i0, int i1, int i2) -> bool {
+            int n0 = 0, n1 = 0, sc = 0;
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                if (i >= ni) break;
+                const int uc = nbv(a0, a1, a2, i), ui = nbv(i0, i1, i2, i);
+                const unsigned ec = uc >= 0 ? cov[uc] : 0u;
+                const unsigned ei = ui >= 0 ? cov[ui] : 0u;
+                n0 += __popcll(__ballot(ec == 0x8000u));
+                n1 += __popcll(__ballot(ei == 0x8001u));
+                sc += (ec & 0x8000u) ? (int)(ec & 0x7fffu) : 0;
+            }
+            sc = gg_wave_sum(sc);
+            return (float)(k3 * (n0 - n1)) > __fmul_rn(a.beta, (float)sc);
+        };
+        auto xyz_of = [&](int v) -> int {
+            const int z = v / gp.gxy, y = (v - z * gp.gxy) / gp.g[0];
+            return (v - z * gp.gxy - y * gp.g[0]) | (y << 10) | (z << 20);
+        };
+        auto near = [&](int p, int q_) -> bool {      // windows of centres p and q_ may overlap
+            const int dx = (p & 1023) - (q_ & 1023), dy = ((p >> 10) & 1023) - ((q_ >> 10) & 1023),
+                      dz = (p >> 20) - (q_ >> 20);
+            const int m = kk - 1;
+            return dx <= m && dx >= -m && dy <= m && dy >= -m && dz <= m && dz >= -m;
+        };
         for (int j0 = 0; j0 < nchal; j0 += 64) {
-            const int j = j0 + lane;
-            int cid = 0, cvx = 0, csl = 0;
-            if (j < nchal) {
-                cid = chal_id[j];
-                cvx = chal_vox[j];
-                const long long gi = (long long)b * N + cid;
-                csl = gg_reservoir_pick((unsigned long long)gi + seed3, M);
-            }
-            // coordinates of the batch's challenger voxels, decoded lane-parallel
-            const int cz = cvx / gp.gxy, cy = (cvx - cz * gp.gxy) / gp.g[0];
-            const int cxyz = (cvx - cz * gp.gxy - cy * gp.g[0]) | (cy << 10) | (cz << 20);
             const int nb = nchal - j0 < 64 ? nchal - j0 : 64;
-            for (int q = 0; q < nb; q++) {
-                const int vc = __builtin_amdgcn_readlane(cvx, q);
-                const int pc = __builtin_amdgcn_readlane(cxyz, q);
-                const int s = __builtin_amdgcn_readlane(csl, q);
-                const int vi = slotvox[s];
-                const int a0 = pc & 1023, a1 = (pc >> 10) & 1023, a2 = pc >> 20;
-                const int i2 = vi / gp.gxy, i1 = (vi - i2 * gp.gxy) / gp.g[0], i0 = vi - i2 * gp.gxy - i1 * gp.g[0];
-                int n0 = 0, n1 = 0, sc = 0;
+            if (tid < nb) {
+                const int vx = chal_vox[j0 + tid];
+                sb_id[tid] = chal_id[j0 + tid];
+                sb_vx[tid] = vx;
+                sb_xyz[tid] = xyz_of(vx);
+                sb_sl[tid] = chal_sl[j0 + tid];
+            }
+            __syncthreads();
+            // ---- phase A: speculative verdicts, four challengers per wave with their LDS reads in
+            // flight together (one evaluation is a chain of dependent LDS latencies) ----
+            {
+                constexpr int U = 4;
+                const int q0 = wave * U;
+                if (q0 < nb) {
+                    int pcs[U], pis[U], n0[U], n1[U], sc[U];
 #pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    if (i >= ni) break;
-                    const int uc = nbv(a0, a1, a2, i), ui = nbv(i0, i1, i2, i);
-                    const unsigned ec = uc >= 0 ? cov[uc] : 0u;
-                    const unsigned ei = ui >= 0 ? cov[ui] : 0u;
-                    n0 += __popcll(__ballot(ec == 0x8000u));
-                    n1 += __popcll(__ballot(ei == 0x8001u));
-                    sc += (ec & 0x8000u) ? (int)(ec & 0x7fffu) : 0;
-                }
-                sc = gg_wave_sum(sc);
-                if ((float)(k3 * (n0 - n1)) > __fmul_rn(a.beta, (float)sc)) {
-                    // (the two windows may overlap, and the next challenger reads what is written
-                    // here through other lanes: fences keep the wave's accesses in program order)
-#pragma unroll
-                    for (int i = 0; i < NI; i++) {
-                        if (i >= ni) break;
-                        const int ui = nbv(i0, i1, i2, i);
-                        if (ui >= 0 && (cov[ui] & 0x8000)) cov[ui] -= 1;
+                    for (int c = 0; c < U; c++) {
+                        const int q = q0 + c < nb ? q0 + c : nb - 1;
+                        pcs[c] = sb_xyz[q];
+                        pis[c] = xyz_of(slotvox[sb_sl[q]]);
+                        n0[c] = 0; n1[c] = 0; sc[c] = 0;
                     }
-                    __threadfence_block();
 #pragma unroll
                     for (int i = 0; i < NI; i++) {
                         if (i >= ni) break;
-                        const int uc = nbv(a0, a1, a2, i);
-                        if (uc >= 0 && (cov[uc] & 0x8000)) cov[uc] += 1;
+                        unsigned ec[U], ei[U];
+#pragma unroll
+                        for (int c = 0; c < U; c++) {
+                            const int uc = nbv(pcs[c] & 1023, (pcs[c] >> 10) & 1023, pcs[c] >> 20, i);
+                            const int ui = nbv(pis[c] & 1023, (pis[c] >> 10) & 1023, pis[c] >> 20, i);
+                            ec[c] = uc >= 0 ? cov[uc] : 0u;
+                            ei[c] = ui >= 0 ? cov[ui] : 0u;
+                        }
+#pragma unroll
+                        for (int c = 0; c < U; c++) {
+                            n0[c] += __popcll(__ballot(ec[c] == 0x8000u));
+                            n1[c] += __popcll(__ballot(ei[c] == 0x8001u));
+                            sc[c] += (ec[c] & 0x8000u) ? (int)(ec[c] & 0x7fffu) : 0;
+                        }
                     }
-                    const int lead = __builtin_amdgcn_readlane(cid, q);
-                    if (lane == 0) {
-                        slotvox[s] = vc;
-                        slotlead[s] = lead;
+#pragma unroll
+                    for (int c = 0; c < U; c++) {
+                        const int t = gg_wave_sum(sc[c]);
+                        const bool acc = (float)(k3 * (n0[c] - n1[c])) > __fmul_rn(a.beta, (float)t);
+                        if (lane == 0 && q0 + c < nb) { sb_dec[q0 + c] = acc ? 1 : 0; sb_vixyz[q0 + c] = pis[c]; }
                     }
-                    __threadfence_block();
                 }
             }
+            __syncthreads();
+            // ---- phase B: wave 0 commits in order.  Lane l holds challenger l of the batch; only the
+            // challengers that were accepted speculatively or whose inputs an accepted one has touched
+            // ("dirty") need a turn of their own -- a handful per batch ----
+            if (wave == 0) {
+                const bool valid = lane < nb;
+                const int l = valid ? lane : 0;
+                const int pc_l = sb_xyz[l], s_l = sb_sl[l], pi_l = sb_vixyz[l];
+                int dec_l = valid ? sb_dec[l] : 0, dirty_l = 0;
+                int from = 0;
+                while (true) {
+                    unsigned long long m = __ballot(dec_l | dirty_l);
+                    m = from < 64 ? (m >> from) << from : 0ull;
+                    if (!m) break;
+                    const int q = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+                    const int pc = __builtin_amdgcn_readlane(pc_l, q), s = __builtin_amdgcn_readlane(s_l, q);
+                    int pi = __builtin_amdgcn_readlane(pi_l, q);
+                    bool acc = __builtin_amdgcn_readlane(dec_l, q) != 0;
+                    if (__builtin_amdgcn_readlane(dirty_l, q)) {
+                        pi = xyz_of(slotvox[s]);
+                        acc = accept(pc & 1023, (pc >> 10) & 1023, pc >> 20, pi & 1023, (pi >> 10) & 1023, pi >> 20);
+                    }
+                    if (acc) {
+                        const int a0 = pc & 1023, a1 = (pc >> 10) & 1023, a2 = pc >> 20;
+                        const int i0 = pi & 1023, i1 = (pi >> 10) & 1023, i2 = pi >> 20;
+                        // (the two windows may overlap, and the next challenger reads what is written
+                        // here through other lanes: fences keep the wave's accesses in program order)
+#pragma unroll
+                        for (int i = 0; i < NI; i++) {
+                            if (i >= ni) break;
+                            const int ui = nbv(i0, i1, i2, i);
+                            if (ui >= 0 && (cov[ui] & 0x8000)) cov[ui] -= 1;
+                        }
+                        __threadfence_block();
+#pragma unroll
+                        for (int i = 0; i < NI; i++) {
+                            if (i >= ni) break;
+                            const int uc = nbv(a0, a1, a2, i);
+                            if (uc >= 0 && (cov[uc] & 0x8000)) cov[uc] += 1;
+                        }
+                        if (lane == 0) {
+                            slotvox[s] = sb_vx[q];
+                            slotlead[s] = sb_id[q];
+                        }
+                        __threadfence_block();
+                        // later challengers that read what was just written
+                        if (valid && lane > q &&
+                            (near(pc, pc_l) || near(pi, pc_l) || near(pc, pi_l) || near(pi, pi_l) || s_l == s))
+                            dirty_l = 1;
+                    }
+                    if (lane == q) { dec_l = 0; dirty_l = 0; }     // q is final
+                    from = q + 1;
+                }
+            }
+            __syncthreads();
         }
     }
     __syncthreads();
@@ -230,7 +320,7 @@ size_t gg_cas_workspace_bytes(int B, int N, const GGGrid &gp)
 {
     const size_t W = ((size_t)N + 31) / 32, Gp = ((size_t)gp.G + 1) & ~(size_t)1;
     return gg_cas_align((size_t)B * gp.G * 4) + gg_cas_align((size_t)B * 2 * W * 4) +
-           gg_cas_align((size_t)B * 2 * N * 4) + gg_cas_align((size_t)B * Gp * 2) +
+           gg_cas_align((size_t)B * 3 * N * 4) + gg_cas_align((size_t)B * Gp * 2) +
            gg_cas_align((size_t)B * 2 * gp.O * 4);
 }
 
@@ -249,12 +339,12 @@ int gg_cas_refine(const float *data, const int *np, int B, int N, const GGGrid &
     char *p = ws;
     a.first = (int *)p;            p += gg_cas_align((size_t)B * gp.G * 4);
     a.bm = (unsigned *)p;          p += gg_cas_align((size_t)B * 2 * W * 4);
-    a.chal = (int *)p;             p += gg_cas_align((size_t)B * 2 * N * 4);
+    a.chal = (int *)p;             p += gg_cas_align((size_t)B * 3 * N * 4);
     a.cov_g = (unsigned short *)p; p += gg_cas_align((size_t)B * Gp * 2);
     a.slot_g = (int *)p;
     a.N = N; a.W = (int)W; a.Gp = (int)Gp; a.beta = beta;
     // LDS placement: the slot arrays first (touched by every challenger), then the counters
-    const size_t budget = 156 * 1024;   // + the kernel's static LDS < 160 KB
+    const size_t budget = 153 * 1024;   // + the kernel's static LDS (batch tables: 2.6 KB) < 160 KB
     size_t used = 0;
     a.slot_lds = -1; a.cov_lds = -1;
     if ((size_t)2 * gp.O * 4 <= budget) { a.slot_lds = 0; used = (size_t)2 * gp.O * 4; }
