@@ -203,8 +203,12 @@ def test_training_step_edge_kernel_matches_torch_ops():
         grads.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
     assert abs(grads[0][0] - grads[1][0]) < 1e-4
     scale = float(grads[1][1].abs().max())
-    assert float((grads[0][1] - grads[1][1]).abs().max()) < 1e-2 * scale
-    rel = float((grads[0][1] - grads[1][1]).norm() / grads[1][1].norm())
+    diff = (grads[0][1] - grads[1][1]).abs()
+    assert float(diff.max()) < 1e-2 * scale
+    # ... and the tight bar for everything but the few entries a flipped near-tie moves: a routing
+    # error in a backward kernel shifts whole tensors, not one entry in a thousand
+    assert float((diff > 2e-3 * scale).float().mean()) < 1e-3
+    rel = float(diff.norm() / grads[1][1].norm())
     assert rel < 1e-2, rel
 
 
