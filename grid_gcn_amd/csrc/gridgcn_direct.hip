@@ -568,89 +568,58 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             }
         }
         } else {
-            // One quad (4 channels per lane = 4 MFMA steps x NT tiles) at a time, the NEXT quad's
-            // loads issued before this quad's MFMAs: the chunk form (all 16 channels loaded, then
-            // 16 steps) needed 48 registers for the loaded values, and at NT = 8 the compiler fell
-            // back to load -> s_waitcnt vmcnt(0) -> 32 MFMAs per quad, i.e. a full memory round
-            // trip in front of every 2048 MFMA cycles.  The arg-max mask is applied at use, not at
-            // load (a select right behind the load is a wait).
-            const int nquad = sparse ? nfull * 4 : 0;
-            if (!sparse) {
-                // dense upstream gradient: nothing conditional to load, and the chunk form (a row's
-                // 64-byte piece fetched by four back-to-back loads) measured 4 % faster than the quad
-                // pipeline here (591 -> 569 us on 655 360 x 128 -> 256)
-                // 2-4 column tiles: registers for the NEXT chunk's eight float4 as well (requested
-                // before this chunk's 16 * NT MFMAs)
-                constexpr bool DB = NT >= 2 && NT <= 4;
-                float4 z[4], g[4], zn[4], gn[4];
-                if (DB && nfull > 0) {
+            // Two register sets of QS quads (a quad = 4 channels per lane = 4 MFMA steps x NT tiles),
+            // dense and sparse upstream gradient alike: the loads of set u + 1 are issued, THEN set u is
+            // turned into dZ and consumed.  The scheduling barriers matter as much as the second set:
+            // left alone, the compiler sinks the "early" loads down to their first use (or, with a
+            // copy zc = zn at the end of the body, waits for them there) -- every version of this
+            // loop before round 3 ran load burst -> s_waitcnt vmcnt(0) -> MFMAs, i.e. HBM time plus
+            // MFMA time.  The arg-max bytes are loaded unconditionally (dense: harmless bytes of Z) and
+            // applied by the same select as the ReLU mask.
+            constexpr int QS = NT == 1 ? 2 : (NT <= 4 ? 4 : (NT <= 6 ? 2 : 1));   // (registers: 16 NT accumulators + two sets)
+            struct Set { float4 z[QS], g[QS]; unsigned am[QS]; };
+            auto ldset = [&](Set &S, int u) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        z[q] = *(const float4 *)(zr + h * 16 + 4 * q);
-                        g[q] = *(const float4 *)(gr + h * 16 + 4 * q);
+                for (int j = 0; j < QS; j++) {
+                    const int qi = u * QS + j;
+                    const int k = (qi >> 2) * 32 + h * 16 + (qi & 3) * 4;
+                    S.z[j] = *(const float4 *)(zr + k);
+                    S.g[j] = *(const float4 *)(gr + k);
+                    S.am[j] = *(const unsigned *)(ar + k);
+                }
+            };
+            auto mmset = [&](const Set &S, int u) {
+#pragma unroll
+                for (int j = 0; j < QS; j++) {
+                    const int qi = u * QS + j;
+                    const int k0 = (qi >> 2) * 32 + h * 16 + (qi & 3) * 4;
+                    const float4 a = dz4m(S.z[j], S.g[j], S.am[j], pp, k0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        float b[NTV];
+                        gg_ldb<NTV>(Wl, (qi * 4 + i) * 64 + lane, b);
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
                     }
                 }
-                for (int c = 0; c < nfull; c++) {
-                    const int k0 = c * 32 + h * 16;
-                    float4 a[4];
-                    if constexpr (DB) {
-                        const int kn = (c + 1 < nfull ? c + 1 : c) * 32 + h * 16;   // (last: a harmless re-read)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            zn[q] = *(const float4 *)(zr + kn + 4 * q);
-                            gn[q] = *(const float4 *)(gr + kn + 4 * q);
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            z[q] = *(const float4 *)(zr + k0 + 4 * q);
-                            g[q] = *(const float4 *)(gr + k0 + 4 * q);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) a[q] = dz4(z[q], g[q], k0 + 4 * q);
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            float b[NTV];
-                            gg_ldb<NTV>(Wl, s * 64 + lane, b);
-#pragma unroll
-                            for (int t = 0; t < NT; t++)
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
-                            s++;
-                        }
-                    if constexpr (DB) {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) { z[q] = zn[q]; g[q] = gn[q]; }
-                    }
+            };
+            const int nset = nfull * 4 / QS;
+            Set SA, SB;
+            if (nset > 0) ldset(SA, 0);
+            for (int u = 0; u < nset; u += 2) {
+                ldset(SB, u + 1 < nset ? u + 1 : u);           // (last: a harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                mmset(SA, u);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < nset) {
+                    ldset(SA, u + 2 < nset ? u + 2 : u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mmset(SB, u + 1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            float4 zc = make_float4(0.f, 0.f, 0.f, 0.f), gc = zc;
-            unsigned amc = 0;
-            if (nquad > 0) {
-                zc = *(const float4 *)(zr + h * 16);
-                gc = *(const float4 *)(gr + h * 16);
-                amc = *(const unsigned *)(ar + h * 16);
-            }
-            for (int qi = 0; qi < nquad; qi++) {
-                const int qn = qi + 1 < nquad ? qi + 1 : qi;      // (last quad: a harmless re-read)
-                const int kn = (qn >> 2) * 32 + h * 16 + (qn & 3) * 4;
-                const float4 zn = *(const float4 *)(zr + kn), gn = *(const float4 *)(gr + kn);
-                const unsigned amn = *(const unsigned *)(ar + kn);
-                const int k0 = (qi >> 2) * 32 + h * 16 + (qi & 3) * 4;
-                const float4 a = dz4m(zc, gc, amc, pp, k0);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    float b[NTV];
-                    gg_ldb<NTV>(Wl, (qi * 4 + i) * 64 + lane, b);
-#pragma unroll
-                    for (int t = 0; t < NT; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a, i), b[t], acc[t], 0, 0, 0);
-                }
-                zc = zn; gc = gn; amc = amn;
-            }
-            if (sparse) s = nquad * 4;
+            s = nfull * 16;
         }
         if (ktail) {
             const int nq = ktail >> 3;
@@ -882,7 +851,7 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 // m-groups of a workgroup walk the SAME rows (the B rows hit L1/L2), RS row streams fill the rest.
 // No LDS, no barriers; two register sets keep the next step's loads in flight.  Partials go to the
 // workspace as [wave][tile][reg][lane]; gg_k_dw_reduce_direct sums them into the framework layout.
-#define GG_DW_D16 8      // register sets of the 16-tile form (one wave per SIMD: depth instead of partners)
+#define GG_DW_D16 6      // register sets of the 16-tile form (one wave per SIMD: depth instead of partners)
 template <int MT, int NQ, int NP, int NS, bool BF16 = false, bool SP = false>
 __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) void gg_k_linear_dw_direct(
     GGLinBwd p, int MG, int RS, long long rows_per_wg, int *__restrict__ tick, int ntick, int lds_red)
@@ -1177,11 +1146,17 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
         // centres): its offset is a vector register advanced by select.
         const long long nin = (rb - ra) >> 1;      // steps with both rows valid
         stream_init(ra + 2 * (D - 1));
+        // (scheduling barriers: left alone, the compiler sinks all D steps' loads to the end of the
+        //  loop body and consumes them together at its top -- a load burst, a wait, then 8 D MFMAs with
+        //  nothing in flight: HBM time and MFMA time simply added up.  Pinned, the loads of step
+        //  s + D - 1 go out in front of step s and the wait at a step's first use is vmcnt(4 (D - 1)).)
         for (; s + 2 * D - 1 <= nin; s += D) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 load_in(R[(d + D - 1) % D]);
+                __builtin_amdgcn_sched_barrier(0);
                 compute(R[d]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         stream_done();

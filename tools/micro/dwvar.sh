@@ -1,7 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for v in "" _a1 _a2 _d12 _d4; do
+for v in "" _d6 _d5 _d4; do
   export GG_HIP_LIB=$R/grid_gcn_amd/lib/libgridgcn_hip$v.so
   rm -rf /tmp/o$v
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/o$v -o p -- python $R/tools/time_dw.py --dense > /tmp/log$v 2>&1
