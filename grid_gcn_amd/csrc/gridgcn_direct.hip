@@ -851,7 +851,9 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 // m-groups of a workgroup walk the SAME rows (the B rows hit L1/L2), RS row streams fill the rest.
 // No LDS, no barriers; two register sets keep the next step's loads in flight.  Partials go to the
 // workspace as [wave][tile][reg][lane]; gg_k_dw_reduce_direct sums them into the framework layout.
+#ifndef GG_DW_D16
 #define GG_DW_D16 6      // register sets of the 16-tile form (one wave per SIMD: depth instead of partners)
+#endif
 template <int MT, int NQ, int NP, int NS, bool BF16 = false, bool SP = false>
 __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) void gg_k_linear_dw_direct(
     GGLinBwd p, int MG, int RS, long long rows_per_wg, int *__restrict__ tick, int ntick, int lds_red)

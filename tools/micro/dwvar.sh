@@ -1,4 +1,6 @@
 #!/bin/bash
+# dW kernel durations under the variant libraries built by tools/micro/mkvar.sh (edit the list below):
+#   rocprofv3 kernel stats of tools/time_dw.py --dense per variant
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for v in "" _d6 _d5 _d4; do
