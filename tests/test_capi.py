@@ -65,6 +65,21 @@ def test_argument_validation_without_gpu(lib):
     assert lib.gridgcn_gridify_workspace_bytes(16, 8192, ctypes.byref(p), ctypes.byref(n)) == 1
 
 
+def test_round3_entries_reject_bad_arguments_without_gpu(lib):
+    """argument checks that run before any launch: the round-3 entry points return GRIDGCN_EINVAL (1)."""
+    null = None
+    # gridgcn_linear_bwd_fin: the sums are mandatory
+    rc = lib.gridgcn_linear_bwd_fin(*([null] * 19), 0, 1024, 32, 32, 32, 0, 0, 0, 0, 0, null, null, null, null,
+                                    null, 0, null, 0, null)
+    assert rc == 1
+    # the batched weight pack: no table / no layers
+    assert lib.gridgcn_pack_linear_batch(null, 0, 0, null) == 1
+    # options outside their ranges
+    from grid_gcn_amd import _lib
+    assert lib.gridgcn_set_option(_lib.OPT_INDEX_SLAB_SHIFT, 99) == 1
+    assert lib.gridgcn_set_option(12345, 0) == 1
+
+
 def test_ops_fail_loudly_without_gpu():
     """No CPU fallback: CPU tensors are rejected, never silently routed elsewhere."""
     import torch
