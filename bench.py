@@ -314,7 +314,7 @@ def main():
                    "kernels": "hand-written HIP for Gridify/BallKNN, edge inputs (gather+geo) and their "
                               "sorted backward, all conv+BatchNorm+ReLU stacks fwd+bwd (fp32 MFMA), "
                               "att product + max, fc1 + dropout + class scores (one op) + softmax "
-                              "cross-entropy; PyTorch-ROCm for the small GEMMs on source points, "
+                              "cross-entropy, the small GEMMs on the source points; PyTorch-ROCm for "
                               "concat/mask on [B,O,C] and fused Adam"},
         # host side of the timed region: time to ENQUEUE the K steps (Python + ctypes + launches);
         # the step is GPU-bound while this stays below ms_per_step

@@ -35,7 +35,7 @@ EXPORTS = [
     "gridgcn_linear_fwd", "gridgcn_linear_bwd_workspace_bytes", "gridgcn_linear_bwd",
     "gridgcn_linear_fwd_ld", "gridgcn_linear_fwd_direct_ld", "gridgcn_linear_bwd_ld",
     "gridgcn_pairmax_fwd_src_z", "gridgcn_pack_desc_fill", "gridgcn_pack_linear_batch",
-    "gridgcn_linear_bwd_fin",
+    "gridgcn_linear_bwd_fin", "gridgcn_gemm_small", "gridgcn_gemm_small_workspace_bytes",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
@@ -139,6 +139,10 @@ def load():
     lib.gridgcn_linear_fwd_ld.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     lib.gridgcn_linear_fwd_direct_ld.restype = ci
     lib.gridgcn_linear_fwd_direct_ld.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, vp]
+    lib.gridgcn_gemm_small.restype = ci
+    lib.gridgcn_gemm_small.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, cs, vp]
+    lib.gridgcn_gemm_small_workspace_bytes.restype = ci
+    lib.gridgcn_gemm_small_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_linear_bwd_fin.restype = ci
     lib.gridgcn_linear_bwd_fin.argtypes = [vp] * 19 + [ci, ll, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp,
                                                        ci, vp, cs, vp]

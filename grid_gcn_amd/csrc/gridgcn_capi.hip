@@ -58,6 +58,9 @@ int gg_pack_linear(const float *, const float *, int, int, int, int, int, float 
                    float *, float *, float *, float *, hipStream_t);
 int gg_bn_finalize(const double *, const float *, const float *, long long, float, float, int,
                    float *, float *, float *, float *, float *, float *, long long *, hipStream_t);
+int gg_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
+                  int K, int zero_left, void *ws, hipStream_t st);      // gridgcn_gemm.hip
+size_t gg_gemm_small_workspace(int M, int N, int K);
 int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
                        hipStream_t);
 
@@ -484,6 +487,23 @@ int gridgcn_linear_bwd_fin(const float *dY, const void *Z_, const float *scale, 
                              Aprev, pscale, pshift, pmean, prstd, Wb, Wg, Wdx, ndx, E, C, cin, cin_w, rot,
                              ldy, ldz, nbn, zfmt, dX, dW, psums, amax, gval, P, workspace, workspace_bytes,
                              stream);
+}
+
+int gridgcn_gemm_small_workspace_bytes(int M, int N, int K, size_t *bytes)
+{
+    if (!bytes || M < 1 || N < 1 || K < 1) return GRIDGCN_EINVAL;
+    *bytes = gg_gemm_small_workspace(M, N, K);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                       int M, int N, int K, int zero_left, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (lda < 1 || ldb < 1 || ldc < 1 || M < 1 || N < 1 || K < 1) return GRIDGCN_EINVAL;
+    if (mode == 2 && (!workspace || workspace_bytes < gg_gemm_small_workspace(M, N, K))) return GRIDGCN_EWORKSPACE;
+    const int rc = gg_gemm_small(mode, A, lda, B, ldb, C, ldc, M, N, K, zero_left, workspace, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
 int gridgcn_linear_dx(const float *dY, const float *Z, const float *scale, const float *shift,

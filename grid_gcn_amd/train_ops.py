@@ -437,11 +437,46 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
     return dY, grads
 
 
+SMALL_GEMM = True      # the source-point products on csrc/gridgcn_gemm.hip instead of rocBLAS
+_GEMM_WS = {}
+
+
+def _gemm_small(mode, A, B, C, M, N, K, zero_left=0):
+    """gridgcn_gemm_small on 2-D views with unit inner stride: mode 0 A[M,K] B[N,K]^T, 1 A[M,K] B[K,N],
+    2 A[K,M]^T B[K,N]; C is written in place (any row stride)."""
+    assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
+    lib = _lib.load()
+    ws, nb = None, 0
+    if mode == 2:
+        n = ctypes.c_size_t(0)
+        lib.gridgcn_gemm_small_workspace_bytes(M, N, K, ctypes.byref(n))
+        nb = n.value
+        # (tickets at the end of the buffer: zero at first use, left zero by the kernel -- one buffer per
+        #  shape and stream, dropped around a graph capture like the zero arena)
+        key = (str(A.device), nb, torch.cuda.current_stream(A.device).cuda_stream)
+        ws = _GEMM_WS.get(key)
+        if ws is None:
+            ws = _GEMM_WS[key] = torch.zeros(nb, dtype=torch.uint8, device=A.device)
+    rc = lib.gridgcn_gemm_small(mode, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0),
+                                M, N, K, zero_left, _ptr(ws) if ws is not None else None, nb, _stream(A))
+    _lib.check(rc, "gridgcn_gemm_small")
+    return C
+
+
+def _small_ok(R, *dims):
+    return SMALL_GEMM and R <= 65536 and all(0 < d <= 512 for d in dims)
+
+
 def _tn_matmul(a, b, out=None):
     """a^T b for tall operands a [R,m], b [R,n] with small m, n: the contraction is cut into
     128-row slabs (one batched GEMM + a sum) so that the work spreads over the chip -- a plain
     [m,R]x[R,n] GEMM runs on m*n/tile workgroups only.  out: optional (strided) destination."""
     R = a.shape[0]
+    if a.is_cuda and a.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1 and \
+            _small_ok(R, a.shape[1], b.shape[1]) and (out is None or out.stride(1) == 1):
+        if out is None:
+            out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+        return _gemm_small(2, a, b, out, a.shape[1], b.shape[1], R)
     if R >= 1024 and R % 128 == 0:
         S = R // 128
         prod = torch.bmm(a.view(S, 128, a.shape[1]).transpose(1, 2), b.view(S, 128, b.shape[1]))
@@ -463,6 +498,7 @@ class _ZeroArena:
         self.chunk, self.off = {}, {}
 
     def reset(self):
+        _GEMM_WS.clear()          # (same reason: a buffer born inside a capture belongs to that graph)
         """Forget the current chunks (live slices keep theirs alive).  A chunk allocated while a
         hipGraph is being captured lives in THAT graph's memory pool and is only re-zeroed by
         that graph's replay: nothing captured or run later may carve slices out of it
@@ -992,7 +1028,11 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             st = _stream(src)
             feat = src.detach()[..., 4:].reshape(R, Cf)
             # [R, C0]: once per source point
-            Ysrc = torch.matmul(feat, W0.detach()[:, rot:].t()).contiguous()
+            if _small_ok(R, C0) and Cf % 8 == 0 and Cf <= 512:
+                Ysrc = _gemm_small(0, feat, W0.detach()[:, rot:], torch.empty((R, C0), dtype=torch.float32,
+                                                                             device=dev), R, C0, Cf)
+            else:
+                Ysrc = torch.matmul(feat, W0.detach()[:, rot:].t()).contiguous()
             # rows 0..2: geo_vec weights [3][C0] (zeros without geo_vec), row 3: bias
             wgb = torch.cat([W0.detach()[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0),
                              b0.detach()[None]])
@@ -1166,8 +1206,13 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 # gradient of the source rows [xyz w | features]: the four leading columns are zero
                 # rows of the (transposed) weight, so the product IS the full row
-                Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0), W0.detach()[:, rot:].t()])
-                gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
+                if _small_ok(R, Cf) and C0 % 8 == 0:
+                    gsrc = torch.empty((R, Cs), dtype=torch.float32, device=dev)
+                    _gemm_small(1, dYsrc, W0.detach()[:, rot:], gsrc[:, 4:], R, Cf, C0, zero_left=4)
+                    gsrc = gsrc.view(B, Nsrc, Cs)
+                else:
+                    Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0), W0.detach()[:, rot:].t()])
+                    gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
             db0 = _zeros(C0, torch.float32, dev)
         grads0 = [dW0, db0, v[2], v[3]]
         return (gsrc, None, None, None) + tuple(grads0) + tuple(grads_rest) + tuple(grads_a)

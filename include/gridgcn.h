@@ -411,6 +411,21 @@ int gridgcn_ctx_max_backward(const float *dctx, const int32_t *cidx, long long n
 int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, const float *shift,
                          const float *mean, const float *rstd, const float *m1, const float *m2,
                          long long ncent, int P, int C, float *out, void *stream);
+/* gridgcn_gemm_small: the small dense products beside the edge pipeline (the first point conv applied
+ *   to the source points and its two backward products; csrc/gridgcn_gemm.hip), fp32 MFMA, operands
+ *   with arbitrary row strides (column slices of wider tensors), no packing:
+ *     mode 0  C[M][N] = A[M][K] * B[N][K]^T        (K % 8 == 0)
+ *     mode 1  C[M][N] = A[M][K] * B[K][N]          (K % 8 == 0; zero_left <= 32: the columns
+ *                                                   [-zero_left, 0) left of C are zero-filled)
+ *     mode 2  C[M][N] = A[K][M]^T * B[K][N]        (contraction over the K rows, any K; fixed summation
+ *                                                   order; workspace of _workspace_bytes whose last
+ *                                                   tiles*4 + 256 bytes are ZERO at the first call --
+ *                                                   the kernel leaves them zero, so the buffer can be
+ *                                                   reused by later calls of the same shape) */
+int gridgcn_gemm_small_workspace_bytes(int M, int N, int K, size_t *bytes);
+int gridgcn_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                       int M, int N, int K, int zero_left, void *workspace, size_t workspace_bytes,
+                       void *stream);
 /* gridgcn_bn_stats: sums[c] += sum_e Z[e][c], sums[C+c] += sum_e Z[e][c]^2 (input of
  *   gridgcn_bn_finalize) for a layer whose GEMM ran elsewhere (the "wide" fallback: stacks beyond
  *   the MFMA kernels' 256 output / 384 input channels use rocBLAS + these BatchNorm kernels). */

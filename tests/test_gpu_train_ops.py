@@ -179,6 +179,41 @@ def test_pack_linear_layouts(C, cin):
             assert torch.equal(o, r)
 
 
+@pytest.mark.parametrize("R,Cf,C0,rot", [(8192, 128, 128, 3), (2048, 64, 64, 3), (192, 256, 128, 3),
+                                         (1000, 8, 36, 0), (33, 136, 4, 1), (40000, 32, 64, 3)])
+def test_gemm_small_matches_torch(R, Cf, C0, rot):
+    """gridgcn_gemm_small (csrc/gridgcn_gemm.hip), the three products of the source-point conv on column
+    slices of wider tensors (row strides 4 + Cf and rot + Cf, not 16-byte aligned) against torch.matmul
+    in float64; fp32 MFMA accumulation: 1e-5 of the largest entry times sqrt(K)."""
+    torch.manual_seed(R + Cf)
+    src = torch.randn(R, 4 + Cf, device=DEV)
+    W0 = torch.randn(C0, rot + Cf, device=DEV)
+    feat, Wf = src[:, 4:], W0[:, rot:]
+    Y = train_ops._gemm_small(0, feat, Wf, torch.empty(R, C0, device=DEV), R, C0, Cf)
+    ref = feat.double() @ Wf.double().t()
+    assert float((Y - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * Cf ** 0.5
+    if C0 % 8 == 0:
+        dY = torch.randn(R, C0, device=DEV)
+        g = torch.full((R, 4 + Cf), 7.0, device=DEV)
+        train_ops._gemm_small(1, dY, Wf, g[:, 4:], R, Cf, C0, zero_left=4)
+        ref = dY.double() @ Wf.double()
+        assert float((g[:, 4:] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * C0 ** 0.5
+        assert float(g[:, :4].abs().max()) == 0.0
+    dY = torch.randn(R, C0, device=DEV)
+    dW = torch.full((C0, rot + Cf), 7.0, device=DEV)
+    train_ops._tn_matmul(dY, feat, out=dW[:, rot:])
+    ref = dY.double().t() @ feat.double()
+    assert float((dW[:, rot:] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * R ** 0.5
+    assert rot == 0 or bool((dW[:, :rot] == 7.0).all())
+    G = torch.randn(R, 4, device=DEV)
+    t = train_ops._tn_matmul(Y, G)
+    ref = Y.double().t() @ G.double()
+    assert t.shape == (C0, 4) and float((t - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * R ** 0.5
+    # bit-reproducible (fixed summation order), and the workspace's tickets are back at zero
+    for _ in range(3):
+        assert torch.equal(t, train_ops._tn_matmul(Y, G))
+
+
 def test_pack_cache_batch_launch_equals_single_packs():
     """train_ops.PACKS: the one-launch rebuild of every layout of a module
     (gridgcn_pack_linear_batch) writes, bit for bit, what the per-layer gridgcn_pack_linear writes;
