@@ -1412,7 +1412,11 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
                 W0, b0, g0, be0 = pp[:4]
                 C0 = W0.shape[0]
                 feat = srcd[..., 4:].reshape(R, Cf)
-                Ysrc = torch.matmul(feat, W0.detach()[:, 3:].t()).contiguous()
+                if _small_ok(R, C0) and Cf % 8 == 0 and Cf <= 512:
+                    Ysrc = _gemm_small(0, feat, W0.detach()[:, 3:],
+                                       torch.empty((R, C0), dtype=torch.float32, device=dev), R, C0, Cf)
+                else:
+                    Ysrc = torch.matmul(feat, W0.detach()[:, 3:].t()).contiguous()
                 wgb = torch.cat([W0.detach()[:, :3].t(), b0.detach()[None]])
                 x0 = torch.empty((E, C0), dtype=torch.float32, device=dev)          # Z0
                 sums0 = _zeros(2 * C0, torch.float64, dev)
@@ -1599,11 +1603,21 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
                 dW0 = torch.cat([dWg.t().float(), _tn_matmul(dYsrc, feat)], dim=1)
                 grads_p = [dW0, _zeros(C0, torch.float32, dev), v0[2], v0[3]] + list(grads_rest)
                 if ctx.needs_input_grad[0]:
-                    Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0),
-                                    W0.detach()[:, 3:].t()])
-                    gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
+                    if _small_ok(R, Cf) and C0 % 8 == 0:
+                        gsrc = torch.empty((R, Cs), dtype=torch.float32, device=dev)
+                        _gemm_small(1, dYsrc, W0.detach()[:, 3:], gsrc[:, 4:], R, Cf, C0, zero_left=4)
+                        gsrc = gsrc.view(B, Nsrc, Cs)
+                    else:
+                        Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0),
+                                        W0.detach()[:, 3:].t()])
+                        gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
                     # the context vector's arg-max rows
-                    dctx = torch.matmul(dcb, Wc).contiguous()
+                    if dcb.stride(1) == 1 and Wc.stride(1) == 1 and dcb.shape[1] % 8 == 0 and \
+                            _small_ok(dcb.shape[0], Wc.shape[1], dcb.shape[1]):
+                        dctx = _gemm_small(1, dcb, Wc, torch.empty((dcb.shape[0], Wc.shape[1]), dtype=torch.float32,
+                                                                  device=dev), dcb.shape[0], Wc.shape[1], dcb.shape[1])
+                    else:
+                        dctx = torch.matmul(dcb, Wc).contiguous()
                     _lib.check(lib.gridgcn_ctx_max_backward(_ptr(dctx), _ptr(cidx), ncent, Cf, Cs,
                                                             _ptr(gsrc), st),
                                "gridgcn_ctx_max_backward")
