@@ -211,18 +211,22 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
                         a[q] = gg_bnrelu4(a[q], *(const float4 *)(scl + k0 + 4 * q),
                                           *(const float4 *)(scl + K + k0 + 4 * q));
                 }
+                // the weight fragment of step st + 1 is read from LDS before the MFMAs of step st (read
+                // right in front of its use, every group of NT MFMAs began with an LDS round trip)
+                float bb[2][NT];
+                gg_ldb<NT>(Wb, s * 64 + lane, bb[0]);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int st = 0; st < 16; st++) {
+                    if (st + 1 < 16) gg_ldb<NT>(Wb, (s + st + 1) * 64 + lane, bb[(st + 1) & 1]);
+                    // (pinned: or the scheduler folds the two buffers back into one register set --
+                    //  ds_read, s_waitcnt lgkmcnt(0), NT MFMAs, sixteen times per chunk)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        float b[NT];
-                        gg_ldb<NT>(Wb, s * 64 + lane, b);
-#pragma unroll
-                        for (int t = 0; t < NT; t++)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[q], i), b[t], acc[t], 0, 0, 0);
-                        s++;
-                    }
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_f4(a[st >> 2], st & 3), bb[st & 1][t], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                s += 16;
 #pragma unroll
                 for (int q = 0; q < 4; q++) xa[q] = xb[q];
             }
