@@ -846,7 +846,7 @@ int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *
     p.Z = Z0; p.Ysrc = Ysrc; p.Wg = Wg; p.b = b; p.dY = dY; p.amax = amax; p.gval = gval; p.scale = scale; p.shift = shift;
     p.mean = mean; p.rstd = rstd; p.m1 = m1; p.m2 = m2; p.att16 = att16; p.index = nebidx;
     p.perm = nullptr; p.keys = nullptr; p.rowptr = nullptr; p.dYsrc = dYsrc; p.dWg = dWg;
-    p.B = B; p.N = Nsrc; p.O = O; p.P = P; p.C0 = C0; p.M = O * P; p.cpc = 0;
+    p.B = B; p.N = Nsrc; p.O = O; p.P = P; p.C0 = C0; p.M = O * P; p.cpc = 0; p.chunk = 0;
     const int rc = gg_edge_lin0_bwd(p, workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }

@@ -27,7 +27,7 @@ struct GGEdgeLin0Bwd {
     const int *perm, *keys, *rowptr;
     float *dYsrc;         // [B*N][C0], zero-filled
     double *dWg;          // [3][C0], zero-filled (nullptr: no geo term)
-    int B, N, O, P, C0, M, cpc;
+    int B, N, O, P, C0, M, cpc, chunk;   // cpc chunks of `chunk` sorted edges per cloud, one wave each
 };
 
 size_t gg_edge_lin0_sparse_workspace(int B, int N, int C);

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
     const bool active = wid < p.B * p.cpc;
     if (active) {
         const int b = wid / p.cpc, ch = wid - b * p.cpc;
-        const int e0 = ch * GG_CSR_CHUNK, e1 = e0 + GG_CSR_CHUNK < M ? e0 + GG_CSR_CHUNK : M;
+        const int e0 = ch * p.chunk, e1 = e0 + p.chunk < M ? e0 + p.chunk : M;
         const long long rows = (long long)p.B * N;
         const int *pk = p.keys + (size_t)b * M, *pp = p.perm + (size_t)b * M;
         const int *rp = p.rowptr + (size_t)b * (N + 3);
@@ -319,7 +319,12 @@ int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st)
     const int rc = gg_csr_build(p.index, p.B, p.N, p.M, workspace, &perm, &keys, &rowptr, st);
     if (rc) return rc;
     p.perm = perm; p.keys = keys; p.rowptr = rowptr;
-    p.cpc = (p.M + GG_CSR_CHUNK - 1) / GG_CSR_CHUNK;
+    // a wave walks its chunk of sorted edges four rows at a time, each round a full memory latency:
+    // short chunks where the edges are few (cfg4 down1: 64 K edges were 64 workgroups x 64 rounds),
+    // rows cut by a chunk boundary go through atomics either way
+    p.chunk = GG_CSR_CHUNK;
+    while (p.chunk > 32 && (long long)p.B * ((p.M + p.chunk - 1) / p.chunk) < 1024) p.chunk >>= 1;
+    p.cpc = (p.M + p.chunk - 1) / p.chunk;
     const int nwave = p.B * p.cpc, grid = (nwave + 3) / 4;
     if (VPL == 1) gg_k_edge_lin0_bwd<1><<<grid, 256, 0, st>>>(p);
     else if (VPL == 2) gg_k_edge_lin0_bwd<2><<<grid, 256, 0, st>>>(p);
@@ -388,60 +393,78 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
         const long long li = flat - ((long long)b * N - 1);
         return (li < 0 || li > N) ? -1 : (int)li;
     };
-    // four centres per group and round, every load level issued for all four before it is used:
-    // amax -> nebidx[arg-max edge] -> LDS row is a dependent chain (the loop was latency bound)
-    constexpr int U = 4;
-    for (int ob0 = o0 + grp; ob0 < o1; ob0 += 32 * U) {
-        int pm[U], idx[U];
-        float gv[U], zs[U];
-        float4 av[U];
-        if (cok) {
+    // per-source geo sums (channel slice 0 only): a flat walk over the edges of this split, one edge
+    // per thread and four in flight (the per-centre form kept P of 32 lanes busy and made these
+    // workgroups the tail of the launch)
+    if (geo_wg && o0 < o1) {
+        const int ea = o0 * P, ez = o1 * P;
+        const float *ab = p.att16 + (size_t)b * O * P * 16;
+        constexpr int UG = 4;
+        for (int e = ea + tid; e < ez; e += 1024 * UG) {
+            float4 a[UG];
+            int id[UG];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
-                const size_t ob = ((size_t)b * O + o) * C;
-                pm[u] = p.amax[ob + c];
-                gv[u] = p.gval[ob + c];
-                zs[u] = p.zsel[ob + c];
+            for (int u = 0; u < UG; u++) {
+                const int ee = e + 1024 * u < ez ? e + 1024 * u : e;
+                a[u] = *(const float4 *)(ab + (size_t)ee * 16);
+                id[u] = nb[ee];
             }
+            __builtin_amdgcn_sched_barrier(0);     // (all loads out before the first one is waited for)
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
-                idx[u] = nb[(size_t)o * P + pm[u]];
-                av[u] = *(const float4 *)(p.att16 + (((size_t)b * O + o) * P + pm[u]) * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (ob0 + 32 * u >= o1) break;
-                const float s = (zs[u] * scv + shv > 0.f) ? scv * gv[u] : 0.f;
-                const int key = keyof(idx[u]);
-                if (s != 0.f) {
-                    if (key >= 0) atomicAdd(&acc[key * 32 + lane], s);
-                    else atomicAdd(&p.fpart[flat_ * C + c], s);
+            for (int u = 0; u < UG; u++) {
+                if (e + 1024 * u >= ez) break;
+                const int key = keyof(id[u]);
+                if (key >= 0) {
+                    atomicAdd(&gs[key * 4 + 0], a[u].y); atomicAdd(&gs[key * 4 + 1], a[u].z);
+                    atomicAdd(&gs[key * 4 + 2], a[u].w); atomicAdd(&gs[key * 4 + 3], 1.f);
+                } else {
+                    atomicAdd(&p.fgs[flat_ * 4 + 0], a[u].y); atomicAdd(&p.fgs[flat_ * 4 + 1], a[u].z);
+                    atomicAdd(&p.fgs[flat_ * 4 + 2], a[u].w); atomicAdd(&p.fgs[flat_ * 4 + 3], 1.f);
                 }
-                wg0 = fmaf(av[u].y, s, wg0); wg1 = fmaf(av[u].z, s, wg1); wg2 = fmaf(av[u].w, s, wg2);
+                g9[0] += a[u].y * a[u].y; g9[1] += a[u].y * a[u].z; g9[2] += a[u].y * a[u].w;
+                g9[3] += a[u].z * a[u].y; g9[4] += a[u].z * a[u].z; g9[5] += a[u].z * a[u].w;
+                g9[6] += a[u].w * a[u].y; g9[7] += a[u].w * a[u].z; g9[8] += a[u].w * a[u].w;
+                g9[9] += a[u].y; g9[10] += a[u].z; g9[11] += a[u].w;
             }
         }
-        if (geo_wg)
+    }
+    // U centres per group and round, every load level issued for all of them before it is used:
+    // amax -> nebidx[arg-max edge] -> LDS row is a dependent chain (the loop was latency bound)
+    constexpr int U = 8;
+    if (cok)
+    for (int ob0 = o0 + grp; ob0 < o1; ob0 += 32 * U) {
+        unsigned pm[U];
+        int idx[U];
+        float gv[U], zs[U];
+        float4 av[U];
+        // (edge numbers in 32 bits -- B*O*P < 2^31 is checked by the launcher: with 64-bit index
+        // arithmetic on the loaded byte the compiler funnels all the amax loads through one register
+        // pair and waits for each of them in turn)
+#pragma unroll
         for (int u = 0; u < U; u++) {
-            const int o = ob0 + 32 * u;
-            if (o >= o1) break;
-            const size_t eb = ((size_t)b * O + o) * P;
-            for (int pp = lane; pp < P; pp += 32) {
-                const float4 a = *(const float4 *)(p.att16 + (eb + pp) * 16);
-                const int key = keyof(nb[(size_t)o * P + pp]);
-                if (key >= 0) {
-                    atomicAdd(&gs[key * 4 + 0], a.y); atomicAdd(&gs[key * 4 + 1], a.z);
-                    atomicAdd(&gs[key * 4 + 2], a.w); atomicAdd(&gs[key * 4 + 3], 1.f);
-                } else {
-                    atomicAdd(&p.fgs[flat_ * 4 + 0], a.y); atomicAdd(&p.fgs[flat_ * 4 + 1], a.z);
-                    atomicAdd(&p.fgs[flat_ * 4 + 2], a.w); atomicAdd(&p.fgs[flat_ * 4 + 3], 1.f);
-                }
-                g9[0] += a.y * a.y; g9[1] += a.y * a.z; g9[2] += a.y * a.w;
-                g9[3] += a.z * a.y; g9[4] += a.z * a.z; g9[5] += a.z * a.w;
-                g9[6] += a.w * a.y; g9[7] += a.w * a.z; g9[8] += a.w * a.w;
-                g9[9] += a.y; g9[10] += a.z; g9[11] += a.w;
+            const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+            const size_t ob = (size_t)(b * O + o) * C + c;
+            pm[u] = p.amax[ob];
+            gv[u] = p.gval[ob];
+            zs[u] = p.zsel[ob];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+            const unsigned e = (unsigned)(b * O + o) * (unsigned)P + pm[u];
+            idx[u] = p.nebidx[e];
+            av[u] = *(const float4 *)(p.att16 + (size_t)e * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (ob0 + 32 * u >= o1) break;
+            const float s = (zs[u] * scv + shv > 0.f) ? scv * gv[u] : 0.f;
+            const int key = keyof(idx[u]);
+            if (s != 0.f) {
+                if (key >= 0) atomicAdd(&acc[key * 32 + lane], s);
+                else atomicAdd(&p.fpart[flat_ * C + c], s);
             }
+            wg0 = fmaf(av[u].y, s, wg0); wg1 = fmaf(av[u].z, s, wg1); wg2 = fmaf(av[u].w, s, wg2);
         }
     }
     __syncthreads();
@@ -545,7 +568,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
                             hipStream_t st)
 {
     size_t lds = (size_t)(N + 1) * 36 * 4;
-    if (lds > 150 * 1024 || C < 1 || (C & 3)) return 1;
+    if (lds > 150 * 1024 || C < 1 || (C & 3) || (long long)B * O * P >= (1ll << 31)) return 1;
     if (lds < 3 * 32 * 32 * 4) lds = 3 * 32 * 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {

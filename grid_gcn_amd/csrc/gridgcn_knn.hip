@@ -332,6 +332,35 @@ __global__ __launch_bounds__(256) void gg_k_edge_inputs_rows(
     }
 }
 
+// the same rows for a layer WITHOUT neighbour features (nfeat = 0: the first down layer, whose source
+// rows are the raw points): nothing to copy, so one edge per lane instead of one per half-wave -- the
+// half-wave form left 26 of 32 lanes idle and ran at a third of the bandwidth of its 96 bytes/edge
+__global__ __launch_bounds__(256) void gg_k_edge_inputs_rows_geo(
+    const float *__restrict__ src, const int *__restrict__ nebidx, const float *__restrict__ cent,
+    int cent_stride, int Nsrc, long long rows, int Cs, int O, int P, int geo, int nfs, int E,
+    float *__restrict__ nf, float *__restrict__ att)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int ci = e / P;
+    const int b = ci / O;
+    long long flat = (long long)nebidx[e] + (long long)b * Nsrc;
+    flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+    const float *srow = src + flat * Cs;
+    const float *cen = cent + (size_t)ci * cent_stride;
+    const float cx = cen[0], cy = cen[1], cz = cen[2];
+    const float nx = srow[0], ny = srow[1], nz = srow[2];
+    const float gx = nx - cx, gy = ny - cy, gz = nz - cz;
+    float4 *a = (float4 *)(att + (size_t)e * 16);
+    a[0] = make_float4(sqrtf((gx * gx + gy * gy) + gz * gz), gx, gy, gz);
+    a[1] = make_float4(cx, cy, cz, nx);
+    a[2] = make_float4(ny, nz, 0.f, 0.f);
+    a[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *n = (float4 *)(nf + (size_t)e * nfs);
+    n[0] = geo ? make_float4(gx, gy, gz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 1; j < (nfs >> 2); j++) n[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 int gg_edge_inputs_rows(const float *src, const int *nebidx, const float *cent, int cent_stride,
                         int B, int Nsrc, int Cs, int O, int P, int has_feats, int localfdim,
                         int nfs, float *nf, float *att, hipStream_t st)
@@ -341,6 +370,12 @@ int gg_edge_inputs_rows(const float *src, const int *nebidx, const float *cent, 
     if ((nfeat & 3) || (nfs & 7) || nfs < nfeat + (geo ? 3 : 0) || nfs - nfeat > 96) return 1;
     const long long E = (long long)B * O * P;
     if (E >= (1ll << 31)) return 1;
+    if (nfeat == 0) {
+        gg_k_edge_inputs_rows_geo<<<(int)((E + 255) / 256), 256, 0, st>>>(
+            src, nebidx, cent, cent_stride, Nsrc, (long long)B * Nsrc, Cs, O, P, geo, nfs, (int)E, nf,
+            att);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     long long nb = (E + 7) / 8;
     const int grid = (int)(nb < 65536 ? nb : 65536);
     gg_k_edge_inputs_rows<<<grid, 256, 0, st>>>(src, nebidx, cent, cent_stride, Nsrc,
