@@ -33,7 +33,7 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
                                                              int m, float radius,
                                                              GGBallGridInfo *__restrict__ info,
                                                              int *__restrict__ cellStart,
-                                                             int *__restrict__ sorted)
+                                                             float4 *__restrict__ sorted)
 {
     extern __shared__ int cnt[];                 // [ncell] counts -> cursors
     __shared__ float rmin[3][16], rmax[3][16];
@@ -123,13 +123,15 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
     }
     if (tid == 1023) cs[g.ncell] = run;
     __syncthreads();
-    int *sb = sorted + (size_t)b * m;
+    // the sorted list carries the coordinates with the index: the query reads ONE contiguous run of
+    // 16-byte records per (z, y) row of cells instead of an index and then three scattered floats
+    float4 *sb = sorted + (size_t)b * m;
     for (int j = tid; j < dn; j += 1024) {
         const float x = kb[j * 3], y = kb[j * 3 + 1], z = kb[j * 3 + 2];
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
             const int c = (gg_bg_axis(z, g.oz, g.inv, g.dz) * g.dy + gg_bg_axis(y, g.oy, g.inv, g.dy)) * g.dx +
                           gg_bg_axis(x, g.ox, g.inv, g.dx);
-            sb[atomicAdd(&cnt[c], 1)] = j;
+            sb[atomicAdd(&cnt[c], 1)] = make_float4(x, y, z, __int_as_float(j));
         }
     }
 }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restr
                                                             int m, int topk, float r2,
                                                             const GGBallGridInfo *__restrict__ info,
                                                             const int *__restrict__ cellStart,
-                                                            const int *__restrict__ sorted,
+                                                            const float4 *__restrict__ sorted,
                                                             int *__restrict__ idx)
 {
     const int b = blockIdx.y;
@@ -150,55 +152,80 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restr
     const GGBallGridInfo g = info[b];
     const float *u = unknown + ((size_t)b * n + qi) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
-    const float *kb = known + (size_t)b * m * 3;
     const int *cs = cellStart + (size_t)b * (GG_BG_NCMAX + 1);
-    const int *sb = sorted + (size_t)b * m;
+    const float4 *sb = sorted + (size_t)b * m;
     float best[K];
     int besti[K];
 #pragma unroll
     for (int l = 0; l < K; l++) { best[l] = FLT_MAX; besti[l] = -1; }
+    auto candidate = [&](const float4 kp) {
+        const int id = __float_as_int(kp.w);
+        const float dx = __fsub_rn(ux, kp.x);
+        const float dy = __fsub_rn(uy, kp.y);
+        const float dz = __fsub_rn(uz, kp.z);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)),
+                                  __fmul_rn(dz, dz));
+        if (d > r2) return;                                        // ball_k_nn-inl.h:77
+        // keep the K smallest by (d, id): what the reference's strict-< insertion over
+        // ascending ids produces
+        bool lt[K];
+#pragma unroll
+        for (int l = 0; l < K; l++)
+            lt[l] = d < best[l] || (d == best[l] && (unsigned)id < (unsigned)besti[l]);
+        if (lt[K - 1]) {
+#pragma unroll
+            for (int l = K - 1; l >= 1; l--) {
+                besti[l] = lt[l - 1] ? besti[l - 1] : (lt[l] ? id : besti[l]);
+                best[l] = lt[l - 1] ? best[l - 1] : (lt[l] ? d : best[l]);
+            }
+            besti[0] = lt[0] ? id : besti[0];
+            best[0] = lt[0] ? d : best[0];
+        }
+    };
     const int cx = gg_bg_axis(ux, g.ox, g.inv, g.dx), cy = gg_bg_axis(uy, g.oy, g.inv, g.dy);
     const int cz = gg_bg_axis(uz, g.oz, g.inv, g.dz);
-    for (int z = (cz > 0 ? cz - 1 : 0); z <= (cz + 1 < g.dz ? cz + 1 : g.dz - 1); z++)
-        for (int y = (cy > 0 ? cy - 1 : 0); y <= (cy + 1 < g.dy ? cy + 1 : g.dy - 1); y++) {
-            // the x-neighbours are contiguous cells: one range per (z, y)
-            const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < g.dx ? cx + 1 : g.dx - 1;
-            const int c0 = (z * g.dy + y) * g.dx;
-            const int p0 = cs[c0 + x0], p1 = cs[c0 + x1 + 1];
-            for (int q = p0; q < p1; q++) {
-                const int id = sb[q];
-                const float dx = __fsub_rn(ux, kb[id * 3]);
-                const float dy = __fsub_rn(uy, kb[id * 3 + 1]);
-                const float dz = __fsub_rn(uz, kb[id * 3 + 2]);
-                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)),
-                                          __fmul_rn(dz, dz));
-                if (d > r2) continue;                                  // ball_k_nn-inl.h:77
-                // keep the K smallest by (d, id): what the reference's strict-< insertion over
-                // ascending ids produces
-                bool lt[K];
+    // the x-neighbours are contiguous cells: one range of records per (z, y) row of cells; the nine
+    // pairs of range bounds are requested together, before the first of them is needed
+    const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < g.dx ? cx + 1 : g.dx - 1;
+    int pa[9], pb[9];
 #pragma unroll
-                for (int l = 0; l < K; l++)
-                    lt[l] = d < best[l] || (d == best[l] && (unsigned)id < (unsigned)besti[l]);
-                if (lt[K - 1]) {
+    for (int r = 0; r < 9; r++) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = (z >= 0) & (z < g.dz) & (y >= 0) & (y < g.dy);
+        const int c0 = ((in ? z : cz) * g.dy + (in ? y : cy)) * g.dx;
+        const int a = cs[c0 + x0], e = cs[c0 + x1 + 1];
+        pa[r] = in ? a : 0;
+        pb[r] = in ? e : 0;
+    }
 #pragma unroll
-                    for (int l = K - 1; l >= 1; l--) {
-                        besti[l] = lt[l - 1] ? besti[l - 1] : (lt[l] ? id : besti[l]);
-                        best[l] = lt[l - 1] ? best[l - 1] : (lt[l] ? d : best[l]);
-                    }
-                    besti[0] = lt[0] ? id : besti[0];
-                    best[0] = lt[0] ? d : best[0];
-                }
-            }
+    for (int r = 0; r < 9; r++) {
+        const int p0 = pa[r], p1 = pb[r];
+        // four records in flight (the one-at-a-time walk was a chain of L2 latencies)
+        for (int q = p0; q < p1; q += 4) {
+            float4 kp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) kp[u] = sb[q + u < p1 ? q + u : p1 - 1];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (q + u < p1) candidate(kp[u]);
         }
+    }
     int *o = idx + ((size_t)b * n + qi) * topk;
 #pragma unroll
     for (int l = 0; l < K; l++)
         if (l < topk) o[l] = besti[l];
 }
 
+// workspace: info[B] | cellStart[B][NCMAX+1] | (16-byte aligned) sorted[B][m] (x, y, z, index)
+static size_t gg_bg_sorted_offset(int B)
+{
+    const size_t o = (size_t)B * sizeof(GGBallGridInfo) + (size_t)B * (GG_BG_NCMAX + 1) * sizeof(int);
+    return (o + 15) & ~(size_t)15;
+}
+
 size_t gg_ball_grid_workspace(int B, int m)
 {
-    return (size_t)B * sizeof(GGBallGridInfo) + ((size_t)B * (GG_BG_NCMAX + 1) + (size_t)B * m) * sizeof(int);
+    return gg_bg_sorted_offset(B) + (size_t)B * m * sizeof(float4);
 }
 
 // 1 = not supported (k > 6): the caller uses the tiled scan
@@ -209,7 +236,7 @@ int gg_ball_knn_grid(const float *unknown, const float *known, const int *downnu
     if (k < 1 || k > 6 || !(radius >= 0.f)) return 1;
     GGBallGridInfo *info = (GGBallGridInfo *)workspace;
     int *cellStart = (int *)(info + B);
-    int *sorted = cellStart + (size_t)B * (GG_BG_NCMAX + 1);
+    float4 *sorted = (float4 *)((char *)workspace + gg_bg_sorted_offset(B));
     gg_k_ball_grid_build<<<B, 1024, GG_BG_NCMAX * sizeof(int), st>>>(known, downnum, m, radius, info,
                                                                      cellStart, sorted);
     dim3 grid((n + 255) / 256, B);

@@ -19,6 +19,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/trace -o p -- python $R/bench.py --config cfg4 --steps 4 --warmup 2 --eager --no-cpu-baseline --no-micro > $R/$OUT/trace_bench.log 2>&1
 cd $R
 F=$(find $OUT/trace -name '*kernel_trace.csv' | head -1)
-python tools/step_trace.py $F 100 80 > $OUT/steptrace_cfg4.txt
+python tools/step_trace.py $F 100 80 narrow > $OUT/steptrace_cfg4.txt
 cat $OUT/steptrace_cfg4.txt
 rm -rf $OUT/trace
