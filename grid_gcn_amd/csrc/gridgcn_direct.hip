@@ -394,11 +394,14 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
     }
     // fp32 form (next chunk prefetched: 16 more registers): 2 waves per SIMD at NT >= 4, 3 at NT = 2
     const bool use16 = g_mlp_bf16 && q.scale && (size_t)((q.K / 2 + 7) / 8) * 64 * NT * 16 + (size_t)2 * q.K * 4 <= 156 * 1024;
-    const int threads = use16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024));
+    // few row tiles (<= 4 per CU): 4-wave workgroups, one wave per SIMD on more CUs (see
+    // launch_dx_direct)
+    const long long ntile = (q.E + 31) >> 5;
+    const int threads = ntile <= 1024 ? 256 :
+        (use16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024)));
     const int nw = threads / 64;
     const size_t wbytes = (size_t)q.K * 32 * NT * 4, sbytes = (size_t)2 * q.K * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
-    const long long ntile = (q.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
     if (nb > 256) nb = 256;
     const bool exact = q.cout == NT * 32;
@@ -793,7 +796,12 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     // (768 threads = 3 waves per SIMD at 168 registers was measured: no gain, 59 spills)
     // narrow outputs (NT <= 2) use ~150-170 registers = 3 waves per SIMD: workgroups of 4 waves so
     // that three of them fit a CU (with 8-wave workgroups only one did)
-    const int threads = NT <= 2 ? 256 : 512, nw = threads / 64;
+    // few row tiles (<= 4 per CU: the layers of the coarse levels, 2 K - 6 K rows): workgroups of 4
+    // waves, so that every wave has a SIMD -- and its MFMA pipe -- to itself on 2x as many CUs.  A row
+    // tile is a serial chain of NT * C/2 MFMAs (27 us at NT = 8, C = 256); 8-wave groups ran two such
+    // chains per SIMD on an eighth of the chip (cfg4 up0: 58 -> us)
+    const long long ntile = (p.E + 31) >> 5;
+    const int threads = (NT <= 2 || ntile <= 1024) ? 256 : 512, nw = threads / 64;
     const bool bf16 = g_mlp_bf16 != 0;
     size_t lds = (bf16 ? (size_t)((p.C / 2 + 7) / 8) * 64 * NTV * 16 + 5 * (size_t)p.C * 4
                        : ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4) + (size_t)4 * NT * 32 * 4;
@@ -817,7 +825,6 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     // 1.30 -> 1.06 ms)
     int per_cu = NT == 1 ? (bf16 ? 2 : 3) : (NT == 2 ? 2 : 1);
     while (per_cu > 1 && per_cu * lds > 152 * 1024) per_cu--;
-    const long long ntile = (p.E + 31) >> 5;
     long long nb = (ntile + nw - 1) / nw;
     if (nb > 256 * per_cu) nb = 256 * per_cu;
     if (bf16) gg_k_linear_dx_direct<NT, true><<<(int)nb, threads, lds, st>>>(p);

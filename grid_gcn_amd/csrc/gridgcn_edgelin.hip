@@ -428,43 +428,55 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
             }
         }
     }
-    // U centres per group and round, every load level issued for all of them before it is used:
-    // amax -> nebidx[arg-max edge] -> LDS row is a dependent chain (the loop was latency bound)
+    // U centres per group and round.  amax -> nebidx[arg-max edge] -> LDS row is a dependent chain of
+    // two memory levels; every level is issued for all U centres at once, and the first level of the
+    // NEXT round is requested before the second level of this one is waited for (the waves of a
+    // workgroup start together and, four per SIMD, stay in step: without the overlap the memory
+    // system idled while they all sat in the second level)
     constexpr int U = 8;
-    if (cok)
-    for (int ob0 = o0 + grp; ob0 < o1; ob0 += 32 * U) {
-        unsigned pm[U];
-        int idx[U];
-        float gv[U], zs[U];
-        float4 av[U];
-        // (edge numbers in 32 bits -- B*O*P < 2^31 is checked by the launcher: with 64-bit index
-        // arithmetic on the loaded byte the compiler funnels all the amax loads through one register
-        // pair and waits for each of them in turn)
+    struct L1 { unsigned pm[U]; float gv[U], zs[U]; };
+    auto load1 = [&](int ob0, L1 &r) {
+        size_t ob[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
-            const size_t ob = (size_t)(b * O + o) * C + c;
-            pm[u] = p.amax[ob];
-            gv[u] = p.gval[ob];
-            zs[u] = p.zsel[ob];
+            ob[u] = (size_t)(b * O + o) * C + c;
+            r.pm[u] = p.amax[ob[u]];
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
-            const unsigned e = (unsigned)(b * O + o) * (unsigned)P + pm[u];
-            idx[u] = p.nebidx[e];
-            av[u] = *(const float4 *)(p.att16 + (size_t)e * 16);
-        }
+        for (int u = 0; u < U; u++) { r.gv[u] = p.gval[ob[u]]; r.zs[u] = p.zsel[ob[u]]; }
+    };
+    if (cok && o0 + grp < o1) {
+        L1 cur;
+        load1(o0 + grp, cur);
+        for (int ob0 = o0 + grp; ob0 < o1; ob0 += 32 * U) {
+            int idx[U];
+            float4 av[U];
+            // (edge numbers in 32 bits -- B*O*P < 2^31 is checked by the launcher: with 64-bit index
+            // arithmetic on the loaded byte the compiler funnels all the amax loads through one
+            // register pair and waits for each of them in turn)
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (ob0 + 32 * u >= o1) break;
-            const float s = (zs[u] * scv + shv > 0.f) ? scv * gv[u] : 0.f;
-            const int key = keyof(idx[u]);
-            if (s != 0.f) {
-                if (key >= 0) atomicAdd(&acc[key * 32 + lane], s);
-                else atomicAdd(&p.fpart[flat_ * C + c], s);
+            for (int u = 0; u < U; u++) {
+                const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+                const unsigned e = (unsigned)(b * O + o) * (unsigned)P + cur.pm[u];
+                idx[u] = p.nebidx[e];
+                av[u] = *(const float4 *)(p.att16 + (size_t)e * 16);
             }
-            wg0 = fmaf(av[u].y, s, wg0); wg1 = fmaf(av[u].z, s, wg1); wg2 = fmaf(av[u].w, s, wg2);
+            L1 nxt;
+            load1(ob0 + 32 * U, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (ob0 + 32 * u >= o1) break;
+                const float s = (cur.zs[u] * scv + shv > 0.f) ? scv * cur.gv[u] : 0.f;
+                const int key = keyof(idx[u]);
+                if (s != 0.f) {
+                    if (key >= 0) atomicAdd(&acc[key * 32 + lane], s);
+                    else atomicAdd(&p.fpart[flat_ * C + c], s);
+                }
+                wg0 = fmaf(av[u].y, s, wg0); wg1 = fmaf(av[u].z, s, wg1); wg2 = fmaf(av[u].w, s, wg2);
+            }
+            cur = nxt;
         }
     }
     __syncthreads();
