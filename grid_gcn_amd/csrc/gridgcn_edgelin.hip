@@ -340,10 +340,18 @@ int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st)
 //   dYsrc[n,c] = sum_{(o,c): src(e*) = n} s[o,c]
 //              + bz_c (cnt(n) (Ysrc[n,c] + b_c) + G(n) . Wg[:,c]) + cnt(n) (cz_c - mu_c bz_c)
 // The edge x channel work (420 M values at cfg4 up2) shrinks to the ncent x C arg-max entries (84 M),
-// scattered with LDS atomics into a per-(cloud, 32-channel slice) copy of the destination rows.
-//   gg_k_edge_lin0_bwd_sparse   grid (nsplit, C/32, B): LDS acc[(N+1)][32]; slice 0 also collects
+// scattered with LDS atomics into a per-(cloud, 16-channel slice) copy of the destination rows.
+//   gg_k_edge_lin0_bwd_sparse   grid (nsplit, C/16, B): LDS acc[(N+1)][16]; slice 0 also collects
 //                               cnt / G per source, sum geo geo^T, sum geo; partials are stored
 //   gg_k_edge_lin0_bwd_finish   dYsrc = partials + dense part; per-source (G, cnt) for dWg
+// The LDS sums are 64-bit FIXED POINT: ds_add_f32 runs at ~2 cycles per active lane on gfx950 (the
+// 42 M float atomics of cfg4 up2 were 270 of this kernel's 650 us, the 13 M of the geo pass another
+// 230), the integer atomics ~8x faster (profiles/r3_sparse_ablation.txt).  Per channel the scale is a
+// power of two set from the workgroup's first round of entries, 2^40 > max |s| * scale >= 2^39: a
+// value is cut at 2^-40 of that maximum (fp32 atomics rounded every partial SUM to 2^-24 of itself),
+// the integer sum is exact whatever the order -- the partials are now bit-reproducible -- and an
+// entry too large for the headroom (2^62 / entries per workgroup) takes the fp32 global-atomic side
+// path that already serves indices clipped into another cloud.
 struct GGEdgeSparse {
     const int *nebidx;       // [B][O*P]
     const float *att16;      // [E][16]
@@ -358,20 +366,26 @@ struct GGEdgeSparse {
     int B, N, O, P, C, nsplit;
 };
 
+// scale 2^k with 2^39 <= m * 2^k < 2^40 for the (finite, non-negative) maximum m given by its bits;
+// m = 0 (nothing seen): a scale under which every non-zero value exceeds the headroom
+__device__ __forceinline__ double gg_fix_scale(unsigned mbits)
+{
+    if (mbits == 0u || mbits >= 0x7f800000u) return mbits == 0u ? 0x1p+1000 : 0x1p-200;
+    const int e = (int)(mbits >> 23) - 127;          // floor(log2 m) for normal m (denormal: -127)
+    return ldexp(1.0, 39 - e);
+}
+
 __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[16][16];
+    __shared__ unsigned cmax[16], gmax;
     const int N = p.N, O = p.O, P = p.P, C = p.C;
     const int sp = blockIdx.x, sl = blockIdx.y, b = blockIdx.z;
-    const int c0 = sl * 32, tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;   // 32 groups
-    float *acc = lds;                          // [(N+1)][32]
-    float *gs = lds + (size_t)(N + 1) * 32;    // [(N+1)][4], slice 0 only
+    const int c0 = sl * 16, tid = threadIdx.x, lane = tid & 15, grp = tid >> 4;   // 64 groups
+    long long *acc = (long long *)lds;         // [(N+1)][16]
+    long long *gs = (long long *)lds;          // [(N+1)][4]: geo pass of slice 0, BEFORE acc is used
     const bool geo_wg = sl == 0;
-    for (int i = tid; i < (N + 1) * 32; i += 1024) acc[i] = 0.f;
-    if (geo_wg)
-        for (int i = tid; i < (N + 1) * 4; i += 1024) gs[i] = 0.f;
-    __syncthreads();
     const long long rows = (long long)p.B * N;
     const int per = (O + p.nsplit - 1) / p.nsplit;
     const int o0 = sp * per, o1 = o0 + per < O ? o0 + per : O;
@@ -393,13 +407,28 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
         const long long li = flat - ((long long)b * N - 1);
         return (li < 0 || li > N) ? -1 : (int)li;
     };
+    if (tid < 16) cmax[tid] = 0u;
+    if (tid == 16) gmax = 0u;
     // per-source geo sums (channel slice 0 only): a flat walk over the edges of this split, one edge
     // per thread and four in flight (the per-centre form kept P of 32 lanes busy and made these
     // workgroups the tail of the launch)
-    if (geo_wg && o0 < o1) {
-        const int ea = o0 * P, ez = o1 * P;
+    if (geo_wg) {                                                 // (uniform in the workgroup)
+        for (int i = tid; i < (N + 1) * 4; i += 1024) gs[i] = 0;
+        const int ea = o0 < o1 ? o0 * P : 0, ez = o0 < o1 ? o1 * P : 0;
         const float *ab = p.att16 + (size_t)b * O * P * 16;
         constexpr int UG = 4;
+        // scale of the three geo sums from the first round of edges (count: exact integers)
+        float gm = 0.f;
+        if (ea + tid < ez) {
+            const float4 a = *(const float4 *)(ab + (size_t)(ea + tid) * 16);
+            gm = fmaxf(fmaxf(fabsf(a.y), fabsf(a.z)), fabsf(a.w));
+            if (!(gm < 3.0e38f)) gm = 0.f;                        // (NaN / inf never set the scale)
+        }
+        __syncthreads();                                          // gs zeroed, gmax zeroed
+        atomicMax(&gmax, __float_as_uint(gm));
+        __syncthreads();
+        const double gF = gg_fix_scale(gmax);
+        const double gthr = 0x1p+62 / ((double)per * P + 1.0);
         for (int e = ea + tid; e < ez; e += 1024 * UG) {
             float4 a[UG];
             int id[UG];
@@ -414,10 +443,16 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
             for (int u = 0; u < UG; u++) {
                 if (e + 1024 * u >= ez) break;
                 const int key = keyof(id[u]);
-                if (key >= 0) {
-                    atomicAdd(&gs[key * 4 + 0], a[u].y); atomicAdd(&gs[key * 4 + 1], a[u].z);
-                    atomicAdd(&gs[key * 4 + 2], a[u].w); atomicAdd(&gs[key * 4 + 3], 1.f);
+                const double x0 = (double)a[u].y * gF, x1 = (double)a[u].z * gF, x2 = (double)a[u].w * gF;
+                const bool fits = (__builtin_fabs(x0) < gthr) & (__builtin_fabs(x1) < gthr) &
+                                  (__builtin_fabs(x2) < gthr);     // (false for NaN)
+                if (key >= 0 && fits) {
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 0], (unsigned long long)(long long)x0);
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 1], (unsigned long long)(long long)x1);
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 2], (unsigned long long)(long long)x2);
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 3], 1ull);
                 } else {
+                    // (key < 0: the flat row itself; key >= 0: the same row, flat_ = b*N - 1 + key)
                     atomicAdd(&p.fgs[flat_ * 4 + 0], a[u].y); atomicAdd(&p.fgs[flat_ * 4 + 1], a[u].z);
                     atomicAdd(&p.fgs[flat_ * 4 + 2], a[u].w); atomicAdd(&p.fgs[flat_ * 4 + 3], 1.f);
                 }
@@ -427,29 +462,50 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
                 g9[9] += a[u].y; g9[10] += a[u].z; g9[11] += a[u].w;
             }
         }
+        __syncthreads();
+        float *gp_ = p.gpart + (((size_t)b * p.nsplit + sp) * (N + 1)) * 4;
+        const double gi = 1.0 / gF;
+        for (int i = tid; i < (N + 1) * 4; i += 1024)
+            gp_[i] = (i & 3) == 3 ? (float)gs[i] : (float)((double)gs[i] * gi);
+        __syncthreads();                                          // gs read before acc is zeroed
     }
+    for (int i = tid; i < (N + 1) * 16; i += 1024) acc[i] = 0;
     // U centres per group and round.  amax -> nebidx[arg-max edge] -> LDS row is a dependent chain of
     // two memory levels; every level is issued for all U centres at once, and the first level of the
-    // NEXT round is requested before the second level of this one is waited for (the waves of a
-    // workgroup start together and, four per SIMD, stay in step: without the overlap the memory
-    // system idled while they all sat in the second level)
+    // NEXT round is requested before the second level of this one is waited for
     constexpr int U = 8;
     struct L1 { unsigned pm[U]; float gv[U], zs[U]; };
     auto load1 = [&](int ob0, L1 &r) {
         size_t ob[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+            const int o = ob0 + 64 * u < o1 ? ob0 + 64 * u : o0 + grp;
             ob[u] = (size_t)(b * O + o) * C + c;
             r.pm[u] = p.amax[ob[u]];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) { r.gv[u] = p.gval[ob[u]]; r.zs[u] = p.zsel[ob[u]]; }
     };
-    if (cok && o0 + grp < o1) {
-        L1 cur;
+    const bool work = cok && o0 + grp < o1;
+    L1 cur;
+    float sm = 0.f;
+    if (work) {
         load1(o0 + grp, cur);
-        for (int ob0 = o0 + grp; ob0 < o1; ob0 += 32 * U) {
+        // scale of this channel's sums: the largest |scale * gradient| of the first round, whatever
+        // the ReLU mask says (a channel whose first entries are all masked still gets a sane scale)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float v = fabsf(scv * cur.gv[u]);
+            if (o0 + grp + 64 * u < o1 && v < 3.0e38f) sm = fmaxf(sm, v);
+        }
+    }
+    __syncthreads();                                              // acc zeroed, cmax zeroed
+    if (work) atomicMax(&cmax[lane], __float_as_uint(sm));
+    __syncthreads();
+    const double F = gg_fix_scale(cmax[lane]);
+    const double thr = 0x1p+62 / ((double)per + 1.0);
+    if (work) {
+        for (int ob0 = o0 + grp; ob0 < o1; ob0 += 64 * U) {
             int idx[U];
             float4 av[U];
             // (edge numbers in 32 bits -- B*O*P < 2^31 is checked by the launcher: with 64-bit index
@@ -457,22 +513,25 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
             // register pair and waits for each of them in turn)
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int o = ob0 + 32 * u < o1 ? ob0 + 32 * u : o0 + grp;
+                const int o = ob0 + 64 * u < o1 ? ob0 + 64 * u : o0 + grp;
                 const unsigned e = (unsigned)(b * O + o) * (unsigned)P + cur.pm[u];
                 idx[u] = p.nebidx[e];
                 av[u] = *(const float4 *)(p.att16 + (size_t)e * 16);
             }
             L1 nxt;
-            load1(ob0 + 32 * U, nxt);
+            load1(ob0 + 64 * U, nxt);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (ob0 + 32 * u >= o1) break;
+                if (ob0 + 64 * u >= o1) break;
                 const float s = (cur.zs[u] * scv + shv > 0.f) ? scv * cur.gv[u] : 0.f;
                 const int key = keyof(idx[u]);
                 if (s != 0.f) {
-                    if (key >= 0) atomicAdd(&acc[key * 32 + lane], s);
-                    else atomicAdd(&p.fpart[flat_ * C + c], s);
+                    const double x = (double)s * F;
+                    if (key >= 0 && __builtin_fabs(x) < thr)
+                        atomicAdd((unsigned long long *)&acc[key * 16 + lane], (unsigned long long)(long long)x);
+                    else
+                        atomicAdd(&p.fpart[flat_ * C + c], s);
                 }
                 wg0 = fmaf(av[u].y, s, wg0); wg1 = fmaf(av[u].z, s, wg1); wg2 = fmaf(av[u].w, s, wg2);
             }
@@ -480,27 +539,24 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
         }
     }
     __syncthreads();
-    // flush: every element of the LDS copy is stored (the finish kernel sums the splits)
+    // flush: every element of the LDS copy is stored (the finish kernel sums the splits); element i
+    // belongs to channel i & 15 = this thread's own (1024 is a multiple of 16), so to its scale
     float *pp_ = p.part + (((size_t)b * p.nsplit + sp) * (N + 1)) * C;
-    for (int i = tid; i < (N + 1) * 32; i += 1024) {
-        const int key = i >> 5, l = i & 31;
-        if (c0 + l < C) pp_[(size_t)key * C + c0 + l] = acc[i];
-    }
-    if (geo_wg) {
-        float *gp_ = p.gpart + (((size_t)b * p.nsplit + sp) * (N + 1)) * 4;
-        for (int i = tid; i < (N + 1) * 4; i += 1024) gp_[i] = gs[i];
-    }
-    // dWg sparse part: lanes hold channel c, 32 groups -> LDS -> one atomic per channel
+    const double Fi = 1.0 / F;
+    if (cok)
+        for (int i = tid; i < (N + 1) * 16; i += 1024)
+            pp_[(size_t)(i >> 4) * C + c] = (float)((double)acc[i] * Fi);
+    // dWg sparse part: lanes hold channel c, 64 groups -> LDS -> one atomic per channel
     __syncthreads();
-    float *wr = lds;                                   // [3][32][32]
-    wr[(0 * 32 + grp) * 32 + lane] = wg0;
-    wr[(1 * 32 + grp) * 32 + lane] = wg1;
-    wr[(2 * 32 + grp) * 32 + lane] = wg2;
+    float *wr = lds;                                   // [3][64][16]
+    wr[(0 * 64 + grp) * 16 + lane] = wg0;
+    wr[(1 * 64 + grp) * 16 + lane] = wg1;
+    wr[(2 * 64 + grp) * 16 + lane] = wg2;
     __syncthreads();
-    if (tid < 96) {
-        const int j = tid >> 5, l = tid & 31;
+    if (tid < 48) {
+        const int j = tid >> 4, l = tid & 15;
         float v = 0.f;
-        for (int g = 0; g < 32; g++) v += wr[(j * 32 + g) * 32 + l];
+        for (int g = 0; g < 64; g++) v += wr[(j * 64 + g) * 16 + l];
         if (c0 + l < C) atomicAdd(&p.wgs[j * C + c0 + l], (double)v);
     }
     if (geo_wg) {
@@ -566,7 +622,7 @@ size_t gg_edge_lin0_sparse_workspace(int B, int N, int C)
 
 int gg_edge_lin0_sparse_nsplit(int B, int C)
 {
-    int ns = 512 / (B * ((C + 31) / 32));
+    int ns = 512 / (B * ((C + 15) / 16));
     return ns < 1 ? 1 : (ns > 32 ? 32 : ns);
 }
 
@@ -579,9 +635,9 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
                             float *dYsrc, float *Gsum, double *wgs, double *gg, void *workspace,
                             hipStream_t st)
 {
-    size_t lds = (size_t)(N + 1) * 36 * 4;
+    size_t lds = (size_t)(N + 1) * 16 * 8;          // acc[(N+1)][16] int64 (the geo sums alias its start)
     if (lds > 150 * 1024 || C < 1 || (C & 3) || (long long)B * O * P >= (1ll << 31)) return 1;
-    if (lds < 3 * 32 * 32 * 4) lds = 3 * 32 * 32 * 4;
+    if (lds < 3 * 64 * 16 * 4) lds = 3 * 64 * 16 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         // (the kernel also has 1 KB of static LDS: dynamic + static must stay within 160 KB)
@@ -598,7 +654,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
     p.fgs = p.fpart + (size_t)B * N * C;
     p.wgs = wgs; p.gg = gg;
     if (hipMemsetAsync(p.fpart, 0, (size_t)B * N * (C + 4) * sizeof(float), st) != hipSuccess) return 3;
-    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 31) / 32, B), 1024, lds, st>>>(p);
+    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 15) / 16, B), 1024, lds, st>>>(p);
     const long long tot = (long long)B * N * C;
     gg_k_edge_lin0_bwd_finish<<<(int)((tot + 255) / 256), 256, 0, st>>>(
         p.part, p.gpart, Ysrc, Wg, bias, scale, mean, rstd, m1, m2, B, N, C, p.nsplit, dYsrc, Gsum,

@@ -685,3 +685,76 @@ def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     assert rel(s1[..., 4:], s0[..., 4:]) <= 5e-2
     for a, b in zip(p1, p0):
         assert rel(a, b) <= 5e-2, (rel(a, b), a.shape)
+
+
+@pytest.mark.parametrize("B,N,O,P,C,outlier", [(2, 50, 300, 5, 40, False), (2, 50, 300, 5, 40, True),
+                                               (3, 257, 2000, 7, 128, True), (1, 1000, 5000, 5, 16, False)])
+def test_edge_lin0_backward_sparse_fixed_point_matches_float64(B, N, O, P, C, outlier):
+    """gridgcn_edge_lin0_backward_sparse (64-bit fixed-point LDS sums, csrc/gridgcn_edgelin.hip) against
+    a float64 restatement of its formula: dYsrc, Gsum, wgs, gg.  `outlier`: one gradient entry 1e9 times
+    the others (beyond the fixed-point headroom -> the fp32 side path) and a few indices that leave the
+    cloud (the clip of mx.sym.take, utils/ops.py:78-93 -> the same side path)."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(B * 1000 + N + C)
+    E = B * O * P
+    nebidx = torch.randint(0, N, (B, O, P), device=DEV, dtype=torch.int32)
+    if outlier:
+        nebidx[0, 5, :] = -3          # clipped to row 0 of cloud 0
+        nebidx[B - 1, 7, :] = N + 9   # clipped to the last row
+        if B > 1:
+            nebidx[1, 9, :] = -2      # lands in cloud 0 (rows N-2 ... of the cloud in front)
+    att16 = torch.randn(E, 16, device=DEV)
+    amax = torch.randint(0, P, (B * O, C), device=DEV, dtype=torch.uint8)
+    gval = torch.randn(B * O, C, device=DEV)
+    zsel = torch.randn(B * O, C, device=DEV)
+    if outlier:
+        gval[O - 1, C // 2] = 1e9
+        zsel[O - 1, C // 2] = 10.0
+    Ysrc = torch.randn(B * N, C, device=DEV)
+    wgb = torch.randn(4, C, device=DEV)
+    sc, sh, mean = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1, torch.randn(C, device=DEV)
+    rstd, m1, m2 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.1, torch.randn(C, device=DEV) * 0.1
+    if outlier:
+        sc[C // 2], sh[C // 2] = 1.0, 0.0
+    dYsrc = torch.empty(B * N, C, device=DEV)
+    Gsum = torch.empty(B * N, 4, device=DEV)
+    acc64 = torch.zeros(3 * C + 12, dtype=torch.float64, device=DEV)
+    nb = ctypes.c_size_t(0)
+    lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes(B, N, C, ctypes.byref(nb))
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rc = lib.gridgcn_edge_lin0_backward_sparse(
+        p(nebidx), p(att16), p(amax), p(gval), p(zsel), p(Ysrc), p(wgb), p(wgb[3]), p(sc), p(sh), p(mean),
+        p(rstd), p(m1), p(m2), B, N, O, P, C, p(dYsrc), p(Gsum), p(acc64), p(acc64[3 * C:]), p(ws), nb.value,
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    # ---- float64 restatement
+    d = torch.float64
+    rows = B * N
+    s = torch.where(zsel * sc + sh > 0, sc * gval, torch.zeros_like(gval)).to(d)          # fp32 values, as the kernel
+    cen = torch.arange(B * O, device=DEV)
+    estar = cen[:, None] * P + amax.long()                                                    # [B*O, C]
+    bof = (torch.arange(B, device=DEV) * N).repeat_interleave(O * P)
+    flat = (nebidx.reshape(-1).long() + bof).clamp(0, rows - 1)                               # [E]
+    dest = flat[estar]                                                                         # [B*O, C]
+    part = torch.zeros(rows, C, dtype=d, device=DEV)
+    part.scatter_add_(0, dest, s)
+    geo = att16[:, 1:4].to(d)
+    G = torch.zeros(rows, 3, dtype=d, device=DEV).index_add_(0, flat, geo)
+    cnt = torch.zeros(rows, dtype=d, device=DEV).index_add_(0, flat, torch.ones(E, dtype=d, device=DEV))
+    scd, bz = sc.to(d), -(sc.to(d) * rstd.to(d)) * m2.to(d)
+    cz = -(scd * m1.to(d))
+    lin = cnt[:, None] * (Ysrc.to(d) + wgb[3].to(d)) + G @ wgb[:3].to(d)
+    ref = part + bz * lin + cnt[:, None] * (cz - mean.to(d) * bz)
+    tol = 2e-6 * ref.abs().max(dim=0).values + 1e-5
+    assert bool(((dYsrc.to(d) - ref).abs() <= tol).all()), float(((dYsrc.to(d) - ref).abs() / tol).max())
+    assert float((Gsum[:, :3].to(d) - G).abs().max()) <= 1e-5 * max(1.0, float(G.abs().max()))
+    assert torch.equal(Gsum[:, 3].to(d), cnt)
+    gstar = geo[estar]                                                                         # [B*O, C, 3]
+    wgs_ref = (gstar * s[..., None]).sum(0).t()                                                # [3, C]
+    assert float((acc64[:3 * C].view(3, C) - wgs_ref).abs().max()) <= 1e-5 * float(wgs_ref.abs().max())
+    gg_ref = torch.cat([(geo[:, :, None] * geo[:, None, :]).sum(0).reshape(9), geo.sum(0)])
+    assert float((acc64[3 * C:] - gg_ref).abs().max()) <= 2e-5 * float(gg_ref.abs().max())
