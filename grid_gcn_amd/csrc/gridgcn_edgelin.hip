@@ -350,8 +350,8 @@ int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st)
 // power of two set from the workgroup's first round of entries, 2^40 > max |s| * scale >= 2^39: a
 // value is cut at 2^-40 of that maximum (fp32 atomics rounded every partial SUM to 2^-24 of itself),
 // the integer sum is exact whatever the order -- the partials are now bit-reproducible -- and an
-// entry too large for the headroom (2^62 / entries per workgroup) takes the fp32 global-atomic side
-// path that already serves indices clipped into another cloud.
+// entry too large for the headroom (2^47, or 2^62 / entries per workgroup if that is less) takes the
+// fp32 global-atomic side path that already serves indices clipped into another cloud.
 struct GGEdgeSparse {
     const int *nebidx;       // [B][O*P]
     const float *att16;      // [E][16]
@@ -366,13 +366,23 @@ struct GGEdgeSparse {
     int B, N, O, P, C, nsplit;
 };
 
-// scale 2^k with 2^39 <= m * 2^k < 2^40 for the (finite, non-negative) maximum m given by its bits;
-// m = 0 (nothing seen): a scale under which every non-zero value exceeds the headroom
-__device__ __forceinline__ double gg_fix_scale(unsigned mbits)
+// scale 2^k with 2^39 <= m * 2^k < 2^40 for the (finite, non-negative) maximum m given by its bits,
+// k kept within +-100 so that the scale and its inverse are fp32 numbers (m = 0: k = 100 -- whatever
+// value then exceeds the headroom takes the side path, the rest is exact at that scale)
+__device__ __forceinline__ int gg_fix_exp(unsigned mbits)
 {
-    if (mbits == 0u || mbits >= 0x7f800000u) return mbits == 0u ? 0x1p+1000 : 0x1p-200;
-    const int e = (int)(mbits >> 23) - 127;          // floor(log2 m) for normal m (denormal: -127)
-    return ldexp(1.0, 39 - e);
+    const int e = (int)(mbits >> 23) - 127;          // floor(log2 m) for normal m (0 / denormal: -127)
+    const int k = 39 - e;
+    return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+
+// x = trunc(v) as a 64-bit integer for |v| < 2^47, v an fp32 number: 24 high bits and the exact
+// remainder, both through the 32-bit converter (a double / int64 conversion is ~30 slow instructions)
+__device__ __forceinline__ long long gg_fix_i64(float v)
+{
+    const float hf = truncf(v * 0x1p-24f);
+    const float lf = __builtin_fmaf(-hf, 0x1p+24f, v);            // exact: the low bits of v
+    return (long long)(int)hf * 16777216ll + (long long)(int)lf;
 }
 
 __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p)
@@ -427,8 +437,9 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
         __syncthreads();                                          // gs zeroed, gmax zeroed
         atomicMax(&gmax, __float_as_uint(gm));
         __syncthreads();
-        const double gF = gg_fix_scale(gmax);
-        const double gthr = 0x1p+62 / ((double)per * P + 1.0);
+        const int gk = gg_fix_exp(gmax);
+        const float gF = ldexpf(1.f, gk);
+        const float gthr = fminf(0x1p+47f, 0x1p+62f / ((float)per * (float)P + 1.f));
         for (int e = ea + tid; e < ez; e += 1024 * UG) {
             float4 a[UG];
             int id[UG];
@@ -443,13 +454,12 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
             for (int u = 0; u < UG; u++) {
                 if (e + 1024 * u >= ez) break;
                 const int key = keyof(id[u]);
-                const double x0 = (double)a[u].y * gF, x1 = (double)a[u].z * gF, x2 = (double)a[u].w * gF;
-                const bool fits = (__builtin_fabs(x0) < gthr) & (__builtin_fabs(x1) < gthr) &
-                                  (__builtin_fabs(x2) < gthr);     // (false for NaN)
+                const float x0 = a[u].y * gF, x1 = a[u].z * gF, x2 = a[u].w * gF;
+                const bool fits = fabsf(x0) < gthr && fabsf(x1) < gthr && fabsf(x2) < gthr;   // (false for NaN)
                 if (key >= 0 && fits) {
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 0], (unsigned long long)(long long)x0);
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 1], (unsigned long long)(long long)x1);
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 2], (unsigned long long)(long long)x2);
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 0], (unsigned long long)gg_fix_i64(x0));
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 1], (unsigned long long)gg_fix_i64(x1));
+                    atomicAdd((unsigned long long *)&gs[key * 4 + 2], (unsigned long long)gg_fix_i64(x2));
                     atomicAdd((unsigned long long *)&gs[key * 4 + 3], 1ull);
                 } else {
                     // (key < 0: the flat row itself; key >= 0: the same row, flat_ = b*N - 1 + key)
@@ -464,9 +474,9 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
         }
         __syncthreads();
         float *gp_ = p.gpart + (((size_t)b * p.nsplit + sp) * (N + 1)) * 4;
-        const double gi = 1.0 / gF;
+        const float gi = ldexpf(1.f, -gk);
         for (int i = tid; i < (N + 1) * 4; i += 1024)
-            gp_[i] = (i & 3) == 3 ? (float)gs[i] : (float)((double)gs[i] * gi);
+            gp_[i] = (i & 3) == 3 ? (float)gs[i] : (float)gs[i] * gi;
         __syncthreads();                                          // gs read before acc is zeroed
     }
     for (int i = tid; i < (N + 1) * 16; i += 1024) acc[i] = 0;
@@ -502,8 +512,9 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
     __syncthreads();                                              // acc zeroed, cmax zeroed
     if (work) atomicMax(&cmax[lane], __float_as_uint(sm));
     __syncthreads();
-    const double F = gg_fix_scale(cmax[lane]);
-    const double thr = 0x1p+62 / ((double)per + 1.0);
+    const int fk = gg_fix_exp(cmax[lane]);
+    const float F = ldexpf(1.f, fk);
+    const float thr = fminf(0x1p+47f, 0x1p+62f / ((float)per + 1.f));
     if (work) {
         for (int ob0 = o0 + grp; ob0 < o1; ob0 += 64 * U) {
             int idx[U];
@@ -527,9 +538,9 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
                 const float s = (cur.zs[u] * scv + shv > 0.f) ? scv * cur.gv[u] : 0.f;
                 const int key = keyof(idx[u]);
                 if (s != 0.f) {
-                    const double x = (double)s * F;
-                    if (key >= 0 && __builtin_fabs(x) < thr)
-                        atomicAdd((unsigned long long *)&acc[key * 16 + lane], (unsigned long long)(long long)x);
+                    const float x = s * F;
+                    if (key >= 0 && fabsf(x) < thr)
+                        atomicAdd((unsigned long long *)&acc[key * 16 + lane], (unsigned long long)gg_fix_i64(x));
                     else
                         atomicAdd(&p.fpart[flat_ * C + c], s);
                 }
@@ -542,10 +553,10 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
     // flush: every element of the LDS copy is stored (the finish kernel sums the splits); element i
     // belongs to channel i & 15 = this thread's own (1024 is a multiple of 16), so to its scale
     float *pp_ = p.part + (((size_t)b * p.nsplit + sp) * (N + 1)) * C;
-    const double Fi = 1.0 / F;
+    const float Fi = ldexpf(1.f, -fk);
     if (cok)
         for (int i = tid; i < (N + 1) * 16; i += 1024)
-            pp_[(size_t)(i >> 4) * C + c] = (float)((double)acc[i] * Fi);
+            pp_[(size_t)(i >> 4) * C + c] = (float)acc[i] * Fi;
     // dWg sparse part: lanes hold channel c, 64 groups -> LDS -> one atomic per channel
     __syncthreads();
     float *wr = lds;                                   // [3][64][16]
