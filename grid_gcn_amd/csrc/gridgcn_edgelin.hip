@@ -341,7 +341,7 @@ int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st)
 //              + bz_c (cnt(n) (Ysrc[n,c] + b_c) + G(n) . Wg[:,c]) + cnt(n) (cz_c - mu_c bz_c)
 // The edge x channel work (420 M values at cfg4 up2) shrinks to the ncent x C arg-max entries (84 M),
 // scattered with LDS atomics into a per-(cloud, 16-channel slice) copy of the destination rows.
-//   gg_k_edge_lin0_bwd_sparse   grid (nsplit, C/16, B): LDS acc[(N+1)][16]; slice 0 also collects
+//   gg_k_edge_lin0_bwd_sparse   grid (nsplit, C/16 + 1, B): LDS acc[(N+1)][16]; the last y row collects
 //                               cnt / G per source, sum geo geo^T, sum geo; partials are stored
 //   gg_k_edge_lin0_bwd_finish   dYsrc = partials + dense part; per-source (G, cnt) for dWg
 // The LDS sums are 64-bit FIXED POINT: ds_add_f32 runs at ~2 cycles per active lane on gfx950 (the
@@ -394,8 +394,11 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
     const int sp = blockIdx.x, sl = blockIdx.y, b = blockIdx.z;
     const int c0 = sl * 16, tid = threadIdx.x, lane = tid & 15, grp = tid >> 4;   // 64 groups
     long long *acc = (long long *)lds;         // [(N+1)][16]
-    long long *gs = (long long *)lds;          // [(N+1)][4]: geo pass of slice 0, BEFORE acc is used
-    const bool geo_wg = sl == 0;
+    // the geo pass has workgroups of its own (the last y row of the grid, no channels): short ones
+    // that fill gaps, instead of a tail on every eighth workgroup of the channel slices
+    const bool geo_wg = sl == (int)gridDim.y - 1;
+    long long *gx = (long long *)lds, *gy = gx + (N + 1), *gz = gy + (N + 1);   // [(N+1)] each: one
+    int *gc = (int *)(gz + (N + 1));           // array per component (bank = key, not 4 keys per bank row)
     const long long rows = (long long)p.B * N;
     const int per = (O + p.nsplit - 1) / p.nsplit;
     const int o0 = sp * per, o1 = o0 + per < O ? o0 + per : O;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
     // per thread and four in flight (the per-centre form kept P of 32 lanes busy and made these
     // workgroups the tail of the launch)
     if (geo_wg) {                                                 // (uniform in the workgroup)
-        for (int i = tid; i < (N + 1) * 4; i += 1024) gs[i] = 0;
+        for (int i = tid; i <= N; i += 1024) { gx[i] = 0; gy[i] = 0; gz[i] = 0; gc[i] = 0; }
         const int ea = o0 < o1 ? o0 * P : 0, ez = o0 < o1 ? o1 * P : 0;
         const float *ab = p.att16 + (size_t)b * O * P * 16;
         constexpr int UG = 4;
@@ -457,10 +460,10 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
                 const float x0 = a[u].y * gF, x1 = a[u].z * gF, x2 = a[u].w * gF;
                 const bool fits = fabsf(x0) < gthr && fabsf(x1) < gthr && fabsf(x2) < gthr;   // (false for NaN)
                 if (key >= 0 && fits) {
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 0], (unsigned long long)gg_fix_i64(x0));
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 1], (unsigned long long)gg_fix_i64(x1));
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 2], (unsigned long long)gg_fix_i64(x2));
-                    atomicAdd((unsigned long long *)&gs[key * 4 + 3], 1ull);
+                    atomicAdd((unsigned long long *)&gx[key], (unsigned long long)gg_fix_i64(x0));
+                    atomicAdd((unsigned long long *)&gy[key], (unsigned long long)gg_fix_i64(x1));
+                    atomicAdd((unsigned long long *)&gz[key], (unsigned long long)gg_fix_i64(x2));
+                    atomicAdd(&gc[key], 1);
                 } else {
                     // (key < 0: the flat row itself; key >= 0: the same row, flat_ = b*N - 1 + key)
                     atomicAdd(&p.fgs[flat_ * 4 + 0], a[u].y); atomicAdd(&p.fgs[flat_ * 4 + 1], a[u].z);
@@ -475,11 +478,11 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
         __syncthreads();
         float *gp_ = p.gpart + (((size_t)b * p.nsplit + sp) * (N + 1)) * 4;
         const float gi = ldexpf(1.f, -gk);
-        for (int i = tid; i < (N + 1) * 4; i += 1024)
-            gp_[i] = (i & 3) == 3 ? (float)gs[i] : (float)gs[i] * gi;
-        __syncthreads();                                          // gs read before acc is zeroed
+        for (int i = tid; i <= N; i += 1024)
+            ((float4 *)gp_)[i] = make_float4((float)gx[i] * gi, (float)gy[i] * gi, (float)gz[i] * gi, (float)gc[i]);
+    } else {
+        for (int i = tid; i < (N + 1) * 16; i += 1024) acc[i] = 0;
     }
-    for (int i = tid; i < (N + 1) * 16; i += 1024) acc[i] = 0;
     // U centres per group and round.  amax -> nebidx[arg-max edge] -> LDS row is a dependent chain of
     // two memory levels; every level is issued for all U centres at once, and the first level of the
     // NEXT round is requested before the second level of this one is waited for
@@ -665,7 +668,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
     p.fgs = p.fpart + (size_t)B * N * C;
     p.wgs = wgs; p.gg = gg;
     if (hipMemsetAsync(p.fpart, 0, (size_t)B * N * (C + 4) * sizeof(float), st) != hipSuccess) return 3;
-    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 15) / 16, B), 1024, lds, st>>>(p);
+    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 15) / 16 + 1, B), 1024, lds, st>>>(p);
     const long long tot = (long long)B * N * C;
     gg_k_edge_lin0_bwd_finish<<<(int)((tot + 255) / 256), 256, 0, st>>>(
         p.part, p.gpart, Ysrc, Wg, bias, scale, mean, rstd, m1, m2, B, N, C, p.nsplit, dYsrc, Gsum,
