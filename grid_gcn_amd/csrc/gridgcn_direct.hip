@@ -798,8 +798,10 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     // that three of them fit a CU (with 8-wave workgroups only one did)
     // few row tiles (<= 4 per CU: the layers of the coarse levels, 2 K - 6 K rows): workgroups of 4
     // waves, so that every wave has a SIMD -- and its MFMA pipe -- to itself on 2x as many CUs.  A row
-    // tile is a serial chain of NT * C/2 MFMAs (27 us at NT = 8, C = 256); 8-wave groups ran two such
-    // chains per SIMD on an eighth of the chip (cfg4 up0: 58 -> us)
+    // tile is a serial chain of NT * C/2 MFMAs; 8-wave groups ran two such chains per SIMD on an
+    // eighth of the chip (cfg4, the 2048 centre rows of up0 at NT = 8: 58 -> 48 us; the 6144 edge rows
+    // of down2 at NT = 4: 58 -> 44 us.  What is left is the chain itself: these launches have no second
+    // tile to overlap their loads with)
     const long long ntile = (p.E + 31) >> 5;
     const int threads = (NT <= 2 || ntile <= 1024) ? 256 : 512, nw = threads / 64;
     const bool bf16 = g_mlp_bf16 != 0;

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ log
     if (lane == 0) { red[0][wave] = loss; red[1][wave] = cnt; }
     __syncthreads();
     // both sums leave the workgroup in ONE atomic instruction (two lanes, one 16-byte piece of a
-    // line): every workgroup of the launch adds to the same line, and those requests are served one
-    // after the other -- 2 x 2560 of them were most of this kernel's time at cfg4
+    // line): every workgroup of the launch adds to the same line and those requests are served one
+    // after the other.  cfg4 (655 360 rows): 2 x 2560 requests 70 us, 512 requests 22 us
     if (threadIdx.x < 2) {
         const int t = threadIdx.x;
         atomicAdd(&acc[t], (double)((red[t][0] + red[t][1]) + (red[t][2] + red[t][3])));
