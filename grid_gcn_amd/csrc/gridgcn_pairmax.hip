@@ -228,6 +228,87 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_fwd4(const float *__restrict
     }
 }
 
+// same result with the P neighbours of a (centre, channel quad) dealt to PS lanes (p = sub, sub + PS, ...)
+// and the partial maxima merged by the order of the sequential scan: the larger product wins, the
+// lower p among equal ones.  For the layers whose (centre, quad) count does not fill the chip -- cfg4
+// down0: 131 072 threads = 2 waves per SIMD walking 128 neighbours each, one dependent pair of loads
+// after the other.  A wave holds 64 / PS quads; lane = sub * (64 / PS) + quad, so that the lanes of one
+// sub read a contiguous piece of one row.
+template <int PS>
+__global__ __launch_bounds__(256) void gg_k_pairmax_fwd4_split(
+    const float *__restrict__ Zp, const float *__restrict__ Za, const float *__restrict__ scp,
+    const float *__restrict__ shp, const float *__restrict__ sca, const float *__restrict__ sha,
+    long long ncent, int P, int C, float *__restrict__ agg, unsigned char *__restrict__ amax,
+    float *__restrict__ zsel, int lda)
+{
+    constexpr int G = 64 / PS;
+    const int C4 = C >> 2;
+    const long long total4 = ncent * C4;
+    const int lane = threadIdx.x & 63, sub = lane / G, ql = lane - sub * G;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long t = wave * G + ql;
+    const bool valid = t < total4;
+    if (!valid) t = total4 - 1;                  // (no early exit: the lane takes part in the merge)
+    const long long o = t / C4;
+    const int c = (int)(t - o * C4) * 4;
+    const float4 a1 = *(const float4 *)(scp + c), b1 = *(const float4 *)(shp + c);
+    const float4 a2 = *(const float4 *)(sca + c), b2 = *(const float4 *)(sha + c);
+    const float *zp = Zp + (o * P) * C + c, *za = Za + (o * P) * C + c;
+    const float a1v[4] = {a1.x, a1.y, a1.z, a1.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+    const float a2v[4] = {a2.x, a2.y, a2.z, a2.w}, b2v[4] = {b2.x, b2.y, b2.z, b2.w};
+    float best[4], zps[4], zas[4];
+    int bi[4];
+    const int pfirst = sub < P ? sub : 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        best[i] = -__builtin_inff(); bi[i] = pfirst;
+        zps[i] = zp[(size_t)pfirst * C + i]; zas[i] = za[(size_t)pfirst * C + i];
+    }
+    constexpr int UL = 4;                        // rows in flight per lane
+    for (int p0 = sub; p0 < P; p0 += PS * UL) {
+        float4 z1[UL], z2[UL];
+#pragma unroll
+        for (int u = 0; u < UL; u++) {
+            const int p = p0 + PS * u < P ? p0 + PS * u : p0;
+            z1[u] = *(const float4 *)(zp + (size_t)p * C);
+            z2[u] = *(const float4 *)(za + (size_t)p * C);
+        }
+#pragma unroll
+        for (int u = 0; u < UL; u++) {
+            const int p = p0 + PS * u;
+            if (p >= P) break;
+            const float z1v[4] = {z1[u].x, z1[u].y, z1[u].z, z1[u].w}, z2v[4] = {z2[u].x, z2[u].y, z2[u].z, z2[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float y1 = fmaxf(z1v[i] * a1v[i] + b1v[i], 0.f);
+                const float y2 = fmaxf(z2v[i] * a2v[i] + b2v[i], 0.f);
+                const float v = y1 * y2;
+                if (v > best[i]) { best[i] = v; bi[i] = p; zps[i] = z1v[i]; zas[i] = z2v[i]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float ov = __shfl_xor(best[i], off, 64);
+            const int op = __shfl_xor(bi[i], off, 64);
+            const float oz1 = __shfl_xor(zps[i], off, 64), oz2 = __shfl_xor(zas[i], off, 64);
+            const bool take = ov > best[i] || (ov == best[i] && op < bi[i]);
+            best[i] = take ? ov : best[i]; bi[i] = take ? op : bi[i];
+            zps[i] = take ? oz1 : zps[i]; zas[i] = take ? oz2 : zas[i];
+        }
+    }
+    if (!valid || sub != 0) return;
+    const long long e = o * C + c;
+    *(float4 *)(agg + o * lda + c) = make_float4(best[0], best[1], best[2], best[3]);
+    *(unsigned *)(amax + e) = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+    if (zsel) {
+        *(float4 *)(zsel + e) = make_float4(zps[0], zps[1], zps[2], zps[3]);
+        *(float4 *)(zsel + ncent * C + e) = make_float4(zas[0], zas[1], zas[2], zas[3]);
+    }
+}
+
 // thread = (centre strip, channel); requires 256 % C == 0 (C <= 256) like gg_k_bn_bwd_reduce
 __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     const float *__restrict__ Zp, const float *__restrict__ Za, const float *__restrict__ scp,
@@ -531,6 +612,20 @@ int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const flo
                    int lda, unsigned char *amax, float *zsel, hipStream_t st)
 {
     if ((C & 3) == 0 && (lda & 3) == 0) {
+        // fewer (centre, quad) threads than 8 waves per SIMD: the neighbours of one are dealt to 2-8 lanes
+        const long long total4 = ncent * (C / 4);
+        int ps = 1;
+        while (ps < 8 && total4 * ps < 524288 && P >= 8 * ps) ps *= 2;
+        if (ps > 1) {
+            const long long nwave = (total4 + 64 / ps - 1) / (64 / ps);
+            const long long nbs = (nwave + 3) / 4;
+            if (nbs <= 0x7fffffffll) {
+                if (ps == 2) gg_k_pairmax_fwd4_split<2><<<(int)nbs, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax, zsel, lda);
+                else if (ps == 4) gg_k_pairmax_fwd4_split<4><<<(int)nbs, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax, zsel, lda);
+                else gg_k_pairmax_fwd4_split<8><<<(int)nbs, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax, zsel, lda);
+                return hipGetLastError() == hipSuccess ? 0 : 3;
+            }
+        }
         long long nb = (ncent * (C / 4) + 255) / 256;
         int grid = (int)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
         gg_k_pairmax_fwd4<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, sca, sha, ncent, P, C, agg, amax,

@@ -758,3 +758,37 @@ def test_edge_lin0_backward_sparse_fixed_point_matches_float64(B, N, O, P, C, ou
     assert float((acc64[:3 * C].view(3, C) - wgs_ref).abs().max()) <= 1e-5 * float(wgs_ref.abs().max())
     gg_ref = torch.cat([(geo[:, :, None] * geo[:, None, :]).sum(0).reshape(9), geo.sum(0)])
     assert float((acc64[3 * C:] - gg_ref).abs().max()) <= 2e-5 * float(gg_ref.abs().max())
+
+
+@pytest.mark.parametrize("ncent,P,C", [(8192, 128, 64), (2048, 32, 128), (192, 32, 256), (777, 17, 12),
+                                       (40000, 16, 64), (5, 8, 4), (300000, 8, 32)])
+def test_pairmax_fwd_first_argmax_exact(ncent, P, C):
+    """gridgcn_pairmax_fwd: products, first arg max and the selected pre-activations EXACTLY as a
+    sequential scan gives them, for shapes on the neighbour-split kernel (few (centre, quad) threads: the
+    P neighbours dealt to 2-8 lanes, partial maxima merged) and on the one-thread-per-quad kernel (the
+    last shape).  Many exact ties: ReLU zeros, and values quantised to a few levels."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(ncent + P + C)
+    Zp = (torch.randn(ncent * P, C, device=DEV) * 2).round() / 2          # multiples of 0.5: ties
+    Za = (torch.randn(ncent * P, C, device=DEV) * 2).round() / 2
+    sp, hp = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    sa, ha = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3
+    agg = torch.empty(ncent, C, device=DEV)
+    amax = torch.empty(ncent, C, device=DEV, dtype=torch.uint8)
+    zsel = torch.empty(2, ncent * C, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rc = lib.gridgcn_pairmax_fwd(p(Zp), p(Za), p(sp), p(hp), p(sa), p(ha), ncent, P, C, p(agg), C, p(amax),
+                                 p(zsel), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    y1 = torch.relu(Zp * sp + hp).view(ncent, P, C)           # the kernel's fp32 operations, one by one
+    y2 = torch.relu(Za * sa + ha).view(ncent, P, C)
+    v = y1 * y2
+    best = v.max(dim=1).values
+    first = (v == best[:, None, :]).to(torch.uint8).argmax(dim=1)            # first maximal neighbour
+    assert torch.equal(agg, best)
+    assert torch.equal(amax.long(), first)
+    idx = first[:, None, :]
+    assert torch.equal(zsel[0].view(ncent, C), Zp.view(ncent, P, C).gather(1, idx)[:, 0])
+    assert torch.equal(zsel[1].view(ncent, C), Za.view(ncent, P, C).gather(1, idx)[:, 0])
