@@ -6,8 +6,9 @@
 // >= 1.001 * radius leaves ~27 cells x a fraction of a point to test:
 //   gg_k_ball_grid_build  one workgroup per cloud: bounding box of the finite known points, cell
 //                         size, counting sort of the points into cells (LDS atomics), cellStart[]
-//   gg_k_ball_grid_query  one thread per unknown point: the 27 neighbouring cells, exact distance
-//                         (same fp32 expression), top-k by (distance, index)
+//   gg_k_ball_grid_query  one thread per unknown point: the 27 neighbouring cells (nine runs of the
+//                         sorted records, which carry the coordinates), exact distance (same fp32
+//                         expression), top-k by (distance, index)
 // Identical output to the sequential scan: the reference inserts with a strict `<`, i.e. it keeps
 // the k smallest by (distance, index) -- an order that does not depend on the traversal.  A point
 // within the radius differs by less than one cell per axis, and the cell function is monotone, so
@@ -138,7 +139,6 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
 
 template <int K>
 __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restrict__ unknown,
-                                                            const float *__restrict__ known,
                                                             const int *__restrict__ upnum, int n,
                                                             int m, int topk, float r2,
                                                             const GGBallGridInfo *__restrict__ info,
@@ -242,10 +242,10 @@ int gg_ball_knn_grid(const float *unknown, const float *known, const int *downnu
     dim3 grid((n + 255) / 256, B);
     const float r2 = radius * radius;
     if (k <= 3)
-        gg_k_ball_grid_query<3><<<grid, 256, 0, st>>>(unknown, known, upnum, n, m, k, r2, info,
+        gg_k_ball_grid_query<3><<<grid, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info,
                                                       cellStart, sorted, idx);
     else
-        gg_k_ball_grid_query<6><<<grid, 256, 0, st>>>(unknown, known, upnum, n, m, k, r2, info,
+        gg_k_ball_grid_query<6><<<grid, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info,
                                                       cellStart, sorted, idx);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
