@@ -17,6 +17,7 @@
 // ordinary linear kernels.  Same fp32 math as the conv on the gathered tensor up to summation order.
 #include "gridgcn_csr.h"
 #include "gridgcn_edgelin.h"
+#include "gridgcn_fixpt.h"
 
 template <int VPL> struct GGV;
 template <> struct GGV<1> { typedef float T; };
@@ -365,25 +366,6 @@ struct GGEdgeSparse {
     double *gg;              // [12] += (sum geo_j geo_k [9], sum geo_j [3])
     int B, N, O, P, C, nsplit;
 };
-
-// scale 2^k with 2^39 <= m * 2^k < 2^40 for the (finite, non-negative) maximum m given by its bits,
-// k kept within +-100 so that the scale and its inverse are fp32 numbers (m = 0: k = 100 -- whatever
-// value then exceeds the headroom takes the side path, the rest is exact at that scale)
-__device__ __forceinline__ int gg_fix_exp(unsigned mbits)
-{
-    const int e = (int)(mbits >> 23) - 127;          // floor(log2 m) for normal m (0 / denormal: -127)
-    const int k = 39 - e;
-    return k > 100 ? 100 : (k < -100 ? -100 : k);
-}
-
-// x = trunc(v) as a 64-bit integer for |v| < 2^47, v an fp32 number: 24 high bits and the exact
-// remainder, both through the 32-bit converter (a double / int64 conversion is ~30 slow instructions)
-__device__ __forceinline__ long long gg_fix_i64(float v)
-{
-    const float hf = truncf(v * 0x1p-24f);
-    const float lf = __builtin_fmaf(-hf, 0x1p+24f, v);            // exact: the low bits of v
-    return (long long)(int)hf * 16777216ll + (long long)(int)lf;
-}
 
 __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p)
 {
