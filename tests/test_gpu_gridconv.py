@@ -184,9 +184,10 @@ def test_training_step_edge_kernel_matches_torch_ops():
     check (wiring: every term present, every gradient routed), not a precision claim -- those are the
     per-block tests against float64 (test_gpu_gridconv_golden.py, test_gpu_fuzz.py).  Two fp32
     evaluations of the whole network differ by whichever near-tied neighbour maxima they order
-    differently (test_gpu_fuzz.py: one flipped entry moves a gradient column by ~1 %), and the float
-    atomics of the sparse scatter make the last bits run dependent; observed 3e-3 of the largest
-    gradient, bar 1e-2, the loss itself to 1e-4."""
+    differently (test_gpu_fuzz.py: one flipped entry moves a gradient column by ~1 %), and the fp64
+    atomics that collect per-workgroup fp32 partial sums (BatchNorm statistics, weight gradients) make
+    the last bits run dependent (the sparse scatter itself sums in fixed point and is not: csrc/
+    gridgcn_fixpt.h); observed 3e-3 of the largest gradient, bar 1e-2, the loss itself to 1e-4."""
     torch.manual_seed(0)
     net = model.GGCNSeg(model.SEG_81920, fixed_seed=True).to(DEV).train()
     data, npn = synth.make_batch(2, 4096, "planes")
