@@ -234,6 +234,7 @@ int gg_ball_knn_grid(const float *unknown, const float *known, const int *downnu
                      void *workspace, hipStream_t st)
 {
     if (k < 1 || k > 6 || !(radius >= 0.f)) return 1;
+    if ((uintptr_t)workspace & 15) return 1;      // float4 records at a 16-byte-aligned OFFSET from it
     GGBallGridInfo *info = (GGBallGridInfo *)workspace;
     int *cellStart = (int *)(info + B);
     float4 *sorted = (float4 *)((char *)workspace + gg_bg_sorted_offset(B));

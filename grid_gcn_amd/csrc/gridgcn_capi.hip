@@ -87,6 +87,7 @@ static int fill_grid(const gridgcn_grid_params *p, int B, int N, bool up, GGGrid
         if (G >= (1ll << 24)) return GRIDGCN_EINVAL;  // the reference indexes voxels in fp32
         gp->shift[j] = p->coord_shift[j];
         gp->vs[j] = p->voxel_size[j];
+        gp->rvs[j] = 1.0f / p->voxel_size[j];
         gp->g[j] = p->grid_size[j];
     }
     const long long k3 = (long long)p->kernel_size * p->kernel_size * p->kernel_size;
@@ -133,6 +134,11 @@ int gridgcn_set_option(int option, int value)
         gg_index_set_tuning(1, value);
         return GRIDGCN_OK;
     }
+    if (option == GRIDGCN_OPT_INDEX_SMALL) {
+        if (value != 0 && value != 1) return GRIDGCN_EINVAL;
+        gg_index_set_tuning(2, value);
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
@@ -141,6 +147,7 @@ int gridgcn_get_option(int option)
     if (option == GRIDGCN_OPT_ATT_BWD_FUSED) return gg_get_att_bwd_fused();
     if (option == GRIDGCN_OPT_INDEX_SLAB_SHIFT) return gg_index_get_tuning(0);
     if (option == GRIDGCN_OPT_INDEX_CHUNK) return gg_index_get_tuning(1);
+    if (option == GRIDGCN_OPT_INDEX_SMALL) return gg_index_get_tuning(2);
     return -1;
 }
 

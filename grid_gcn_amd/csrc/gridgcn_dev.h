@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gridgcn_voxq.h"
 
 #define GG_WAVE 64
 #define GG_PMAX 128   // max_p_grid limit (reference: best[128] gridifyknn.cu:257; LDS slot arrays)
@@ -11,6 +12,7 @@
 struct GGGrid {
     float shift[3];
     float vs[3];
+    float rvs[3];  // 1.0f / vs[j] (IEEE, host): gg_floor_quot
     int g[3];
     int G;     // g0*g1*g2
     int gxy;   // g0*g1
@@ -52,13 +54,14 @@ __device__ __forceinline__ int gg_reservoir_pick(unsigned long long seed, int n)
     return (int)(ceilf(__fmul_rn(u, (float)n)) - 1.0f);
 }
 
-// voxel of a point (gridify.cu:134-143); -1 = dropped.  add then divide, IEEE, no contraction.
+// voxel of a point (gridify.cu:134-143); -1 = dropped.  add then divide, IEEE, no contraction: the
+// floor of the IEEE quotient comes from gg_floor_quot (one multiply + a guarded exact fallback,
+// gridgcn_voxq.h: bit for bit floorf(__fdiv_rn(a, vs)))
 __device__ __forceinline__ int gg_voxel_of(float x, float y, float z, const GGGrid &gp, int *c3)
 {
-    float q0 = __fdiv_rn(__fadd_rn(x, gp.shift[0]), gp.vs[0]);
-    float q1 = __fdiv_rn(__fadd_rn(y, gp.shift[1]), gp.vs[1]);
-    float q2 = __fdiv_rn(__fadd_rn(z, gp.shift[2]), gp.vs[2]);
-    float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+    float f0 = gg_floor_quot(__fadd_rn(x, gp.shift[0]), gp.vs[0], gp.rvs[0]);
+    float f1 = gg_floor_quot(__fadd_rn(y, gp.shift[1]), gp.vs[1], gp.rvs[1]);
+    float f2 = gg_floor_quot(__fadd_rn(z, gp.shift[2]), gp.vs[2], gp.rvs[2]);
     bool ok = (f0 >= 0.0f) && (f0 < (float)gp.g[0]) && (f1 >= 0.0f) && (f1 < (float)gp.g[1]) &&
               (f2 >= 0.0f) && (f2 < (float)gp.g[2]);
     if (!ok) return -1;

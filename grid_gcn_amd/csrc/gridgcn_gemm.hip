@@ -152,12 +152,19 @@ __global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
         }
     }
     if (S > 1) {
+        // Hand-off partials -> ticket -> last arriver.  The partials are written through (sc1 stores) and
+        // drained (vmcnt(0)) before the barrier, which is what gfx950 needs; the release on the ticket
+        // and the acquire fence of the last arriver are what the HIP memory model asks for on top
+        // (one thread per workgroup pays: the release finds nothing dirty to write back).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int t = __hip_atomic_fetch_add(&p.tick[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int t = __hip_atomic_fetch_add(&p.tick[tile], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_last = t == S - 1;
-            if (s_last) __hip_atomic_store(&p.tick[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(&p.tick[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
         if (!s_last) return;

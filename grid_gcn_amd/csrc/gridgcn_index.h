@@ -45,6 +45,7 @@ struct GGIndexWs {
     int NW2;              // split: waves per workgroup of the slab kernel
     int CH;               // split: points per chunk
     int legacy;           // 1: built by the legacy generation
+    int small;            // 1: built by the one-launch kernel for clouds <= 4096 points
 };
 
 size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres, GGIndexWs *ws);
@@ -53,7 +54,7 @@ int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid 
                    hipStream_t st);
 int gg_index_init();
 // plan overrides for measurements: which = 0: shift of log2(slabs per cloud), 1: points per chunk
-// (1024 / 2048 / 4096, 0 = automatic)
+// (1024 / 2048 / 4096, 0 = automatic), 2: one-launch build for clouds <= 4096 points (1 = on)
 void gg_index_set_tuning(int which, int value);
 int gg_index_get_tuning(int which);
 

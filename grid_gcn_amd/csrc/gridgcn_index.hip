@@ -562,6 +562,265 @@ __global__ __launch_bounds__(GG_NT3) void gg_k_centre_slots(
 GG_PROF_SETTER(gridgcn_prof_set_index)
 
 // ------------------------------------------------------------------------------------------
+// Small clouds (N <= 4096 points: layers 1.. of every model, the 1024-point classification input).
+// The three launches above pay three launch ramps and two kernel boundaries for a few hundred KB; here
+// the whole build is ONE launch of one 1024-thread workgroup per cloud, everything in LDS:
+//   1. voxel of every point (list position = point id);
+//   2. stable LSD radix sort of the list by voxel id, <= 8 bits per pass (1-3 passes for G < 2^24),
+//      each pass the same per-wave-counter + ballot split as K1 -- waves own contiguous ranges of the
+//      list, so the order inside a digit never depends on arrival; invalid points drop out in pass 0;
+//   3. segment heads by comparing neighbours of the sorted list: start, population and every item's
+//      rank inside its voxel from ONE block scan of the head flags; the head of a segment is the
+//      voxel's first point (leader);
+//   4. voxel table (zero fill issued at kernel start, heads overwrite behind a drained barrier),
+//      sorted ids, leader bitmap -> rank of first appearance (popcount prefix) -> RVS centre slots,
+//      stage-1 bucket reservoir of over-full voxels -- LDS atomicMax, written out once.
+// Produces exactly what K1-K3 leave in the workspace (vtab, sorted, bkt, slotfirst1, centnum, exact):
+// the query kernels do not know which build ran.  Same arithmetic and the same "largest id wins"
+// rule as above, so the result is the S0 result bit for bit (tests: every golden / fuzz case with
+// N <= 4096 runs through this kernel, and test_small_build_equals_split_build compares the two
+// builds' outputs on the same inputs).
+#define GG_SM_MAXN 4096
+#define GG_SM_MAXO 4096
+#define GG_SM_NW 16
+
+struct GGSmallArgs {
+    const float4 *data;
+    const int *np;
+    int2 *vtab;
+    int *sorted, *bkt, *slotfirst1, *centnum, *exact;
+    int N, B, nbits;
+};
+
+static size_t gg_small_lds(bool with_centres)
+{
+    // vox[2][4096] | id[2][4096] u16 | wc[16][256] | H[4097] | (bkt[4096] | slot[4096] | bm[128] | pre[128])
+    size_t n = 2 * GG_SM_MAXN * 4 + 2 * GG_SM_MAXN * 2 + GG_SM_NW * 256 * 4 + (GG_SM_MAXN + 8) * 4;
+    if (with_centres) n += GG_SM_MAXN * 4 + GG_SM_MAXO * 4 + 256 * 4;
+    return n;
+}
+
+template <int IPT, bool WITH_CENTRES>
+__global__ __launch_bounds__(1024) void gg_k_small_build(GGSmallArgs a, GGGrid gp)
+{
+    constexpr int CHN = 1024 * IPT;
+    extern __shared__ __attribute__((aligned(16))) int ldss[];
+    int *vox0 = ldss, *vox1 = vox0 + GG_SM_MAXN;
+    unsigned short *id0 = (unsigned short *)(vox1 + GG_SM_MAXN), *id1 = id0 + GG_SM_MAXN;
+    int *wc = (int *)(id1 + GG_SM_MAXN);            // [16][256]
+    int *H = wc + GG_SM_NW * 256;                   // [nheads + 1] list positions of the segment heads
+    int *s_bkt = H + GG_SM_MAXN + 8;                // [N]   (centres)
+    int *s_slot = s_bkt + GG_SM_MAXN;               // [O]
+    unsigned *s_bm = (unsigned *)(s_slot + GG_SM_MAXO);   // [128] leader bitmap
+    int *s_pre = (int *)(s_bm + 128);               // [128] leaders below a word
+    __shared__ int s_w[GG_SM_NW];
+    __shared__ long long s_sum[GG_SM_NW];
+    __shared__ int s_flag[GG_SM_NW];
+    const int b = blockIdx.x, N = a.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long seed = gg_seed(gp);
+
+    float4 p[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int ip = wave * (64 * IPT) + j * 64 + lane;
+        p[j] = ip < N ? a.data[(size_t)b * N + ip] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int nvalid = a.np[b];
+    nvalid = nvalid < N ? nvalid : N;
+    // voxel table: empty everywhere first (the heads overwrite their entries in phase 4)
+    int2 *vt = a.vtab + (size_t)b * gp.G;
+    for (int v = tid; v < gp.G; v += 1024) vt[v] = make_int2(0, 0);
+
+    // ---- 1. voxels; weight statistics of the cloud (as K1 / K3) ----
+    {
+        long long aw = 0;
+        int flags = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const int ip = wave * (64 * IPT) + j * 64 + lane;
+            int v = -1;
+            if (ip < nvalid) {
+                v = gg_voxel_of(p[j].x, p[j].y, p[j].z, gp, nullptr);
+                if (v >= 0) {
+                    const float w = p[j].w;
+                    const bool bad = !(truncf(w) == w) || !(fabsf(w) < 8388608.0f);
+                    flags |= (bad ? 1 : 0) | ((w == 1.0f) ? 0 : 2);
+                    aw += bad ? 0 : (long long)fabsf(w);
+                }
+            }
+            vox0[ip] = v;
+            id0[ip] = (unsigned short)ip;
+        }
+        if (WITH_CENTRES) {
+            const long long ws = gg_wave_sum_ll(aw);
+            int f = flags;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) f |= __shfl_xor(f, d, 64);
+            if (lane == 0) { s_sum[wave] = ws; s_flag[wave] = f; }
+        }
+    }
+
+    // ---- 2. stable LSD radix sort by voxel id ----
+    const int npass = a.nbits <= 8 ? 1 : (a.nbits <= 16 ? 2 : 3);
+    int rb = (a.nbits + npass - 1) / npass;
+    rb = rb < 1 ? 1 : rb;
+    const int nb = 1 << rb;
+    int *cv = vox0, *nv = vox1;
+    unsigned short *ci = id0, *ni = id1;
+    int nlist = CHN;                     // pass 0: validity is v >= 0; later: position < nlist
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int pass = 0; pass < npass; pass++) {
+        const int shift = pass * rb;
+        for (int j = tid; j < GG_SM_NW * nb; j += 1024) wc[j] = 0;
+        __syncthreads();
+        int v[IPT], dig[IPT];
+        unsigned short idv[IPT];
+        bool val[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const int pos = wave * (64 * IPT) + j * 64 + lane;
+            v[j] = cv[pos];
+            idv[j] = ci[pos];
+            val[j] = pass == 0 ? v[j] >= 0 : pos < nlist;
+            dig[j] = (v[j] >> shift) & (nb - 1);
+            if (val[j]) atomicAdd(&wc[wave * nb + dig[j]], 1);
+        }
+        __syncthreads();
+        int c[GG_SM_NW];
+        int tot = 0;
+        if (tid < nb) {
+#pragma unroll
+            for (int w = 0; w < GG_SM_NW; w++) c[w] = wc[w * nb + tid];
+#pragma unroll
+            for (int w = 0; w < GG_SM_NW; w++) { const int t = c[w]; c[w] = tot; tot += t; }
+        }
+        int total;
+        const int excl = gg_block_excl_scan<GG_SM_NW>(tot, s_w, &total);
+        if (tid < nb) {
+#pragma unroll
+            for (int w = 0; w < GG_SM_NW; w++) wc[w * nb + tid] = c[w] + excl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const unsigned long long peers = gg_wave_peers(val[j], (unsigned)dig[j], rb);
+            if (val[j]) {
+                const int rank = __popcll(peers & lt), npeer = __popcll(peers);
+                const int base = wc[wave * nb + dig[j]];
+                nv[base + rank] = v[j];
+                ni[base + rank] = idv[j];
+                if (IPT > 1 && rank == npeer - 1) wc[wave * nb + dig[j]] = base + npeer;
+            }
+        }
+        nlist = total;
+        __syncthreads();
+        { int *t = cv; cv = nv; nv = t; }
+        { unsigned short *t = ci; ci = ni; ni = t; }
+    }
+    const int n = nlist;                 // in-grid points of the cloud, cv / ci sorted by (voxel, id)
+
+    // ---- 3. segments: thread t owns the list positions [t*IPT, (t+1)*IPT) ----
+    int *hr = nv;                        // head rank (= segment number) of every list position
+    bool head[IPT];
+    int nh = 0;
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int pos = tid * IPT + j;
+        head[j] = pos < n && (pos == 0 || cv[pos] != cv[pos - 1]);
+        nh += head[j] ? 1 : 0;
+    }
+    int nheads;
+    int run = gg_block_excl_scan<GG_SM_NW>(nh, s_w, &nheads);
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int pos = tid * IPT + j;
+        if (head[j]) H[run++] = pos;
+        if (pos < n) hr[pos] = run - 1;
+    }
+    if (tid == 0) H[nheads] = n;
+    if (WITH_CENTRES) {
+        if (tid < 128) s_bm[tid] = 0u;
+        for (int o = tid; o < gp.O; o += 1024) s_slot[o] = 0;
+    }
+    // (the zero fill of the voxel table must have reached L2 before another wave's head entry)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- 4. outputs ----
+    const size_t gbase = (size_t)b * N;
+    int st_[IPT], pop_[IPT], id_[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int pos = tid * IPT + j;
+        st_[j] = 0; pop_[j] = 0; id_[j] = 0;
+        if (pos < n) {
+            const int r = hr[pos];
+            st_[j] = H[r];
+            pop_[j] = H[r + 1] - st_[j];
+            id_[j] = (int)ci[pos];
+            a.sorted[gbase + pos] = id_[j];
+            if (head[j]) {
+                vt[cv[pos]] = make_int2((int)(gbase + pos), pop_[j]);
+                if (WITH_CENTRES) atomicOr(&s_bm[id_[j] >> 5], 1u << (id_[j] & 31));
+            }
+            if (WITH_CENTRES && pop_[j] > gp.P && pos - st_[j] < gp.P) s_bkt[pos] = -1;
+        }
+    }
+    if (!WITH_CENTRES) return;
+    __syncthreads();
+    {
+        const int pc = tid < 128 ? __popc(s_bm[tid]) : 0;
+        int nlead;
+        const int ex = gg_block_excl_scan<GG_SM_NW>(pc, s_w, &nlead);
+        if (tid < 128) s_pre[tid] = ex;
+    }
+    __syncthreads();
+    const int O = gp.O, P = gp.P;
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int pos = tid * IPT + j;
+        if (pos < n) {
+            const int id = id_[j];
+            const int gi = (int)((long long)b * N + id);
+            if (head[j]) {
+                // rank of first appearance of the voxel = leaders with a smaller id (gridify.cu:165-189)
+                const int t = s_pre[id >> 5] + __popc(s_bm[id >> 5] & ((1u << (id & 31)) - 1u));
+                int sl = t;
+                if (t >= O) sl = gg_reservoir_pick((unsigned long long)(long long)gi + 2ull * seed, t + 1);
+                if (sl < O) atomicMax(&s_slot[sl], id + 1);
+            }
+            if (pop_[j] > P) {
+                // S0: item n < P sits in slot n; item n >= P overwrites slot r(n) if r(n) < P
+                // (gridify.cu:146-153).  Last writer = largest n = largest id.
+                const int nn = pos - st_[j];
+                int sl = nn;
+                if (nn >= P) sl = gg_reservoir_pick((unsigned long long)(long long)gi + seed, nn + 1);
+                if (sl < P) atomicMax(&s_bkt[st_[j] + sl], id);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+        const int pos = tid * IPT + j;
+        if (pos < n && pop_[j] > P && pos - st_[j] < P) a.bkt[gbase + pos] = s_bkt[pos];
+    }
+    for (int o = tid; o < O; o += 1024) a.slotfirst1[(size_t)b * O + o] = s_slot[o];
+    if (tid == 0) {
+        long long ws = 0;
+        int ff = 0;
+#pragma unroll
+        for (int w = 0; w < GG_SM_NW; w++) { ws += s_sum[w]; ff |= s_flag[w]; }
+        a.centnum[b] = nheads < O ? nheads : O;
+        // integer weights with sum |w| < 2^23: S0's total_weight may be summed in any order (bit 0);
+        // every in-grid weight exactly 1 (bit 1)
+        const int ex = (!(ff & 1) && ws < (1ll << 23)) ? 1 : 0;
+        a.exact[b] = ex | ((ex && !(ff & 2)) ? 2 : 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 static unsigned gg_inv_odd(unsigned a)  // inverse of an odd number mod 2^32 (Newton)
 {
     unsigned x = a;
@@ -571,13 +830,19 @@ static unsigned gg_inv_odd(unsigned a)  // inverse of an odd number mod 2^32 (Ne
 
 // plan overrides for measurements (include/gridgcn.h: gridgcn_set_option): shift of log2(slabs per
 // cloud), points per chunk (0 = automatic)
-static int g_opt_kb_shift = 0, g_opt_chunk = 0;
+static int g_opt_kb_shift = 0, g_opt_chunk = 0, g_opt_small = 1;
 void gg_index_set_tuning(int which, int value)
 {
     if (which == 0) g_opt_kb_shift = value;
-    else g_opt_chunk = value;
+    else if (which == 1) g_opt_chunk = value;
+    else g_opt_small = value ? 1 : 0;
 }
-int gg_index_get_tuning(int which) { return which == 0 ? g_opt_kb_shift : g_opt_chunk; }
+int gg_index_get_tuning(int which) { return which == 0 ? g_opt_kb_shift : (which == 1 ? g_opt_chunk : g_opt_small); }
+
+static bool gg_small_ok(int N, const GGGrid &gp, bool with_centres)
+{
+    return g_opt_small && N <= GG_SM_MAXN && (!with_centres || gp.O <= GG_SM_MAXO);
+}
 
 static bool gg_plan(int B, int N, const GGGrid &gp, GGIndexWs *w)
 {
@@ -648,11 +913,23 @@ static size_t gg_k2_lds(int SB, int nchunk, int NW)
 size_t gg_index_workspace_bytes(int B, int N, const GGGrid &gp, bool with_centres, GGIndexWs *ws)
 {
     GGIndexWs w = {};
-    if (!gg_plan(B, N, gp, &w))
-        return gg_index_legacy_workspace_bytes(B, N, gp, with_centres, ws);
     const size_t BG = (size_t)B * gp.G, BN = (size_t)B * N;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    if (gg_small_ok(N, gp, with_centres)) {
+        // one-launch build: only what the query kernels read
+        w.o_slotfirst1 = take(with_centres ? (size_t)B * gp.O * 4 : 0);
+        w.o_vtab = take(BG * 8);
+        w.o_sorted = take(BN * 4);
+        w.o_bkt = take(with_centres ? BN * 4 : 0);
+        w.o_exact = take((size_t)B * 4);
+        w.total = o;
+        w.small = 1;
+        if (ws) *ws = w;
+        return o;
+    }
+    if (!gg_plan(B, N, gp, &w))
+        return gg_index_legacy_workspace_bytes(B, N, gp, with_centres, ws);
     // ---- zeroed by K1 ----
     w.o_slotfirst1 = take(with_centres ? (size_t)B * gp.O * 4 : 0);
     w.o_lbm = take(with_centres ? (size_t)B * ((N + 31) / 32) * 4 : 0);
@@ -685,6 +962,33 @@ int gg_index_build(const float *data, const int *np, int B, int N, const GGGrid 
 {
     if (w.legacy)
         return gg_index_legacy_build(data, np, B, N, gp, with_centres, centnum, wsbase, w, st);
+    if (w.small) {
+        GGSmallArgs a;
+        a.data = (const float4 *)data;
+        a.np = np;
+        a.vtab = (int2 *)(wsbase + w.o_vtab);
+        a.sorted = (int *)(wsbase + w.o_sorted);
+        a.bkt = with_centres ? (int *)(wsbase + w.o_bkt) : nullptr;
+        a.slotfirst1 = with_centres ? (int *)(wsbase + w.o_slotfirst1) : nullptr;
+        a.centnum = centnum;
+        a.exact = (int *)(wsbase + w.o_exact);
+        a.N = N;
+        a.B = B;
+        a.nbits = 0;
+        while (a.nbits < 24 && (1 << a.nbits) < gp.G) a.nbits++;
+        const size_t lds = gg_small_lds(with_centres);
+        const int ipt = N <= 1024 ? 1 : (N <= 2048 ? 2 : 4);
+        if (with_centres) {
+            if (ipt == 1) gg_k_small_build<1, true><<<B, 1024, lds, st>>>(a, gp);
+            else if (ipt == 2) gg_k_small_build<2, true><<<B, 1024, lds, st>>>(a, gp);
+            else gg_k_small_build<4, true><<<B, 1024, lds, st>>>(a, gp);
+        } else {
+            if (ipt == 1) gg_k_small_build<1, false><<<B, 1024, lds, st>>>(a, gp);
+            else if (ipt == 2) gg_k_small_build<2, false><<<B, 1024, lds, st>>>(a, gp);
+            else gg_k_small_build<4, false><<<B, 1024, lds, st>>>(a, gp);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     const GGSplit sp = gg_split_of(w);
     unsigned *part = (unsigned *)(wsbase + w.o_part);
     int *ctab = (int *)(wsbase + w.o_ctab);
@@ -741,6 +1045,13 @@ int gg_index_init()
     for (int i = 0; i < 6; i++)
         if (hipFuncSetAttribute(k2[i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)gg_k2_lds(sb2[i], GG_MAX_CHUNKS, nw2[i])) != hipSuccess)
+            return 3;
+    const void *k3[6] = {(const void *)gg_k_small_build<1, true>, (const void *)gg_k_small_build<2, true>,
+                         (const void *)gg_k_small_build<4, true>, (const void *)gg_k_small_build<1, false>,
+                         (const void *)gg_k_small_build<2, false>, (const void *)gg_k_small_build<4, false>};
+    for (int i = 0; i < 6; i++)
+        if (hipFuncSetAttribute(k3[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)gg_small_lds(i < 3)) != hipSuccess)
             return 3;
     return gg_index_legacy_init();
 }

@@ -951,7 +951,9 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     p.ldd = C4 | 1;
     p.lda = (ntm * 32) | 1;
     // ---- 32 -> 64/128 layer behind a BatchNorm'd layer: dX, sums and dW in one pass over Z ----
-    if (p.dX && p.Wdx && g_opt_att_bwd_fused) {
+    // (a bf16 Z has no other reader: it takes the fused kernel whatever the option says NOW -- the
+    //  storage format was decided at forward time, when the option was on)
+    if (p.dX && p.Wdx && (g_opt_att_bwd_fused || p.zfmt)) {
         const int rc = gg_att_bwd_fused(p, st);
         if (rc != 1) return rc;
     }

@@ -142,7 +142,15 @@ class _PackCache:
     exactly one lookup without a launch of its own: the ~27 pack launches of a step become one.
     Any other lookup (no prepack before it, a second use in the same forward, a weight whose
     version counter has moved since) packs its layer alone, as before.  (Freshness cannot be read
-    off Tensor._version alone: the fused optimizers update weights without moving it.)"""
+    off Tensor._version alone: the fused optimizers update weights without moving it.)
+
+    Ordering contract: forward -> backward -> optimizer step.  The buffers are shared by every forward
+    that uses the Parameter and the views of them are what save_for_backward keeps, so a re-pack between
+    a forward and ITS backward would silently change that backward's operands.  The kernels write
+    through raw pointers, which autograd cannot see -- so every re-pack moves the buffer's version
+    counter by hand (torch.autograd.graph.increment_version) and autograd's own saved-tensor check
+    turns such an interleaving into its "modified by an inplace operation" error instead of wrong
+    gradients (tests/test_model_cpu.py::test_pack_cache_*)."""
 
     def __init__(self):
         self.entries = {}          # key -> dict(W, b, pk, bufs, fresh, ver, desc)
@@ -165,6 +173,9 @@ class _PackCache:
             self._drop(key)        # the id was recycled by another tensor
             e = None
         if e is None:
+            # the Parameter got new storage (net.to(dev), param.data = ...): the entries made for its
+            # old storage hold dead pointers in their descriptors and must not reach a device table
+            self.drop_stale(W, b)
             pk, bufs = self._alloc(W.device, direct, ndx, sizes)
             d = _lib.PackDesc()
             d.W, d.b = W.data_ptr(), b.data_ptr()
@@ -178,8 +189,20 @@ class _PackCache:
             self.tables.clear()
         if not (e["fresh"] and e["ver"] == (W._version, b._version)):
             self._pack_one(lib, W, b, cout, cin_w, rot, cin, ndx, e["bufs"], stream)
+            torch.autograd.graph.increment_version(e["pk"])
         e["fresh"] = False
         return e["bufs"]
+
+    def drop_stale(self, W, b):
+        """forget every entry of (W, b) whose recorded storage is no longer the live one"""
+        live = (W.data_ptr(), b.data_ptr())
+        for k in [k for k in self.entries if k[0] == id(W) and k[1] == id(b) and k[8:10] != live]:
+            self._drop(k)
+
+    def _live(self, k):
+        e = self.entries[k]
+        W, b = e["W"](), e["b"]()
+        return W is not None and b is not None and (W.data_ptr(), b.data_ptr()) == k[8:10]
 
     @staticmethod
     def _alloc(dev, direct, ndx, sizes):
@@ -204,8 +227,9 @@ class _PackCache:
             t = None
         if t is None:
             ids = {id(p) for p in module.parameters()}
-            keys = [k for k, e in self.entries.items()
-                    if k[0] in ids and k[1] in ids and e["W"]() is not None and e["b"]() is not None]
+            for k in [k for k in self.entries if k[0] in ids and k[1] in ids and not self._live(k)]:
+                self._drop(k)      # (storage moved since the entry was made: dead pointers)
+            keys = [k for k in self.entries if k[0] in ids and k[1] in ids]
             if len(keys) < 2:
                 return
             if torch.cuda.is_current_stream_capturing():
@@ -218,6 +242,9 @@ class _PackCache:
                  max(self.entries[k]["desc"].n for k in keys))
             self.tables[id(module)] = t
         _, keys, table, max_n = t
+        if not all(k in self.entries and self._live(k) for k in keys):
+            del self.tables[id(module)]     # a parameter moved under a cached table: rebuild it
+            return self.prepack(module)
         with torch.cuda.device(table.device):
             rc = _lib.load().gridgcn_pack_linear_batch(
                 table.data_ptr(), len(keys), max_n, torch.cuda.current_stream(table.device).cuda_stream)
@@ -225,6 +252,7 @@ class _PackCache:
         for k in keys:
             e = self.entries[k]
             e["fresh"], e["ver"] = True, (e["W"]()._version, e["b"]()._version)
+            torch.autograd.graph.increment_version(e["pk"])
 
 
     def release(self, module):
@@ -1077,7 +1105,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             # the step, written once and read twice -- is STORED as bf16 (its writer's fp32
             # accumulators are rounded once; BatchNorm statistics from the fp32 values).  Only where
             # both readers take it: the source-side max kernel and the fused attention backward.
-            z16 = (Z16_STORAGE and noz and La == 2 and A0 in (16, 32) and C in (64, 128)
+            # (E >= 32: below that the fused backward declines and nothing else reads a bf16 Z)
+            z16 = (Z16_STORAGE and noz and La == 2 and A0 in (16, 32) and C in (64, 128) and E >= 32
                    and lib.gridgcn_get_mlp_precision() == 1
                    and lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 1)
             sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)

@@ -79,6 +79,11 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
 #define GRIDGCN_OPT_INDEX_CHUNK 2      /* [0 = automatic] voxel-index build: points per chunk, 1024 / 2048 /
                                         *     4096.  Both only move work between the build's kernels;
                                         *     results are identical for every setting. */
+#define GRIDGCN_OPT_INDEX_SMALL 3      /* [1] clouds of <= 4096 points (and max_o_grid <= 4096): the whole
+                                        *     voxel-index build as ONE launch, one workgroup per cloud, all
+                                        *     in LDS; 0 = the three-launch build for every size.  Identical
+                                        *     results.  The workspace size depends on it: set it before
+                                        *     asking for *_workspace_bytes, not between that and the call. */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 
@@ -176,7 +181,8 @@ int gridgcn_ball_knn(const float *unknown, const float *known, const int32_t *do
  * insertion over ascending indices keeps the k smallest by (distance, index), whatever the
  * traversal), through a uniform cell grid (cell >= 1.001 * radius, <= 24^3 cells) built over the
  * cloud's known points: 27 cells instead of m points per query.  k <= 6.
- * workspace: gridgcn_ball_knn_grid_workspace_bytes(B, m). */
+ * workspace: gridgcn_ball_knn_grid_workspace_bytes(B, m), 16-byte aligned (it holds float4 records;
+ * a misaligned base is refused with GRIDGCN_EINVAL). */
 int gridgcn_ball_knn_grid_workspace_bytes(int B, int m, size_t *bytes);
 int gridgcn_ball_knn_grid(const float *unknown, const float *known, const int32_t *downnum,
                           const int32_t *upnum, int B, int n, int m, int k, float radius,

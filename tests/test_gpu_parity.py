@@ -239,3 +239,57 @@ def test_torch_ops_namespace_runs_the_same_kernels():
     (g1 * w).sum().backward()
     (g2 * w).sum().backward()
     assert torch.allclose(f1.grad, f2.grad, rtol=1e-5, atol=1e-5)
+
+
+SMALL = [c for c in ALL if c[0].startswith(("gridify", "occaware", "fastrand"))]
+
+
+@pytest.mark.parametrize("name,build,run", SMALL, ids=[c[0] for c in SMALL])
+def test_small_build_equals_split_build(name, build, run):
+    """Clouds of <= 4096 points take the one-launch, all-LDS index build (gg_k_small_build, round 4); the
+    three-launch two-level split stays the build of every larger cloud.  Same inputs through both
+    (GRIDGCN_OPT_INDEX_SMALL 1 / 0): every output byte equal -- and the default path is what the oracle /
+    golden test above has checked.  Cases with N > 4096 or max_o_grid > 4096 run the split build twice
+    (nothing to compare, kept for the ids)."""
+    from grid_gcn_amd import _lib
+    lib = _lib.load()
+    args, kw = build()
+    assert lib.gridgcn_get_option(_lib.OPT_INDEX_SMALL) == 1
+    a = run_hip(name, args, kw)
+    try:
+        _lib.check(lib.gridgcn_set_option(_lib.OPT_INDEX_SMALL, 0), "set_option")
+        b = run_hip(name, args, kw)
+    finally:
+        _lib.check(lib.gridgcn_set_option(_lib.OPT_INDEX_SMALL, 1), "set_option")
+    for j, (x, y) in enumerate(zip(a, b)):
+        assert x.tobytes() == y.tobytes(), "%s output %d" % (name, j)
+
+
+@pytest.mark.parametrize("N,G,P,O,k", [(1, 5, 4, 3, 3), (63, 1, 8, 1, 1), (64, 3, 2, 70, 3), (1000, 9, 4, 50, 3),
+                                       (1025, 17, 3, 2000, 5), (2048, 40, 64, 1024, 7), (3001, 64, 1, 4096, 3),
+                                       (4096, 2, 128, 8, 3), (4096, 200, 5, 4096, 3), (4096, 255, 2, 300, 1)])
+def test_small_build_shapes(N, G, P, O, k):
+    """The one-launch build at the edges of its domain (1 / 2 / 4 items per thread, 1 / 2 / 3 radix passes:
+    G^3 up to 2^24 - 1, one voxel, ragged counts, every voxel over-full, more slots than voxels) against
+    the oracle, bit for bit."""
+    rng = np.random.default_rng(N * 131 + G)
+    B = 3
+    xyz = rng.uniform(-1.05, 1.05, (B, N, 3)).astype(np.float32)
+    w = np.ones((B, N, 1), np.float32)
+    w[1] = rng.integers(1, 5, (N, 1)).astype(np.float32)
+    data = np.concatenate([xyz, w], 2)
+    npn = np.array([[N], [max(1, N - 7)], [max(1, N // 2)]], np.int32)
+    kw = dict(max_p_grid=P, max_o_grid=O, kernel_size=k, stride=1, loc=1, coord_shift=[1.0] * 3,
+              voxel_size=[2.0 / G] * 3, grid_size=[G] * 3, seed=N + 17)
+    want = orc.gridify(data, npn, **kw)
+    got = NP(ops.Gridify(T(data), T(npn), **kw))
+    for j, (g, x) in enumerate(zip(got, want)):
+        assert g.tobytes() == x.tobytes(), "output %d" % j
+    ukw = dict(kw, max_o_grid=777)
+    ukw.pop("stride"); ukw.pop("loc")
+    up = rng.uniform(-1.0, 1.0, (B, 777, 4)).astype(np.float32)
+    upn = np.array([[777], [700], [1]], np.int32)
+    want = orc.gridify_up(data, up, npn, upn, **ukw)
+    got = NP(ops.GridifyUp(T(data), T(up), T(npn), T(upn), **ukw))
+    for j, (g, x) in enumerate(zip(got, want)):
+        assert g.tobytes() == x.tobytes(), "up output %d" % j
