@@ -211,6 +211,63 @@ def time_training(step, steps, warmup, world, dev):
     return dt, t_enq
 
 
+def time_allreduce(sync, world, dev, iters=20):
+    """The gradient collective alone: median ms of one all-reduce of the flat bucket (what the step adds per
+    rank count), with what the process group itself reports -- so that a scaling record can be audited."""
+    out = {"allreduce_ms": None, "flat_bucket_bytes": int(sync.flat.numel() * sync.flat.element_size()),
+           "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+           "dist_backend": dist.get_backend() if dist.is_initialized() else None}
+    if world > 1:
+        buf = torch.zeros_like(sync.flat)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for e0, e1 in ev:
+            e0.record()
+            dist.all_reduce(buf)
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        t = torch.tensor([ts[len(ts) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["allreduce_ms"] = float(t.item())
+    return out
+
+
+def param_sync_spread(net, world, dev):
+    """max - min over the ranks of sum(parameters) after the timed steps: 0.0 when every rank applied the
+    same all-reduced gradients to the same broadcast start (what data parallelism promises)."""
+    with torch.no_grad():
+        s = torch.zeros(1, dtype=torch.float64, device=dev)
+        for prm in net.parameters():
+            s += prm.double().sum()
+    if world > 1:
+        hi, lo = s.clone(), s.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        return float((hi - lo).item())
+    return 0.0
+
+
+def in_step_ms(net, loss_fn, inputs, target, keys, steps=4):
+    """Device time of selected library calls inside EAGER training steps (forward + loss + backward; the
+    kernels behind their real predecessors, real tensors, cold L2): train_ops.LaunchTimers.  The first step
+    is dropped."""
+    from grid_gcn_amd import train_ops
+    train_ops.TIMERS = train_ops.LaunchTimers(keys)
+    try:
+        for _ in range(steps):
+            for prm in net.parameters():
+                prm.grad = None
+            loss_fn(net(*inputs), target).backward()
+        torch.cuda.synchronize()
+        per_step = {k: len(v) // steps for k, v in train_ops.TIMERS.ev.items()}
+        return {k: train_ops.TIMERS.median(k, skip=per_step[k]) for k in keys}, per_step
+    finally:
+        train_ops.TIMERS = None
+
+
 def cagq_roofline(d4, n, kw, B, N, traffic, key, iters=100):
     ms, _ = ops.gridify_timed(d4, n, iters, **kw)
     alg = B * synth.gridify_algorithmic_bytes(N, kw["max_o_grid"], kw["max_p_grid"])
@@ -266,7 +323,8 @@ def main():
 
     if a.config != "cfg4":
         import bench_configs
-        out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step)
+        out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step,
+                                time_allreduce, param_sync_spread)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if world > 1:
@@ -297,6 +355,8 @@ def main():
 
     dt, t_enq = time_training(step, a.steps, a.warmup, world, dev)
     ms_step = dt / a.steps * 1e3
+    allreduce = time_allreduce(sync, world, dev)
+    allreduce["param_sync_spread"] = param_sync_spread(net, world, dev)
     fe, fr = model.seg_forward_flops(net, B, points)
     step_flops = 3.0 * (fe + fr)
     tf_step = step_flops / (ms_step * 1e-3) / 1e12
@@ -319,6 +379,10 @@ def main():
         # host side of the timed region: time to ENQUEUE the K steps (Python + ctypes + launches);
         # the step is GPU-bound while this stays below ms_per_step
         "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
+        # the gradient collective alone and what the process group reports (N > 1; null on one rank)
+        "allreduce_ms": allreduce["allreduce_ms"], "flat_bucket_bytes": allreduce["flat_bucket_bytes"],
+        "dist_world_size": allreduce["dist_world_size"], "dist_backend": allreduce["dist_backend"],
+        "param_sync_spread": allreduce["param_sync_spread"],
         # whole step against the fp32 matrix peak: SURVEY section 8(d) algorithmic flops of the step
         # (3 x forward: per-edge MLPs + per-point MLPs + head) / ms_per_step
         "roofline_step": {"bound": "mfma", "kernel": "whole training step (all kernels)",
@@ -406,7 +470,13 @@ def main():
         # (one-byte amax + fp32 gval) [ncent,C], the previous layer's raw output [E,cin]; write
         # dX [E,cin]
         bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 5.0 * ncent_b * c_b
-        gbs_b = bytes_b / (ms_b * 1e-3) / 1e9
+        # ... and the same two calls timed INSIDE eager training steps (their real predecessors and tensors):
+        # `frac` is what the step pays, `frac_micro` the back-to-back micro-benchmark
+        e_f, cin_f, c_f = B * points, 256, 128
+        kb_, kf_ = ("linear_bwd", int(e_b), cin_b, c_b), ("linear_fwd", e_f, cin_f, c_f)
+        instep, per_step = in_step_ms(net, model.seg_loss, (x, n), lab, [kb_, kf_])
+        ms_b_step = instep[kb_] or ms_b
+        gbs_b = bytes_b / (ms_b_step * 1e-3) / 1e9
         key_b = "att_bwd_fused_E%d_%dto%d" % (int(e_b), cin_b, c_b)
         out["roofline"] = {"bound": "hbm", "kernel": "gg_k_att_bwd_fused + gg_k_att_dw_reduce "
                            "(fused backward of the %d->%d attention conv of GridConv %s over %d "
@@ -417,13 +487,17 @@ def main():
                            "frac": gbs_b / HBM_PEAK_GBS,
                            "traffic": traffic.get(key_b), "traffic_key": key_b,
                            "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
+                           "ms_in_step": instep[kb_], "launches_per_step": per_step[kb_],
+                           "frac_micro": bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "timing": "frac / achieved from ms_in_step (HIP events around the call inside eager "
+                                     "training steps, median); ms_per_launch = back-to-back micro-benchmark",
                            "algorithmic_flops_per_launch": 4.0 * e_b * cin_b * c_b,
                            "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         # the largest MFMA-bound kernel of the step: forward of the 256->128 update conv over
         # all B*N points (previous BatchNorm+ReLU applied while loading, statistics epilogue)
-        e_f, cin_f, c_f = B * points, 256, 128
         ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=mi, device=dev)
-        tf_f = 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12
+        ms_f_step = instep[kf_] or ms_f
+        tf_f = 2.0 * e_f * cin_f * c_f / (ms_f_step * 1e-3) / 1e12
         out["roofline_mfma"] = {"bound": "mfma", "kernel": "gg_k_linear_fwd_direct (%d->%d conv + "
                                 "BN/ReLU prologue + statistics over %d rows)" % (cin_f, c_f, e_f),
                                 "achieved": tf_f, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -431,7 +505,10 @@ def main():
                                 "traffic": traffic.get("linear_fwd_E%d_%dto%d" % (e_f, cin_f, c_f)),
                                 "traffic_key": "linear_fwd_E%d_%dto%d" % (e_f, cin_f, c_f),
                                 "algorithmic_flops_per_launch": 2.0 * e_f * cin_f * c_f,
-                                "ms_per_launch": ms_f, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+                                "ms_per_launch": ms_f, "ms_in_step": instep[kf_],
+                                "launches_per_step": per_step[kf_],
+                                "frac_micro": 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         # ---- the materialising neighbour gather as an operator (SURVEY §8(d) algorithmic bytes):
         #      batch_take_g forward + its sorted backward at the shape of layer up2 ----
         with torch.no_grad():

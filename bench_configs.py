@@ -26,7 +26,8 @@ def _line(metric, value, unit, a, world, ms_step, workload, extra):
     return out
 
 
-def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step):
+def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step, time_allreduce=None,
+        param_sync_spread=None):
     torch.manual_seed(0)
     if a.config == "cfg1":
         # latency of one CAGQ layer on one cloud: the reference's CPU-runnable case
@@ -87,6 +88,9 @@ def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step):
     extra = {"host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "step_mode": step_mode,
              "rccl_capture_probe": getattr(make_step, "probe", None)}
     extra["config_extra"] = {"global_batch": world * B, "points_per_cloud": N}
+    if time_allreduce is not None:
+        extra.update(time_allreduce(sync, world, dev))
+        extra["param_sync_spread"] = param_sync_spread(net, world, dev)
     if flops is not None:
         tf = flops / (ms_step * 1e-3) / 1e12
         peak = MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0

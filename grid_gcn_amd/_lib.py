@@ -14,6 +14,7 @@ OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
 OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
 OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK
 OPT_INDEX_SMALL = 3             # GRIDGCN_OPT_INDEX_SMALL
+OPT_COL_SPLIT = 4               # GRIDGCN_OPT_COL_SPLIT
 
 EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",

@@ -216,6 +216,106 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restr
         if (l < topk) o[l] = besti[l];
 }
 
+// Few queries (the coarse up layers: 2 K - 8 K unknown points): one thread per query is one serial chain
+// of ~50 top-k insertions on a handful of workgroups (59 us for 8192 queries at cfg4 up1 -- as long as the
+// 655 360 queries of up2).  Here L consecutive lanes share a query: candidate f of the query's flat
+// candidate list (its nine record runs one after the other) goes to lane f mod L, every lane keeps its own
+// top-K, and the L lists are merged by K rounds of a group-wide minimum over (distance, index) -- the same
+// total order as above, so the result is the same K records whatever L is.
+template <int K, int L>
+__global__ __launch_bounds__(256) void gg_k_ball_grid_query_ml(const float *__restrict__ unknown,
+                                                               const int *__restrict__ upnum, int n,
+                                                               int m, int topk, float r2,
+                                                               const GGBallGridInfo *__restrict__ info,
+                                                               const int *__restrict__ cellStart,
+                                                               const float4 *__restrict__ sorted,
+                                                               int *__restrict__ idx)
+{
+    const int b = blockIdx.y;
+    const int qi = (int)((blockIdx.x * 256 + threadIdx.x) / L), sub = (int)(threadIdx.x % L);
+    const bool act = qi < n && qi < upnum[b];    // (the same for the L lanes of a group; no early return:
+                                                 //  the merge shuffles need every lane)
+    const int qc = qi < n ? qi : n - 1;
+    const GGBallGridInfo g = info[b];
+    const float *u = unknown + ((size_t)b * n + qc) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const int *cs = cellStart + (size_t)b * (GG_BG_NCMAX + 1);
+    const float4 *sb = sorted + (size_t)b * m;
+    float best[K];
+    int besti[K];
+#pragma unroll
+    for (int l = 0; l < K; l++) { best[l] = FLT_MAX; besti[l] = -1; }
+    const int cx = gg_bg_axis(ux, g.ox, g.inv, g.dx), cy = gg_bg_axis(uy, g.oy, g.inv, g.dy);
+    const int cz = gg_bg_axis(uz, g.oz, g.inv, g.dz);
+    const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < g.dx ? cx + 1 : g.dx - 1;
+    int pa[9], pb[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = act & (z >= 0) & (z < g.dz) & (y >= 0) & (y < g.dy);
+        const int c0 = ((in ? z : cz) * g.dy + (in ? y : cy)) * g.dx;
+        const int a = cs[c0 + x0], e = cs[c0 + x1 + 1];
+        pa[r] = in ? a : 0;
+        pb[r] = in ? e : 0;
+    }
+    int off = 0;                                  // flat position of the run's first record
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const int p0 = pa[r], p1 = pb[r];
+        for (int q = p0 + ((sub - off) & (L - 1)); q < p1; q += L) {
+            const float4 kp = sb[q];
+            const int id = __float_as_int(kp.w);
+            const float dx = __fsub_rn(ux, kp.x);
+            const float dy = __fsub_rn(uy, kp.y);
+            const float dz = __fsub_rn(uz, kp.z);
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (d > r2) continue;                                  // ball_k_nn-inl.h:77
+            bool lt[K];
+#pragma unroll
+            for (int l = 0; l < K; l++)
+                lt[l] = d < best[l] || (d == best[l] && (unsigned)id < (unsigned)besti[l]);
+            if (lt[K - 1]) {
+#pragma unroll
+                for (int l = K - 1; l >= 1; l--) {
+                    besti[l] = lt[l - 1] ? besti[l - 1] : (lt[l] ? id : besti[l]);
+                    best[l] = lt[l - 1] ? best[l - 1] : (lt[l] ? d : best[l]);
+                }
+                besti[0] = lt[0] ? id : besti[0];
+                best[0] = lt[0] ? d : best[0];
+            }
+        }
+        off += p1 - p0;
+    }
+    // merge: K rounds, the group's smallest head by (d, id) leaves its list (empty = (FLT_MAX, -1) sorts last)
+    int res[K];
+#pragma unroll
+    for (int l = 0; l < K; l++) {
+        float d = best[0];
+        int id = besti[0];
+#pragma unroll
+        for (int o = L / 2; o >= 1; o >>= 1) {
+            const float od = __shfl_xor(d, o, 64);
+            const int oi = __shfl_xor(id, o, 64);
+            const bool take = od < d || (od == d && (unsigned)oi < (unsigned)id);
+            d = take ? od : d;
+            id = take ? oi : id;
+        }
+        res[l] = id;
+        if (id != -1 && besti[0] == id) {
+#pragma unroll
+            for (int j = 0; j + 1 < K; j++) { best[j] = best[j + 1]; besti[j] = besti[j + 1]; }
+            best[K - 1] = FLT_MAX;
+            besti[K - 1] = -1;
+        }
+    }
+    if (act && sub == 0) {
+        int *o = idx + ((size_t)b * n + qi) * topk;
+#pragma unroll
+        for (int l = 0; l < K; l++)
+            if (l < topk) o[l] = res[l];
+    }
+}
+
 // workspace: info[B] | cellStart[B][NCMAX+1] | (16-byte aligned) sorted[B][m] (x, y, z, index)
 static size_t gg_bg_sorted_offset(int B)
 {
@@ -242,6 +342,15 @@ int gg_ball_knn_grid(const float *unknown, const float *known, const int *downnu
                                                                      cellStart, sorted);
     dim3 grid((n + 255) / 256, B);
     const float r2 = radius * radius;
+    if ((long long)B * n <= 32768) {
+        // few queries: 8 lanes per query (see gg_k_ball_grid_query_ml)
+        dim3 g8(((unsigned)n * 8 + 255) / 256, B);
+        if (k <= 3)
+            gg_k_ball_grid_query_ml<3, 8><<<g8, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info, cellStart, sorted, idx);
+        else
+            gg_k_ball_grid_query_ml<6, 8><<<g8, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info, cellStart, sorted, idx);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     if (k <= 3)
         gg_k_ball_grid_query<3><<<grid, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info,
                                                       cellStart, sorted, idx);

@@ -139,6 +139,11 @@ int gridgcn_set_option(int option, int value)
         gg_index_set_tuning(2, value);
         return GRIDGCN_OK;
     }
+    if (option == GRIDGCN_OPT_COL_SPLIT) {
+        if (value != 0 && value != 1) return GRIDGCN_EINVAL;
+        gg_set_col_split(value);
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
@@ -148,6 +153,7 @@ int gridgcn_get_option(int option)
     if (option == GRIDGCN_OPT_INDEX_SLAB_SHIFT) return gg_index_get_tuning(0);
     if (option == GRIDGCN_OPT_INDEX_CHUNK) return gg_index_get_tuning(1);
     if (option == GRIDGCN_OPT_INDEX_SMALL) return gg_index_get_tuning(2);
+    if (option == GRIDGCN_OPT_COL_SPLIT) return gg_get_col_split();
     return -1;
 }
 

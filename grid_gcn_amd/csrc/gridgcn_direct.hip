@@ -28,6 +28,11 @@ template <int NT> struct GGBVec { float v[NT]; };
 static int g_mlp_bf16 = 0;
 void gg_set_mlp_bf16(int on) { g_mlp_bf16 = on ? 1 : 0; }
 int gg_get_mlp_bf16() { return g_mlp_bf16; }
+// column split of the forward / dX kernels for layers of few row tiles (GRIDGCN_OPT_COL_SPLIT)
+#define GG_CS_TILES 512       // at most so many 32-row tiles (16 K rows)
+static int g_opt_col_split = 1;
+void gg_set_col_split(int on) { g_opt_col_split = on ? 1 : 0; }
+int gg_get_col_split() { return g_opt_col_split; }
 
 typedef __bf16 ggm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned ggm_u32x4 __attribute__((ext_vector_type(4)));
@@ -101,17 +106,29 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 
 // Z[E, cout] = act(X[E, K]) * W + b, batch statistics of Z in the epilogue.  K % 8 == 0, X row
 // stride K.  NT = ldw / 32 column tiles per wave (all of them: the wave owns full rows of Z).
-template <int NT, bool WLDS, bool EXACT, bool BF16 = false>
-__global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024))) void gg_k_linear_fwd_direct(GGLinFwd p)
+// CS (column split, few row tiles): the layer's ldw / 32 column tiles are dealt to gridDim.y workgroup
+// columns of NT tiles each -- a row tile is ONE serial chain of NT * K / 2 MFMAs per wave, and a layer of
+// 2 K - 6 K rows has too few of them to fill the chip; every column group re-reads the
+// rows (nothing at these sizes) and owns its columns of Z, of the bias and of the statistics.
+template <int NT, bool WLDS, bool EXACT, bool BF16 = false, bool CS = false>
+__global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024)))) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int K = p.K, h = lane >> 5;
+    const int col0 = CS ? (int)blockIdx.y * NT * 32 : 0;
     float *Wl = lds;
     const int ng8 = (K / 2 + 7) >> 3;               // bf16: groups of 8 steps
     float *scl = lds + (BF16 ? ng8 * 64 * NT * 4 : (WLDS ? K * 32 * NT : 0));     // [K] scale, [K] shift
     if (BF16) {
         gg_stage_w_bf16<NT>((ggm_u32x4 *)Wl, p.W, K / 2, tid, blockDim.x);
+    } else if (CS) {
+        // NT of the ntf tiles of every [step][lane] entry of the packed operand
+        const int ntf = p.ldw >> 5, t0 = (int)blockIdx.y * NT;
+        for (int i = tid; i < K * 32 * NT; i += blockDim.x) {
+            const int sl = i / NT, t = i - sl * NT;
+            Wl[i] = t0 + t < ntf ? p.W[(size_t)sl * ntf + t0 + t] : 0.f;
+        }
     } else if (WLDS) {
         const float4 *src = (const float4 *)p.W;
         for (int i = tid; i < K * 8 * NT; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         ssum[t] = 0.f; ssq[t] = 0.f;
-        const int col = t * 32 + (lane & 31);
+        const int col = col0 + t * 32 + (lane & 31);
         bias[t] = col < p.cout ? p.b[col] : 0.f;
     }
     const long long ntile = (p.E + 31) >> 5;
@@ -284,12 +301,12 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
             const float *rb = p.rowbias + (r0 / p.P) * p.cout;
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                const int col = t * 32 + (lane & 31);
+                const int col = col0 + t * 32 + (lane & 31);
                 bias[t] = col < p.cout ? rb[col] : 0.f;
             }
         }
-        float *zp = p.Z + (r0 + 4 * h) * ldz + (lane & 31);
-        unsigned short *zh = (unsigned short *)p.Z + (r0 + 4 * h) * ldz + (lane & 31);   // zfmt 1
+        float *zp = p.Z + (r0 + 4 * h) * ldz + col0 + (lane & 31);
+        unsigned short *zh = (unsigned short *)p.Z + (r0 + 4 * h) * ldz + col0 + (lane & 31);   // zfmt 1
         const bool z16 = p.zfmt != 0;
         auto zst = [&](int off, float z) {
             if (z16) zh[off] = (unsigned short)(gg_pk_bf16(z, 0.f) & 0xffffu);
@@ -301,11 +318,11 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
             // adds one constant, rows step by a scalar offset, column tiles by the immediate offset;
             // bias and statistics two rows per instruction (v_pk_add_f32 / v_pk_fma_f32).
             const gg_rsrc zs = gg_make_rsrc(p.Z ? p.Z + r0 * ldz : (float *)p.sums);
-            const unsigned lo = (unsigned)(4 * h * ldz + (lane & 31)) * 4u;
+            const unsigned lo = (unsigned)(4 * h * ldz + col0 + (lane & 31)) * 4u;
             const bool wr = p.Z != nullptr;            // (nullptr: statistics only)
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                if (EXACT || t * 32 + (lane & 31) < p.cout) {
+                if (EXACT || col0 + t * 32 + (lane & 31) < p.cout) {
                     gg_f32x2 sm = {0.f, 0.f}, sq = {0.f, 0.f};
                     const gg_f32x2 b2 = {bias[t], bias[t]};
 #pragma unroll
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
         } else if (nrows == 32) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                if (EXACT || t * 32 + (lane & 31) < p.cout) {
+                if (EXACT || col0 + t * 32 + (lane & 31) < p.cout) {
                     float sm = 0.f, sq = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const float z = acc[t][r] + bias[t];
-                    if ((EXACT || t * 32 + (lane & 31) < p.cout) && ggm_row(r, lane) < nrows) {
+                    if ((EXACT || col0 + t * 32 + (lane & 31) < p.cout) && ggm_row(r, lane) < nrows) {
                         if (p.Z) zst(((r & 3) + 8 * (r >> 2)) * ldz + t * 32, z);
                         sm += z;
                         sq += z * z;
@@ -372,11 +389,30 @@ __global__ __launch_bounds__(BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (
     __syncthreads();
     for (int i = tid; i < 2 * NT * 32; i += blockDim.x) {
         const int which = i / (NT * 32), col = i - which * NT * 32;
-        if (col >= p.cout) continue;
+        if (col0 + col >= p.cout) continue;
         float v = 0.f;
         for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
-        atomicAdd(&p.sums[which * p.cout + col], (double)v);
+        atomicAdd(&p.sums[which * p.cout + col0 + col], (double)v);
     }
+}
+
+// few row tiles: column groups of NTS tiles over gridDim.y (see the kernel's CS form)
+template <int NTS>
+static int launch_fwd_direct_cs(const GGLinFwd &q, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NTS, true, false, false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    const long long ntile = (q.E + 31) >> 5;
+    const int ntf = q.ldw >> 5, groups = (ntf + NTS - 1) / NTS;
+    size_t lds = (size_t)q.K * 32 * NTS * 4 + (size_t)2 * q.K * 4;
+    const size_t rbytes = (size_t)4 * 2 * NTS * 32 * 4;
+    if (lds < rbytes) lds = rbytes;
+    gg_k_linear_fwd_direct<NTS, true, false, false, true><<<dim3((unsigned)((ntile + 3) / 4), groups), 256, lds, st>>>(q);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
 template <int NT>
@@ -422,6 +458,11 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
         else gg_k_linear_fwd_direct<NT, true, false, true><<<(int)nb, threads, l16, st>>>(q);
         return hipGetLastError() == hipSuccess ? 0 : 3;
     }
+    // few row tiles, several column tiles (fp32 Z): the column tiles go to separate workgroups
+    if (NT >= 2 && ntile <= GG_CS_TILES && !q.zfmt && g_opt_col_split) {
+        if (ntile <= GG_CS_TILES / 4 || NT == 2) return launch_fwd_direct_cs<1>(q, st);
+        return launch_fwd_direct_cs<2>(q, st);
+    }
     const bool wlds = wbytes + sbytes <= 156 * 1024;
     size_t lds = (wlds ? wbytes : 0) + sbytes;
     if (lds < rbytes) lds = rbytes;
@@ -451,13 +492,16 @@ int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st)
 // BatchNorm-backward sums of the PREVIOUS layer (its raw output Aprev read in the C/D layout).
 //   dz = scale*dyr - scale*m1 - scale*rstd*m2*(z - mean),   dyr = dy * (z*scale + shift > 0)
 // NT = ceil(ndx/32) column tiles, NTV = its vector width in Wdx (1/2/4/8).
-template <int NT, bool BF16 = false>
-__global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
+// CS (column split, few row tiles): as in the forward kernel -- gridDim.y column groups of NT tiles, each
+// forming dZ itself; p.dx_wstride = vector width of the packed operand (1/2/4/8).
+template <int NT, bool BF16 = false, bool CS = false>
+__global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd p)
 {
     constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int C = p.C, h = lane >> 5, ldx = p.cin;
+    const int dx_col0 = CS ? (int)blockIdx.y * NT * 32 : p.dx_col0;
     unsigned drop_lo = p.drop_lo, drop_hi = p.drop_hi;
     if (p.drop_thr && p.drop_dev) {  // graph replay: the dropout seed advances through a device scalar
         const unsigned long long sd = (((unsigned long long)drop_hi << 32) | drop_lo) + *p.drop_dev;
@@ -471,9 +515,15 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
     {
         if (BF16) {
             gg_stage_w_bf16<NTV>((ggm_u32x4 *)Wl, p.Wdx, C / 2, tid, blockDim.x);
+        } else if (CS) {
+            const int nvf = p.dx_wstride, t0 = (int)blockIdx.y * NT;
+            for (int i = tid; i < C * 32 * NTV; i += blockDim.x) {
+                const int sl = i / NTV, t = i - sl * NTV;
+                Wl[i] = t0 + t < nvf ? p.Wdx[(size_t)sl * nvf + t0 + t] : 0.f;
+            }
         } else {
             // (column-half mode, NT == 4 of a layout packed for 8 tiles: every second float4)
-            const float4 *src = (const float4 *)p.Wdx + (p.dx_col0 ? 1 : 0);
+            const float4 *src = (const float4 *)p.Wdx + (dx_col0 ? 1 : 0);
             const int ws = p.dx_wstride;
             for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[(size_t)i * ws];
         }
@@ -488,7 +538,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
         // (kept in LDS, not in 4*NT registers per lane: the 8-tile form spilled 70 of them)
         const bool pb = p.pscale != nullptr;
         for (int c = tid; c < NT * 32; c += blockDim.x) {
-            const int col = p.dx_col0 + c;
+            const int col = dx_col0 + c;
             const bool ok = pb && col < p.ndx;
             pcs[c] = ok ? p.pscale[col] : 0.f;
             pcs[NT * 32 + c] = ok ? p.pshift[col] : 0.f;
@@ -674,13 +724,13 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             // a lane adds its constant (4h rows + its column): no per-element address arithmetic,
             // no per-row branches.  (The general form below cost ~30 VALU instructions per element:
             // 7.9 VALU per MFMA at 8 column tiles, profiles/r2_pmc_bwd_gemm.txt.)
-            const gg_rsrc xs = gg_make_rsrc(p.dX + (r0 * ldx + p.dx_col0));
-            const gg_rsrc as = gg_make_rsrc(p.Aprev + (r0 * ldx + p.dx_col0));
+            const gg_rsrc xs = gg_make_rsrc(p.dX + (r0 * ldx + dx_col0));
+            const gg_rsrc as = gg_make_rsrc(p.Aprev + (r0 * ldx + dx_col0));
             const unsigned lo = (unsigned)(4 * h * ldx + (lane & 31)) * 4u;
 #pragma unroll
             for (int t = 0; t < NT; t++) {
-                if (p.dx_col0 + t * 32 + (lane & 31) < p.ndx) {
-                    const bool tbn = prevbn && (p.nbn == 0 || p.dx_col0 + t * 32 < p.nbn);
+                if (dx_col0 + t * 32 + (lane & 31) < p.ndx) {
+                    const bool tbn = prevbn && (p.nbn == 0 || dx_col0 + t * 32 < p.nbn);
                     if (tbn) {
                         const int pc = t * 32 + (lane & 31);
                         const float ps_t = pcs[pc], psh_t = pcs[NT * 32 + pc], pm_t = pcs[2 * NT * 32 + pc],
@@ -716,12 +766,12 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
             }
             continue;
         }
-        const long long base = (r0 + 4 * h) * ldx + p.dx_col0 + (lane & 31);
+        const long long base = (r0 + 4 * h) * ldx + dx_col0 + (lane & 31);
         float *xp = p.dX + base;
         const float *ap = p.Aprev + base;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            if (p.dx_col0 + t * 32 + (lane & 31) < p.ndx) {
+            if (dx_col0 + t * 32 + (lane & 31) < p.ndx) {
                 float s1 = 0.f, s2 = 0.f;
                 const int pc = t * 32 + (lane & 31);
                 const float ps_t = pcs[pc], psh_t = pcs[NT * 32 + pc], pm_t = pcs[2 * NT * 32 + pc],
@@ -729,7 +779,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
                 // all 16 loads of the previous layer's raw output first: dX and Aprev may alias as
                 // far as the compiler knows, so loads placed between the stores were serialised
                 float zpv[16];
-                const bool tbn = prevbn && (p.nbn == 0 || p.dx_col0 + t * 32 < p.nbn);
+                const bool tbn = prevbn && (p.nbn == 0 || dx_col0 + t * 32 < p.nbn);
                 if (tbn) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {          // (rows past the end: any valid address)
@@ -776,10 +826,10 @@ __global__ __launch_bounds__(512) void gg_k_linear_dx_direct(GGLinBwd p)
     __syncthreads();
     for (int i = tid; i < 2 * NT * 32; i += blockDim.x) {
         const int which = i / (NT * 32), col = i - which * NT * 32;
-        if (p.dx_col0 + col >= p.ndx) continue;
+        if (dx_col0 + col >= p.ndx) continue;
         float v = 0.f;
         for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
-        atomicAdd(&p.psums[which * p.cin + p.dx_col0 + col], (double)v);
+        atomicAdd(&p.psums[which * p.cin + dx_col0 + col], (double)v);
     }
 }
 
@@ -805,6 +855,27 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     const long long ntile = (p.E + 31) >> 5;
     const int threads = (NT <= 2 || ntile <= 1024) ? 256 : 512, nw = threads / 64;
     const bool bf16 = g_mlp_bf16 != 0;
+    // few row tiles, several column tiles: the column tiles go to separate workgroups (a row tile is one
+    // serial chain of NT * C / 2 MFMAs per wave)
+    if (NT >= 2 && ntile <= GG_CS_TILES && !bf16 && p.dx_wstride == 1 && p.dx_col0 == 0 && g_opt_col_split) {
+        static bool cs_attr = false;
+        if (!cs_attr) {
+            if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return 3;
+            cs_attr = true;
+        }
+        const int nts = (ntile <= GG_CS_TILES / 4 || NT == 2) ? 1 : 2;
+        GGLinBwd q = p;
+        q.dx_wstride = NTV;
+        size_t l = ((size_t)p.C * 32 * nts + 5 * (size_t)p.C) * 4 + (size_t)4 * nts * 32 * 4;
+        const size_t rb = (size_t)4 * 2 * nts * 32 * 4;
+        if (l < rb) l = rb;
+        const dim3 grid((unsigned)((ntile + 3) / 4), (NT + nts - 1) / nts);
+        if (nts == 1) gg_k_linear_dx_direct<1, false, true><<<grid, 256, l, st>>>(q);
+        else gg_k_linear_dx_direct<2, false, true><<<grid, 256, l, st>>>(q);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     size_t lds = (bf16 ? (size_t)((p.C / 2 + 7) / 8) * 64 * NTV * 16 + 5 * (size_t)p.C * 4
                        : ((size_t)p.C * 32 * NTV + 5 * (size_t)p.C) * 4) + (size_t)4 * NT * 32 * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;

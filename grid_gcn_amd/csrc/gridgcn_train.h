@@ -125,3 +125,5 @@ void gg_set_att_bwd_fused(int on);   // gridgcn_train.hip (GRIDGCN_OPT_ATT_BWD_F
 int gg_get_att_bwd_fused();
 void gg_set_mlp_bf16(int on);
 int gg_get_mlp_bf16();
+void gg_set_col_split(int on);       // gridgcn_direct.hip (GRIDGCN_OPT_COL_SPLIT)
+int gg_get_col_split();

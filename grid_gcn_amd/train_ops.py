@@ -268,6 +268,34 @@ class _PackCache:
 PACKS = _PackCache()
 
 
+class LaunchTimers:
+    """Device time of selected library calls INSIDE a running training step (bench.py: `ms_in_step`).  A
+    micro-benchmark launches a kernel back to back on random tensors with warm caches; the step pays for it
+    behind other kernels' traffic (0.717 ms in the micro-benchmark, 0.823 ms in the traced step).
+    With `train_ops.TIMERS = LaunchTimers({key, ...})` set, the chain code brackets every matching call --
+    key = ("linear_fwd" | "linear_bwd", rows, cin, cout) -- by a pair of events on the launch stream (eager
+    steps only: events cannot be read back from a graph replay).  median(key) -> ms."""
+
+    def __init__(self, keys):
+        self.ev = {k: [] for k in keys}
+
+    def bracket(self, key):
+        lst = self.ev.get(key)
+        if lst is None:
+            return None
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        lst.append(pair)
+        pair[0].record()
+        return pair[1]
+
+    def median(self, key, skip=0):
+        ts = sorted(a.elapsed_time(b) for a, b in self.ev[key][skip:])
+        return ts[len(ts) // 2] if ts else None
+
+
+TIMERS = None
+
+
 def release_packs_hook(module, _inputs, _output):
     PACKS.release(module)
 _LINK_TEMPLATES = {}
@@ -356,6 +384,7 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         so += 2 * cout
         ps = _ptr(pscale) if pscale is not None else None
         ph = _ptr(pshift) if pshift is not None else None
+        t_end = TIMERS.bracket(("linear_fwd", E, cin, cout)) if TIMERS is not None else None
         if direct:
             rc = lib.gridgcn_linear_fwd_direct_ld(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
                                                   cout, ps, ph, _ptr(Z), _ptr(sums), ldz, zfmt,
@@ -363,6 +392,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         else:
             rc = lib.gridgcn_linear_fwd_ld(_ptr(prev), E, cin, _ptr(Wp), _ptr(Bp), K, ldw, cout,
                                            ps, ph, _ptr(Z), _ptr(sums), ldz, stream)
+        if t_end is not None:
+            t_end.record()
         _lib.check(rc, "gridgcn_linear_fwd")
         if last and last_vec is not None:
             vec = last_vec[:, :cout]            # rows of the link's [4, total] table
@@ -445,6 +476,7 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
         else:
             sp = (None, None, 0)
             dyp = _ptr(dY)
+        t_end = TIMERS.bracket(("linear_bwd", E, cin, C)) if TIMERS is not None else None
         rc = lib.gridgcn_linear_bwd_fin(
             dyp, _ptr(Z), _ptr(scales[l]), _ptr(shifts[l]), _ptr(means[l]), _ptr(rstds[l]),
             _ptr(sums), _ptr(m1), _ptr(m2), _ptr(v[2]), _ptr(v[3]),
@@ -457,6 +489,8 @@ def _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs, nd
             _ptr(dX) if want_dx else None, _ptr(dW),
             _ptr(psums) if psums is not None else None, sp[0], sp[1], sp[2],
             _ptr(ws), nbytes.value, _stream(x))
+        if t_end is not None:
+            t_end.record()
         _lib.check(rc, "gridgcn_linear_bwd")
         grads[4 * l] = dW
         dY, sums, sparse = dX, psums, None

@@ -84,6 +84,11 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                         *     in LDS; 0 = the three-launch build for every size.  Identical
                                         *     results.  The workspace size depends on it: set it before
                                         *     asking for *_workspace_bytes, not between that and the call. */
+#define GRIDGCN_OPT_COL_SPLIT 4        /* [1] forward / input-gradient GEMM kernels of layers with <= 16 K rows:
+                                        *     the output column tiles go to separate workgroups (a 32-row
+                                        *     tile is one serial MFMA chain per wave; such layers have too few
+                                        *     tiles to fill the chip); 0 = one wave owns whole rows.  Same
+                                        *     arithmetic per element: identical results. */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 

@@ -119,7 +119,9 @@ def test_gridify_synth200k():
 @pytest.mark.parametrize("n,m,k,radius,kind", [
     (4096, 512, 5, 0.1275, "ball"), (4096, 512, 3, 0.05, "planes"), (2000, 300, 6, 0.4, "ball"),
     (3000, 128, 5, 5.0, "ball"), (3000, 128, 4, 0.0, "ball"), (5000, 1024, 6, 0.02, "lattice"),
-    (1500, 700, 5, 0.3, "special")])
+    (1500, 700, 5, 0.3, "special"),
+    # B * n > 32768: one thread per query (the cases above: eight lanes per query, merged top-k lists)
+    (12000, 256, 5, 0.1275, "ball"), (16384, 300, 3, 0.2, "lattice"), (11000, 200, 6, 0.3, "special")])
 def test_ball_knn_grid_equals_scan(n, m, k, radius, kind):
     """BallKNN through the cell grid (gridgcn_ball_knn_grid) == the S0 oracle's all-pairs scan, bit
     for bit: ties (lattice: many equal distances), queries outside the known points' box, partial

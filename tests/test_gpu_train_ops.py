@@ -93,6 +93,46 @@ def test_mlp_train_matches_torch(E, cin, dims):
             close(b2, b1, 1e-5)
 
 
+@pytest.mark.parametrize("E,cin,dims", [(6000, 128, [128, 128, 256]), (1500, 72, [64, 256, 32]), (2048, 256, [256, 160]),
+                                        (16384, 136, [128, 64]), (95, 64, [256])],
+                         ids=["6000", "1500", "2048", "16384", "95"])
+def test_col_split_equals_whole_rows(E, cin, dims):
+    """Layers of <= 16 K rows deal the output column tiles of the forward / dX kernels to separate
+    workgroups (GRIDGCN_OPT_COL_SPLIT, round 4).  Every element of Z and dX is the same MFMA chain in the
+    same order either way; only the BatchNorm sums are added up over differently shaped groups of rows, so
+    the two paths agree to fp32 round-off of those sums, far inside the bar against the stock modules."""
+    from grid_gcn_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(E)
+    net = mlp(cin, dims).to(DEV).train()
+    x = torch.randn(E, cin, device=DEV)
+    g = torch.randn(E, dims[-1], device=DEV)
+    res = []
+    for on in (1, 0):
+        _lib.check(lib.gridgcn_set_option(_lib.OPT_COL_SPLIT, on), "set_option")
+        try:
+            m = copy.deepcopy(net)
+            xi = x.clone().requires_grad_(True)
+            y = train_ops.mlp_bn_relu_train(xi, list(m))
+            y.backward(g)
+            res.append((y.detach(), xi.grad, [p.grad for p in m.parameters()]))
+        finally:
+            _lib.check(lib.gridgcn_set_option(_lib.OPT_COL_SPLIT, 1), "set_option")
+    (y1, dx1, gp1), (y0, dx0, gp0) = res
+
+    # (a hidden ReLU whose input lies within that round-off of zero may open on one path only and moves
+    #  one row of dX / one row's share of the weight gradients: at most two such rows are tolerated)
+    def close(a, b, tol, rows=0):
+        bad = (a - b).abs() > tol * max(1e-3, float(b.abs().max()))
+        nbad = int(bad.reshape(bad.shape[0], -1).any(dim=1).sum()) if bad.dim() > 1 else int(bad.sum())
+        assert nbad <= rows, (nbad, float((a - b).abs().max()))
+    close(y1, y0, 2e-6, rows=2)
+    close(dx1, dx0, 2e-5, rows=2)
+    flipped = not torch.equal(dx1 != 0, dx0 != 0) or float((dx1 - dx0).abs().max()) > 2e-5 * float(dx0.abs().max())
+    for a, b in zip(gp1, gp0):
+        close(a, b, 2e-2 if flipped else 2e-5, rows=a.shape[0] if flipped else 0)
+
+
 EB_CASES = [
     # B, O, P, cin, pt dims, C
     (2, 300, 5, 131, [128]),

@@ -13,7 +13,7 @@ cp $OUT/pmc/pmc_step.txt $OUT/r3_pmc_step.txt
 bash tools/pmc_step_kernels.sh $1/pmck cfg4 > /dev/null 2>&1; cp $OUT/pmck/kernels_cfg4.txt $OUT/r3_pmc_step_kernels_cfg4.txt
 bash tools/pmc_step_kernels.sh $1/pmckb cfg4 --dtype bf16 > /dev/null 2>&1; cp $OUT/pmckb/kernels_cfg4.txt $OUT/r3_pmc_step_kernels_cfg4_bf16.txt
 bash tools/pmc_gemm.sh $1/pmcg --dense > /dev/null 2>&1; cp $OUT/pmcg/summary.txt $OUT/r3_pmc_bwd_gemm.txt
-bash tools/r2_steptrace.sh $1/trace cfg4 150 --no-micro > /dev/null 2>&1; cp $OUT/trace/steptrace_cfg4.txt $OUT/r3_step_trace_cfg4.txt
+bash tools/steptrace.sh $1/trace cfg4 150 --no-micro > /dev/null 2>&1; cp $OUT/trace/steptrace_cfg4.txt $OUT/r3_step_trace_cfg4.txt
 {
   for m in mfma_peak mfma_valu mfma_mem; do
     hipcc --offload-arch=gfx950 -O3 tools/micro/$m.hip -o /tmp/$m 2>/dev/null
