@@ -474,7 +474,9 @@ def main():
         # `frac` is what the step pays, `frac_micro` the back-to-back micro-benchmark
         e_f, cin_f, c_f = B * points, 256, 128
         kb_, kf_ = ("linear_bwd", int(e_b), cin_b, c_b), ("linear_fwd", e_f, cin_f, c_f)
+        net.train()
         instep, per_step = in_step_ms(net, model.seg_loss, (x, n), lab, [kb_, kf_])
+        net.eval()
         ms_b_step = instep[kb_] or ms_b
         gbs_b = bytes_b / (ms_b_step * 1e-3) / 1e9
         key_b = "att_bwd_fused_E%d_%dto%d" % (int(e_b), cin_b, c_b)

@@ -75,6 +75,29 @@ __device__ __forceinline__ void gg_stage_w_bf16(ggm_u32x4 *dst, const float *__r
     }
 }
 
+// column-split staging: NV of the nvf floats of every [step][lane] entry of a packed operand, first tile t0
+// (t0 % NV == 0, t0 + NV <= nvf), eight vector loads in flight per thread -- a loop of dependent single
+// loads was 30-50 us of a launch whose MFMA chain takes 7
+template <int NV>
+__device__ __forceinline__ void gg_stage_sub(float *Wl, const float *__restrict__ W, int nent, int nvf, int t0,
+                                             int tid, int nthr)
+{
+    typedef float vec_t __attribute__((ext_vector_type(NV)));
+    for (int e0 = tid; e0 < nent; e0 += nthr * 8) {
+        vec_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * nthr;
+            v[u] = *(const vec_t *)(W + (size_t)(e < nent ? e : nent - 1) * nvf + t0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * nthr;
+            if (e < nent) *(vec_t *)(Wl + (size_t)e * NV) = v[u];
+        }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void gg_ldb(const float *__restrict__ base, int idx, float (&b)[NT])
 {
@@ -124,11 +147,7 @@ __global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 
         gg_stage_w_bf16<NT>((ggm_u32x4 *)Wl, p.W, K / 2, tid, blockDim.x);
     } else if (CS) {
         // NT of the ntf tiles of every [step][lane] entry of the packed operand
-        const int ntf = p.ldw >> 5, t0 = (int)blockIdx.y * NT;
-        for (int i = tid; i < K * 32 * NT; i += blockDim.x) {
-            const int sl = i / NT, t = i - sl * NT;
-            Wl[i] = t0 + t < ntf ? p.W[(size_t)sl * ntf + t0 + t] : 0.f;
-        }
+        gg_stage_sub<NT>(Wl, p.W, K * 32, p.ldw >> 5, (int)blockIdx.y * NT, tid, blockDim.x);
     } else if (WLDS) {
         const float4 *src = (const float4 *)p.W;
         for (int i = tid; i < K * 8 * NT; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
@@ -516,11 +535,7 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
         if (BF16) {
             gg_stage_w_bf16<NTV>((ggm_u32x4 *)Wl, p.Wdx, C / 2, tid, blockDim.x);
         } else if (CS) {
-            const int nvf = p.dx_wstride, t0 = (int)blockIdx.y * NT;
-            for (int i = tid; i < C * 32 * NTV; i += blockDim.x) {
-                const int sl = i / NTV, t = i - sl * NTV;
-                Wl[i] = t0 + t < nvf ? p.Wdx[(size_t)sl * nvf + t0 + t] : 0.f;
-            }
+            gg_stage_sub<NTV>(Wl, p.Wdx, C * 32, p.dx_wstride, (int)blockIdx.y * NT, tid, blockDim.x);
         } else {
             // (column-half mode, NT == 4 of a layout packed for 8 tiles: every second float4)
             const float4 *src = (const float4 *)p.Wdx + (dx_col0 ? 1 : 0);

@@ -93,7 +93,7 @@ def test_mlp_train_matches_torch(E, cin, dims):
             close(b2, b1, 1e-5)
 
 
-@pytest.mark.parametrize("E,cin,dims", [(6000, 128, [128, 128, 256]), (1500, 72, [64, 256, 32]), (2048, 256, [256, 160]),
+@pytest.mark.parametrize("E,cin,dims", [(6000, 128, [128, 128, 256]), (1500, 72, [64, 256, 32]), (2048, 256, [256, 128]),
                                         (16384, 136, [128, 64]), (95, 64, [256])],
                          ids=["6000", "1500", "2048", "16384", "95"])
 def test_col_split_equals_whole_rows(E, cin, dims):

@@ -36,16 +36,11 @@ __device__ __forceinline__ f4v lds_rd128(const float *p)
 #define LDS_WAIT(q, n) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
                             for (int l_ = 0; l_ < (n); l_++) asm volatile("" : "+v"(q[l_])); } while (0)
 
-// Global loads and their waits as volatile asm: in plain C the compiler either sinks every "early" load down to its
-// use or (round 3's form of this file) hoists the CONSUMING adds up to the load -- either way nothing stays in
-// flight and the loop measures latency.  Here the order load ... s_waitcnt vmcnt(N) ... use is what is written.
-__device__ __forceinline__ f4v gld128(const float4 *p)
-{
-    f4v r;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p));
-    return r;
-}
-#define VM_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// Plain loads, kept in flight by construction: the group of loads for step s + DS - 1 is issued, a scheduling
+// barrier pins it there, and the values of step s pass through an opaque "+v" asm right where they are consumed
+// -- without it the compiler hoists the CONSUMING adds up to the load (round 3's form of this file: the ring
+// then holds sums, every load is waited for at once and the loop measures latency); the compiler's own
+// s_waitcnt vmcnt(N) then has N = the loads issued since (checked in the ISA of every cell: tools/micro/check_waits.py).
 #define PIN(x) asm volatile("" : "+v"(x))
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -64,15 +59,20 @@ __global__ __launch_bounds__(256, WPS) void k_a(const float4 *src, size_t per_wa
 #pragma unroll
     for (int d = 0; d < DS - 1; d++)
 #pragma unroll
-        for (int l = 0; l < NL; l++) ring[d][l] = gld128(p + (size_t)(d * NL + l) * 64);
+        for (int l = 0; l < NL; l++) ring[d][l] = *(const f4v *)(p + (size_t)(d * NL + l) * 64);
     float a = 1.f, b = 2.f;
-    for (int it = 0; it < iters; it += DS) {
+    // (UR revolutions of the ring per loop body: at the loop header the compiler's wait insertion cannot tell
+    //  the pending loads apart and drains the ring once -- vmcnt(NL) instead of vmcnt(NL * (DS - 1)); with UR = 4
+    //  that costs one exposed latency per 4 * DS steps instead of every DS)
+    constexpr int UR = 4;
+    for (int it = 0; it < iters; it += UR * DS) {
 #pragma unroll
-        for (int d = 0; d < DS; d++) {
+        for (int dd = 0; dd < UR * DS; dd++) {
+            const int d = dd % DS;
 #pragma unroll
             for (int l = 0; l < NL; l++)
-                ring[(d + DS - 1) % DS][l] = gld128(p + (size_t)((it + d + DS - 1) * NL + l) * 64);
-            VM_WAIT(NL * (DS - 1));               // the NL loads of this step have returned
+                ring[(d + DS - 1) % DS][l] = *(const f4v *)(p + (size_t)((it + dd + DS - 1) * NL + l) * 64);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int l = 0; l < NL; l++) PIN(ring[d][l]);
             a = ring[d][0].x; b = ring[d][NL - 1].w;
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256, WPS) void k_a(const float4 *src, size_t per_wa
             for (int l = 0; l < NL; l++) a += ring[d][l].y + ring[d][l].z + ring[d][l].w;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i & 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float s = 0.f;
@@ -152,13 +153,15 @@ __global__ __launch_bounds__(64 * (4 + LW), 1) void k_c(const float4 *src, size_
     const int nload = iters * 4 * NL / LW;
     f4v ring[RK];
 #pragma unroll
-    for (int d = 0; d < RK - 1; d++) ring[d] = gld128(p + (size_t)d * 64);
+    for (int d = 0; d < RK - 1; d++) ring[d] = *(const f4v *)(p + (size_t)d * 64);
     float s = 0.f;
-    for (int it = 0; it < nload; it += RK) {
+    constexpr int UR = 4;
+    for (int it = 0; it < nload; it += UR * RK) {
 #pragma unroll
-        for (int d = 0; d < RK; d++) {
-            ring[(d + RK - 1) % RK] = gld128(p + (size_t)(it + d + RK - 1) * 64);
-            VM_WAIT(RK - 1);
+        for (int dd = 0; dd < UR * RK; dd++) {
+            const int d = dd % RK;
+            ring[(d + RK - 1) % RK] = *(const f4v *)(p + (size_t)(it + dd + RK - 1) * 64);
+            __builtin_amdgcn_sched_barrier(0);
             PIN(ring[d]);
             s += ring[d].x + ring[d].w;
         }
@@ -252,7 +255,7 @@ template <int NL, int RK, int WPS> static void run_a()
     constexpr int regs = RK * 4 + 64 + 24;
     if (regs > 512 / WPS) { printf("%-58s n/a (registers)\n", cell); return; }
     const int nb = 256 * WPS, iters = ITERS * 4 / WPS;
-    const size_t per_wave4 = (size_t)(iters + RK) * NL * 64;
+    const size_t per_wave4 = (size_t)(iters + 5 * RK) * NL * 64;
     if (per_wave4 * nb * 4 > g_src4) { printf("%-58s n/a (buffer)\n", cell); return; }
     const float ms = timeit([&] { k_a<NL, RK, WPS><<<nb, 256>>>(g_src, per_wave4, g_out, iters); });
     report(cell, ms, (double)nb * 4 * iters * 16 * 4096.0, (double)nb * 4 * iters * NL * 1024.0);
@@ -275,7 +278,7 @@ template <int NL, int RK, int LW> static void run_c()
     char cell[128];
     snprintf(cell, sizeof cell, "C 4 MFMA + %2d loader waves/CU, independent NL=%d %2d KB/loader", LW, NL, RK);
     const int nb = 256, iters = ITERS * 4;
-    const size_t per_wave4 = ((size_t)iters * 4 * NL / LW + RK) * 64;
+    const size_t per_wave4 = ((size_t)iters * 4 * NL / LW + 5 * RK) * 64;
     if (per_wave4 * nb * LW > g_src4) { printf("%-58s n/a (buffer)\n", cell); return; }
     const float ms = timeit([&] { k_c<NL, RK, LW><<<nb, 64 * (4 + LW)>>>(g_src, per_wave4, g_out, iters); });
     report(cell, ms, (double)nb * 4 * iters * 16 * 4096.0, (double)nb * 4 * iters * NL * 1024.0);
@@ -309,6 +312,7 @@ template <int NL> static void sweep()
 }
 int main()
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     g_src4 = (size_t)3 << 26;                      // 3 GiB of float4
     CHECK(hipMalloc(&g_src, g_src4 * sizeof(float4)));
     CHECK(hipMemset(g_src, 0, g_src4 * sizeof(float4)));
