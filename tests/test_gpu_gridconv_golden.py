@@ -3,10 +3,10 @@
 they are made and for the bars).
 
   eval-mode BatchNorm  : |HIP - fixture| <= 1e-5 * max(1, max|x|)            (north_star bar)
-  train-mode BatchNorm : |HIP - fixture| <= max(2 * |stock fp32 ops - fixture|, 1e-5 * max(1, max|x|))
-                         (fp32 batch statistics are ill-conditioned on these inputs for ANY
-                          implementation; the kernels must not be worse than the stock ops)
-  gradients            : per tensor, |HIP - fp64| <= max(3 * |stock fp32 - fp64|, 1e-5 * max|g|),
+  train-mode BatchNorm : |HIP - fixture| <= 1e-5 * max(1, max|x|)            (north_star bar; measured
+                         3.5e-7 .. 1.3e-6, profiles/r4_float_parity.txt) and not worse than 2 x the stock fp32 ops
+  gradients            : per tensor, |HIP - fp64| <= 1e-5 * max|g| (measured <= 3.5e-6) and
+                         <= max(3 * |stock fp32 - fp64|, 1e-5 * max|g|),
                          fp64 = the stock modules in float64 on the CPU (their forward is pinned to
                          the restatement at 1e-9 by the CPU tests)
 """
@@ -105,6 +105,9 @@ def test_hip_train_not_worse_than_stock_fp32(name):
                name, e_hip / scale, e_stock / scale, e_hip / max(e_stock, 1e-30), scale))
     assert e_stock <= 1e-4 * scale, (name, e_stock)
     assert e_hip <= max(2.0 * e_stock, 1e-5 * scale), (name, e_hip, e_stock)
+    # round 4: the measured distances (profiles/r4_float_parity.txt: 3.5e-7 .. 1.3e-6 of the scale) sit inside
+    # north_star's bar itself, so the bar is asserted as it stands -- no reference to the stock ops needed
+    assert e_hip <= 1e-5 * scale, (name, e_hip, scale)
 
 
 @pytest.mark.parametrize("name", ["gridconv_seg_L1", "gridconv_up2", "gridconv_cls_L0"])
@@ -171,3 +174,9 @@ def test_hip_gradients_bounded_by_stock_fp32(name):
         report("grad   %-18s %-28s |HIP - fp64| = %.3e * max|g|, |stock - fp64| = %.3e * max|g|, ratio %.2f" % (
             name, k, e_hip / scale, e_stock / scale, e_hip / max(e_stock, 1e-30)))
         assert e_hip <= max(3.0 * e_stock, 1e-5 * scale), (name, k, e_hip, e_stock, scale)
+        # round 4: every gradient tensor within 1e-5 of its own scale (measured: <= 3.5e-6).  The conv biases
+        # in front of a BatchNorm are analytically zero (fp64 leaves ~1e-17 of round-off, the kernels return 0)
+        if not k.endswith("lin.bias"):
+            assert e_hip <= 1e-5 * scale, (name, k, e_hip, scale)
+        else:
+            assert np.abs(g_hip[k]).max() == 0.0 and scale < 1e-9, (name, k, scale)

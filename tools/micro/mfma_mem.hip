@@ -313,7 +313,7 @@ template <int NL> static void sweep()
 int main()
 {
     setvbuf(stdout, nullptr, _IONBF, 0);
-    g_src4 = (size_t)3 << 26;                      // 3 GiB of float4
+    g_src4 = (size_t)20 << 26;                     // 20 Gi float4-bytes/16: 21.5 GB (a cell streams up to 17 GB)
     CHECK(hipMalloc(&g_src, g_src4 * sizeof(float4)));
     CHECK(hipMemset(g_src, 0, g_src4 * sizeof(float4)));
     CHECK(hipMalloc(&g_out, (size_t)1024 * 1024 * 4));
