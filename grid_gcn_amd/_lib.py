@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GG_HIP_LIB: profiling variant of the same library (lib/libgridgcn_hip_prof.so, tools/prof_phases.py)
 LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
-ABI_VERSION = 4                 # include/gridgcn.h: gridgcn_abi_version()
+ABI_VERSION = 5                 # include/gridgcn.h: gridgcn_abi_version()
 OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
 OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
 OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK
@@ -38,7 +38,8 @@ EXPORTS = [
     "gridgcn_linear_fwd_ld", "gridgcn_linear_fwd_direct_ld", "gridgcn_linear_bwd_ld",
     "gridgcn_pairmax_fwd_src_z", "gridgcn_pack_desc_fill", "gridgcn_pack_linear_batch",
     "gridgcn_linear_bwd_fin", "gridgcn_gemm_small", "gridgcn_gemm_small_workspace_bytes",
-    "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd",
+    "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd", "gridgcn_pairmax_bwd_masked",
+    "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
@@ -160,6 +161,12 @@ def load():
     lib.gridgcn_pairmax_fwd.argtypes = [vp] * 6 + [ll, ci, ci, vp, ci, vp, vp, vp]
     lib.gridgcn_pairmax_bwd.restype = ci
     lib.gridgcn_pairmax_bwd.argtypes = [vp] * 12 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_pairmax_bwd_masked.restype = ci
+    lib.gridgcn_pairmax_bwd_masked.argtypes = [vp] * 10 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_att_bwd_noz_workspace_bytes.restype = ci
+    lib.gridgcn_att_bwd_noz_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_att_bwd_noz.restype = ci
+    lib.gridgcn_att_bwd_noz.argtypes = [vp] * 13 + [ci, ll, ci, ci] + [vp] * 8 + [vp, cs, vp]
     lib.gridgcn_bn_relu_apply.restype = ci
     lib.gridgcn_bn_relu_apply.argtypes = [vp, vp, vp, vp, ll, ci, ci, vp]
     lib.gridgcn_bn_relu_dropout_apply.restype = ci

@@ -52,7 +52,7 @@ int gg_pairmax_fwd_src(const float *, const int *, const float *, const float *,
 int gg_pairmax_bwd(const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const float *,
                    const float *, const unsigned char *, long long, int, int, int, float *, float *,
-                   double *, double *, const float *, hipStream_t);
+                   double *, double *, const float *, int, hipStream_t);
 
 int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
                    float *, float *, float *, float *, hipStream_t);
@@ -64,6 +64,12 @@ size_t gg_gemm_small_workspace(int M, int N, int K);
 int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
                        hipStream_t);
 
+bool gg_att_bwd_noz_ok(long long E, int cin, int C);               // gridgcn_attbwd_nz.hip
+size_t gg_att_bwd_noz_workspace(long long E);
+int gg_att_bwd_noz(const float *, const float *, const float *, const float *, const float *, const float *,
+                   const float *, const float *, const float *, const float *, const double *,
+                   const unsigned char *, const float *, int, long long, float *, float *, float *, float *,
+                   float *, float *, double *, double *, void *, hipStream_t);
 int gg_pack_desc_fill(gridgcn_pack_desc *e);
 int gg_pack_linear_batch(const gridgcn_pack_desc *dev, int nlayers, int max_n, hipStream_t st);
 
@@ -119,7 +125,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 4; }
+int gridgcn_abi_version(void) { return 5; }
 
 int gridgcn_set_option(int option, int value)
 {
@@ -605,8 +611,48 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
         ncent < 1 || P < 1 || P > 256 || ld_dagg < C)
         return GRIDGCN_EINVAL;
     int rc = gg_pairmax_bwd(Zp, Za, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
-                            rstd_a, dagg, amax, ncent, P, C, ld_dagg, gp, ga, sums_p, sums_a, zsel,
+                            rstd_a, dagg, amax, ncent, P, C, ld_dagg, gp, ga, sums_p, sums_a, zsel, 0,
                             (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_pairmax_bwd_masked(const float *scale_p, const float *shift_p, const float *mean_p,
+                               const float *rstd_p, const float *scale_a, const float *shift_a,
+                               const float *mean_a, const float *rstd_a, const float *dagg,
+                               const uint8_t *amax, long long ncent, int P, int C, int ld_dagg, float *gp,
+                               float *ga, double *sums_p, double *sums_a, const float *zsel, void *stream)
+{
+    if (!zsel || !dagg || !amax || !gp || !ga || !sums_p || !sums_a || ncent < 1 || P < 1 || P > 256 ||
+        ld_dagg < C)
+        return GRIDGCN_EINVAL;
+    int rc = gg_pairmax_bwd(nullptr, nullptr, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
+                            rstd_a, dagg, amax, ncent, P, C, ld_dagg, gp, ga, sums_p, sums_a, zsel, 1,
+                            (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_att_bwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes)
+{
+    if (!bytes || E < 1) return GRIDGCN_EINVAL;
+    if (!gg_att_bwd_noz_ok(E, cin, C)) return GRIDGCN_EINVAL;
+    *bytes = gg_att_bwd_noz_workspace(E);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshift, const float *pmean,
+                        const float *prstd, const float *W2, const float *b2, const float *scale,
+                        const float *mean, const float *rstd, const double *sums, const uint8_t *amax,
+                        const float *gval, int P, long long E, int cin, int C, float *dX, float *dW, float *m1,
+                        float *m2, float *dgamma, float *dbeta, double *psums, double *s1, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    if (!Z1 || !pscale || !pshift || !pmean || !prstd || !W2 || !b2 || !scale || !mean || !rstd || !sums ||
+        !amax || !gval || !dX || !dW || !m1 || !m2 || !dgamma || !dbeta || !psums || !s1)
+        return GRIDGCN_EINVAL;
+    if (!gg_att_bwd_noz_ok(E, cin, C) || P < 1 || P > 256 || (E % P)) return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_att_bwd_noz_workspace(E)) return GRIDGCN_EWORKSPACE;
+    const int rc = gg_att_bwd_noz(Z1, pscale, pshift, pmean, prstd, W2, b2, scale, mean, rstd, sums, amax, gval,
+                                  P, E, dX, dW, m1, m2, dgamma, dbeta, psums, s1, workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

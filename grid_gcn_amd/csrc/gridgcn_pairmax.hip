@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
     const float *__restrict__ rsa, const float *__restrict__ dagg, const unsigned char *__restrict__ amax,
     long long ncent, int P, int C, float *__restrict__ gp, float *__restrict__ ga,
     double *__restrict__ sums_p, double *__restrict__ sums_a, const float *__restrict__ zsel,
-    int ldd)
+    int ldd, int mask_a)
 {
     __shared__ float sh[4][256];
     const int tid = threadIdx.x;
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
         // gradient w.r.t. the post-ReLU activations; the ReLU mask (y > 0) is applied by the
         // consumer (gg_k_linear_bwd staging) and here for the sums
         const float g1 = g * y2, g2 = g * y1;
-        gp[t] = g1;
-        ga[t] = g2;
         const float d1 = y1 > 0.f ? g1 : 0.f, d2 = y2 > 0.f ? g2 : 0.f;
+        gp[t] = g1;
+        ga[t] = mask_a ? d2 : g2;       // (mask_a: the consumer has no pre-activation to mask with -- gg_att_bwd_noz)
         s1p += d1; s2p += d1 * ((zp - m1) * r1);
         s1a += d2; s2a += d2 * ((za - m2) * r2);
     }
@@ -643,13 +643,13 @@ int gg_pairmax_bwd(const float *Zp, const float *Za, const float *scp, const flo
                    const float *mup, const float *rsp, const float *sca, const float *sha,
                    const float *mua, const float *rsa, const float *dagg, const unsigned char *amax,
                    long long ncent, int P, int C, int ldd, float *gp, float *ga, double *sums_p,
-                   double *sums_a, const float *zsel, hipStream_t st)
+                   double *sums_a, const float *zsel, int mask_a, hipStream_t st)
 {
     if (C > 256 || 256 % C != 0) return 1;
     const int rpp = 256 / C;
     long long nb = (ncent + rpp * 8 - 1) / (rpp * 8);
     int grid = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
     gg_k_pairmax_bwd<<<grid, 256, 0, st>>>(Zp, Za, scp, shp, mup, rsp, sca, sha, mua, rsa, dagg,
-                                           amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel, ldd);
+                                           amax, ncent, P, C, gp, ga, sums_p, sums_a, zsel, ldd, mask_a);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

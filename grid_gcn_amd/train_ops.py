@@ -50,6 +50,9 @@ NO_Z0 = True
 SPARSE_L0 = True
 # bf16 mode (set_mlp_precision("bf16")): bf16 STORAGE of the attention pre-activation of the up layers
 Z16_STORAGE = True
+# fp32 mode, up layers: backward of the second attention conv without its [E, 128] pre-activation
+# (csrc/gridgcn_attbwd_nz.hip): the tensor is not kept for the backward at all
+NOZ_ATT_BWD = True
 
 
 
@@ -1068,6 +1071,36 @@ class _EdgeBlockTrain(torch.autograd.Function):
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
+def _att_bwd_noz(lib, att16, Z1, aS, aH, aM, aR, aWb, aWg, aWx, ndxs, W2, b2, sums_a, amax, ga, P, cwa, st):
+    """backward of the attention chain (10 -> 32 -> 128) of an up layer without the second conv's [E, 128]
+    pre-activation: gridgcn_att_bwd_noz for the second conv (dA1, dW2, its BatchNorm vectors, the BatchNorm-
+    backward sums of the first layer), then the ordinary chain backward for the first conv.  Returns the
+    chain's gradient list [dW, db, dgamma, dbeta] * 2."""
+    E, dev = att16.shape[0], att16.device
+    C, cin = W2.shape
+    dA1 = torch.empty((E, cin), dtype=torch.float32, device=dev)
+    dW2 = torch.empty((C, cin), dtype=torch.float32, device=dev)
+    v = torch.empty((4, C), dtype=torch.float32, device=dev)          # m1, m2, dgamma, dbeta
+    acc = _zeros(3 * cin, torch.float64, dev)
+    psums, s1 = acc[:2 * cin], acc[2 * cin:]
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.gridgcn_att_bwd_noz_workspace_bytes(E, cin, C, ctypes.byref(nbytes)), "att_bwd_noz_workspace")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    t_end = TIMERS.bracket(("linear_bwd", E, cin, C)) if TIMERS is not None else None
+    rc = lib.gridgcn_att_bwd_noz(_ptr(Z1), _ptr(aS[0]), _ptr(aH[0]), _ptr(aM[0]), _ptr(aR[0]),
+                                 _ptr(W2.detach()), _ptr(b2.detach()), _ptr(aS[1]), _ptr(aM[1]), _ptr(aR[1]),
+                                 _ptr(sums_a), _ptr(amax), _ptr(ga), int(P), E, cin, C, _ptr(dA1), _ptr(dW2),
+                                 _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(psums), _ptr(s1),
+                                 _ptr(ws), nbytes.value, st)
+    if t_end is not None:
+        t_end.record()
+    _lib.check(rc, "gridgcn_att_bwd_noz")
+    _, g0 = _chain_backward(lib, att16, [Z1], aS[:1], aH[:1], aM[:1], aR[:1], aWb[:1], aWg[:1], aWx[:1],
+                            ndxs[:1], psums, dA1, None, False, cwa, 0)
+    db2 = _zeros(C, torch.float32, dev)          # a bias in front of a BatchNorm: sum(dZ) == 0
+    return list(g0) + [dW2, db2, v[2], v[3]]
+
+
 class _EdgeBlockSrcTrain(torch.autograd.Function):
     """The whole GridConv edge block from (src, nebidx, cent): the first conv of the point MLP is
     applied to the SOURCE points (Ysrc = features * Wf^T, [B*Nsrc, C0]) and gathered, instead of
@@ -1144,6 +1177,10 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                    and lib.gridgcn_get_mlp_precision() == 1
                    and lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 1)
             sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)
+            # the backward of the second attention conv needs no Z2 (gridgcn_att_bwd_noz): decided HERE, because
+            # the tensor is then not saved
+            nz = (NOZ_ATT_BWD and noz and La == 2 and not z16 and lib.gridgcn_get_mlp_precision() == 0
+                  and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16)
             if noz:
                 rc = lib.gridgcn_pairmax_fwd_src_z(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
@@ -1157,10 +1194,15 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             _lib.check(rc, "gridgcn_pairmax_fwd")
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
+        ctx.nz = nz
+        saZ = list(sa.Z)
+        if nz:
+            saZ[-1] = torch.empty(0, dtype=torch.float32, device=dev)     # Z2: read by nobody any more
         ctx.save_for_backward(
             src, nebidx, att16, amax, Ysrc if noz else Z0, vec0, W0, zsel, wgb,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
-            *sa.Z, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx)
+            *saZ, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx,
+            *((pa[4], pa[5]) if nz else ()))
         ctx.mark_non_differentiable(amax)
         return agg if out is not None else agg.reshape(B, O, C)
 
@@ -1178,6 +1220,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         pZ, pS, pH, pM, pR, pWb, pWg, pWx = (t[o + k * L1:o + (k + 1) * L1] for k in range(8))
         o += 8 * L1
         aZ, aS, aH, aM, aR, aWb, aWg, aWx = (t[o + k * La:o + (k + 1) * La] for k in range(8))
+        o += 8 * La
+        nz = ctx.nz
+        W2, b2 = (t[o], t[o + 1]) if nz else (None, None)
         dev = src.device
         E, R, Cf, ncent = B * O * P, B * Nsrc, Cs - 4, B * O
         Zl = pZ[-1] if L1 else Z0
@@ -1193,18 +1238,29 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             sums_pa = _zeros((2, 2 * C), torch.float64, dev)
             sums_p, sums_a = sums_pa[0], sums_pa[1]
             # (the arg-max pre-activations come from zsel: Zl may not exist)
-            rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None,
-                                         # (a bf16-stored attention tensor: the values at the arg
-                                         #  max come from zsel)
-                                         _ptr(aZ[-1]) if aZ[-1].dtype == torch.float32 else None,
-                                         _ptr(lS), _ptr(lH), _ptr(lM),
-                                         _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
-                                         _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C,
-                                         dagg.stride(0), _ptr(gp),
-                                         _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
+            if nz:
+                # ga with the attention ReLU mask applied: its consumer has no pre-activation to mask with
+                rc = lib.gridgcn_pairmax_bwd_masked(_ptr(lS), _ptr(lH), _ptr(lM), _ptr(lR), _ptr(aS[-1]),
+                                                    _ptr(aH[-1]), _ptr(aM[-1]), _ptr(aR[-1]), _ptr(dagg),
+                                                    _ptr(amax), ncent, P, C, dagg.stride(0), _ptr(gp), _ptr(ga),
+                                                    _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
+            else:
+                rc = lib.gridgcn_pairmax_bwd(_ptr(Zl) if Zl is not None else None,
+                                             # (a bf16-stored attention tensor: the values at the arg
+                                             #  max come from zsel)
+                                             _ptr(aZ[-1]) if aZ[-1].dtype == torch.float32 else None,
+                                             _ptr(lS), _ptr(lH), _ptr(lM),
+                                             _ptr(lR), _ptr(aS[-1]), _ptr(aH[-1]), _ptr(aM[-1]),
+                                             _ptr(aR[-1]), _ptr(dagg), _ptr(amax), ncent, P, C,
+                                             dagg.stride(0), _ptr(gp),
+                                             _ptr(ga), _ptr(sums_p), _ptr(sums_a), _ptr(zsel), st)
             _lib.check(rc, "gridgcn_pairmax_bwd")
-            _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx,
-                                         ctx.ndx[1], sums_a, None, (amax, ga, P), False, cwa, 0)
+            if nz:
+                grads_a = _att_bwd_noz(lib, att16, aZ[0], aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1], W2, b2,
+                                       sums_a, amax, ga, P, cwa, st)
+            else:
+                _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx,
+                                             ctx.ndx[1], sums_a, None, (amax, ga, P), False, cwa, 0)
             if L1:
                 dY0, grads_rest, sums0 = _chain_backward(
                     lib, Z0, pZ, pS, pH, pM, pR, pWb, pWg, pWx, ctx.ndx[0], sums_p, None,

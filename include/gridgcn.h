@@ -68,7 +68,8 @@ const char *gridgcn_strerror(int code);
 /* library/ABI version, bumped on any signature change */
 int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors;
                                  * 4: gridgcn_set_option, Z-less attention pair removed, the library
-                                 *    reads nothing from the process environment */
+                                 *    reads nothing from the process environment
+                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, options 3 / 4 */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -527,6 +528,36 @@ int gridgcn_pairmax_bwd(const float *Zp, const float *Za, const float *scale_p,
                         long long ncent, int P, int C, int ld_dagg, float *gp, float *ga,
                         double *sums_p,
                         double *sums_a, const float *zsel, void *stream);
+/* gridgcn_pairmax_bwd_masked: the same from zsel alone, with the ReLU mask of the ATTENTION activation already
+ * applied to ga (ga = 0 where relu(bn(za)) == 0): for a consumer that has no pre-activation to mask with. */
+int gridgcn_pairmax_bwd_masked(const float *scale_p, const float *shift_p, const float *mean_p,
+                               const float *rstd_p, const float *scale_a, const float *shift_a,
+                               const float *mean_a, const float *rstd_a, const float *dagg,
+                               const uint8_t *amax, long long ncent, int P, int C, int ld_dagg, float *gp,
+                               float *ga, double *sums_p, double *sums_a, const float *zsel, void *stream);
+
+/* ---- backward of the second attention conv WITHOUT its [E, C] pre-activation -----------------------------
+ * (update_att_mlp2d_scnd, gcn_module_g_att.py:152: 32 -> 128 channels, behind the BatchNorm'd 10 -> 32 conv,
+ * in front of the neighbour max pool.)  BatchNorm backward gives dZ2 = sc (mask ? g : 0) + (z2 - mu) bz + cz:
+ * the first term is sparse (the arg-max edge per (centre, channel): amax, gval -- gval with the ReLU mask
+ * applied, gridgcn_pairmax_bwd_masked), the second affine in z2 = W2 a1 + b2, a1 = relu(bn1(Z1)); so
+ *   dA1 = dZ2_sparse W2 + a1 (W2^T diag(bz) W2) + W2^T (cz + bz (b2 - mu)),
+ *   dW2 = dZ2_sparse^T a1 + (cz + bz (b2 - mu)) (sum_e a1) + diag(bz) W2 (sum_e a1 a1^T)
+ * need Z1 [E, 32] and the sparse gradient only; Z2 [E, 128] is neither read nor kept for the backward.
+ * in : Z1[E,32] with its BatchNorm vectors p* [32]; W2[128,32], b2[128] (framework layout); this layer's scale
+ *      (= gamma * rstd), mean, rstd [128]; sums [2][128] (fp64) = its BatchNorm-backward sums (pairmax_bwd);
+ *      amax / gval [E / P, 128].
+ * out: dX[E,32] (gradient w.r.t. relu(bn1(Z1))), dW[128,32], m1 / m2 / dgamma / dbeta [128] of this layer,
+ *      psums [2][32] += BatchNorm-backward sums of the layer in front, s1 [32] += sum_e a1 (fp64, both zeroed
+ *      by the caller).  cin == 32, C == 128, E % P == 0, E >= 32; other shapes: GRIDGCN_EINVAL (use
+ *      gridgcn_linear_bwd, which reads Z2). */
+int gridgcn_att_bwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes);
+int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshift, const float *pmean,
+                        const float *prstd, const float *W2, const float *b2, const float *scale,
+                        const float *mean, const float *rstd, const double *sums, const uint8_t *amax,
+                        const float *gval, int P, long long E, int cin, int C, float *dX, float *dW, float *m1,
+                        float *m2, float *dgamma, float *dbeta, double *psums, double *s1, void *workspace,
+                        size_t workspace_bytes, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
                           long long E, int C, int ldy, void *stream);
 /* Head of the segmentation net: fc1 (conv+BN+ReLU) -> Dropout(p) -> fc2

@@ -179,6 +179,51 @@ def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P):
             close(b2, b1, 1e-5)
 
 
+@pytest.mark.parametrize("O,P,B", [(700, 5, 3), (33, 5, 2), (2000, 5, 1), (64, 7, 2)])
+def test_att_bwd_noz_equals_direct_form(O, P, B, monkeypatch):
+    """Up layers (attention MLP 10 -> 32 -> 128 behind a single point conv): the backward of the second
+    attention conv runs WITHOUT its [E, 128] pre-activation (csrc/gridgcn_attbwd_nz.hip, round 4: sparse
+    arg-max term by MFMA, dense BatchNorm term through the 32 x 32 matrix W2^T diag(bz) W2 and the moments of
+    the 32-wide activation) and the tensor is not saved.  Same inputs through that form and the one that
+    reads Z2 (gg_k_att_bwd_fused): every gradient agrees to fp32 association (the stock-module / float64
+    bars are the other tests')."""
+    import copy
+    from grid_gcn_amd import train_ops
+    torch.manual_seed(O + P)
+    gen = torch.Generator().manual_seed(O * 7 + P)
+    cin, Nsrc = 128, 150
+    net = SubGUpdate(cin, [128], localfdim=3).to(DEV).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    src = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV)
+    nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    g = torch.randn((B, O, 128), generator=gen).to(DEV)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(train_ops, "NOZ_ATT_BWD", on)
+        m = copy.deepcopy(net)
+        s_ = src.clone().requires_grad_(True)
+        y = m.forward_src(cent, s_, nebidx, None)
+        y.backward(g)
+        res.append((y.detach(), s_.grad, {n: p_.grad for n, p_ in m.named_parameters() if p_.grad is not None}))
+    (y1, ds1, g1), (y0, ds0, g0) = res
+    assert torch.equal(y1, y0)                      # the forward is the same code either way
+
+    def close(a, b, tol, what):
+        sc = max(1e-6, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * sc, (what, float((a - b).abs().max()), sc)
+    close(ds1, ds0, 2e-5, "src")
+    assert set(g1) == set(g0)
+    for k in g0:
+        if k.endswith("lin.bias"):
+            assert float(g1[k].abs().max()) == 0.0 and float(g0[k].abs().max()) == 0.0
+        else:
+            close(g1[k], g0[k], 5e-5, k)
+
+
 def test_training_step_edge_kernel_matches_torch_ops():
     """one fwd+bwd of the whole network: HIP edge-input kernel path vs stock-op path.  An INTEGRATION
     check (wiring: every term present, every gradient routed), not a precision claim -- those are the
