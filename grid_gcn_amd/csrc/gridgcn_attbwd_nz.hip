@@ -93,7 +93,12 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
     __syncthreads();
     const float ps = pcs[l31], psh = pcs[32 + l31];
     const float pm = p.pm[l31], pr = p.pr[l31];
-    const float pc = -(pm * pr);                       // zhat = zp * pr + pc
+    // zhat of the layer in front from its ACTIVATION: where the ReLU is open, a = z ps + psh, so
+    // zhat = (z - pm) pr = a zA + zB; where it is closed the term is multiplied by d = 0 anyway.  (The raw rows
+    // then need not stay in registers next to the activations.)
+    // (ps == 0 -- a BatchNorm weight of exactly 0 -- has no such inverse: those lanes re-read their raw values in
+    //  the epilogue; never taken in practice, never wrong)
+    const float zA = ps != 0.f ? pr / ps : 0.f, zB = ps != 0.f ? -(pm * pr) - psh * (pr / ps) : 0.f;
     const float v0l = v0[l31];
     float a1 = 0.f, a2 = 0.f, a3 = 0.f;
     ggm_f32x16 accw[NJ], accS;
@@ -121,44 +126,47 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
             am[q] = *(const unsigned *)(ar_ + k0 + 4 * q);
         }
     };
+    // the layer in front in the C/D row order (rows (r&3) + 8(r>>2) + 4h, column l31): A operand of the dW^T /
+    // S2 products, input of the epilogue's sums.  Loaded one TILE ahead (zpn); NaN where the lane has no row:
+    // its activation is then 0 and the row adds nothing to dW^T, S2 or the sums.
+    float zpn[16];
+    auto issue_zp = [&](long long tl) {
+        const long long r0_ = tl << 5;
+        const int nr = (p.E - r0_ < 32) ? (int)(p.E - r0_) : 32;
+        const long long bs = (r0_ + 4 * h) * GG_NZ_K + l31;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const bool ok = tl < ntile && (nr == 32 || rr + 4 * h < nr);
+            const float v = *(ok ? p.Z1 + bs + rr * GG_NZ_K : p.Z1);          // (no branch around the load)
+            zpn[r] = ok ? v : __builtin_nanf("");
+        }
+    };
     if ((long long)blockIdx.x * 4 + wave < ntile) {
         const float *g0;
         const unsigned char *a0;
         int p0;
         tileptrs((long long)blockIdx.x * 4 + wave, g0, a0, p0);
         issue(g0, a0, 0);
+        issue_zp((long long)blockIdx.x * 4 + wave);
     }
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
+        const long long tn = tile + (long long)gridDim.x * 4;
         const float *gr, *ngr;
         const unsigned char *ar, *nar;
         int pp, pn;
         tileptrs(tile, gr, ar, pp);
         ngr = gr; nar = ar;
-        {
-            const long long tn = tile + (long long)gridDim.x * 4;
-            if (tn < ntile) tileptrs(tn, ngr, nar, pn);
-        }
-        // the layer in front, twice: C/D row order (rows (r&3) + 8(r>>2) + 4h, column l31) as the A operand of
-        // the dW^T / S2 products and for the epilogue's sums; row order (lane = row, 16 consecutive columns) as
-        // the A operand of the dense product.  NaN where the lane has no row: its activation is then 0.
+        if (tn < ntile) tileptrs(tn, ngr, nar, pn);
         const long long base = (r0 + 4 * h) * GG_NZ_K + l31;
-        float avr[16], zpv[16];
+        float avr[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            const bool ok = nrows == 32 || rr + 4 * h < nrows;
-            const float v = *(ok ? p.Z1 + base + rr * GG_NZ_K : p.Z1);      // (no branch around the load)
-            zpv[r] = ok ? v : __builtin_nanf("");
-        }
+        for (int r = 0; r < 16; r++) avr[r] = fmaxf(__builtin_fmaf(zpn[r], ps, psh), 0.f);   // 0 where zpn is NaN
         long long rw = r0 + l31;
         if (rw >= p.E) rw = p.E - 1;
-        float4 z1r[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) z1r[q] = *(const float4 *)(p.Z1 + rw * GG_NZ_K + 16 * h + 4 * q);
-#pragma unroll
-        for (int r = 0; r < 16; r++) avr[r] = fmaxf(__builtin_fmaf(zpv[r], ps, psh), 0.f);   // 0 where zpv is NaN
+        float4 z1r[4];        // the same rows in row order (lane = row, 16 consecutive columns): dense product
         ggm_f32x16 accx;
 #pragma unroll
         for (int r = 0; r < 16; r++) accx[r] = 0.f;
@@ -182,6 +190,13 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
             }
             if (ci + 1 < NJ) issue(gr, ar, ci + 1);
             else issue(ngr, nar, 0);
+            // this tile's rows for the dense product two chunks before their use, the next tile's C/D-order
+            // rows a whole tile before theirs: nothing in this loop waits for a load it has just issued
+            if (ci == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) z1r[q] = *(const float4 *)(p.Z1 + rw * GG_NZ_K + 16 * h + 4 * q);
+            }
+            if (ci == NJ - 1) issue_zp(tn);
             // (keep the loads HERE: left alone, the scheduler sinks them to their first use)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -228,7 +243,9 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
                     xp[rr * GG_NZ_K] = dx;
                     const float d = avr[r] > 0.f ? dx : 0.f;
                     s1 += d;
-                    s2 = __builtin_fmaf(d, __builtin_fmaf(zpv[r], pr, pc), s2);
+                    float zh = __builtin_fmaf(avr[r], zA, zB);
+                    if (ps == 0.f) zh = (p.Z1[base + rr * GG_NZ_K] - pm) * pr;
+                    s2 = __builtin_fmaf(d, zh, s2);
                     s3 += avr[r];
                 }
             }
