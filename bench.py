@@ -303,6 +303,9 @@ def main():
                     help="contraction precision of the training GEMM kernels: f32 = exact fp32 MFMA "
                          "(parity path, the headline), bf16 = bf16 MFMA operands with fp32 storage, "
                          "accumulation and statistics (BASELINE configs[2] 'bf16 MLP / fp32 indices')")
+    ap.add_argument("--switch", action="append", default=[],
+                    help="NAME=0|1: a path switch of grid_gcn_amd.train_ops (A/B measurements, e.g. "
+                         "NOZ_ATT_BWD=0); the defaults are what is shipped and reported")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -320,6 +323,10 @@ def main():
     traffic = load_traffic()
     from grid_gcn_amd import train_ops as _tops
     _tops.set_mlp_precision("bf16" if a.dtype == "bf16" else "fp32")
+    for sw in a.switch:
+        name, val = sw.split("=")
+        assert isinstance(getattr(_tops, name), bool), name
+        setattr(_tops, name, bool(int(val)))
 
     if a.config != "cfg4":
         import bench_configs

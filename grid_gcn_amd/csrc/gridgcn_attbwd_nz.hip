@@ -23,7 +23,8 @@
 #include "gridgcn_mma.h"
 #include "gridgcn_train.h"
 
-#define GG_NZ_TS 68    // LDS row stride (floats) of a wave's dZ half tile: 64 channels + 4
+#define GG_NZ_TS 36    // LDS stride (floats) of one CHANNEL of a wave's transposed dZ half tile: 32 rows + 4
+#define GG_NZ_WS 20    // LDS stride (floats) of one lane's 16 operand values (16 + 4: conflict-free ds_read_b128)
 #define GG_NZ_C 128
 #define GG_NZ_K 32
 
@@ -43,11 +44,16 @@ struct GGAttNz {
     int P;
 };
 
-// W2[c][i] out of the dX operand layout in LDS: Wl[step][lane] = W2[k][col], k = 32 (step >> 4) + 16 (lane >> 5)
-// + (step & 15), col = lane & 31
+// LDS operand layouts: every MFMA run of this kernel reads its B operands with four ds_read_b128 IN FRONT of the
+// run (one ds_read_b32 + s_waitcnt in front of every second MFMA, as a [step][lane] layout gives, left the matrix
+// pipe waiting for an LDS round trip 32 times per chunk):
+//   Wl[(chunk * 64 + lane) * WS + s] = W2[k][col],  k = 32 chunk + 16 (lane >> 5) + s, col = lane & 31, s < 16
+//   Mp[lane * WS + s]                = M[j][col],   j = 16 (lane >> 5) + s
+//   T (per wave, TRANSPOSED): Tt[(cc * 32 + ch) * TS + row] -- written by the row's lane one channel at a time,
+//       read by the channel's lane as the rows (r & 3) + 8 (r >> 2) + 4 h: four runs of four consecutive rows
 __device__ __forceinline__ float gg_nz_w2(const float *Wl, int c, int i)
 {
-    return Wl[((c >> 5) * 16 + (c & 15)) * 64 + ((c >> 4) & 1) * 32 + i];
+    return Wl[((c >> 5) * 64 + ((c >> 4) & 1) * 32 + i) * GG_NZ_WS + (c & 15)];
 }
 
 __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
@@ -56,18 +62,17 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
-    float *Wl = lds;                       // [64 steps][64]   dX operand
-    float *Mp = Wl + C * 32;               // [16 steps][64]   dense operand M
-    float *csc = Mp + 1024;                // [C] scale
+    float *Wl = lds;                       // [4 chunks][64 lanes][WS]   dX operand
+    float *Mp = Wl + 4 * 64 * GG_NZ_WS;    // [64 lanes][WS]             dense operand M
+    float *csc = Mp + 64 * GG_NZ_WS;       // [C] scale
     float *cbz = csc + C;                  // [C] bz = -(sc rstd) m2
     float *ct = cbz + C;                   // [C] cz + bz (b2 - mu)
     float *v0 = ct + C;                    // [32]
     float *pcs = v0 + 32;                  // [2][32] previous layer's scale, shift
-    float *T = pcs + 64 + wave * (32 * GG_NZ_TS);
+    float *T = pcs + 64 + wave * (64 * GG_NZ_TS);
     for (int i = tid; i < C * 32; i += 256) {
-        const int st = i >> 6, ln = i & 63;
-        const int k = 32 * (st >> 4) + 16 * (ln >> 5) + (st & 15);
-        Wl[i] = p.W2[k * GG_NZ_K + (ln & 31)];
+        const int k = i >> 5, col = i & 31;           // (coalesced read of W2[k][:])
+        Wl[((k >> 5) * 64 + ((k >> 4) & 1) * 32 + col) * GG_NZ_WS + (k & 15)] = p.W2[i];
     }
     for (int c = tid; c < C; c += 256) {
         const float sc = p.sc[c];
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
         const int s = i >> 6, ln = i & 63, j = 16 * (ln >> 5) + s, col = ln & 31;
         float m = 0.f;
         for (int c = 0; c < C; c++) m = __builtin_fmaf(cbz[c] * gg_nz_w2(Wl, c, j), gg_nz_w2(Wl, c, col), m);
-        Mp[i] = m;
+        Mp[ln * GG_NZ_WS + s] = m;
     }
     if (tid < 32) {
         float v = 0.f;
@@ -93,12 +98,7 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
     __syncthreads();
     const float ps = pcs[l31], psh = pcs[32 + l31];
     const float pm = p.pm[l31], pr = p.pr[l31];
-    // zhat of the layer in front from its ACTIVATION: where the ReLU is open, a = z ps + psh, so
-    // zhat = (z - pm) pr = a zA + zB; where it is closed the term is multiplied by d = 0 anyway.  (The raw rows
-    // then need not stay in registers next to the activations.)
-    // (ps == 0 -- a BatchNorm weight of exactly 0 -- has no such inverse: those lanes re-read their raw values in
-    //  the epilogue; never taken in practice, never wrong)
-    const float zA = ps != 0.f ? pr / ps : 0.f, zB = ps != 0.f ? -(pm * pr) - psh * (pr / ps) : 0.f;
+    const float pc = -(pm * pr);                       // zhat = zp * pr + pc
     const float v0l = v0[l31];
     float a1 = 0.f, a2 = 0.f, a3 = 0.f;
     ggm_f32x16 accw[NJ], accS;
@@ -126,51 +126,45 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
             am[q] = *(const unsigned *)(ar_ + k0 + 4 * q);
         }
     };
-    // the layer in front in the C/D row order (rows (r&3) + 8(r>>2) + 4h, column l31): A operand of the dW^T /
-    // S2 products, input of the epilogue's sums.  Loaded one TILE ahead (zpn); NaN where the lane has no row:
-    // its activation is then 0 and the row adds nothing to dW^T, S2 or the sums.
-    float zpn[16];
-    auto issue_zp = [&](long long tl) {
-        const long long r0_ = tl << 5;
-        const int nr = (p.E - r0_ < 32) ? (int)(p.E - r0_) : 32;
-        const long long bs = (r0_ + 4 * h) * GG_NZ_K + l31;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            const bool ok = tl < ntile && (nr == 32 || rr + 4 * h < nr);
-            const float v = *(ok ? p.Z1 + bs + rr * GG_NZ_K : p.Z1);          // (no branch around the load)
-            zpn[r] = ok ? v : __builtin_nanf("");
-        }
-    };
     if ((long long)blockIdx.x * 4 + wave < ntile) {
         const float *g0;
         const unsigned char *a0;
         int p0;
         tileptrs((long long)blockIdx.x * 4 + wave, g0, a0, p0);
         issue(g0, a0, 0);
-        issue_zp((long long)blockIdx.x * 4 + wave);
     }
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
         const long long r0 = tile << 5;
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        const long long tn = tile + (long long)gridDim.x * 4;
         const float *gr, *ngr;
         const unsigned char *ar, *nar;
         int pp, pn;
         tileptrs(tile, gr, ar, pp);
         ngr = gr; nar = ar;
-        if (tn < ntile) tileptrs(tn, ngr, nar, pn);
+        {
+            const long long tn = tile + (long long)gridDim.x * 4;
+            if (tn < ntile) tileptrs(tn, ngr, nar, pn);
+        }
+        // the layer in front, twice: C/D row order (rows (r&3) + 8(r>>2) + 4h, column l31) as the A operand of
+        // the dW^T / S2 products and for the epilogue's sums; row order (lane = row, 16 consecutive columns) as
+        // the A operand of the dense product.  NaN where the lane has no row: its activation is then 0.
         const long long base = (r0 + 4 * h) * GG_NZ_K + l31;
-        float avr[16];
+        float avr[16], zpv[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) avr[r] = fmaxf(__builtin_fmaf(zpn[r], ps, psh), 0.f);   // 0 where zpn is NaN
+        for (int r = 0; r < 16; r++) {
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const bool ok = nrows == 32 || rr + 4 * h < nrows;
+            const float v = *(ok ? p.Z1 + base + rr * GG_NZ_K : p.Z1);      // (no branch around the load)
+            zpv[r] = ok ? v : __builtin_nanf("");
+        }
         long long rw = r0 + l31;
         if (rw >= p.E) rw = p.E - 1;
-        float4 z1r[4];        // the same rows in row order (lane = row, 16 consecutive columns): dense product
+        float4 z1r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) z1r[q] = *(const float4 *)(p.Z1 + rw * GG_NZ_K + 16 * h + 4 * q);
         ggm_f32x16 accx;
 #pragma unroll
         for (int r = 0; r < 16; r++) accx[r] = 0.f;
-        int s = 0;
 #pragma unroll
         for (int ci = 0; ci < NJ; ci++) {
             const int cc = ci & 1, k0 = ci * 32 + h * 16;
@@ -186,37 +180,48 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
                 d.z = (int)((am[q] >> 16) & 255u) == pp ? sg.z : 0.f;
                 d.w = (int)(am[q] >> 24) == pp ? sg.w : 0.f;
                 a[q] = __builtin_bit_cast(float4, d);
-                *(gg_f32x4 *)(T + l31 * GG_NZ_TS + cc * 32 + h * 16 + 4 * q) = d;
+                float *tw = T + (cc * 32 + h * 16 + 4 * q) * GG_NZ_TS + l31;
+                tw[0] = d.x; tw[GG_NZ_TS] = d.y; tw[2 * GG_NZ_TS] = d.z; tw[3 * GG_NZ_TS] = d.w;
             }
             if (ci + 1 < NJ) issue(gr, ar, ci + 1);
             else issue(ngr, nar, 0);
-            // this tile's rows for the dense product two chunks before their use, the next tile's C/D-order
-            // rows a whole tile before theirs: nothing in this loop waits for a load it has just issued
-            if (ci == 1) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) z1r[q] = *(const float4 *)(p.Z1 + rw * GG_NZ_K + 16 * h + 4 * q);
-            }
-            if (ci == NJ - 1) issue_zp(tn);
             // (keep the loads HERE: left alone, the scheduler sinks them to their first use)
             __builtin_amdgcn_sched_barrier(0);
+            {
+                gg_f32x4 w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+                for (int q = 0; q < 4; q++) w4[q] = gg_ld_f4(Wl + (ci * 64 + lane) * GG_NZ_WS + 4 * q);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], Wl[s * 64 + lane], accx, 0, 0, 0);
-                    s++;
+                for (int q = 0; q < 4; q++) {
+                    const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+                    const float wv[4] = {w4[q].x, w4[q].y, w4[q].z, w4[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wv[i], accx, 0, 0, 0);
                 }
             }
-            // dW^T tile ci += a1^T dZ(columns cc*32.. of the LDS tile).  The tile belongs to this wave alone: its
-            // LDS writes only have to land before its reads; the columns read here are overwritten two chunks
+            // (the activations of the layer in front are formed HERE, behind the first chunk's dZ and dX MFMAs:
+            //  at the top of the tile the wave would wait out the full latency of the loads it has just issued)
+            if (ci == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) avr[r] = fmaxf(__builtin_fmaf(zpv[r], ps, psh), 0.f);   // 0 where zpv is NaN
+            }
+            // dW^T tile ci += a1^T dZ(channels cc*32.. of the LDS tile).  The tile belongs to this wave alone: its
+            // LDS writes only have to land before its reads; the channels read here are overwritten two chunks
             // later, behind another of these barriers.
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                gg_f32x4 t4[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_NZ_TS + l31;
-                accw[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[r], trow[cc * 32], accw[ci], 0, 0, 0);
+                for (int jg = 0; jg < 4; jg++) t4[jg] = gg_ld_f4(T + (cc * 32 + l31) * GG_NZ_TS + 8 * jg + 4 * h);
+#pragma unroll
+                for (int jg = 0; jg < 4; jg++) {
+                    const float tv[4] = {t4[jg].x, t4[jg].y, t4[jg].z, t4[jg].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        accw[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[4 * jg + i], tv[i], accw[ci], 0, 0, 0);
+                }
             }
         }
         // dense term: a1 (row order) x M, and S2 += a1^T a1
@@ -225,9 +230,10 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
             const gg_f32x4 y = gg_bnrelu4v(__builtin_bit_cast(gg_f32x4, z1r[q]), gg_ld_f4(pcs + 16 * h + 4 * q),
                                            gg_ld_f4(pcs + 32 + 16 * h + 4 * q));
             const float yv[4] = {y.x, y.y, y.z, y.w};
+            const gg_f32x4 m4 = gg_ld_f4(Mp + lane * GG_NZ_WS + 4 * q);
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                accx = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[i], Mp[(4 * q + i) * 64 + lane], accx, 0, 0, 0);
+            for (int i = 0; i < 4; i++) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[i], mv[i], accx, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) accS = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[r], avr[r], accS, 0, 0, 0);
@@ -243,9 +249,7 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
                     xp[rr * GG_NZ_K] = dx;
                     const float d = avr[r] > 0.f ? dx : 0.f;
                     s1 += d;
-                    float zh = __builtin_fmaf(avr[r], zA, zB);
-                    if (ps == 0.f) zh = (p.Z1[base + rr * GG_NZ_K] - pm) * pr;
-                    s2 = __builtin_fmaf(d, zh, s2);
+                    s2 = __builtin_fmaf(d, __builtin_fmaf(zpv[r], pr, pc), s2);
                     s3 += avr[r];
                 }
             }
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
     }
     // partial tiles: the four waves add up in LDS (fixed order), one [tile][reg][lane] block per workgroup
     {
-        float *blk = pcs + 64;                         // 5 * 1024 floats over the tile area (4 * 32 * 68)
+        float *blk = pcs + 64;                         // 5 * 1024 floats over the tile area (4 * 64 * 36)
         __syncthreads();
         for (int w = 0; w < 4; w++) {
             if (wave == w) {
@@ -370,7 +374,7 @@ int gg_att_bwd_noz(const float *Z1, const float *ps, const float *psh, const flo
     p.E = E; p.P = P;
     const int nwg = gg_att_nz_grid(E);
     float *S2 = p.part + (size_t)nwg * 5 * 1024;
-    const size_t lds = (size_t)(GG_NZ_C * 32 + 1024 + 3 * GG_NZ_C + 32 + 64 + 4 * 32 * GG_NZ_TS) * sizeof(float);
+    const size_t lds = (size_t)(5 * 64 * GG_NZ_WS + 3 * GG_NZ_C + 32 + 64 + 4 * 64 * GG_NZ_TS) * sizeof(float);
     gg_k_att_bwd_nz<<<nwg, 256, lds, st>>>(p);
     gg_k_att_nz_reduce<<<5 * 16, 1024, 0, st>>>(p.part, nwg, dW, S2);
     gg_k_att_nz_finish<<<(GG_NZ_C * GG_NZ_K + 255) / 256, 256, 0, st>>>(p, S2, dW, m1, m2, dgamma, dbeta);
