@@ -35,7 +35,7 @@ struct GGAttNz {
     const float *sc, *mu, *rs;           // [128] this layer: scale = gamma * rstd, mean, rstd
     const double *bsums;                 // [2][128] BatchNorm-backward sums of this layer (gridgcn_pairmax_bwd)
     const unsigned char *amax;           // [E / P][128] arg-max neighbour
-    const float *gval;                   // [E / P][128] gradient w.r.t. relu(bn(z2)) there, ReLU mask APPLIED
+    const float *gval;                   // [E / P][128] sparse term of dZ2 there: scale * (ReLU mask ? gradient : 0)
     float *dX;                           // [E][32]
     float *part;                         // [workgroups][5][1024]
     double *psums;                       // [2][32], zero on entry: BatchNorm-backward sums of the layer in front
@@ -167,13 +167,12 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
         for (int r = 0; r < 16; r++) accx[r] = 0.f;
 #pragma unroll
         for (int ci = 0; ci < NJ; ci++) {
-            const int cc = ci & 1, k0 = ci * 32 + h * 16;
+            const int cc = ci & 1;
             float4 a[4];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const gg_f32x4 sc4 = gg_ld_f4(csc + k0 + 4 * q);
-                const gg_f32x4 sg = sc4 * __builtin_bit_cast(gg_f32x4, g[q]);
+                const gg_f32x4 sg = __builtin_bit_cast(gg_f32x4, g[q]);      // (scale and ReLU mask applied upstream)
                 gg_f32x4 d;
                 d.x = (int)(am[q] & 255u) == pp ? sg.x : 0.f;
                 d.y = (int)((am[q] >> 8) & 255u) == pp ? sg.y : 0.f;

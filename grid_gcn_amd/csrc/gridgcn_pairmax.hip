@@ -344,7 +344,9 @@ __global__ __launch_bounds__(256) void gg_k_pairmax_bwd(
         const float g1 = g * y2, g2 = g * y1;
         const float d1 = y1 > 0.f ? g1 : 0.f, d2 = y2 > 0.f ? g2 : 0.f;
         gp[t] = g1;
-        ga[t] = mask_a ? d2 : g2;       // (mask_a: the consumer has no pre-activation to mask with -- gg_att_bwd_noz)
+        // (mask_a: the consumer has no pre-activation to mask with -- gg_att_bwd_noz -- and wants the sparse term
+        //  of dZ itself: the attention layer's BatchNorm scale applied as well)
+        ga[t] = mask_a ? d2 * a2 : g2;
         s1p += d1; s2p += d1 * ((zp - m1) * r1);
         s1a += d2; s2a += d2 * ((za - m2) * r2);
     }
