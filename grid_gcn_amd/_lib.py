@@ -39,8 +39,7 @@ EXPORTS = [
     "gridgcn_pairmax_fwd_src_z", "gridgcn_pack_desc_fill", "gridgcn_pack_linear_batch",
     "gridgcn_linear_bwd_fin", "gridgcn_gemm_small", "gridgcn_gemm_small_workspace_bytes",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd", "gridgcn_pairmax_bwd_masked",
-    "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz", "gridgcn_att_moments_workspace_bytes",
-    "gridgcn_att_moments", "gridgcn_att_pairmax",
+    "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
@@ -166,12 +165,6 @@ def load():
     lib.gridgcn_pairmax_bwd_masked.argtypes = [vp] * 10 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_att_bwd_noz_workspace_bytes.restype = ci
     lib.gridgcn_att_bwd_noz_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
-    lib.gridgcn_att_moments_workspace_bytes.restype = ci
-    lib.gridgcn_att_moments_workspace_bytes.argtypes = [ll, ctypes.POINTER(cs)]
-    lib.gridgcn_att_moments.restype = ci
-    lib.gridgcn_att_moments.argtypes = [vp] * 5 + [ll, ci, ci, vp, vp, vp, cs, vp]
-    lib.gridgcn_att_pairmax.restype = ci
-    lib.gridgcn_att_pairmax.argtypes = [vp] * 14 + [ci] * 6 + [vp, ci, vp, vp, vp]
     lib.gridgcn_att_bwd_noz.restype = ci
     lib.gridgcn_att_bwd_noz.argtypes = [vp] * 13 + [ci, ll, ci, ci] + [vp] * 8 + [vp, cs, vp]
     lib.gridgcn_bn_relu_apply.restype = ci

@@ -70,14 +70,6 @@ int gg_att_bwd_noz(const float *, const float *, const float *, const float *, c
                    const float *, const float *, const float *, const float *, const double *,
                    const unsigned char *, const float *, int, long long, float *, float *, float *, float *,
                    float *, float *, double *, double *, void *, hipStream_t);
-size_t gg_att_moments_workspace(long long E);                      // gridgcn_attfwd_nz.hip
-int gg_att_moments(const float *, const float *, const float *, const float *, const float *, long long,
-                   double *, double *, void *, hipStream_t);
-bool gg_att_pairmax_ok(int P, int cin, int C);
-int gg_att_pairmax_c(const float *Z1, const float *ps, const float *psh, const float *W2, const float *b2,
-                     const float *sa, const float *ha, const float *Ysrc, const int *nebidx, const float *att16,
-                     const float *Wg, const float *bp, const float *sp, const float *hp, int B, int Nsrc, int O,
-                     int P, float *agg, int lda, unsigned char *amax, float *zsel, hipStream_t st);
 int gg_pack_desc_fill(gridgcn_pack_desc *e);
 int gg_pack_linear_batch(const gridgcn_pack_desc *dev, int nlayers, int max_n, hipStream_t st);
 
@@ -636,39 +628,6 @@ int gridgcn_pairmax_bwd_masked(const float *scale_p, const float *shift_p, const
     int rc = gg_pairmax_bwd(nullptr, nullptr, scale_p, shift_p, mean_p, rstd_p, scale_a, shift_a, mean_a,
                             rstd_a, dagg, amax, ncent, P, C, ld_dagg, gp, ga, sums_p, sums_a, zsel, 1,
                             (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
-}
-
-int gridgcn_att_moments_workspace_bytes(long long E, size_t *bytes)
-{
-    if (!bytes || E < 1) return GRIDGCN_EINVAL;
-    *bytes = gg_att_moments_workspace(E);
-    return GRIDGCN_OK;
-}
-
-int gridgcn_att_moments(const float *Z1, const float *pscale, const float *pshift, const float *W2,
-                        const float *b2, long long E, int cin, int C, double *sums, double *s1, void *workspace,
-                        size_t workspace_bytes, void *stream)
-{
-    if (!Z1 || !pscale || !pshift || !W2 || !b2 || !sums || !s1 || E < 1 || cin != 32 || C != 128)
-        return GRIDGCN_EINVAL;
-    if (!workspace || workspace_bytes < gg_att_moments_workspace(E)) return GRIDGCN_EWORKSPACE;
-    const int rc = gg_att_moments(Z1, pscale, pshift, W2, b2, E, sums, s1, workspace, (hipStream_t)stream);
-    return rc == 1 ? GRIDGCN_EINVAL : rc;
-}
-
-int gridgcn_att_pairmax(const float *Z1, const float *pscale, const float *pshift, const float *W2,
-                        const float *b2, const float *scale_a, const float *shift_a, const float *Ysrc,
-                        const int32_t *nebidx, const float *att16, const float *Wg, const float *b,
-                        const float *scale_p, const float *shift_p, int B, int Nsrc, int O, int P, int cin, int C,
-                        float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream)
-{
-    if (!Z1 || !pscale || !pshift || !W2 || !b2 || !scale_a || !shift_a || !nebidx || !att16 || !b || !scale_p ||
-        !shift_p || !agg || !amax || !zsel || B < 1 || Nsrc < 1 || O < 1 || ld_agg < C)
-        return GRIDGCN_EINVAL;
-    if (!gg_att_pairmax_ok(P, cin, C)) return GRIDGCN_EINVAL;
-    const int rc = gg_att_pairmax_c(Z1, pscale, pshift, W2, b2, scale_a, shift_a, Ysrc, nebidx, att16, Wg, b,
-                                    scale_p, shift_p, B, Nsrc, O, P, agg, ld_agg, amax, zsel, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

@@ -53,8 +53,6 @@ Z16_STORAGE = True
 # fp32 mode, up layers: backward of the second attention conv without its [E, 128] pre-activation
 # (csrc/gridgcn_attbwd_nz.hip): the tensor is not kept for the backward at all
 NOZ_ATT_BWD = True
-# ... and its forward without writing the tensor (csrc/gridgcn_attfwd_nz.hip; needs NOZ_ATT_BWD)
-NOZ_ATT_FWD = True
 
 
 
@@ -1073,47 +1071,6 @@ class _EdgeBlockTrain(torch.autograd.Function):
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
-def _att_fwd_noz(lib, att16, pa, bns_a, eps, Ysrc, nebidx, Wg, bp, scl, shl, B, Nsrc, O, P, agg, lda, amax, zsel, st):
-    """attention branch (10 -> 32 -> 128) + product with the point branch + max over the P neighbours of an up
-    layer without the [E, 128] pre-activation of the second conv: the first conv as any chain layer, the second
-    layer's BatchNorm vectors from the moments of the first one's activation (gridgcn_att_moments ->
-    gridgcn_bn_finalize), then gridgcn_att_pairmax.  Returns the chain state the backward expects (second
-    layer: BatchNorm vectors only -- no tensor, no packed operands)."""
-    E, dev = att16.shape[0], att16.device
-    s0 = _chain_forward(lib, att16, pa[:4], bns_a[:1], eps)
-    W2, b2, g2, be2 = pa[4:8]
-    C, cin = W2.shape
-    Z1 = s0.Z[0]
-    acc = torch.empty(2 * C, dtype=torch.float64, device=dev)
-    s1 = _zeros(cin, torch.float64, dev)
-    nbytes = ctypes.c_size_t(0)
-    _lib.check(lib.gridgcn_att_moments_workspace_bytes(E, ctypes.byref(nbytes)), "att_moments_workspace")
-    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    rc = lib.gridgcn_att_moments(_ptr(Z1), _ptr(s0.scale[0]), _ptr(s0.shift[0]), _ptr(W2.detach()),
-                                 _ptr(b2.detach()), E, cin, C, _ptr(acc), _ptr(s1), _ptr(ws), nbytes.value, st)
-    _lib.check(rc, "gridgcn_att_moments")
-    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
-    bn = bns_a[1]
-    track = bn is not None and bn.track_running_stats
-    rc = lib.gridgcn_bn_finalize(
-        _ptr(acc), _ptr(g2.detach()), _ptr(be2.detach()), E, eps, _momentum(bn) if track else 0.0, C,
-        _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]), _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
-        _ptr(bn.running_var) if track else None, _ptr(bn.num_batches_tracked) if track else None, st)
-    _lib.check(rc, "gridgcn_bn_finalize")
-    t_end = TIMERS.bracket(("att_pairmax", E, cin, C)) if TIMERS is not None else None
-    rc = lib.gridgcn_att_pairmax(_ptr(Z1), _ptr(s0.scale[0]), _ptr(s0.shift[0]), _ptr(W2.detach()), _ptr(b2.detach()),
-                                 _ptr(vec[0]), _ptr(vec[1]), _ptr(Ysrc), _ptr(nebidx), _ptr(att16),
-                                 _ptr(Wg) if Wg is not None else None, _ptr(bp), _ptr(scl), _ptr(shl), B, Nsrc, O, P,
-                                 cin, C, _ptr(agg), lda, _ptr(amax), _ptr(zsel), st)
-    if t_end is not None:
-        t_end.record()
-    _lib.check(rc, "gridgcn_att_pairmax")
-    none = torch.empty(0, dtype=torch.float32, device=dev)
-    s0.Z.append(none); s0.Wb.append(none); s0.Wg.append(none); s0.Wdx.append(none); s0.ndx.append(0)
-    s0.scale.append(vec[0]); s0.shift.append(vec[1]); s0.mean.append(vec[2]); s0.rstd.append(vec[3])
-    return s0
-
-
 def _att_bwd_noz(lib, att16, Z1, aS, aH, aM, aR, aWb, aWg, aWx, ndxs, W2, b2, sums_a, amax, ga, P, cwa, st):
     """backward of the attention chain (10 -> 32 -> 128) of an up layer without the second conv's [E, 128]
     pre-activation: gridgcn_att_bwd_noz for the second conv (dA1, dW2, its BatchNorm vectors, the BatchNorm-
@@ -1223,18 +1180,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             # the tensor is then not saved ...
             nz = (NOZ_ATT_BWD and noz and La == 2 and not z16 and lib.gridgcn_get_mlp_precision() == 0
                   and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16)
-            # ... and with five neighbours per centre (every up layer) it is not even written: BatchNorm statistics
-            # from the moments of the 32-wide activation, conv + product + max in one kernel (gridgcn_attfwd_nz.hip)
-            nzf = nz and NOZ_ATT_FWD and P == 5
-            if nzf:
-                sa = _att_fwd_noz(lib, att16, pa, bns_a, eps, Ysrc, nebidx, Wg if geo else None, wgb[3], scl, shl,
-                                  B, Nsrc, O, P, agg, lda, amax, zsel, st)
-                rc = 0
-            else:
-                sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)
-            if nzf:
-                pass
-            elif noz:
+            sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)
+            if noz:
                 rc = lib.gridgcn_pairmax_fwd_src_z(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
                     B, Nsrc, O, _ptr(sa.Z[-1]), 1 if z16 else 0, _ptr(scl), _ptr(shl),
@@ -1249,7 +1196,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.nz = nz
         saZ = list(sa.Z)
-        if nz and not nzf:
+        if nz:
             saZ[-1] = torch.empty(0, dtype=torch.float32, device=dev)     # Z2: read by nobody any more
         ctx.save_for_backward(
             src, nebidx, att16, amax, Ysrc if noz else Z0, vec0, W0, zsel, wgb,

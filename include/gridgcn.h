@@ -69,8 +69,7 @@ const char *gridgcn_strerror(int code);
 int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors;
                                  * 4: gridgcn_set_option, Z-less attention pair removed, the library
                                  *    reads nothing from the process environment
-                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_att_moments,
-                                 *    gridgcn_att_pairmax, options 3 / 4 */
+                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, options 3 / 4 */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -554,22 +553,6 @@ int gridgcn_pairmax_bwd_masked(const float *scale_p, const float *shift_p, const
  *      by the caller).  cin == 32, C == 128, E % P == 0, E >= 32; other shapes: GRIDGCN_EINVAL (use
  *      gridgcn_linear_bwd, which reads Z2). */
 int gridgcn_att_bwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes);
-/* ... and the forward of that attention branch without the tensor (P == 5, cin == 32, C == 128):
- * gridgcn_att_moments: sums[2][128] (fp64, written) = (sum_e z2, sum_e z2^2) per channel of z2 = W2 a1 + b2,
- *   a1 = relu(Z1 pscale + pshift), from the moments sum_e a1 (s1 [32], fp64, zeroed by the caller) and
- *   sum_e a1 a1^T of ONE pass over Z1 [E, 32] -- the input of gridgcn_bn_finalize for that layer.
- * gridgcn_att_pairmax: agg[o, c] = max_p relu(bn_p(z0[(o,p), c])) * relu(bn_a(z2[(o,p), c])) with
- *   z0 = Ysrc[src] + Wg geo + b (as gridgcn_pairmax_fwd_src) and z2 = W2 relu(bn_1(Z1)) + b2 formed by MFMA inside
- *   the kernel; amax / zsel as gridgcn_pairmax_fwd_src (zsel[1] = z2 at the arg max). */
-int gridgcn_att_moments_workspace_bytes(long long E, size_t *bytes);
-int gridgcn_att_moments(const float *Z1, const float *pscale, const float *pshift, const float *W2,
-                        const float *b2, long long E, int cin, int C, double *sums, double *s1, void *workspace,
-                        size_t workspace_bytes, void *stream);
-int gridgcn_att_pairmax(const float *Z1, const float *pscale, const float *pshift, const float *W2,
-                        const float *b2, const float *scale_a, const float *shift_a, const float *Ysrc,
-                        const int32_t *nebidx, const float *att16, const float *Wg, const float *b,
-                        const float *scale_p, const float *shift_p, int B, int Nsrc, int O, int P, int cin, int C,
-                        float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream);
 int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshift, const float *pmean,
                         const float *prstd, const float *W2, const float *b2, const float *scale,
                         const float *mean, const float *rstd, const double *sums, const uint8_t *amax,
