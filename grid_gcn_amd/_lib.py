@@ -39,7 +39,7 @@ EXPORTS = [
     "gridgcn_pairmax_fwd_src_z", "gridgcn_pack_desc_fill", "gridgcn_pack_linear_batch",
     "gridgcn_linear_bwd_fin", "gridgcn_gemm_small", "gridgcn_gemm_small_workspace_bytes",
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd", "gridgcn_pairmax_bwd_masked",
-    "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz",
+    "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz", "gridgcn_gemm_bias",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
@@ -165,6 +165,8 @@ def load():
     lib.gridgcn_pairmax_bwd_masked.argtypes = [vp] * 10 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_att_bwd_noz_workspace_bytes.restype = ci
     lib.gridgcn_att_bwd_noz_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_gemm_bias.restype = ci
+    lib.gridgcn_gemm_bias.argtypes = [ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.gridgcn_att_bwd_noz.restype = ci
     lib.gridgcn_att_bwd_noz.argtypes = [vp] * 13 + [ci, ll, ci, ci] + [vp] * 8 + [vp, cs, vp]
     lib.gridgcn_bn_relu_apply.restype = ci

@@ -59,7 +59,7 @@ int gg_pack_linear(const float *, const float *, int, int, int, int, int, float 
 int gg_bn_finalize(const double *, const float *, const float *, long long, float, float, int,
                    float *, float *, float *, float *, float *, float *, long long *, hipStream_t);
 int gg_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
-                  int K, int zero_left, void *ws, hipStream_t st);      // gridgcn_gemm.hip
+                  int K, int zero_left, const float *bias, void *ws, hipStream_t st);      // gridgcn_gemm.hip
 size_t gg_gemm_small_workspace(int M, int N, int K);
 int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *, float *,
                        hipStream_t);
@@ -521,7 +521,15 @@ int gridgcn_gemm_small(int mode, const float *A, int lda, const float *B, int ld
 {
     if (lda < 1 || ldb < 1 || ldc < 1 || M < 1 || N < 1 || K < 1) return GRIDGCN_EINVAL;
     if (mode == 2 && (!workspace || workspace_bytes < gg_gemm_small_workspace(M, N, K))) return GRIDGCN_EWORKSPACE;
-    const int rc = gg_gemm_small(mode, A, lda, B, ldb, C, ldc, M, N, K, zero_left, workspace, (hipStream_t)stream);
+    const int rc = gg_gemm_small(mode, A, lda, B, ldb, C, ldc, M, N, K, zero_left, nullptr, workspace, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_gemm_bias(int mode, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
+                      int ldc, int M, int N, int K, void *stream)
+{
+    if (lda < 1 || ldb < 1 || ldc < 1 || M < 1 || N < 1 || K < 1 || (mode != 0 && mode != 1)) return GRIDGCN_EINVAL;
+    const int rc = gg_gemm_small(mode, A, lda, B, ldb, C, ldc, M, N, K, 0, bias, nullptr, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 

@@ -23,6 +23,7 @@ struct GGGemm {
     float *C;
     int M, N, K, lda, ldb, ldc;
     int zero_left;        // mode 1 only: columns [-zero_left, 0) left of C are zero-filled
+    const float *bias;    // modes 0 / 1: added per output column (nullptr: none)
     float *part;          // mode 2: [tiles][S][1024]
     int *tick;            // mode 2: [tiles], zero on entry, zero again on exit
 };
@@ -76,18 +77,24 @@ __global__ __launch_bounds__(256) void gg_k_gemm_rows(GGGemm p)
             for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][i], acc, 0, 0, 0);
     }
     for (; kb < p.K; kb += 8) {
+        // (the last chunk may be short -- K need not be a multiple of 8: zeros beyond K, loads from valid addresses)
         float a[4], b[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a[i] = ar[kb + i]; b[i] = br[(size_t)(kb + i) * bs]; }
+        for (int i = 0; i < 4; i++) {
+            const bool ok = kb + 4 * h + i < p.K;
+            const float av = *(ok ? ar + kb + i : p.A), bv = *(ok ? br + (size_t)(kb + i) * bs : p.B);
+            a[i] = ok ? av : 0.f; b[i] = ok ? bv : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
     }
     // D layout: lane = column, register r = row (r & 3) + 8 (r >> 2) + 4 h
     float *cp = p.C + (size_t)(tm * 32 + 4 * h) * p.ldc + tn * 32 + l31;
+    const float bias = (p.bias && colok) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int rr = (r & 3) + 8 * (r >> 2);
-        if (colok && tm * 32 + 4 * h + rr < p.M) cp[(size_t)rr * p.ldc] = acc[r];
+        if (colok && tm * 32 + 4 * h + rr < p.M) cp[(size_t)rr * p.ldc] = acc[r] + bias;
     }
     if (MODE == 1 && p.zero_left && tn == 0 && l31 < p.zero_left) {
 #pragma unroll
@@ -213,12 +220,13 @@ size_t gg_gemm_small_workspace(int M, int N, int K)
 // workspace (mode 2 only): gg_gemm_small_workspace bytes, its LAST tiles * 4 + 256 bytes (the tickets) zero
 // on first use -- the kernel leaves them zero
 int gg_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
-                  int K, int zero_left, void *ws, hipStream_t st)
+                  int K, int zero_left, const float *bias, void *ws, hipStream_t st)
 {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || mode < 0 || mode > 2) return 1;
     GGGemm p;
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.zero_left = mode == 1 ? zero_left : 0;
+    p.bias = mode == 2 ? nullptr : bias;
     p.part = nullptr; p.tick = nullptr;
     const int ntile = ((M + 31) / 32) * ((N + 31) / 32);
     if (mode == 2) {
@@ -228,7 +236,7 @@ int gg_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, fl
         p.tick = (int *)((char *)ws + (size_t)ntile * S * 1024 * sizeof(float));
         gg_k_gemm_tn<<<dim3(S, ntile), 256, 0, st>>>(p);
     } else {
-        if ((K & 7) || zero_left < 0 || zero_left > 32) return 1;
+        if (zero_left < 0 || zero_left > 32) return 1;
         if (mode == 0) gg_k_gemm_rows<0><<<(ntile + 3) / 4, 256, 0, st>>>(p);
         else gg_k_gemm_rows<1><<<(ntile + 3) / 4, 256, 0, st>>>(p);
     }

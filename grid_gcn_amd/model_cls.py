@@ -108,7 +108,8 @@ class FCBNReLU(nn.Module):
         self.dropout = dropout
 
     def forward(self, x):
-        return F.dropout(self.l(x), self.dropout, self.training)
+        # (run_mlp: the hand-written kernels in training and evaluation on the GPU, the stock module elsewhere)
+        return F.dropout(run_mlp([self.l], x), self.dropout, self.training)
 
 
 class GGCNCls(nn.Module):
@@ -158,7 +159,11 @@ class GGCNCls(nn.Module):
                 cf = layer(cent[..., 0:3], neighbors, centmsk)                        # :104
             data = torch.cat([cent, cf], dim=2)                                   # :106
         net = cf.reshape(cf.shape[0], -1)                                         # flatten=True
-        return self.fc3(self.fc2(self.fc1(net)))
+        h = self.fc2(self.fc1(net))
+        if h.is_cuda and self._take_kw:
+            from . import train_ops
+            return train_ops.linear_mm(h, self.fc3)
+        return self.fc3(h)
 
 
 def cls_loss(logits, label, weights=None):

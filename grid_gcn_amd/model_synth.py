@@ -70,7 +70,11 @@ class GGCNSynth(nn.Module):
         # negative with relu=False: mask with -inf)
         neg = torch.finfo(cf.dtype).min
         pooled = torch.where(centmsk[..., None] > 0, cf, torch.full_like(cf, neg)).max(dim=1).values
-        logits = self.fc(pooled)
+        if pooled.is_cuda and _is_hip(ix):
+            from . import train_ops
+            logits = train_ops.linear_mm(pooled, self.fc)
+        else:
+            logits = self.fc(pooled)
         return (logits, outs) if return_layers else logits
 
 

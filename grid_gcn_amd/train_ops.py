@@ -532,13 +532,54 @@ def _small_ok(R, *dims):
     return SMALL_GEMM and R <= 65536 and all(0 < d <= 512 for d in dims)
 
 
+def _mm_nt(a, b, bias=None, out=None):
+    """a [M,K] x b [N,K]^T (+ bias [N]) -> [M,N] on csrc/gridgcn_gemm.hip: the products beside the edge pipeline
+    whatever their shape (any K, any row strides) -- nothing of a training or evaluation step goes to rocBLAS.
+    Not a throughput kernel (one wave per 32 x 32 tile, operands straight from memory): the large layers never
+    come here (the register-direct kernels take them, _WideLayerTrain included)."""
+    M, K = a.shape
+    N = b.shape[0]
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.stride(1) == 1 and b.shape[1] == K
+    rc = _lib.load().gridgcn_gemm_bias(0, _ptr(a), a.stride(0), _ptr(b), b.stride(0),
+                                       _ptr(bias.detach().contiguous()) if bias is not None else None, _ptr(out),
+                                       out.stride(0), M, N, K, _stream(a))
+    _lib.check(rc, "gridgcn_gemm_bias")
+    return out
+
+
+def _mm_nn(a, b, out=None):
+    """a [M,K] x b [K,N] -> [M,N] (see _mm_nt)"""
+    M, K = a.shape
+    N = b.shape[1]
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.stride(1) == 1 and b.shape[0] == K
+    rc = _lib.load().gridgcn_gemm_bias(1, _ptr(a), a.stride(0), _ptr(b), b.stride(0), None, _ptr(out),
+                                       out.stride(0), M, N, K, _stream(a))
+    _lib.check(rc, "gridgcn_gemm_bias")
+    return out
+
+
 def _tn_matmul(a, b, out=None):
     """a^T b for tall operands a [R,m], b [R,n] with small m, n: the contraction is cut into
     128-row slabs (one batched GEMM + a sum) so that the work spreads over the chip -- a plain
     [m,R]x[R,n] GEMM runs on m*n/tile workgroups only.  out: optional (strided) destination."""
     R = a.shape[0]
-    if a.is_cuda and a.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1 and \
-            _small_ok(R, a.shape[1], b.shape[1]) and (out is None or out.stride(1) == 1):
+    if a.is_cuda and a.dtype == torch.float32 and SMALL_GEMM and (out is None or out.stride(1) == 1):
+        if a.stride(1) != 1:
+            a = a.contiguous()
+        if b.stride(1) != 1:
+            b = b.contiguous()
         if out is None:
             out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
         return _gemm_small(2, a, b, out, a.shape[1], b.shape[1], R)
@@ -733,44 +774,86 @@ class _MLPTrain(torch.autograd.Function):
         return (dX, None) + tuple(grads)
 
 
+def _wide_direct_ok(E, cin, C):
+    """a layer of more than 256 output channels the register-direct kernels can take as 256-column slices"""
+    return (DIRECT_FWD and DIRECT_DX and E >= 4096 and cin % 8 == 0 and cin <= 320 and C % 256 == 0
+            and 256 < C <= 1024 and _dw_direct_ok(256, cin) and _lib.load().gridgcn_get_mlp_precision() == 0)
+
+
+def _pack_tmp(lib, W, b, cout, cin, st):
+    """operand layouts of a temporary weight (a slice, a transpose): packed per call, never cached"""
+    K, ldw, nwp, nwb = packed_sizes(cout, cin)
+    bufs = PACKS.get(lib, W, b, cout, cin, 0, cin, 0, True, (nwp, ldw, nwb, cin * ldw, 0), st)
+    return ldw, bufs
+
+
 class _WideLayerTrain(torch.autograd.Function):
-    """conv + BatchNorm(batch statistics) + ReLU of a layer BEYOND the MFMA kernels' widths
-    (> 256 output or > 384 input channels: the last layer of the classifier and of the 200k-point
-    workload).  The GEMMs go to rocBLAS; the BatchNorm work -- statistics, apply, backward sums,
-    dZ -- to this library's elementwise kernels (the framework's channels-last BatchNorm kernels
-    ran at 0.5-0.8 TB/s on these [131 k, 512] tensors and were 20 % of cfg5's step)."""
+    """conv + BatchNorm(batch statistics) + ReLU of a layer BEYOND the MFMA kernels' widths (> 256 output or
+    > 384 input channels: the last layer of the classifier and of the 200k-point workload).  No rocBLAS:
+      * large layers (>= 4096 rows, output a multiple of 256, input <= 320 columns): the register-direct kernels
+        on 256-column SLICES -- forward per output slice (statistics in its epilogue), dW per output slice of the
+        elementwise-formed dZ (identity BatchNorm constants), dX = dZ W as a plain forward product with W^T;
+      * anything else (a handful of rows, inputs of 512 / 1027 columns): csrc/gridgcn_gemm.hip (_mm_nt / _mm_nn /
+        _tn_matmul) + this library's BatchNorm kernels."""
 
     @staticmethod
     def forward(ctx, x, W, b, gamma, beta, bn):
         lib = _lib.load()
         x = x.contiguous()
         E, C = x.shape[0], W.shape[0]
+        cin = x.shape[1]
         dev = x.device
+        direct = _wide_direct_ok(E, cin, C)
         with torch.cuda.device(dev):
             st = _stream(x)
-            Z = torch.addmm(b.detach(), x.detach(), W.detach().t())
-            sums = _zeros(2 * C, torch.float64, dev)
-            _lib.check(lib.gridgcn_bn_stats(_ptr(Z), E, C, C, _ptr(sums), st), "gridgcn_bn_stats")
             vec = torch.empty((4, C), dtype=torch.float32, device=dev)
             track = bn.track_running_stats
-            rc = lib.gridgcn_bn_finalize(
-                _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, bn.eps,
-                _momentum(bn) if track else 0.0, C, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
-                _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
-                _ptr(bn.running_var) if track else None,
-                _ptr(bn.num_batches_tracked) if track else None, st)
-            _lib.check(rc, "gridgcn_bn_finalize")
+            if direct:
+                Z = torch.empty((E, C), dtype=torch.float32, device=dev)
+                allsums = _zeros(2 * C, torch.float64, dev)
+                Wbs = []
+                for h in range(C // 256):
+                    sl = slice(h * 256, (h + 1) * 256)
+                    ldw, bufs = _pack_tmp(lib, W.detach()[sl], b.detach()[sl], 256, cin, st)
+                    Wbs.append(bufs[2])
+                    sums = allsums[h * 512:(h + 1) * 512]
+                    rc = lib.gridgcn_linear_fwd_direct_ld(_ptr(x), E, cin, cin, _ptr(bufs[4]), _ptr(bufs[1]), ldw,
+                                                          256, None, None, _ptr(Z[:, sl]), _ptr(sums), C, 0, st)
+                    _lib.check(rc, "gridgcn_linear_fwd_direct")
+                    rc = lib.gridgcn_bn_finalize(
+                        _ptr(sums), _ptr(gamma.detach()[sl]), _ptr(beta.detach()[sl]), E, bn.eps,
+                        _momentum(bn) if track else 0.0, 256, _ptr(vec[0][sl]), _ptr(vec[1][sl]), _ptr(vec[2][sl]),
+                        _ptr(vec[3][sl]), _ptr(bn.running_mean[sl]) if track else None,
+                        _ptr(bn.running_var[sl]) if track else None,
+                        _ptr(bn.num_batches_tracked) if (track and h == 0) else None, st)
+                    _lib.check(rc, "gridgcn_bn_finalize")
+                saved_w = Wbs
+            else:
+                Z = _mm_nt(x.detach(), W.detach(), bias=b)
+                sums = _zeros(2 * C, torch.float64, dev)
+                _lib.check(lib.gridgcn_bn_stats(_ptr(Z), E, C, C, _ptr(sums), st), "gridgcn_bn_stats")
+                rc = lib.gridgcn_bn_finalize(
+                    _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, bn.eps,
+                    _momentum(bn) if track else 0.0, C, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                    _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
+                    _ptr(bn.running_var) if track else None,
+                    _ptr(bn.num_batches_tracked) if track else None, st)
+                _lib.check(rc, "gridgcn_bn_finalize")
+                saved_w = []
             Y = torch.empty_like(Z)
             rc = lib.gridgcn_bn_relu_apply(_ptr(Z), _ptr(vec[0]), _ptr(vec[1]), _ptr(Y), E, C, C, st)
             _lib.check(rc, "gridgcn_bn_relu_apply")
-        ctx.save_for_backward(x, W, Z, vec)
+        ctx.direct = direct
+        ctx.save_for_backward(x, W, Z, vec, *saved_w)
         return Y
 
     @staticmethod
     def backward(ctx, dY):
         lib = _lib.load()
-        x, W, Z, vec = ctx.saved_tensors
+        x, W, Z, vec = ctx.saved_tensors[:4]
+        Wbs = ctx.saved_tensors[4:]
         E, C = Z.shape
+        cin = x.shape[1]
         dev = x.device
         dY = dY.contiguous()
         with torch.cuda.device(dev):
@@ -788,8 +871,36 @@ class _WideLayerTrain(torch.autograd.Function):
                                                _ptr(vec[2]), _ptr(vec[3]), _ptr(v[0]), _ptr(v[1]),
                                                E, C, _ptr(dZ), st)
             _lib.check(rc, "gridgcn_bn_relu_bwd_elemt")
-            dX = torch.matmul(dZ, W.detach()) if ctx.needs_input_grad[0] else None
-            dW = _tn_matmul(dZ, x.detach())
+            if ctx.direct:
+                dX = None
+                if ctx.needs_input_grad[0]:
+                    # dX = dZ W: a plain forward product over K = C with the rows of W^T as "output channels"
+                    dX = torch.empty((E, cin), dtype=torch.float32, device=dev)
+                    Wt = W.detach().t()
+                    for c0 in range(0, cin, 256):
+                        n = min(256, cin - c0)
+                        ldw, bufs = _pack_tmp(lib, Wt[c0:c0 + n].contiguous(), _cached_zeros(n, dev), n, C, st)
+                        rc = lib.gridgcn_linear_fwd_direct_ld(_ptr(dZ), E, C, C, _ptr(bufs[4]), _ptr(bufs[1]), ldw, n,
+                                                              None, None, _ptr(dX[:, c0:]), None, cin, 0, st)
+                        _lib.check(rc, "gridgcn_linear_fwd_direct")
+                # dW = dZ^T x per 256-channel slice of dZ: the register-direct dW kernel with identity BatchNorm
+                # constants (dz = dy), the "pre-activation" it asks for being dZ itself (never used: shift = inf)
+                dW = torch.empty((C, cin), dtype=torch.float32, device=dev)
+                ident = _identity_consts(256, dev)
+                nbytes = ctypes.c_size_t(0)
+                lib.gridgcn_linear_bwd_workspace_bytes(E, cin, 256, ctypes.byref(nbytes))
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                for h in range(C // 256):
+                    sl = slice(h * 256, (h + 1) * 256)
+                    rc = lib.gridgcn_linear_bwd_ld(
+                        _ptr(dZ[:, sl]), _ptr(dZ[:, sl]), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]),
+                        _ptr(ident[3]), _ptr(ident[4]), _ptr(ident[5]), _ptr(x), None, None, None, None,
+                        _ptr(Wbs[h]), None, None, 0, E, 256, cin, cin, 0, C, C, 0, 0, None, _ptr(dW[sl]), None,
+                        None, None, 0, _ptr(ws), nbytes.value, st)
+                    _lib.check(rc, "gridgcn_linear_bwd")
+            else:
+                dX = _mm_nn(dZ, W.detach()) if ctx.needs_input_grad[0] else None
+                dW = _tn_matmul(dZ, x.detach())
             db = _zeros(C, torch.float32, dev)      # bias in front of a BatchNorm: sum(dZ) == 0
         return dX, dW, db, v[2], v[3], None
 
@@ -899,7 +1010,7 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim, out=
     with torch.cuda.device(dev):
         st = _stream(src)
         feat = src[..., 4:].reshape(R, Cf)
-        Ysrc = torch.matmul(feat, W0[:, rot:].t()).contiguous()
+        Ysrc = _mm_nt(feat, W0[:, rot:])
         wgb = torch.cat([W0[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0), b0[None]])
         att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
         rc = lib.gridgcn_edge_lin0_forward(
@@ -1127,7 +1238,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 Ysrc = _gemm_small(0, feat, W0.detach()[:, rot:], torch.empty((R, C0), dtype=torch.float32,
                                                                              device=dev), R, C0, Cf)
             else:
-                Ysrc = torch.matmul(feat, W0.detach()[:, rot:].t()).contiguous()
+                Ysrc = _mm_nt(feat, W0.detach()[:, rot:])
             # rows 0..2: geo_vec weights [3][C0] (zeros without geo_vec), row 3: bias
             wgb = torch.cat([W0.detach()[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0),
                              b0.detach()[None]])
@@ -1330,8 +1441,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                     _gemm_small(1, dYsrc, W0.detach()[:, rot:], gsrc[:, 4:], R, Cf, C0, zero_left=4)
                     gsrc = gsrc.view(B, Nsrc, Cs)
                 else:
-                    Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0), W0.detach()[:, rot:].t()])
-                    gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
+                    gsrc = torch.zeros((R, Cs), dtype=torch.float32, device=dev)
+                    _mm_nn(dYsrc, W0.detach()[:, rot:], out=gsrc[:, 4:])
+                    gsrc = gsrc.view(B, Nsrc, Cs)
             db0 = _zeros(C0, torch.float32, dev)
         grads0 = [dW0, db0, v[2], v[3]]
         return (gsrc, None, None, None) + tuple(grads0) + tuple(grads_rest) + tuple(grads_a)
@@ -1535,7 +1647,7 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
                     Ysrc = _gemm_small(0, feat, W0.detach()[:, 3:],
                                        torch.empty((R, C0), dtype=torch.float32, device=dev), R, C0, Cf)
                 else:
-                    Ysrc = torch.matmul(feat, W0.detach()[:, 3:].t()).contiguous()
+                    Ysrc = _mm_nt(feat, W0.detach()[:, 3:])
                 wgb = torch.cat([W0.detach()[:, :3].t(), b0.detach()[None]])
                 x0 = torch.empty((E, C0), dtype=torch.float32, device=dev)          # Z0
                 sums0 = _zeros(2 * C0, torch.float64, dev)
@@ -1572,7 +1684,7 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
             W2, b2, g2, be2 = pa2[:4]
             W2d = W2.detach()
             N0, K12 = W2d.shape[0], A0 + C
-            rowb = torch.addmm(b2.detach(), ctxv, W2d[:, K12:].t())                 # [ncent, N0]
+            rowb = _mm_nt(ctxv, W2d[:, K12:], bias=b2)                              # [ncent, N0]
             _, ldw, _, _ = packed_sizes(N0, K12)
             Wq = torch.empty(K12 * ldw, dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_pack_linear(_ptr(W2d[:, :K12].contiguous()), None, N0, K12, 0,
@@ -1727,16 +1839,16 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
                         _gemm_small(1, dYsrc, W0.detach()[:, 3:], gsrc[:, 4:], R, Cf, C0, zero_left=4)
                         gsrc = gsrc.view(B, Nsrc, Cs)
                     else:
-                        Wt = torch.cat([_cached_zeros(4 * C0, dev).view(4, C0),
-                                        W0.detach()[:, 3:].t()])
-                        gsrc = torch.matmul(dYsrc, Wt.t()).view(B, Nsrc, Cs)
+                        gsrc = torch.zeros((R, Cs), dtype=torch.float32, device=dev)
+                        _mm_nn(dYsrc, W0.detach()[:, 3:], out=gsrc[:, 4:])
+                        gsrc = gsrc.view(B, Nsrc, Cs)
                     # the context vector's arg-max rows
                     if dcb.stride(1) == 1 and Wc.stride(1) == 1 and dcb.shape[1] % 8 == 0 and \
                             _small_ok(dcb.shape[0], Wc.shape[1], dcb.shape[1]):
                         dctx = _gemm_small(1, dcb, Wc, torch.empty((dcb.shape[0], Wc.shape[1]), dtype=torch.float32,
                                                                   device=dev), dcb.shape[0], Wc.shape[1], dcb.shape[1])
                     else:
-                        dctx = torch.matmul(dcb, Wc).contiguous()
+                        dctx = _mm_nn(dcb, Wc)
                     _lib.check(lib.gridgcn_ctx_max_backward(_ptr(dctx), _ptr(cidx), ncent, Cf, Cs,
                                                             _ptr(gsrc), st),
                                "gridgcn_ctx_max_backward")
@@ -1790,7 +1902,7 @@ def edge_block_cls_eval(src, nebidx, cent, pt_layers, att1_layers, att2_layers):
         if Cf > 0:
             l0 = pt_layers[0]
             W0, C0 = l0.lin.weight, l0.lin.out_features
-            Ysrc = torch.matmul(src[..., 4:].reshape(R, Cf), W0[:, 3:].t()).contiguous()
+            Ysrc = _mm_nt(src[..., 4:].reshape(R, Cf), W0[:, 3:])
             wgb = torch.cat([W0[:, :3].t(), l0.lin.bias[None]])
             Z0 = torch.empty((E, C0), dtype=torch.float32, device=dev)
             rc = lib.gridgcn_edge_lin0_forward(
@@ -1809,7 +1921,7 @@ def edge_block_cls_eval(src, nebidx, cent, pt_layers, att1_layers, att2_layers):
         A0 = Za1.shape[1]
         a20 = att2_layers[0]
         W2, N0, K12 = a20.lin.weight, a20.lin.out_features, A0 + C
-        rowb = torch.addmm(a20.lin.bias, ctxv, W2[:, K12:].t())
+        rowb = _mm_nt(ctxv, W2[:, K12:], bias=a20.lin.bias)
         _, ldw, _, _ = packed_sizes(N0, K12)
         Wq = torch.empty(K12 * ldw, dtype=torch.float32, device=dev)
         _lib.check(lib.gridgcn_pack_linear(_ptr(W2[:, :K12].contiguous()), None, N0, K12, 0, K12, 0,
@@ -1924,6 +2036,33 @@ class _LinearPlain(torch.autograd.Function):
             db64 = _zeros(Cp, torch.float64, dev)
             _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C, _ptr(db64), st), "gridgcn_colsum")
         return dX, dW[:C], db64[:C].float()
+
+
+class _LinearMM(torch.autograd.Function):
+    """x W^T + b of a torch.nn.Linear of any shape on csrc/gridgcn_gemm.hip (the classifier's 256 -> 40 scores on
+    a batch of rows: nothing for a conv + BatchNorm kernel, and not worth a GEMM library)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        with torch.cuda.device(x.device):
+            return _mm_nt(x.detach(), W.detach(), bias=b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous()
+        with torch.cuda.device(x.device):
+            dX = _mm_nn(g, W.detach()) if ctx.needs_input_grad[0] else None
+            dW = _tn_matmul(g, x.detach())
+        return dX, dW, g.sum(0)
+
+
+def linear_mm(x, lin):
+    """torch.nn.Linear on fp32 GPU rows through _LinearMM (stock module elsewhere)"""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.bias is not None:
+        return _LinearMM.apply(x.contiguous(), lin.weight, lin.bias)
+    return lin(x)
 
 
 def linear_plain_train(x, lin):

@@ -69,7 +69,7 @@ const char *gridgcn_strerror(int code);
 int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors;
                                  * 4: gridgcn_set_option, Z-less attention pair removed, the library
                                  *    reads nothing from the process environment
-                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, options 3 / 4 */
+                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4 */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -426,8 +426,8 @@ int gridgcn_bn_dz_segsum(const float *dY, const float *Z, const float *scale, co
 /* gridgcn_gemm_small: the small dense products beside the edge pipeline (the first point conv applied
  *   to the source points and its two backward products; csrc/gridgcn_gemm.hip), fp32 MFMA, operands
  *   with arbitrary row strides (column slices of wider tensors), no packing:
- *     mode 0  C[M][N] = A[M][K] * B[N][K]^T        (K % 8 == 0)
- *     mode 1  C[M][N] = A[M][K] * B[K][N]          (K % 8 == 0; zero_left <= 32: the columns
+ *     mode 0  C[M][N] = A[M][K] * B[N][K]^T        (any K since ABI 5)
+ *     mode 1  C[M][N] = A[M][K] * B[K][N]          (any K; zero_left <= 32: the columns
  *                                                   [-zero_left, 0) left of C are zero-filled)
  *     mode 2  C[M][N] = A[K][M]^T * B[K][N]        (contraction over the K rows, any K; fixed summation
  *                                                   order; workspace of _workspace_bytes whose last
@@ -438,6 +438,11 @@ int gridgcn_gemm_small_workspace_bytes(int M, int N, int K, size_t *bytes);
 int gridgcn_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                        int M, int N, int K, int zero_left, void *workspace, size_t workspace_bytes,
                        void *stream);
+/* gridgcn_gemm_bias: modes 0 / 1 with bias[N] (may be NULL) added to every row: torch's addmm / Linear for the
+ * products beside the edge pipeline that no conv+BatchNorm kernel takes (per-centre context bias of the
+ * classification block, layers of a handful of rows). */
+int gridgcn_gemm_bias(int mode, const float *A, int lda, const float *B, int ldb, const float *bias, float *C,
+                      int ldc, int M, int N, int K, void *stream);
 /* gridgcn_bn_stats: sums[c] += sum_e Z[e][c], sums[C+c] += sum_e Z[e][c]^2 (input of
  *   gridgcn_bn_finalize) for a layer whose GEMM ran elsewhere (the "wide" fallback: stacks beyond
  *   the MFMA kernels' 256 output / 384 input channels use rocBLAS + these BatchNorm kernels). */

@@ -133,6 +133,66 @@ def test_col_split_equals_whole_rows(E, cin, dims):
         close(a, b, 2e-2 if flipped else 2e-5, rows=a.shape[0] if flipped else 0)
 
 
+@pytest.mark.parametrize("E,cin,dims", [(5000, 256, [512]), (4100, 264, [256, 512]), (8192, 128, [512, 256]),
+                                        (300, 512, [512, 256]), (64, 1027, [512, 512]), (33, 259, [256, 512])],
+                         ids=["5000_256", "4100_264", "8192_128", "300_512", "64_1027", "33_259"])
+def test_wide_layers_without_rocblas_match_torch(E, cin, dims):
+    """Layers beyond 256 output / 384 input channels (last layer of the classifier and of the 200k-point
+    workload, the classifier's FC head): register-direct kernels on 256-column slices where the layer is
+    large, csrc/gridgcn_gemm.hip (any K) + the BatchNorm kernels otherwise -- against the stock modules."""
+    torch.manual_seed(E + cin)
+    ref = mlp(cin, dims).to(DEV).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+    new = copy.deepcopy(ref)
+    x1 = torch.randn(E, cin, device=DEV).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    assert not train_ops.supported(list(new), x2) and train_ops.wide_supported(list(new), x2)
+    y1 = ref(x1)
+    y2 = train_ops.mlp_wide_train(x2, list(new))
+    assert float((y1 - y2).abs().max()) <= 3e-5 * max(1.0, float(y1.abs().max()))
+    g = torch.randn_like(y1)
+    y1.backward(g)
+    y2.backward(g)
+
+    def close(a, b, tol):
+        s = max(1e-3, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= tol * s, (float((a - b).abs().max()), s)
+    close(x2.grad, x1.grad, 5e-4)
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), new.named_parameters()):
+        if n1.endswith("lin.bias"):
+            assert float(p2.grad.abs().max()) == 0.0
+        else:
+            close(p2.grad, p1.grad, 5e-4)
+    for (n1, b1), (n2, b2) in zip(ref.named_buffers(), new.named_buffers()):
+        if "num_batches" in n1:
+            assert int(b1) == int(b2)
+        else:
+            close(b2, b1, 1e-5)
+
+
+def test_gemm_any_k_and_bias():
+    """gridgcn_gemm_bias: modes 0 / 1 for any K (short last chunk), strided operands, optional bias."""
+    torch.manual_seed(3)
+    for M, N, K in ((70, 40, 259), (33, 195, 1027), (5, 3, 1), (128, 64, 7), (1000, 512, 515)):
+        a = torch.randn(M, K + 5, device=DEV)[:, :K]
+        b = torch.randn(N, K + 3, device=DEV)[:, :K]
+        bias = torch.randn(N, device=DEV)
+        want = a.double() @ b.double().t() + bias.double()
+        got = train_ops._mm_nt(a, b, bias=bias)
+        assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * K ** 0.5
+        b2 = torch.randn(K, N + 2, device=DEV)[:, :N]
+        want = a.double() @ b2.double()
+        got = train_ops._mm_nn(a, b2)
+        assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * K ** 0.5
+        c = torch.randn(M, N, device=DEV)
+        want = a.double().t() @ c.double()
+        got = train_ops._tn_matmul(a, c)
+        assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * M ** 0.5
+
+
 EB_CASES = [
     # B, O, P, cin, pt dims, C
     (2, 300, 5, 131, [128]),
