@@ -14,7 +14,16 @@
 #include "gridgcn_mma.h"
 #include "gridgcn_train.h"
 
-#define GG_AF_TS 68    // LDS row stride (floats) of the staged half tile: 64 channels + 4
+// LDS operand layouts (round 4): every MFMA run reads its B operands with four ds_read_b128 IN FRONT of the run.
+// With [step][lane] layouts each MFMA had its own ds_read_b32 and the compiler -- out of registers at 247 --
+// emitted ds_read, s_waitcnt lgkmcnt(0), two MFMAs, thirty-two times per chunk: the matrix pipe waited for an LDS
+// round trip at every second instruction (gridgcn_attbwd_nz.hip: 973 -> 800 us from this change alone).
+//   Wl (fp32) : Wl[(chunk * 64 + lane) * WS + s] = Wdx[(chunk * 16 + s) * 64 + lane], s < 16
+//   T per wave: TRANSPOSED, Tt[(cc * 32 + channel) * TS + row]: written by the row's lane one channel at a time,
+//               read by the channel's lane as the rows (r & 3) + 8 (r >> 2) + 4 h -- four runs of four rows
+#define GG_AF_TS 36    // LDS stride (floats) of one channel of the transposed half tile: 32 rows + 4
+#define GG_AF_WS 20    // LDS stride (floats) of one lane's 16 operand values: 16 + 4 (conflict-free ds_read_b128)
+#define GG_AF_TILE (64 * GG_AF_TS)
 
 // bf16 contraction mode (gridgcn_direct.hip: gg_set_mlp_bf16): eight fp32 MFMA steps = one
 // v_mfma_f32_32x32x16_bf16, operands rounded in registers (compiler-made conversion, see there)
@@ -51,9 +60,9 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
     const int h = lane >> 5, l31 = lane & 31;
     const int cin = p.cin;
     const bool colok = l31 < cin;                      // cin = 16: half of the dX / dW^T tile is idle
-    float *Wl = lds;                                   // Wdx: [C/2 steps][64]
-    float *cst = lds + C * 32;                         // scale, shift, mean, bz, cz  [5][C]
-    float *T = cst + 5 * C + wave * (32 * GG_AF_TS);   // this wave's dZ half tile [32][TS]
+    float *Wl = lds;                                   // Wdx: [C/32 chunks][64 lanes][WS]
+    float *cst = lds + (C / 32) * 64 * GG_AF_WS;       // scale, shift, mean, bz, cz  [5][C]
+    float *T = cst + 5 * C + wave * GG_AF_TILE;        // this wave's transposed dZ half tile [64 channels][TS]
     {
         if (BF16) {
             // [C/16 groups of 8 steps][64 lanes] x 8 bf16 in the first half of the Wl area
@@ -67,8 +76,10 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                 ((ggaf_u32x4 *)Wl)[e] = o;
             }
         } else {
-            const float4 *src = (const float4 *)p.Wdx;
-            for (int i = tid; i < C * 8; i += 256) ((float4 *)Wl)[i] = src[i];
+            for (int i = tid; i < C * 32; i += 256) {
+                const int st = i >> 6, ln = i & 63;
+                Wl[((st >> 4) * 64 + ln) * GG_AF_WS + (st & 15)] = p.Wdx[i];
+            }
         }
         for (int c = tid; c < C; c += 256) {
             const float sc = p.scale[c];
@@ -207,22 +218,26 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
             if constexpr (BF16) {
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    float tv[8];
-#pragma unroll
-                    for (int jx = 0; jx < 8; jx++) {
-                        const int r = hf * 8 + jx;
-                        tv[jx] = T[((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31 + cc * 32];
-                    }
+                    // rows r = 8 hf + jx: two runs of four consecutive rows
+                    const gg_f32x4 t0 = gg_ld_f4(T + (cc * 32 + l31) * GG_AF_TS + 16 * hf + 4 * h);
+                    const gg_f32x4 t1 = gg_ld_f4(T + (cc * 32 + l31) * GG_AF_TS + 16 * hf + 8 + 4 * h);
+                    const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
                     const ggaf_u32x4 b8 = {ggaf_pk(tv[0], tv[1]), ggaf_pk(tv[2], tv[3]),
                                            ggaf_pk(tv[4], tv[5]), ggaf_pk(tv[6], tv[7])};
                     accw[j] = ggaf_mfma(av8[hf], b8, accw[j]);
                 }
             } else {
+                gg_f32x4 t4[4];
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float *trow = T + ((r & 3) + 8 * (r >> 2) + 4 * h) * GG_AF_TS + l31;
-                    const float avr = fmaxf(__builtin_fmaf(zpv[r], ps, psh), 0.f);      // 0 where zpv is NaN
-                    accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr, trow[cc * 32], accw[j], 0, 0, 0);
+                for (int jg = 0; jg < 4; jg++) t4[jg] = gg_ld_f4(T + (cc * 32 + l31) * GG_AF_TS + 8 * jg + 4 * h);
+#pragma unroll
+                for (int jg = 0; jg < 4; jg++) {
+                    const float tv[4] = {t4[jg].x, t4[jg].y, t4[jg].z, t4[jg].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float avr = fmaxf(__builtin_fmaf(zpv[4 * jg + i], ps, psh), 0.f);   // 0 where zpv is NaN
+                        accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr, tv[i], accw[j], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -240,7 +255,8 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                     const gg_f32x4 d = gg_dz4v(__builtin_bit_cast(gg_f32x4, z[q]), __builtin_bit_cast(gg_f32x4, g[q]),
                                                am[q], pp, sparse, cst, C, k0 + 4 * q);
                     a[q] = __builtin_bit_cast(float4, d);
-                    *(gg_f32x4 *)(T + l31 * GG_AF_TS + cc * 32 + h * 16 + 4 * q) = d;
+                    float *tw = T + (cc * 32 + h * 16 + 4 * q) * GG_AF_TS + l31;
+                    tw[0] = d.x; tw[GG_AF_TS] = d.y; tw[2 * GG_AF_TS] = d.z; tw[3 * GG_AF_TS] = d.w;
                     __builtin_amdgcn_sched_barrier(0);   // (one quad's constants live at a time)
                 }
                 if (2 * hc + cc + 1 < NJ) issue(zr, gr, ar, 2 * hc + cc + 1);
@@ -256,14 +272,16 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                         accx = ggaf_mfma(a8, ((const ggaf_u32x4 *)Wl)[(2 * (2 * hc + cc) + g) * 64 + lane], accx);
                     }
                 } else {
+                gg_f32x4 w4[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++)
+                for (int q = 0; q < 4; q++) w4[q] = gg_ld_f4(Wl + ((2 * hc + cc) * 64 + lane) * GG_AF_WS + 4 * q);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_af_f4(a[q], i), Wl[s * 64 + lane],
-                                                                    accx, 0, 0, 0);
-                        s++;
-                    }
+                for (int q = 0; q < 4; q++) {
+                    const float wv[4] = {w4[q].x, w4[q].y, w4[q].z, w4[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(gg_af_f4(a[q], i), wv[i], accx, 0, 0, 0);
+                }
                 }
                 // NJ = 4: dW of THIS chunk's 32 channels right away (not of both chunks after the second):
                 // every chunk then has its dX and its dW MFMAs between the issue of the next chunk's
@@ -390,7 +408,7 @@ static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
         attr_done = true;
     }
     const int C = NJ * 32;
-    const size_t lds = ((size_t)C * 32 + 5 * C + 4 * 32 * GG_AF_TS) * sizeof(float);
+    const size_t lds = ((size_t)(C / 32) * 64 * GG_AF_WS + 5 * C + 4 * GG_AF_TILE) * sizeof(float);
     int grid = gg_att_fused_grid(p.E, C);
     if (gg_get_mlp_bf16() && grid > 512) grid = 512;   // the bf16 form holds two workgroups per CU at either width
     if (gg_get_mlp_bf16()) gg_k_att_bwd_fused<NJ, true><<<grid, 256, lds, st>>>(p);
