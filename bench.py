@@ -142,6 +142,15 @@ def rccl_capture_probe(world, rank, local, dev):
     return ok
 
 
+def make_opt(net, eager):
+    """Adam(lr 1e-3, wd 1e-5): the one-launch kernel of grid_gcn_amd.optim (torch.optim.Adam's update to
+    within rounding; tests/test_gpu_glue.py), or -- --switch OWN_ADAM=0 -- the framework's multi-tensor one"""
+    from grid_gcn_amd import optim, train_ops
+    if train_ops.OWN_ADAM:
+        return optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
+    return torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=not eager)
+
+
 def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
     """The timed step.  Default: one captured hipGraph (for N > 1 with the flat RCCL all-reduce
     inside, when rccl_capture_probe says a captured collective replays correctly here) --
@@ -149,10 +158,12 @@ def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
     launches; the GPU work of a replay is that of the eager step, launch for launch, with the
     random draws still fresh per step (device-side seed).  Falls back to the eager step when the
     capture fails; `step_mode` in the JSON line says which one was timed."""
+    one = torch.ones((), dtype=torch.float32, device=inputs[0].device)
+
     def eager():
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(net(*inputs), target)
-        loss.backward()
+        loss.backward(one)                    # (the default would launch a fill for the same scalar)
         sync()
         opt.step()
         return loss
@@ -331,7 +342,7 @@ def main():
     if a.config != "cfg4":
         import bench_configs
         out = bench_configs.run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step,
-                                time_allreduce, param_sync_spread)
+                                time_allreduce, param_sync_spread, make_opt)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if world > 1:
@@ -349,9 +360,7 @@ def main():
     torch.manual_seed(0)
     net = model.GGCNSeg(cfg, seed=rank).to(dev)
     net.train()
-    # one multi-tensor kernel for the whole update instead of ~10 tiny launches per parameter
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True,
-                           capturable=not a.eager)
+    opt = make_opt(net, a.eager)
     sync = dp.FlatGradAllReduce(net)
     sync.broadcast_parameters()
     data, npn = synth.make_batch(B, points, kind, first_id=rank * B)   # a different shard per rank
@@ -381,8 +390,9 @@ def main():
                    "kernels": "hand-written HIP for Gridify/BallKNN, edge inputs (gather+geo) and their "
                               "sorted backward, all conv+BatchNorm+ReLU stacks fwd+bwd (fp32 MFMA), "
                               "att product + max, fc1 + dropout + class scores (one op) + softmax "
-                              "cross-entropy, the small GEMMs on the source points; PyTorch-ROCm for "
-                              "concat/mask on [B,O,C] and fused Adam"},
+                              "cross-entropy, the small GEMMs on the source points, concat + centre mask of "
+                              "the layer boundaries, Adam (one launch); PyTorch-ROCm for device memory, "
+                              "streams, autograd bookkeeping and the RCCL call"},
         # host side of the timed region: time to ENQUEUE the K steps (Python + ctypes + launches);
         # the step is GPU-bound while this stays below ms_per_step
         "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,

@@ -27,7 +27,7 @@ def _line(metric, value, unit, a, world, ms_step, workload, extra):
 
 
 def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step, time_allreduce=None,
-        param_sync_spread=None):
+        param_sync_spread=None, make_opt=None):
     torch.manual_seed(0)
     if a.config == "cfg1":
         # latency of one CAGQ layer on one cloud: the reference's CPU-runnable case
@@ -75,8 +75,7 @@ def run(a, world, rank, dev, traffic, time_training, cagq_roofline, make_step, t
         metric = "point-clouds/sec fwd+bwd (synthetic 200k-pt, 4-layer GridConv)"
         flops = 3.0 * model_synth.forward_flops(net, B)
 
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True,
-                           capturable=not a.eager)
+    opt = make_opt(net, a.eager)
     sync = dp.FlatGradAllReduce(net)
     sync.broadcast_parameters()
     x = torch.from_numpy(data[..., :3].copy()).to(dev)

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GG_HIP_LIB: profiling variant of the same library (lib/libgridgcn_hip_prof.so, tools/prof_phases.py)
 LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
-ABI_VERSION = 5                 # include/gridgcn.h: gridgcn_abi_version()
+ABI_VERSION = 6                 # include/gridgcn.h: gridgcn_abi_version()
 OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
 OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
 OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK
@@ -46,6 +46,8 @@ EXPORTS = [
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
     "gridgcn_linear_fwd_direct2", "gridgcn_ctx_max", "gridgcn_ctx_max_backward",
     "gridgcn_bn_dz_segsum", "gridgcn_sparse_add", "gridgcn_bn_stats",
+    "gridgcn_ball_knn_grid_ld", "gridgcn_bn_finalize_tail", "gridgcn_softmax_ce_loss", "gridgcn_colsum_f32",
+    "gridgcn_cat_mask", "gridgcn_mask_sum", "gridgcn_adam_step",
 ]
 
 
@@ -60,8 +62,9 @@ class GridParams(ctypes.Structure):
 
 class PackDesc(ctypes.Structure):
     """struct gridgcn_pack_desc (include/gridgcn.h)."""
-    _fields_ = [(n, ctypes.c_void_p) for n in ("W", "b", "Wp", "Bp", "Wb", "Wg", "Wq", "Wdx")] + \
-               [(n, ctypes.c_int32) for n in ("C", "cin_w", "rot", "cin", "ndx", "K", "ldw", "n")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("W", "b", "Wp", "Bp", "Wb", "Wg", "Wq", "Wdx", "wgb")] + \
+               [(n, ctypes.c_int32) for n in ("C", "cin_w", "rot", "cin", "ndx", "K", "ldw", "n", "geo",
+                                              "reserved")]
 
 
 class ConvLayer(ctypes.Structure):
@@ -165,6 +168,23 @@ def load():
     lib.gridgcn_pairmax_bwd_masked.argtypes = [vp] * 10 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_att_bwd_noz_workspace_bytes.restype = ci
     lib.gridgcn_att_bwd_noz_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_ball_knn_grid_ld.restype = ci
+    lib.gridgcn_ball_knn_grid_ld.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp,
+                                             vp, ctypes.c_size_t, vp]
+    lib.gridgcn_bn_finalize_tail.restype = ci
+    lib.gridgcn_bn_finalize_tail.argtypes = [vp, vp, vp, ll, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp,
+                                             vp, vp, vp, vp, vp, vp]
+    lib.gridgcn_softmax_ce_loss.restype = ci
+    lib.gridgcn_softmax_ce_loss.argtypes = [vp, ci, ci, vp, ll, ci, vp, vp, vp, vp]
+    lib.gridgcn_colsum_f32.restype = ci
+    lib.gridgcn_colsum_f32.argtypes = [vp, ll, ci, ci, vp, vp, vp]
+    lib.gridgcn_cat_mask.restype = ci
+    lib.gridgcn_cat_mask.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, ci, ll, vp]
+    lib.gridgcn_mask_sum.restype = ci
+    lib.gridgcn_mask_sum.argtypes = [vp, ci, vp, ci, ci, ci, vp, vp, ll, vp]
+    lib.gridgcn_adam_step.restype = ci
+    lib.gridgcn_adam_step.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ctypes.c_float, vp, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp]
     lib.gridgcn_gemm_bias.restype = ci
     lib.gridgcn_gemm_bias.argtypes = [ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.gridgcn_att_bwd_noz.restype = ci

@@ -22,7 +22,7 @@ SOURCES = ["gridgcn_index.hip", "gridgcn_index_legacy.hip", "gridgcn_query.hip",
            "gridgcn_direct.hip", "gridgcn_attbwd.hip", "gridgcn_attbwd_nz.hip", "gridgcn_atteval.hip",
            "gridgcn_pairmax.hip", "gridgcn_head.hip", "gridgcn_scatter.hip",
            "gridgcn_edgelin.hip", "gridgcn_ballgrid.hip", "gridgcn_clsblock.hip", "gridgcn_cas.hip", "gridgcn_fastrand.hip",
-           "gridgcn_gemm.hip",
+           "gridgcn_gemm.hip", "gridgcn_optim.hip",
            "gridgcn_capi.hip"]
 # -ffp-contract=off: the parity contract is "fp32, IEEE, no FMA contraction" (SURVEY App. A);
 # the MFMA/FMA use inside the GridConv kernels is explicit (intrinsics), never compiler-made.

@@ -31,7 +31,7 @@ __device__ __forceinline__ int gg_bg_axis(float x, float o, float inv, int d)
 
 __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__restrict__ known,
                                                              const int *__restrict__ downnum,
-                                                             int m, float radius,
+                                                             int m, int sk, float radius,
                                                              GGBallGridInfo *__restrict__ info,
                                                              int *__restrict__ cellStart,
                                                              float4 *__restrict__ sorted)
@@ -43,10 +43,10 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int dn = downnum[b];
     dn = dn > m ? m : (dn < 0 ? 0 : dn);
-    const float *kb = known + (size_t)b * m * 3;
+    const float *kb = known + (size_t)b * m * sk;   // sk floats per point (3, or 4: rows x y z w)
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int j = tid; j < dn; j += 1024) {
-        const float x = kb[j * 3], y = kb[j * 3 + 1], z = kb[j * 3 + 2];
+        const float x = kb[(size_t)j * sk], y = kb[(size_t)j * sk + 1], z = kb[(size_t)j * sk + 2];
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
             mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
     for (int c = tid; c < g.ncell; c += 1024) cnt[c] = 0;
     __syncthreads();
     for (int j = tid; j < dn; j += 1024) {
-        const float x = kb[j * 3], y = kb[j * 3 + 1], z = kb[j * 3 + 2];
+        const float x = kb[(size_t)j * sk], y = kb[(size_t)j * sk + 1], z = kb[(size_t)j * sk + 2];
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
             const int c = (gg_bg_axis(z, g.oz, g.inv, g.dz) * g.dy + gg_bg_axis(y, g.oy, g.inv, g.dy)) * g.dx +
                           gg_bg_axis(x, g.ox, g.inv, g.dx);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
     // 16-byte records per (z, y) row of cells instead of an index and then three scattered floats
     float4 *sb = sorted + (size_t)b * m;
     for (int j = tid; j < dn; j += 1024) {
-        const float x = kb[j * 3], y = kb[j * 3 + 1], z = kb[j * 3 + 2];
+        const float x = kb[(size_t)j * sk], y = kb[(size_t)j * sk + 1], z = kb[(size_t)j * sk + 2];
         if (isfinite(x) && isfinite(y) && isfinite(z)) {
             const int c = (gg_bg_axis(z, g.oz, g.inv, g.dz) * g.dy + gg_bg_axis(y, g.oy, g.inv, g.dy)) * g.dx +
                           gg_bg_axis(x, g.ox, g.inv, g.dx);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void gg_k_ball_grid_build(const float *__rest
 
 template <int K>
 __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restrict__ unknown,
-                                                            const int *__restrict__ upnum, int n,
+                                                            const int *__restrict__ upnum, int n, int su, int ztail,
                                                             int m, int topk, float r2,
                                                             const GGBallGridInfo *__restrict__ info,
                                                             const int *__restrict__ cellStart,
@@ -148,9 +148,14 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restr
 {
     const int b = blockIdx.y;
     const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= n || qi >= upnum[b]) return;       // rows >= upnum are not written (as the reference)
+    if (qi >= n) return;
+    if (qi >= upnum[b]) {                        // rows >= upnum are not written (as the reference) ...
+        if (ztail)                               // ... or zeroed, for callers that hand over raw memory
+            for (int l = 0; l < topk; l++) idx[((size_t)b * n + qi) * topk + l] = 0;
+        return;
+    }
     const GGBallGridInfo g = info[b];
-    const float *u = unknown + ((size_t)b * n + qi) * 3;
+    const float *u = unknown + ((size_t)b * n + qi) * su;
     const float ux = u[0], uy = u[1], uz = u[2];
     const int *cs = cellStart + (size_t)b * (GG_BG_NCMAX + 1);
     const float4 *sb = sorted + (size_t)b * m;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query(const float *__restr
 // total order as above, so the result is the same K records whatever L is.
 template <int K, int L>
 __global__ __launch_bounds__(256) void gg_k_ball_grid_query_ml(const float *__restrict__ unknown,
-                                                               const int *__restrict__ upnum, int n,
+                                                               const int *__restrict__ upnum, int n, int su, int ztail,
                                                                int m, int topk, float r2,
                                                                const GGBallGridInfo *__restrict__ info,
                                                                const int *__restrict__ cellStart,
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query_ml(const float *__re
                                                  //  the merge shuffles need every lane)
     const int qc = qi < n ? qi : n - 1;
     const GGBallGridInfo g = info[b];
-    const float *u = unknown + ((size_t)b * n + qc) * 3;
+    const float *u = unknown + ((size_t)b * n + qc) * su;
     const float ux = u[0], uy = u[1], uz = u[2];
     const int *cs = cellStart + (size_t)b * (GG_BG_NCMAX + 1);
     const float4 *sb = sorted + (size_t)b * m;
@@ -313,6 +318,8 @@ __global__ __launch_bounds__(256) void gg_k_ball_grid_query_ml(const float *__re
 #pragma unroll
         for (int l = 0; l < K; l++)
             if (l < topk) o[l] = res[l];
+    } else if (ztail && sub == 0 && qi < n) {
+        for (int l = 0; l < topk; l++) idx[((size_t)b * n + qi) * topk + l] = 0;
     }
 }
 
@@ -331,14 +338,14 @@ size_t gg_ball_grid_workspace(int B, int m)
 // 1 = not supported (k > 6): the caller uses the tiled scan
 int gg_ball_knn_grid(const float *unknown, const float *known, const int *downnum,
                      const int *upnum, int B, int n, int m, int k, float radius, int *idx,
-                     void *workspace, hipStream_t st)
+                     void *workspace, hipStream_t st, int su, int sk, int ztail)
 {
     if (k < 1 || k > 6 || !(radius >= 0.f)) return 1;
     if ((uintptr_t)workspace & 15) return 1;      // float4 records at a 16-byte-aligned OFFSET from it
     GGBallGridInfo *info = (GGBallGridInfo *)workspace;
     int *cellStart = (int *)(info + B);
     float4 *sorted = (float4 *)((char *)workspace + gg_bg_sorted_offset(B));
-    gg_k_ball_grid_build<<<B, 1024, GG_BG_NCMAX * sizeof(int), st>>>(known, downnum, m, radius, info,
+    gg_k_ball_grid_build<<<B, 1024, GG_BG_NCMAX * sizeof(int), st>>>(known, downnum, m, sk, radius, info,
                                                                      cellStart, sorted);
     dim3 grid((n + 255) / 256, B);
     const float r2 = radius * radius;
@@ -346,16 +353,16 @@ int gg_ball_knn_grid(const float *unknown, const float *known, const int *downnu
         // few queries: 8 lanes per query (see gg_k_ball_grid_query_ml)
         dim3 g8(((unsigned)n * 8 + 255) / 256, B);
         if (k <= 3)
-            gg_k_ball_grid_query_ml<3, 8><<<g8, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info, cellStart, sorted, idx);
+            gg_k_ball_grid_query_ml<3, 8><<<g8, 256, 0, st>>>(unknown, upnum, n, su, ztail, m, k, r2, info, cellStart, sorted, idx);
         else
-            gg_k_ball_grid_query_ml<6, 8><<<g8, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info, cellStart, sorted, idx);
+            gg_k_ball_grid_query_ml<6, 8><<<g8, 256, 0, st>>>(unknown, upnum, n, su, ztail, m, k, r2, info, cellStart, sorted, idx);
         return hipGetLastError() == hipSuccess ? 0 : 3;
     }
     if (k <= 3)
-        gg_k_ball_grid_query<3><<<grid, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info,
+        gg_k_ball_grid_query<3><<<grid, 256, 0, st>>>(unknown, upnum, n, su, ztail, m, k, r2, info,
                                                       cellStart, sorted, idx);
     else
-        gg_k_ball_grid_query<6><<<grid, 256, 0, st>>>(unknown, upnum, n, m, k, r2, info,
+        gg_k_ball_grid_query<6><<<grid, 256, 0, st>>>(unknown, upnum, n, su, ztail, m, k, r2, info,
                                                       cellStart, sorted, idx);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

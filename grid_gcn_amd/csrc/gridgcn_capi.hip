@@ -9,6 +9,7 @@
 #include "gridgcn_edgelin.h"
 #include "gridgcn_atteval.h"
 #include "gridgcn_clsblock.h"
+#include "gridgcn_optim.h"
 
 int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase,
                             const GGIndexWs &w, int *nebidx, float *nebmsk, float *cent,
@@ -31,14 +32,18 @@ int gg_edge_inputs(const float *, const int *, const float *, int, int, int, int
 
 int gg_edge_inputs_rows(const float *, const int *, const float *, int, int, int, int, int, int, int,
                         int, int, float *, float *, hipStream_t);
-int gg_ce_fwd(const float *, int, int, const long long *, long long, int, float *, double *,
+int gg_ce_fwd(const float *, int, int, const long long *, long long, int, float *, double *, float *,
               hipStream_t);
 int gg_ce_bwd(const float *, int, int, const long long *, long long, int, const float *,
               const double *, const float *, const float *, float *, hipStream_t);
-int gg_colsum(const float *, long long, int, int, double *, hipStream_t);
+int gg_colsum(const float *, long long, int, int, double *, float *, hipStream_t);
 size_t gg_ball_grid_workspace(int B, int m);
 int gg_ball_knn_grid(const float *, const float *, const int *, const int *, int, int, int, int,
-                     float, int *, void *, hipStream_t);
+                     float, int *, void *, hipStream_t, int su = 3, int sk = 3, int ztail = 0);
+int gg_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb, const float *mask,
+                float *out, int ldo, float *out2, int ldo2, long long E, hipStream_t st);
+int gg_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, int C, const float *mask,
+                float *out, long long E, hipStream_t st);
 size_t gg_take_bwd_sorted_workspace(int B, int N, int M);
 int gg_take_bwd_sorted(const float *, const int *, int, int, int, int, float *, int, int, void *,
                        hipStream_t);
@@ -57,7 +62,7 @@ int gg_pairmax_bwd(const float *, const float *, const float *, const float *, c
 int gg_pack_linear(const float *, const float *, int, int, int, int, int, float *, float *,
                    float *, float *, float *, float *, hipStream_t);
 int gg_bn_finalize(const double *, const float *, const float *, long long, float, float, int,
-                   float *, float *, float *, float *, float *, float *, long long *, hipStream_t);
+                   float *, float *, float *, float *, float *, float *, long long *, hipStream_t, int tail = 0);
 int gg_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N,
                   int K, int zero_left, const float *bias, void *ws, hipStream_t st);      // gridgcn_gemm.hip
 size_t gg_gemm_small_workspace(int M, int N, int K);
@@ -125,7 +130,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 5; }
+int gridgcn_abi_version(void) { return 6; }
 
 int gridgcn_set_option(int option, int value)
 {
@@ -809,6 +814,19 @@ int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *bet
                           (hipStream_t)stream);
 }
 
+int gridgcn_bn_finalize_tail(const double *sums, const float *gamma, const float *beta, long long E,
+                             float eps, float momentum, int C, int tail, float *scale, float *shift,
+                             float *mean, float *rstd, float *running_mean, float *running_var,
+                             int64_t *num_batches_tracked, void *stream)
+{
+    if (!sums || !gamma || !beta || !scale || !shift || !mean || !rstd || E < 1 || C < 1 || tail < 0 ||
+        (running_mean && !running_var))
+        return GRIDGCN_EINVAL;
+    return gg_bn_finalize(sums, gamma, beta, E, eps, momentum, C, scale, shift, mean, rstd,
+                          running_mean, running_var, (long long *)num_batches_tracked,
+                          (hipStream_t)stream, tail);
+}
+
 int gridgcn_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2,
                             float *dgamma, float *dbeta, void *stream)
 {
@@ -845,7 +863,16 @@ int gridgcn_softmax_ce_fwd(const float *logits, int ld, int ncls, const int64_t 
                            int ignore_label, float *lse, double *acc, void *stream)
 {
     if (!logits || !label || !lse || !acc) return GRIDGCN_EINVAL;
-    int rc = gg_ce_fwd(logits, ld, ncls, (const long long *)label, E, ignore_label, lse, acc,
+    int rc = gg_ce_fwd(logits, ld, ncls, (const long long *)label, E, ignore_label, lse, acc, nullptr,
+                       (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_softmax_ce_loss(const float *logits, int ld, int ncls, const int64_t *label, long long E,
+                            int ignore_label, float *lse, double *acc3, float *loss, void *stream)
+{
+    if (!logits || !label || !lse || !acc3 || !loss) return GRIDGCN_EINVAL;
+    int rc = gg_ce_fwd(logits, ld, ncls, (const long long *)label, E, ignore_label, lse, acc3, loss,
                        (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
@@ -864,7 +891,15 @@ int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t 
 int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream)
 {
     if (!X || !out) return GRIDGCN_EINVAL;
-    int rc = gg_colsum(X, E, ld, ncols, out, (hipStream_t)stream);
+    int rc = gg_colsum(X, E, ld, ncols, out, nullptr, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_colsum_f32(const float *X, long long E, int ld, int ncols, double *acc, float *out,
+                       void *stream)
+{
+    if (!X || !acc || !out) return GRIDGCN_EINVAL;
+    int rc = gg_colsum(X, E, ld, ncols, acc, out, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
@@ -996,6 +1031,55 @@ int gridgcn_ball_knn_grid(const float *unknown, const float *known, const int32_
     const int rc = gg_ball_knn_grid(unknown, known, downnum, upnum, B, n, m, k, radius, idx,
                                     workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_ball_knn_grid_ld(const float *unknown, int ldu, const float *known, int ldk,
+                             const int32_t *downnum, const int32_t *upnum, int B, int n, int m, int k,
+                             float radius, int zero_tail, int32_t *idx, void *workspace,
+                             size_t workspace_bytes, void *stream)
+{
+    if (!unknown || !known || !downnum || !upnum || !idx || B < 1 || n < 1 || m < 1 || k < 1 ||
+        k > 6 || !(radius >= 0.f) || (long long)B * n >= (1ll << 31) || ldu < 3 || ldk < 3)
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_ball_grid_workspace(B, m)) return GRIDGCN_EWORKSPACE;
+    const int rc = gg_ball_knn_grid(unknown, known, downnum, upnum, B, n, m, k, radius, idx,
+                                    workspace, (hipStream_t)stream, ldu, ldk, zero_tail ? 1 : 0);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb,
+                     const float *mask, float *out, int ldo, float *out2, int ldo2, long long E,
+                     void *stream)
+{
+    if (!out || E < 1 || ca < 0 || cb < 0 || ca + cb < 1 || ldo < ca + cb || (ca && (!a || lda < ca)) ||
+        (b && ldb < cb) || (out2 && ldo2 < ca + cb))
+        return GRIDGCN_EINVAL;
+    return gg_cat_mask(a, lda, ca, b, ldb, cb, mask, out, ldo, out2, ldo2, E, (hipStream_t)stream);
+}
+
+int gridgcn_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, int C,
+                     const float *mask, float *out, long long E, void *stream)
+{
+    if (!out || E < 1 || C < 1 || col0 < 0 || (!g1 && !g2) || (g1 && ld1 < col0 + C) ||
+        (g2 && ld2 < col0 + C))
+        return GRIDGCN_EINVAL;
+    return gg_mask_sum(g1, ld1, g2, ld2, col0, C, mask, out, E, (hipStream_t)stream);
+}
+
+int gridgcn_adam_step(float *const *params, const float *const *grads, const long long *sizes,
+                      const long long *mchunk, int n, float *m, float *v, int32_t *state, float lr,
+                      const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      int mode, void *stream)
+{
+    if (n < 0 || !m || !v || !state || (n && (!params || !grads || !sizes || !mchunk)) ||
+        !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || (mode != 0 && mode != 1))
+        return GRIDGCN_EINVAL;
+    for (int i = 0; i < n; i++)
+        if (!params[i] || !grads[i] || sizes[i] < 0 || sizes[i] >= (1ll << 32) || mchunk[i] < 0 ||
+            mchunk[i] >= (1ll << 32) || ((uintptr_t)params[i] & 3) || ((uintptr_t)grads[i] & 3))
+            return GRIDGCN_EINVAL;
+    return gg_adam_step(params, grads, sizes, mchunk, n, m, v, state, lr, lr_dev, beta1, beta2, eps,
+                        weight_decay, mode, (hipStream_t)stream) ? GRIDGCN_ELAUNCH : GRIDGCN_OK;
 }
 
 int gridgcn_take_backward_workspace_bytes(int B, int N, int M, size_t *bytes)

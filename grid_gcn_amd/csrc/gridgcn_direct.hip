@@ -841,10 +841,11 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
     __syncthreads();
     for (int i = tid; i < 2 * NT * 32; i += blockDim.x) {
         const int which = i / (NT * 32), col = i - which * NT * 32;
-        if (dx_col0 + col >= p.ndx) continue;
+        if (dx_col0 + col >= p.ndx || (p.nbn && dx_col0 + col >= p.nbn)) continue;
         float v = 0.f;
         for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
-        atomicAdd(&p.psums[which * p.cin + dx_col0 + col], (double)v);
+        // (nbn > 0: psums is the [2][nbn] table of the layer that produced those columns)
+        atomicAdd(&p.psums[which * (p.nbn ? p.nbn : p.cin) + dx_col0 + col], (double)v);
     }
 }
 
@@ -920,7 +921,7 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-// requires C % 8 == 0, Wdx packed for ndx columns, psums (if any) indexed with stride cin
+// requires C % 8 == 0, Wdx packed for ndx columns, psums (if any) indexed with stride cin (nbn when nbn > 0)
 int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 {
     if (!p.Wdx || !p.dX || p.ndx < 1 || p.ndx > 256 || p.ndx > p.cin || (p.C & 7) || p.C > 256) return 1;

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ log
                                                    const long long *__restrict__ label,
                                                    long long E, int ignore,
                                                    float *__restrict__ lse_out,
-                                                   double *__restrict__ acc)
+                                                   double *__restrict__ acc,
+                                                   float *__restrict__ loss_out)
 {
     __shared__ float red[2][4];
     float loss = 0.f, cnt = 0.f;
@@ -66,6 +67,20 @@ __global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ log
     if (threadIdx.x < 2) {
         const int t = threadIdx.x;
         atomicAdd(&acc[t], (double)((red[t][0] + red[t][1]) + (red[t][2] + red[t][3])));
+    }
+    if (loss_out) {
+        // loss = sum / max(count, 1) by the last workgroup to arrive (ticket in the low word of acc[2]):
+        // the three framework ops that used to form it were 13 us of a step
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int *ticket = (int *)(acc + 2);
+            __threadfence();
+            if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+                const double s = __hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double n = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                loss_out[0] = (float)(s / (n > 1.0 ? n : 1.0));
+            }
+        }
     }
 }
 
@@ -112,9 +127,11 @@ __global__ __launch_bounds__(256) void gg_k_ce_bwd(const float *__restrict__ log
 
 template <int NV>
 __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, long long E,
-                                                   int ncols, double *__restrict__ out)
+                                                   int ncols, double *__restrict__ out,
+                                                   float *__restrict__ out32)
 {
     __shared__ float red[4][4 * NV];
+    __shared__ int s_last;
     float a[4 * NV];
 #pragma unroll
     for (int c = 0; c < 4 * NV; c++) a[c] = 0.f;
@@ -136,18 +153,31 @@ __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, 
     if (threadIdx.x < ncols)
         atomicAdd(&out[threadIdx.x], (double)((red[0][threadIdx.x] + red[1][threadIdx.x]) +
                                               (red[2][threadIdx.x] + red[3][threadIdx.x])));
+    if (out32) {
+        // fp32 copy of the sums by the last workgroup to arrive (ticket in the low word of out[ncols];
+        // ncols <= 32: the atomics above were all issued by wave 0, whose fence covers them)
+        if (threadIdx.x == 0) {
+            __threadfence();
+            s_last = __hip_atomic_fetch_add((int *)(out + ncols), 1, __ATOMIC_ACQ_REL,
+                                            __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x < ncols)
+            out32[threadIdx.x] = (float)__hip_atomic_load(&out[threadIdx.x], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // logits rows of ld floats (ld in {4,8,...,32}), ncls <= ld
 int gg_ce_fwd(const float *logits, int ld, int ncls, const long long *label, long long E, int ignore,
-              float *lse, double *acc, hipStream_t st)
+              float *lse, double *acc, float *loss, hipStream_t st)
 {
     if (ld < 4 || ld > 32 || (ld & 3) || ncls < 1 || ncls > ld || E < 1) return 1;
     // at most two workgroups per CU, rows in a grid-stride loop (see the note at the atomics)
     const long long nb = (E + 255) / 256;
     const int grid = (int)(nb < 512 ? nb : 512);
     switch (ld / 4) {
-#define GG_CASE(n) case n: gg_k_ce_fwd<n><<<grid, 256, 0, st>>>(logits, ncls, label, E, ignore, lse, acc); break;
+#define GG_CASE(n) case n: gg_k_ce_fwd<n><<<grid, 256, 0, st>>>(logits, ncls, label, E, ignore, lse, acc, loss); break;
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }
@@ -168,13 +198,13 @@ int gg_ce_bwd(const float *logits, int ld, int ncls, const long long *label, lon
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
-int gg_colsum(const float *X, long long E, int ld, int ncols, double *out, hipStream_t st)
+int gg_colsum(const float *X, long long E, int ld, int ncols, double *out, float *out32, hipStream_t st)
 {
     if (ld < 4 || ld > 32 || (ld & 3) || ncols < 1 || ncols > ld || E < 1) return 1;
     long long nb = (E + 1023) / 1024;
     const int grid = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
     switch (ld / 4) {
-#define GG_CASE(n) case n: gg_k_colsum<n><<<grid, 256, 0, st>>>(X, E, ncols, out); break;
+#define GG_CASE(n) case n: gg_k_colsum<n><<<grid, 256, 0, st>>>(X, E, ncols, out, out32); break;
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }

@@ -1,0 +1,173 @@
+// gridgcn_optim.hip -- the Adam update of every parameter tensor of a model in one launch (gfx950).
+//
+// Reference: the step's optimizer is mx.optimizer.Adam with wd (segmentation/train_test/base_solver.py:
+// 105-114: learning_rate, wd, beta1, beta2).  A segmentation network has 126 parameter tensors of
+// 21 .. 32768 floats (340 k in all): the framework's multi-tensor kernel takes four launches of ~20 us
+// for what is 10 MB of traffic.  Here the pointer table travels in the kernel arguments (<= 128
+// tensors per launch, nothing uploaded, nothing to keep alive for a captured graph), one workgroup owns
+// 1024 consecutive elements of one tensor, and the two moment vectors live in flat buffers of whole
+// 1024-element chunks.
+//
+//   g  = grad + wd * w
+//   m  = m + (1 - b1) (g - m)          v = b2 v + (1 - b2) g g
+//   mode 0 (torch.optim.Adam):  w -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//   mode 1 (mx.optimizer.Adam): w -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+//
+// t lives on the device (replays of a captured step advance it): every workgroup reads it, the last
+// one to finish (ticket) writes t + 1 back when `bump` is set (the last launch of a step).
+#include <hip/hip_runtime.h>
+
+#include "gridgcn_optim.h"
+
+__global__ __launch_bounds__(256) void gg_k_adam(const GGAdamTable tb, float *__restrict__ m,
+                                                 float *__restrict__ v, int *__restrict__ state,
+                                                 float lr, const float *__restrict__ lr_dev, float b1,
+                                                 float b2, float eps, float wd, int mode, int bump)
+{
+    const unsigned c = blockIdx.x;
+    int lo = 0, hi = tb.nt;                       // tensor of this chunk: cstart[lo] <= c < cstart[lo + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tb.cstart[mid] <= c) lo = mid; else hi = mid;
+    }
+    const unsigned k = c - tb.cstart[lo];         // chunk inside the tensor
+    const unsigned n = tb.n[lo];
+    float *__restrict__ w = tb.p[lo] + (size_t)k * GG_ADAM_CHUNK;
+    const float *__restrict__ g = tb.g[lo] + (size_t)k * GG_ADAM_CHUNK;
+    const size_t mo = ((size_t)tb.mchunk[lo] + k) * GG_ADAM_CHUNK;
+    const unsigned left = n - k * GG_ADAM_CHUNK;  // elements of the tensor from this chunk on
+    const int t = state[0] + 1;
+    const double p1 = exp((double)t * log((double)b1)), p2 = exp((double)t * log((double)b2));
+    const float bc1 = (float)(1.0 - p1), bc2s = (float)sqrt(1.0 - p2);
+    if (lr_dev) lr = *lr_dev;
+    const float step = mode ? lr * bc2s / bc1 : lr / bc1;
+    const float rs = mode ? 1.f : 1.f / bc2s;
+    const unsigned i = threadIdx.x * 4;
+    const bool vec = ((((size_t)w | (size_t)g) & 15) == 0) && i + 4 <= left;
+    if (vec) {
+        float4 W = *(const float4 *)(w + i), G = *(const float4 *)(g + i);
+        float4 M = *(const float4 *)(m + mo + i), V = *(const float4 *)(v + mo + i);
+        float *Wf = &W.x, *Gf = &G.x, *Mf = &M.x, *Vf = &V.x;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float gg = Gf[j] + wd * Wf[j];
+            Mf[j] = Mf[j] + (1.f - b1) * (gg - Mf[j]);
+            Vf[j] = b2 * Vf[j] + (1.f - b2) * gg * gg;
+            Wf[j] -= step * Mf[j] / (sqrtf(Vf[j]) * rs + eps);
+        }
+        *(float4 *)(w + i) = W;
+        *(float4 *)(m + mo + i) = M;
+        *(float4 *)(v + mo + i) = V;
+    } else {
+        for (unsigned j = i; j < i + 4 && j < left; j++) {
+            const float gg = g[j] + wd * w[j];
+            const float mm = m[mo + j] + (1.f - b1) * (gg - m[mo + j]);
+            const float vv = b2 * v[mo + j] + (1.f - b2) * gg * gg;
+            m[mo + j] = mm;
+            v[mo + j] = vv;
+            w[j] -= step * mm / (sqrtf(vv) * rs + eps);
+        }
+    }
+    __syncthreads();                              // every thread of the workgroup has read state[0]
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            state[1] = 0;
+            if (bump) state[0] = t;
+        }
+    }
+}
+
+int gg_adam_step(float *const *params, const float *const *grads, const long long *sizes,
+                 const long long *mchunk, int n, float *m, float *v, int *state, float lr,
+                 const float *lr_dev, float b1, float b2, float eps, float wd, int mode, hipStream_t st)
+{
+    for (int i0 = 0; i0 < n || i0 == 0; i0 += GG_ADAM_MAXT) {
+        GGAdamTable tb;
+        const int nt = n - i0 < GG_ADAM_MAXT ? n - i0 : GG_ADAM_MAXT;
+        unsigned chunks = 0;
+        for (int i = 0; i < nt; i++) {
+            tb.p[i] = params[i0 + i];
+            tb.g[i] = grads[i0 + i];
+            tb.n[i] = (unsigned)sizes[i0 + i];
+            tb.mchunk[i] = (unsigned)mchunk[i0 + i];
+            tb.cstart[i] = chunks;
+            chunks += (unsigned)((sizes[i0 + i] + GG_ADAM_CHUNK - 1) / GG_ADAM_CHUNK);
+        }
+        for (int i = nt; i <= GG_ADAM_MAXT; i++) tb.cstart[i] = chunks;
+        tb.nt = nt > 0 ? nt : 1;
+        const int last = i0 + GG_ADAM_MAXT >= n;
+        if (chunks == 0) {
+            if (!last) continue;
+            // a step in which no parameter has a gradient still counts
+            tb.n[0] = 0; tb.mchunk[0] = 0; tb.p[0] = nullptr; tb.g[0] = nullptr;
+            tb.cstart[1] = 1;
+            chunks = 1;
+        }
+        hipLaunchKernelGGL(gg_k_adam, dim3(chunks), dim3(256), 0, st, tb, m, v, state, lr, lr_dev, b1, b2,
+                           eps, wd, mode, last);
+        if (last) break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---- concat / mask glue of the layer boundary ----------------------------------------------------
+// out[r, 0:ca] = a[r, :], out[r, ca:ca+cb] = b[r, :] * mask[r], out[r, ca+cb:ldo] = 0:
+//   data_layer = concat(cent, centre features * centmsk)  (segmentation/models/ggcn_models_g.py:186,
+//   gcn_module_g_att.py:284-285) in one pass instead of a multiply and a concat;
+//   b == nullptr: the cb columns are 1.0 (data = concat(xyz, ones), ggcn_models_g.py:137);
+//   out2 (optional): the same rows once more with stride ldo2 -- the zero-padded copy (a multiple of 8
+//   floats per row) the centre MLP of the up path reads, which used to cost a fill and a copy.
+__global__ __launch_bounds__(256) void gg_k_cat_mask(const float *__restrict__ a, int lda, int ca,
+                                                     const float *__restrict__ b, int ldb, int cb,
+                                                     const float *__restrict__ mask,
+                                                     float *__restrict__ out, int ldo,
+                                                     float *__restrict__ out2, int ldo2, long long total)
+{
+    const int ldt = ldo + ldo2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / ldt;
+        int c = (int)(i - r * ldt);
+        float *dst = out + r * ldo + c;
+        if (c >= ldo) { c -= ldo; dst = out2 + r * ldo2 + c; }
+        float v = 0.f;
+        if (c < ca) v = a[r * lda + c];
+        else if (c < ca + cb) v = b ? b[r * ldb + (c - ca)] * (mask ? mask[r] : 1.f) : 1.f;
+        *dst = v;
+    }
+}
+
+// backward of the above: out[r, :] = (g1[r, col0:col0+C] + g2[r, col0:col0+C]) * mask[r]
+// (g1 / g2: gradients of the two outputs, either may be nullptr)
+__global__ __launch_bounds__(256) void gg_k_mask_sum(const float *__restrict__ g1, int ld1,
+                                                     const float *__restrict__ g2, int ld2, int col0, int C,
+                                                     const float *__restrict__ mask,
+                                                     float *__restrict__ out, long long total)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C) + col0;
+        float v = g1 ? g1[r * ld1 + c] : 0.f;
+        if (g2) v += g2[r * ld2 + c];
+        out[i] = mask ? v * mask[r] : v;
+    }
+}
+
+int gg_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb, const float *mask,
+                float *out, int ldo, float *out2, int ldo2, long long E, hipStream_t st)
+{
+    const long long total = E * (ldo + (out2 ? ldo2 : 0));
+    const long long nb = (total + 255) / 256;
+    gg_k_cat_mask<<<(int)(nb < 8192 ? nb : 8192), 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
+                                                                out2 ? ldo2 : 0, total);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
+int gg_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, int C, const float *mask,
+                float *out, long long E, hipStream_t st)
+{
+    const long long total = E * C;
+    const long long nb = (total + 255) / 256;
+    gg_k_mask_sum<<<(int)(nb < 8192 ? nb : 8192), 256, 0, st>>>(g1, ld1, g2, ld2, col0, C, mask, out, total);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}

@@ -371,11 +371,15 @@ __global__ void gg_k_bn_finalize(const double *__restrict__ sums, const float *_
                                  float momentum, int C, float *__restrict__ scale,
                                  float *__restrict__ shift, float *__restrict__ mean,
                                  float *__restrict__ rstd, float *__restrict__ run_mean,
-                                 float *__restrict__ run_var, long long *__restrict__ nbt)
+                                 float *__restrict__ run_var, long long *__restrict__ nbt, int tail)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) nbt[0] += 1;                  // BatchNorm1d.num_batches_tracked
-    if (c >= C) return;
+    if (c >= C) {
+        // columns beyond the layer in a wider table (train_ops.RawLink): the identity
+        if (c < C + tail) { scale[c] = 1.f; shift[c] = 0.f; mean[c] = 0.f; rstd[c] = 0.f; }
+        return;
+    }
     const double m = sums[c] / (double)E;
     double v = sums[C + c] / (double)E - m * m;
     if (v < 0.0) v = 0.0;
@@ -512,6 +516,14 @@ __global__ void gg_k_pack_linear_batch(const gridgcn_pack_desc *__restrict__ d)
     const gridgcn_pack_desc e = d[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= e.n) return;
+    if (e.wgb) {
+        // geo_vec weights + bias of a first point conv (see gridgcn_pack_desc): nothing else is packed
+        if (t < 4 * e.C) {
+            const int r = t / e.C, c = t - r * e.C;
+            e.wgb[t] = r < 3 ? (e.geo ? e.W[(size_t)c * e.cin_w + r] : 0.f) : e.b[c];
+        }
+        return;
+    }
     gg_pack_linear_body(t, e.W, e.b, e.C, e.cin_w, e.rot, e.cin, e.K, e.ldw, e.ndx, e.Wp, e.Bp, e.Wb,
                         e.Wg, e.Wq, e.Wdx);
 }
@@ -537,6 +549,10 @@ int gg_pack_desc_fill(gridgcn_pack_desc *e)
     e->K = (e->cin + 3) & ~3;
     e->ldw = e->C <= 32 ? 32 : (e->C <= 64 ? 64 : (e->C <= 128 ? 128 : 256));
     e->n = gg_pack_threads(e->C, e->cin, e->Wdx != nullptr);
+    if (e->wgb) {
+        if (!e->b || (e->geo && e->cin_w < 3)) return 1;
+        e->n = 4 * e->C;
+    }
     return 0;
 }
 
@@ -568,10 +584,10 @@ int gg_pack_linear(const float *W, const float *b, int C, int cin_w, int rot, in
 
 int gg_bn_finalize(const double *sums, const float *gamma, const float *beta, long long E,
                    float eps, float momentum, int C, float *scale, float *shift, float *mean,
-                   float *rstd, float *run_mean, float *run_var, long long *nbt, hipStream_t st)
+                   float *rstd, float *run_mean, float *run_var, long long *nbt, hipStream_t st, int tail)
 {
-    gg_k_bn_finalize<<<(C + 255) / 256, 256, 0, st>>>(sums, gamma, beta, E, eps, momentum, C, scale,
-                                                      shift, mean, rstd, run_mean, run_var, nbt);
+    gg_k_bn_finalize<<<(C + tail + 255) / 256, 256, 0, st>>>(sums, gamma, beta, E, eps, momentum, C, scale,
+                                                             shift, mean, rstd, run_mean, run_var, nbt, tail);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

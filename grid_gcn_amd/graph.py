@@ -37,7 +37,8 @@ class GraphedTrainStep:
     all-reduce (world > 1) ; opt.step() -- replayed from one captured graph.
 
     net       a GGCNSeg / GGCNCls / GGCNSynth in train() mode on the GPU
-    opt       torch.optim.Adam(..., fused=True, capturable=True) (any capturable optimizer)
+    opt       grid_gcn_amd.optim.Adam, or torch.optim.Adam(..., fused=True, capturable=True) (any capturable
+              optimizer)
     inputs    tuple of STATIC input tensors (their storage is what the graph reads: refill them
               in place to feed a new batch); target likewise
     sync      dp.FlatGradAllReduce or None
@@ -55,11 +56,13 @@ class GraphedTrainStep:
         net.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.params = [p for p in net.parameters() if p.requires_grad]
 
+        one = torch.ones((), dtype=torch.float32, device=dev)
+
         def fwd_bwd():
             net.seed_dev.add_(_GOLDEN)
             opt.zero_grad(set_to_none=True)
             loss = loss_fn(net(*self.inputs), self.target)
-            loss.backward()
+            loss.backward(one)       # (the default gradient would be one more fill launch per step)
             return loss.detach()
 
         # warm-up on a side stream (allocator pools, lazy initialisations, autotuned paths)

@@ -210,11 +210,15 @@ class SubGUpdate(nn.Module):
         agg = pair.max(dim=2).values                                       # :57-59 (unmasked, F10)
         return self.finish(agg, center_masks, center_ori_feats, tail=tail)
 
-    def forward_src(self, cent, src, nebidx, center_masks=None, center_ori_feats=None, tail=None):
+    def forward_src(self, cent, src, nebidx, center_masks=None, center_ori_feats=None, tail=None,
+                    defer_mask=False):
         """Training path on the GPU: the edge inputs (gather + geo features + concat) come from
         one HIP kernel (ops.edge_inputs, scatter-add backward); the MLPs with batch-statistics
-        BatchNorm are stock PyTorch ops."""
+        BatchNorm are stock PyTorch ops.  defer_mask: the caller multiplies by center_masks itself
+        (train_ops.cat_mask: the mask and the concat with the centres in one launch)."""
         from . import ops
+        if defer_mask:
+            center_masks = None
         att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
         src = src.contiguous()
         if self.mfma_train and self.training and torch.is_grad_enabled():

@@ -105,6 +105,7 @@ class GGCNSeg(nn.Module):
     fused = True   # eval mode: run GridConv through csrc/gridgcn_conv.hip (BatchNorm folded)
     jobs = None    # set to a list to record (name, layer, cent, src, nebidx) of every fused call
     edge_kernel = True  # training: edge inputs from one HIP kernel instead of take+slice+cat ops
+    glue_kernels = True  # training: concat + mask + padding of a layer boundary in one launch
 
     def use_fused(self):
         # the fused evaluation kernels return tensors without a grad_fn: eval() WITH grad enabled
@@ -127,9 +128,22 @@ class GGCNSeg(nn.Module):
         """data_xyz [B,N,3] f32, actual_centnum [B,1] i32 -> logits [B,N,num_classes]."""
         cfg, g, ix = self.cfg, self.cfg["grid"], self.ix
         B, N, _ = data_xyz.shape
-        data = torch.cat([data_xyz, torch.ones_like(data_xyz[..., :1])], dim=2)     # :137
+        nd = len(self.down)
+        # training on the HIP path: concat / centre mask / zero padding of the layer boundaries in one
+        # launch each (train_ops.cat_mask) instead of 2-4 framework ops
+        glue = (self.glue_kernels and _is_hip(ix) and self.edge_kernel and data_xyz.is_cuda
+                and data_xyz.dtype == torch.float32 and self.training and torch.is_grad_enabled())
+        if glue:
+            from . import train_ops
+            glue = train_ops.GLUE_KERNELS
+        if glue:
+            data, data_pad = train_ops.cat_mask(data_xyz.detach(), None, None, pad=True)  # :137
+        else:
+            data = torch.cat([data_xyz, torch.ones_like(data_xyz[..., :1])], dim=2)     # :137
+            data_pad = data
         locs = [data]                 # centers_reverse_lst: [B,n,4] per level
         feats = [data]                # center_locnfeat_alllayers: [B,n,4+C]
+        feats_pad = [data_pad]        # (rows zero-padded to whole 32-byte pieces: the centre MLPs' input)
         masks, nums = [], [actual_centnum]
         data_loc, data_layer = data, data
         fwd_no = self.forward_no
@@ -150,12 +164,16 @@ class GGCNSeg(nn.Module):
                     self.jobs.append(("down%d" % i, layer, cent, data_layer, nebidx))
                 cf = layer.forward_fused(cent, data_layer, nebidx, centmsk)
             elif _is_hip(self.ix) and self.edge_kernel:
-                cf = layer.forward_src(cent, data_layer, nebidx, centmsk)
+                cf = layer.forward_src(cent, data_layer, nebidx, centmsk, defer_mask=glue)
             else:
                 neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx, **self._take_kw)  # :172-173
                 cf = layer(cent[..., 0:3], neighbors, centmsk)                      # :185
-            data_layer = torch.cat([cent, cf], dim=2)                               # :186
+            if glue:
+                data_layer, dl_pad = train_ops.cat_mask(cent, cf, centmsk, pad=i != nd - 1)   # :186
+            else:
+                data_layer = dl_pad = torch.cat([cent, cf], dim=2)                  # :186
             locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
+            feats_pad.append(dl_pad)
         f_last = feats[-1]
         nup = len(self.up)
         # what follows the last up layer (fc1, dropout, fc2): offered to that layer's chain per call
@@ -171,15 +189,19 @@ class GGCNSeg(nn.Module):
             U = g["up"][i]
             if cfg["up_neigh_fetch"]:
                 radius = U["voxel_size"][0] * U["kernel_size"] * 1.7 / 2            # :204
-                nebidx = ix.BallKNN(upl[..., 0:3].detach().contiguous(),
-                                    down[..., 0:3].detach().contiguous(), downnum, upnum,
-                                    k=U["max_p_grid"], radius=radius)               # :85
+                # (the HIP operator reads the xyz columns of the [B,n,4] rows in place)
+                cont = (lambda t: t) if _is_hip(ix) else (lambda t: t.contiguous())
+                nebidx = ix.BallKNN(cont(upl[..., 0:3].detach()), cont(down[..., 0:3].detach()),
+                                    downnum, upnum, k=U["max_p_grid"], radius=radius)   # :85
             else:
                 nebidx, _ = ix.GridifyUp(down.detach().contiguous(), upl.detach().contiguous(),
                                          downnum, upnum,
                                          **synth.gridify_up_kwargs(g, i, self._seed(fwd_no, 16 + i)),
                                          **sd)  # :206-210
             f_this = feats[-i - 2]
+            if glue and layer.center_mlp is not None and layer.mfma_train and \
+                    train_ops.supported(list(layer.center_mlp), f_this):
+                f_this = feats_pad[-i - 2]        # (the MFMA kernels take the zero-padded rows as they are)
             cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
             if self.use_fused():
                 if self.jobs is not None:
@@ -188,13 +210,16 @@ class GGCNSeg(nn.Module):
                                          tail=tail if i == nup - 1 else None)
             elif _is_hip(self.ix) and self.edge_kernel:
                 cf = layer.forward_src(upl, f_last, nebidx, cmask, center_ori_feats=f_this,
-                                       tail=tail if i == nup - 1 else None)
+                                       tail=tail if i == nup - 1 else None, defer_mask=glue)
             else:
                 neighbors = ix.batch_take_g(f_last.contiguous(), nebidx, **self._take_kw)  # :217-218
                 cf = layer(upl[..., 0:3], neighbors, cmask, center_ori_feats=f_this,
                            tail=tail if i == nup - 1 else None)                       # :229
             if i != nup - 1:                      # (the last layer's features go to the head only)
-                f_last = torch.cat([upl, cf], dim=2)                                # :231
+                if glue:
+                    f_last = train_ops.cat_mask(upl, cf, cmask)[0]                  # :231
+                else:
+                    f_last = torch.cat([upl, cf], dim=2)                            # :231
         self.last_tail_done = tail.done           # (introspection only: which head path ran)
         if tail.done == 2:                        # fc1, dropout and fc2 ran inside the last up layer
             return cf

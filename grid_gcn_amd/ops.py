@@ -238,30 +238,59 @@ def GridifyUp(downdata, updata, down_actual_numpoints, up_actual_numpoints, *, m
     return nebidx, nebidxmsk
 
 
+def _point_rows(t, name):
+    """[B, n, 3] coordinates, contiguous OR a column slice of wider contiguous rows (xyz of [B, n, 4+C]
+    point rows: the up path hands those over without a copy).  Returns (tensor, floats per row)."""
+    _require(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 3 and t.shape[-1] == 3
+             and t.dtype == torch.float32, "%s should be a float32 [B,n,3] GPU tensor" % name)
+    if t.is_contiguous():
+        return t, 3
+    n, ld = t.shape[1], t.stride(1)
+    if t.stride(2) == 1 and ld >= 3 and (t.shape[0] == 1 or t.stride(0) == n * ld):
+        return t, ld
+    return t.contiguous(), 3
+
+
 def _knn_common(ball, unknown, known, downnum, upnum, k, radius, out):
     lib = _lib.load()
-    _chk(unknown, "unknown", 3, torch.float32, 3)   # ball_k_nn.cc:36-42
-    _chk(known, "known", 3, torch.float32, 3)
+    n = unknown.shape[1] if (isinstance(unknown, torch.Tensor) and unknown.dim() == 3) else 0
+    grid_ok = (ball and BALL_GRID and int(k) <= 6 and isinstance(known, torch.Tensor) and known.dim() == 3 and known.shape[1] >= 64
+               and n * known.shape[1] >= (1 << 16) and radius >= 0)
+    if grid_ok:
+        unknown, ldu = _point_rows(unknown, "unknown")
+        known, ldk = _point_rows(known, "known")
+    else:
+        if ball and all(isinstance(t, torch.Tensor) and t.dim() == 3 and t.stride(2) == 1
+                        for t in (unknown, known)):
+            # (xyz columns of wider rows, as the grid path takes them in place: packed for the scan)
+            unknown, known = unknown.contiguous(), known.contiguous()
+        _chk(unknown, "unknown", 3, torch.float32, 3)   # ball_k_nn.cc:36-42
+        _chk(known, "known", 3, torch.float32, 3)
     B, n, _ = unknown.shape
     _require(known.shape[0] == B, "unknown and known must have the same batch size")
     m = known.shape[1]
     _num(downnum, "downnum", B)
     _num(upnum, "upnum", B)
     dev = unknown.device
+    ztail = 0
     if out is None:
-        # the reference leaves rows >= upnum[b] untouched (undefined memory); zero them here
-        out = torch.zeros((B, n, int(k)), dtype=torch.int32, device=dev)
+        # the reference leaves rows >= upnum[b] untouched (undefined memory); zero them here -- inside
+        # the query kernel where it can (one fill less per call)
+        if grid_ok:
+            out, ztail = torch.empty((B, n, int(k)), dtype=torch.int32, device=dev), 1
+        else:
+            out = torch.zeros((B, n, int(k)), dtype=torch.int32, device=dev)
     else:
         _chk(out, "out", 3, torch.int32, int(k))
     with torch.cuda.device(dev):
-        if ball and BALL_GRID and int(k) <= 6 and m >= 64 and n * m >= (1 << 16) and radius >= 0:
+        if grid_ok:
             # same indices through a cell grid over the known points (csrc/gridgcn_ballgrid.hip)
             nb = ctypes.c_size_t(0)
             lib.gridgcn_ball_knn_grid_workspace_bytes(B, m, ctypes.byref(nb))
             ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-            rc = lib.gridgcn_ball_knn_grid(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum),
-                                           B, n, m, int(k), ctypes.c_float(radius), _ptr(out),
-                                           _ptr(ws), nb.value, _stream(unknown))
+            rc = lib.gridgcn_ball_knn_grid_ld(_ptr(unknown), ldu, _ptr(known), ldk, _ptr(downnum),
+                                              _ptr(upnum), B, n, m, int(k), ctypes.c_float(radius), ztail,
+                                              _ptr(out), _ptr(ws), nb.value, _stream(unknown))
         elif ball:
             rc = lib.gridgcn_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n,
                                       m, int(k), ctypes.c_float(radius), _ptr(out),

@@ -196,6 +196,41 @@ class _PackCache:
         e["fresh"] = False
         return e["bufs"]
 
+    def get_wgb(self, lib, W, b, geo):
+        """[4, C0] table of a first point conv whose feature columns are applied on the source points
+        (gridgcn_edge_lin0_*): rows 0..2 = W[:, :3]^T (the geo_vec weights; zeros without geo_vec), row 3 =
+        bias.  An entry of the module's prepack table like the layer layouts: built by that ONE launch when
+        the table has it, by a concat otherwise."""
+        C0, cin_w = W.shape
+
+        def build(out=None):
+            rows = W.detach()[:, :3].t() if geo else _cached_zeros(3 * C0, W.device).view(3, C0)
+            return torch.cat([rows, b.detach()[None]], out=out)
+
+        if not (isinstance(W, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter)):
+            return build()
+        key = (id(W), id(b), C0, cin_w, "wgb", bool(geo), 0, False, W.data_ptr(), b.data_ptr())
+        e = self.entries.get(key)
+        if e is not None and (e["W"]() is not W or e["b"]() is not b):
+            self._drop(key)
+            e = None
+        if e is None:
+            self.drop_stale(W, b)
+            pk = torch.empty((4, C0), dtype=torch.float32, device=W.device)
+            d = _lib.PackDesc()
+            d.W, d.b, d.wgb = W.data_ptr(), b.data_ptr(), pk.data_ptr()
+            d.C, d.cin_w, d.rot, d.cin, d.ndx, d.geo = C0, cin_w, 0, cin_w, 0, int(bool(geo))
+            _lib.check(lib.gridgcn_pack_desc_fill(ctypes.byref(d)), "gridgcn_pack_desc_fill")
+            e = dict(W=weakref.ref(W, lambda _r, k=key: self._drop(k)), b=weakref.ref(b), pk=pk,
+                     bufs=(pk,), fresh=False, ver=None, desc=d)
+            self.entries[key] = e
+            self.tables.clear()
+        if not (e["fresh"] and e["ver"] == (W._version, b._version)):
+            build(out=e["pk"])
+            torch.autograd.graph.increment_version(e["pk"])
+        e["fresh"] = False
+        return e["pk"]
+
     def drop_stale(self, W, b):
         """forget every entry of (W, b) whose recorded storage is no longer the live one"""
         live = (W.data_ptr(), b.data_ptr())
@@ -301,7 +336,6 @@ TIMERS = None
 
 def release_packs_hook(module, _inputs, _output):
     PACKS.release(module)
-_LINK_TEMPLATES = {}
 
 
 class RawLink:
@@ -316,17 +350,20 @@ class RawLink:
     BatchNorm bookkeeping); sums: fp64 [2, total], left by the consumer's backward."""
 
     def __init__(self, n, total, device):
-        key = (n, total, str(device))
-        if key not in _LINK_TEMPLATES:
-            t = torch.zeros((4, total), dtype=torch.float32, device=device)
-            t[0, n:] = 1.0
-            _LINK_TEMPLATES[key] = t
         self.n, self.total = n, total
-        self.vec = _LINK_TEMPLATES[key].clone()
+        # (the identity entries of the columns >= n are written by the producer's BatchNorm finalisation
+        #  launch: gridgcn_bn_finalize_tail)
+        self.vec = torch.empty((4, total), dtype=torch.float32, device=device)
         self.sums = None
 
     def prev_bn(self):
         return (self.vec[0], self.vec[1], self.vec[2], self.vec[3])
+
+    def take_sums(self, psums, cin):
+        """the consumer's psums buffer as the producer's [2, n] table: with nbn() the dX epilogue wrote it
+        with row stride n (contiguous, no copy); otherwise [2, total], of which the producer slices its part"""
+        n = self.nbn()
+        return psums[:2 * n].view(2, n) if n else psums.view(2, cin)
 
     def nbn(self):
         """input columns of the consumer that carry the producer's BatchNorm, as the dX kernel wants
@@ -406,9 +443,11 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         track = bn is not None and bn.track_running_stats
         # (a separate launch on purpose: folded into the forward kernel's last workgroup -- returning
         #  fp64 atomics, ticket, device-scope read-back -- the step was 0.1 ms SLOWER over 31 layers)
-        rc = lib.gridgcn_bn_finalize(
+        rc = lib.gridgcn_bn_finalize_tail(
             _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
-            _momentum(bn) if track else 0.0, cout, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+            _momentum(bn) if track else 0.0, cout,
+            last_vec.shape[1] - cout if (last and last_vec is not None) else 0,
+            _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
             _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
             _ptr(bn.running_var) if track else None,
             _ptr(bn.num_batches_tracked) if track else None, stream)
@@ -638,6 +677,10 @@ class _ZeroArena:
 
 
 ZERO_ARENA = True
+# the optimizer of bench.py / the tests' training loops: grid_gcn_amd.optim.Adam (one launch)
+OWN_ADAM = True
+# concat + centre mask + zero padding of a layer boundary in one launch (model.GGCNSeg.forward)
+GLUE_KERNELS = True
 # evaluation of single-layer-pt edge blocks (the up layers) through the source-side kernels
 SRC_EVAL = True
 ATT_MAX_EVAL = True
@@ -674,6 +717,94 @@ class _Cat2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g[..., :ctx.ca], g[..., ctx.ca:], None
+
+
+def _rows2d(t):
+    """(tensor, row stride in floats) of a [..., W] float32 tensor seen as rows of W floats -- without a copy
+    when the rows are regularly strided (a gradient that is a column slice of a wider buffer)"""
+    W = t.shape[-1]
+    if t.is_contiguous():
+        return t, W
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= W:
+        return t, t.stride(0)
+    if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) >= W and \
+            (t.shape[0] == 1 or t.stride(0) == t.shape[1] * t.stride(1)):
+        return t, t.stride(1)
+    return t.contiguous(), W
+
+
+class _CatMask(torch.autograd.Function):
+    """(concat([a, b * mask[..., None]], -1), the same rows zero-padded to a multiple of 8 floats) in ONE
+    launch: data_layer = concat(cent, features * centmsk) of the layer boundary
+    (segmentation/models/ggcn_models_g.py:186, gcn_module_g_att.py:284-285) and the copy of it the centre
+    MLP of the up path reads (its first layer's register-direct kernels want rows of whole 32-byte
+    pieces).  b None: a column of ones (ggcn_models_g.py:137, data = concat(xyz, 1)).  The backward adds the
+    gradients of the two outputs and applies the mask in one launch as well.  a carries no gradient (the
+    index operators' centres)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mask, pad):
+        lib = _lib.load()
+        a = a.contiguous()
+        lead, ca = a.shape[:-1], a.shape[-1]
+        E = a.numel() // ca
+        dev = a.device
+        if b is not None:
+            b = b.contiguous()
+            cb = b.shape[-1]
+            assert b.shape[:-1] == lead
+        else:
+            cb = 1
+        if mask is not None:
+            mask = mask.contiguous()
+            assert mask.numel() == E and mask.dtype == torch.float32
+        W = ca + cb
+        W8 = (W + 7) & ~7
+        out = torch.empty(lead + (W,), dtype=torch.float32, device=dev)
+        out2 = torch.empty(lead + (W8,), dtype=torch.float32, device=dev) if (pad and W8 != W) else None
+        with torch.cuda.device(dev):
+            rc = lib.gridgcn_cat_mask(_ptr(a), ca, ca, _ptr(b) if b is not None else None, cb, cb,
+                                      _ptr(mask) if mask is not None else None, _ptr(out), W,
+                                      _ptr(out2) if out2 is not None else None, W8, E, _stream(a))
+        _lib.check(rc, "gridgcn_cat_mask")
+        ctx.dims = (ca, cb, E, b is not None)
+        ctx.save_for_backward(mask)
+        ctx.set_materialize_grads(False)
+        if out2 is None:
+            return out, None
+        return out, out2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        ca, cb, E, has_b = ctx.dims
+        if not has_b or (g1 is None and g2 is None) or not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        g = g1 if g1 is not None else g2
+        l1 = l2 = 0
+        if g1 is not None:
+            g1, l1 = _rows2d(g1)
+        if g2 is not None:
+            g2, l2 = _rows2d(g2)
+        db = torch.empty(g.shape[:-1] + (cb,), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.gridgcn_mask_sum(_ptr(g1) if g1 is not None else None, l1,
+                                      _ptr(g2) if g2 is not None else None, l2, ca, cb,
+                                      _ptr(mask) if mask is not None else None, _ptr(db), E, _stream(g))
+        _lib.check(rc, "gridgcn_mask_sum")
+        return None, db, None, None
+
+
+def cat_mask(a, b, mask=None, pad=False):
+    """-> (concat([a, b * mask], -1), zero-padded copy or the same tensor); float32 GPU tensors."""
+    out, out2 = _CatMask.apply(a, b, mask, pad)
+    return out, (out2 if out2 is not None else out)
+
+
+def cat_mask_supported(a, b):
+    return (a.is_cuda and a.dtype == torch.float32 and not a.requires_grad
+            and (b is None or (b.is_cuda and b.dtype == torch.float32)))
 
 
 def _dw_direct_ok(C, cin):
@@ -768,7 +899,7 @@ class _MLPTrain(torch.autograd.Function):
                                 nbn=prev.nbn() if prev is not None else 0)
             dX, grads = r[0], r[1]
             if prev is not None:
-                prev.sums = r[2].view(2, x.shape[1])
+                prev.sums = prev.take_sums(r[2], x.shape[1])
             if dX is not None and ctx.cin0 != x.shape[1]:
                 dX = dX[:, :ctx.cin0]
         return (dX, None) + tuple(grads)
@@ -1240,8 +1371,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             else:
                 Ysrc = _mm_nt(feat, W0.detach()[:, rot:])
             # rows 0..2: geo_vec weights [3][C0] (zeros without geo_vec), row 3: bias
-            wgb = torch.cat([W0.detach()[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0),
-                             b0.detach()[None]])
+            wgb = PACKS.get_wgb(lib, W0, b0, geo)
             Wg = wgb if geo else None
             # a single-layer point MLP never materialises Z0: its consumers recompute it
             noz = Lp == 1 and NO_Z0 and C0 % 4 == 0
@@ -2033,9 +2163,10 @@ class _LinearPlain(torch.autograd.Function):
                 _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0, 0,
                 _ptr(dX) if ndx else None, _ptr(dW), None, None, None, 0, _ptr(ws), nbytes.value, st)
             _lib.check(rc, "gridgcn_linear_bwd")
-            db64 = _zeros(Cp, torch.float64, dev)
-            _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C, _ptr(db64), st), "gridgcn_colsum")
-        return dX, dW[:C], db64[:C].float()
+            db64 = _zeros(Cp + 1, torch.float64, dev)           # (+ the ticket of the fp32 copy)
+            db = torch.empty(C, dtype=torch.float32, device=dev)
+            _lib.check(lib.gridgcn_colsum_f32(_ptr(dL), E, Cp, C, _ptr(db64), _ptr(db), st), "gridgcn_colsum")
+        return dX, dW[:C], db
 
 
 class _LinearMM(torch.autograd.Function):
@@ -2140,8 +2271,9 @@ class _HeadTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(x)
             dH = torch.empty((E, C), dtype=torch.float32, device=dev)
-            acc = _zeros(2 * C + Cp, torch.float64, dev)
+            acc = _zeros(2 * C + Cp + 1, torch.float64, dev)    # (+ the ticket of the fp32 copy)
             sums, db64 = acc[:2 * C], acc[2 * C:]
+            db2 = torch.empty(C2, dtype=torch.float32, device=dev)
             # gradient w.r.t. relu(bn(Z_fc1)) (dropout mask applied) + fc1's BatchNorm-backward sums
             _lib.check(lib.gridgcn_linear_dx(
                 _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
@@ -2158,7 +2290,7 @@ class _HeadTrain(torch.autograd.Function):
                 _ptr(ident[4]), _ptr(ident[5]), _ptr(Hd), None, None, None, None, _ptr(Wb2), None,
                 None, 0, E, Cp, C, C, 0, 0, None, _ptr(dW2), None, None, None, 0, _ptr(ws),
                 nbytes.value, st), "gridgcn_linear_bwd")
-            _lib.check(lib.gridgcn_colsum(_ptr(dL), E, Cp, C2, _ptr(db64), st), "gridgcn_colsum")
+            _lib.check(lib.gridgcn_colsum_f32(_ptr(dL), E, Cp, C2, _ptr(db64), _ptr(db2), st), "gridgcn_colsum")
             prev = ctx.prev
             r = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,
                                 ctx.ndx, sums, dH, None, ctx.needs_input_grad[0],
@@ -2166,8 +2298,8 @@ class _HeadTrain(torch.autograd.Function):
                                 nbn=prev.nbn() if prev is not None else 0)
             dX, grads = r[0], r[1]
             if prev is not None:
-                prev.sums = r[2].view(2, x.shape[1])
-        return (dX, None) + tuple(grads) + (dW2[:C2], db64[:C2].float())
+                prev.sums = prev.take_sums(r[2], x.shape[1])
+        return (dX, None) + tuple(grads) + (dW2[:C2], db2)
 
 
 def head_supported(x, layers, lin):
@@ -2222,17 +2354,19 @@ class _SoftmaxCE(torch.autograd.Function):
             logits = buf[:, :C]
         label = label.contiguous()
         lse = torch.empty(E, dtype=torch.float32, device=dev)
-        acc = _zeros(2, torch.float64, dev)
+        acc = _zeros(3, torch.float64, dev)             # sum, count, ticket
+        loss = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.gridgcn_softmax_ce_fwd(_ptr(logits), ld, C, _ptr(label), E, ignore,
-                                                  _ptr(lse), _ptr(acc), _stream(logits)),
-                       "gridgcn_softmax_ce_fwd")
+            _lib.check(lib.gridgcn_softmax_ce_loss(_ptr(logits), ld, C, _ptr(label), E, ignore,
+                                                   _ptr(lse), _ptr(acc), _ptr(loss), _stream(logits)),
+                       "gridgcn_softmax_ce_loss")
         ctx.save_for_backward(logits, label, lse, acc)
         ctx.meta = (ld, ignore)
         ctx.cw = cw
         # SoftmaxOutput(normalization='valid'): the valid count is clamped to >= 1, so a batch
         # whose labels are all ignore_label gives loss 0 and gradient 0 instead of 0/0
-        return (acc[0] / acc[1].clamp_min(1.0)).float()
+        # (formed by the kernel's last workgroup)
+        return loss
 
     @staticmethod
     def backward(ctx, g):

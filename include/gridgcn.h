@@ -69,7 +69,11 @@ const char *gridgcn_strerror(int code);
 int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-max tensors;
                                  * 4: gridgcn_set_option, Z-less attention pair removed, the library
                                  *    reads nothing from the process environment
-                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4 */
+                                 * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4
+                                 * 6: gridgcn_pack_desc.wgb / geo, gridgcn_adam_step, gridgcn_cat_mask,
+                                 *    gridgcn_mask_sum, gridgcn_ball_knn_grid_ld, gridgcn_bn_finalize_tail,
+                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32; psums of a dX launch with
+                                 *    nbn > 0 is [2][nbn] */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -193,6 +197,14 @@ int gridgcn_ball_knn_grid_workspace_bytes(int B, int m, size_t *bytes);
 int gridgcn_ball_knn_grid(const float *unknown, const float *known, const int32_t *downnum,
                           const int32_t *upnum, int B, int n, int m, int k, float radius,
                           int32_t *idx, void *workspace, size_t workspace_bytes, void *stream);
+/* gridgcn_ball_knn_grid_ld: the same with the coordinates read in place from wider rows -- unknown[B,n]
+ * rows of ldu floats, known[B,m] rows of ldk floats (x, y, z first; the [B,n,4+C] point rows of the
+ * up path, ggcn_models_g.py:204-205, without the two packing copies) -- and, zero_tail != 0, rows
+ * >= upnum[b] of idx written as 0 (for a caller that hands over uninitialised memory). */
+int gridgcn_ball_knn_grid_ld(const float *unknown, int ldu, const float *known, int ldk,
+                             const int32_t *downnum, const int32_t *upnum, int B, int n, int m, int k,
+                             float radius, int zero_tail, int32_t *idx, void *workspace,
+                             size_t workspace_bytes, void *stream);
 int gridgcn_knn(const float *unknown, const float *known, const int32_t *downnum,
                 const int32_t *upnum, int B, int n, int m, int k,
                 int32_t *idx, void *stream);
@@ -344,7 +356,8 @@ int gridgcn_linear_fwd(const float *X, long long E, int cin, const float *W, con
  * copy nor a separate BatchNorm-backward reduce pass exists (gridgcn_linear_bwd_ld: the
  * register-direct dX / dW kernels only; other shapes return GRIDGCN_EINVAL;
  * nbn: only the first nbn input columns (a multiple of 32; 0 = all) carry a previous BatchNorm -- the
- * dX epilogue reads Aprev and accumulates psums for those alone). */
+ * dX epilogue reads Aprev and accumulates psums for those alone, and psums is then [2][nbn]: the
+ * producer's own table). */
 int gridgcn_linear_fwd_ld(const float *X, long long E, int cin, const float *W, const float *b, int K,
                           int ldw, int cout, const float *scale, const float *shift, float *Z,
                           double *sums, int ldz, void *stream);
@@ -371,8 +384,11 @@ int gridgcn_pack_linear(const float *W, const float *b, int C, int cin_w, int ro
 typedef struct gridgcn_pack_desc {
     const float *W, *b;
     float *Wp, *Bp, *Wb, *Wg, *Wq, *Wdx;
+    float *wgb;                 /* optional [4][C]: rows 0..2 = W[:, 0:3]^T (geo != 0) or zeros, row 3 = b:
+                                 * the geo_vec weights + bias table of the gridgcn_edge_lin0_* kernels */
     int32_t C, cin_w, rot, cin, ndx;
     int32_t K, ldw, n;          /* written by gridgcn_pack_desc_fill */
+    int32_t geo, reserved;
 } gridgcn_pack_desc;
 int gridgcn_pack_desc_fill(gridgcn_pack_desc *desc_host);
 int gridgcn_pack_linear_batch(const gridgcn_pack_desc *descs_dev, int nlayers, int max_n, void *stream);
@@ -468,6 +484,13 @@ int gridgcn_bn_finalize(const double *sums, const float *gamma, const float *bet
                         float eps, float momentum, int C, float *scale, float *shift, float *mean,
                         float *rstd, float *running_mean, float *running_var,
                         int64_t *num_batches_tracked, void *stream);
+/* gridgcn_bn_finalize_tail: scale .. rstd are rows of a table of C + tail columns; the tail columns get
+ * the identity (scale 1, shift / mean / rstd 0): the concat(centre MLP output, aggregate) buffer whose
+ * consumer applies the producer's BatchNorm while loading (gridgcn_linear_bwd_ld, nbn). */
+int gridgcn_bn_finalize_tail(const double *sums, const float *gamma, const float *beta, long long E,
+                             float eps, float momentum, int C, int tail, float *scale, float *shift,
+                             float *mean, float *rstd, float *running_mean, float *running_var,
+                             int64_t *num_batches_tracked, void *stream);
 int gridgcn_bn_bwd_finalize(const double *sums, long long E, int C, float *m1, float *m2,
                             float *dgamma, float *dbeta, void *stream);
 int gridgcn_linear_bwd_workspace_bytes(long long E, int cin, int C, size_t *bytes);
@@ -615,6 +638,37 @@ int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t 
  * the loss (custom_op/weighted_gradient.py:18-26, ggcn_models_g.py:40): every row of dlogits is
  * multiplied by max_c [dlogits_c < 0] * class_weight_c, i.e. by the weight of the row's label. */
 int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream);
+/* gridgcn_softmax_ce_loss: gridgcn_softmax_ce_fwd + loss[0] = acc3[0] / max(acc3[1], 1) written by the
+ *   last workgroup to arrive; acc3 = (sum, count, ticket) fp64[3], zeroed by the caller.
+ * gridgcn_colsum_f32: gridgcn_colsum + out[c] = (float)acc[c] likewise; acc fp64[ncols + 1], zeroed. */
+int gridgcn_softmax_ce_loss(const float *logits, int ld, int ncls, const int64_t *label, long long E,
+                            int ignore_label, float *lse, double *acc3, float *loss, void *stream);
+int gridgcn_colsum_f32(const float *X, long long E, int ld, int ncols, double *acc, float *out,
+                       void *stream);
+
+/* ---- glue of a layer boundary and the optimizer -------------------------------------------------
+ * gridgcn_cat_mask: out[r, 0:ca] = a[r, :], out[r, ca:ca+cb] = b[r, :] * mask[r], zeros up to ldo;
+ *   b == NULL: the cb columns are 1.0; mask == NULL: no mask; out2 (optional, row stride ldo2): the
+ *   same rows once more (the zero-padded copy).  data_layer = concat(cent, feats * centmsk):
+ *   segmentation/models/ggcn_models_g.py:137,186,231, gcn_module_g_att.py:284-285.
+ * gridgcn_mask_sum: out[r, c] = (g1[r, col0 + c] + g2[r, col0 + c]) * mask[r], c < C: its backward
+ *   (g1 / g2 with row strides ld1 / ld2; either may be NULL).
+ * gridgcn_adam_step: the Adam update of n tensors in one launch per 128 tensors (base_solver.py:105-114:
+ *   mx.optimizer.Adam with wd).  params / grads / sizes / mchunk are HOST arrays (device pointers,
+ *   element counts, first 1024-element chunk of tensor i in the moment buffers m and v); state =
+ *   int32[2] on the device (step count t, ticket), zero before the first call, t += 1 per call;
+ *   lr_dev (optional): learning rate read from device memory instead of lr.
+ *   mode 0: torch.optim.Adam  w -= lr/(1-b1^t) m / (sqrt(v)/sqrt(1-b2^t) + eps);
+ *   mode 1: mx.optimizer.Adam w -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps); g = grad + wd w. */
+int gridgcn_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb,
+                     const float *mask, float *out, int ldo, float *out2, int ldo2, long long E,
+                     void *stream);
+int gridgcn_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, int C,
+                     const float *mask, float *out, long long E, void *stream);
+int gridgcn_adam_step(float *const *params, const float *const *grads, const long long *sizes,
+                      const long long *mchunk, int n, float *m, float *v, int32_t *state, float lr,
+                      const float *lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      int mode, void *stream);
 
 /* ---- GridConv edge pipeline (inference-mode BatchNorm) ----------------------------------------
  * Replaces, for one sub_g_update call (segmentation/models/gcn_module_g_att.py:172-287, aggtype

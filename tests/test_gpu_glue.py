@@ -1,0 +1,150 @@
+"""The glue kernels of a training step (csrc/gridgcn_optim.hip, gridgcn_ballgrid.hip strided entry) against
+the stock PyTorch ops they replace."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _params(sizes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in sizes]
+
+
+SIZES = [(128, 131), (128,), (1,), (21, 128), (21,), (257, 9), (3,), (2048 + 5,), (64, 64), (1024,), (1023,),
+         (1025,)]
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_adam_matches_torch(wd):
+    """five steps with fresh gradients: parameters and both moments within rounding of torch.optim.Adam"""
+    from grid_gcn_amd import optim
+    p1 = _params(SIZES, 0)
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in p1]
+    o1 = torch.optim.Adam(p1, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    o2 = optim.Adam(p2, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    g = torch.Generator().manual_seed(1)
+    for it in range(5):
+        for a, b in zip(p1, p2):
+            gr = torch.randn(a.shape, generator=g).to(DEV) * (0.1 + it)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        v0 = [b._version for b in p2]
+        o1.step()
+        o2.step()
+        assert all(b._version > v for b, v in zip(p2, v0))      # caches keyed on _version see the update
+    for a, b in zip(p1, p2):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+        assert torch.allclose(o1.state[a]["exp_avg"], o2.state[b]["exp_avg"], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(o1.state[a]["exp_avg_sq"], o2.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+    assert int(o2.state[p2[0]]["step"]) == 5
+
+
+def test_adam_many_tensors_none_grads_and_mxnet_form():
+    """300 tensors (three launches), some without a gradient; mx.optimizer.Adam's form against its formula"""
+    from grid_gcn_amd import optim
+    sizes = [(7 + i % 13, 3 + i % 5) for i in range(300)]
+    ps = _params(sizes, 2)
+    ref = [p.detach().clone().double() for p in ps]
+    m = [torch.zeros_like(r) for r in ref]
+    v = [torch.zeros_like(r) for r in ref]
+    lr, b1, b2, eps, wd = 1e-2, 0.9, 0.999, 1e-8, 1e-3
+    opt = optim.Adam(ps, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, mxnet=True)
+    g = torch.Generator().manual_seed(3)
+    for t in range(1, 4):
+        for i, p in enumerate(ps):
+            if i % 17 == 5:
+                p.grad = None
+                continue
+            gr = torch.randn(p.shape, generator=g).to(DEV)
+            p.grad = gr
+            gd = gr.double() + wd * ref[i]
+            m[i] = b1 * m[i] + (1 - b1) * gd
+            v[i] = b2 * v[i] + (1 - b2) * gd * gd
+            ref[i] = ref[i] - lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t) * m[i] / (v[i].sqrt() + eps)
+        opt.step()
+    for p, r in zip(ps, ref):
+        assert float((p.double() - r).abs().max()) <= 3e-6 * max(1.0, float(r.abs().max()))
+
+
+def test_adam_state_dict_round_trip_and_tensor_lr():
+    from grid_gcn_amd import optim
+    p1 = _params(SIZES[:5], 4)
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in p1]
+    lr = torch.tensor(2e-3, device=DEV)
+    o1 = optim.Adam(p1, lr=lr, weight_decay=1e-4)
+    o2 = optim.Adam(p2, lr=2e-3, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(5)
+
+    def grads():
+        for a, b in zip(p1, p2):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+
+    for _ in range(2):
+        grads()
+        o1.step()
+        o2.step()
+    sd = copy.deepcopy(o2.state_dict())
+    o3 = optim.Adam(p2, lr=2e-3, weight_decay=1e-4)
+    o3.load_state_dict(sd)
+    lr.fill_(5e-4)                       # the kernel reads the device scalar at every launch
+    o3.param_groups[0]["lr"] = 5e-4
+    grads()
+    o1.step()
+    o3.step()
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a, b, rtol=0, atol=2e-7)
+    assert int(o3.state[p2[0]]["step"]) == 3
+
+
+@pytest.mark.parametrize("ca,cb,mask,pad", [(4, 64, True, True), (4, 128, True, False), (4, 256, False, True),
+                                            (3, None, False, True), (4, 12, True, True), (4, 4, True, True)])
+def test_cat_mask_matches_torch(ca, cb, mask, pad):
+    from grid_gcn_amd import train_ops
+    torch.manual_seed(ca * 100 + (cb or 0))
+    B, O = 3, 37
+    a = torch.randn(B, O, ca, device=DEV)
+    b = torch.randn(B, O, cb, device=DEV, requires_grad=True) if cb else None
+    mk = (torch.rand(B, O, device=DEV) > 0.3).float() if mask else None
+    out, outp = train_ops.cat_mask(a, b, mk, pad=pad)
+    bb = b if b is not None else torch.ones(B, O, 1, device=DEV)
+    ref = torch.cat([a, bb * mk[..., None] if mk is not None else bb], dim=-1)
+    assert torch.equal(out, ref)
+    W = ref.shape[-1]
+    if pad and W % 8:
+        assert outp.shape[-1] == (W + 7) // 8 * 8 and torch.equal(outp[..., :W], ref)
+        assert float(outp[..., W:].abs().max()) == 0.0
+    else:
+        assert outp is out
+    if b is None:
+        return
+    # both outputs used, one through a column slice of a wider gradient (as the edge block's source rows)
+    w1 = torch.randn_like(out)
+    w2 = torch.randn_like(outp)
+    loss = (out * w1).sum() + ((outp * w2).sum() if outp is not out else 0.0)
+    loss.backward()
+    b2 = b.detach().clone().requires_grad_(True)
+    ref = torch.cat([a, b2 * mk[..., None] if mk is not None else b2], dim=-1)
+    l2 = (ref * w1).sum() + ((ref * w2[..., :W]).sum() if outp is not out else 0.0)
+    l2.backward()
+    assert torch.allclose(b.grad, b2.grad, rtol=1e-6, atol=1e-6)
+
+
+def test_ball_knn_reads_wider_rows_in_place():
+    """xyz columns of [B, n, 4+C] rows (any row width): the indices of the packed call, rows >= upnum zero"""
+    from grid_gcn_amd import ops
+    torch.manual_seed(0)
+    B, n, m = 2, 700, 300
+    up = torch.rand(B, n, 7, device=DEV)
+    down = torch.rand(B, m, 4, device=DEV)
+    upnum = torch.tensor([[n], [n - 50]], dtype=torch.int32, device=DEV)
+    downnum = torch.tensor([[m], [m - 9]], dtype=torch.int32, device=DEV)
+    i1 = ops.BallKNN(up[..., :3].contiguous(), down[..., :3].contiguous(), downnum, upnum, k=3, radius=0.2)
+    i2 = ops.BallKNN(up[..., :3], down[..., :3], downnum, upnum, k=3, radius=0.2)
+    assert torch.equal(i1, i2)
+    assert int(i2[1, n - 50:].abs().max()) == 0
+    assert int((i1 >= 0).sum()) > 0

@@ -32,7 +32,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     for _ in range(K):
         step()
     torch.cuda.synchronize()
@@ -62,3 +62,17 @@ for k, (cnt, dt) in sorted(byop.items(), key=lambda kv: -kv[1][1]):
     print("%8.1f us/step n=%5.1f %s" % (dt / K, cnt / K, k))
     n += cnt; t += dt
 print("aten total: %.1f launches, %.1f us per step" % (n / K, t / K))
+
+# ... and where in this package each of them is issued (innermost frames of the package / bench)
+print("---- aten ops by call site")
+bysite = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=14):
+    dt = getattr(ev, "self_device_time_total", 0.0)
+    if dt <= 0 or not ev.key.startswith("aten::"):
+        continue
+    fr = [f for f in ev.stack if "grid_gcn_amd" in f or "aten_ops.py" in f or "optim" in f]
+    site = " < ".join(x.split("/")[-1].strip() for x in fr[:3]) or "?"
+    bysite[(ev.key, site, str(ev.input_shapes)[:60])][0] += ev.count
+    bysite[(ev.key, site, str(ev.input_shapes)[:60])][1] += dt
+for (k, site, shp), (cnt, dt) in sorted(bysite.items(), key=lambda kv: -kv[1][1]):
+    print("%7.1f us n=%4.1f %-16s %s  %s" % (dt / K, cnt / K, k, site, shp))
