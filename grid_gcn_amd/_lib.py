@@ -46,7 +46,7 @@ EXPORTS = [
     "gridgcn_pack_linear", "gridgcn_linear_fwd_direct", "gridgcn_bn_finalize", "gridgcn_bn_bwd_finalize",
     "gridgcn_linear_fwd_direct2", "gridgcn_ctx_max", "gridgcn_ctx_max_backward",
     "gridgcn_bn_dz_segsum", "gridgcn_sparse_add", "gridgcn_bn_stats",
-    "gridgcn_ball_knn_grid_ld", "gridgcn_bn_finalize_tail", "gridgcn_softmax_ce_loss", "gridgcn_colsum_f32",
+    "gridgcn_ball_knn_grid_ld", "gridgcn_ball_knn_ld", "gridgcn_bn_finalize_tail", "gridgcn_softmax_ce_loss", "gridgcn_colsum_f32",
     "gridgcn_cat_mask", "gridgcn_mask_sum", "gridgcn_adam_step",
 ]
 
@@ -168,6 +168,8 @@ def load():
     lib.gridgcn_pairmax_bwd_masked.argtypes = [vp] * 10 + [ll, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_att_bwd_noz_workspace_bytes.restype = ci
     lib.gridgcn_att_bwd_noz_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_ball_knn_ld.restype = ci
+    lib.gridgcn_ball_knn_ld.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp, vp]
     lib.gridgcn_ball_knn_grid_ld.restype = ci
     lib.gridgcn_ball_knn_grid_ld.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ctypes.c_float, ci, vp,
                                              vp, ctypes.c_size_t, vp]

@@ -21,7 +21,7 @@ int gg_launch_query_up(const float *updata, const int *up_np, int B, int Nd, con
                        char *wsbase, const GGIndexWs &w, int *nebidx, float *nebmsk,
                        hipStream_t st);
 int gg_ball_knn(const float *, const float *, const int *, const int *, int, int, int, int, float,
-                int *, hipStream_t);
+                int *, hipStream_t, int su = 3, int sk = 3, int ztail = 0);
 int gg_knn(const float *, const float *, const int *, const int *, int, int, int, int, int *,
            hipStream_t);
 int gg_batch_take(const float *, const int *, int, int, int, int, float *, hipStream_t);
@@ -354,6 +354,16 @@ int gridgcn_ball_knn(const float *unknown, const float *known, const int32_t *do
     if (B < 1 || n < 1 || m < 1 || k < 1 || k > 6) return GRIDGCN_EINVAL;  // best[6]
     return gg_ball_knn(unknown, known, downnum, upnum, B, n, m, k, radius, idx,
                        (hipStream_t)stream);
+}
+
+int gridgcn_ball_knn_ld(const float *unknown, int ldu, const float *known, int ldk,
+                        const int32_t *downnum, const int32_t *upnum, int B, int n, int m, int k,
+                        float radius, int zero_tail, int32_t *idx, void *stream)
+{
+    if (!unknown || !known || !downnum || !upnum || !idx || ldu < 3 || ldk < 3) return GRIDGCN_EINVAL;
+    if (B < 1 || n < 1 || m < 1 || k < 1 || k > 6) return GRIDGCN_EINVAL;  // best[6]
+    return gg_ball_knn(unknown, known, downnum, upnum, B, n, m, k, radius, idx,
+                       (hipStream_t)stream, ldu, ldk, zero_tail ? 1 : 0);
 }
 
 int gridgcn_knn(const float *unknown, const float *known, const int32_t *downnum,

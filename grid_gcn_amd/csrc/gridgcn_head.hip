@@ -12,6 +12,15 @@
 //   gg_k_colsum   column sums of a [E, ld] tensor (bias gradient of the last linear layer)
 #include <hip/hip_runtime.h>
 
+// Sums that every workgroup of a launch adds to: atomics on ONE address are served one after the other at
+// ~45 ns each (512 workgroups: 23 us, as long as these kernels' reads), so the `slotted` entries spread
+// them over 16 slots on cache lines of their own and a tiny second launch adds the slots up -- which also
+// forms what the framework formed with 1-3 ops of its own (loss = sum / max(count, 1); the fp32 bias
+// gradient).  (A last-arriver ticket instead of the second launch was tried: the agent-scope release /
+// acquire it needs is an L2 write-back + invalidate per workgroup on this 8-XCD part, 22 -> 45 us.)
+#define GG_SLOTS 16
+__device__ __forceinline__ int gg_slot() { return (int)(blockIdx.x % GG_SLOTS); }
+
 template <int NV>
 __device__ __forceinline__ void gg_row_load(const float *__restrict__ p, float (&v)[4 * NV])
 {
@@ -66,22 +75,20 @@ __global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ log
     // after the other.  cfg4 (655 360 rows): 2 x 2560 requests 70 us, 512 requests 22 us
     if (threadIdx.x < 2) {
         const int t = threadIdx.x;
-        atomicAdd(&acc[t], (double)((red[t][0] + red[t][1]) + (red[t][2] + red[t][3])));
+        // (loss_out: the sums go to one of 16 slots)
+        atomicAdd(&acc[t + (loss_out ? 16 * gg_slot() : 0)],
+                  (double)((red[t][0] + red[t][1]) + (red[t][2] + red[t][3])));
     }
-    if (loss_out) {
-        // loss = sum / max(count, 1) by the last workgroup to arrive (ticket in the low word of acc[2]):
-        // the three framework ops that used to form it were 13 us of a step
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int *ticket = (int *)(acc + 2);
-            __threadfence();
-            if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-                const double s = __hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double n = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                loss_out[0] = (float)(s / (n > 1.0 ? n : 1.0));
-            }
-        }
-    }
+}
+
+// acc: [16 slots x 16] partial (sum, count) -> acc[256] = sum, acc[257] = count, loss = sum / max(count, 1)
+__global__ void gg_k_ce_finish(double *__restrict__ acc, float *__restrict__ loss_out)
+{
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < GG_SLOTS; k++) { s0 += acc[16 * k]; s1 += acc[16 * k + 1]; }
+    acc[16 * GG_SLOTS] = s0;
+    acc[16 * GG_SLOTS + 1] = s1;
+    loss_out[0] = (float)(s0 / (s1 > 1.0 ? s1 : 1.0));
 }
 
 template <int NV>
@@ -131,7 +138,6 @@ __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, 
                                                    float *__restrict__ out32)
 {
     __shared__ float red[4][4 * NV];
-    __shared__ int s_last;
     float a[4 * NV];
 #pragma unroll
     for (int c = 0; c < 4 * NV; c++) a[c] = 0.f;
@@ -151,21 +157,17 @@ __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, 
     }
     __syncthreads();
     if (threadIdx.x < ncols)
-        atomicAdd(&out[threadIdx.x], (double)((red[0][threadIdx.x] + red[1][threadIdx.x]) +
-                                              (red[2][threadIdx.x] + red[3][threadIdx.x])));
-    if (out32) {
-        // fp32 copy of the sums by the last workgroup to arrive (ticket in the low word of out[ncols];
-        // ncols <= 32: the atomics above were all issued by wave 0, whose fence covers them)
-        if (threadIdx.x == 0) {
-            __threadfence();
-            s_last = __hip_atomic_fetch_add((int *)(out + ncols), 1, __ATOMIC_ACQ_REL,
-                                            __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-        }
-        __syncthreads();
-        if (s_last && threadIdx.x < ncols)
-            out32[threadIdx.x] = (float)__hip_atomic_load(&out[threadIdx.x], __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-    }
+        atomicAdd(&out[threadIdx.x + (out32 ? 32 * gg_slot() : 0)],
+                  (double)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])));
+}
+
+// out: [16 slots x 32] partial sums -> fp32 totals
+__global__ void gg_k_colsum_finish(const double *__restrict__ out, int ncols, float *__restrict__ out32)
+{
+    if ((int)threadIdx.x >= ncols) return;
+    double a = 0.0;
+    for (int k = 0; k < GG_SLOTS; k++) a += out[32 * k + threadIdx.x];
+    out32[threadIdx.x] = (float)a;
 }
 
 // logits rows of ld floats (ld in {4,8,...,32}), ncls <= ld
@@ -181,6 +183,7 @@ int gg_ce_fwd(const float *logits, int ld, int ncls, const long long *label, lon
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }
+    if (loss) gg_k_ce_finish<<<1, 1, 0, st>>>(acc, loss);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -208,5 +211,6 @@ int gg_colsum(const float *X, long long E, int ld, int ncols, double *out, float
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }
+    if (out32) gg_k_colsum_finish<<<1, 32, 0, st>>>(out, ncols, out32);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

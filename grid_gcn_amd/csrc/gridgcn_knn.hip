@@ -16,8 +16,11 @@ __global__ __launch_bounds__(256) void gg_k_knn(const float *__restrict__ unknow
                                                 const float *__restrict__ known,
                                                 const int *__restrict__ downnum,
                                                 const int *__restrict__ upnum, int n, int m,
-                                                int topk, float r2, int *__restrict__ idx)
+                                                int topk, float r2, int *__restrict__ idx,
+                                                int su, int sk, int ztail)
 {
+    // su / sk: floats per unknown / known point row (3, or the width of the [B,n,4+C] point rows the up
+    // path reads in place); ztail: rows >= upnum[b] are written as 0 instead of being left alone
     __shared__ float sx[GG_KNN_TILE], sy[GG_KNN_TILE], sz[GG_KNN_TILE];
     const int b = blockIdx.y;
     const int qi = blockIdx.x * 256 + threadIdx.x;
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(256) void gg_k_knn(const float *__restrict__ unknow
     const bool active = qi < n && qi < upn;
     float ux = 0.f, uy = 0.f, uz = 0.f;
     if (active) {
-        const float *u = unknown + ((size_t)b * n + qi) * 3;
+        const float *u = unknown + ((size_t)b * n + qi) * su;
         ux = u[0]; uy = u[1]; uz = u[2];
     }
     float best[K];
@@ -35,13 +38,13 @@ __global__ __launch_bounds__(256) void gg_k_knn(const float *__restrict__ unknow
 #pragma unroll
     for (int l = 0; l < K; l++) { best[l] = FLT_MAX; besti[l] = -1; }
 
-    const float *kb = known + (size_t)b * m * 3;
+    const float *kb = known + (size_t)b * m * sk;
     for (int t0 = 0; t0 < dn; t0 += GG_KNN_TILE) {
         int tn = dn - t0 < GG_KNN_TILE ? dn - t0 : GG_KNN_TILE;
         __syncthreads();
         for (int j = threadIdx.x; j < tn * 3; j += 256) {
-            float val = kb[(size_t)t0 * 3 + j];
             int pidx = j / 3, c = j - pidx * 3;
+            float val = kb[(size_t)(t0 + pidx) * sk + c];
             (c == 0 ? sx : (c == 1 ? sy : sz))[pidx] = val;
         }
         __syncthreads();
@@ -74,17 +77,19 @@ __global__ __launch_bounds__(256) void gg_k_knn(const float *__restrict__ unknow
 #pragma unroll
         for (int l = 0; l < K; l++)
             if (l < topk) o[l] = besti[l];
+    } else if (ztail && qi < n) {
+        for (int l = 0; l < topk; l++) idx[((size_t)b * n + qi) * topk + l] = 0;
     }
 }
 
 template <bool BALL>
 static int gg_launch_knn(const float *unknown, const float *known, const int *downnum,
                          const int *upnum, int B, int n, int m, int k, float r2, int *idx,
-                         hipStream_t st)
+                         hipStream_t st, int su = 3, int sk = 3, int ztail = 0)
 {
     dim3 grid((n + 255) / 256, B);
 #define GG_KNN_CASE(KK)                                                                       \
-    gg_k_knn<KK, BALL><<<grid, 256, 0, st>>>(unknown, known, downnum, upnum, n, m, k, r2, idx)
+    gg_k_knn<KK, BALL><<<grid, 256, 0, st>>>(unknown, known, downnum, upnum, n, m, k, r2, idx, su, sk, ztail)
     if (k <= 3) GG_KNN_CASE(3);
     else if (k <= 6) GG_KNN_CASE(6);
     else if (k <= 8) GG_KNN_CASE(8);
@@ -96,10 +101,10 @@ static int gg_launch_knn(const float *unknown, const float *known, const int *do
 }
 
 int gg_ball_knn(const float *unknown, const float *known, const int *downnum, const int *upnum,
-                int B, int n, int m, int k, float radius, int *idx, hipStream_t st)
+                int B, int n, int m, int k, float radius, int *idx, hipStream_t st, int su, int sk, int ztail)
 {
     return gg_launch_knn<true>(unknown, known, downnum, upnum, B, n, m, k, radius * radius, idx,
-                               st);
+                               st, su, sk, ztail);
 }
 int gg_knn(const float *unknown, const float *known, const int *downnum, const int *upnum, int B,
            int n, int m, int k, int *idx, hipStream_t st)

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void gg_k_adam(const GGAdamTable tb, float *__
     }
     __syncthreads();                              // every thread of the workgroup has read state[0]
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (relaxed: the ticket publishes no data, it only orders the reads of state[0] above -- complete at
+        //  the barrier -- before the one write below; an agent-scope release / acquire here would be an L2
+        //  write-back + invalidate per workgroup on this 8-XCD part)
+        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (int)gridDim.x - 1) {
             state[1] = 0;
             if (bump) state[0] = t;
@@ -118,37 +121,42 @@ int gg_adam_step(float *const *params, const float *const *grads, const long lon
 //   b == nullptr: the cb columns are 1.0 (data = concat(xyz, ones), ggcn_models_g.py:137);
 //   out2 (optional): the same rows once more with stride ldo2 -- the zero-padded copy (a multiple of 8
 //   floats per row) the centre MLP of the up path reads, which used to cost a fill and a copy.
+template <typename I>
 __global__ __launch_bounds__(256) void gg_k_cat_mask(const float *__restrict__ a, int lda, int ca,
                                                      const float *__restrict__ b, int ldb, int cb,
                                                      const float *__restrict__ mask,
                                                      float *__restrict__ out, int ldo,
                                                      float *__restrict__ out2, int ldo2, long long total)
 {
-    const int ldt = ldo + ldo2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long r = i / ldt;
+    // (I = unsigned when the element count allows it: the 64-bit divide per element is half the time of
+    //  the [655360, 4 + 8] first level)
+    const I ldt = (I)(ldo + ldo2), tot = (I)total;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < tot; i += (I)gridDim.x * 256) {
+        const I r = i / ldt;
         int c = (int)(i - r * ldt);
-        float *dst = out + r * ldo + c;
-        if (c >= ldo) { c -= ldo; dst = out2 + r * ldo2 + c; }
+        float *dst = out + (size_t)r * ldo + c;
+        if (c >= ldo) { c -= ldo; dst = out2 + (size_t)r * ldo2 + c; }
         float v = 0.f;
-        if (c < ca) v = a[r * lda + c];
-        else if (c < ca + cb) v = b ? b[r * ldb + (c - ca)] * (mask ? mask[r] : 1.f) : 1.f;
+        if (c < ca) v = a[(size_t)r * lda + c];
+        else if (c < ca + cb) v = b ? b[(size_t)r * ldb + (c - ca)] * (mask ? mask[r] : 1.f) : 1.f;
         *dst = v;
     }
 }
 
 // backward of the above: out[r, :] = (g1[r, col0:col0+C] + g2[r, col0:col0+C]) * mask[r]
 // (g1 / g2: gradients of the two outputs, either may be nullptr)
+template <typename I>
 __global__ __launch_bounds__(256) void gg_k_mask_sum(const float *__restrict__ g1, int ld1,
                                                      const float *__restrict__ g2, int ld2, int col0, int C,
                                                      const float *__restrict__ mask,
                                                      float *__restrict__ out, long long total)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long r = i / C;
-        const int c = (int)(i - r * C) + col0;
-        float v = g1 ? g1[r * ld1 + c] : 0.f;
-        if (g2) v += g2[r * ld2 + c];
+    const I tot = (I)total;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < tot; i += (I)gridDim.x * 256) {
+        const I r = i / (I)C;
+        const int c = (int)(i - r * (I)C) + col0;
+        float v = g1 ? g1[(size_t)r * ld1 + c] : 0.f;
+        if (g2) v += g2[(size_t)r * ld2 + c];
         out[i] = mask ? v * mask[r] : v;
     }
 }
@@ -158,8 +166,13 @@ int gg_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb
 {
     const long long total = E * (ldo + (out2 ? ldo2 : 0));
     const long long nb = (total + 255) / 256;
-    gg_k_cat_mask<<<(int)(nb < 8192 ? nb : 8192), 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
-                                                                out2 ? ldo2 : 0, total);
+    const int grid = (int)(nb < 8192 ? nb : 8192);
+    if (total < (1ll << 31))
+        gg_k_cat_mask<unsigned><<<grid, 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
+                                                      out2 ? ldo2 : 0, total);
+    else
+        gg_k_cat_mask<long long><<<grid, 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
+                                                       out2 ? ldo2 : 0, total);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -168,6 +181,10 @@ int gg_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, in
 {
     const long long total = E * C;
     const long long nb = (total + 255) / 256;
-    gg_k_mask_sum<<<(int)(nb < 8192 ? nb : 8192), 256, 0, st>>>(g1, ld1, g2, ld2, col0, C, mask, out, total);
+    const int grid = (int)(nb < 8192 ? nb : 8192);
+    if (total < (1ll << 31))
+        gg_k_mask_sum<unsigned><<<grid, 256, 0, st>>>(g1, ld1, g2, ld2, col0, C, mask, out, total);
+    else
+        gg_k_mask_sum<long long><<<grid, 256, 0, st>>>(g1, ld1, g2, ld2, col0, C, mask, out, total);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

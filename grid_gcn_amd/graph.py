@@ -56,7 +56,8 @@ class GraphedTrainStep:
         net.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.params = [p for p in net.parameters() if p.requires_grad]
 
-        one = torch.ones((), dtype=torch.float32, device=dev)
+        # (kept alive with the graph: the captured loss-gradient kernel reads it at every replay)
+        self._one = one = torch.ones((), dtype=torch.float32, device=dev)
 
         def fwd_bwd():
             net.seed_dev.add_(_GOLDEN)

@@ -254,16 +254,17 @@ def _point_rows(t, name):
 def _knn_common(ball, unknown, known, downnum, upnum, k, radius, out):
     lib = _lib.load()
     n = unknown.shape[1] if (isinstance(unknown, torch.Tensor) and unknown.dim() == 3) else 0
-    grid_ok = (ball and BALL_GRID and int(k) <= 6 and isinstance(known, torch.Tensor) and known.dim() == 3 and known.shape[1] >= 64
+    grid_ok = (ball and BALL_GRID and int(k) <= 6 and isinstance(known, torch.Tensor) and known.dim() == 3
+               and known.shape[1] >= 64
                and n * known.shape[1] >= (1 << 16) and radius >= 0)
-    if grid_ok:
+    rows_ok = (ball and int(k) <= 6 and all(isinstance(t, torch.Tensor) and t.dim() == 3 and t.is_cuda
+                                            and t.dtype == torch.float32 and t.shape[-1] == 3
+                                            for t in (unknown, known)))
+    grid_ok = grid_ok and rows_ok
+    if rows_ok:
         unknown, ldu = _point_rows(unknown, "unknown")
         known, ldk = _point_rows(known, "known")
     else:
-        if ball and all(isinstance(t, torch.Tensor) and t.dim() == 3 and t.stride(2) == 1
-                        for t in (unknown, known)):
-            # (xyz columns of wider rows, as the grid path takes them in place: packed for the scan)
-            unknown, known = unknown.contiguous(), known.contiguous()
         _chk(unknown, "unknown", 3, torch.float32, 3)   # ball_k_nn.cc:36-42
         _chk(known, "known", 3, torch.float32, 3)
     B, n, _ = unknown.shape
@@ -276,7 +277,7 @@ def _knn_common(ball, unknown, known, downnum, upnum, k, radius, out):
     if out is None:
         # the reference leaves rows >= upnum[b] untouched (undefined memory); zero them here -- inside
         # the query kernel where it can (one fill less per call)
-        if grid_ok:
+        if rows_ok:
             out, ztail = torch.empty((B, n, int(k)), dtype=torch.int32, device=dev), 1
         else:
             out = torch.zeros((B, n, int(k)), dtype=torch.int32, device=dev)
@@ -291,6 +292,10 @@ def _knn_common(ball, unknown, known, downnum, upnum, k, radius, out):
             rc = lib.gridgcn_ball_knn_grid_ld(_ptr(unknown), ldu, _ptr(known), ldk, _ptr(downnum),
                                               _ptr(upnum), B, n, m, int(k), ctypes.c_float(radius), ztail,
                                               _ptr(out), _ptr(ws), nb.value, _stream(unknown))
+        elif rows_ok:
+            rc = lib.gridgcn_ball_knn_ld(_ptr(unknown), ldu, _ptr(known), ldk, _ptr(downnum), _ptr(upnum),
+                                         B, n, m, int(k), ctypes.c_float(radius), ztail, _ptr(out),
+                                         _stream(unknown))
         elif ball:
             rc = lib.gridgcn_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n,
                                       m, int(k), ctypes.c_float(radius), _ptr(out),

@@ -207,7 +207,7 @@ class _PackCache:
             rows = W.detach()[:, :3].t() if geo else _cached_zeros(3 * C0, W.device).view(3, C0)
             return torch.cat([rows, b.detach()[None]], out=out)
 
-        if not (isinstance(W, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter)):
+        if not (WGB_PREPACK and isinstance(W, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter)):
             return build()
         key = (id(W), id(b), C0, cin_w, "wgb", bool(geo), 0, False, W.data_ptr(), b.data_ptr())
         e = self.entries.get(key)
@@ -679,6 +679,8 @@ class _ZeroArena:
 ZERO_ARENA = True
 # the optimizer of bench.py / the tests' training loops: grid_gcn_amd.optim.Adam (one launch)
 OWN_ADAM = True
+# geo_vec weight + bias table of the source-side first conv built by the prepack launch
+WGB_PREPACK = True
 # concat + centre mask + zero padding of a layer boundary in one launch (model.GGCNSeg.forward)
 GLUE_KERNELS = True
 # evaluation of single-layer-pt edge blocks (the up layers) through the source-side kernels
@@ -1559,9 +1561,12 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             feat = src.detach()[..., 4:].reshape(R, Cf)
             if rot and dWg is None:
                 _tn_matmul(dYsrc, feat, out=dW0[:, rot:])             # [C0, Cf] beside dWg
+            elif rot:
+                dW0 = torch.empty((C0, rot + Cf), dtype=torch.float32, device=dev)
+                _tn_matmul(dYsrc, feat, out=dW0[:, rot:])
+                dW0[:, :rot].copy_(dWg.t())                           # (fp64 sums -> the three geo columns)
             else:
-                dWf = _tn_matmul(dYsrc, feat)
-                dW0 = torch.cat([dWg.t().float(), dWf], dim=1) if rot else dWf
+                dW0 = _tn_matmul(dYsrc, feat)
             gsrc = None
             if ctx.needs_input_grad[0]:
                 # gradient of the source rows [xyz w | features]: the four leading columns are zero
@@ -2163,7 +2168,7 @@ class _LinearPlain(torch.autograd.Function):
                 _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0, 0,
                 _ptr(dX) if ndx else None, _ptr(dW), None, None, None, 0, _ptr(ws), nbytes.value, st)
             _lib.check(rc, "gridgcn_linear_bwd")
-            db64 = _zeros(Cp + 1, torch.float64, dev)           # (+ the ticket of the fp32 copy)
+            db64 = _zeros(512, torch.float64, dev)              # (16 slots of partial sums)
             db = torch.empty(C, dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_colsum_f32(_ptr(dL), E, Cp, C, _ptr(db64), _ptr(db), st), "gridgcn_colsum")
         return dX, dW[:C], db
@@ -2271,7 +2276,7 @@ class _HeadTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(x)
             dH = torch.empty((E, C), dtype=torch.float32, device=dev)
-            acc = _zeros(2 * C + Cp + 1, torch.float64, dev)    # (+ the ticket of the fp32 copy)
+            acc = _zeros(2 * C + 512, torch.float64, dev)       # (db64: 16 slots of partial sums)
             sums, db64 = acc[:2 * C], acc[2 * C:]
             db2 = torch.empty(C2, dtype=torch.float32, device=dev)
             # gradient w.r.t. relu(bn(Z_fc1)) (dropout mask applied) + fc1's BatchNorm-backward sums
@@ -2354,18 +2359,18 @@ class _SoftmaxCE(torch.autograd.Function):
             logits = buf[:, :C]
         label = label.contiguous()
         lse = torch.empty(E, dtype=torch.float32, device=dev)
-        acc = _zeros(3, torch.float64, dev)             # sum, count, ticket
+        acc = _zeros(272, torch.float64, dev)           # 16 slots of partial sums | total, count at [256:258]
         loss = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.gridgcn_softmax_ce_loss(_ptr(logits), ld, C, _ptr(label), E, ignore,
                                                    _ptr(lse), _ptr(acc), _ptr(loss), _stream(logits)),
                        "gridgcn_softmax_ce_loss")
-        ctx.save_for_backward(logits, label, lse, acc)
+        ctx.save_for_backward(logits, label, lse, acc[256:258])
         ctx.meta = (ld, ignore)
         ctx.cw = cw
         # SoftmaxOutput(normalization='valid'): the valid count is clamped to >= 1, so a batch
         # whose labels are all ignore_label gives loss 0 and gradient 0 instead of 0/0
-        # (formed by the kernel's last workgroup)
+        # (formed by the entry's second launch)
         return loss
 
     @staticmethod

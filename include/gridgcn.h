@@ -71,7 +71,7 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  *    reads nothing from the process environment
                                  * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4
                                  * 6: gridgcn_pack_desc.wgb / geo, gridgcn_adam_step, gridgcn_cat_mask,
-                                 *    gridgcn_mask_sum, gridgcn_ball_knn_grid_ld, gridgcn_bn_finalize_tail,
+                                 *    gridgcn_mask_sum, gridgcn_ball_knn[_grid]_ld, gridgcn_bn_finalize_tail,
                                  *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32; psums of a dX launch with
                                  *    nbn > 0 is [2][nbn] */
 
@@ -197,10 +197,13 @@ int gridgcn_ball_knn_grid_workspace_bytes(int B, int m, size_t *bytes);
 int gridgcn_ball_knn_grid(const float *unknown, const float *known, const int32_t *downnum,
                           const int32_t *upnum, int B, int n, int m, int k, float radius,
                           int32_t *idx, void *workspace, size_t workspace_bytes, void *stream);
-/* gridgcn_ball_knn_grid_ld: the same with the coordinates read in place from wider rows -- unknown[B,n]
+/* gridgcn_ball_knn_ld / gridgcn_ball_knn_grid_ld: the same with the coordinates read in place from wider rows -- unknown[B,n]
  * rows of ldu floats, known[B,m] rows of ldk floats (x, y, z first; the [B,n,4+C] point rows of the
  * up path, ggcn_models_g.py:204-205, without the two packing copies) -- and, zero_tail != 0, rows
  * >= upnum[b] of idx written as 0 (for a caller that hands over uninitialised memory). */
+int gridgcn_ball_knn_ld(const float *unknown, int ldu, const float *known, int ldk,
+                        const int32_t *downnum, const int32_t *upnum, int B, int n, int m, int k,
+                        float radius, int zero_tail, int32_t *idx, void *stream);
 int gridgcn_ball_knn_grid_ld(const float *unknown, int ldu, const float *known, int ldk,
                              const int32_t *downnum, const int32_t *upnum, int B, int n, int m, int k,
                              float radius, int zero_tail, int32_t *idx, void *workspace,
@@ -638,9 +641,12 @@ int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t 
  * the loss (custom_op/weighted_gradient.py:18-26, ggcn_models_g.py:40): every row of dlogits is
  * multiplied by max_c [dlogits_c < 0] * class_weight_c, i.e. by the weight of the row's label. */
 int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream);
-/* gridgcn_softmax_ce_loss: gridgcn_softmax_ce_fwd + loss[0] = acc3[0] / max(acc3[1], 1) written by the
- *   last workgroup to arrive; acc3 = (sum, count, ticket) fp64[3], zeroed by the caller.
- * gridgcn_colsum_f32: gridgcn_colsum + out[c] = (float)acc[c] likewise; acc fp64[ncols + 1], zeroed. */
+/* gridgcn_softmax_ce_loss: gridgcn_softmax_ce_fwd with the two sums spread over 16 slots (atomics on ONE
+ *   address serialise at ~45 ns per workgroup) and a one-thread second launch that adds the slots up and
+ *   writes loss[0] = sum / max(count, 1).  acc = fp64[272], zeroed by the caller, 128-byte aligned:
+ *   16 slots x 16, then acc[256] = sum, acc[257] = count (pass acc + 256 to gridgcn_softmax_ce_bwd).
+ * gridgcn_colsum_f32: gridgcn_colsum likewise, out[c] = (float) total; acc fp64[512], zeroed, 128-byte
+ *   aligned (16 slots x 32 partial sums). */
 int gridgcn_softmax_ce_loss(const float *logits, int ld, int ncls, const int64_t *label, long long E,
                             int ignore_label, float *lse, double *acc3, float *loss, void *stream);
 int gridgcn_colsum_f32(const float *X, long long E, int ld, int ncols, double *acc, float *out,
