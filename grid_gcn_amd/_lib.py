@@ -48,6 +48,7 @@ EXPORTS = [
     "gridgcn_bn_dz_segsum", "gridgcn_sparse_add", "gridgcn_bn_stats",
     "gridgcn_ball_knn_grid_ld", "gridgcn_ball_knn_ld", "gridgcn_bn_finalize_tail", "gridgcn_softmax_ce_loss", "gridgcn_colsum_f32",
     "gridgcn_cat_mask", "gridgcn_mask_sum", "gridgcn_adam_step",
+    "gridgcn_edge_geo_forward_workspace_bytes", "gridgcn_edge_geo_forward",
 ]
 
 
@@ -231,6 +232,10 @@ def load():
     lib.gridgcn_bn_finalize.argtypes = [vp, vp, vp, ll, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gridgcn_bn_bwd_finalize.restype = ci
     lib.gridgcn_bn_bwd_finalize.argtypes = [vp, ll, ci, vp, vp, vp, vp, vp]
+    lib.gridgcn_edge_geo_forward_workspace_bytes.restype = ci
+    lib.gridgcn_edge_geo_forward_workspace_bytes.argtypes = [ci, ci, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_edge_geo_forward.restype = ci
+    lib.gridgcn_edge_geo_forward.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp] * 7 + [cs, vp]
     lib.gridgcn_edge_lin0_forward.restype = ci
     lib.gridgcn_edge_lin0_forward.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp] * 6
     lib.gridgcn_edge_lin0_backward.restype = ci

@@ -941,6 +941,27 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_edge_geo_forward_workspace_bytes(int B, int Nsrc, int O, int P, size_t *bytes)
+{
+    if (!bytes || B < 1 || Nsrc < 1 || O < 1 || P < 1) return GRIDGCN_EINVAL;
+    *bytes = gg_edge_geo_workspace(B, Nsrc, (long long)O * P);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_edge_geo_forward(const float *Ysrc, const float *src, const int32_t *nebidx, const float *cent,
+                             int cent_stride, int B, int Nsrc, int Cs, int O, int P, int C0,
+                             const float *Wg, const float *b, float *att16, float *Gsum, double *gg,
+                             double *sums, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!Ysrc || !src || !nebidx || !cent || !b || !att16 || !Gsum || !gg || !sums || B < 1 || Nsrc < 1 ||
+        Cs < 3 || O < 1 || P < 1 || C0 < 1 || (long long)B * O * P >= (1ll << 31))
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_edge_geo_workspace(B, Nsrc, (long long)O * P)) return GRIDGCN_EWORKSPACE;
+    const int rc = gg_edge_geo_fwd(Ysrc, src, nebidx, cent, cent_stride, B, Nsrc, Cs, O, P, C0, Wg, b, att16,
+                                   Gsum, gg, sums, workspace, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_edge_lin0_backward(const float *Z0, const float *Ysrc, const float *Wg, const float *b,
                                const float *dY, const uint8_t *amax,
                                const float *gval, const float *scale, const float *shift,

@@ -42,4 +42,8 @@ int gg_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const 
                      const float *scale, const float *mean, const float *rstd, const float *m1,
                      const float *m2, int C, float *dW, int ld, hipStream_t st);
 int gg_edge_lin0_fwd(const GGEdgeLin0 &p, hipStream_t st);
+size_t gg_edge_geo_workspace(int B, int N, long long edges_per_cloud);
+int gg_edge_geo_fwd(const float *Ysrc, const float *src, const int *nebidx, const float *cent, int cent_stride,
+                    int B, int N, int Cs, int O, int P, int C, const float *Wg, const float *bias, float *att16,
+                    float *Gsum, double *gg, double *sums, void *workspace, hipStream_t st);
 int gg_edge_lin0_bwd(GGEdgeLin0Bwd p, void *workspace, hipStream_t st);   // workspace: gg_csr_workspace

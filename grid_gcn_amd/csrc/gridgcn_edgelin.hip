@@ -293,6 +293,252 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
 
 static int vpl_for(int C0) { return C0 <= 64 ? 1 : (C0 <= 128 ? 2 : 4); }
 
+// ------------------------------------------------------------------------------------------
+// Batch statistics of a single-layer point MLP WITHOUT the edge x channel pass.  z0[e, c] =
+// y[n(e), c] + w_c . g(e) (y = Ysrc + b per source point, g = geo_vec, w_c = the layer's three geo
+// weights) is affine in per-source and per-edge quantities, so with cnt(n) = #edges of source n,
+// G(n) = sum of their geo_vec and GG = sum_e g g^T
+//   sum_e z0   = sum_n cnt(n) y[n,c] + w_c . G(n)
+//   sum_e z0^2 = sum_n (cnt(n) y[n,c]^2 + 2 y[n,c] w_c . G(n)) + w_c^T GG w_c
+// -- 8 K source rows x C instead of 3.3 M edges x C at cfg4 up2 (gg_k_edge_lin0_fwd: 186 us, VALU bound
+// on 6 flops per edge and channel).  What is left per edge is what the attention branch needs anyway:
+//   gg_k_edge_geo_fwd    grid (nsplit, B): the att_vec row of every edge (as gg_k_edge_lin0_fwd writes
+//                        it) and, in LDS, cnt / G per source of the cloud -- 64-bit fixed-point integer
+//                        atomics exactly as the geo pass of gg_k_edge_lin0_bwd_sparse (scale from the
+//                        first round, fp32 global side path beyond the headroom or for an index clipped
+//                        into another cloud) -> gpart[B][nsplit][N+1][4]; GG and sum g by fp64 atomics
+//   gg_k_edge_geo_stats  per block of 32 source rows: Gsum[r] = (G, cnt) summed over the splits in a
+//                        fixed order, then the two sums above per channel (fp64 atomics into `sums`)
+struct GGEdgeGeoFwd {
+    const float *src;     // [B*N][Cs]
+    const int *nebidx;    // [B][O*P]
+    const float *cent;    // centre ci at cent + ci*cent_stride
+    float *att16;         // [E][16]
+    float *gpart;         // [B][nsplit][N+1][4]  (gx, gy, gz, count)
+    float *fgs;           // [B*N][4], zero-filled
+    double *gg;           // [12] += (sum g_j g_k [9], sum g_j [3]), zero-filled
+    int cent_stride, B, N, Cs, O, P, nsplit, epw;   // epw edges per workgroup (a multiple of 1024)
+};
+
+__global__ __launch_bounds__(1024, 8) void gg_k_edge_geo_fwd(GGEdgeGeoFwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[16][12];
+    __shared__ unsigned gmax;
+    const int N = p.N, O = p.O, P = p.P;
+    const int sp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    long long *gx = (long long *)lds, *gy = gx + (N + 1), *gz = gy + (N + 1);
+    int *gc = (int *)(gz + (N + 1));
+    const long long rows = (long long)p.B * N;
+    // the cloud's O*P edges in runs of epw per workgroup.  FOUR lanes per edge: lane q of the quad writes
+    // the q-th 16-byte piece of the edge's att_vec row (a wave's store is 1 KB of consecutive bytes; one
+    // lane per edge wrote four pieces 64 bytes apart, 256 L1 transactions per 64 edges instead of 64) and
+    // adds the q-th of (gx, gy, gz, count); the quad's loads hit the same addresses
+    const int ec = O * P;
+    const int ea = sp * p.epw < ec ? sp * p.epw : ec, ez = ea + p.epw < ec ? ea + p.epw : ec;
+    const int *nb = p.nebidx + (size_t)b * O * P;
+    float *ab = p.att16 + (size_t)b * O * P * 16;
+    const int q = tid & 3, et = tid >> 2;                          // 256 edges per round of the workgroup
+    for (int i = tid; i <= N; i += 1024) { gx[i] = 0; gy[i] = 0; gz[i] = 0; gc[i] = 0; }
+    if (tid == 0) gmax = 0u;
+    const bool v4 = (p.cent_stride & 3) == 0 && (p.Cs & 3) == 0 && (((size_t)p.cent | (size_t)p.src) & 15) == 0;
+    // one edge: source row (mx.sym.take clip mode, utils/ops.py:78-93), centre, geo_vec
+    auto edge = [&](int e, long long &flat, float4 &s4, float4 &c4) {
+        flat = (long long)nb[e] + (long long)b * N;
+        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
+        const float *srow = p.src + flat * p.Cs;
+        const float *cen = p.cent + ((size_t)b * O + e / P) * p.cent_stride;
+        if (v4) {
+            s4 = *(const float4 *)srow;
+            c4 = *(const float4 *)cen;
+        } else {
+            s4 = make_float4(srow[0], srow[1], srow[2], 0.f);
+            c4 = make_float4(cen[0], cen[1], cen[2], 0.f);
+        }
+    };
+    auto geo = [&](const float4 s4, const float4 c4) -> float4 {
+        const float x = s4.x - c4.x, y = s4.y - c4.y, z = s4.z - c4.z;
+        return make_float4(sqrtf((x * x + y * y) + z * z), x, y, z);
+    };
+    // scale of the three geo sums from the first round of edges (count: exact integers)
+    float gm = 0.f;
+    if (ea + et < ez) {
+        long long fl;
+        float4 s4, c4;
+        edge(ea + et, fl, s4, c4);
+        const float4 g = geo(s4, c4);
+        gm = fmaxf(fmaxf(fabsf(g.y), fabsf(g.z)), fabsf(g.w));
+        if (!(gm < 3.0e38f)) gm = 0.f;                            // (NaN / inf never set the scale)
+    }
+    __syncthreads();
+    atomicMax(&gmax, __float_as_uint(gm));
+    __syncthreads();
+    const int gk = gg_fix_exp(gmax);
+    const float gF = ldexpf(1.f, gk);
+    const float gthr = fminf(0x1p+47f, 0x1p+62f / ((float)p.epw + 1.f));
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};      // lane q < 3: sum g_q g_0, g_q g_1, g_q g_2, g_q
+    constexpr int UG = 4;
+    for (int e = ea + et; e < ez; e += 256 * UG) {
+        long long fl[UG];
+        float4 s4[UG], c4[UG];
+#pragma unroll
+        for (int u = 0; u < UG; u++) edge(e + 256 * u < ez ? e + 256 * u : e, fl[u], s4[u], c4[u]);
+#pragma unroll
+        for (int u = 0; u < UG; u++) {
+            if (e + 256 * u >= ez) break;
+            const float4 g = geo(s4[u], c4[u]);
+            const float4 piece = q == 0 ? g : (q == 1 ? make_float4(c4[u].x, c4[u].y, c4[u].z, s4[u].x)
+                                                      : (q == 2 ? make_float4(s4[u].y, s4[u].z, 0.f, 0.f)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f)));
+            *(float4 *)(ab + (size_t)(e + 256 * u) * 16 + 4 * q) = piece;
+            // key in [0, N] = destination row - (b*N - 1); a row of ANOTHER cloud (never produced by the
+            // index ops) goes to the global side buffer by its flat row
+            const long long li = fl[u] - ((long long)b * N - 1);
+            const int key = (li < 0 || li > N) ? -1 : (int)li;
+            const float x0 = g.y * gF, x1 = g.z * gF, x2 = g.w * gF;
+            const bool fits = fabsf(x0) < gthr && fabsf(x1) < gthr && fabsf(x2) < gthr;   // (false for NaN)
+            const float mine = q == 0 ? g.y : (q == 1 ? g.z : g.w);                       // (q < 3)
+            if (key >= 0 && fits) {
+                if (q == 3) atomicAdd(&gc[key], 1);
+                else
+                    atomicAdd((unsigned long long *)(q == 0 ? &gx[key] : (q == 1 ? &gy[key] : &gz[key])),
+                              (unsigned long long)gg_fix_i64(mine * gF));
+            } else {
+                atomicAdd(&p.fgs[fl[u] * 4 + q], q == 3 ? 1.f : mine);
+            }
+            if (q < 3) { g4[0] += mine * g.y; g4[1] += mine * g.z; g4[2] += mine * g.w; g4[3] += mine; }
+        }
+    }
+    __syncthreads();
+    float *gp_ = p.gpart + (((size_t)b * p.nsplit + sp) * (N + 1)) * 4;
+    const float gi = ldexpf(1.f, -gk);
+    for (int i = tid; i <= N; i += 1024)
+        ((float4 *)gp_)[i] = make_float4((float)gx[i] * gi, (float)gy[i] * gi, (float)gz[i] * gi, (float)gc[i]);
+    // GG / sum g: lanes of equal q -> waves -> one fp64 atomic per value and workgroup
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float v = q < 3 ? g4[i] : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o, 64);
+        // lane q of the wave now holds the sum over the wave's lanes == q (mod 4)
+        if ((tid & 63) < 3) red[tid >> 6][i < 3 ? 3 * (tid & 63) + i : 9 + (tid & 63)] = v;
+    }
+    __syncthreads();
+    if (tid < 12) {
+        float v = 0.f;
+        for (int w = 0; w < 16; w++) v += red[w][tid];
+        atomicAdd(&p.gg[tid], (double)v);
+    }
+}
+
+#define GG_GS_ROWS 32
+__global__ __launch_bounds__(256) void gg_k_edge_geo_stats(
+    const float *__restrict__ gpart, const float *__restrict__ fgs, const float *__restrict__ Ysrc,
+    const float *__restrict__ Wg, const float *__restrict__ bias, int B, int N, int C, int nsplit,
+    float *__restrict__ Gsum, const double *__restrict__ gg, double *__restrict__ sums)
+{
+    __shared__ float4 sg[GG_GS_ROWS], sp8[8][GG_GS_ROWS];
+    const long long rows = (long long)B * N;
+    const long long r0 = (long long)blockIdx.x * GG_GS_ROWS;
+    const int nr = rows - r0 < GG_GS_ROWS ? (int)(rows - r0) : GG_GS_ROWS;
+    {
+        // row r collects key n+1 of its own cloud and, for its last row, key 0 of the next (as
+        // gg_k_edge_lin0_bwd_finish); eight thread groups take every eighth split, added up in a fixed order
+        const int ri = threadIdx.x & (GG_GS_ROWS - 1), part = threadIdx.x / GG_GS_ROWS;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ri < nr) {
+            const long long r = r0 + ri;
+            const int b = (int)(r / N), n = (int)(r - (long long)b * N);
+            for (int sp = part; sp < nsplit; sp += 8) {
+                const float4 g = *(const float4 *)(gpart + (((size_t)b * nsplit + sp) * (N + 1) + (n + 1)) * 4);
+                a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+                if (n == N - 1 && b + 1 < B) {
+                    const float4 h = *(const float4 *)(gpart + ((size_t)(b + 1) * nsplit + sp) * (N + 1) * 4);
+                    a.x += h.x; a.y += h.y; a.z += h.z; a.w += h.w;
+                }
+            }
+        }
+        sp8[part][ri] = a;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nr) {
+        const long long r = r0 + threadIdx.x;
+        float4 a = *(const float4 *)(fgs + r * 4);
+        for (int k = 0; k < 8; k++) {
+            const float4 g = sp8[k][threadIdx.x];
+            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        }
+        sg[threadIdx.x] = a;
+        *(float4 *)(Gsum + r * 4) = a;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float w0 = Wg ? Wg[c] : 0.f, w1 = Wg ? Wg[C + c] : 0.f, w2 = Wg ? Wg[2 * C + c] : 0.f, bc = bias[c];
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < nr; i++) {
+            const float4 g = sg[i];
+            const float y = Ysrc[(r0 + i) * C + c] + bc;
+            const float gw = (g.x * w0 + g.y * w1) + g.z * w2;
+            s += g.w * y + gw;
+            q += (g.w * y) * y + 2.f * (y * gw);
+        }
+        double qd = (double)q;
+        if (blockIdx.x == 0) {
+            // w^T GG w: the edges' own quadratic term, once
+            const double W[3] = {(double)w0, (double)w1, (double)w2};
+            for (int j = 0; j < 3; j++)
+                for (int k = 0; k < 3; k++) qd += W[j] * W[k] * gg[3 * j + k];
+        }
+        atomicAdd(&sums[c], (double)s);
+        atomicAdd(&sums[C + c], qd);
+    }
+}
+
+// edges per workgroup: whole rounds of 4 x 256, at most two workgroups per CU over the batch
+static int gg_edge_geo_epw(int B, long long ec)
+{
+    long long want = (ec * B + 511) / 512;
+    want = (want + 1023) / 1024 * 1024;
+    return (int)(want < 1024 ? 1024 : want);
+}
+static int gg_edge_geo_nsplit(int B, long long ec)
+{
+    const int epw = gg_edge_geo_epw(B, ec);
+    return (int)((ec + epw - 1) / epw);
+}
+
+size_t gg_edge_geo_workspace(int B, int N, long long ec)
+{
+    return ((size_t)B * gg_edge_geo_nsplit(B, ec) * (N + 1) * 4 + (size_t)B * N * 4) * sizeof(float);
+}
+
+// 1 = shape not supported (the caller uses gg_edge_lin0_fwd).  gg[12], sums[2C] zero-filled by the caller.
+int gg_edge_geo_fwd(const float *Ysrc, const float *src, const int *nebidx, const float *cent, int cent_stride,
+                    int B, int N, int Cs, int O, int P, int C, const float *Wg, const float *bias, float *att16,
+                    float *Gsum, double *gg, double *sums, void *workspace, hipStream_t st)
+{
+    const size_t lds = (size_t)(N + 1) * 28;
+    if (lds > 150 * 1024 || C < 1 || C > 1024 || (long long)B * O * P >= (1ll << 31)) return 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gg_k_edge_geo_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) return 3;
+        attr_done = true;
+    }
+    GGEdgeGeoFwd p;
+    p.src = src; p.nebidx = nebidx; p.cent = cent; p.att16 = att16; p.gg = gg;
+    p.cent_stride = cent_stride; p.B = B; p.N = N; p.Cs = Cs; p.O = O; p.P = P;
+    p.epw = gg_edge_geo_epw(B, (long long)O * P);
+    p.nsplit = gg_edge_geo_nsplit(B, (long long)O * P);
+    p.gpart = (float *)workspace;
+    p.fgs = p.gpart + (size_t)B * p.nsplit * (N + 1) * 4;
+    if (hipMemsetAsync(p.fgs, 0, (size_t)B * N * 4 * sizeof(float), st) != hipSuccess) return 3;
+    gg_k_edge_geo_fwd<<<dim3(p.nsplit, B), 1024, lds, st>>>(p);
+    const long long rows = (long long)B * N;
+    gg_k_edge_geo_stats<<<(int)((rows + GG_GS_ROWS - 1) / GG_GS_ROWS), 256, 0, st>>>(
+        p.gpart, p.fgs, Ysrc, Wg, bias, B, N, C, p.nsplit, Gsum, gg, sums);
+    return hipGetLastError() == hipSuccess ? 0 : 3;
+}
+
 int gg_edge_lin0_fwd(const GGEdgeLin0 &p, hipStream_t st)
 {
     if (p.C0 < 1 || p.C0 > 256 || p.E < 1) return 1;

@@ -12,14 +12,29 @@
 //   gg_k_colsum   column sums of a [E, ld] tensor (bias gradient of the last linear layer)
 #include <hip/hip_runtime.h>
 
-// Sums that every workgroup of a launch adds to: atomics on ONE address are served one after the other at
-// ~45 ns each (512 workgroups: 23 us, as long as these kernels' reads), so the `slotted` entries spread
-// them over 16 slots on cache lines of their own and a tiny second launch adds the slots up -- which also
-// forms what the framework formed with 1-3 ops of its own (loss = sum / max(count, 1); the fp32 bias
-// gradient).  (A last-arriver ticket instead of the second launch was tried: the agent-scope release /
-// acquire it needs is an L2 write-back + invalidate per workgroup on this 8-XCD part, 22 -> 45 us.)
+// Sums that every workgroup of a launch adds to: atomics on ONE address are served one after the other
+// (512 workgroups: ~20 us, as long as these kernels' reads), so the `slotted` entries spread them over 16
+// slots on cache lines of their own, and the last workgroup to arrive adds the slots up and forms what the
+// framework formed with 1-3 ops of its own (loss = sum / max(count, 1); the fp32 bias gradient).
+// Hand-off per MI355X_MICROARCH "inter-workgroup visibility", the {8-byte agent atomics on both sides}
+// form: the partial sums ARE agent-scope atomics, the arriving lane drains them (s_waitcnt vmcnt(0)) before
+// its relaxed ticket, the last arriver reads them back with agent-scope atomic loads.  (With
+// __threadfence() instead -- an L2 write-back + invalidate per workgroup on this 8-XCD part -- the two
+// kernels went 22 -> 45 us.)  Two ticket levels: 16 counters on lines of their own, then one.
+// tk: 17 lines of 16 doubles, zero at launch.
 #define GG_SLOTS 16
 __device__ __forceinline__ int gg_slot() { return (int)(blockIdx.x % GG_SLOTS); }
+__device__ __forceinline__ bool gg_last_arriver(double *tk)
+{
+    const int S = (int)gridDim.x < GG_SLOTS ? (int)gridDim.x : GG_SLOTS;
+    const int s = gg_slot();
+    const int members = ((int)gridDim.x - s + GG_SLOTS - 1) / GG_SLOTS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__hip_atomic_fetch_add((int *)(tk + 16 * s), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1)
+        return false;
+    return __hip_atomic_fetch_add((int *)(tk + 16 * GG_SLOTS), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+           S - 1;
+}
 
 template <int NV>
 __device__ __forceinline__ void gg_row_load(const float *__restrict__ p, float (&v)[4 * NV])
@@ -79,16 +94,17 @@ __global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ log
         atomicAdd(&acc[t + (loss_out ? 16 * gg_slot() : 0)],
                   (double)((red[t][0] + red[t][1]) + (red[t][2] + red[t][3])));
     }
-}
-
-// acc: [16 slots x 16] partial (sum, count) -> acc[256] = sum, acc[257] = count, loss = sum / max(count, 1)
-__global__ void gg_k_ce_finish(double *__restrict__ acc, float *__restrict__ loss_out)
-{
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < GG_SLOTS; k++) { s0 += acc[16 * k]; s1 += acc[16 * k + 1]; }
-    acc[16 * GG_SLOTS] = s0;
-    acc[16 * GG_SLOTS + 1] = s1;
-    loss_out[0] = (float)(s0 / (s1 > 1.0 ? s1 : 1.0));
+    if (loss_out && threadIdx.x == 0 && gg_last_arriver(acc + 16 * GG_SLOTS + 16)) {
+        // acc: [16 slots x 16] partial (sum, count) | [256] sum, [257] count | tickets
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < GG_SLOTS; k++) {
+            s0 += __hip_atomic_load(&acc[16 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(&acc[16 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        acc[16 * GG_SLOTS] = s0;          // (read by the NEXT launches: gridgcn_softmax_ce_bwd)
+        acc[16 * GG_SLOTS + 1] = s1;
+        loss_out[0] = (float)(s0 / (s1 > 1.0 ? s1 : 1.0));
+    }
 }
 
 template <int NV>
@@ -138,6 +154,7 @@ __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, 
                                                    float *__restrict__ out32)
 {
     __shared__ float red[4][4 * NV];
+    __shared__ int s_last;
     float a[4 * NV];
 #pragma unroll
     for (int c = 0; c < 4 * NV; c++) a[c] = 0.f;
@@ -159,15 +176,18 @@ __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, 
     if (threadIdx.x < ncols)
         atomicAdd(&out[threadIdx.x + (out32 ? 32 * gg_slot() : 0)],
                   (double)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])));
-}
-
-// out: [16 slots x 32] partial sums -> fp32 totals
-__global__ void gg_k_colsum_finish(const double *__restrict__ out, int ncols, float *__restrict__ out32)
-{
-    if ((int)threadIdx.x >= ncols) return;
-    double a = 0.0;
-    for (int k = 0; k < GG_SLOTS; k++) a += out[32 * k + threadIdx.x];
-    out32[threadIdx.x] = (float)a;
+    if (out32) {
+        // out: [16 slots x 32] partial sums | tickets; the fp32 totals by the last workgroup to arrive
+        // (ncols <= 32: the atomics above were all issued by wave 0, which drains them before its ticket)
+        if (threadIdx.x == 0) s_last = gg_last_arriver(out + 32 * GG_SLOTS);
+        __syncthreads();
+        if (s_last && threadIdx.x < ncols) {
+            double a = 0.0;
+            for (int k = 0; k < GG_SLOTS; k++)
+                a += __hip_atomic_load(&out[32 * k + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out32[threadIdx.x] = (float)a;
+        }
+    }
 }
 
 // logits rows of ld floats (ld in {4,8,...,32}), ncls <= ld
@@ -183,7 +203,6 @@ int gg_ce_fwd(const float *logits, int ld, int ncls, const long long *label, lon
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }
-    if (loss) gg_k_ce_finish<<<1, 1, 0, st>>>(acc, loss);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -211,6 +230,5 @@ int gg_colsum(const float *X, long long E, int ld, int ncols, double *out, float
     GG_CASE(1) GG_CASE(2) GG_CASE(3) GG_CASE(4) GG_CASE(5) GG_CASE(6) GG_CASE(7) GG_CASE(8)
 #undef GG_CASE
     }
-    if (out32) gg_k_colsum_finish<<<1, 32, 0, st>>>(out, ncols, out32);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }

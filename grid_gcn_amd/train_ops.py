@@ -679,6 +679,9 @@ class _ZeroArena:
 ZERO_ARENA = True
 # the optimizer of bench.py / the tests' training loops: grid_gcn_amd.optim.Adam (one launch)
 OWN_ADAM = True
+# BatchNorm statistics of a single-layer point MLP from per-source counts and geo_vec sums
+SRC_STATS = True
+SRC_STATS_MIN_EDGES = 1 << 19     # (below: the edge pass is a 10-20 us launch, these are two)
 # geo_vec weight + bias table of the source-side first conv built by the prepack launch
 WGB_PREPACK = True
 # concat + centre mask + zero padding of a layer boundary in one launch (model.GGCNSeg.forward)
@@ -1380,10 +1383,23 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             Z0 = None if noz else torch.empty((E, C0), dtype=torch.float32, device=dev)
             att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
             sums0 = _zeros(2 * C0, torch.float64, dev)
-            rc = lib.gridgcn_edge_lin0_forward(
-                _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P,
-                C0, _ptr(Wg) if geo else None, _ptr(wgb[3]), None if noz else _ptr(Z0),
-                _ptr(att16), _ptr(sums0), st)
+            if noz and SRC_STATS and (Nsrc + 1) * 28 <= 150 * 1024 and C0 <= 1024 and E >= SRC_STATS_MIN_EDGES:
+                # statistics of the never-stored Z0 from per-source counts and geo_vec sums: no edge x
+                # channel pass (csrc/gridgcn_edgelin.hip, gg_k_edge_geo_fwd)
+                nbytes = ctypes.c_size_t(0)
+                lib.gridgcn_edge_geo_forward_workspace_bytes(B, Nsrc, O, P, ctypes.byref(nbytes))
+                ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                gsum = torch.empty((R, 4), dtype=torch.float32, device=dev)
+                gg = _zeros(12, torch.float64, dev)
+                rc = lib.gridgcn_edge_geo_forward(
+                    _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P,
+                    C0, _ptr(Wg) if geo else None, _ptr(wgb[3]), _ptr(att16), _ptr(gsum), _ptr(gg),
+                    _ptr(sums0), _ptr(ws), nbytes.value, st)
+            else:
+                rc = lib.gridgcn_edge_lin0_forward(
+                    _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P,
+                    C0, _ptr(Wg) if geo else None, _ptr(wgb[3]), None if noz else _ptr(Z0),
+                    _ptr(att16), _ptr(sums0), st)
             _lib.check(rc, "gridgcn_edge_lin0_forward")
             vec0 = torch.empty((4, C0), dtype=torch.float32, device=dev)
             bn = bns_p[0]
@@ -2168,7 +2184,7 @@ class _LinearPlain(torch.autograd.Function):
                 _ptr(Wdx) if ndx else None, ndx, E, Cp, cin, cin, 0, 0,
                 _ptr(dX) if ndx else None, _ptr(dW), None, None, None, 0, _ptr(ws), nbytes.value, st)
             _lib.check(rc, "gridgcn_linear_bwd")
-            db64 = _zeros(512, torch.float64, dev)              # (16 slots of partial sums)
+            db64 = _zeros(784, torch.float64, dev)              # (16 slots of partial sums | tickets)
             db = torch.empty(C, dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_colsum_f32(_ptr(dL), E, Cp, C, _ptr(db64), _ptr(db), st), "gridgcn_colsum")
         return dX, dW[:C], db
@@ -2276,7 +2292,7 @@ class _HeadTrain(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream(x)
             dH = torch.empty((E, C), dtype=torch.float32, device=dev)
-            acc = _zeros(2 * C + 512, torch.float64, dev)       # (db64: 16 slots of partial sums)
+            acc = _zeros(2 * C + 784, torch.float64, dev)       # (db64: 16 slots of partial sums | tickets)
             sums, db64 = acc[:2 * C], acc[2 * C:]
             db2 = torch.empty(C2, dtype=torch.float32, device=dev)
             # gradient w.r.t. relu(bn(Z_fc1)) (dropout mask applied) + fc1's BatchNorm-backward sums
@@ -2359,7 +2375,7 @@ class _SoftmaxCE(torch.autograd.Function):
             logits = buf[:, :C]
         label = label.contiguous()
         lse = torch.empty(E, dtype=torch.float32, device=dev)
-        acc = _zeros(272, torch.float64, dev)           # 16 slots of partial sums | total, count at [256:258]
+        acc = _zeros(544, torch.float64, dev)           # 16 slots | total, count at [256:258] | tickets
         loss = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.gridgcn_softmax_ce_loss(_ptr(logits), ld, C, _ptr(label), E, ignore,
@@ -2370,7 +2386,7 @@ class _SoftmaxCE(torch.autograd.Function):
         ctx.cw = cw
         # SoftmaxOutput(normalization='valid'): the valid count is clamped to >= 1, so a batch
         # whose labels are all ignore_label gives loss 0 and gradient 0 instead of 0/0
-        # (formed by the entry's second launch)
+        # (formed by the kernel's last workgroup)
         return loss
 
     @staticmethod

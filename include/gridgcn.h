@@ -72,7 +72,7 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4
                                  * 6: gridgcn_pack_desc.wgb / geo, gridgcn_adam_step, gridgcn_cat_mask,
                                  *    gridgcn_mask_sum, gridgcn_ball_knn[_grid]_ld, gridgcn_bn_finalize_tail,
-                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32; psums of a dX launch with
+                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward; psums of a dX launch with
                                  *    nbn > 0 is [2][nbn] */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
@@ -281,6 +281,19 @@ int gridgcn_edge_lin0_forward(const float *Ysrc, const float *src, const int32_t
                               const float *cent, int cent_stride, int B, int Nsrc, int Cs, int O,
                               int P, int C0, const float *Wg, const float *b, float *Z0,
                               float *att16, double *sums, void *stream);
+/* gridgcn_edge_geo_forward: att16 and the BatchNorm statistics of a single-layer point MLP (Z0 never
+ *   stored) WITHOUT the edge x channel pass: z0[e,c] = (Ysrc[n(e),c] + b[c]) + Wg[:,c] . geo(e) is affine
+ *   in per-source and per-edge quantities, so sum z0 and sum z0^2 follow from cnt(n) = #edges of source
+ *   n, G(n) = sum of their geo_vec and GG = sum_e geo geo^T (csrc/gridgcn_edgelin.hip) -- 8 K source
+ *   rows x C0 instead of 3.3 M edges x C0 at BASELINE configs[3]'s last up layer.
+ *   out: att16[E][16] as gridgcn_edge_lin0_forward; Gsum[B*Nsrc][4] = (G, cnt) per source row;
+ *   gg[12] += (GG[9], sum geo[3]) and sums[2*C0] += (sum z0, sum z0^2), both fp64, zeroed by the caller.
+ *   (Nsrc + 1) * 28 bytes of LDS per cloud: GRIDGCN_EINVAL beyond 150 KB (use gridgcn_edge_lin0_forward). */
+int gridgcn_edge_geo_forward_workspace_bytes(int B, int Nsrc, int O, int P, size_t *bytes);
+int gridgcn_edge_geo_forward(const float *Ysrc, const float *src, const int32_t *nebidx, const float *cent,
+                             int cent_stride, int B, int Nsrc, int Cs, int O, int P, int C0,
+                             const float *Wg, const float *b, float *att16, float *Gsum, double *gg,
+                             double *sums, void *workspace, size_t workspace_bytes, void *stream);
 /* Z0 may be NULL in both calls: the forward then only produces the statistics and att16, and the
  * consumers (gridgcn_pairmax_fwd_src, the backward) recompute Z0 from (Ysrc, Wg, b) with the same
  * operation order, i.e. bit-identical -- the [E, C0] tensor never exists (single-layer point MLPs). */
@@ -642,11 +655,11 @@ int gridgcn_softmax_ce_bwd(const float *logits, int ld, int ncls, const int64_t 
  * multiplied by max_c [dlogits_c < 0] * class_weight_c, i.e. by the weight of the row's label. */
 int gridgcn_colsum(const float *X, long long E, int ld, int ncols, double *out, void *stream);
 /* gridgcn_softmax_ce_loss: gridgcn_softmax_ce_fwd with the two sums spread over 16 slots (atomics on ONE
- *   address serialise at ~45 ns per workgroup) and a one-thread second launch that adds the slots up and
- *   writes loss[0] = sum / max(count, 1).  acc = fp64[272], zeroed by the caller, 128-byte aligned:
- *   16 slots x 16, then acc[256] = sum, acc[257] = count (pass acc + 256 to gridgcn_softmax_ce_bwd).
- * gridgcn_colsum_f32: gridgcn_colsum likewise, out[c] = (float) total; acc fp64[512], zeroed, 128-byte
- *   aligned (16 slots x 32 partial sums). */
+ *   address are served one after the other) and loss[0] = sum / max(count, 1) written by the last
+ *   workgroup to arrive.  acc = fp64[544], zeroed by the caller, 128-byte aligned: 16 slots x 16, then
+ *   acc[256] = sum, acc[257] = count (pass acc + 256 to gridgcn_softmax_ce_bwd), then 17 ticket lines.
+ * gridgcn_colsum_f32: gridgcn_colsum likewise, out[c] = (float) total; acc fp64[784], zeroed, 128-byte
+ *   aligned (16 slots x 32 partial sums, then 17 ticket lines). */
 int gridgcn_softmax_ce_loss(const float *logits, int ld, int ncls, const int64_t *label, long long E,
                             int ignore_label, float *lse, double *acc3, float *loss, void *stream);
 int gridgcn_colsum_f32(const float *X, long long E, int ld, int ncols, double *acc, float *out,

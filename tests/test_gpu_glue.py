@@ -148,3 +148,54 @@ def test_ball_knn_reads_wider_rows_in_place():
     assert torch.equal(i1, i2)
     assert int(i2[1, n - 50:].abs().max()) == 0
     assert int((i1 >= 0).sum()) > 0
+
+
+@pytest.mark.parametrize("B,N,O,P,C0,geo", [(2, 24, 256, 8, 64, True), (3, 1024, 3000, 5, 128, True),
+                                            (1, 300, 77, 5, 32, False), (2, 5000, 600, 3, 16, True),
+                                            (2, 1024, 40000, 5, 128, True)])
+def test_edge_geo_forward_statistics_match_the_edge_pass(B, N, O, P, C0, geo):
+    """BatchNorm sums of the source-side first conv from per-source counts / geo_vec sums
+    (gridgcn_edge_geo_forward) against the pass over every (edge, channel) (gridgcn_edge_lin0_forward);
+    att16 bit for bit, Gsum against a float64 scatter."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(B * 1000 + N)
+    Cs = 4 + 8
+    src = torch.rand(B, N, Cs, device=DEV)
+    cent = torch.rand(B, O, 4, device=DEV)
+    idx = torch.randint(-1, N, (B, O, P), device=DEV, dtype=torch.int32)     # (-1: "no neighbour", clipped)
+    Ysrc = torch.randn(B * N, C0, device=DEV)
+    Wg = torch.randn(3, C0, device=DEV)
+    b = torch.randn(C0, device=DEV)
+    E = B * O * P
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr())                               # noqa: E731
+    att_a = torch.empty(E, 16, device=DEV)
+    sums_a = torch.zeros(2 * C0, dtype=torch.float64, device=DEV)
+    rc = lib.gridgcn_edge_lin0_forward(p(Ysrc), p(src), p(idx), p(cent), 4, B, N, Cs, O, P, C0,
+                                       p(Wg) if geo else None, p(b), None, p(att_a), p(sums_a), st)
+    assert rc == 0
+    att_b = torch.empty(E, 16, device=DEV)
+    sums_b = torch.zeros(2 * C0, dtype=torch.float64, device=DEV)
+    gg = torch.zeros(12, dtype=torch.float64, device=DEV)
+    gsum = torch.empty(B * N, 4, device=DEV)
+    nb = ctypes.c_size_t(0)
+    assert lib.gridgcn_edge_geo_forward_workspace_bytes(B, N, O, P, ctypes.byref(nb)) == 0
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=DEV)
+    rc = lib.gridgcn_edge_geo_forward(p(Ysrc), p(src), p(idx), p(cent), 4, B, N, Cs, O, P, C0,
+                                      p(Wg) if geo else None, p(b), p(att_b), p(gsum), p(gg), p(sums_b),
+                                      p(ws), nb.value, st)
+    assert rc == 0
+    assert torch.equal(att_a, att_b)
+    # per-source (G, cnt) against a float64 scatter of the geo vectors
+    flat = (idx.long() + torch.arange(B, device=DEV)[:, None, None] * N).clamp(0, B * N - 1).reshape(-1)
+    ref = torch.zeros(B * N, 4, dtype=torch.float64, device=DEV)
+    g4 = torch.cat([att_a[:, 1:4].double(), torch.ones(E, 1, dtype=torch.float64, device=DEV)], dim=1)
+    ref.index_add_(0, flat, g4)
+    assert float((gsum.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    n = float(E)
+    mean_a, mean_b = sums_a[:C0] / n, sums_b[:C0] / n
+    var_a, var_b = sums_a[C0:] / n - mean_a ** 2, sums_b[C0:] / n - mean_b ** 2
+    assert float((mean_a - mean_b).abs().max()) <= 2e-6 * max(1.0, float(mean_a.abs().max()))
+    assert float((var_a - var_b).abs().max()) <= 5e-6 * float(var_a.abs().max())
