@@ -49,6 +49,7 @@ EXPORTS = [
     "gridgcn_ball_knn_grid_ld", "gridgcn_ball_knn_ld", "gridgcn_bn_finalize_tail", "gridgcn_softmax_ce_loss", "gridgcn_colsum_f32",
     "gridgcn_cat_mask", "gridgcn_mask_sum", "gridgcn_adam_step",
     "gridgcn_edge_geo_forward_workspace_bytes", "gridgcn_edge_geo_forward",
+    "gridgcn_edge_lin0_backward_sparse_geo",
 ]
 
 
@@ -254,6 +255,8 @@ def load():
     lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes.argtypes = [ci, ci, ci, ctypes.POINTER(cs)]
     lib.gridgcn_edge_lin0_backward_sparse.restype = ci
     lib.gridgcn_edge_lin0_backward_sparse.argtypes = [vp] * 14 + [ci] * 5 + [vp] * 5 + [cs, vp]
+    lib.gridgcn_edge_lin0_backward_sparse_geo.restype = ci
+    lib.gridgcn_edge_lin0_backward_sparse_geo.argtypes = [vp] * 14 + [ci] * 5 + [vp] * 4 + [cs, vp]
     lib.gridgcn_att_max_eval.restype = ci
     lib.gridgcn_att_max_eval.argtypes = [vp] * 14 + [ci] * 5 + [vp, ci, vp]
     lib.gridgcn_edge_lin0_dwg.restype = ci

@@ -1012,6 +1012,27 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_edge_lin0_backward_sparse_geo(const int32_t *nebidx, const float *att16,
+                                          const uint8_t *amax, const float *gval, const float *zsel,
+                                          const float *Ysrc, const float *Wg, const float *b,
+                                          const float *scale, const float *shift, const float *mean,
+                                          const float *rstd, const float *m1, const float *m2, int B,
+                                          int Nsrc, int O, int P, int C0, float *dYsrc,
+                                          const float *Gsum, double *wgs, void *workspace,
+                                          size_t workspace_bytes, void *stream)
+{
+    if (!nebidx || !att16 || !amax || !gval || !zsel || (!Ysrc && !Wg) || !b || !scale || !shift ||
+        !mean || !rstd || !m1 || !m2 || !dYsrc || !Gsum || !wgs || B < 1 || Nsrc < 1 ||
+        O < 1 || P < 1 || P > 256 || C0 < 1)
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_edge_lin0_sparse_workspace(B, Nsrc, C0))
+        return GRIDGCN_EWORKSPACE;
+    const int rc = gg_edge_lin0_bwd_sparse(nebidx, att16, amax, gval, zsel, Ysrc, Wg, b, scale,
+                                           shift, mean, rstd, m1, m2, B, Nsrc, O, P, C0, dYsrc,
+                                           (float *)Gsum, wgs, nullptr, workspace, (hipStream_t)stream, 1);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
                           const float *scale, const float *mean, const float *rstd,
                           const float *m1, const float *m2, int C0, float *dW, int ld,

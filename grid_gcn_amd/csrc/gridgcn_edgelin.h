@@ -37,7 +37,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
                             const float *shift, const float *mean, const float *rstd,
                             const float *m1, const float *m2, int B, int N, int O, int P, int C,
                             float *dYsrc, float *Gsum, double *wgs, double *gg, void *workspace,
-                            hipStream_t st);
+                            hipStream_t st, int geo_given = 0);
 int gg_edge_lin0_dwg(const double *wgs, const double *gg, const float *T, const float *wgb,
                      const float *scale, const float *mean, const float *rstd, const float *m1,
                      const float *m2, int C, float *dW, int ld, hipStream_t st);

@@ -611,6 +611,7 @@ struct GGEdgeSparse {
     double *wgs;             // [3][C] += sum_(o,c) geo_j(e*) s[o,c]
     double *gg;              // [12] += (sum geo_j geo_k [9], sum geo_j [3])
     int B, N, O, P, C, nsplit;
+    int geo_given;           // the forward left (G, cnt) per source and gg (gg_k_edge_geo_fwd): no geo pass here
 };
 
 __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p)
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(1024) void gg_k_edge_lin0_bwd_sparse(GGEdgeSparse p
     long long *acc = (long long *)lds;         // [(N+1)][16]
     // the geo pass has workgroups of its own (the last y row of the grid, no channels): short ones
     // that fill gaps, instead of a tail on every eighth workgroup of the channel slices
-    const bool geo_wg = sl == (int)gridDim.y - 1;
+    const bool geo_wg = !p.geo_given && sl == (int)gridDim.y - 1;
     long long *gx = (long long *)lds, *gy = gx + (N + 1), *gz = gy + (N + 1);   // [(N+1)] each: one
     int *gc = (int *)(gz + (N + 1));           // array per component (bank = key, not 4 keys per bank row)
     const long long rows = (long long)p.B * N;
@@ -824,7 +825,8 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd_finish(
     const float *__restrict__ Wg, const float *__restrict__ bias, const float *__restrict__ scale,
     const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ m1,
     const float *__restrict__ m2, int B, int N, int C, int nsplit, float *__restrict__ dYsrc,
-    float *__restrict__ Gsum, const float *__restrict__ fpart, const float *__restrict__ fgs)
+    float *__restrict__ Gsum, const float *__restrict__ fpart, const float *__restrict__ fgs,
+    const float *__restrict__ Gin)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)B * N * C) return;
@@ -832,18 +834,23 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd_finish(
     const int c = (int)(t - r * C);
     const int b = (int)(r / N), n = (int)(r - (long long)b * N);
     // destination row r collects key n+1 of its own cloud and, for its last row, key 0 of the next
-    const float4 f4 = *(const float4 *)(fgs + r * 4);
+    // (Gin: the per-source geo sums are the forward's)
+    const float4 f4 = *(const float4 *)((Gin ? Gin : fgs) + r * 4);
     float s = fpart[t], g0 = f4.x, g1 = f4.y, g2 = f4.z, cnt = f4.w;
     for (int sp = 0; sp < nsplit; sp++) {
         const size_t base = ((size_t)b * nsplit + sp) * (N + 1) + (n + 1);
         s += part[base * C + c];
-        const float4 g = *(const float4 *)(gpart + base * 4);
-        g0 += g.x; g1 += g.y; g2 += g.z; cnt += g.w;
+        if (!Gin) {
+            const float4 g = *(const float4 *)(gpart + base * 4);
+            g0 += g.x; g1 += g.y; g2 += g.z; cnt += g.w;
+        }
         if (n == N - 1 && b + 1 < B) {
             const size_t nb_ = ((size_t)(b + 1) * nsplit + sp) * (N + 1);
             s += part[nb_ * C + c];
-            const float4 h = *(const float4 *)(gpart + nb_ * 4);
-            g0 += h.x; g1 += h.y; g2 += h.z; cnt += h.w;
+            if (!Gin) {
+                const float4 h = *(const float4 *)(gpart + nb_ * 4);
+                g0 += h.x; g1 += h.y; g2 += h.z; cnt += h.w;
+            }
         }
     }
     const float sc = scale[c];
@@ -851,7 +858,7 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd_finish(
     float lin = cnt * ((Ysrc ? Ysrc[r * C + c] : 0.f) + bias[c]);
     if (Wg) lin += g0 * Wg[c] + g1 * Wg[C + c] + g2 * Wg[2 * C + c];
     dYsrc[t] = s + (bz * lin + cnt * (cz - mean[c] * bz));
-    if (c == 0) *(float4 *)(Gsum + r * 4) = make_float4(g0, g1, g2, cnt);
+    if (c == 0 && !Gin) *(float4 *)(Gsum + r * 4) = make_float4(g0, g1, g2, cnt);
 }
 
 int gg_edge_lin0_sparse_nsplit(int B, int C);
@@ -875,7 +882,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
                             const float *shift, const float *mean, const float *rstd,
                             const float *m1, const float *m2, int B, int N, int O, int P, int C,
                             float *dYsrc, float *Gsum, double *wgs, double *gg, void *workspace,
-                            hipStream_t st)
+                            hipStream_t st, int geo_given)
 {
     size_t lds = (size_t)(N + 1) * 16 * 8;          // acc[(N+1)][16] int64 (the geo sums alias its start)
     if (lds > 150 * 1024 || C < 1 || (C & 3) || (long long)B * O * P >= (1ll << 31)) return 1;
@@ -894,13 +901,13 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
     p.gpart = p.part + (size_t)B * p.nsplit * (N + 1) * C;
     p.fpart = p.gpart + (size_t)B * p.nsplit * (N + 1) * 4;
     p.fgs = p.fpart + (size_t)B * N * C;
-    p.wgs = wgs; p.gg = gg;
+    p.wgs = wgs; p.gg = gg; p.geo_given = geo_given;
     if (hipMemsetAsync(p.fpart, 0, (size_t)B * N * (C + 4) * sizeof(float), st) != hipSuccess) return 3;
-    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 15) / 16 + 1, B), 1024, lds, st>>>(p);
+    gg_k_edge_lin0_bwd_sparse<<<dim3(p.nsplit, (C + 15) / 16 + (geo_given ? 0 : 1), B), 1024, lds, st>>>(p);
     const long long tot = (long long)B * N * C;
     gg_k_edge_lin0_bwd_finish<<<(int)((tot + 255) / 256), 256, 0, st>>>(
         p.part, p.gpart, Ysrc, Wg, bias, scale, mean, rstd, m1, m2, B, N, C, p.nsplit, dYsrc, Gsum,
-        p.fpart, p.fgs);
+        p.fpart, p.fgs, geo_given ? Gsum : nullptr);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -1383,6 +1383,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             Z0 = None if noz else torch.empty((E, C0), dtype=torch.float32, device=dev)
             att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
             sums0 = _zeros(2 * C0, torch.float64, dev)
+            gsum = gg = None
             if noz and SRC_STATS and (Nsrc + 1) * 28 <= 150 * 1024 and C0 <= 1024 and E >= SRC_STATS_MIN_EDGES:
                 # statistics of the never-stored Z0 from per-source counts and geo_vec sums: no edge x
                 # channel pass (csrc/gridgcn_edgelin.hip, gg_k_edge_geo_fwd)
@@ -1454,6 +1455,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.nz = nz
+        ctx.geo = gsum is not None      # (per-source geo sums of the forward: the backward's geo pass is skipped)
         saZ = list(sa.Z)
         if nz:
             saZ[-1] = torch.empty(0, dtype=torch.float32, device=dev)     # Z2: read by nobody any more
@@ -1461,7 +1463,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             src, nebidx, att16, amax, Ysrc if noz else Z0, vec0, W0, zsel, wgb,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
             *saZ, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx,
-            *((pa[4], pa[5]) if nz else ()))
+            *((pa[4], pa[5]) if nz else ()), *((gsum, gg) if gsum is not None else ()))
         ctx.mark_non_differentiable(amax)
         return agg if out is not None else agg.reshape(B, O, C)
 
@@ -1482,6 +1484,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         o += 8 * La
         nz = ctx.nz
         W2, b2 = (t[o], t[o + 1]) if nz else (None, None)
+        o += 2 if nz else 0
+        gsum_f, gg_f = (t[o], t[o + 1]) if ctx.geo else (None, None)
         dev = src.device
         E, R, Cf, ncent = B * O * P, B * Nsrc, Cs - 4, B * O
         Zl = pZ[-1] if L1 else Z0
@@ -1536,18 +1540,26 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 # single-layer point MLP: only the arg-max entries are scattered; the dense
                 # BatchNorm terms collapse onto per-source counts and geo_vec sums
                 dYsrc = torch.empty((R, C0), dtype=torch.float32, device=dev)
-                Gsum = torch.empty((R, 4), dtype=torch.float32, device=dev)
                 acc64 = _zeros(3 * C0 + 12, torch.float64, dev)
                 wgs, gg = acc64[:3 * C0].view(3, C0), acc64[3 * C0:]
                 nbytes = ctypes.c_size_t(0)
                 lib.gridgcn_edge_lin0_backward_sparse_workspace_bytes(B, Nsrc, C0,
                                                                       ctypes.byref(nbytes))
                 ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-                rc = lib.gridgcn_edge_lin0_backward_sparse(
-                    _ptr(nebidx), _ptr(att16), _ptr(amax), _ptr(gp), _ptr(zsel[0]), _ptr(Ysrc),
-                    _ptr(wgb) if rot else None, _ptr(wgb[3]), _ptr(vec0[0]), _ptr(vec0[1]),
-                    _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), B, Nsrc, O, P, C0,
-                    _ptr(dYsrc), _ptr(Gsum), _ptr(wgs), _ptr(gg), _ptr(ws), nbytes.value, st)
+                if gsum_f is not None:
+                    Gsum, gg = gsum_f, gg_f
+                    rc = lib.gridgcn_edge_lin0_backward_sparse_geo(
+                        _ptr(nebidx), _ptr(att16), _ptr(amax), _ptr(gp), _ptr(zsel[0]), _ptr(Ysrc),
+                        _ptr(wgb) if rot else None, _ptr(wgb[3]), _ptr(vec0[0]), _ptr(vec0[1]),
+                        _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), B, Nsrc, O, P, C0,
+                        _ptr(dYsrc), _ptr(Gsum), _ptr(wgs), _ptr(ws), nbytes.value, st)
+                else:
+                    Gsum = torch.empty((R, 4), dtype=torch.float32, device=dev)
+                    rc = lib.gridgcn_edge_lin0_backward_sparse(
+                        _ptr(nebidx), _ptr(att16), _ptr(amax), _ptr(gp), _ptr(zsel[0]), _ptr(Ysrc),
+                        _ptr(wgb) if rot else None, _ptr(wgb[3]), _ptr(vec0[0]), _ptr(vec0[1]),
+                        _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), B, Nsrc, O, P, C0,
+                        _ptr(dYsrc), _ptr(Gsum), _ptr(wgs), _ptr(gg), _ptr(ws), nbytes.value, st)
                 _lib.check(rc, "gridgcn_edge_lin0_backward_sparse")
                 dWg = None
                 if rot:

@@ -72,7 +72,7 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4
                                  * 6: gridgcn_pack_desc.wgb / geo, gridgcn_adam_step, gridgcn_cat_mask,
                                  *    gridgcn_mask_sum, gridgcn_ball_knn[_grid]_ld, gridgcn_bn_finalize_tail,
-                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward; psums of a dX launch with
+                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward, gridgcn_edge_lin0_backward_sparse_geo; psums of a dX launch with
                                  *    nbn > 0 is [2][nbn] */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
@@ -346,6 +346,16 @@ int gridgcn_edge_lin0_backward_sparse(const int32_t *nebidx, const float *att16,
                                       int Nsrc, int O, int P, int C0, float *dYsrc, float *Gsum,
                                       double *wgs, double *gg, void *workspace,
                                       size_t workspace_bytes, void *stream);
+/* ..._geo: Gsum (and gg) are INPUTS, left by gridgcn_edge_geo_forward of the same layer: the kernel's geo
+ * pass over the edges is not run. */
+int gridgcn_edge_lin0_backward_sparse_geo(const int32_t *nebidx, const float *att16,
+                                          const uint8_t *amax, const float *gval, const float *zsel,
+                                          const float *Ysrc, const float *Wg, const float *b,
+                                          const float *scale, const float *shift, const float *mean,
+                                          const float *rstd, const float *m1, const float *m2, int B,
+                                          int Nsrc, int O, int P, int C0, float *dYsrc,
+                                          const float *Gsum, double *wgs, void *workspace,
+                                          size_t workspace_bytes, void *stream);
 /* gridgcn_edge_lin0_dwg: that last formula in one launch.  T[C0][4] = Ysrc^T Gsum (columns 0..2),
  * wgb[4][C0] = (Wg rows, b).  dWg is written transposed into dW[c*ld + j], j = 0..2: the geo_vec
  * columns of the layer's weight gradient [C0][3 + Cf] (ld = 3 + Cf). */
