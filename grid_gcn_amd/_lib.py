@@ -49,7 +49,7 @@ EXPORTS = [
     "gridgcn_ball_knn_grid_ld", "gridgcn_ball_knn_ld", "gridgcn_bn_finalize_tail", "gridgcn_softmax_ce_loss", "gridgcn_colsum_f32",
     "gridgcn_cat_mask", "gridgcn_mask_sum", "gridgcn_adam_step",
     "gridgcn_edge_geo_forward_workspace_bytes", "gridgcn_edge_geo_forward",
-    "gridgcn_edge_lin0_backward_sparse_geo",
+    "gridgcn_edge_lin0_backward_sparse_geo", "gridgcn_linear_fwd_direct_fin",
 ]
 
 
@@ -67,6 +67,14 @@ class PackDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("W", "b", "Wp", "Bp", "Wb", "Wg", "Wq", "Wdx", "wgb")] + \
                [(n, ctypes.c_int32) for n in ("C", "cin_w", "rot", "cin", "ndx", "K", "ldw", "n", "geo",
                                               "reserved")]
+
+
+class BnFin(ctypes.Structure):
+    """struct gridgcn_bn_fin (include/gridgcn.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("gamma", "beta", "scale", "shift", "mean", "rstd", "running_mean",
+                                               "running_var", "num_batches_tracked", "ticket")] + \
+               [("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("tail", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class ConvLayer(ctypes.Structure):
@@ -147,6 +155,9 @@ def load():
     lib.gridgcn_linear_fwd_ld.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     lib.gridgcn_linear_fwd_direct_ld.restype = ci
     lib.gridgcn_linear_fwd_direct_ld.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, vp]
+    lib.gridgcn_linear_fwd_direct_fin.restype = ci
+    lib.gridgcn_linear_fwd_direct_fin.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci,
+                                                  ctypes.POINTER(BnFin), vp]
     lib.gridgcn_gemm_small.restype = ci
     lib.gridgcn_gemm_small.argtypes = [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp, cs, vp]
     lib.gridgcn_gemm_small_workspace_bytes.restype = ci

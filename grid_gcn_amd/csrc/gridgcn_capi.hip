@@ -743,6 +743,28 @@ int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, co
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_linear_fwd_direct_fin(const float *X, long long E, int K, int ldx, const float *Wq,
+                                  const float *b, int ldw, int cout, const float *scale,
+                                  const float *shift, void *Z, double *sums, int ldz, int zfmt,
+                                  const gridgcn_bn_fin *fin, void *stream)
+{
+    if (!X || !Wq || !b || !sums || cout < 1 || cout > ldw || (scale && !shift) || ldx < K ||
+        (ldx & 3) || ((uintptr_t)X & 15) || (ldz && ldz < cout) || (zfmt != 0 && zfmt != 1))
+        return GRIDGCN_EINVAL;
+    if (!fin || !fin->gamma || !fin->beta || !fin->scale || !fin->shift || !fin->mean || !fin->rstd ||
+        !fin->ticket || fin->tail < 0 || (fin->running_mean && !fin->running_var) || E < 1)
+        return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = (float *)Z; p.sums = sums;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx; p.ldz = ldz; p.zfmt = zfmt;
+    p.gamma = fin->gamma; p.beta = fin->beta; p.fscale = fin->scale; p.fshift = fin->shift;
+    p.fmean = fin->mean; p.frstd = fin->rstd; p.run_mean = fin->running_mean; p.run_var = fin->running_var;
+    p.nbt = (long long *)fin->num_batches_tracked; p.fin_ticket = fin->ticket; p.eps = fin->eps;
+    p.momentum = fin->momentum; p.fin_tail = fin->tail;
+    int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream)

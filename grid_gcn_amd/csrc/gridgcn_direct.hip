@@ -413,6 +413,41 @@ __global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 
         for (int w = 0; w < nw; w++) v += red[(w * 2 + which) * NT * 32 + col];
         atomicAdd(&p.sums[which * p.cout + col0 + col], (double)v);
     }
+    // The BatchNorm finalisation of the layer by the last workgroup to arrive -- the grid is a few hundred
+    // persistent workgroups, so this is one ticket per workgroup -- instead of a 256-thread launch behind
+    // every one of the ~26 layers of a step.  Hand-off in the {agent atomics on both sides} form of
+    // MI355X_MICROARCH "inter-workgroup visibility": the sums above ARE agent-scope atomics, every lane
+    // drains its own (s_waitcnt vmcnt(0)) before the barrier in front of the relaxed ticket, the last
+    // arriver reads them back with agent-scope atomic loads.  (No agent-scope fence: that is an L2
+    // write-back per workgroup on this part.)
+    // The finalisation's eleven parameters are read from the kernel-argument segment HERE, through a
+    // pointer the compiler cannot see through: as ordinary uses of `p` they were loaded at the top of the
+    // kernel and cost the main loop 26 more spilled scalar registers.
+    const GGLinFwd *kp = (const GGLinFwd *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    int *const ticket = kp->fin_ticket;
+    if (!ticket) return;
+    int *s_last = (int *)lds;                           // (the reduction buffer is free behind the barrier;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    //  no static LDS: the dynamic size is set to the limit)
+    __syncthreads();
+    if (tid == 0)
+        *s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                  (int)(gridDim.x * gridDim.y) - 1;
+    __syncthreads();
+    if (!*s_last) return;
+    if (tid == 0 && kp->nbt) kp->nbt[0] += 1;           // BatchNorm1d.num_batches_tracked
+    const int cout = kp->cout;
+    for (int c = tid; c < cout + kp->fin_tail; c += blockDim.x) {
+        if (c < cout) {
+            const double s1 = __hip_atomic_load(&kp->sums[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double s2 = __hip_atomic_load(&kp->sums[cout + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gg_bn_fin_write(s1, s2, c, kp->gamma, kp->beta, kp->E, kp->eps, kp->momentum, kp->fscale, kp->fshift,
+                            kp->fmean, kp->frstd, kp->run_mean, kp->run_var);
+        } else {
+            // columns beyond the layer in a wider table (train_ops.RawLink): the identity
+            kp->fscale[c] = 1.f; kp->fshift[c] = 0.f; kp->fmean[c] = 0.f; kp->frstd[c] = 0.f;
+        }
+    }
 }
 
 // few row tiles: column groups of NTS tiles over gridDim.y (see the kernel's CS form)

@@ -12,6 +12,7 @@
 // staging its tile.
 #include <hip/hip_runtime.h>
 #include "../../include/gridgcn.h"
+#include "gridgcn_train.h"
 
 __global__ __launch_bounds__(256) void gg_k_pairmax_fwd(const float *__restrict__ Zp,
                                                         const float *__restrict__ Za,
@@ -380,21 +381,8 @@ __global__ void gg_k_bn_finalize(const double *__restrict__ sums, const float *_
         if (c < C + tail) { scale[c] = 1.f; shift[c] = 0.f; mean[c] = 0.f; rstd[c] = 0.f; }
         return;
     }
-    const double m = sums[c] / (double)E;
-    double v = sums[C + c] / (double)E - m * m;
-    if (v < 0.0) v = 0.0;
-    const float mf = (float)m, vf = (float)v;
-    const float rs = rsqrtf(vf + eps);
-    const float sc = gamma[c] * rs;
-    scale[c] = sc;
-    shift[c] = beta[c] - mf * sc;
-    mean[c] = mf;
-    rstd[c] = rs;
-    if (run_mean) {
-        const float unb = vf * ((float)E / (float)(E > 1 ? E - 1 : 1));
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mf;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
-    }
+    gg_bn_fin_write(sums[c], sums[C + c], c, gamma, beta, E, eps, momentum, scale, shift, mean, rstd, run_mean,
+                    run_var);
 }
 
 // m1 = s1/E, m2 = s2/E, dbeta = s1, dgamma = s2

@@ -30,6 +30,16 @@ struct GGLinFwd {
     int ldz = 0;          // row stride of Z (0: cout) -- Z may be the left columns of a wider buffer
     int zfmt = 0;         // 0: Z is fp32; 1: Z is bf16 (round to nearest even; ldz in elements) -- the
                           // register-direct kernel only; the statistics are those of the fp32 values
+    // register-direct kernel only, optional (fin_ticket != nullptr): the layer's BatchNorm finalisation
+    // (gg_bn_fin_write: scale / shift / mean / rstd, running statistics) by the last workgroup to arrive
+    // instead of a launch of its own.  fin_ticket: one zero int per call.
+    const float *gamma = nullptr, *beta = nullptr;
+    float *fscale = nullptr, *fshift = nullptr, *fmean = nullptr, *frstd = nullptr;
+    float *run_mean = nullptr, *run_var = nullptr;
+    long long *nbt = nullptr;
+    int *fin_ticket = nullptr;
+    float eps = 0.f, momentum = 0.f;
+    int fin_tail = 0;
 };
 
 struct GGLinBwd {
@@ -84,6 +94,29 @@ __device__ __forceinline__ float gg_bn_m1(const GGLinBwd &p, int c)
 __device__ __forceinline__ float gg_bn_m2(const GGLinBwd &p, int c)
 {
     return p.bsums ? (float)(p.bsums[p.C + c] / (double)p.E) : p.m2[c];
+}
+// BatchNorm bookkeeping of channel c from its two sums: what gg_k_bn_finalize writes (utils/ops.py:141-158,
+// BatchNorm(eps, momentum, fix_gamma=False); running_var takes the unbiased variance as torch / MXNet do)
+__device__ __forceinline__ void gg_bn_fin_write(double s1, double s2, int c, const float *gamma,
+                                                const float *beta, long long E, float eps, float momentum,
+                                                float *scale, float *shift, float *mean, float *rstd,
+                                                float *run_mean, float *run_var)
+{
+    const double m = s1 / (double)E;
+    double v = s2 / (double)E - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    const float rs = rsqrtf(vf + eps);
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mf * sc;
+    mean[c] = mf;
+    rstd[c] = rs;
+    if (run_mean) {
+        const float unb = vf * ((float)E / (float)(E > 1 ? E - 1 : 1));
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mf;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+    }
 }
 // tail of a dW reduce kernel (one thread per channel): the vectors gg_k_bn_bwd_finalize would write
 __device__ __forceinline__ void gg_bn_bwd_fin_write(const double *bsums, long long E, int C, int c, float *m1,

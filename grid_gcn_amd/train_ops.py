@@ -389,7 +389,9 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
     if prev_bn is not None:
         pscale, pshift = prev_bn
     couts = [params[4 * l].shape[0] for l in range(L)]
-    allsums = _zeros(2 * sum(couts), torch.float64, dev)
+    # (+ one 8-byte slot per layer: the arrival ticket of the folded BatchNorm finalisation)
+    allsums = _zeros(2 * sum(couts) + L, torch.float64, dev)
+    tickets = allsums[2 * sum(couts):]
     so = 0
     stream = _stream(x)
     for l in range(L):
@@ -425,7 +427,29 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         ps = _ptr(pscale) if pscale is not None else None
         ph = _ptr(pshift) if pshift is not None else None
         t_end = TIMERS.bracket(("linear_fwd", E, cin, cout)) if TIMERS is not None else None
-        if direct:
+        if last and last_vec is not None:
+            vec = last_vec[:, :cout]            # rows of the link's [4, total] table
+        else:
+            vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
+        bn = bns[l]
+        track = bn is not None and bn.track_running_stats
+        tail = last_vec.shape[1] - cout if (last and last_vec is not None) else 0
+        folded = direct and FOLD_FINALIZE
+        if folded:
+            # the BatchNorm bookkeeping by the kernel's last workgroup (no launch of its own)
+            fin = _lib.BnFin()
+            fin.gamma, fin.beta = gamma.data_ptr(), beta.data_ptr()
+            fin.scale, fin.shift, fin.mean, fin.rstd = (vec[0].data_ptr(), vec[1].data_ptr(),
+                                                        vec[2].data_ptr(), vec[3].data_ptr())
+            fin.running_mean = bn.running_mean.data_ptr() if track else None
+            fin.running_var = bn.running_var.data_ptr() if track else None
+            fin.num_batches_tracked = bn.num_batches_tracked.data_ptr() if track else None
+            fin.ticket = tickets[l].data_ptr()
+            fin.eps, fin.momentum, fin.tail = eps, (_momentum(bn) if track else 0.0), tail
+            rc = lib.gridgcn_linear_fwd_direct_fin(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
+                                                   cout, ps, ph, _ptr(Z), _ptr(sums), ldz, zfmt,
+                                                   ctypes.byref(fin), stream)
+        elif direct:
             rc = lib.gridgcn_linear_fwd_direct_ld(_ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw,
                                                   cout, ps, ph, _ptr(Z), _ptr(sums), ldz, zfmt,
                                                   stream)
@@ -435,23 +459,17 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         if t_end is not None:
             t_end.record()
         _lib.check(rc, "gridgcn_linear_fwd")
-        if last and last_vec is not None:
-            vec = last_vec[:, :cout]            # rows of the link's [4, total] table
-        else:
-            vec = torch.empty((4, cout), dtype=torch.float32, device=dev)
-        bn = bns[l]
-        track = bn is not None and bn.track_running_stats
-        # (a separate launch on purpose: folded into the forward kernel's last workgroup -- returning
-        #  fp64 atomics, ticket, device-scope read-back -- the step was 0.1 ms SLOWER over 31 layers)
-        rc = lib.gridgcn_bn_finalize_tail(
-            _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
-            _momentum(bn) if track else 0.0, cout,
-            last_vec.shape[1] - cout if (last and last_vec is not None) else 0,
-            _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
-            _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
-            _ptr(bn.running_var) if track else None,
-            _ptr(bn.num_batches_tracked) if track else None, stream)
-        _lib.check(rc, "gridgcn_bn_finalize")
+        if not folded:
+            # (round 2 folded this with returning fp64 atomics, a fenced ticket and a device-scope read-back:
+            #  0.1 ms SLOWER over 31 layers; the fold above drains relaxed atomics instead)
+            rc = lib.gridgcn_bn_finalize_tail(
+                _ptr(sums), _ptr(gamma.detach()), _ptr(beta.detach()), E, eps,
+                _momentum(bn) if track else 0.0, cout, tail,
+                _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                _ptr(vec[3]), _ptr(bn.running_mean) if track else None,
+                _ptr(bn.running_var) if track else None,
+                _ptr(bn.num_batches_tracked) if track else None, stream)
+            _lib.check(rc, "gridgcn_bn_finalize")
         st.Z.append(Z); st.scale.append(vec[0]); st.shift.append(vec[1])
         st.mean.append(vec[2]); st.rstd.append(vec[3])
         st.Wb.append(Wb); st.Wg.append(Wg)
@@ -679,6 +697,8 @@ class _ZeroArena:
 ZERO_ARENA = True
 # the optimizer of bench.py / the tests' training loops: grid_gcn_amd.optim.Adam (one launch)
 OWN_ADAM = True
+# BatchNorm finalisation of a conv layer by the forward kernel's last workgroup instead of a launch of its own
+FOLD_FINALIZE = True
 # BatchNorm statistics of a single-layer point MLP from per-source counts and geo_vec sums
 SRC_STATS = True
 SRC_STATS_MIN_EDGES = 1 << 19     # (below: the edge pass is a 10-20 us launch, these are two)

@@ -72,7 +72,7 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4
                                  * 6: gridgcn_pack_desc.wgb / geo, gridgcn_adam_step, gridgcn_cat_mask,
                                  *    gridgcn_mask_sum, gridgcn_ball_knn[_grid]_ld, gridgcn_bn_finalize_tail,
-                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward, gridgcn_edge_lin0_backward_sparse_geo; psums of a dX launch with
+                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward, gridgcn_edge_lin0_backward_sparse_geo, gridgcn_linear_fwd_direct_fin; psums of a dX launch with
                                  *    nbn > 0 is [2][nbn] */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
@@ -431,6 +431,24 @@ int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, co
                                  const float *b, int ldw, int cout, const float *scale,
                                  const float *shift, void *Z, double *sums, int ldz, int zfmt,
                                  void *stream);
+/* gridgcn_linear_fwd_direct_fin: the same launch also FINALISES the layer's BatchNorm -- what
+ *   gridgcn_bn_finalize[_tail] does in a launch of its own (scale / shift / mean / rstd of the batch
+ *   statistics, running statistics, num_batches_tracked) is done by the last workgroup to arrive
+ *   (a few hundred persistent workgroups: one relaxed ticket each; ~26 launches less per training step).
+ *   fin->ticket: one int32, zero at the call.  sums must be given. */
+typedef struct gridgcn_bn_fin {
+    const float *gamma, *beta;
+    float *scale, *shift, *mean, *rstd;     /* [cout + tail] tables (outputs) */
+    float *running_mean, *running_var;      /* may be NULL */
+    int64_t *num_batches_tracked;           /* may be NULL */
+    int32_t *ticket;
+    float eps, momentum;
+    int32_t tail, reserved;
+} gridgcn_bn_fin;
+int gridgcn_linear_fwd_direct_fin(const float *X, long long E, int K, int ldx, const float *Wq,
+                                  const float *b, int ldw, int cout, const float *scale,
+                                  const float *shift, void *Z, double *sums, int ldz, int zfmt,
+                                  const gridgcn_bn_fin *fin, void *stream);
 /* (zfmt 1: Z is written as bf16, round to nearest even, ldz in elements -- "bf16 storage" of a large
  *  per-edge pre-activation in the bf16 mode of BASELINE configs[2]; the BatchNorm statistics are those
  *  of the fp32 values.  Its readers: gridgcn_pairmax_fwd_src_z (za_bf16) and gridgcn_linear_bwd_ld
