@@ -308,7 +308,7 @@ def main():
                     help="launches per micro-benchmark (median reported); the PMC passes use 3")
     ap.add_argument("--no-micro", action="store_true",
                     help="only the timed step: no per-kernel rooflines, no inference, no CPU baseline "
-                         "(what the PMC passes of tools/r3_pmc_step.sh run)")
+                         "(what the PMC passes of tools/pmc_step.sh run)")
     ap.add_argument("--eager", action="store_true", help="time the eager step instead of the hipGraph replay")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="contraction precision of the training GEMM kernels: f32 = exact fp32 MFMA "
@@ -412,7 +412,7 @@ def main():
     }
 
     # whole-step HBM bytes and MFMA-pipe utilisation from the PMC passes over one eager step
-    # (tools/r3_pmc_step.sh -> profiles/traffic.json), f32 only
+    # (tools/pmc_step.sh -> profiles/traffic.json), f32 only
     if a.dtype == "f32" and points == 81920 and B == 8:
         out["roofline_step"]["traffic"] = traffic.get("step_cfg4")
         out["roofline_step"]["mfma_busy"] = traffic.get("step_cfg4_mfma_busy")
@@ -470,24 +470,33 @@ def main():
             "note": "kernel-level figure for gg_k_gridconv on this layer's shape; the evaluation "
                     "forward itself runs up layers through ms_source_side_path (source-side conv + "
                     "gridgcn_att_max_eval) and uses gg_k_gridconv for the down layers"}
-        # ---- dominant kernels of the TIMED training step.  The point conv of this layer runs on
-        #      the source points (gridgcn_edgelin.hip), so the largest per-edge GEMMs left are those
-        #      of the attention MLP: backward of its C/4 -> C conv = gg_k_att_bwd_fused (dZ formed
-        #      in registers from the sparse arg-max gradient; dX, the BatchNorm-backward sums of
-        #      the layer in front and dW in ONE pass over Z) + its small reduce.  With K = C/4 it is
-        #      HBM bound. ----
+        # ---- dominant kernel of the TIMED training step.  The point conv of this layer runs on the source
+        #      points (gridgcn_edgelin.hip), so the largest per-edge GEMMs left are those of the attention
+        #      MLP.  Backward of its C/4 -> C conv WITHOUT the [E, C] pre-activation (gridgcn_att_bwd_noz,
+        #      csrc/gridgcn_attbwd_nz.hip: the arg-max term by MFMA from the sparse gradient, the dense
+        #      BatchNorm term through W2^T diag(bz) W2 and the moments of the C/4-wide activation; dA1,
+        #      the BatchNorm-backward sums of the layer in front and dW2 from one read of Z1) is the longest
+        #      single launch of the step.  Its algorithmic traffic (Z1 in, dA1 out, the [ncent, C] sparse
+        #      gradient) is 1.3 GB -- 0.2 ms at HBM peak -- so the roof that binds it is the fp32 MFMA pipe,
+        #      which its VALU work shares. ----
         from grid_gcn_amd import train_ops
         cin_b = layer.att2[0].lin.in_features
         c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
-        ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev,
-                                         ndx=cin_b, prev_bn=True)
         e_b = float(ncent_b * p_b)
-        # algorithmic bytes of the operation: read Z [E,C] once, the sparse upstream gradient
-        # (one-byte amax + fp32 gval) [ncent,C], the previous layer's raw output [E,cin]; write
-        # dX [E,cin]
-        bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 5.0 * ncent_b * c_b
-        # ... and the same two calls timed INSIDE eager training steps (their real predecessors and tensors):
+        noz = (train_ops.NOZ_ATT_BWD and a.dtype == "f32" and cin_b == 32 and c_b == 128)
+        if noz:
+            ms_b = train_ops.time_att_bwd_noz(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev)
+            # read Z1 [E,cin], the sparse upstream gradient (one-byte amax + fp32 value) [ncent,C]; write dA1
+            bytes_b = 4.0 * e_b * 2 * cin_b + 5.0 * ncent_b * c_b
+        else:
+            ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev,
+                                             ndx=cin_b, prev_bn=True)
+            # read Z [E,C] once, the sparse upstream gradient [ncent,C], the previous layer's raw output
+            # [E,cin]; write dX [E,cin]
+            bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 5.0 * ncent_b * c_b
+        flops_b = 4.0 * e_b * cin_b * c_b            # dX + dW products
+        # ... and the same calls timed INSIDE eager training steps (their real predecessors and tensors):
         # `frac` is what the step pays, `frac_micro` the back-to-back micro-benchmark
         e_f, cin_f, c_f = B * points, 256, 128
         kb_, kf_ = ("linear_bwd", int(e_b), cin_b, c_b), ("linear_fwd", e_f, cin_f, c_f)
@@ -495,23 +504,44 @@ def main():
         instep, per_step = in_step_ms(net, model.seg_loss, (x, n), lab, [kb_, kf_])
         net.eval()
         ms_b_step = instep[kb_] or ms_b
-        gbs_b = bytes_b / (ms_b_step * 1e-3) / 1e9
-        key_b = "att_bwd_fused_E%d_%dto%d" % (int(e_b), cin_b, c_b)
-        out["roofline"] = {"bound": "hbm", "kernel": "gg_k_att_bwd_fused + gg_k_att_dw_reduce "
-                           "(fused backward of the %d->%d attention conv of GridConv %s over %d "
-                           "edges: BN/ReLU backward formed in registers from the sparse arg-max "
-                           "gradient; dX, BN-backward sums of the layer in front and dW in one pass "
-                           "over Z)" % (cin_b, c_b, name, ncent_b * p_b),
-                           "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs_b / HBM_PEAK_GBS,
-                           "traffic": traffic.get(key_b), "traffic_key": key_b,
-                           "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
-                           "ms_in_step": instep[kb_], "launches_per_step": per_step[kb_],
-                           "frac_micro": bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "timing": "frac / achieved from ms_in_step (HIP events around the call inside eager "
-                                     "training steps, median); ms_per_launch = back-to-back micro-benchmark",
-                           "algorithmic_flops_per_launch": 4.0 * e_b * cin_b * c_b,
-                           "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        if noz:
+            tf_b = flops_b / (ms_b_step * 1e-3) / 1e12
+            key_b = "att_bwd_noz_E%d_%dto%d" % (int(e_b), cin_b, c_b)
+            out["roofline"] = {"bound": "mfma", "kernel": "gg_k_att_bwd_nz + gg_k_att_nz_reduce + gg_k_att_nz_finish "
+                               "(backward of the %d->%d attention conv of GridConv %s over %d edges without "
+                               "its [E,%d] pre-activation: dX, BN-backward sums of the layer in front and dW "
+                               "from one read of the %d-wide activation)" % (cin_b, c_b, name, ncent_b * p_b,
+                                                                            c_b, cin_b),
+                               "achieved": tf_b, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tf_b / MFMA_F32_PEAK_TF,
+                               "traffic": traffic.get(key_b), "traffic_key": key_b,
+                               "algorithmic_flops_per_launch": flops_b, "algorithmic_bytes_per_launch": bytes_b,
+                               "hbm_frac": bytes_b / (ms_b_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "ms_per_launch": ms_b, "ms_in_step": instep[kb_],
+                               "launches_per_step": per_step[kb_],
+                               "frac_micro": flops_b / (ms_b * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                               "timing": "frac / achieved from ms_in_step (HIP events around the call inside "
+                                         "eager training steps, median); ms_per_launch = back-to-back "
+                                         "micro-benchmark",
+                               "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        else:
+            gbs_b = bytes_b / (ms_b_step * 1e-3) / 1e9
+            key_b = "att_bwd_fused_E%d_%dto%d" % (int(e_b), cin_b, c_b)
+            out["roofline"] = {"bound": "hbm", "kernel": "gg_k_att_bwd_fused + gg_k_att_dw_reduce "
+                               "(fused backward of the %d->%d attention conv of GridConv %s over %d "
+                               "edges: BN/ReLU backward formed in registers from the sparse arg-max "
+                               "gradient; dX, BN-backward sums of the layer in front and dW in one pass "
+                               "over Z)" % (cin_b, c_b, name, ncent_b * p_b),
+                               "achieved": gbs_b, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs_b / HBM_PEAK_GBS,
+                               "traffic": traffic.get(key_b), "traffic_key": key_b,
+                               "algorithmic_bytes_per_launch": bytes_b, "ms_per_launch": ms_b,
+                               "ms_in_step": instep[kb_], "launches_per_step": per_step[kb_],
+                               "frac_micro": bytes_b / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "timing": "frac / achieved from ms_in_step (HIP events around the call inside eager "
+                                         "training steps, median); ms_per_launch = back-to-back micro-benchmark",
+                               "algorithmic_flops_per_launch": flops_b,
+                               "dtype": "f32 (v_mfma_f32_32x32x2_f32)" if a.dtype == "f32" else "bf16 MFMA operands"}
         # the largest MFMA-bound kernel of the step: forward of the 256->128 update conv over
         # all B*N points (previous BatchNorm+ReLU applied while loading, statistics epilogue)
         ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=mi, device=dev)

@@ -1744,6 +1744,39 @@ def time_linear_bwd(ncent, P, cin, C, iters=50, device="cuda:0", ndx=0, prev_bn=
     return median_ms(call, iters, device=device)
 
 
+def time_att_bwd_noz(ncent, P, cin, C, iters=50, device="cuda:0"):
+    """Time one gridgcn_att_bwd_noz call (backward of an up layer's second attention conv without its [E, C]
+    pre-activation: gg_k_att_bwd_nz + its reduce and finish launches) on synthetic tensors; bench.py's
+    roofline of the dominant kernel of the step.  Returns the median ms/call."""
+    lib = _lib.load()
+    E = ncent * P
+    g = torch.Generator(device=device).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=device, generator=g)  # noqa: E731
+    Z1 = rnd(E, cin)
+    s1v, h1v, m1v, r1v = rnd(cin).abs() + 0.5, rnd(cin) * 0.1, rnd(cin) * 0.1, rnd(cin).abs() + 0.5
+    W2, b2 = rnd(C, cin) * 0.2, rnd(C) * 0.1
+    s2v, m2v, r2v = rnd(C).abs() + 0.5, rnd(C) * 0.1, rnd(C).abs() + 0.5
+    sums_a = torch.zeros(2 * C, dtype=torch.float64, device=device)
+    amax = torch.randint(0, P, (ncent, C), device=device, dtype=torch.int32, generator=g).to(torch.uint8)
+    ga = rnd(ncent, C)
+    dA1 = torch.empty(E, cin, device=device)
+    dW2 = torch.empty(C, cin, device=device)
+    v = torch.empty(4, C, device=device)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.gridgcn_att_bwd_noz_workspace_bytes(E, cin, C, ctypes.byref(nbytes)), "att_bwd_noz_workspace")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+
+    def call():
+        acc = torch.zeros(3 * cin, dtype=torch.float64, device=device)
+        rc = lib.gridgcn_att_bwd_noz(_ptr(Z1), _ptr(s1v), _ptr(h1v), _ptr(m1v), _ptr(r1v), _ptr(W2), _ptr(b2),
+                                     _ptr(s2v), _ptr(m2v), _ptr(r2v), _ptr(sums_a), _ptr(amax), _ptr(ga), int(P),
+                                     E, cin, C, _ptr(dA1), _ptr(dW2), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]),
+                                     _ptr(v[3]), _ptr(acc[:2 * cin]), _ptr(acc[2 * cin:]), _ptr(ws), nbytes.value,
+                                     _stream(Z1))
+        _lib.check(rc, "gridgcn_att_bwd_noz")
+    return median_ms(call, iters, device=device)
+
+
 def edge_block_supported(pt_layers, att_layers, nf, P=None):
     """P: neighbours per centre.  The arg max of the neighbour max-pool is stored in ONE byte
     (uint8 amax, four of them per 32-bit store), so the kernels take P <= 256 (include/gridgcn.h);

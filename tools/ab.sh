@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of a train_ops switch on the timed cfg4 step: r4_ab.sh <outdir> NAME [reps]
+# A/B of a train_ops switch on the timed cfg4 step: ab.sh <outdir> NAME [reps]
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=gpurun_out/${1:-r4ab}; NAME=$2; REPS=${3:-2}
+OUT=gpurun_out/${1:-ab}; NAME=$2; REPS=${3:-2}
 mkdir -p $OUT
 for rep in $(seq 1 $REPS); do
   for v in 1 0; do

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 Gridify session: r4_gridify.sh <outdir> [notests]
+# Gridify session: gridify_session.sh <outdir> [notests]
 #   full -m gpu suite, device time of every Gridify layer of every config (small-cloud build on / off),
 #   batch curve of layer 0, per-workgroup phase timelines
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=gpurun_out/${1:-r4_gridify}
+OUT=gpurun_out/${1:-gridify}
 mkdir -p $OUT
 if [ -z "$2" ]; then
   timeout 1500 python -m pytest tests -q -m gpu --timeout 600 > $OUT/gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/gpu_tests.log

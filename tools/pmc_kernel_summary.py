@@ -3,7 +3,7 @@ usage: python tools/pmc_kernel_summary.py <label>=<dir of a --pmc pass> ...  > p
 import csv, glob, os, sys
 from collections import defaultdict
 print("# rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python tools/prof_index.py --cfg <cfg> --iters 5")
-print("# (tools/r2_bench_all.sh; MI355X).  One row per (kernel, grid size): dispatches, mean duration in THIS")
+print("# (tools/final.sh; MI355X).  One row per (kernel, grid size): dispatches, mean duration in THIS")
 print("# (counter-collecting, hence slower) pass, mean counter value in KB.  The un-profiled device time of a whole")
 print("# Gridify call is bench.py's ms_per_cagq_layer; traffic per call (profiles/traffic.json) = tools/pmc_traffic.py.")
 for arg in sys.argv[1:]:

@@ -1,5 +1,5 @@
 """Whole-step HBM traffic and MFMA-pipe utilisation from rocprofv3 PMC passes over bench.py
-(tools/r3_pmc_step.sh) -> profiles/traffic.json + a per-kernel table.
+(tools/pmc_step.sh) -> profiles/traffic.json + a per-kernel table.
 
     python tools/pmc_step.py --fetch DIR --write DIR --busy DIR [--out profiles/traffic.json] > table
 

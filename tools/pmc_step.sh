@@ -1,9 +1,9 @@
 #!/bin/bash
 # PMC passes over bench.py (cfg4): whole-step HBM bytes + MFMA-pipe utilisation, and the per-launch traffic of
-# the micro-benchmarked kernels -> profiles/traffic.json, profiles/r3_pmc_step.txt
+# the micro-benchmarked kernels -> profiles/traffic.json, <outdir>/pmc_step.txt
 # (separate --pmc passes, --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 section)
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=gpurun_out/${1:-r3_pmc}
+OUT=gpurun_out/${1:-pmc}
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 cp profiles/traffic.json $OUT/traffic.json
@@ -17,8 +17,8 @@ python tools/pmc_step.py --fetch $OUT/fetch --write $OUT/write --busy $OUT/busy 
 head -60 $OUT/pmc_step.txt
 # per-launch traffic of the micro-benchmarked kernels: bench.py runs them after the steps, so the LAST launches
 # of each kernel name are the benchmarked shape (5 warm-up + 3 timed)
-python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key att_bwd_fused_E3276800_32to128 \
-    --kernels "gg_k_att_bwd_fused<4,gg_k_att_dw_reduce" --wide "gg_k_att_bwd_fused<4" --last 8 --out $OUT/traffic.json
+python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key att_bwd_noz_E3276800_32to128 \
+    --kernels "gg_k_att_bwd_nz,gg_k_att_nz_reduce,gg_k_att_nz_finish" --wide "gg_k_att_bwd_nz" --last 8 --out $OUT/traffic.json
 python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key linear_fwd_E655360_256to128 \
     --kernels "gg_k_linear_fwd_direct<4" --wide "gg_k_linear_fwd_direct<4" --last 8 --out $OUT/traffic.json
 python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key batch_take_up2_E3276800 \

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 GPU session: r4_session.sh <outdir> [what...]   what = tests micro bench trace pmc configs (default: all but pmc/configs)
+# GPU session: session.sh <outdir> [what...]   what = tests micro bench trace pmc configs (default: all but pmc/configs)
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-OUT=gpurun_out/${1:-r4}; shift
+OUT=gpurun_out/${1:-session}; shift
 WHAT="${@:-tests micro bench trace}"
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT

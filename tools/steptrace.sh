@@ -1,5 +1,5 @@
 #!/bin/bash
-# ordered kernel list of one eager training step: r2_steptrace.sh <outdir> <cfg> [min_us] [extra bench args]
+# ordered kernel list of one eager training step: steptrace.sh <outdir> <cfg> [min_us] [extra bench args]
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/$1; CFG=$2; MINUS=${3:-40}; shift 3
 mkdir -p $OUT
