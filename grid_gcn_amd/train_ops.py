@@ -933,7 +933,7 @@ class _MLPTrain(torch.autograd.Function):
 def _wide_direct_ok(E, cin, C):
     """a layer of more than 256 output channels the register-direct kernels can take as 256-column slices"""
     return (DIRECT_FWD and DIRECT_DX and E >= 4096 and cin % 8 == 0 and cin <= 320 and C % 256 == 0
-            and 256 < C <= 1024 and _dw_direct_ok(256, cin) and _lib.load().gridgcn_get_mlp_precision() == 0)
+            and 256 < C <= 1024 and _dw_direct_ok(256, cin))
 
 
 def _pack_tmp(lib, W, b, cout, cin, st):

@@ -721,6 +721,35 @@ def test_bf16_mlp_precision_mode_close_to_fp32():
         assert rel(b, a) <= 1e-1
 
 
+def test_bf16_mode_wide_layer_close_to_fp32():
+    """a 512-wide layer (256-column slices of the register-direct kernels) in the bf16 contraction mode:
+    same stated tolerance as the narrow stacks above (cfg5's last layer; in fp32-only form it fell to the
+    small-GEMM kernels in this mode: 27 instead of 20 ms per cfg5 step)"""
+    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.gridconv import mlp
+    torch.manual_seed(3)
+    net = mlp(128, [512, 256]).to(DEV).train()
+    x = torch.randn(8192, 128, device=DEV)
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            train_ops.set_mlp_precision(mode)
+            n2 = copy.deepcopy(net)
+            xx = x.clone().requires_grad_(True)
+            assert train_ops.wide_supported(list(n2), xx)
+            y = train_ops.mlp_wide_train(xx, list(n2))
+            y.square().mean().backward()
+            res[mode] = (y.detach(), xx.grad, [p.grad for p in n2.parameters()])
+    finally:
+        train_ops.set_mlp_precision("fp32")
+    rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
+    assert rel(res["bf16"][0], res["fp32"][0]) <= 2e-2
+    assert rel(res["bf16"][1], res["fp32"][1]) <= 1e-1
+    for a, b in zip(res["bf16"][2], res["fp32"][2]):
+        if float(b.norm()) > 1e-6:
+            assert rel(a, b) <= 1e-1
+
+
 def test_bf16_mode_whole_model_loss_and_gradient_direction():
     """bf16 contraction mode on the whole segmentation network (hidden layers only: the first conv
     of every stack sees raw coordinates and stays fp32): the training loss moves by < 1e-3 relative;

@@ -21,7 +21,7 @@ from collections import defaultdict
 WIDE = ("gg_k_linear_fwd_direct", "gg_k_linear_dx_direct", "gg_k_att_bwd_fused", "gg_k_bn_apply",
         "gg_k_bn_bwd_reduce", "gg_k_pairmax", "gg_k_edge_lin0", "gg_k_chunk_split",
         "gg_k_ce_", "gg_k_colsum", "gg_k_linear_fwd<", "multi_tensor_apply", "gg_k_dw_reduce",
-        "gg_k_att_dw_reduce", "gg_k_att_max_eval")
+        "gg_k_att_dw_reduce", "gg_k_att_max_eval", "gg_k_att_bwd_nz", "gg_k_adam")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--fetch", required=True)

@@ -18,7 +18,7 @@ head -60 $OUT/pmc_step.txt
 # per-launch traffic of the micro-benchmarked kernels: bench.py runs them after the steps, so the LAST launches
 # of each kernel name are the benchmarked shape (5 warm-up + 3 timed)
 python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key att_bwd_noz_E3276800_32to128 \
-    --kernels "gg_k_att_bwd_nz,gg_k_att_nz_reduce,gg_k_att_nz_finish" --wide "gg_k_att_bwd_nz" --last 8 --out $OUT/traffic.json
+    --kernels "gg_k_att_bwd_nz,gg_k_att_nz_reduce,gg_k_att_nz_finish" --wide "gg_k_att_bwd_nz" --largest --out $OUT/traffic.json
 python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key linear_fwd_E655360_256to128 \
     --kernels "gg_k_linear_fwd_direct<4" --wide "gg_k_linear_fwd_direct<4" --last 8 --out $OUT/traffic.json
 python tools/pmc_traffic.py --fetch $OUT/fetch --write $OUT/write --key batch_take_up2_E3276800 \
