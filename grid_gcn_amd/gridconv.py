@@ -64,7 +64,8 @@ _warned_shapes = set()
 
 def _warn_stock_fallback(layers, x):
     """The MFMA training kernels take stacks of <= 256 output / <= 384 input channels (fp32,
-    contiguous rows); wider conv+BN+ReLU stacks run on rocBLAS + this library's BatchNorm kernels
+    contiguous rows); wider conv+BN+ReLU stacks run on 256-column slices of those kernels or on
+    csrc/gridgcn_gemm.hip + this library's BatchNorm kernels
     (train_ops.mlp_wide_train); anything else (no BatchNorm, no ReLU, other dtypes) on the stock
     PyTorch modules -- several times slower.  Say so once per shape instead of silently."""
     key = (tuple((l.lin.in_features, l.lin.out_features) for l in layers), str(x.dtype))
@@ -84,7 +85,7 @@ def run_mlp(layers, x, mfma=True):
         if train_ops.supported(layers, x):
             return train_ops.mlp_bn_relu_train(x, layers)
         if train_ops.wide_supported(layers, x):
-            # beyond the MFMA kernels' widths: rocBLAS GEMMs + this library's BatchNorm kernels
+            # beyond the MFMA kernels' widths: 256-column slices / gridgcn_gemm + this library's BatchNorm kernels
             return train_ops.mlp_wide_train(x, layers)
         _warn_stock_fallback(layers, x)
     if mfma and x.is_cuda and layers and not layers[0].training and not torch.is_grad_enabled():

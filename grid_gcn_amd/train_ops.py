@@ -1077,8 +1077,9 @@ def _padded_supported(layer, x):
 
 
 def mlp_wide_train(x, layers):
-    """x [..., cin] through `layers` in training mode: rocBLAS GEMMs + this library's BatchNorm
-    kernels (_WideLayerTrain); layers the MFMA kernels take still go through them."""
+    """x [..., cin] through `layers` in training mode: wide layers on _WideLayerTrain (256-column slices of the
+    register-direct kernels or gridgcn_gemm + this library's BatchNorm kernels; no BLAS library); layers the
+    MFMA kernels take still go through them."""
     shp = x.shape
     y = x.reshape(-1, shp[-1])
     i = 0

@@ -505,7 +505,8 @@ int gridgcn_gemm_bias(int mode, const float *A, int lda, const float *B, int ldb
                       int ldc, int M, int N, int K, void *stream);
 /* gridgcn_bn_stats: sums[c] += sum_e Z[e][c], sums[C+c] += sum_e Z[e][c]^2 (input of
  *   gridgcn_bn_finalize) for a layer whose GEMM ran elsewhere (the "wide" fallback: stacks beyond
- *   the MFMA kernels' 256 output / 384 input channels use rocBLAS + these BatchNorm kernels). */
+ *   the MFMA kernels' 256 output / 384 input channels use gridgcn_gemm_small / _bias + these BatchNorm
+ *   kernels). */
 int gridgcn_bn_stats(const float *Z, long long E, int C, int ld, double *sums, void *stream);
 int gridgcn_sparse_add(const uint8_t *amax, const float *gval, long long ncent, int P, int C,
                        float *dX, void *stream);
