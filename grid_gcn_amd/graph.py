@@ -55,6 +55,7 @@ class GraphedTrainStep:
         assert not self.split or sync is not None
         net.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.params = [p for p in net.parameters() if p.requires_grad]
+        self._state = list(net.parameters()) + [b for b in net.buffers() if b.is_floating_point()]
 
         # (kept alive with the graph: the captured loss-gradient kernel reads it at every replay)
         self._one = one = torch.ones((), dtype=torch.float32, device=dev)
@@ -122,4 +123,8 @@ class GraphedTrainStep:
 
     def __call__(self):
         self.g1.replay()
+        # a replay rewrites parameters and BatchNorm buffers without any Python running: caches keyed on
+        # Tensor._version (folded evaluation constants, gridconv.SubGUpdate.packed_layers) must see it
+        with torch.no_grad():
+            torch.autograd.graph.increment_version(self._state)
         return self.loss

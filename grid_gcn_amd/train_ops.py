@@ -459,6 +459,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
         if t_end is not None:
             t_end.record()
         _lib.check(rc, "gridgcn_linear_fwd")
+        if track:
+            _stats_written(bn)
         if not folded:
             # (round 2 folded this with returning fp64 atomics, a fenced ticket and a device-scope read-back:
             #  0.1 ms SLOWER over 31 layers; the fold above drains relaxed atomics instead)
@@ -470,6 +472,8 @@ def _chain_forward(lib, x, params, bns, eps, rot=0, ndx0=0, prev_bn=None, out_ra
                 _ptr(bn.running_var) if track else None,
                 _ptr(bn.num_batches_tracked) if track else None, stream)
             _lib.check(rc, "gridgcn_bn_finalize")
+            if track:
+                _stats_written(bn)
         st.Z.append(Z); st.scale.append(vec[0]); st.shift.append(vec[1])
         st.mean.append(vec[2]); st.rstd.append(vec[3])
         st.Wb.append(Wb); st.Wg.append(Wg)
@@ -983,6 +987,8 @@ class _WideLayerTrain(torch.autograd.Function):
                         _ptr(bn.running_var[sl]) if track else None,
                         _ptr(bn.num_batches_tracked) if (track and h == 0) else None, st)
                     _lib.check(rc, "gridgcn_bn_finalize")
+                    if track:
+                        _stats_written(bn)
                 saved_w = Wbs
             else:
                 Z = _mm_nt(x.detach(), W.detach(), bias=b)
@@ -995,6 +1001,8 @@ class _WideLayerTrain(torch.autograd.Function):
                     _ptr(bn.running_var) if track else None,
                     _ptr(bn.num_batches_tracked) if track else None, st)
                 _lib.check(rc, "gridgcn_bn_finalize")
+                if track:
+                    _stats_written(bn)
                 saved_w = []
             Y = torch.empty_like(Z)
             rc = lib.gridgcn_bn_relu_apply(_ptr(Z), _ptr(vec[0]), _ptr(vec[1]), _ptr(Y), E, C, C, st)
@@ -1104,9 +1112,60 @@ def mlp_wide_train(x, layers):
     return y.reshape(shp[:-1] + (y.shape[-1],))
 
 
+# Evaluation constants of a layer -- BatchNorm folded to (scale, shift) with the running statistics, the packed
+# forward operand of the weight -- cached per module and rebuilt when a Tensor._version of what they are made of
+# moves.  (They were recomputed at every call: five element-wise framework launches per BatchNorm and one pack
+# launch per layer, ~200 launches = 1 ms of a 2.7-ms evaluation forward of the segmentation net.)  Whoever
+# writes these tensors through raw pointers moves the counter by hand: the training kernels for the running
+# statistics (_stats_written), optim.Adam for the parameters, graph.GraphedTrainStep after every replay.
+# (`p.data.op_()` does not move a version counter -- as with gridconv.SubGUpdate.packed_layers, call
+# clear_eval_cache() after editing parameters that way.)
+EVAL_CACHE = True
+_EVAL_BN, _EVAL_W = {}, {}
+
+
+def clear_eval_cache():
+    _EVAL_BN.clear()
+    _EVAL_W.clear()
+
+
+def _stats_written(bn):
+    """the kernels update the running statistics through raw pointers"""
+    torch.autograd.graph.increment_version((bn.running_mean, bn.running_var))
+
+
 def _bn_eval_vectors(bn):
-    sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
-    return sc, (bn.bias - bn.running_mean * sc).contiguous()
+    """(scale, shift) of a BatchNorm in evaluation mode: y = x * scale + shift"""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps)
+    e = _EVAL_BN.get(id(bn)) if EVAL_CACHE else None
+    if e is not None and e[0]() is bn and e[1] == key:
+        return e[2], e[3]
+    with torch.no_grad():
+        sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+        sh = (bn.bias - bn.running_mean * sc).contiguous()
+    if EVAL_CACHE:
+        _EVAL_BN[id(bn)] = (weakref.ref(bn, lambda _r, k=id(bn): _EVAL_BN.pop(k, None)), key, sc, sh)
+    return sc, sh
+
+
+def _eval_packed(lib, lin, cout_p, cin, st):
+    """(Bp, Wq, ldw): zero-padded bias and forward operand of lin.weight for a kernel that sees `cin` input
+    columns and cout_p >= out_features output columns (gridgcn_pack_linear)"""
+    W, b = lin.weight, lin.bias
+    cout, cin_w = W.shape
+    key = (cout_p, cin, W._version, b._version, W.data_ptr(), b.data_ptr())
+    e = _EVAL_W.get(id(lin)) if EVAL_CACHE else None
+    if e is not None and e[0]() is lin and e[1] == key:
+        return e[2]
+    K, ldw, nwp, nwb = packed_sizes(cout_p, cin)
+    pk = torch.empty(ldw + cin * ldw, dtype=torch.float32, device=W.device)
+    Bp, Wq = pk[:ldw], pk[ldw:]
+    _lib.check(lib.gridgcn_pack_linear(_ptr(W.detach()), _ptr(b.detach()), cout, cin_w, 0, cin, 0, None,
+                                       _ptr(Bp), None, None, _ptr(Wq), None, st), "pack")
+    if EVAL_CACHE:
+        _EVAL_W[id(lin)] = (weakref.ref(lin, lambda _r, k=id(lin): _EVAL_W.pop(k, None)), key, (Bp, Wq, ldw))
+    return Bp, Wq, ldw
 
 
 def _chain_eval_raw(lib, prev, layers, prev_bn=None):
@@ -1121,18 +1180,13 @@ def _chain_eval_raw(lib, prev, layers, prev_bn=None):
             W, b, bn = l.lin.weight, l.lin.bias, l.bn
             cout, cin_w = W.shape
             cin = prev.shape[1]
-            K, ldw, nwp, nwb = packed_sizes(cout, cin)
-            pk = torch.empty(ldw + cin * ldw, dtype=torch.float32, device=dev)
-            Bp, Wq = pk[:ldw], pk[ldw:]
-            _lib.check(lib.gridgcn_pack_linear(_ptr(W), _ptr(b), cout, cin_w, 0, cin, 0, None,
-                                               _ptr(Bp), None, None, _ptr(Wq), None, st), "pack")
+            Bp, Wq, ldw = _eval_packed(lib, l.lin, cout, cin, st)
             Z = torch.empty((E, cout), dtype=torch.float32, device=dev)
             _lib.check(lib.gridgcn_linear_fwd_direct(
                 _ptr(prev), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, cout,
                 _ptr(sc) if sc is not None else None, _ptr(sh) if sh is not None else None,
                 _ptr(Z), None, st), "gridgcn_linear_fwd_direct")
-            sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
-            sh = (bn.bias - bn.running_mean * sc).contiguous()
+            sc, sh = _bn_eval_vectors(bn)
             prev = Z
     return prev, sc, sh
 
@@ -1168,14 +1222,21 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim, out=
         st = _stream(src)
         feat = src[..., 4:].reshape(R, Cf)
         Ysrc = _mm_nt(feat, W0[:, rot:])
-        wgb = torch.cat([W0[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0), b0[None]])
+        wkey = (geo, W0._version, b0._version, W0.data_ptr(), b0.data_ptr())
+        e = _EVAL_W.get(("wgb", id(pt_layer))) if EVAL_CACHE else None
+        if e is not None and e[0]() is pt_layer and e[1] == wkey:
+            wgb = e[2]
+        else:
+            wgb = torch.cat([W0[:, :3].t() if geo else _cached_zeros(3 * C0, dev).view(3, C0), b0[None]])
+            if EVAL_CACHE:
+                k_ = ("wgb", id(pt_layer))
+                _EVAL_W[k_] = (weakref.ref(pt_layer, lambda _r, k=k_: _EVAL_W.pop(k, None)), wkey, wgb)
         att16 = torch.empty((E, 16), dtype=torch.float32, device=dev)
         rc = lib.gridgcn_edge_lin0_forward(
             _ptr(Ysrc), _ptr(src), _ptr(nebidx), _ptr(cent), cent.shape[2], B, Nsrc, Cs, O, P, C0,
             _ptr(wgb) if geo else None, _ptr(wgb[3]), None, _ptr(att16), None, st)
         _lib.check(rc, "gridgcn_edge_lin0_forward")
-        sc_p = (bn0.weight * torch.rsqrt(bn0.running_var + bn0.eps)).contiguous()
-        sh_p = (bn0.bias - bn0.running_mean * sc_p).contiguous()
+        sc_p, sh_p = _bn_eval_vectors(bn0)
         a2 = att_layers[-1]
         C = a2.lin.out_features
         ncent = B * O
@@ -1186,9 +1247,7 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim, out=
             # second attention conv + activations + product + max in one kernel: the [E, C]
             # attention tensor is never written (csrc/gridgcn_atteval.hip)
             Z1, s1, h1 = _chain_eval_raw(lib, att16, att_layers[:-1])
-            bn2 = a2.bn
-            sc_a = (bn2.weight * torch.rsqrt(bn2.running_var + bn2.eps)).contiguous()
-            sh_a = (bn2.bias - bn2.running_mean * sc_a).contiguous()
+            sc_a, sh_a = _bn_eval_vectors(a2.bn)
             rc = lib.gridgcn_att_max_eval(
                 _ptr(Z1), _ptr(s1), _ptr(h1), _ptr(a2.lin.weight), _ptr(a2.lin.bias), _ptr(sc_a),
                 _ptr(sh_a), _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(wgb) if geo else None,
@@ -1243,13 +1302,9 @@ def head_eval(x, layers, lin):
     dev = Z.device
     C = lin.out_features
     Cp = (C + 7) & ~7
-    K, ldw, nwp, nwb = packed_sizes(C, cin)
     with torch.cuda.device(dev):
         st = _stream(Z)
-        pk = torch.empty(ldw + cin * ldw, dtype=torch.float32, device=dev)
-        Bp, Wq = pk[:ldw], pk[ldw:]
-        _lib.check(lib.gridgcn_pack_linear(_ptr(lin.weight), _ptr(lin.bias), C, cin, 0, cin, 0, None,
-                                           _ptr(Bp), None, None, _ptr(Wq), None, st), "pack")
+        Bp, Wq, ldw = _eval_packed(lib, lin, C, cin, st)
         Y = torch.empty((E, Cp), dtype=torch.float32, device=dev)
         _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(Z), E, cin, cin, _ptr(Wq), _ptr(Bp), ldw, Cp,
                                                  _ptr(sc), _ptr(sh), _ptr(Y), None, st),
@@ -1433,6 +1488,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 _ptr(bn.running_var) if track else None,
                 _ptr(bn.num_batches_tracked) if track else None, st)
             _lib.check(rc, "gridgcn_bn_finalize")
+            if track:
+                _stats_written(bn)
             if Lp > 1:
                 sp = _chain_forward(lib, Z0, params[4:4 * Lp], bns_p[1:], eps, 0, C0,
                                     prev_bn=(vec0[0], vec0[1]))
@@ -1882,6 +1939,8 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
                     _ptr(bn.running_var) if track else None,
                     _ptr(bn.num_batches_tracked) if track else None, st)
                 _lib.check(rc, "gridgcn_bn_finalize")
+                if track:
+                    _stats_written(bn)
                 sp = _chain_forward(lib, x0, pp[4:], bns_p[1:], eps, 0, C0,
                                     prev_bn=(vec0[0], vec0[1]))
             else:
@@ -1927,6 +1986,8 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
                 _ptr(bn.running_var) if track else None,
                 _ptr(bn.num_batches_tracked) if track else None, st)
             _lib.check(rc, "gridgcn_bn_finalize")
+            if track:
+                _stats_written(bn)
             sa = _chain_forward(lib, Z20, pa2[4:], bns_a2[1:], eps, 0, N0,
                                 prev_bn=(vecA[0], vecA[1]))
             agg = torch.empty((ncent, C), dtype=torch.float32, device=dev)

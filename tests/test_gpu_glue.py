@@ -199,3 +199,50 @@ def test_edge_geo_forward_statistics_match_the_edge_pass(B, N, O, P, C0, geo):
     var_a, var_b = sums_a[C0:] / n - mean_a ** 2, sums_b[C0:] / n - mean_b ** 2
     assert float((mean_a - mean_b).abs().max()) <= 2e-6 * max(1.0, float(mean_a.abs().max()))
     assert float((var_a - var_b).abs().max()) <= 5e-6 * float(var_a.abs().max())
+
+
+def test_eval_constants_cache_follows_training():
+    """the cached evaluation constants (folded BatchNorm, packed weights) are rebuilt after eager training steps
+    (optim.Adam and the kernels' running-statistics updates move the version counters by hand) and after
+    replays of a captured step: evaluation == evaluation with the cache switched off"""
+    from grid_gcn_amd import graph, model, optim, synth, train_ops
+    torch.manual_seed(1)
+    net = model.GGCNSeg(model.SEG_8192, seed=3).to(DEV)
+    data, npn = synth.make_batch(2, 8192, "planes", first_id=5)
+    x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    lab = torch.randint(0, 21, (2, 8192), device=DEV)
+    opt = optim.Adam(net.parameters(), lr=1e-2)
+
+    def evaluate():
+        net.eval()
+        with torch.no_grad():
+            a = net(x, n).clone()
+            train_ops.EVAL_CACHE = False
+            try:
+                b = net(x, n).clone()
+            finally:
+                train_ops.EVAL_CACHE = True
+        net.train()
+        return a, b
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        model.seg_loss(net(x, n), lab).backward()
+        opt.step()
+
+    net.train()
+    outs = []
+    for _ in range(3):
+        a, b = evaluate()
+        assert torch.equal(a, b)
+        outs.append(a)
+        step()
+    assert float((outs[0] - outs[1]).abs().max()) > 0 and float((outs[1] - outs[2]).abs().max()) > 0
+    gs = graph.GraphedTrainStep(net, opt, model.seg_loss, (x, n), lab, warmup=1)
+    for _ in range(2):
+        gs()
+        a, b = evaluate()
+        assert torch.equal(a, b)
+        assert float((a - outs[-1]).abs().max()) > 0
+        outs.append(a)
