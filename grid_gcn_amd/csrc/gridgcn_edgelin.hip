@@ -342,12 +342,16 @@ __global__ __launch_bounds__(1024, 8) void gg_k_edge_geo_fwd(GGEdgeGeoFwd p)
     for (int i = tid; i <= N; i += 1024) { gx[i] = 0; gy[i] = 0; gz[i] = 0; gc[i] = 0; }
     if (tid == 0) gmax = 0u;
     const bool v4 = (p.cent_stride & 3) == 0 && (p.Cs & 3) == 0 && (((size_t)p.cent | (size_t)p.src) & 15) == 0;
-    // one edge: source row (mx.sym.take clip mode, utils/ops.py:78-93), centre, geo_vec
-    auto edge = [&](int e, long long &flat, float4 &s4, float4 &c4) {
-        flat = (long long)nb[e] + (long long)b * N;
-        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
-        const float *srow = p.src + flat * p.Cs;
-        const float *cen = p.cent + ((size_t)b * O + e / P) * p.cent_stride;
+    // one edge: source row (mx.sym.take clip mode, utils/ops.py:78-93), centre.  32-bit arithmetic throughout
+    // (B * N and B * O * P are below 2^31: checked by the entry): the 64-bit forms were a third of the kernel's
+    // instructions.  ci = e / P is kept incrementally by the caller.
+    const int rowsm1 = (int)rows - 1, bN = b * N;
+    auto edge = [&](int e, int ci, int &flat, float4 &s4, float4 &c4) {
+        int f = nb[e] + bN;
+        f = f < 0 ? 0 : (f > rowsm1 ? rowsm1 : f);
+        flat = f;
+        const float *srow = p.src + (size_t)f * p.Cs;
+        const float *cen = p.cent + ((size_t)b * O + ci) * p.cent_stride;
         if (v4) {
             s4 = *(const float4 *)srow;
             c4 = *(const float4 *)cen;
@@ -363,9 +367,9 @@ __global__ __launch_bounds__(1024, 8) void gg_k_edge_geo_fwd(GGEdgeGeoFwd p)
     // scale of the three geo sums from the first round of edges (count: exact integers)
     float gm = 0.f;
     if (ea + et < ez) {
-        long long fl;
+        int fl;
         float4 s4, c4;
-        edge(ea + et, fl, s4, c4);
+        edge(ea + et, (ea + et) / P, fl, s4, c4);
         const float4 g = geo(s4, c4);
         gm = fmaxf(fmaxf(fabsf(g.y), fabsf(g.z)), fabsf(g.w));
         if (!(gm < 3.0e38f)) gm = 0.f;                            // (NaN / inf never set the scale)
@@ -378,11 +382,24 @@ __global__ __launch_bounds__(1024, 8) void gg_k_edge_geo_fwd(GGEdgeGeoFwd p)
     const float gthr = fminf(0x1p+47f, 0x1p+62f / ((float)p.epw + 1.f));
     float g4[4] = {0.f, 0.f, 0.f, 0.f};      // lane q < 3: sum g_q g_0, g_q g_1, g_q g_2, g_q
     constexpr int UG = 4;
+    // centre of edge e + 256 u, kept without a division per edge: (quotient, remainder) of 256 by P once
+    const int q256 = 256 / P, r256 = 256 - q256 * P;
+    int ci0 = (ea + et) / P, rm0 = (ea + et) - ci0 * P;
+    const int keyoff = bN - 1;
     for (int e = ea + et; e < ez; e += 256 * UG) {
-        long long fl[UG];
+        int fl[UG], ci[UG];
         float4 s4[UG], c4[UG];
 #pragma unroll
-        for (int u = 0; u < UG; u++) edge(e + 256 * u < ez ? e + 256 * u : e, fl[u], s4[u], c4[u]);
+        for (int u = 0; u < UG; u++) {
+            ci[u] = ci0;
+            ci0 += q256; rm0 += r256;
+            if (rm0 >= P) { rm0 -= P; ci0++; }
+        }
+#pragma unroll
+        for (int u = 0; u < UG; u++) {
+            const bool in = e + 256 * u < ez;
+            edge(in ? e + 256 * u : e, in ? ci[u] : ci[0], fl[u], s4[u], c4[u]);
+        }
 #pragma unroll
         for (int u = 0; u < UG; u++) {
             if (e + 256 * u >= ez) break;
@@ -393,18 +410,18 @@ __global__ __launch_bounds__(1024, 8) void gg_k_edge_geo_fwd(GGEdgeGeoFwd p)
             *(float4 *)(ab + (size_t)(e + 256 * u) * 16 + 4 * q) = piece;
             // key in [0, N] = destination row - (b*N - 1); a row of ANOTHER cloud (never produced by the
             // index ops) goes to the global side buffer by its flat row
-            const long long li = fl[u] - ((long long)b * N - 1);
-            const int key = (li < 0 || li > N) ? -1 : (int)li;
+            const int li = fl[u] - keyoff;
+            const int key = (li < 0 || li > N) ? -1 : li;
+            const float mine = q == 0 ? g.y : (q == 1 ? g.z : g.w);                       // (q < 3)
             const float x0 = g.y * gF, x1 = g.z * gF, x2 = g.w * gF;
             const bool fits = fabsf(x0) < gthr && fabsf(x1) < gthr && fabsf(x2) < gthr;   // (false for NaN)
-            const float mine = q == 0 ? g.y : (q == 1 ? g.z : g.w);                       // (q < 3)
             if (key >= 0 && fits) {
                 if (q == 3) atomicAdd(&gc[key], 1);
                 else
                     atomicAdd((unsigned long long *)(q == 0 ? &gx[key] : (q == 1 ? &gy[key] : &gz[key])),
                               (unsigned long long)gg_fix_i64(mine * gF));
             } else {
-                atomicAdd(&p.fgs[fl[u] * 4 + q], q == 3 ? 1.f : mine);
+                atomicAdd(&p.fgs[(size_t)fl[u] * 4 + q], q == 3 ? 1.f : mine);
             }
             if (q < 3) { g4[0] += mine * g.y; g4[1] += mine * g.z; g4[2] += mine * g.w; g4[3] += mine; }
         }
