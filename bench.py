@@ -315,8 +315,9 @@ def main():
                          "(parity path, the headline), bf16 = bf16 MFMA operands with fp32 storage, "
                          "accumulation and statistics (BASELINE configs[2] 'bf16 MLP / fp32 indices')")
     ap.add_argument("--switch", action="append", default=[],
-                    help="NAME=0|1: a path switch of grid_gcn_amd.train_ops (A/B measurements, e.g. "
-                         "NOZ_ATT_BWD=0); the defaults are what is shipped and reported")
+                    help="NAME=0|1: a path switch of grid_gcn_amd.train_ops (e.g. NOZ_ATT_BWD=0) or a "
+                         "gridgcn_set_option name (COL_SPLIT, INDEX_SMALL, ATT_BWD_FUSED) for A/B measurements; "
+                         "the defaults are what is shipped and reported")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -336,6 +337,10 @@ def main():
     _tops.set_mlp_precision("bf16" if a.dtype == "bf16" else "fp32")
     for sw in a.switch:
         name, val = sw.split("=")
+        from grid_gcn_amd import _lib as _glib
+        if hasattr(_glib, "OPT_" + name):       # a kernel-selection option of the library (gridgcn_set_option)
+            _glib.check(_glib.load().gridgcn_set_option(getattr(_glib, "OPT_" + name), int(val)), "set_option")
+            continue
         assert isinstance(getattr(_tops, name), bool), name
         setattr(_tops, name, bool(int(val)))
 
