@@ -143,6 +143,44 @@ __global__ __launch_bounds__(256) void gg_k_cat_mask(const float *__restrict__ a
     }
 }
 
+// 16-byte form: every width, stride and pointer a multiple of four floats (the layer boundaries of the shipped
+// nets: 4 + C columns); one float4 of either output per thread, no per-element division
+__global__ __launch_bounds__(256) void gg_k_cat_mask4(const float *__restrict__ a, int lda, int ca,
+                                                      const float *__restrict__ b, int ldb, int cb,
+                                                      const float *__restrict__ mask,
+                                                      float *__restrict__ out, int ldo,
+                                                      float *__restrict__ out2, int ldo2, unsigned total4)
+{
+    const unsigned ldt4 = (unsigned)(ldo + ldo2) >> 2;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const unsigned r = i / ldt4;
+        int c = (int)(i - r * ldt4) * 4;
+        float *dst = out + (size_t)r * ldo + c;
+        if (c >= ldo) { c -= ldo; dst = out2 + (size_t)r * ldo2 + c; }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < ca) v = *(const float4 *)(a + (size_t)r * lda + c);
+        else if (c < ca + cb) {
+            v = *(const float4 *)(b + (size_t)r * ldb + (c - ca));
+            if (mask) { const float m = mask[r]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+        }
+        *(float4 *)dst = v;
+    }
+}
+
+// data = concat(xyz, 1) (+ its 8-float padded copy): one thread per point
+__global__ __launch_bounds__(256) void gg_k_xyz1(const float *__restrict__ a, int lda, float *__restrict__ out,
+                                                 float *__restrict__ out2, long long E)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= E) return;
+    const float4 v = make_float4(a[r * lda], a[r * lda + 1], a[r * lda + 2], 1.f);
+    *(float4 *)(out + r * 4) = v;
+    if (out2) {
+        *(float4 *)(out2 + r * 8) = v;
+        *(float4 *)(out2 + r * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // backward of the above: out[r, :] = (g1[r, col0:col0+C] + g2[r, col0:col0+C]) * mask[r]
 // (g1 / g2: gradients of the two outputs, either may be nullptr)
 template <typename I>
@@ -161,18 +199,51 @@ __global__ __launch_bounds__(256) void gg_k_mask_sum(const float *__restrict__ g
     }
 }
 
+__global__ __launch_bounds__(256) void gg_k_mask_sum4(const float *__restrict__ g1, int ld1,
+                                                      const float *__restrict__ g2, int ld2, int col0, int C,
+                                                      const float *__restrict__ mask,
+                                                      float *__restrict__ out, unsigned total4)
+{
+    const unsigned C4 = (unsigned)C >> 2;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const unsigned r = i / C4;
+        const int c = (int)(i - r * C4) * 4 + col0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g1) v = *(const float4 *)(g1 + (size_t)r * ld1 + c);
+        if (g2) {
+            const float4 u = *(const float4 *)(g2 + (size_t)r * ld2 + c);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (mask) { const float m = mask[r]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+        *(float4 *)(out + (size_t)i * 4) = v;
+    }
+}
+
+static bool gg_al16(const void *p) { return ((size_t)p & 15) == 0; }
+
 int gg_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb, const float *mask,
                 float *out, int ldo, float *out2, int ldo2, long long E, hipStream_t st)
 {
-    const long long total = E * (ldo + (out2 ? ldo2 : 0));
+    if (!out2) ldo2 = 0;
+    const long long total = E * (ldo + ldo2);
+    if (!b && ca == 3 && cb == 1 && ldo == 4 && (!out2 || ldo2 == 8) && gg_al16(out) && gg_al16(out2)) {
+        gg_k_xyz1<<<(int)((E + 255) / 256), 256, 0, st>>>(a, lda, out, out2, E);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
+    if (b && !((lda | ca | ldb | cb | ldo | ldo2) & 3) && gg_al16(a) && gg_al16(b) && gg_al16(out) && gg_al16(out2) &&
+        total < (1ll << 33)) {
+        const unsigned total4 = (unsigned)(total >> 2);
+        const unsigned nb = (total4 + 255) / 256;
+        gg_k_cat_mask4<<<(int)(nb < 16384 ? nb : 16384), 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
+                                                                       ldo2, total4);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     const long long nb = (total + 255) / 256;
     const int grid = (int)(nb < 8192 ? nb : 8192);
     if (total < (1ll << 31))
-        gg_k_cat_mask<unsigned><<<grid, 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
-                                                      out2 ? ldo2 : 0, total);
+        gg_k_cat_mask<unsigned><<<grid, 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2, ldo2, total);
     else
-        gg_k_cat_mask<long long><<<grid, 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2,
-                                                       out2 ? ldo2 : 0, total);
+        gg_k_cat_mask<long long><<<grid, 256, 0, st>>>(a, lda, ca, b, ldb, cb, mask, out, ldo, out2, ldo2, total);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
@@ -180,6 +251,13 @@ int gg_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, in
                 float *out, long long E, hipStream_t st)
 {
     const long long total = E * C;
+    if (!((C | col0 | (g1 ? ld1 : 0) | (g2 ? ld2 : 0)) & 3) && gg_al16(g1) && gg_al16(g2) && gg_al16(out) &&
+        total < (1ll << 33)) {
+        const unsigned total4 = (unsigned)(total >> 2);
+        const unsigned nb = (total4 + 255) / 256;
+        gg_k_mask_sum4<<<(int)(nb < 16384 ? nb : 16384), 256, 0, st>>>(g1, ld1, g2, ld2, col0, C, mask, out, total4);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
     const long long nb = (total + 255) / 256;
     const int grid = (int)(nb < 8192 ? nb : 8192);
     if (total < (1ll << 31))

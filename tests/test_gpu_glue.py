@@ -102,7 +102,9 @@ def test_adam_state_dict_round_trip_and_tensor_lr():
 
 
 @pytest.mark.parametrize("ca,cb,mask,pad", [(4, 64, True, True), (4, 128, True, False), (4, 256, False, True),
-                                            (3, None, False, True), (4, 12, True, True), (4, 4, True, True)])
+                                            (3, None, False, True), (3, None, False, False), (4, 12, True, True),
+                                            (4, 4, True, True), (3, 5, True, True), (4, 6, False, False),
+                                            (5, 64, True, True)])
 def test_cat_mask_matches_torch(ca, cb, mask, pad):
     from grid_gcn_amd import train_ops
     torch.manual_seed(ca * 100 + (cb or 0))
