@@ -545,6 +545,9 @@ int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st)
 // forward kernel, with the channels as contraction index.  Epilogue: store dX and accumulate the
 // BatchNorm-backward sums of the PREVIOUS layer (its raw output Aprev read in the C/D layout).
 //   dz = scale*dyr - scale*m1 - scale*rstd*m2*(z - mean),   dyr = dy * (z*scale + shift > 0)
+#ifndef GG_DX_RING8
+#define GG_DX_RING8 3      // register sets in flight at 7-8 column tiles (128 accumulator registers)
+#endif
 // NT = ceil(ndx/32) column tiles, NTV = its vector width in Wdx (1/2/4/8).
 // CS (column split, few row tiles): as in the forward kernel -- gridDim.y column groups of NT tiles, each
 // forming dZ itself; p.dx_wstride = vector width of the packed operand (1/2/4/8).
@@ -683,7 +686,12 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             // loop before round 3 ran load burst -> s_waitcnt vmcnt(0) -> MFMAs, i.e. HBM time plus
             // MFMA time.  The arg-max bytes are loaded unconditionally (dense: harmless bytes of Z) and
             // applied by the same select as the ReLU mask.
-            constexpr int QS = NT == 1 ? 2 : (NT <= 4 ? 4 : (NT <= 6 ? 2 : 1));   // (registers: 16 NT accumulators + two sets)
+            // Round 4: at 7-8 column tiles a RING of three one-quad sets (a set is consumed in 32 MFMAs = 0.85 us,
+            // less than a memory latency under load: with one set ahead the pipe idled a third of the time):
+            // 547 -> 525 us at cfg4's 128 -> 256 layer.  Four sets spilled 29 registers (552 us); at 3-4 tiles a
+            // ring of four two-quad sets instead of two four-quad ones was slower (306 -> 337 us).
+            constexpr int QS = NT == 1 ? 2 : (NT <= 4 ? 4 : (NT <= 6 ? 2 : 1));
+            constexpr int NS = NT <= 6 ? 2 : GG_DX_RING8;
             struct Set { float4 z[QS], g[QS]; unsigned am[QS]; };
             auto ldset = [&](Set &S, int u) {
 #pragma unroll
@@ -712,18 +720,20 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
                 }
             };
             const int nset = nfull * 4 / QS;
-            Set SA, SB;
-            if (nset > 0) ldset(SA, 0);
-            for (int u = 0; u < nset; u += 2) {
-                ldset(SB, u + 1 < nset ? u + 1 : u);           // (last: a harmless re-read)
-                __builtin_amdgcn_sched_barrier(0);
-                mmset(SA, u);
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < nset) {
-                    ldset(SA, u + 2 < nset ? u + 2 : u + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mmset(SB, u + 1);
-                    __builtin_amdgcn_sched_barrier(0);
+            Set S[NS];
+#pragma unroll
+            for (int j = 0; j < NS - 1; j++)
+                if (j < nset) ldset(S[j], j);
+            for (int u = 0; u < nset; u += NS) {
+#pragma unroll
+                for (int j = 0; j < NS; j++) {
+                    if (u + j < nset) {                                      // (wave uniform)
+                        const int un = u + j + NS - 1;
+                        ldset(S[(j + NS - 1) % NS], un < nset ? un : nset - 1);   // (past the end: a harmless re-read)
+                        __builtin_amdgcn_sched_barrier(0);
+                        mmset(S[j], u + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             s = nfull * 16;
@@ -767,9 +777,8 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             }
         }
         const int nrows = (p.E - r0 < 32) ? (int)(p.E - r0) : 32;
-        if (nrows == 32 && !p.drop_thr) {
-            // Full row block, no Dropout (every call of the conv stacks but the last block and the
-            // head): straight-line stores.  The row/column-tile part of every address is wave
+        if (nrows == 32) {
+            // Full row block: straight-line stores.  The row/column-tile part of every address is wave
             // uniform (r0 comes from a readfirstlane'd tile number) and lives in scalar registers,
             // a lane adds its constant (4h rows + its column): no per-element address arithmetic,
             // no per-row branches.  (The general form below cost ~30 VALU instructions per element:
@@ -777,6 +786,20 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             const gg_rsrc xs = gg_make_rsrc(p.dX + (r0 * ldx + dx_col0));
             const gg_rsrc as = gg_make_rsrc(p.Aprev + (r0 * ldx + dx_col0));
             const unsigned lo = (unsigned)(4 * h * ldx + (lane & 31)) * 4u;
+            // Dropout of the input activation (the class-score conv of the head: the only call with it) in
+            // this form too -- the general form below took that launch 313 us for 840 MB and 5 GFLOP.  The
+            // mask is the element's hash as everywhere (gg_drop_keep of row * ldx + column).
+            const bool drop = p.drop_thr != 0;
+            const unsigned long long idx0 = (unsigned long long)((r0 + 4 * h) * ldx + dx_col0 + (lane & 31));
+            if (drop) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const unsigned long long e = idx0 + (unsigned long long)(((r & 3) + 8 * (r >> 2)) * ldx + t * 32);
+                        acc[t][r] = gg_drop_keep(e, drop_lo, drop_hi, p.drop_thr) ? acc[t][r] * p.drop_scale : 0.f;
+                    }
+            }
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 if (dx_col0 + t * 32 + (lane & 31) < p.ndx) {
