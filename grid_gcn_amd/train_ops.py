@@ -831,11 +831,6 @@ def cat_mask(a, b, mask=None, pad=False):
     return out, (out2 if out2 is not None else out)
 
 
-def cat_mask_supported(a, b):
-    return (a.is_cuda and a.dtype == torch.float32 and not a.requires_grad
-            and (b is None or (b.is_cuda and b.dtype == torch.float32)))
-
-
 def _dw_direct_ok(C, cin):
     """mirror of gg_dw_direct_cfg (csrc/gridgcn_direct.hip): shapes the register-direct dW kernel
     takes (the dX kernel additionally needs C % 8 == 0, i.e. a packed Wdx)."""

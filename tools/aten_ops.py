@@ -15,7 +15,8 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 net = model.GGCNSeg(model.SEG_81920).to(dev).train()
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+from grid_gcn_amd import optim  # noqa: E402
+opt = optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
 data, npn = synth.make_batch(8, 81920, "planes")
 x = torch.from_numpy(data[..., :3].copy()).to(dev)
 n = torch.from_numpy(npn).to(dev)
@@ -32,7 +33,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(K):
         step()
     torch.cuda.synchronize()
@@ -63,16 +64,4 @@ for k, (cnt, dt) in sorted(byop.items(), key=lambda kv: -kv[1][1]):
     n += cnt; t += dt
 print("aten total: %.1f launches, %.1f us per step" % (n / K, t / K))
 
-# ... and where in this package each of them is issued (innermost frames of the package / bench)
-print("---- aten ops by call site")
-bysite = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=14):
-    dt = getattr(ev, "self_device_time_total", 0.0)
-    if dt <= 0 or not ev.key.startswith("aten::"):
-        continue
-    fr = [f for f in ev.stack if "grid_gcn_amd" in f or "aten_ops.py" in f or "optim" in f]
-    site = " < ".join(x.split("/")[-1].strip() for x in fr[:3]) or "?"
-    bysite[(ev.key, site, str(ev.input_shapes)[:60])][0] += ev.count
-    bysite[(ev.key, site, str(ev.input_shapes)[:60])][1] += dt
-for (k, site, shp), (cnt, dt) in sorted(bysite.items(), key=lambda kv: -kv[1][1]):
-    print("%7.1f us n=%4.1f %-16s %s  %s" % (dt / K, cnt / K, k, site, shp))
+# (where each of them is issued: tools/aten_sites.py)

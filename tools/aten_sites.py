@@ -11,7 +11,7 @@ import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from grid_gcn_amd import model, synth  # noqa: E402
+from grid_gcn_amd import model, optim, synth  # noqa: E402
 
 VIEWS = ("view", "reshape", "slice", "select", "detach", "t.", "transpose", "permute", "expand", "as_strided",
          "alias", "unsqueeze", "squeeze", "_unsafe_view", "empty", "new_empty", "split", "unbind", "narrow",
@@ -24,7 +24,7 @@ torch.manual_seed(0)
 N = 81920 if cfg == "cfg4" else 8192
 B = 8 if cfg == "cfg4" else 32
 net = model.GGCNSeg(model.SEG_81920 if cfg == "cfg4" else model.SEG_8192).to(dev).train()
-opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+opt = optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)        # (what bench.py times)
 data, npn = synth.make_batch(B, N, "planes")
 x = torch.from_numpy(data[..., :3].copy()).to(dev)
 n = torch.from_numpy(npn).to(dev)
