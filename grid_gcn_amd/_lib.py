@@ -15,6 +15,7 @@ OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
 OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK
 OPT_INDEX_SMALL = 3             # GRIDGCN_OPT_INDEX_SMALL
 OPT_COL_SPLIT = 4               # GRIDGCN_OPT_COL_SPLIT
+OPT_PAIRMAX_SPLIT = 5           # GRIDGCN_OPT_PAIRMAX_SPLIT
 
 EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",

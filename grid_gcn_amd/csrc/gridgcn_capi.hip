@@ -40,6 +40,7 @@ int gg_colsum(const float *, long long, int, int, double *, float *, hipStream_t
 size_t gg_ball_grid_workspace(int B, int m);
 int gg_ball_knn_grid(const float *, const float *, const int *, const int *, int, int, int, int,
                      float, int *, void *, hipStream_t, int su = 3, int sk = 3, int ztail = 0);
+extern int gg_pairmax_split;        // gridgcn_pairmax.hip (GRIDGCN_OPT_PAIRMAX_SPLIT)
 int gg_cat_mask(const float *a, int lda, int ca, const float *b, int ldb, int cb, const float *mask,
                 float *out, int ldo, float *out2, int ldo2, long long E, hipStream_t st);
 int gg_mask_sum(const float *g1, int ld1, const float *g2, int ld2, int col0, int C, const float *mask,
@@ -155,6 +156,11 @@ int gridgcn_set_option(int option, int value)
         gg_set_col_split(value);
         return GRIDGCN_OK;
     }
+    if (option == GRIDGCN_OPT_PAIRMAX_SPLIT) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return GRIDGCN_EINVAL;
+        gg_pairmax_split = value;
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
@@ -165,6 +171,7 @@ int gridgcn_get_option(int option)
     if (option == GRIDGCN_OPT_INDEX_CHUNK) return gg_index_get_tuning(1);
     if (option == GRIDGCN_OPT_INDEX_SMALL) return gg_index_get_tuning(2);
     if (option == GRIDGCN_OPT_COL_SPLIT) return gg_get_col_split();
+    if (option == GRIDGCN_OPT_PAIRMAX_SPLIT) return gg_pairmax_split;
     return -1;
 }
 

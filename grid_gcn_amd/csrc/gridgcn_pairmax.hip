@@ -613,6 +613,8 @@ int gg_pairmax_fwd_src(const float *Ysrc, const int *nebidx, const float *att16,
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+int gg_pairmax_split = 0;          // GRIDGCN_OPT_PAIRMAX_SPLIT: 0 = by size
+
 int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const float *shp,
                    const float *sca, const float *sha, long long ncent, int P, int C, float *agg,
                    int lda, unsigned char *amax, float *zsel, hipStream_t st)
@@ -622,6 +624,7 @@ int gg_pairmax_fwd(const float *Zp, const float *Za, const float *scp, const flo
         const long long total4 = ncent * (C / 4);
         int ps = 1;
         while (ps < 8 && total4 * ps < 524288 && P >= 8 * ps) ps *= 2;
+        if (gg_pairmax_split) ps = gg_pairmax_split;
         if (ps > 1) {
             const long long nwave = (total4 + 64 / ps - 1) / (64 / ps);
             const long long nbs = (nwave + 3) / 4;

@@ -94,6 +94,9 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                         *     tile is one serial MFMA chain per wave; such layers have too few
                                         *     tiles to fill the chip); 0 = one wave owns whole rows.  Same
                                         *     arithmetic per element: identical results. */
+#define GRIDGCN_OPT_PAIRMAX_SPLIT 5    /* [0] lanes per (centre, 4 channels) of gridgcn_pairmax_fwd: 0 = chosen from
+                                        *     the layer's size, 1 / 2 / 4 / 8 forced (tuning; the first arg max is
+                                        *     exact for every setting). */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 
