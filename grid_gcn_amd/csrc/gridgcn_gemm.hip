@@ -127,7 +127,15 @@ __global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     const float *ap = p.A + m, *bp = p.B + n;
     long long k = ka + h;                                          // this half-wave's row of a step
-    // eight steps (16 rows) with their loads issued together; uniform trip count (MFMAs need every lane)
+    // sixteen, then eight steps (32 / 16 rows) with their loads issued together; uniform trip counts (MFMAs need
+    // every lane).  (A wave's 64 rows were four rounds of eight steps: four memory latencies in a 20-us kernel.)
+    for (; (k - h) + 31 < kz; k += 32) {
+        float a[16], b[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { a[i] = ap[(size_t)(k + 2 * i) * p.lda]; b[i] = bp[(size_t)(k + 2 * i) * p.ldb]; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
+    }
     for (; (k - h) + 15 < kz; k += 16) {
         float a[8], b[8];
 #pragma unroll
@@ -176,30 +184,32 @@ __global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
         __syncthreads();
         if (!s_last) return;
     }
-    // the last arriver: slices 0..S-1 in order; 256 threads x 4 elements of the tile
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-        float s;
-        if (S > 1) {
-            s = 0.f;
-            const float *q = p.part + (size_t)tile * S * 1024 + e;
-            int zz = 0;
-            for (; zz + 8 <= S; zz += 8) {                 // eight loads in flight, added in order
-                float v[8];
+    // the last arriver: slices 0..S-1 in order; 256 threads x 4 CONSECUTIVE elements of the tile, one 16-byte
+    // load per slice and eight slices in flight (behind the acquire above plain loads are valid: MI355X_MICROARCH,
+    // "consumer: one agent acquire -> __syncthreads() -> plain loads").  One element at a time -- 4 x 8 rounds of
+    // dword loads for 64 slices -- was 16 of this kernel's 28 us at 16 K rows.
+    if (S > 1) {
+        const int e = threadIdx.x * 4;
+        const float *q = p.part + (size_t)tile * S * 1024 + e;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int zz = 0;
+        for (; zz + 8 <= S; zz += 8) {
+            float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    v[u] = __hip_atomic_load(&q[(size_t)(zz + u) * 1024], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 8; u++) v[u] = *(const float4 *)(q + (size_t)(zz + u) * 1024);
 #pragma unroll
-                for (int u = 0; u < 8; u++) s += v[u];
-            }
-            for (; zz < S; zz++)
-                s += __hip_atomic_load(&q[(size_t)zz * 1024], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            // (one slice: wave 0 holds the tile; hand it over through LDS)
-            s = 0.f;
+            for (int u = 0; u < 8; u++) { s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w; }
+        }
+        for (; zz < S; zz++) {
+            const float4 v = *(const float4 *)(q + (size_t)zz * 1024);
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
         }
         const int r = e >> 6, ln = e & 63;
         const int row = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = tn * 32 + (ln & 31);
-        if (S > 1 && row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = s;
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (row < p.M && col + i < p.N) p.C[(size_t)row * p.ldc + col + i] = sv[i];
     }
     if (S == 1 && wave == 0) {
 #pragma unroll
