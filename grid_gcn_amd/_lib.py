@@ -51,6 +51,7 @@ EXPORTS = [
     "gridgcn_cat_mask", "gridgcn_mask_sum", "gridgcn_adam_step",
     "gridgcn_edge_geo_forward_workspace_bytes", "gridgcn_edge_geo_forward",
     "gridgcn_edge_lin0_backward_sparse_geo", "gridgcn_linear_fwd_direct_fin",
+    "gridgcn_linear_fwd_direct_drop", "gridgcn_linear_dw_drop",
 ]
 
 
@@ -156,6 +157,12 @@ def load():
     lib.gridgcn_linear_fwd_ld.argtypes = [vp, ll, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     lib.gridgcn_linear_fwd_direct_ld.restype = ci
     lib.gridgcn_linear_fwd_direct_ld.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, vp]
+    lib.gridgcn_linear_fwd_direct_drop.restype = ci
+    lib.gridgcn_linear_fwd_direct_drop.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, ctypes.c_float,
+                                                   ctypes.c_uint64, vp, vp]
+    lib.gridgcn_linear_dw_drop.restype = ci
+    lib.gridgcn_linear_dw_drop.argtypes = [vp] * 11 + [ll, ci, ci, ctypes.c_float, ctypes.c_uint64, vp, vp, vp,
+                                           cs, vp]
     lib.gridgcn_linear_fwd_direct_fin.restype = ci
     lib.gridgcn_linear_fwd_direct_fin.argtypes = [vp, ll, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci,
                                                   ctypes.POINTER(BnFin), vp]

@@ -772,6 +772,49 @@ int gridgcn_linear_fwd_direct_fin(const float *X, long long E, int K, int ldx, c
     return rc == 1 ? GRIDGCN_EINVAL : rc;
 }
 
+int gridgcn_linear_fwd_direct_drop(const float *X, long long E, int K, int ldx, const float *Wq,
+                                   const float *b, int ldw, int cout, const float *scale,
+                                   const float *shift, float *Z, float drop_p, uint64_t drop_seed,
+                                   const uint64_t *drop_seed_dev, void *stream)
+{
+    if (!X || !Wq || !b || !Z || !scale || !shift || cout < 1 || cout > 32 || cout > ldw || ldx < K ||
+        (ldx & 3) || ((uintptr_t)X & 15) || (K & 31) || E < 1 || !(drop_p > 0.f && drop_p < 1.f))
+        return GRIDGCN_EINVAL;
+    GGLinFwd p;
+    p.X = X; p.W = Wq; p.b = b; p.scale = scale; p.shift = shift; p.Z = Z; p.sums = nullptr;
+    p.E = E; p.cin = K; p.K = K; p.ldw = ldw; p.cout = cout; p.lda = ldx;
+    gg_drop_consts(drop_p, &p.drop_thr, &p.drop_scale);
+    if (!p.drop_thr) return GRIDGCN_EINVAL;
+    p.drop_lo = (unsigned)drop_seed; p.drop_hi = (unsigned)(drop_seed >> 32);
+    p.drop_dev = (const unsigned long long *)drop_seed_dev;
+    int rc = gg_linear_fwd_direct(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_linear_dw_drop(const float *dY, const float *Z, const float *scale, const float *shift,
+                           const float *mean, const float *rstd, const float *m1, const float *m2,
+                           const float *Aprev, const float *pscale, const float *pshift, long long E, int C,
+                           int cin, float drop_p, uint64_t drop_seed, const uint64_t *drop_seed_dev,
+                           float *dW, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!dY || !Z || !scale || !shift || !mean || !rstd || !m1 || !m2 || !Aprev || !pscale || !pshift || !dW ||
+        E < 1 || C < 1 || cin < 1 || !(drop_p > 0.f && drop_p < 1.f))
+        return GRIDGCN_EINVAL;
+    const size_t need = gg_linear_dw_direct_workspace(E, cin, C);
+    if (!need) return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < need) return GRIDGCN_EWORKSPACE;
+    GGLinBwd p = {};
+    p.dY = dY; p.Z = Z; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.m1 = m1; p.m2 = m2;
+    p.Aprev = Aprev; p.pscale = pscale; p.pshift = pshift; p.pmean = pscale; p.prstd = pscale;   // (unused by dW)
+    p.dWpart = (float *)workspace; p.dW = dW; p.E = E; p.C = C; p.cin = cin; p.cin_w = cin; p.ldy = C; p.P = 1;
+    gg_drop_consts(drop_p, &p.drop_thr, &p.drop_scale);
+    if (!p.drop_thr) return GRIDGCN_EINVAL;
+    p.drop_lo = (unsigned)drop_seed; p.drop_hi = (unsigned)(drop_seed >> 32);
+    p.drop_dev = (const unsigned long long *)drop_seed_dev;
+    const int rc = gg_linear_dw_direct(p, (hipStream_t)stream);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
 int gridgcn_linear_fwd_direct(const float *X, long long E, int K, int ldx, const float *Wq,
                               const float *b, int ldw, int cout, const float *scale,
                               const float *shift, float *Z, double *sums, void *stream)

@@ -133,9 +133,17 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 // columns of NT tiles each -- a row tile is ONE serial chain of NT * K / 2 MFMAs per wave, and a layer of
 // 2 K - 6 K rows has too few of them to fill the chip; every column group re-reads the
 // rows (nothing at these sizes) and owns its columns of Z, of the bias and of the statistics.
-template <int NT, bool WLDS, bool EXACT, bool BF16 = false, bool CS = false>
+// DROP (one column tile, fp32): Dropout of the activated input while it is loaded (GGLinFwd.drop_*).
+template <int NT, bool WLDS, bool EXACT, bool BF16 = false, bool CS = false, bool DROP = false>
 __global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024)))) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
+    static_assert(!DROP || (NT == 1 && !BF16 && !CS), "Dropout prologue: one column tile, fp32");
+    unsigned drop_lo = p.drop_lo, drop_hi = p.drop_hi;
+    if (DROP && p.drop_dev) {        // graph replay: the dropout seed advances through a device scalar
+        const unsigned long long sd = (((unsigned long long)drop_hi << 32) | drop_lo) + *p.drop_dev;
+        drop_lo = (unsigned)sd;
+        drop_hi = (unsigned)(sd >> 32);
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int K = p.K, h = lane >> 5;
@@ -246,6 +254,19 @@ __global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 
                     for (int q = 0; q < 4; q++)
                         a[q] = gg_bnrelu4(a[q], *(const float4 *)(scl + k0 + 4 * q),
                                           *(const float4 *)(scl + K + k0 + 4 * q));
+                }
+                if constexpr (DROP) {
+                    // the mask of element (row, k): the hash every reader of this activation evaluates
+                    // (gg_k_bn_apply when the dropped copy is written, the dX epilogue in the backward)
+                    const unsigned long long e0 = (unsigned long long)row * (unsigned long long)K + (unsigned)k0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float *av = &a[q].x;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            av[i] = gg_drop_keep(e0 + (unsigned)(4 * q + i), drop_lo, drop_hi, p.drop_thr)
+                                        ? av[i] * p.drop_scale : 0.f;
+                    }
                 }
                 // the weight fragment of step st + 1 is read from LDS before the MFMAs of step st (read
                 // right in front of its use, every group of NT MFMAs began with an LDS round trip)
@@ -496,6 +517,26 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
     if (nb > 256) nb = 256;
     const bool exact = q.cout == NT * 32;
     const size_t w16 = (size_t)((q.K / 2 + 7) / 8) * 64 * NT * 16;
+    if (q.drop_thr) {
+        // Dropout prologue: the class-score conv (one column tile, fp32, K a multiple of 32, weights in LDS)
+        if constexpr (NT == 1) {
+            if (g_mlp_bf16 || (q.K & 31) || wbytes + sbytes > 156 * 1024 || !q.scale || q.X2 || q.zfmt) return 1;
+            static bool attr_d = false;
+            if (!attr_d) {
+                if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<1, true, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<1, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return 3;
+                attr_d = true;
+            }
+            size_t ld = wbytes + sbytes;
+            if (ld < rbytes) ld = rbytes;
+            if (exact) gg_k_linear_fwd_direct<1, true, true, false, false, true><<<(int)nb, threads, ld, st>>>(q);
+            else gg_k_linear_fwd_direct<1, true, false, false, false, true><<<(int)nb, threads, ld, st>>>(q);
+            return hipGetLastError() == hipSuccess ? 0 : 3;
+        } else {
+            return 1;
+        }
+    }
     // bf16 only behind a BatchNorm+ReLU (q.scale): the FIRST conv of a stack sees raw coordinates /
     // geometric features (|mean| / sigma ~ 30 for the attention inputs), which 8 mantissa bits destroy
     if (g_mlp_bf16 && q.scale && w16 + sbytes <= 156 * 1024) {
@@ -1012,11 +1053,20 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st)
 #ifndef GG_DW_D16
 #define GG_DW_D16 6      // register sets of the 16-tile form (one wave per SIMD: depth instead of partners)
 #endif
-template <int MT, int NQ, int NP, int NS, bool BF16 = false, bool SP = false>
+// DROP: the B operand is the DROPPED activation of the layer in front -- Dropout applied on the fly to
+// relu(bn(Aprev)) (GGLinBwd.drop_*: element idx = row * cin + column, gg_drop_keep), as the dX epilogue applies
+// it to the gradient -- so that no dropped copy of that activation exists (the class-score conv of the head).
+template <int MT, int NQ, int NP, int NS, bool BF16 = false, bool SP = false, bool DROP = false>
 __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) void gg_k_linear_dw_direct(
     GGLinBwd p, int MG, int RS, long long rows_per_wg, int *__restrict__ tick, int ntick, int lds_red)
 {
     constexpr int NJ = 4 * NQ + 2 * NP + NS;
+    unsigned drop_lo = p.drop_lo, drop_hi = p.drop_hi;
+    if (DROP && p.drop_dev) {        // graph replay: the dropout seed advances through a device scalar
+        const unsigned long long sd = (((unsigned long long)drop_hi << 32) | drop_lo) + *p.drop_dev;
+        drop_lo = (unsigned)sd;
+        drop_hi = (unsigned)(sd >> 32);
+    }
     typedef float v2f __attribute__((ext_vector_type(2)));
     // (the wave number is the same in all lanes: everything derived from it -- the wave's row range,
     //  its m-group -- lives in scalar registers)
@@ -1083,6 +1133,7 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
         float z[MT], g[MT], x[NJ];
         int am[MT], pp;
         bool ok;
+        long long row;                    // (DROP only: the row of the lane's B operand)
     };
     long long cen = 0;
     int pp = 0;
@@ -1099,6 +1150,7 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
         const long long row = ra + 2 * s + h;
         R.ok = row < rb;
         const long long rw = R.ok ? row : (p.E - 1);
+        if constexpr (DROP) R.row = rw;
         const float *zr = p.Z + rw * ldz + chl;
         const long long cc = R.ok ? cen : 0;
         const float *gr = sparse ? p.gval + cc * C + chl : p.dY + rw * p.ldy + chl;
@@ -1156,6 +1208,12 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
             xa[j + 1] = fmaxf(y.y, lo);
         }
         if (NJ & 1) xa[NJ - 1] = fmaxf(__builtin_fmaf(R.x[NJ - 1], psc[NJ - 1], psh[NJ - 1]), lo);
+        if constexpr (DROP) {
+            const unsigned long long e0 = (unsigned long long)R.row * (unsigned long long)cin;
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                xa[j] = gg_drop_keep(e0 + (unsigned)col[j], drop_lo, drop_hi, p.drop_thr) ? xa[j] * p.drop_scale : 0.f;
+        }
     };
     auto compute = [&](const Regs &R) {
         float dz[MT], xa[NJ];
@@ -1185,6 +1243,7 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
     const unsigned vxp = (unsigned)(h * cin + NQ * 128 + 2 * cq) * 4u;
     const unsigned vxs = (unsigned)(h * cin + scol) * 4u;
     unsigned vg = 0, va = 0, sz = 0, sx = 0, sg = 0;   // (s*: scalar byte offsets of the next step)
+    long long rowv = 0;                                // (DROP: row of the lane in the next streamed step)
     const unsigned dz_ = 2u * ldz * 4u, dx_ = 2u * cin * 4u, dg_ = sparse ? 0u : 2u * p.ldy * 4u;
     const unsigned Cb = (unsigned)C;
     auto stream_init = [&](long long r1) {
@@ -1195,12 +1254,14 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
         vg = sparse ? (unsigned)(cen * C + chl) * 4u : (unsigned)(h * p.ldy + chl) * 4u;
         va = (unsigned)(cen * C + chl);
         sz = 0; sx = 0; sg = 0;
+        rowv = r1 + h;
     };
     auto stream_done = [&]() {                     // the generic steps continue from here
         if (sparse) cen = (long long)((va - (unsigned)chl) / Cb);
     };
     auto load_in = [&](Regs &R) {
         R.ok = true;
+        if constexpr (DROP) { R.row = rowv; rowv += 2; }
 #if defined(GG_DW_ABLATE) && (GG_DW_ABLATE & 2)      // no loads in the main rounds (operands: whatever the sets hold)
         asm volatile("" : "+v"(R.z[0]), "+v"(R.g[0]), "+v"(R.x[0]), "+v"(R.x[NJ - 1]));
         return;
@@ -1545,6 +1606,17 @@ static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
     }
 #define GG_DWL(BF, SPV)                                                                           \
     gg_k_linear_dw_direct<MT, NQ, NP, NS, BF, SPV><<<c.nwg, c.threads, ldsb, st>>>(p, c.MG, c.RS, c.rows_per_wg, tick, ntick, c.lds_red)
+    if (p.drop_thr) {
+        // Dropout on the B operand: the class-score conv's shape only (fp32, dense, 128 input columns)
+        if constexpr (MT == 1 && NQ == 1 && NP == 0 && NS == 0) {
+            if (g_mlp_bf16 || sp || !p.pscale) return 1;
+            gg_k_linear_dw_direct<1, 1, 0, 0, false, false, true><<<c.nwg, c.threads, ldsb, st>>>(
+                p, c.MG, c.RS, c.rows_per_wg, tick, ntick, c.lds_red);
+            return hipGetLastError() == hipSuccess ? 0 : 3;
+        } else {
+            return 1;
+        }
+    }
     if (bf && sp) GG_DWL(true, true);
     else if (bf) GG_DWL(true, false);
     else if (sp) GG_DWL(false, true);

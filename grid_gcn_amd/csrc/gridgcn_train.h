@@ -40,6 +40,12 @@ struct GGLinFwd {
     int *fin_ticket = nullptr;
     float eps = 0.f, momentum = 0.f;
     int fin_tail = 0;
+    // register-direct kernel, one column tile, fp32 only: Dropout of the activated input rows applied while
+    // they are loaded (element idx = row * K + k, gg_drop_keep; drop_thr 0 = off) -- the class-score conv of
+    // the segmentation head reads fc1's raw output and no activated / dropped copy of it exists
+    const unsigned long long *drop_dev = nullptr;
+    unsigned drop_thr = 0, drop_lo = 0, drop_hi = 0;
+    float drop_scale = 1.f;
 };
 
 struct GGLinBwd {

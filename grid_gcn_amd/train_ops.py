@@ -705,6 +705,7 @@ OWN_ADAM = True
 FOLD_FINALIZE = True
 # BatchNorm statistics of a single-layer point MLP from per-source counts and geo_vec sums
 SRC_STATS = True
+FUSE_DROPOUT = True     # head: Dropout evaluated inside fc2's forward / dW kernels (no dropped tensor)
 SRC_STATS_MIN_EDGES = 1 << 19     # (below: the edge pass is a 10-20 us launch, these are two)
 # geo_vec weight + bias table of the source-side first conv built by the prepack launch
 WGB_PREPACK = True
@@ -2369,19 +2370,30 @@ class _HeadTrain(torch.autograd.Function):
                                 x.shape[1] if ctx.needs_input_grad[0] else 0,
                                 prev_bn=prev.prev_bn()[:2] if prev is not None else None)
             C = st.Z[-1].shape[1]
-            Hd = torch.empty((E, C), dtype=torch.float32, device=dev)
-            _lib.check(lib.gridgcn_bn_relu_dropout_apply(
-                _ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]), _ptr(Hd), E, C, C,
-                float(p), int(seed), _ptr(seed_dev) if seed_dev is not None else None, stream),
-                "gridgcn_bn_relu_dropout_apply")
+            # the dropped activation is never stored when fc2's kernels can evaluate the mask themselves
+            # (fp32 mode, 128 columns: the segmentation head's shape)
+            fuse = (FUSE_DROPOUT and 0.0 < float(p) < 1.0 and C == 128 and E * C < 2 ** 32
+                    and lib.gridgcn_get_mlp_precision() == 0)
+            sd = _ptr(seed_dev) if seed_dev is not None else None
             K, ldw, nwp, nwb = packed_sizes(C2, C)
             ntv = next(v for v in (1, 2, 4, 8) if v * 32 >= C)
             _, Bp, Wb, _, Wq, Wdx = PACKS.get(lib, W2, b2, C2, C, 0, C, C, True,
                                               (0, ldw, nwb, C * ldw, Cp * 32 * ntv), stream)
             Z2 = torch.empty((E, Cp), dtype=torch.float32, device=dev)
-            _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(Hd), E, C, C, _ptr(Wq), _ptr(Bp), ldw,
-                                                     Cp, None, None, _ptr(Z2), None, stream),
-                       "gridgcn_linear_fwd_direct")
+            if fuse:
+                Hd = st.Z[-1].new_empty(0)
+                _lib.check(lib.gridgcn_linear_fwd_direct_drop(
+                    _ptr(st.Z[-1]), E, C, C, _ptr(Wq), _ptr(Bp), ldw, Cp, _ptr(st.scale[-1]),
+                    _ptr(st.shift[-1]), _ptr(Z2), float(p), int(seed), sd, stream),
+                    "gridgcn_linear_fwd_direct_drop")
+            else:
+                Hd = torch.empty((E, C), dtype=torch.float32, device=dev)
+                _lib.check(lib.gridgcn_bn_relu_dropout_apply(
+                    _ptr(st.Z[-1]), _ptr(st.scale[-1]), _ptr(st.shift[-1]), _ptr(Hd), E, C, C,
+                    float(p), int(seed), sd, stream), "gridgcn_bn_relu_dropout_apply")
+                _lib.check(lib.gridgcn_linear_fwd_direct(_ptr(Hd), E, C, C, _ptr(Wq), _ptr(Bp), ldw,
+                                                         Cp, None, None, _ptr(Z2), None, stream),
+                           "gridgcn_linear_fwd_direct")
         ctx.L = L
         ctx.prev = prev
         ctx.ndx = st.ndx
@@ -2428,11 +2440,19 @@ class _HeadTrain(torch.autograd.Function):
             nbytes = ctypes.c_size_t(0)
             lib.gridgcn_linear_bwd_workspace_bytes(E, C, Cp, ctypes.byref(nbytes))
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-            _lib.check(lib.gridgcn_linear_bwd(
-                _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
-                _ptr(ident[4]), _ptr(ident[5]), _ptr(Hd), None, None, None, None, _ptr(Wb2), None,
-                None, 0, E, Cp, C, C, 0, 0, None, _ptr(dW2), None, None, None, 0, _ptr(ws),
-                nbytes.value, st), "gridgcn_linear_bwd")
+            if Hd.numel() == 0:         # (fused Dropout: fc2's input is rebuilt from Z_fc1 and the mask)
+                _lib.check(lib.gridgcn_linear_dw_drop(
+                    _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
+                    _ptr(ident[4]), _ptr(ident[5]), _ptr(Zs[-1]), _ptr(scales[-1]), _ptr(shifts[-1]),
+                    E, Cp, C, ctx.drop[0], ctx.drop[1],
+                    _ptr(ctx.drop[2]) if ctx.drop[2] is not None else None,
+                    _ptr(dW2), _ptr(ws), nbytes.value, st), "gridgcn_linear_dw_drop")
+            else:
+                _lib.check(lib.gridgcn_linear_bwd(
+                    _ptr(dL), _ptr(Z2), _ptr(ident[0]), _ptr(ident[1]), _ptr(ident[2]), _ptr(ident[3]),
+                    _ptr(ident[4]), _ptr(ident[5]), _ptr(Hd), None, None, None, None, _ptr(Wb2), None,
+                    None, 0, E, Cp, C, C, 0, 0, None, _ptr(dW2), None, None, None, 0, _ptr(ws),
+                    nbytes.value, st), "gridgcn_linear_bwd")
             _lib.check(lib.gridgcn_colsum_f32(_ptr(dL), E, Cp, C2, _ptr(db64), _ptr(db2), st), "gridgcn_colsum")
             prev = ctx.prev
             r = _chain_backward(lib, x, Zs, scales, shifts, means, rstds, Wbs, Wgs, Wdxs,

@@ -72,7 +72,8 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  * 5: gridgcn_pairmax_bwd_masked, gridgcn_att_bwd_noz, gridgcn_gemm_bias, options 3 / 4
                                  * 6: gridgcn_pack_desc.wgb / geo, gridgcn_adam_step, gridgcn_cat_mask,
                                  *    gridgcn_mask_sum, gridgcn_ball_knn[_grid]_ld, gridgcn_bn_finalize_tail,
-                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward, gridgcn_edge_lin0_backward_sparse_geo, gridgcn_linear_fwd_direct_fin; psums of a dX launch with
+                                 *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward, gridgcn_edge_lin0_backward_sparse_geo, gridgcn_linear_fwd_direct_fin,
+                                 *    gridgcn_linear_fwd_direct_drop, gridgcn_linear_dw_drop, GRIDGCN_OPT_PAIRMAX_SPLIT; psums of a dX launch with
                                  *    nbn > 0 is [2][nbn] */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
@@ -434,6 +435,23 @@ int gridgcn_linear_fwd_direct_ld(const float *X, long long E, int K, int ldx, co
                                  const float *b, int ldw, int cout, const float *scale,
                                  const float *shift, void *Z, double *sums, int ldz, int zfmt,
                                  void *stream);
+/* Dropout without a dropped tensor (the class-score conv of the segmentation head, ggcn_models_g.py:36-38:
+ * fc1 -> Dropout -> fc2).  gridgcn_linear_fwd_direct_drop: Z = dropout(relu(X * scale + shift)) * W + b with the
+ * mask evaluated while the rows are loaded (cout <= 32, K % 32 == 0, fp32 mode); gridgcn_linear_dw_drop:
+ * dW[C][cin] = dZ^T dropout(relu(Aprev * pscale + pshift)) with dZ formed from (dY, Z, scale .. m2) as in
+ * gridgcn_linear_bwd (cin == 128, C <= 32; workspace: gridgcn_linear_bwd_workspace_bytes).  The mask of element
+ * (row, column) is the hash of row * K + column and (drop_seed + *drop_seed_dev) that
+ * gridgcn_bn_relu_dropout_apply and gridgcn_linear_dx evaluate: the three agree bit for bit.  Other shapes:
+ * GRIDGCN_EINVAL (use gridgcn_bn_relu_dropout_apply + the plain entries). */
+int gridgcn_linear_fwd_direct_drop(const float *X, long long E, int K, int ldx, const float *Wq,
+                                   const float *b, int ldw, int cout, const float *scale,
+                                   const float *shift, float *Z, float drop_p, uint64_t drop_seed,
+                                   const uint64_t *drop_seed_dev, void *stream);
+int gridgcn_linear_dw_drop(const float *dY, const float *Z, const float *scale, const float *shift,
+                           const float *mean, const float *rstd, const float *m1, const float *m2,
+                           const float *Aprev, const float *pscale, const float *pshift, long long E, int C,
+                           int cin, float drop_p, uint64_t drop_seed, const uint64_t *drop_seed_dev,
+                           float *dW, void *workspace, size_t workspace_bytes, void *stream);
 /* gridgcn_linear_fwd_direct_fin: the same launch also FINALISES the layer's BatchNorm -- what
  *   gridgcn_bn_finalize[_tail] does in a launch of its own (scale / shift / mean / rstd of the batch
  *   statistics, running statistics, num_batches_tracked) is done by the last workgroup to arrive

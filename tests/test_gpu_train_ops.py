@@ -582,6 +582,32 @@ def test_head_train_matches_torch(E, cin, dims, C2, p):
             close(b2, b1, 1e-5)
 
 
+def test_head_fused_dropout_equals_stored_dropout(monkeypatch):
+    """Dropout evaluated inside fc2's forward / dW kernels (train_ops.FUSE_DROPOUT) against the path that
+    stores the dropped activation: the same mask bit for bit, so outputs and gradients agree to rounding."""
+    torch.manual_seed(11)
+    E, C, C2, p, seed = 40003, 128, 21, 0.5, 1234567890123
+    net = mlp(256, [C]).to(DEV).train()
+    lin = torch.nn.Linear(C, C2).to(DEV)
+    x = torch.randn(E, 256, device=DEV)
+    g = torch.randn(E, C2, device=DEV)
+    out = []
+    for fuse in (True, False):
+        monkeypatch.setattr(train_ops, "FUSE_DROPOUT", fuse)
+        n2, l2 = copy.deepcopy(net), copy.deepcopy(lin)
+        xi = x.clone().requires_grad_(True)
+        y = train_ops.head_train(xi, list(n2), p, l2, seed)
+        y.backward(g)
+        out.append((y.detach(), xi.grad, l2.weight.grad, l2.bias.grad, [q.grad for q in n2.parameters()]))
+    (ya, xa, wa, ba, pa), (yb, xb, wb, bb, pb) = out
+    assert float((ya - yb).abs().max()) <= 2e-6 * float(yb.abs().max())
+    assert torch.equal(xa, xb)                     # (the dX kernel is the same launch in both)
+    assert float((wa - wb).abs().max()) <= 1e-5 * float(wb.abs().max())
+    assert torch.equal(ba, bb)
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1e-3, float(b.abs().max()))
+
+
 def test_head_in_model_matches_unfused_head_without_dropout():
     """GGCNSeg with the fused head == the separate fc1 / dropout / fc2 ops when dropout is off."""
     from grid_gcn_amd import model, synth
