@@ -833,11 +833,16 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             const bool drop = p.drop_thr != 0;
             const unsigned long long idx0 = (unsigned long long)((r0 + 4 * h) * ldx + dx_col0 + (lane & 31));
             if (drop) {
+                // (an opaque copy of the row stride: its 16 * NT multiples are then formed here, in the one launch
+                //  that drops, instead of being hoisted out of the tile loop into scalar registers every launch
+                //  keeps live -- 238 / 384 spilled SGPRs at 4 / 8 column tiles)
+                int ldx_d = ldx;
+                asm volatile("" : "+s"(ldx_d));
 #pragma unroll
                 for (int t = 0; t < NT; t++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const unsigned long long e = idx0 + (unsigned long long)(((r & 3) + 8 * (r >> 2)) * ldx + t * 32);
+                        const unsigned long long e = idx0 + (unsigned long long)(((r & 3) + 8 * (r >> 2)) * ldx_d + t * 32);
                         acc[t][r] = gg_drop_keep(e, drop_lo, drop_hi, p.drop_thr) ? acc[t][r] * p.drop_scale : 0.f;
                     }
             }
@@ -880,7 +885,9 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             }
             continue;
         }
-        const long long base = (r0 + 4 * h) * ldx + dx_col0 + (lane & 31);
+        int ldx_g = ldx;                       // (the last, partial row block: opaque stride as above)
+        asm volatile("" : "+s"(ldx_g));
+        const long long base = (r0 + 4 * h) * ldx_g + dx_col0 + (lane & 31);
         float *xp = p.dX + base;
         const float *ap = p.Aprev + base;
 #pragma unroll
@@ -898,15 +905,15 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
 #pragma unroll
                     for (int r = 0; r < 16; r++) {          // (rows past the end: any valid address)
                         const int rr = (r & 3) + 8 * (r >> 2);
-                        const float *a = (nrows == 32 || rr + 4 * h < nrows) ? ap + rr * ldx + t * 32 : p.Aprev;
+                        const float *a = (rr + 4 * h < nrows) ? ap + rr * ldx_g + t * 32 : p.Aprev;
                         zpv[r] = *a;
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int rr = (r & 3) + 8 * (r >> 2);
-                    if (nrows == 32 || rr + 4 * h < nrows) {
-                        const int off = rr * ldx + t * 32;
+                    if (rr + 4 * h < nrows) {
+                        const int off = rr * ldx_g + t * 32;
                         float dx = acc[t][r];
                         if (p.drop_thr)   // the input activation went through Dropout (gg_k_bn_apply)
                             dx = gg_drop_keep((unsigned long long)(base + off), drop_lo, drop_hi,

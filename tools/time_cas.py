@@ -1,7 +1,11 @@
 """Device time of Gridify_occaware (CAS) next to Gridify (RVS) on synthetic batches; also the
 coverage (occupied voxels inside at least one centre's window) of both samples."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF = "--prof" in sys.argv      # the -DGG_PROF library (python -m grid_gcn_amd.build --prof): the kernel prints
+if PROF:                         # where the time of cloud 0 goes
+    os.environ["GG_HIP_LIB"] = os.path.join(ROOT, "grid_gcn_amd", "lib", "libgridgcn_hip_prof.so")
 import numpy as np
 import torch
 from grid_gcn_amd import ops, synth
@@ -47,9 +51,10 @@ for name, cfg, B, N, kind in (("cfg4 down0 (8 x 81920, 40^3, O=1024)", synth.SEG
     d, n = torch.from_numpy(data).cuda(), torch.from_numpy(npn).cuda()
     kw = synth.gridify_kwargs(cfg, 0)
     t_rvs = timeit(lambda: ops.Gridify(d, n, **kw))
-    t_cas = timeit(lambda: ops.Gridify_occaware(d, n, beta=1.0, **kw), it=5, warm=2)
+    t_cas = timeit(lambda: ops.Gridify_occaware(d, n, beta=1.0, **kw), it=1 if PROF else 5, warm=0 if PROF else 2)
     a = ops.Gridify(d, n, **kw)
     c = ops.Gridify_occaware(d, n, beta=1.0, **kw)
+    torch.cuda.synchronize()
     ca, no = coverage(d, a[2], a[4], kw)
     cc, _ = coverage(d, c[2], c[4], kw)
     print("%s: Gridify (RVS) %.3f ms, Gridify_occaware (CAS, beta=1) %.3f ms; cloud 0: %d occupied voxels, "
