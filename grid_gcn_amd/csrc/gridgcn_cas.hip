@@ -58,6 +58,14 @@ __device__ __forceinline__ int gg_cas_voxel(const float4 *cloud, int i, const GG
     const float4 p = cloud[i];
     return gg_voxel_of(p.x, p.y, p.z, gp, nullptr);
 }
+// the same voxel as x | y << 10 | z << 20 (what the sweep works with: no division to get back to coordinates)
+__device__ __forceinline__ int gg_cas_voxel_xyz(const float4 *cloud, int i, const GGGrid &gp)
+{
+    const float4 p = cloud[i];
+    int c[3] = {0, 0, 0};
+    gg_voxel_of(p.x, p.y, p.z, gp, c);
+    return c[0] | (c[1] << 10) | (c[2] << 20);
+}
 
 // neighbour `nei` of voxel (c0,c1,c2) in the k^3 window, -1 outside the grid (gridify.cu:240-246)
 __device__ __forceinline__ int gg_cas_nb(int c0, int c1, int c2, int nei, const GGGrid &gp)
@@ -127,15 +135,14 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     for (int s = tid; s < M; s += GG_CAS_NT) {
         const int id = a.slotfirst1[(size_t)b * O + s] - 1;
         slotlead[s] = id;
-        slotvox[s] = gg_cas_voxel(cloud, id, gp);
+        slotvox[s] = gg_cas_voxel_xyz(cloud, id, gp);           // (slot -> packed voxel coordinates)
         atomicOr(&pbm[id >> 5], 1u << (id & 31));
     }
     __syncthreads();
     for (int idx = tid; idx < M * k3; idx += GG_CAS_NT) {
         const int s = idx / k3, nei = idx - s * k3;
         const int v = slotvox[s];
-        const int c2 = v / gp.gxy, c1 = (v - c2 * gp.gxy) / gp.g[0], c0 = v - c2 * gp.gxy - c1 * gp.g[0];
-        const int u = gg_cas_nb(c0, c1, c2, nei, gp);
+        const int u = gg_cas_nb(v & 1023, (v >> 10) & 1023, v >> 20, nei, gp);
         if (u >= 0 && (cov[u] & 0x8000)) atomicAdd(&cov32[u >> 1], (u & 1) ? 0x10000u : 1u);
     }
     // ---- challengers: leaders that are not incumbents, ascending first point ----
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
         __syncthreads();
     }
     const int nchal = s_carry;
-    for (int j = tid; j < nchal; j += GG_CAS_NT) chal_vox[j] = gg_cas_voxel(cloud, chal_id[j], gp);
+    for (int j = tid; j < nchal; j += GG_CAS_NT) chal_vox[j] = gg_cas_voxel_xyz(cloud, chal_id[j], gp);   // (packed)
     __syncthreads();
 
     // ---- the sweep: batches of 64 challengers, evaluated speculatively by all 16 waves ----
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     for (int j = tid; j < nchal; j += GG_CAS_NT)
         a.chal[(size_t)b * 3 * N + 2 * N + j] =
             gg_reservoir_pick((unsigned long long)((long long)b * N + chal_id[j]) + seed3, M);
-    __shared__ int sb_vx[64], sb_xyz[64], sb_sl[64], sb_id[64], sb_dec[64], sb_vixyz[64];
+    __shared__ int sb_xyz[64], sb_sl[64], sb_id[64], sb_dec[64], sb_vixyz[64];
     __shared__ unsigned long long sb_row[64];
     __shared__ int sb_task[GG_CAS_NT / 64], sb_res[GG_CAS_NT / 64];
     const int *chal_sl = a.chal + (size_t)b * 3 * N + 2 * N;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
             const int d = od[i] + c2, h = oh[i] + c1, w = ow[i] + c0;
             const bool in = (lane + 64 * i < k3) & ((unsigned)d < (unsigned)gp.g[2]) &
                             ((unsigned)h < (unsigned)gp.g[1]) & ((unsigned)w < (unsigned)gp.g[0]);
-            return in ? d * gp.gxy + h * gp.g[0] + w : -1;
+            return in ? __mul24(d, gp.gxy) + __mul24(h, gp.g[0]) + w : -1;   // (full-rate multiplies: |d|, |h| < 2^11, gxy < 2^20)
         };
         // k^3 <= 32 (k = 3): BOTH windows of a challenger in one pass -- the challenger's window on lanes 0..31, the
         // incumbent's on lanes 32..63 (phase A is bound by the VALU instructions of its 16 waves: 27 useful lanes of
@@ -218,12 +225,17 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
             const int d = odp + (c >> 20), h = ohp + ((c >> 10) & 1023), w = owp + (c & 1023);
             const bool in = (neip < k3) & ((unsigned)d < (unsigned)gp.g[2]) & ((unsigned)h < (unsigned)gp.g[1]) &
                             ((unsigned)w < (unsigned)gp.g[0]);
-            return in ? d * gp.gxy + h * gp.g[0] + w : -1;
+            return in ? __mul24(d, gp.gxy) + __mul24(h, gp.g[0]) + w : -1;   // (full-rate multiplies: |d|, |h| < 2^11, gxy < 2^20)
         };
         auto verdict2 = [&](unsigned e) -> bool {
             const int n0 = __popc((unsigned)__ballot(e == 0x8000u));
             const int n1 = __popc((unsigned)(__ballot(e == 0x8001u) >> 32));
-            const int sc = gg_wave_sum((halfp == 0 && (e & 0x8000u)) ? (int)(e & 0x7fffu) : 0);
+            // sum of the counters of the challenger's window: a voxel lies in the windows of at most k^3 <= 32 centres
+            // (the slots hold distinct voxels), so six bit planes, a ballot each -- no cross-lane adds through LDS
+            const unsigned cnt = (halfp == 0 && (e & 0x8000u)) ? (e & 0x7fffu) : 0u;
+            int sc = 0;
+#pragma unroll
+            for (int bit = 0; bit < 6; bit++) sc += __popcll(__ballot((cnt >> bit) & 1u)) << bit;
             return (float)(k3 * (n0 - n1)) > __fmul_rn(a.beta, (float)sc);
         };
         // H_add > H_rmv for challenger voxel (a0,a1,a2) against incumbent voxel (i0,i1,i2): wave-wide
@@ -241,10 +253,6 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
             }
             sc = gg_wave_sum(sc);
             return (float)(k3 * (n0 - n1)) > __fmul_rn(a.beta, (float)sc);
-        };
-        auto xyz_of = [&](int v) -> int {
-            const int z = v / gp.gxy, y = (v - z * gp.gxy) / gp.g[0];
-            return (v - z * gp.gxy - y * gp.g[0]) | (y << 10) | (z << 20);
         };
         // A replacement writes the counters of two windows and one slot; it reads the same.  Two challengers
         // CONFLICT when a window of the one may overlap a window of the other (centres within k - 1 in every
@@ -269,10 +277,9 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
             if (tid < nb) {
                 const int vx = nx_vx, sl = nx_sl;
                 sb_id[tid] = nx_id;
-                sb_vx[tid] = vx;
-                sb_xyz[tid] = xyz_of(vx);
+                sb_xyz[tid] = vx;
                 sb_sl[tid] = sl;
-                sb_vixyz[tid] = xyz_of(slotvox[sl]);        // the incumbent at the START of the batch
+                sb_vixyz[tid] = slotvox[sl];                // the incumbent at the START of the batch
             }
             if (tid < 64 && j0 + 64 + tid < nchal) {
                 nx_vx = chal_vox[j0 + 64 + tid]; nx_id = chal_id[j0 + 64 + tid]; nx_sl = chal_sl[j0 + 64 + tid];
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
                         int pi = sb_vixyz[q];
                         bool acc = true;
                         if (task & 0x100) {
-                            pi = xyz_of(slotvox[s]);
+                            pi = slotvox[s];
                             acc = accept(pc & 1023, (pc >> 10) & 1023, pc >> 20, pi & 1023, (pi >> 10) & 1023, pi >> 20);
                         }
                         if (acc) {
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
                                 if (e & 0x8000u) cov[uc] = (unsigned short)(e + 1u);
                             }
                             if (lane == 0) {
-                                slotvox[s] = sb_vx[q];
+                                slotvox[s] = pc;
                                 slotlead[s] = sb_id[q];
                             }
                         }
