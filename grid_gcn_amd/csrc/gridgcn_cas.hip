@@ -21,9 +21,10 @@
 // point per voxel, occupancy + coverage counters (16 bits per voxel, in LDS whenever the grid fits:
 // 40^3 voxels = 128 KB of the CU's 160 KB), incumbent slots, the compacted challenger list with the
 // drawn incumbent slot of every challenger -- and then walk the challengers in batches of 64: all 16
-// waves evaluate the batch speculatively (a lane per window voxel: LDS latency only), wave 0 commits
-// the verdicts in order and re-evaluates the few whose inputs an earlier replacement of the same
-// batch has touched (see "the sweep" below): same verdicts as the one-by-one walk, ~10x its speed.
+// waves evaluate the batch speculatively and form its conflict matrix, then the challengers that need
+// a turn (accepted, or touched by an earlier replacement of the batch) are resolved in ROUNDS -- those
+// that no earlier unresolved challenger can still affect go to the 16 waves together (see "phase B"
+// below).  Same verdicts as the one-by-one walk (tests/test_cas.py, bit for bit), 7x its speed.
 #include "gridgcn_index.h"
 
 #define GG_CAS_NT 1024

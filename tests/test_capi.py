@@ -84,6 +84,23 @@ def test_round3_entries_reject_bad_arguments_without_gpu(lib):
     assert lib.gridgcn_set_option(12345, 0) == 1
 
 
+def test_round4_dropout_entries_reject_bad_arguments_without_gpu(lib):
+    """the fused-Dropout entries check their shape domain before any launch (K % 32, <= 32 outputs, 0 < p < 1)"""
+    f32 = (ctypes.c_float * 64)()
+    a = ctypes.cast(f32, ctypes.c_void_p)
+    # null pointers
+    assert lib.gridgcn_linear_fwd_direct_drop(None, 64, 128, 128, None, None, 32, 24, None, None, None, 0.5, 1, None,
+                                              None) == 1
+    # K not a multiple of 32, too many outputs, p outside (0, 1)
+    assert lib.gridgcn_linear_fwd_direct_drop(a, 64, 100, 100, a, a, 32, 24, a, a, a, 0.5, 1, None, None) == 1
+    assert lib.gridgcn_linear_fwd_direct_drop(a, 64, 128, 128, a, a, 64, 40, a, a, a, 0.5, 1, None, None) == 1
+    assert lib.gridgcn_linear_fwd_direct_drop(a, 64, 128, 128, a, a, 32, 24, a, a, a, 0.0, 1, None, None) == 1
+    assert lib.gridgcn_linear_dw_drop(*([None] * 11), 64, 24, 128, 0.5, 1, None, None, None, 0, None) == 1
+    assert lib.gridgcn_linear_dw_drop(*([a] * 11), 64, 24, 128, 1.0, 1, None, a, a, 1 << 20, None) == 1
+    # a workspace that is too small is its own code (GRIDGCN_EWORKSPACE)
+    assert lib.gridgcn_linear_dw_drop(*([a] * 11), 1 << 16, 24, 128, 0.5, 1, None, a, a, 16, None) == 2
+
+
 def test_ops_fail_loudly_without_gpu():
     """No CPU fallback: CPU tensors are rejected, never silently routed elsewhere."""
     import torch
