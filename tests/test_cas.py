@@ -76,6 +76,14 @@ CASES = [
     ("cls_k7_o64", synth.CLS_MODELNET40, 0, 1024, "ball", dict(max_o_grid=64)),
     ("synth_64cube", synth.SYNTH_200K, 0, 20000, "planes", dict(max_o_grid=512, beta=2.0)),
     ("ragged", synth.SEG_SCANNET_8192, 0, 4096, "planes", dict(max_o_grid=100, ragged=True)),
+    # the conflict rounds of the sweep under stress: eight slots (almost every pair of a batch shares its slot:
+    # long chains, the slot-inheritance path), a coarse grid (every window overlaps every other), k = 5 (two
+    # passes per window: the generic evaluation), and beta = 0 on few slots (most challengers accepted)
+    ("tiny_o8", synth.SEG_SCANNET_8192, 0, 8192, "planes", dict(max_o_grid=8)),
+    ("coarse_grid", synth.SEG_SCANNET_8192, 0, 4096, "ball",
+     dict(max_o_grid=32, grid_size=[12, 12, 12], voxel_size=[0.17, 0.17, 0.17])),
+    ("k5_o128", synth.SEG_SCANNET_8192, 0, 8192, "planes", dict(max_o_grid=128, kernel_size=5)),
+    ("beta0_o16", synth.SEG_SCANNET_8192, 0, 8192, "ball", dict(max_o_grid=16, beta=0.0)),
 ]
 
 
