@@ -215,7 +215,8 @@ static int gridify_common(bool knn, const float *data, const int32_t *np, int B,
     if (rc) return rc;
     if (cas_beta >= 0.0f) {
         rc = gg_cas_refine(data, np, B, N, gp, cas_beta, (int *)((char *)ws + w.o_slotfirst1),
-                           centnum, (char *)ws + cas_off, st);
+                           centnum, (const int2 *)((char *)ws + w.o_vtab), (const int *)((char *)ws + w.o_sorted),
+                           (char *)ws + cas_off, st);
         if (rc) return rc;
     }
     if (knn)

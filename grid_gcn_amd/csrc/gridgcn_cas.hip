@@ -44,7 +44,8 @@ struct GGCasArgs {
     const int *np;
     int *slotfirst1;        // [B][O]  in/out: first point of the slot's voxel + 1
     const int *centnum;     // [B]
-    int *first;             // [B][G]
+    const int2 *vtab;       // [B][G]  the index build's voxel table: .x = segment start in `sorted`, .y = population
+    const int *sorted;      // [B*N]   point ids grouped by voxel, ascending inside a voxel
     unsigned *bm;           // [B][2][W]  leader bitmap, incumbent bitmap
     int *chal;              // [B][3][N]  challenger first point, challenger voxel, drawn incumbent slot
     unsigned short *cov_g;  // [B][Gp]  (Gp = G rounded up to 2) when the counters do not fit LDS
@@ -92,10 +93,7 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     const int N = a.N, G = gp.G, O = gp.O, k3 = gp.k3, W = a.W;
     const int M = a.centnum[b];
     if (M < O) return;                       // fewer occupied voxels than slots: all of them are centres
-    int npts = a.np[b];
-    npts = npts < 0 ? 0 : (npts > N ? N : npts);
     const float4 *cloud = a.data + (size_t)b * N;
-    int *first = a.first + (size_t)b * G;
     unsigned *lbm = a.bm + (size_t)b * 2 * W, *pbm = lbm + W;
     int *chal_id = a.chal + (size_t)b * 3 * N, *chal_vox = chal_id + N;
     unsigned short *cov;
@@ -117,20 +115,28 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
     int cas_n[4] = {0, 0, 0, 0};
 #endif
     // ---- tables ----
-    for (int v = tid; v < G; v += GG_CAS_NT) first[v] = 0x7fffffff;
-    for (int v = tid; v < a.Gp / 2; v += GG_CAS_NT) cov32[v] = 0u;
+    // Occupancy and the first point of every voxel come from the index build that ran just before (its voxel
+    // table: start and population of a voxel's segment of the sorted ids, ascending inside a voxel -- so the first
+    // entry IS the first point): no pass over the points, no atomicMin table (round 3 rebuilt both here).
     for (int w = tid; w < 2 * W; w += GG_CAS_NT) lbm[w] = 0u;
     __syncthreads();
-    for (int i = tid; i < npts; i += GG_CAS_NT) {
-        const int v = gg_cas_voxel(cloud, i, gp);
-        if (v >= 0) atomicMin(&first[v], i);
-    }
-    __syncthreads();
-    for (int v = tid; v < G; v += GG_CAS_NT) {
-        const int f = first[v];
-        if (f != 0x7fffffff) {
-            cov[v] = 0x8000;                                   // occupied, covered by nobody yet
-            atomicOr(&lbm[f >> 5], 1u << (f & 31));
+    {
+        const int2 *vt = a.vtab + (size_t)b * G;
+        for (int v2 = tid; v2 < a.Gp / 2; v2 += GG_CAS_NT) {           // two voxels per thread: one 32-bit store
+            unsigned w32 = 0u;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int v = 2 * v2 + hh;
+                if (v < G) {
+                    const int2 t = vt[v];
+                    if (t.y > 0) {
+                        w32 |= 0x8000u << (16 * hh);                   // occupied, covered by nobody yet
+                        const int f = a.sorted[t.x];
+                        atomicOr(&lbm[f >> 5], 1u << (f & 31));
+                    }
+                }
+            }
+            cov32[v2] = w32;
         }
     }
     for (int s = tid; s < M; s += GG_CAS_NT) {
@@ -501,8 +507,10 @@ size_t gg_cas_workspace_bytes(int B, int N, const GGGrid &gp)
            gg_cas_align((size_t)B * 2 * gp.O * 4);
 }
 
+// vtab / sorted: what the index build of the same call left in its workspace (GGIndexWs o_vtab, o_sorted)
 int gg_cas_refine(const float *data, const int *np, int B, int N, const GGGrid &gp, float beta,
-                  int *slotfirst1, const int *centnum, char *ws, hipStream_t st)
+                  int *slotfirst1, const int *centnum, const int2 *vtab, const int *sorted, char *ws,
+                  hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
@@ -515,7 +523,8 @@ int gg_cas_refine(const float *data, const int *np, int B, int N, const GGGrid &
     const size_t W = ((size_t)N + 31) / 32, Gp = ((size_t)gp.G + 1) & ~(size_t)1;
     a.data = (const float4 *)data; a.np = np; a.slotfirst1 = slotfirst1; a.centnum = centnum;
     char *p = ws;
-    a.first = (int *)p;            p += gg_cas_align((size_t)B * gp.G * 4);
+    a.vtab = vtab; a.sorted = sorted;
+    p += gg_cas_align((size_t)B * gp.G * 4);      // (a [B][G] table of the fast_rand query, which shares this workspace size)
     a.bm = (unsigned *)p;          p += gg_cas_align((size_t)B * 2 * W * 4);
     a.chal = (int *)p;             p += gg_cas_align((size_t)B * 3 * N * 4);
     a.cov_g = (unsigned short *)p; p += gg_cas_align((size_t)B * Gp * 2);

@@ -68,7 +68,8 @@ int gg_index_legacy_init();
 // gridgcn_cas.hip: coverage-aware refinement of the centre slots (parity unpinned, see there)
 size_t gg_cas_workspace_bytes(int B, int N, const GGGrid &gp);
 int gg_cas_refine(const float *data, const int *np, int B, int N, const GGGrid &gp, float beta,
-                  int *slotfirst1, const int *centnum, char *ws, hipStream_t st);
+                  int *slotfirst1, const int *centnum, const int2 *vtab, const int *sorted, char *ws,
+                  hipStream_t st);
 
 // gridgcn_fastrand.hip: centre slots + query of the fast_rand build (scratch: gg_cas_workspace_bytes)
 int gg_fastrand_query(const float *data, const int *np, int B, int N, const GGGrid &gp, char *wsbase,
