@@ -459,11 +459,12 @@ __global__ __launch_bounds__(GG_CAS_NT) void gg_k_cas_refine(GGCasArgs a, GGGrid
                 GG_CAS_T(4);
                 if (wave == 0) {
                     unsigned long long m = R;
+                    const int res_l = sb_res[lane & (GG_CAS_NT / 64 - 1)];           // (one LDS read, not one per task)
                     for (int t = 0; m; t++) {
                         const int q = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         if (lane == q) { st_acc = false; st_dirty = false; }          // q is final
-                        if (sb_res[t]) {
+                        if (__builtin_amdgcn_readlane(res_l, t)) {
                             const bool hit = lane > q && ((row_l >> q) & 1ull);
                             st_dirty = st_dirty || hit;
                             st_acc = st_acc && !hit;
