@@ -134,8 +134,11 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 // 2 K - 6 K rows has too few of them to fill the chip; every column group re-reads the
 // rows (nothing at these sizes) and owns its columns of Z, of the bias and of the statistics.
 // DROP (one column tile, fp32): Dropout of the activated input while it is loaded (GGLinFwd.drop_*).
+#ifndef GG_FWD4_THREADS
+#define GG_FWD4_THREADS 512    // fp32 forward at four column tiles: 8 waves = two per SIMD (768 = three per SIMD at 168 registers: 25 spilled, 372 -> 418 us at 256 -> 128)
+#endif
 template <int NT, bool WLDS, bool EXACT, bool BF16 = false, bool CS = false, bool DROP = false>
-__global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024)))) void gg_k_linear_fwd_direct(GGLinFwd p)
+__global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT == 8 ? 512 : (NT == 4 ? GG_FWD4_THREADS : (NT == 2 ? 768 : 1024))))) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
     static_assert(!DROP || (NT == 1 && !BF16 && !CS), "Dropout prologue: one column tile, fp32");
     unsigned drop_lo = p.drop_lo, drop_hi = p.drop_hi;
@@ -509,7 +512,7 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
     // launch_dx_direct)
     const long long ntile = (q.E + 31) >> 5;
     const int threads = ntile <= 1024 ? 256 :
-        (use16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT >= 4 ? 512 : (NT == 2 ? 768 : 1024)));
+        (use16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT == 8 ? 512 : (NT == 4 ? GG_FWD4_THREADS : (NT == 2 ? 768 : 1024))));
     const int nw = threads / 64;
     const size_t wbytes = (size_t)q.K * 32 * NT * 4, sbytes = (size_t)2 * q.K * 4;
     const size_t rbytes = (size_t)nw * 2 * NT * 32 * 4;
