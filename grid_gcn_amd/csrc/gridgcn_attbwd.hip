@@ -366,7 +366,15 @@ __global__ __launch_bounds__(1024) void gg_k_att_dw_reduce(const float *__restri
     const int j = blockIdx.x >> 4, r = blockIdx.x & 15;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     float v = 0.f;
-    for (int w = grp; w < nwaves; w += 16) v += part[((size_t)w * NJ + j) * 1024 + r * 64 + lane];
+    int w = grp;
+    for (; w + 7 * 16 < nwaves; w += 8 * 16) {          // eight loads in flight, added in the same order as one by one
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = part[((size_t)(w + 16 * u) * NJ + j) * 1024 + r * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (; w < nwaves; w += 16) v += part[((size_t)w * NJ + j) * 1024 + r * 64 + lane];
     sh[grp][lane] = v;
     __syncthreads();
     if (threadIdx.x < 64) {

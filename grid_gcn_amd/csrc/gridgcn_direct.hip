@@ -1499,16 +1499,25 @@ __global__ __launch_bounds__(64 * GG_DWR_SL) void gg_k_dw_reduce_direct(
                                __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             s_last = __hip_atomic_fetch_add(&tick[mg * gridDim.x + blockIdx.x], 1, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+            // (the consumer side of MI355X_MICROARCH's hand-off: one agent acquire, a barrier, then plain loads)
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         __syncthreads();
         if (!s_last) return;
         if (sl == 0 && e < per) {
+            // all S <= 16 slice sums requested together, added in the order z = 0 .. S-1.  (One device-scope
+            // atomic load per slice, each waited for before the next was issued, was ~10 of this kernel's
+            // 10 us: sixteen memory round trips in a row.)
+            float v[16];
+#pragma unroll
+            for (int zz = 0; zz < 16; zz++)
+                v[zz] = part2[((size_t)(zz < S ? zz : S - 1) * MG + mg) * per + e];
             s = 0.f;
-            for (int zz = 0; zz < S; zz++)
-                s += __hip_atomic_load(&part2[((size_t)zz * MG + mg) * per + e], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int zz = 0; zz < 16; zz++) s += zz < S ? v[zz] : 0.f;
         }
     }
     if (sl != 0 || e >= per) return;

@@ -96,11 +96,16 @@ __global__ __launch_bounds__(256) void gg_k_ce_fwd(const float *__restrict__ log
     }
     if (loss_out && threadIdx.x == 0 && gg_last_arriver(acc + 16 * GG_SLOTS + 16)) {
         // acc: [16 slots x 16] partial (sum, count) | [256] sum, [257] count | tickets
-        double s0 = 0.0, s1 = 0.0;
+        // (all 32 loads requested together, then added in slot order: one memory round trip instead of 32)
+        double v0[GG_SLOTS], v1[GG_SLOTS];
+#pragma unroll
         for (int k = 0; k < GG_SLOTS; k++) {
-            s0 += __hip_atomic_load(&acc[16 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s1 += __hip_atomic_load(&acc[16 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v0[k] = __hip_atomic_load(&acc[16 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v1[k] = __hip_atomic_load(&acc[16 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < GG_SLOTS; k++) { s0 += v0[k]; s1 += v1[k]; }
         acc[16 * GG_SLOTS] = s0;          // (read by the NEXT launches: gridgcn_softmax_ce_bwd)
         acc[16 * GG_SLOTS + 1] = s1;
         loss_out[0] = (float)(s0 / (s1 > 1.0 ? s1 : 1.0));
@@ -182,9 +187,12 @@ __global__ __launch_bounds__(256) void gg_k_colsum(const float *__restrict__ X, 
         if (threadIdx.x == 0) s_last = gg_last_arriver(out + 32 * GG_SLOTS);
         __syncthreads();
         if (s_last && threadIdx.x < ncols) {
-            double a = 0.0;
+            double v[GG_SLOTS], a = 0.0;           // (the 16 loads in flight together, added in slot order)
+#pragma unroll
             for (int k = 0; k < GG_SLOTS; k++)
-                a += __hip_atomic_load(&out[32 * k + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[k] = __hip_atomic_load(&out[32 * k + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < GG_SLOTS; k++) a += v[k];
             out32[threadIdx.x] = (float)a;
         }
     }
