@@ -70,9 +70,16 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
     float *v0 = ct + C;                    // [32]
     float *pcs = v0 + 32;                  // [2][32] previous layer's scale, shift
     float *T = pcs + 64 + wave * (64 * GG_NZ_TS);
-    for (int i = tid; i < C * 32; i += 256) {
-        const int k = i >> 5, col = i & 31;           // (coalesced read of W2[k][:])
-        Wl[((k >> 5) * 64 + ((k >> 4) & 1) * 32 + col) * GG_NZ_WS + (k & 15)] = p.W2[i];
+    for (int i0 = tid; i0 < C * 32; i0 += 256 * 8) {  // (eight loads in flight: one by one they were 16 L2 round trips)
+        float w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w8[u] = p.W2[i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 256 * u;
+            const int k = i >> 5, col = i & 31;       // (coalesced read of W2[k][:])
+            if (i < C * 32) Wl[((k >> 5) * 64 + ((k >> 4) & 1) * 32 + col) * GG_NZ_WS + (k & 15)] = w8[u];
+        }
     }
     for (int c = tid; c < C; c += 256) {
         const float sc = p.sc[c];

@@ -30,9 +30,17 @@ __global__ __launch_bounds__(256) void gg_k_att_max_eval(GGAttEval p)
     __shared__ __attribute__((aligned(16))) float cst[8 * C];        // sa, ha', w0, w1, w2, bp, sp, hp
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
-    for (int i = tid; i < 16 * 64 * NJ; i += 256) {
-        const int t = i % NJ, ln = (i / NJ) & 63, s = i / (NJ * 64);
-        Wz[i] = p.W2[(32 * t + (ln & 31)) * 32 + 16 * (ln >> 5) + s];
+    for (int i0 = tid; i0 < 16 * 64 * NJ; i0 += 256 * 8) {        // (eight loads in flight)
+        float w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 256 * u < 16 * 64 * NJ ? i0 + 256 * u : 16 * 64 * NJ - 1;
+            const int t = i % NJ, ln = (i / NJ) & 63, s = i / (NJ * 64);
+            w8[u] = p.W2[(32 * t + (ln & 31)) * 32 + 16 * (ln >> 5) + s];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 256 * u < 16 * 64 * NJ) Wz[i0 + 256 * u] = w8[u];
     }
     for (int c = tid; c < C; c += 256) {
         const float sa = p.sa[c];

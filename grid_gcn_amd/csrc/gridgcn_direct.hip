@@ -75,6 +75,27 @@ __device__ __forceinline__ void gg_stage_w_bf16(ggm_u32x4 *dst, const float *__r
     }
 }
 
+// n float4 from src (every sstride-th) to LDS, eight loads in flight per thread.  (The plain loop -- load, wait, LDS
+// store, sixteen times for a 256 x 128 operand -- opened EVERY forward / dX launch with ~10 us in which the whole
+// chip waited for L2 round trips one after the other; found in the ISA at the end of round 4.)
+__device__ __forceinline__ void gg_stage_copy4(float4 *dst, const float4 *__restrict__ src, int n, int sstride,
+                                               int tid, int nthr)
+{
+    for (int i0 = tid; i0 < n; i0 += nthr * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * nthr;
+            v[u] = src[(size_t)(i < n ? i : n - 1) * sstride];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * nthr;
+            if (i < n) dst[i] = v[u];
+        }
+    }
+}
+
 // column-split staging: NV of the nvf floats of every [step][lane] entry of a packed operand, first tile t0
 // (t0 % NV == 0, t0 + NV <= nvf), eight vector loads in flight per thread -- a loop of dependent single
 // loads was 30-50 us of a launch whose MFMA chain takes 7
@@ -160,8 +181,7 @@ __global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 
         // NT of the ntf tiles of every [step][lane] entry of the packed operand
         gg_stage_sub<NT>(Wl, p.W, K * 32, p.ldw >> 5, (int)blockIdx.y * NT, tid, blockDim.x);
     } else if (WLDS) {
-        const float4 *src = (const float4 *)p.W;
-        for (int i = tid; i < K * 8 * NT; i += blockDim.x) ((float4 *)Wl)[i] = src[i];
+        gg_stage_copy4((float4 *)Wl, (const float4 *)p.W, K * 8 * NT, 1, tid, blockDim.x);
     }
     if (p.scale)
         for (int i = tid; i < K; i += blockDim.x) { scl[i] = p.scale[i]; scl[K + i] = p.shift[i]; }
@@ -620,9 +640,8 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             gg_stage_sub<NTV>(Wl, p.Wdx, C * 32, p.dx_wstride, (int)blockIdx.y * NT, tid, blockDim.x);
         } else {
             // (column-half mode, NT == 4 of a layout packed for 8 tiles: every second float4)
-            const float4 *src = (const float4 *)p.Wdx + (dx_col0 ? 1 : 0);
-            const int ws = p.dx_wstride;
-            for (int i = tid; i < C * 8 * NTV; i += blockDim.x) ((float4 *)Wl)[i] = src[(size_t)i * ws];
+            gg_stage_copy4((float4 *)Wl, (const float4 *)p.Wdx + (dx_col0 ? 1 : 0), C * 8 * NTV, p.dx_wstride, tid,
+                           blockDim.x);
         }
         for (int c = tid; c < C; c += blockDim.x) {
             const float sc = p.scale[c];
