@@ -1494,12 +1494,19 @@ __global__ __launch_bounds__(64 * GG_DWR_SL) void gg_k_dw_reduce_direct(
     if (e < per) {
         const float *src = part + (size_t)mg * per + e;
         const size_t stride = (size_t)MG * per;
-        int i = i0 + sl;
-        for (; i + 7 * GG_DWR_SL < i1; i += 8 * GG_DWR_SL) {
+        // eight loads in flight in EVERY round, the last one included (its terms beyond the slice read a valid
+        // address and add zero: the same sums in the same order as a one-by-one tail, which was up to seven
+        // memory round trips in a row for the short slices of the small layers)
+        for (int i = i0 + sl; i < i1; i += 8 * GG_DWR_SL) {
+            float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc[u] += src[(size_t)(i + u * GG_DWR_SL) * stride];
+            for (int u = 0; u < 8; u++) {
+                const int ii = i + u * GG_DWR_SL;
+                t[u] = src[(size_t)(ii < i1 ? ii : i1 - 1) * stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] += (i + u * GG_DWR_SL < i1) ? t[u] : 0.f;
         }
-        for (int u = 0; i < i1; i += GG_DWR_SL, u++) acc[u & 7] += src[(size_t)i * stride];
     }
     sh[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
@@ -1603,6 +1610,7 @@ static GGDwRed gg_dw_reduce_cfg(const GGDwCfg &c)
     int S = 2048 / (r.gx * c.MG);
     S = S > 16 ? 16 : S;
     while (S > 1 && nwm / S < 8) S >>= 1;          // at least 8 waves per slice
+    if (nwm <= 64) S = 1;                          // two load rounds at most: no slices, no ticket, no second pass
     r.S = S < 1 ? 1 : S;
     r.part_floats = (size_t)c.slots * per;
     r.part2_floats = r.S > 1 ? (size_t)r.S * c.MG * per : 0;
