@@ -60,18 +60,30 @@ template <int NV>
 __device__ __forceinline__ void gg_stage_w_bf16(ggm_u32x4 *dst, const float *__restrict__ W,
                                                 int nsteps, int tid, int nthr)
 {
-    const int ng = (nsteps + 7) >> 3;
-    for (int e = tid; e < ng * 64 * NV; e += nthr) {
-        const int t = e % NV, lane = (e / NV) & 63, g = e / (NV * 64);
-        float v[8];
+    const int ng = (nsteps + 7) >> 3, n = ng * 64 * NV;
+    // two entries = sixteen loads in flight per thread and round (see gg_stage_copy4)
+    for (int e0 = tid; e0 < n; e0 += 2 * nthr) {
+        float v[2][8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int st = g * 8 + j;
-            v[j] = st < nsteps ? W[((size_t)st * 64 + lane) * NV + t] : 0.f;
+        for (int u = 0; u < 2; u++) {
+            const int e = e0 + u * nthr < n ? e0 + u * nthr : n - 1;
+            const int t = e % NV, lane = (e / NV) & 63, g = e / (NV * 64);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int st = g * 8 + j;
+                const float w = W[((size_t)(st < nsteps ? st : nsteps - 1) * 64 + lane) * NV + t];
+                v[u][j] = st < nsteps ? w : 0.f;
+            }
         }
-        ggm_u32x4 o = {gg_pk_bf16(v[0], v[1]), gg_pk_bf16(v[2], v[3]), gg_pk_bf16(v[4], v[5]),
-                       gg_pk_bf16(v[6], v[7])};
-        dst[e] = o;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = e0 + u * nthr;
+            if (e < n) {
+                ggm_u32x4 o = {gg_pk_bf16(v[u][0], v[u][1]), gg_pk_bf16(v[u][2], v[u][3]), gg_pk_bf16(v[u][4], v[u][5]),
+                               gg_pk_bf16(v[u][6], v[u][7])};
+                dst[e] = o;
+            }
+        }
     }
 }
 
