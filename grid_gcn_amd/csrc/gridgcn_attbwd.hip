@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
             cst[c] = sc;
             cst[C + c] = p.shift[c];
             cst[2 * C + c] = p.mean[c];
-            cst[3 * C + c] = -(sc * p.rstd[c]) * gg_bn_m2(p, c);
-            cst[4 * C + c] = -(sc * gg_bn_m1(p, c));
+            float m1v, m2v;
+            gg_bn_m12(p, c, m1v, m2v);
+            cst[3 * C + c] = -(sc * p.rstd[c]) * m2v;
+            cst[4 * C + c] = -(sc * m1v);
         }
     }
     __syncthreads();

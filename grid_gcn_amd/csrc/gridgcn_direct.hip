@@ -660,8 +660,10 @@ __global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd
             cst[c] = sc;
             cst[C + c] = p.shift[c];
             cst[2 * C + c] = p.mean[c];
-            cst[3 * C + c] = -(sc * p.rstd[c]) * gg_bn_m2(p, c);
-            cst[4 * C + c] = -(sc * gg_bn_m1(p, c));
+            float m1v, m2v;
+            gg_bn_m12(p, c, m1v, m2v);
+            cst[3 * C + c] = -(sc * p.rstd[c]) * m2v;
+            cst[4 * C + c] = -(sc * m1v);
         }
         // (kept in LDS, not in 4*NT registers per lane: the 8-tile form spilled 70 of them)
         const bool pb = p.pscale != nullptr;
@@ -1137,10 +1139,15 @@ __global__ __launch_bounds__((MT * (4 * NQ + 2 * NP + NS) > 10) ? 256 : 512, 1) 
     for (int i = 0; i < MT; i++) {
         const int c = chA + i;
         const bool ok = c < C;
-        const float s = ok ? p.scale[c] : 0.f;
-        sc[i] = s; sh[i] = ok ? p.shift[c] : 0.f; mu[i] = ok ? p.mean[c] : 0.f;
-        bz[i] = ok ? -(s * p.rstd[c]) * gg_bn_m2(p, c) : 0.f;
-        cz[i] = ok ? -(s * gg_bn_m1(p, c)) : 0.f;
+        // (unconditional loads from a clamped index, the select applied afterwards: all of them in flight together)
+        const int cc = ok ? c : 0;
+        const float sv = p.scale[cc], shv = p.shift[cc], muv = p.mean[cc], rsv = p.rstd[cc];
+        float m1v, m2v;
+        gg_bn_m12(p, cc, m1v, m2v);
+        const float s = ok ? sv : 0.f;
+        sc[i] = s; sh[i] = ok ? shv : 0.f; mu[i] = ok ? muv : 0.f;
+        bz[i] = ok ? -(s * rsv) * m2v : 0.f;
+        cz[i] = ok ? -(s * m1v) : 0.f;
     }
     const bool chok = chA + MT - 1 < C;               // C % MT == 0: all or none of the MT channels
     const int chl = chok ? chA : 0;

@@ -101,6 +101,20 @@ __device__ __forceinline__ float gg_bn_m2(const GGLinBwd &p, int c)
 {
     return p.bsums ? (float)(p.bsums[p.C + c] / (double)p.E) : p.m2[c];
 }
+// both at once: the two loads (and, with bsums, the two divisions) issue together -- called one after the other
+// they were two memory round trips in a row at the start of every dX / dW launch
+__device__ __forceinline__ void gg_bn_m12(const GGLinBwd &p, int c, float &m1, float &m2)
+{
+    if (p.bsums) {
+        const double s1 = p.bsums[c], s2 = p.bsums[p.C + c];
+        m1 = (float)(s1 / (double)p.E);
+        m2 = (float)(s2 / (double)p.E);
+    } else {
+        const float a = p.m1[c], b = p.m2[c];
+        m1 = a;
+        m2 = b;
+    }
+}
 // BatchNorm bookkeeping of channel c from its two sums: what gg_k_bn_finalize writes (utils/ops.py:141-158,
 // BatchNorm(eps, momentum, fix_gamma=False); running_var takes the unbiased variance as torch / MXNet do)
 __device__ __forceinline__ void gg_bn_fin_write(double s1, double s2, int c, const float *gamma,
