@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256, (NJ == 2 && !BF16) ? 3 : 2) void gg_k_att_bwd_
                 for (int u = 0; u < 8; u++) w8[u] = p.Wdx[i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = i0 + 256 * u;
+                    const int i = i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1;   // (unconditional store)
                     const int st = i >> 6, ln = i & 63;
-                    if (i < C * 32) Wl[((st >> 4) * 64 + ln) * GG_AF_WS + (st & 15)] = w8[u];
+                    Wl[((st >> 4) * 64 + ln) * GG_AF_WS + (st & 15)] = w8[u];
                 }
             }
         }

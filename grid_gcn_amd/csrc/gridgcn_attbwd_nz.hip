@@ -76,9 +76,9 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
         for (int u = 0; u < 8; u++) w8[u] = p.W2[i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int i = i0 + 256 * u;
-            const int k = i >> 5, col = i & 31;       // (coalesced read of W2[k][:])
-            if (i < C * 32) Wl[((k >> 5) * 64 + ((k >> 4) & 1) * 32 + col) * GG_NZ_WS + (k & 15)] = w8[u];
+            const int i = i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1;   // (unconditional store: a load whose
+            const int k = i >> 5, col = i & 31;       //  only use is conditional is sunk into the branch and waited for)
+            Wl[((k >> 5) * 64 + ((k >> 4) & 1) * 32 + col) * GG_NZ_WS + (k & 15)] = w8[u];
         }
     }
     for (int c = tid; c < C; c += 256) {

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gg_k_att_max_eval(GGAttEval p)
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
-            if (i0 + 256 * u < 16 * 64 * NJ) Wz[i0 + 256 * u] = w8[u];
+            Wz[i0 + 256 * u < 16 * 64 * NJ ? i0 + 256 * u : 16 * 64 * NJ - 1] = w8[u];      // (unconditional store)
     }
     for (int c = tid; c < C; c += 256) {
         const float sa = p.sa[c];

@@ -78,11 +78,9 @@ __device__ __forceinline__ void gg_stage_w_bf16(ggm_u32x4 *dst, const float *__r
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int e = e0 + u * nthr;
-            if (e < n) {
-                ggm_u32x4 o = {gg_pk_bf16(v[u][0], v[u][1]), gg_pk_bf16(v[u][2], v[u][3]), gg_pk_bf16(v[u][4], v[u][5]),
-                               gg_pk_bf16(v[u][6], v[u][7])};
-                dst[e] = o;
-            }
+            ggm_u32x4 o = {gg_pk_bf16(v[u][0], v[u][1]), gg_pk_bf16(v[u][2], v[u][3]), gg_pk_bf16(v[u][4], v[u][5]),
+                           gg_pk_bf16(v[u][6], v[u][7])};
+            dst[e < n ? e : n - 1] = o;                                          // (unconditional: see gg_stage_copy4)
         }
     }
 }
@@ -100,10 +98,13 @@ __device__ __forceinline__ void gg_stage_copy4(float4 *dst, const float4 *__rest
             const int i = i0 + u * nthr;
             v[u] = src[(size_t)(i < n ? i : n - 1) * sstride];
         }
+        // (no `if (i < n)` around the stores: the compiler sinks a load whose only use is conditional into that
+        //  branch -- load, wait, store, eight times, as the ISA of the first version showed.  Past the end the last
+        //  element is stored again, with its own value.)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int i = i0 + u * nthr;
-            if (i < n) dst[i] = v[u];
+            dst[i < n ? i : n - 1] = v[u];
         }
     }
 }
@@ -126,7 +127,7 @@ __device__ __forceinline__ void gg_stage_sub(float *Wl, const float *__restrict_
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int e = e0 + u * nthr;
-            if (e < nent) *(vec_t *)(Wl + (size_t)e * NV) = v[u];
+            *(vec_t *)(Wl + (size_t)(e < nent ? e : nent - 1) * NV) = v[u];      // (unconditional: see gg_stage_copy4)
         }
     }
 }
