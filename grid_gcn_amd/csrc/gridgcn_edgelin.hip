@@ -131,21 +131,26 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
     const int cl = live ? c : 0;
     float sc[VPL], sh[VPL], mu[VPL], bz[VPL], cz[VPL], wg[3][VPL], acc[VPL];
     float w0[VPL], w1[VPL], w2[VPL], bb[VPL];        // forward constants (Z recomputed)
+    // (every constant loaded unconditionally from a valid address -- cl is clamped, an absent table reads the
+    //  scale vector instead -- and selected afterwards: a load behind its own condition is a branch with a wait,
+    //  nine memory round trips in a row at the start of this kernel)
+    {
+        const bool rw = !p.Z && live, hw = rw && p.Wg, hb = rw && p.b;
+        const float *wgp = p.Wg ? p.Wg : p.scale;          // [3][C0] or, absent, anything readable at [cl + i]
+        const int cs = p.Wg ? C0 : 0;
+        const float *bp = p.b ? p.b : p.scale;
 #pragma unroll
-    for (int i = 0; i < VPL; i++) {
-        const bool rw = !p.Z && live;
-        w0[i] = (rw && p.Wg) ? p.Wg[cl + i] : 0.f;
-        w1[i] = (rw && p.Wg) ? p.Wg[C0 + cl + i] : 0.f;
-        w2[i] = (rw && p.Wg) ? p.Wg[2 * C0 + cl + i] : 0.f;
-        bb[i] = rw ? p.b[cl + i] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < VPL; i++) {
-        const float s = live ? p.scale[cl + i] : 0.f;
-        sc[i] = s; sh[i] = live ? p.shift[cl + i] : 0.f; mu[i] = live ? p.mean[cl + i] : 0.f;
-        bz[i] = live ? -(s * p.rstd[cl + i]) * p.m2[cl + i] : 0.f;
-        cz[i] = live ? -(s * p.m1[cl + i]) : 0.f;
-        wg[0][i] = 0.f; wg[1][i] = 0.f; wg[2][i] = 0.f; acc[i] = 0.f;
+        for (int i = 0; i < VPL; i++) {
+            const float a0 = wgp[cl + i], a1 = wgp[cs + cl + i], a2 = wgp[2 * cs + cl + i], a3 = bp[cl + i];
+            const float sv = p.scale[cl + i], shv = p.shift[cl + i], muv = p.mean[cl + i], rsv = p.rstd[cl + i],
+                        m1v = p.m1[cl + i], m2v = p.m2[cl + i];
+            w0[i] = hw ? a0 : 0.f; w1[i] = hw ? a1 : 0.f; w2[i] = hw ? a2 : 0.f; bb[i] = hb ? a3 : 0.f;
+            const float s = live ? sv : 0.f;
+            sc[i] = s; sh[i] = live ? shv : 0.f; mu[i] = live ? muv : 0.f;
+            bz[i] = live ? -(s * rsv) * m2v : 0.f;
+            cz[i] = live ? -(s * m1v) : 0.f;
+            wg[0][i] = 0.f; wg[1][i] = 0.f; wg[2][i] = 0.f; acc[i] = 0.f;
+        }
     }
     const bool active = wid < p.B * p.cpc;
     if (active) {
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256) void gg_k_edge_lin0_bwd(GGEdgeLin0Bwd p)
             long long dest = (long long)b * N - 1 + key;
             if (dest < 0) dest = 0;
             float *d = p.dYsrc + dest * C0 + c;
-            const bool whole = key != 0 && key != N && rbeg == rp[key] && rend == rp[key + 1];
+            const int r0 = rp[key], r1 = rp[key + 1];      // (both loads together: rp has N + 3 entries, key <= N)
+            const bool whole = (key != 0) & (key != N) & (rbeg == r0) & (rend == r1);
             if (whole) {
 #pragma unroll
                 for (int i = 0; i < VPL; i++) d[i] = acc[i];
