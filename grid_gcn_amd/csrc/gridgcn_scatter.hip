@@ -39,8 +39,15 @@ __global__ __launch_bounds__(1024) void gg_k_csr_hist(const int *__restrict__ in
     const long long rows = (long long)B * N;
     const int per = (M + GG_CSR_PARTS - 1) / GG_CSR_PARTS;
     const int m0 = part * per, m1 = m0 + per < M ? m0 + per : M;
-    for (int m = m0 + threadIdx.x; m < m1; m += 1024)
-        atomicAdd(&cnt[gg_csr_key(index[(size_t)b * M + m], b, N, rows)], 1);
+    // four index loads in flight per thread (one by one: a memory round trip per 1024 edges); past the end the last
+    // edge is read again and counted with 0 -- no branch around the use, or the load is sunk into it
+    for (int m = m0 + threadIdx.x; m < m1; m += 4096) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = index[(size_t)b * M + (m + 1024 * u < m1 ? m + 1024 * u : m1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) atomicAdd(&cnt[gg_csr_key(v[u], b, N, rows)], m + 1024 * u < m1 ? 1 : 0);
+    }
     __syncthreads();
     int *out = hist + ((size_t)b * GG_CSR_PARTS + part) * nk;
     for (int j = threadIdx.x; j < nk; j += 1024) out[j] = cnt[j];
@@ -62,7 +69,13 @@ __global__ __launch_bounds__(1024) void gg_k_csr_scan(int N, int *__restrict__ h
         const int k = k0 + threadIdx.x;
         int tot = 0;
         if (k < nk)
-            for (int s = 0; s < GG_CSR_PARTS; s++) tot += h[(size_t)s * nk + k];
+            {
+                int c[GG_CSR_PARTS];                       // (the 16 loads together, added in part order)
+#pragma unroll
+                for (int s = 0; s < GG_CSR_PARTS; s++) c[s] = h[(size_t)s * nk + k];
+#pragma unroll
+                for (int s = 0; s < GG_CSR_PARTS; s++) tot += c[s];
+            }
         // inclusive scan of tot over the block
         int v = tot;
 #pragma unroll
@@ -78,10 +91,13 @@ __global__ __launch_bounds__(1024) void gg_k_csr_scan(int N, int *__restrict__ h
         if (k < nk) {
             rp[k] = excl;
             int run = excl;
+            int c[GG_CSR_PARTS];
+#pragma unroll
+            for (int s = 0; s < GG_CSR_PARTS; s++) c[s] = h[(size_t)s * nk + k];
+#pragma unroll
             for (int s = 0; s < GG_CSR_PARTS; s++) {
-                const int c = h[(size_t)s * nk + k];
                 h[(size_t)s * nk + k] = run;
-                run += c;
+                run += c[s];
             }
         }
         __syncthreads();
@@ -104,11 +120,20 @@ __global__ __launch_bounds__(1024) void gg_k_csr_scatter(const int *__restrict__
     const long long rows = (long long)B * N;
     const int per = (M + GG_CSR_PARTS - 1) / GG_CSR_PARTS;
     const int m0 = part * per, m1 = m0 + per < M ? m0 + per : M;
-    for (int m = m0 + threadIdx.x; m < m1; m += 1024) {
-        const int key = gg_csr_key(index[(size_t)b * M + m], b, N, rows);
-        const int pos = atomicAdd(&cur[key], 1);
-        perm[(size_t)b * M + pos] = m;
-        keys[(size_t)b * M + pos] = key;
+    for (int m = m0 + threadIdx.x; m < m1; m += 4096) {       // (four index loads in flight, as in gg_k_csr_hist)
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = index[(size_t)b * M + (m + 1024 * u < m1 ? m + 1024 * u : m1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool ok = m + 1024 * u < m1;
+            const int key = gg_csr_key(v[u], b, N, rows);
+            const int pos = atomicAdd(&cur[key], ok ? 1 : 0);
+            if (ok) {
+                perm[(size_t)b * M + pos] = m + 1024 * u;
+                keys[(size_t)b * M + pos] = key;
+            }
+        }
     }
 }
 
