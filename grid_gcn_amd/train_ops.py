@@ -2349,10 +2349,13 @@ def linear_plain_train(x, lin):
 
 class _HeadTrain(torch.autograd.Function):
     """conv+BN+ReLU chain -> Dropout(p) -> Linear (ggcn_models_g.py:33-38: fc1, fc1/dropout, fc2)
-    as one op.  The Dropout mask is a hash of (seed, element index): the forward applies it while
-    the last BatchNorm+ReLU is written, the backward while fc2's input gradient is written -- whose
-    epilogue also accumulates fc1's BatchNorm-backward sums.  Against the separate ops this drops
-    the dropout forward / backward passes and one reduce pass over the [E, C] gradient."""
+    as one op.  The Dropout mask is a hash of (seed, element index) that every reader of the dropped
+    activation evaluates itself: fc2's forward while it loads the rows of Z_fc1 (BatchNorm + ReLU + mask
+    in the prologue), fc2's weight-gradient kernel on its B operand, and the kernel that writes fc2's input
+    gradient -- whose epilogue also accumulates fc1's BatchNorm-backward sums (FUSE_DROPOUT; fp32 mode,
+    128 columns).  Otherwise the dropped activation is written once (gridgcn_bn_relu_dropout_apply) and
+    only the backward regenerates the mask.  Against the separate ops this drops the dropout forward /
+    backward passes, the dropped tensor and one reduce pass over the [E, C] gradient."""
 
     @staticmethod
     def forward(ctx, x, meta, *params):
