@@ -165,3 +165,28 @@ __device__ __forceinline__ gg_f32x4 gg_dz4v(gg_f32x4 z, gg_f32x4 g, unsigned am,
     gm.w = ((y.w > 0.f) & (ns | ((int)(am >> 24) == pp))) ? g.w : 0.f;
     return __builtin_elementwise_fma(sc, gm, t);
 }
+
+// n float4 from src (every sstride-th) to LDS, eight loads in flight per thread.  (The plain loop -- load, wait, LDS
+// store, sixteen times for a 256 x 128 operand -- opened EVERY forward / dX launch with ~10 us in which the whole
+// chip waited for L2 round trips one after the other; found in the ISA at the end of round 4.)
+__device__ __forceinline__ void gg_stage_copy4(float4 *dst, const float4 *__restrict__ src, int n, int sstride,
+                                               int tid, int nthr)
+{
+    for (int i0 = tid; i0 < n; i0 += nthr * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * nthr;
+            v[u] = src[(size_t)(i < n ? i : n - 1) * sstride];
+        }
+        // (no `if (i < n)` around the stores: the compiler sinks a load whose only use is conditional into that
+        //  branch -- load, wait, store, eight times, as the ISA of the first version showed.  Past the end the last
+        //  element is stored again, with its own value.)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * nthr;
+            dst[i < n ? i : n - 1] = v[u];
+        }
+    }
+}
+
