@@ -26,6 +26,7 @@ struct GGGemm {
     const float *bias;    // modes 0 / 1: added per output column (nullptr: none)
     float *part;          // mode 2: [tiles][S][1024]
     int *tick;            // mode 2: [tiles], zero on entry, zero again on exit
+    int rps;              // mode 2: rows of one workgroup's slice (a multiple of GG_TN_ROWS)
 };
 
 // mode 0: C[m][n] = sum_k A[m][k] B[n][k]      mode 1: C[m][n] = sum_k A[m][k] B[k][n]
@@ -105,7 +106,9 @@ __global__ __launch_bounds__(256) void gg_k_gemm_rows(GGGemm p)
     }
 }
 
-#define GG_TN_ROWS 256      // rows of a workgroup's slice (64 per wave: 32 MFMA steps)
+#define GG_TN_ROWS 256      // rows of a workgroup's slice (64 per wave: 32 MFMA steps) ...
+#define GG_TN_MAX_PART 4096 // ... or a multiple of that, so that tiles x slices <= this many 4-KB partial tiles (16 MB):
+                            // a [512 x 320] product over 10^6 rows would otherwise ask for 2.6 GB of workspace
 
 // C[m][n] = sum_k A[k][m] B[k][n]
 __global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
     int m = tm * 32 + l31, n = tn * 32 + l31;
     if (m >= p.M) m = p.M - 1;
     if (n >= p.N) n = p.N - 1;
-    const long long ka = (long long)z * GG_TN_ROWS + wave * (GG_TN_ROWS / 4);
-    long long kz = ka + GG_TN_ROWS / 4;
+    const long long ka = (long long)z * p.rps + wave * (p.rps / 4);
+    long long kz = ka + p.rps / 4;
     if (kz > p.K) kz = p.K;
     ggm_f32x16 acc;
 #pragma unroll
@@ -220,11 +223,24 @@ __global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
     }
 }
 
+// rows per slice and number of slices of the transposed product
+static void gg_tn_slices(int M, int N, int K, int &rps, int &S)
+{
+    const long long tiles = (long long)((M + 31) / 32) * ((N + 31) / 32);
+    const long long s0 = ((long long)K + GG_TN_ROWS - 1) / GG_TN_ROWS;
+    long long smax = GG_TN_MAX_PART / tiles;
+    if (smax < 1) smax = 1;
+    const long long nsub = (s0 + smax - 1) / smax;            // sub-slices of GG_TN_ROWS rows a workgroup walks
+    rps = (int)(nsub * GG_TN_ROWS);
+    S = (int)(((long long)K + rps - 1) / rps);
+}
+
 size_t gg_gemm_small_workspace(int M, int N, int K)
 {
     const size_t tiles = (size_t)((M + 31) / 32) * ((N + 31) / 32);
-    const size_t S = ((size_t)K + GG_TN_ROWS - 1) / GG_TN_ROWS;
-    return tiles * S * 1024 * sizeof(float) + tiles * sizeof(int) + 256;
+    int rps, S;
+    gg_tn_slices(M, N, K, rps, S);
+    return tiles * (size_t)S * 1024 * sizeof(float) + tiles * sizeof(int) + 256;
 }
 
 // workspace (mode 2 only): gg_gemm_small_workspace bytes, its LAST tiles * 4 + 256 bytes (the tickets) zero
@@ -241,7 +257,8 @@ int gg_gemm_small(int mode, const float *A, int lda, const float *B, int ldb, fl
     const int ntile = ((M + 31) / 32) * ((N + 31) / 32);
     if (mode == 2) {
         if (zero_left || !ws) return 1;
-        const int S = (K + GG_TN_ROWS - 1) / GG_TN_ROWS;
+        int S;
+        gg_tn_slices(M, N, K, p.rps, S);
         p.part = (float *)ws;
         p.tick = (int *)((char *)ws + (size_t)ntile * S * 1024 * sizeof(float));
         gg_k_gemm_tn<<<dim3(S, ntile), 256, 0, st>>>(p);

@@ -127,4 +127,5 @@ class GraphedTrainStep:
         # Tensor._version (folded evaluation constants, gridconv.SubGUpdate.packed_layers) must see it
         with torch.no_grad():
             torch.autograd.graph.increment_version(self._state)
+        train_ops.params_changed()
         return self.loss

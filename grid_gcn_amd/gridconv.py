@@ -262,8 +262,9 @@ class SubGUpdate(nn.Module):
 
     def packed_layers(self):
         """BatchNorm-folded, padded weights for the fused kernel (cached; eval mode only)."""
-        from . import ops
-        key = tuple(p._version for p in self.parameters()) + tuple(
+        from . import ops, train_ops
+        # (the parameter generation: fused optimizers rewrite weights without moving Tensor._version)
+        key = (train_ops._PARAM_GEN[0],) + tuple(p._version for p in self.parameters()) + tuple(
             b._version for b in self.buffers())
         if getattr(self, "_packed_key", None) != key:
             # LDS row of the first pt layer = the gathered source row (x,y,z,w,features) with

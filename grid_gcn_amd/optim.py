@@ -70,8 +70,20 @@ class Adam(torch.optim.Optimizer):
         self._flat[id(group)] = fs
         return fs
 
+    def state_dict(self):
+        """torch.optim.Adam's schema.  Inside this optimizer every parameter's `step` is a view of the GROUP's one
+        device-side counter; a checkpoint carries an independent float32 scalar per parameter instead (what
+        torch.optim.Adam stores), so that loading it there does not advance one shared element once per parameter."""
+        sd = super().state_dict()
+        for s in sd["state"].values():
+            if "step" in s:
+                s["step"] = s["step"].detach().to(torch.float32).reshape(()).clone()
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            g.setdefault("mxnet", False)     # (a torch.optim.Adam checkpoint has no such key)
         self._flat.clear()        # the loaded moments are copied into fresh flat buffers at the next step
 
     @torch.no_grad()
@@ -116,7 +128,7 @@ class Adam(torch.optim.Optimizer):
                                            ctypes.c_void_p(fs["state"].data_ptr()), float(lr), lr_dev,
                                            float(group["betas"][0]), float(group["betas"][1]),
                                            float(group["eps"]), float(group["weight_decay"]),
-                                           1 if group["mxnet"] else 0,
+                                           1 if group.get("mxnet", False) else 0,
                                            torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(rc, "gridgcn_adam_step")
             # (the kernel writes through raw pointers: caches keyed on Tensor._version -- the folded

@@ -32,6 +32,7 @@ import ctypes
 import weakref
 
 import torch
+from torch.optim import optimizer as _torch_optimizer_mod
 
 from . import _lib
 from .ops import _ptr, _stream
@@ -582,6 +583,9 @@ def _gemm_small(mode, A, B, C, M, N, K, zero_left=0):
         key = (str(A.device), nb, torch.cuda.current_stream(A.device).cuda_stream)
         ws = _GEMM_WS.get(key)
         if ws is None:
+            # (the library bounds a workspace at ~16 MB whatever the row count; at most 32 of them are kept)
+            if len(_GEMM_WS) >= 32:
+                _GEMM_WS.clear()
             ws = _GEMM_WS[key] = torch.zeros(nb, dtype=torch.uint8, device=A.device)
     rc = lib.gridgcn_gemm_small(mode, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0),
                                 M, N, K, zero_left, _ptr(ws) if ws is not None else None, nb, _stream(A))
@@ -1118,6 +1122,21 @@ def mlp_wide_train(x, layers):
 # clear_eval_cache() after editing parameters that way.)
 EVAL_CACHE = True
 _EVAL_BN, _EVAL_W = {}, {}
+# Tensor._version alone is not enough: torch's fused / foreach optimizers update the parameters without moving it
+# (torch.optim.Adam(fused=True) in an eager loop, then eval() -> the first evaluation's packed weights
+# were reused).  Every cache key therefore also carries a process-wide PARAMETER GENERATION, advanced by a global
+# optimizer-step hook (any torch.optim.Optimizer, this package's Adam included) and by graph.GraphedTrainStep
+# after a replay: whatever may have rewritten a weight since the entry was built makes it stale.  An
+# evaluation-only loop never advances it, so it keeps its cache.
+_PARAM_GEN = [0]
+
+
+def params_changed(*_args, **_kw):
+    """Declare that parameters / BatchNorm buffers may have been rewritten behind autograd's back."""
+    _PARAM_GEN[0] += 1
+
+
+_torch_optimizer_mod.register_optimizer_step_post_hook(params_changed)
 
 
 def clear_eval_cache():
@@ -1132,7 +1151,7 @@ def _stats_written(bn):
 
 def _bn_eval_vectors(bn):
     """(scale, shift) of a BatchNorm in evaluation mode: y = x * scale + shift"""
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+    key = (_PARAM_GEN[0], bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps)
     e = _EVAL_BN.get(id(bn)) if EVAL_CACHE else None
     if e is not None and e[0]() is bn and e[1] == key:
@@ -1150,7 +1169,7 @@ def _eval_packed(lib, lin, cout_p, cin, st):
     columns and cout_p >= out_features output columns (gridgcn_pack_linear)"""
     W, b = lin.weight, lin.bias
     cout, cin_w = W.shape
-    key = (cout_p, cin, W._version, b._version, W.data_ptr(), b.data_ptr())
+    key = (_PARAM_GEN[0], cout_p, cin, W._version, b._version, W.data_ptr(), b.data_ptr())
     e = _EVAL_W.get(id(lin)) if EVAL_CACHE else None
     if e is not None and e[0]() is lin and e[1] == key:
         return e[2]
@@ -1218,7 +1237,7 @@ def edge_block_src_eval(src, nebidx, cent, pt_layer, att_layers, localfdim, out=
         st = _stream(src)
         feat = src[..., 4:].reshape(R, Cf)
         Ysrc = _mm_nt(feat, W0[:, rot:])
-        wkey = (geo, W0._version, b0._version, W0.data_ptr(), b0.data_ptr())
+        wkey = (_PARAM_GEN[0], geo, W0._version, b0._version, W0.data_ptr(), b0.data_ptr())
         e = _EVAL_W.get(("wgb", id(pt_layer))) if EVAL_CACHE else None
         if e is not None and e[0]() is pt_layer and e[1] == wkey:
             wgb = e[2]

@@ -248,3 +248,83 @@ def test_eval_constants_cache_follows_training():
         assert torch.equal(a, b)
         assert float((a - outs[-1]).abs().max()) > 0
         outs.append(a)
+
+
+def test_adam_checkpoints_travel_to_and_from_torch_adam():
+    """(a) a torch.optim.Adam checkpoint has no 'mxnet' group key; (b) this optimizer's per-parameter
+    `step` entries are views of ONE device counter -- a checkpoint must carry independent scalars, or
+    torch.optim.Adam's _foreach_add_ advances the shared element once per parameter."""
+    from grid_gcn_amd import optim
+    p1 = _params(SIZES[:5], 6)
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in p1]
+    own = optim.Adam(p1, lr=1e-3)
+    ref = torch.optim.Adam(p2, lr=1e-3)
+    g = torch.Generator().manual_seed(7)
+
+    def grads():
+        for a, b in zip(p1, p2):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+
+    for _ in range(2):
+        grads()
+        own.step()
+        ref.step()
+    sd = own.state_dict()
+    steps = [s["step"] for s in sd["state"].values()]
+    assert len({t.data_ptr() for t in steps}) == len(steps) and all(float(t) == 2.0 for t in steps)
+    # own -> torch: three more steps there == three more steps here
+    t2 = torch.optim.Adam(p2, lr=1e-3)
+    t2.load_state_dict(copy.deepcopy(sd))
+    # torch -> own (no 'mxnet' key in that checkpoint)
+    o2 = optim.Adam(p1, lr=1e-3)
+    o2.load_state_dict(copy.deepcopy(ref.state_dict()))
+    for _ in range(3):
+        grads()
+        o2.step()
+        t2.step()
+    assert all(float(s["step"]) == 5.0 for s in t2.state.values())
+    assert int(o2.state[p1[0]]["step"]) == 5
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a, b, rtol=0, atol=5e-7)
+
+
+def test_eval_cache_sees_torch_fused_adam():
+    """torch's fused Adam rewrites the weights without moving Tensor._version; the evaluation caches
+    (folded BatchNorm vectors, packed weights, the wgb table, SubGUpdate.packed_layers) are keyed on the
+    parameter generation that the global optimizer-step hook advances -- evaluation after eager training with
+    that optimizer == evaluation with the cache off."""
+    from grid_gcn_amd import model, synth, train_ops
+    torch.manual_seed(2)
+    net = model.GGCNSeg(model.SEG_8192, seed=3).to(DEV)
+    data, npn = synth.make_batch(2, 8192, "planes", first_id=9)
+    x = torch.from_numpy(data[..., :3].copy()).to(DEV)
+    n = torch.from_numpy(npn).to(DEV)
+    lab = torch.randint(0, 21, (2, 8192), device=DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+
+    def evaluate(cache):
+        net.eval()
+        train_ops.EVAL_CACHE = cache
+        try:
+            with torch.no_grad():
+                return net(x, n).clone()
+        finally:
+            train_ops.EVAL_CACHE = True
+            net.train()
+
+    net.train()
+    prev = None
+    for _ in range(3):
+        a = evaluate(True)
+        assert torch.equal(a, evaluate(False))
+        assert prev is None or float((a - prev).abs().max()) > 0
+        prev = a
+        v0 = net.fc2.weight._version
+        opt.zero_grad(set_to_none=True)
+        model.seg_loss(net(x, n), lab).backward()
+        g0 = train_ops._PARAM_GEN[0]
+        opt.step()
+        assert train_ops._PARAM_GEN[0] > g0
+    a = evaluate(True)
+    assert torch.equal(a, evaluate(False)) and float((a - prev).abs().max()) > 0

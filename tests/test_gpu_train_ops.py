@@ -321,6 +321,27 @@ def test_gemm_small_matches_torch(R, Cf, C0, rot):
         assert torch.equal(t, train_ops._tn_matmul(Y, G))
 
 
+def test_tn_matmul_tall_product_bounded_workspace():
+    """the transposed product's workspace used to grow with the row count (tiles x ceil(R/256) x 4 KB:
+    2.6 GB for a [512 x 320] product over 10^6 rows).  The library now caps tiles x slices at 4096 partial tiles
+    and a workgroup walks several 256-row sub-slices instead: same result, workspace <= ~16 MB."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    lib = _lib.load()
+    n = ctypes.c_size_t(0)
+    lib.gridgcn_gemm_small_workspace_bytes(512, 320, 1 << 20, ctypes.byref(n))
+    assert n.value <= (17 << 20)
+    torch.manual_seed(11)
+    R, m, k = 300000 + 77, 96, 160          # 15 tiles -> 273 slices allowed, 1172 sub-slices: 5 per workgroup
+    a, b = torch.randn(R, m, device=DEV), torch.randn(R, k, device=DEV)
+    lib.gridgcn_gemm_small_workspace_bytes(m, k, R, ctypes.byref(n))
+    assert n.value <= (17 << 20)
+    t = train_ops._tn_matmul(a, b)
+    ref = a.double().t() @ b.double()
+    assert float((t - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * R ** 0.5
+    assert torch.equal(t, train_ops._tn_matmul(a, b))
+
+
 def test_pack_cache_batch_launch_equals_single_packs():
     """train_ops.PACKS: the one-launch rebuild of every layout of a module
     (gridgcn_pack_linear_batch) writes, bit for bit, what the per-layer gridgcn_pack_linear writes;
