@@ -198,6 +198,22 @@ def make_step(net, opt, sync, loss_fn, inputs, target, use_graph):
     return eager, "eager"
 
 
+def ranks_agree(what, value, world, dev):
+    """N > 1: every rank must time the SAME kind of step.  One rank silently on the eager fallback (its capture
+    failed, its probe disagreed) would read as a scaling loss in SCALE_r*.json; this makes it fatal on all ranks
+    instead.  `value` is a short string; compared through its bytes' MIN and MAX over the ranks."""
+    if world <= 1 or not dist.is_initialized():
+        return
+    b = (value or "").encode()[:32].ljust(32, b"\0")
+    t = torch.tensor(list(b), dtype=torch.int32, device=dev)
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not bool((lo == hi).all()):
+        raise RuntimeError("[rank %d] %s differs across ranks (this rank: %r): refusing to time a mixed "
+                           "hipgraph / eager job" % (dist.get_rank(), what, value))
+
+
 def time_training(step, steps, warmup, world, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.
     Also returns the host time needed to ENQUEUE the K steps (before the final synchronize)."""
@@ -373,6 +389,8 @@ def main():
     n = torch.from_numpy(npn).to(dev)
     lab = torch.randint(0, cfg["num_classes"], (B, points), device=dev)
     step, step_mode = make_step(net, opt, sync, model.seg_loss, (x, n), lab, not a.eager)
+    ranks_agree("step_mode", step_mode, world, dev)
+    ranks_agree("rccl_capture_probe", getattr(make_step, "probe", None), world, dev)
 
     dt, t_enq = time_training(step, a.steps, a.warmup, world, dev)
     ms_step = dt / a.steps * 1e3

@@ -305,6 +305,260 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// gg_k_att_bwd_nz2 (round 5): the same arithmetic in the same order -- every output word equals gg_k_att_bwd_nz's
+// -- with the tile loop stripped of what the ISA showed it spending outside its 160 MFMAs (tools/isa.py: 575 VALU +
+// 330 SALU per tile): two 64-bit divisions per tile (row -> centre, neighbour), 16 predicated 64-bit addresses for
+// the layer-in-front rows, 16 row branches in the epilogue, NaN selects.
+//   * (centre, neighbour) of a lane's row advance by a constant per iteration: add, compare, select -- no division;
+//   * every stream is a buffer access with a range-checked descriptor: rows past the end load 0 / are not stored,
+//     so a partial last tile needs no predicate on any load or store (its idle rows get a1 = 0 under ONE
+//     wave-uniform branch); gval / amax of a lane are 4 + 1 sixteen-byte loads per chunk with immediate offsets;
+//   * the descriptor of the tile's Z1 / dX rows is rebased per tile on the scalar unit.
+// Needs 32-bit byte offsets: E < 2^24 rows, E / P < 2^22 centres (gg_att_nz2_ok); otherwise the first form runs.
+__device__ gg_i32x4 gg_buf_ld4i(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+
+__device__ __forceinline__ gg_rsrc gg_make_rsrc_n(const void *uniform_base, unsigned bytes)
+{
+    gg_rsrc r = gg_make_rsrc(uniform_base);
+    r.z = (int)bytes;                    // raw buffer, stride 0: num_records in bytes; beyond it loads return 0
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
+{
+    constexpr int C = GG_NZ_C, NJ = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    float *Wl = lds;                       // [4 chunks][64 lanes][WS]   dX operand
+    float *Mp = Wl + 4 * 64 * GG_NZ_WS;    // [64 lanes][WS]             dense operand M
+    float *csc = Mp + 64 * GG_NZ_WS;       // [C] scale
+    float *cbz = csc + C;                  // [C] bz = -(sc rstd) m2
+    float *ct = cbz + C;                   // [C] cz + bz (b2 - mu)
+    float *v0 = ct + C;                    // [32]
+    float *pcs = v0 + 32;                  // [2][32] previous layer's scale, shift
+    float *T = pcs + 64 + wave * (64 * GG_NZ_TS);
+    for (int i0 = tid; i0 < C * 32; i0 += 256 * 8) {
+        float w8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w8[u] = p.W2[i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 256 * u < C * 32 ? i0 + 256 * u : C * 32 - 1;
+            const int k = i >> 5, col = i & 31;
+            Wl[((k >> 5) * 64 + ((k >> 4) & 1) * 32 + col) * GG_NZ_WS + (k & 15)] = w8[u];
+        }
+    }
+    for (int c = tid; c < C; c += 256) {
+        const float sc = p.sc[c];
+        const float m1 = (float)(p.bsums[c] / (double)p.E), m2 = (float)(p.bsums[C + c] / (double)p.E);
+        const float bz = -(sc * p.rs[c]) * m2, cz = -(sc * m1);
+        csc[c] = sc;
+        cbz[c] = bz;
+        ct[c] = cz + bz * (p.b2[c] - p.mu[c]);
+    }
+    if (tid < 32) { pcs[tid] = p.ps[tid]; pcs[32 + tid] = p.psh[tid]; }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        const int s = i >> 6, ln = i & 63, j = 16 * (ln >> 5) + s, col = ln & 31;
+        float m = 0.f;
+        for (int c = 0; c < C; c++) m = __builtin_fmaf(cbz[c] * gg_nz_w2(Wl, c, j), gg_nz_w2(Wl, c, col), m);
+        Mp[ln * GG_NZ_WS + s] = m;
+    }
+    if (tid < 32) {
+        float v = 0.f;
+        for (int c = 0; c < C; c++) v = __builtin_fmaf(ct[c], gg_nz_w2(Wl, c, tid), v);
+        v0[tid] = v;
+    }
+    __syncthreads();
+    const float ps = pcs[l31], psh = pcs[32 + l31];
+    const float pm = p.pm[l31], pr = p.pr[l31];
+    const float pc = -(pm * pr);                       // zhat = zp * pr + pc
+    const float v0l = v0[l31];
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    ggm_f32x16 accw[NJ], accS;
+    ggm_zero<NJ>(accw);
+#pragma unroll
+    for (int r = 0; r < 16; r++) accS[r] = 0.f;
+
+    const int E = (int)p.E, P = p.P;
+    const int ntile = (E + 31) >> 5;
+    const int tstride = (int)gridDim.x * 4;
+    int tile = (int)blockIdx.x * 4 + wave;             // (wave uniform)
+    // (centre, neighbour) of this lane's row, now and one iteration (tstride tiles) on: constants qs, rs
+    const int qs = (tstride * 32) / P, rs = tstride * 32 - qs * P;
+    int cen, pp;
+    {
+        const int row = tile * 32 + l31;
+        cen = row / P;
+        pp = row - cen * P;
+    }
+    const unsigned ncent = (unsigned)(E / P);
+    const gg_rsrc rg = gg_make_rsrc_n(p.gval, ncent * (unsigned)(C * 4));
+    const gg_rsrc ra = gg_make_rsrc_n(p.amax, ncent * (unsigned)C);
+    // lane constants of the two row layouts of a 32-row block of [.][32] floats
+    const unsigned vcd = (unsigned)(h * 4 * GG_NZ_K + l31) * 4u;           // C/D order: row 4h (+ rr), column l31
+    const unsigned vrw = (unsigned)(l31 * GG_NZ_K + 16 * h) * 4u;          // row order: row l31, columns 16h ..
+
+    // the 16 channels a lane consumes next (upstream gradient, arg-max bytes), one chunk ahead
+    gg_f32x4 g[4];
+    gg_i32x4 am;
+    auto issue = [&](int cen_, int ci) {
+        const unsigned vg = (unsigned)cen_ * (unsigned)(C * 4) + (unsigned)(ci * 32 + h * 16) * 4u;
+        const unsigned va = (unsigned)cen_ * (unsigned)C + (unsigned)(ci * 32 + h * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[q] = gg_buf_ld4(rg, vg + 16u * q, 0);
+        am = gg_buf_ld4i(ra, va, 0);
+    };
+    if (tile < ntile) issue(cen, 0);
+    for (; tile < ntile; tile += tstride) {
+        const int r0 = tile << 5;
+        const int nrows = E - r0 < 32 ? E - r0 : 32;                        // (wave uniform)
+        int cenN = cen + qs, ppN = pp + rs;
+        { const bool t = ppN >= P; ppN -= t ? P : 0; cenN += t ? 1 : 0; }
+        const gg_rsrc rz = gg_make_rsrc_n(p.Z1 + (size_t)r0 * GG_NZ_K, (unsigned)nrows * (GG_NZ_K * 4));
+        const gg_rsrc rx = gg_make_rsrc_n(p.dX + (size_t)r0 * GG_NZ_K, (unsigned)nrows * (GG_NZ_K * 4));
+        // the layer in front, twice: C/D row order (rows (r&3) + 8(r>>2) + 4h, column l31) as the A operand of
+        // the dW^T / S2 products and for the epilogue's sums; row order (lane = row, 16 consecutive columns) as
+        // the A operand of the dense product.  Rows past the end load 0.
+        float avr[16], zpv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) zpv[r] = gg_buf_ld(rz, vcd + (unsigned)(((r & 3) + 8 * (r >> 2)) * GG_NZ_K * 4), 0);
+        gg_f32x4 z1r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) z1r[q] = gg_buf_ld4(rz, vrw + 16u * q, 0);
+        ggm_f32x16 accx;
+#pragma unroll
+        for (int r = 0; r < 16; r++) accx[r] = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < NJ; ci++) {
+            const int cc = ci & 1;
+            float a[4][4];
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned amv[4] = {(unsigned)am.x, (unsigned)am.y, (unsigned)am.z, (unsigned)am.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    a[q][0] = (int)(amv[q] & 255u) == pp ? g[q].x : 0.f;     // (scale and ReLU mask applied upstream)
+                    a[q][1] = (int)((amv[q] >> 8) & 255u) == pp ? g[q].y : 0.f;
+                    a[q][2] = (int)((amv[q] >> 16) & 255u) == pp ? g[q].z : 0.f;
+                    a[q][3] = (int)(amv[q] >> 24) == pp ? g[q].w : 0.f;
+                    float *tw = T + (cc * 32 + h * 16 + 4 * q) * GG_NZ_TS + l31;
+                    tw[0] = a[q][0]; tw[GG_NZ_TS] = a[q][1]; tw[2 * GG_NZ_TS] = a[q][2]; tw[3 * GG_NZ_TS] = a[q][3];
+                }
+            }
+            if (ci + 1 < NJ) issue(cen, ci + 1);
+            else issue(cenN, 0);
+            // (keep the loads HERE: left alone, the scheduler sinks them to their first use)
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                gg_f32x4 w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) w4[q] = gg_ld_f4(Wl + (ci * 64 + lane) * GG_NZ_WS + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float wv[4] = {w4[q].x, w4[q].y, w4[q].z, w4[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], wv[i], accx, 0, 0, 0);
+                }
+            }
+            // (the activations of the layer in front are formed HERE, behind the first chunk's dZ and dX MFMAs:
+            //  at the top of the tile the wave would wait out the full latency of the loads it has just issued)
+            if (ci == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) avr[r] = fmaxf(__builtin_fmaf(zpv[r], ps, psh), 0.f);
+                if (nrows < 32) {                      // (wave uniform: the last tile only)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) avr[r] = ((r & 3) + 8 * (r >> 2) + 4 * h < nrows) ? avr[r] : 0.f;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                gg_f32x4 t4[4];
+#pragma unroll
+                for (int jg = 0; jg < 4; jg++) t4[jg] = gg_ld_f4(T + (cc * 32 + l31) * GG_NZ_TS + 8 * jg + 4 * h);
+#pragma unroll
+                for (int jg = 0; jg < 4; jg++) {
+                    const float tv[4] = {t4[jg].x, t4[jg].y, t4[jg].z, t4[jg].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        accw[ci] = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[4 * jg + i], tv[i], accw[ci], 0, 0, 0);
+                }
+            }
+        }
+        // dense term: a1 (row order) x M, and S2 += a1^T a1
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const gg_f32x4 y = gg_bnrelu4v(z1r[q], gg_ld_f4(pcs + 16 * h + 4 * q), gg_ld_f4(pcs + 32 + 16 * h + 4 * q));
+            const float yv[4] = {y.x, y.y, y.z, y.w};
+            const gg_f32x4 m4 = gg_ld_f4(Mp + lane * GG_NZ_WS + 4 * q);
+            const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[i], mv[i], accx, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) accS = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[r], avr[r], accS, 0, 0, 0);
+        // dX tile + BatchNorm-backward sums of the layer in front + S1 (rows past the end: a1 = 0, store dropped)
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float dx = accx[r] + v0l;
+            gg_buf_st(dx, rx, vcd + (unsigned)(((r & 3) + 8 * (r >> 2)) * GG_NZ_K * 4), 0);
+            const float d = avr[r] > 0.f ? dx : 0.f;
+            s1 += d;
+            s2 = __builtin_fmaf(d, __builtin_fmaf(zpv[r], pr, pc), s2);
+            s3 += avr[r];
+        }
+        a1 += s1;
+        a2 += s2;
+        a3 += s3;
+        cen = cenN;
+        pp = ppN;
+    }
+    // partial tiles: the four waves add up in LDS (fixed order), one [tile][reg][lane] block per workgroup
+    {
+        float *blk = pcs + 64;                         // 5 * 1024 floats over the tile area (4 * 64 * 36)
+        __syncthreads();
+        for (int w = 0; w < 4; w++) {
+            if (wave == w) {
+#pragma unroll
+                for (int j = 0; j < NJ + 1; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int idx = (j * 16 + r) * 64 + lane;
+                        blk[idx] = (w == 0 ? 0.f : blk[idx]) + (j < NJ ? accw[j < NJ ? j : 0][r] : accS[r]);
+                    }
+            }
+            __syncthreads();
+        }
+        float *part = p.part + (size_t)blockIdx.x * (NJ + 1) * 1024;
+        for (int i = tid; i < (NJ + 1) * 1024; i += 256) part[i] = blk[i];
+    }
+    __syncthreads();
+    float *red = lds;                                  // [4 waves][3][32]
+    {
+        const float t1 = a1 + __shfl_xor(a1, 32, 64);
+        const float t2 = a2 + __shfl_xor(a2, 32, 64);
+        const float t3 = a3 + __shfl_xor(a3, 32, 64);
+        if (lane < 32) {
+            red[(wave * 3 + 0) * 32 + lane] = t1;
+            red[(wave * 3 + 1) * 32 + lane] = t2;
+            red[(wave * 3 + 2) * 32 + lane] = t3;
+        }
+    }
+    __syncthreads();
+    if (tid < 96) {
+        const int which = tid >> 5, col = tid & 31;
+        float v = 0.f;
+        for (int w = 0; w < 4; w++) v += red[(w * 3 + which) * 32 + col];
+        if (which < 2) atomicAdd(&p.psums[which * GG_NZ_K + col], (double)v);
+        else atomicAdd(&p.s1[col], (double)v);
+    }
+}
+
 // Sum of the workgroups' partial tiles.  One 1024-thread workgroup per (tile j, register r): 16 groups of 64
 // lanes each sum a slice of the workgroups, LDS adds the groups in a fixed order.  Tile j < 4, lane l, register r
 // hold dW^T[i][ch], ch = 32j + (l & 31), i = (r & 3) + 8(r >> 2) + 4(l >> 5); tile 4 holds S2[i][l & 31].
@@ -354,6 +608,13 @@ __global__ __launch_bounds__(256) void gg_k_att_nz_finish(GGAttNz p, const float
     if (i == 0 && fm1) gg_bn_bwd_fin_write(p.bsums, p.E, C, c, fm1, fm2, fdg, fdb);
 }
 
+// GRIDGCN_OPT_ATT_NZ_V2 [1]: the stripped tile loop (identical results); 0 = the round-4 kernel
+static int g_att_nz_v2 = 1;
+void gg_set_att_nz_v2(int v) { g_att_nz_v2 = v ? 1 : 0; }
+int gg_get_att_nz_v2() { return g_att_nz_v2; }
+// 32-bit byte offsets into gval ([E / P][128] floats) and row numbers with room for one iteration's advance
+static bool gg_att_nz2_ok(long long E, int P) { return E < (1ll << 24) && E / P < (1ll << 22); }
+
 static int gg_att_nz_grid(long long E)
 {
     const long long ntile = (E + 31) >> 5;
@@ -380,6 +641,7 @@ int gg_att_bwd_noz(const float *Z1, const float *ps, const float *psh, const flo
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
     GGAttNz p;
@@ -389,7 +651,8 @@ int gg_att_bwd_noz(const float *Z1, const float *ps, const float *psh, const flo
     const int nwg = gg_att_nz_grid(E);
     float *S2 = p.part + (size_t)nwg * 5 * 1024;
     const size_t lds = (size_t)(5 * 64 * GG_NZ_WS + 3 * GG_NZ_C + 32 + 64 + 4 * 64 * GG_NZ_TS) * sizeof(float);
-    gg_k_att_bwd_nz<<<nwg, 256, lds, st>>>(p);
+    if (g_att_nz_v2 && gg_att_nz2_ok(E, P)) gg_k_att_bwd_nz2<<<nwg, 256, lds, st>>>(p);
+    else gg_k_att_bwd_nz<<<nwg, 256, lds, st>>>(p);
     gg_k_att_nz_reduce<<<5 * 16, 1024, 0, st>>>(p.part, nwg, dW, S2);
     gg_k_att_nz_finish<<<(GG_NZ_C * GG_NZ_K + 255) / 256, 256, 0, st>>>(p, S2, dW, m1, m2, dgamma, dbeta);
     return hipGetLastError() == hipSuccess ? 0 : 3;

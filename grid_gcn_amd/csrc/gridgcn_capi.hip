@@ -71,6 +71,8 @@ int gg_bn_bwd_finalize(const double *, long long, int, float *, float *, float *
                        hipStream_t);
 
 bool gg_att_bwd_noz_ok(long long E, int cin, int C);               // gridgcn_attbwd_nz.hip
+void gg_set_att_nz_v2(int v);
+int gg_get_att_nz_v2();
 size_t gg_att_bwd_noz_workspace(long long E);
 int gg_att_bwd_noz(const float *, const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const double *,
@@ -161,6 +163,11 @@ int gridgcn_set_option(int option, int value)
         gg_pairmax_split = value;
         return GRIDGCN_OK;
     }
+    if (option == GRIDGCN_OPT_ATT_NZ_V2) {
+        if (value != 0 && value != 1) return GRIDGCN_EINVAL;
+        gg_set_att_nz_v2(value);
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
@@ -172,6 +179,7 @@ int gridgcn_get_option(int option)
     if (option == GRIDGCN_OPT_INDEX_SMALL) return gg_index_get_tuning(2);
     if (option == GRIDGCN_OPT_COL_SPLIT) return gg_get_col_split();
     if (option == GRIDGCN_OPT_PAIRMAX_SPLIT) return gg_pairmax_split;
+    if (option == GRIDGCN_OPT_ATT_NZ_V2) return gg_get_att_nz_v2();
     return -1;
 }
 

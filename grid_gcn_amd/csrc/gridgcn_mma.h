@@ -114,6 +114,7 @@ __device__ __forceinline__ void ggm_mma(const float *A, int lda, const float *__
 typedef int gg_rsrc __attribute__((ext_vector_type(4)));
 typedef float gg_f32x2 __attribute__((ext_vector_type(2)));
 typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
+typedef int gg_i32x4 __attribute__((ext_vector_type(4)));
 __device__ gg_f32x4 gg_buf_ld4(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ gg_f32x2 gg_buf_ld2(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float gg_buf_ld(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.f32");

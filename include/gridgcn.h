@@ -98,6 +98,9 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
 #define GRIDGCN_OPT_PAIRMAX_SPLIT 5    /* [0] lanes per (centre, 4 channels) of gridgcn_pairmax_fwd: 0 = chosen from
                                         *     the layer's size, 1 / 2 / 4 / 8 forced (tuning; the first arg max is
                                         *     exact for every setting). */
+#define GRIDGCN_OPT_ATT_NZ_V2 6        /* [1] gridgcn_att_bwd_noz: the round-5 tile loop (no per-tile divisions,
+                                        *     range-checked buffer streams); 0 = the round-4 kernel.  Identical
+                                        *     results, word for word (tests/test_gpu_train_ops.py). */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 

@@ -333,7 +333,8 @@ def test_seg_model_gridify_up_variant_matches_cpu_oracle_model():
     for step in range(2):                      # second forward: the per-call seeds have moved on
         loss_cpu = model.seg_loss(net_cpu(x, n), lab)
         loss_gpu = model.seg_loss(net_gpu(x.to(DEV), n.to(DEV)), lab.to(DEV))
-        assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu))), step
+        # (measured 0 .. 7e-8 relative: fp32 round-off of a mean over 16 K rows)
+        assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-6 * max(1.0, abs(float(loss_cpu))), step
     net_cpu.zero_grad(); net_gpu.zero_grad()
     loss_cpu.backward()
     loss_gpu.backward()
@@ -342,7 +343,7 @@ def test_seg_model_gridify_up_variant_matches_cpu_oracle_model():
     rel = float((a - b).norm() / b.norm())
     parity_report("model seg 8192 GridifyUp variant HIP vs CPU oracle-index model: |dloss|/loss %.3e  rel-L2(grad) %.3e"
                   % (abs(float(loss_cpu) - float(loss_gpu)) / max(1.0, abs(float(loss_cpu))), rel))
-    assert rel < 1e-2
+    assert rel < 3.2e-3          # measured 1.03e-3 (profiles/r5_float_parity.txt); bar = 3x
 
 
 @pytest.mark.parametrize("cfgname,npts", [("SEG_8192", (2048, 1311)), ("SEG_81920", (3000, 4096))])
@@ -365,7 +366,7 @@ def test_seg_model_ragged_batch_matches_cpu_oracle_model(cfgname, npts):
     lab = torch.randint(0, 21, (2, N))
     loss_cpu = model.seg_loss(net_cpu(x, n), lab)
     loss_gpu = model.seg_loss(net_gpu(x.to(DEV), n.to(DEV)), lab.to(DEV))
-    assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-3 * max(1.0, abs(float(loss_cpu)))
+    assert abs(float(loss_cpu) - float(loss_gpu)) < 2e-6 * max(1.0, abs(float(loss_cpu)))   # measured 7e-8
     loss_cpu.backward()
     loss_gpu.backward()
     a = torch.cat([p.grad.reshape(-1) for p in net_gpu.parameters()]).cpu().double()
@@ -374,7 +375,9 @@ def test_seg_model_ragged_batch_matches_cpu_oracle_model(cfgname, npts):
     rel = float((a - b).norm() / b.norm())
     parity_report("model seg ragged %s HIP vs CPU oracle-index model: |dloss|/loss %.3e  1-cos(grad) %.3e  rel-L2(grad) %.3e"
                   % (cfgname, abs(float(loss_cpu) - float(loss_gpu)) / max(1.0, abs(float(loss_cpu))), 1.0 - cos, rel))
-    assert cos > 0.999, cos
+    # measured 1 - cos 3.5e-6 / 2.7e-6, rel-L2 2.7e-3 / 2.3e-3 (profiles/r5_float_parity.txt); bars = 3x
+    assert 1.0 - cos < 1.1e-5, cos
+    assert rel < 8e-3, rel
 
 
 
@@ -408,15 +411,16 @@ def test_full_size_training_step_matches_stock_pytorch_ops():
         res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()))
         del loss
         torch.cuda.empty_cache()
-    assert abs(res[0][0] - res[1][0]) <= 1e-4 * max(1.0, abs(res[1][0])), (res[0][0], res[1][0])
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * max(1.0, abs(res[1][0])), (res[0][0], res[1][0])   # measured 0
     a, b = res
     cos = float((a[1] * b[1]).sum() / (a[1].norm() * b[1].norm()))
     rel = float((a[1] - b[1]).norm() / b[1].norm())
     parity_report("model seg cfg4 full size (8 x 81920) HIP kernels vs stock fp32 ops: |dloss|/loss %.3e  "
                   "1-cos(grad) %.3e  rel-L2(grad) %.3e" % (abs(res[0][0] - res[1][0]) / max(1.0, abs(res[1][0])),
                                                            1.0 - cos, rel))
-    assert cos > 0.9999, cos
-    assert rel < 1e-2
+    # measured 1 - cos 9.5e-9, rel-L2 1.43e-4 (profiles/r5_float_parity.txt); bars = 3x
+    assert 1.0 - cos < 3e-8, cos
+    assert rel < 4.5e-4, rel
 
 
 @pytest.mark.parametrize("cin,C,O,P", [(128, 128, 700, 5), (64, 64, 90, 7), (32, 128, 41, 33), (256, 128, 300, 1)])

@@ -321,6 +321,55 @@ def test_gemm_small_matches_torch(R, Cf, C0, rot):
         assert torch.equal(t, train_ops._tn_matmul(Y, G))
 
 
+@pytest.mark.parametrize("ncent,P", [(655, 5), (64, 7), (2000, 5), (33, 1), (4096, 5), (70000, 5), (13, 3)])
+def test_att_bwd_noz_round5_tile_loop_is_word_identical(ncent, P):
+    """gg_k_att_bwd_nz2 (GRIDGCN_OPT_ATT_NZ_V2, the default: no per-tile divisions, range-checked buffer streams,
+    no predicates on the partial last tile) against the round-4 kernel on the same inputs: dX and dW bit for bit
+    (same arithmetic in the same order), the fp64 sums to their atomics' ordering."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    OPT = 6                                   # GRIDGCN_OPT_ATT_NZ_V2
+    cin, C = 32, 128
+    E = ncent * P
+    g = torch.Generator(device=DEV).manual_seed(ncent * 31 + P)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    Z1 = rnd(E, cin)
+    s1v, h1v, m1v, r1v = rnd(cin).abs() + 0.5, rnd(cin) * 0.1, rnd(cin) * 0.1, rnd(cin).abs() + 0.5
+    W2, b2 = rnd(C, cin) * 0.2, rnd(C) * 0.1
+    s2v, m2v, r2v = rnd(C).abs() + 0.5, rnd(C) * 0.1, rnd(C).abs() + 0.5
+    sums_a = rnd(2 * C).double()
+    amax = torch.randint(0, P, (ncent, C), device=DEV, dtype=torch.int32, generator=g).to(torch.uint8)
+    ga = rnd(ncent, C)
+    nbytes = ctypes.c_size_t(0)
+    assert lib.gridgcn_att_bwd_noz_workspace_bytes(E, cin, C, ctypes.byref(nbytes)) == 0
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
+    res = []
+    try:
+        for v2 in (1, 0):
+            assert lib.gridgcn_set_option(OPT, v2) == 0 and lib.gridgcn_get_option(OPT) == v2
+            dA1 = torch.full((E + 64, cin), 7.0, device=DEV)          # (guard rows: nothing may be written past E)
+            dW2 = torch.empty(C, cin, device=DEV)
+            v = torch.empty(4, C, device=DEV)
+            acc = torch.zeros(3 * cin, dtype=torch.float64, device=DEV)
+            rc = lib.gridgcn_att_bwd_noz(_ptr(Z1), _ptr(s1v), _ptr(h1v), _ptr(m1v), _ptr(r1v), _ptr(W2), _ptr(b2),
+                                         _ptr(s2v), _ptr(m2v), _ptr(r2v), _ptr(sums_a), _ptr(amax), _ptr(ga), int(P),
+                                         E, cin, C, _ptr(dA1), _ptr(dW2), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]),
+                                         _ptr(v[3]), _ptr(acc[:2 * cin]), _ptr(acc[2 * cin:]), _ptr(ws),
+                                         nbytes.value, _stream(Z1))
+            assert rc == 0
+            res.append((dA1, dW2, v, acc))
+    finally:
+        lib.gridgcn_set_option(OPT, 1)
+    (x1, w1, v1, a1), (x0, w0, v0, a0) = res
+    assert bool((x1[E:] == 7.0).all()) and bool((x0[E:] == 7.0).all())
+    assert torch.equal(x1[:E], x0[:E])
+    assert torch.equal(w1, w0) and torch.equal(v1, v0)
+    assert float((a1 - a0).abs().max()) <= 1e-12 * max(1.0, float(a0.abs().max()))
+    assert float(x0[:E].abs().max()) > 0 and bool(torch.isfinite(x1[:E]).all())
+
+
 def test_tn_matmul_tall_product_bounded_workspace():
     """the transposed product's workspace used to grow with the row count (tiles x ceil(R/256) x 4 KB:
     2.6 GB for a [512 x 320] product over 10^6 rows).  The library now caps tiles x slices at 4096 partial tiles

@@ -65,7 +65,7 @@ def test_cls_training_step_mfma_kernels_match_stock_modules():
         loss = model_cls.cls_loss(net(x, n), lab)
         loss.backward()
         res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
-    assert abs(res[0][0] - res[1][0]) < 1e-4 * max(1.0, abs(res[1][0]))
+    assert abs(res[0][0] - res[1][0]) < 2e-6 * max(1.0, abs(res[1][0]))    # measured 1.3e-7
     # this net is discretely sensitive at fp32 round-off (max-pool arg-max over 128 padded
     # neighbours, BatchNorm over 8 rows in the head): perturbing the INPUT of the stock path by 1e-7
     # already moves single weight gradients by ~1e-2 of their scale, so the
@@ -76,8 +76,9 @@ def test_cls_training_step_mfma_kernels_match_stock_modules():
     from conftest import parity_report
     parity_report("model cls (8 x 1024) HIP kernels vs stock fp32 modules: |dloss|/loss %.3e  1-cos(grad) %.3e  "
                   "rel-L2(grad) %.3e" % (abs(res[0][0] - res[1][0]) / max(1.0, abs(res[1][0])), 1.0 - cos, rel))
-    assert cos > 0.9995, cos
-    assert rel < 3e-2
+    # measured 1 - cos 1.2e-5, rel-L2 4.9e-3 (profiles/r5_float_parity.txt); bars = 3x
+    assert 1.0 - cos < 3.6e-5, cos
+    assert rel < 1.5e-2, rel
 
 
 @pytest.mark.gpu
