@@ -168,6 +168,11 @@ int gridgcn_set_option(int option, int value)
         gg_set_att_nz_v2(value);
         return GRIDGCN_OK;
     }
+    if (option == GRIDGCN_OPT_BWD_FUSED128) {
+        if (value != 0 && value != 1) return GRIDGCN_EINVAL;
+        gg_set_bwd_fused128(value);
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
@@ -180,6 +185,7 @@ int gridgcn_get_option(int option)
     if (option == GRIDGCN_OPT_COL_SPLIT) return gg_get_col_split();
     if (option == GRIDGCN_OPT_PAIRMAX_SPLIT) return gg_pairmax_split;
     if (option == GRIDGCN_OPT_ATT_NZ_V2) return gg_get_att_nz_v2();
+    if (option == GRIDGCN_OPT_BWD_FUSED128) return gg_get_bwd_fused128();
     return -1;
 }
 

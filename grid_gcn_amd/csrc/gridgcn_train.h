@@ -158,6 +158,10 @@ int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st);    // 1 = shape not 
 int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st);
 size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shape not supported
 int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st);       // gridgcn_attbwd.hip; 1 = other shape
+int gg_linear_bwd_fused128(const GGLinBwd &p, hipStream_t st); // gridgcn_bwdfused.hip; 1 = other shape
+size_t gg_linear_bwd_fused128_workspace(long long E);
+void gg_set_bwd_fused128(int v);     // GRIDGCN_OPT_BWD_FUSED128
+int gg_get_bwd_fused128();
 size_t gg_att_bwd_fused_workspace(long long E, int cin, int C);
 int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg);
 int gg_linear_bwd(const GGLinBwd &p, hipStream_t st);

@@ -924,6 +924,8 @@ int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg
         if (d > *bytes) *bytes = d;
         const size_t f = gg_att_bwd_fused_workspace(E, cin, C);
         if (f > *bytes) *bytes = f;
+        const size_t f2 = gg_linear_bwd_fused128_workspace(E);
+        if (C == 128 && (cin == 128 || cin == 256) && f2 > *bytes) *bytes = f2;
     }
     return 0;
 }
@@ -958,6 +960,11 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
         if (rc != 1) return rc;
     }
     if (p.zfmt) return 1;   // a bf16 Z is only read by the fused attention backward
+    // ---- 128-output per-point layer, dense gradient: dX, dW and the sums from ONE pass over Z and dY ----
+    {
+        const int rc = gg_linear_bwd_fused128(p, st);
+        if (rc != 1) return rc;
+    }
     // ---- register-direct dX (gridgcn_direct.hip) when the operand was packed for it ----
     if (p.dX && p.Wdx) {
         const int rc = gg_linear_dx_direct(p, st);

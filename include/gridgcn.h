@@ -101,6 +101,11 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
 #define GRIDGCN_OPT_ATT_NZ_V2 6        /* [1] gridgcn_att_bwd_noz: the round-5 tile loop (no per-tile divisions,
                                         *     range-checked buffer streams); 0 = the round-4 kernel.  Identical
                                         *     results, word for word (tests/test_gpu_train_ops.py). */
+#define GRIDGCN_OPT_BWD_FUSED128 7     /* [1] gridgcn_linear_bwd of a 128-output layer with 128 / 256 inputs, dense
+                                        *     gradient, E % 128 == 0, E >= 32768: dX, dW and the sums of the layer
+                                        *     in front from ONE pass over Z and dY (csrc/gridgcn_bwdfused.hip);
+                                        *     0 = the separate dX and dW kernels.  dX identical; dW and the sums
+                                        *     differ by summation order. */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 

@@ -370,6 +370,77 @@ def test_att_bwd_noz_round5_tile_loop_is_word_identical(ncent, P):
     assert float(x0[:E].abs().max()) > 0 and bool(torch.isfinite(x1[:E]).all())
 
 
+@pytest.mark.parametrize("E,cin,prev_bn,nbn", [(32768, 128, True, 0), (65536, 256, True, 128), (40960, 128, False, 0),
+                                               (131072, 256, True, 0)])
+def test_linear_bwd_fused128_matches_separate_kernels(E, cin, prev_bn, nbn):
+    """csrc/gridgcn_bwdfused.hip (GRIDGCN_OPT_BWD_FUSED128, round 5): dX, dW and the BatchNorm-backward sums of the
+    layer in front from ONE pass over Z and dY, against the register-direct dX + dW kernels on the same inputs.
+    Same terms, other summation orders: dX to 2e-6 of its largest entry (one association of the 128-channel sum
+    differs), dW 1e-5 (fp32 sums over E rows), the sums (fp64 atomics of fp32 partials) 1e-6.
+    Both against a float64 restatement as well."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    OPT = 7
+    C = 128
+    g = torch.Generator(device=DEV).manual_seed(E + cin + nbn)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    Z, X, dY = rnd(E, C), rnd(E, cin), rnd(E, C)
+    scale, shift = rnd(C).abs() + 0.5, rnd(C) * 0.1
+    mean, rstd = rnd(C) * 0.1, rnd(C).abs() + 0.5
+    sums = (rnd(2 * C) * 1e-3 * E).double()
+    Wt = rnd(C, cin) * 0.1
+    Wb, Wg = train_ops.pack_tiles(Wt), train_ops.pack_groups(Wt)
+    Wdx = torch.empty(C * 32 * (4 if cin == 128 else 8), device=DEV)
+    st = _stream(Z)
+    assert lib.gridgcn_pack_linear(_ptr(Wt), None, C, cin, 0, cin, cin, None, None, None, None, None, _ptr(Wdx), st) == 0
+    pv = [rnd(cin).abs() + 0.5, rnd(cin) * 0.1, rnd(cin) * 0.1, rnd(cin).abs() + 0.5]
+    if nbn:                      # RawLink: identity on the columns beyond nbn
+        pv[0][nbn:] = 1.0
+        pv[1][nbn:] = 0.0
+        X[:, nbn:].abs_()
+    pb = [_ptr(t) for t in pv] if prev_bn else [None] * 4
+    nbytes = ctypes.c_size_t(0)
+    lib.gridgcn_linear_bwd_workspace_bytes(E, cin, C, ctypes.byref(nbytes))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
+    res = []
+    try:
+        for fused in (1, 0):
+            assert lib.gridgcn_set_option(OPT, fused) == 0
+            dX = torch.empty(E, cin, device=DEV)
+            dW = torch.full((C, cin), 7.0, device=DEV)
+            v = torch.empty(4, C, device=DEV)
+            psums = torch.zeros(2 * (nbn or cin), dtype=torch.float64, device=DEV)
+            rc = lib.gridgcn_linear_bwd_fin(
+                _ptr(dY), _ptr(Z), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(sums), _ptr(v[0]), _ptr(v[1]),
+                _ptr(v[2]), _ptr(v[3]), _ptr(X), pb[0], pb[1], pb[2], pb[3], _ptr(Wb), _ptr(Wg), _ptr(Wdx), cin, E, C,
+                cin, cin, 0, C, 0, nbn, 0, _ptr(dX), _ptr(dW), _ptr(psums) if prev_bn else None, None, None, 0,
+                _ptr(ws), nbytes.value, st)
+            assert rc == 0
+            res.append((dX, dW, v, psums))
+    finally:
+        lib.gridgcn_set_option(OPT, 1)
+    (x1, w1, v1, p1), (x0, w0, v0, p0) = res
+    # (dX: the two channel halves of a row tile are contracted by two waves and added once -- one fp32 association
+    #  differs from the 128-step chain of the separate kernel)
+    assert float((x1 - x0).abs().max()) <= 2e-6 * float(x0.abs().max())
+    assert torch.equal(v1, v0)
+    assert float((w1 - w0).abs().max()) <= 1e-5 * float(w0.abs().max())
+    if prev_bn:
+        assert float((p1 - p0).abs().max()) <= 1e-6 * float(p0.abs().max())
+    # float64 restatement
+    m1, m2 = sums[:C] / E, sums[C:] / E
+    y = Z.double() * scale.double() + shift.double()
+    dz = scale.double() * torch.where(y > 0, dY.double(), torch.zeros_like(y)) + \
+        (Z.double() - mean.double()) * (-(scale.double() * rstd.double()) * m2) - scale.double() * m1
+    act = torch.relu(X.double() * pv[0].double() + pv[1].double()) if prev_bn else X.double()
+    refW = dz.t() @ act
+    assert float((w1 - refW).abs().max()) <= 2e-5 * float(refW.abs().max())
+    refX = dz @ Wt.double()
+    assert float((x1 - refX).abs().max()) <= 2e-5 * float(refX.abs().max())
+
+
 def test_tn_matmul_tall_product_bounded_workspace():
     """the transposed product's workspace used to grow with the row count (tiles x ceil(R/256) x 4 KB:
     2.6 GB for a [512 x 320] product over 10^6 rows).  The library now caps tiles x slices at 4096 partial tiles
