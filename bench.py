@@ -146,7 +146,7 @@ def make_opt(net, eager):
     """Adam(lr 1e-3, wd 1e-5): the one-launch kernel of grid_gcn_amd.optim (torch.optim.Adam's update to
     within rounding; tests/test_gpu_glue.py), or -- --switch OWN_ADAM=0 -- the framework's multi-tensor one"""
     from grid_gcn_amd import optim, train_ops
-    if train_ops.OWN_ADAM:
+    if train_ops.OPT.OWN_ADAM:
         return optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
     return torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=not eager)
 
@@ -282,17 +282,17 @@ def in_step_ms(net, loss_fn, inputs, target, keys, steps=4):
     kernels behind their real predecessors, real tensors, cold L2): train_ops.LaunchTimers.  The first step
     is dropped."""
     from grid_gcn_amd import train_ops
-    train_ops.TIMERS = train_ops.LaunchTimers(keys)
+    train_ops.OPT.TIMERS = train_ops.LaunchTimers(keys)
     try:
         for _ in range(steps):
             for prm in net.parameters():
                 prm.grad = None
             loss_fn(net(*inputs), target).backward()
         torch.cuda.synchronize()
-        per_step = {k: len(v) // steps for k, v in train_ops.TIMERS.ev.items()}
-        return {k: train_ops.TIMERS.median(k, skip=per_step[k]) for k in keys}, per_step
+        per_step = {k: len(v) // steps for k, v in train_ops.OPT.TIMERS.ev.items()}
+        return {k: train_ops.OPT.TIMERS.median(k, skip=per_step[k]) for k in keys}, per_step
     finally:
-        train_ops.TIMERS = None
+        train_ops.OPT.TIMERS = None
 
 
 def cagq_roofline(d4, n, kw, B, N, traffic, key, iters=100):
@@ -357,8 +357,7 @@ def main():
         if hasattr(_glib, "OPT_" + name):       # a kernel-selection option of the library (gridgcn_set_option)
             _glib.check(_glib.load().gridgcn_set_option(getattr(_glib, "OPT_" + name), int(val)), "set_option")
             continue
-        assert isinstance(getattr(_tops, name), bool), name
-        setattr(_tops, name, bool(int(val)))
+        _tops.OPT.set(name, val)               # (KeyError on an unknown name)
 
     if a.config != "cfg4":
         import bench_configs
@@ -507,7 +506,7 @@ def main():
         c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
         e_b = float(ncent_b * p_b)
-        noz = (train_ops.NOZ_ATT_BWD and a.dtype == "f32" and cin_b == 32 and c_b == 128)
+        noz = (train_ops.OPT.NOZ_ATT_BWD and a.dtype == "f32" and cin_b == 32 and c_b == 128)
         if noz:
             ms_b = train_ops.time_att_bwd_noz(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev)
             # read Z1 [E,cin], the sparse upstream gradient (one-byte amax + fp32 value) [ncent,C]; write dA1

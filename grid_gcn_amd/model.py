@@ -135,7 +135,7 @@ class GGCNSeg(nn.Module):
                 and data_xyz.dtype == torch.float32 and self.training and torch.is_grad_enabled())
         if glue:
             from . import train_ops
-            glue = train_ops.GLUE_KERNELS
+            glue = train_ops.OPT.GLUE_KERNELS
         if glue:
             data, data_pad = train_ops.cat_mask(data_xyz.detach(), None, None, pad=True)  # :137
         else:

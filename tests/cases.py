@@ -86,6 +86,18 @@ def gridify_cases(oracle_gridify):
         kw.update(max_o_grid=100, loc=0)
         return (data, npnts), kw
     cases.append(("gridify_ragged", ragged))
+
+    def bigvox():
+        # 168 x 168 x 160 = 4.5 M voxels: beyond the two-level split's 1024 slabs x 4096 voxels (2^22), i.e. the
+        # index build of csrc/gridgcn_index_legacy.hip (round-1 kernels kept as the large-grid fallback) -- a golden
+        # case of its own (hygiene): over-full buckets and both reservoirs included
+        data, npnts = synth.make_batch(2, 8192, "planes", first_id=90)
+        data[:, :3000, :3] *= np.float32(0.03)        # a dense clump: buckets beyond P, neighbourhoods beyond P
+        npnts = np.array([[8192], [6000]], np.int32)
+        kw = dict(max_p_grid=8, max_o_grid=700, kernel_size=3, stride=1, loc=1, coord_shift=[1, 1, 1],
+                  voxel_size=[2.0 / 168, 2.0 / 168, 2.0 / 160], grid_size=[168, 168, 160], seed=11)
+        return (data, npnts), kw
+    cases.append(("gridify_legacy_4m_voxels", bigvox))
     return cases
 
 

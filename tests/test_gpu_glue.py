@@ -220,11 +220,11 @@ def test_eval_constants_cache_follows_training():
         net.eval()
         with torch.no_grad():
             a = net(x, n).clone()
-            train_ops.EVAL_CACHE = False
+            train_ops.OPT.EVAL_CACHE = False
             try:
                 b = net(x, n).clone()
             finally:
-                train_ops.EVAL_CACHE = True
+                train_ops.OPT.EVAL_CACHE = True
         net.train()
         return a, b
 
@@ -305,12 +305,12 @@ def test_eval_cache_sees_torch_fused_adam():
 
     def evaluate(cache):
         net.eval()
-        train_ops.EVAL_CACHE = cache
+        train_ops.OPT.EVAL_CACHE = cache
         try:
             with torch.no_grad():
                 return net(x, n).clone()
         finally:
-            train_ops.EVAL_CACHE = True
+            train_ops.OPT.EVAL_CACHE = True
             net.train()
 
     net.train()

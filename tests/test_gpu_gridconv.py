@@ -204,7 +204,7 @@ def test_att_bwd_noz_equals_direct_form(O, P, B, monkeypatch):
     g = torch.randn((B, O, 128), generator=gen).to(DEV)
     res = []
     for bwd in (True, False):
-        monkeypatch.setattr(train_ops, "NOZ_ATT_BWD", bwd)
+        monkeypatch.setattr(train_ops.OPT, "NOZ_ATT_BWD", bwd)
         m = copy.deepcopy(net)
         s_ = src.clone().requires_grad_(True)
         y = m.forward_src(cent, s_, nebidx, None)
@@ -443,11 +443,11 @@ def test_att_max_eval_kernel_equals_two_kernel_path(cin, C, O, P):
     assert train_ops.edge_block_src_eval_supported([pt], att_layers, src, True)
     outs = []
     for flag in (True, False):
-        train_ops.ATT_MAX_EVAL = flag
+        train_ops.OPT.ATT_MAX_EVAL = flag
         try:
             outs.append(train_ops.edge_block_src_eval(src, nebidx, cent, pt, att_layers, 3))
         finally:
-            train_ops.ATT_MAX_EVAL = True
+            train_ops.OPT.ATT_MAX_EVAL = True
     with torch.no_grad():
         ref = layer(cent[..., 0:3], ops.batch_take_g(src, nebidx), None)
     scale = max(1.0, float(ref.abs().max()))

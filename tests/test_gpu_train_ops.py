@@ -724,7 +724,7 @@ def test_head_train_matches_torch(E, cin, dims, C2, p):
 
 
 def test_head_fused_dropout_equals_stored_dropout(monkeypatch):
-    """Dropout evaluated inside fc2's forward / dW kernels (train_ops.FUSE_DROPOUT) against the path that
+    """Dropout evaluated inside fc2's forward / dW kernels (train_ops.OPT.FUSE_DROPOUT) against the path that
     stores the dropped activation: the same mask bit for bit, so outputs and gradients agree to rounding."""
     torch.manual_seed(11)
     E, C, C2, p, seed = 40003, 128, 21, 0.5, 1234567890123
@@ -734,7 +734,7 @@ def test_head_fused_dropout_equals_stored_dropout(monkeypatch):
     g = torch.randn(E, C2, device=DEV)
     out = []
     for fuse in (True, False):
-        monkeypatch.setattr(train_ops, "FUSE_DROPOUT", fuse)
+        monkeypatch.setattr(train_ops.OPT, "FUSE_DROPOUT", fuse)
         n2, l2 = copy.deepcopy(net), copy.deepcopy(lin)
         xi = x.clone().requires_grad_(True)
         y = train_ops.head_train(xi, list(n2), p, l2, seed)
@@ -953,7 +953,7 @@ def test_bf16_mode_whole_model_loss_and_gradient_direction():
 
 def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     """bf16 mode with the [E, C] pre-activation of the second attention conv STORED as bf16
-    (train_ops.Z16_STORAGE: written by gridgcn_linear_fwd_direct_ld zfmt 1, read by
+    (train_ops.OPT.Z16_STORAGE: written by gridgcn_linear_fwd_direct_ld zfmt 1, read by
     gridgcn_pairmax_fwd_src_z and the fused attention backward) against the same mode with fp32
     storage.  Stated tolerance of the variant: aggregate within 1e-2 * max|y| (one bf16 rounding of a
     pre-activation whose BatchNorm+ReLU+product follow), every gradient within 5e-2 in relative L2
@@ -975,7 +975,7 @@ def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     try:
         train_ops.set_mlp_precision("bf16")
         for net, src, z16 in ((ref, src1, False), (new, src2, True)):
-            monkeypatch.setattr(train_ops, "Z16_STORAGE", z16)
+            monkeypatch.setattr(train_ops.OPT, "Z16_STORAGE", z16)
             y = net.forward_src(cent, src, nebidx, None)
             y.backward(g)
             outs.append((y.detach(), src.grad.clone(), [p.grad.clone() for p in net.parameters()]))
