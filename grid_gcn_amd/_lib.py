@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GG_HIP_LIB: profiling variant of the same library (lib/libgridgcn_hip_prof.so, tools/prof_phases.py)
 LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
-ABI_VERSION = 6                 # include/gridgcn.h: gridgcn_abi_version()
+ABI_VERSION = 7                 # include/gridgcn.h: gridgcn_abi_version()
 OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
 OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
 OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK

@@ -133,7 +133,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 6; }
+int gridgcn_abi_version(void) { return 7; }
 
 int gridgcn_set_option(int option, int value)
 {

@@ -74,7 +74,10 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  *    gridgcn_mask_sum, gridgcn_ball_knn[_grid]_ld, gridgcn_bn_finalize_tail,
                                  *    gridgcn_softmax_ce_loss, gridgcn_colsum_f32, gridgcn_edge_geo_forward, gridgcn_edge_lin0_backward_sparse_geo, gridgcn_linear_fwd_direct_fin,
                                  *    gridgcn_linear_fwd_direct_drop, gridgcn_linear_dw_drop, GRIDGCN_OPT_PAIRMAX_SPLIT; psums of a dX launch with
-                                 *    nbn > 0 is [2][nbn] */
+                                 *    nbn > 0 is [2][nbn]
+                                 * 7: GRIDGCN_OPT_ATT_NZ_V2, GRIDGCN_OPT_BWD_FUSED128 (gridgcn_linear_bwd may take the one-pass
+                                 *    kernel: dX / dW / sums in other summation orders); gridgcn_gemm_small_workspace_bytes is
+                                 *    bounded (~16 MB) whatever the row count */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */

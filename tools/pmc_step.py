@@ -60,8 +60,20 @@ def short(name):
     return name.split("(")[0].replace("void ", "")[:44]
 
 
+# kernels whose reads are PARTLY dwordx4 row streams: factor = 1 + (share of the fetched bytes that are wide)
+# gg_k_linear_bwd_fused128: Z and dY as 16-byte row reads (2/3 of its HBM reads), X as coalesced dword rows
+PARTLY = {"gg_k_linear_bwd_fused128": 1.5}
+
+
 def is_wide(name):
     return any(w in name for w in WIDE)
+
+
+def fetch_factor(name):
+    for k, f in PARTLY.items():
+        if k in name:
+            return f
+    return 2.0 if is_wide(name) else 1.0
 
 
 per = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum over the step
@@ -82,8 +94,8 @@ for d, want in ((a.fetch, ("FETCH_SIZE",)), (a.write, ("WRITE_SIZE",)),
         per[k][c] += v
         tot[c] += v
         if c == "FETCH_SIZE":
-            per[k]["FETCH_x2"] += v * (2.0 if is_wide(r["Kernel_Name"]) else 1.0)
-            tot["FETCH_x2"] += v * (2.0 if is_wide(r["Kernel_Name"]) else 1.0)
+            per[k]["FETCH_x2"] += v * fetch_factor(r["Kernel_Name"])
+            tot["FETCH_x2"] += v * fetch_factor(r["Kernel_Name"])
             if r["Dispatch_Id"] not in seen:
                 cnt[k] += 1
                 seen.add(r["Dispatch_Id"])

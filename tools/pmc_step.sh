@@ -3,8 +3,23 @@
 # the micro-benchmarked kernels -> profiles/traffic.json, <outdir>/pmc_step.txt
 # (separate --pmc passes, --kernel-trace only: MI355X_MICROARCH.md, rocprofv3 section)
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+# pmc_step.sh <outdir> [bf16]: with bf16 only the whole-step passes, key step_cfg4_bf16 (bench.py --dtype bf16)
 OUT=gpurun_out/${1:-pmc}
 mkdir -p $OUT
+if [ "$2" = "bf16" ]; then
+  R=$GRAFT_REPO_ROOT
+  cp profiles/traffic.json $OUT/traffic.json
+  cd /tmp && export TMPDIR=/tmp
+  ARGS="--steps 2 --warmup 1 --eager --no-cpu-baseline --no-micro --dtype bf16"
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/fetch16 -o p -- python $R/bench.py $ARGS > $R/$OUT/fetch16.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/write16 -o p -- python $R/bench.py $ARGS > $R/$OUT/write16.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/$OUT/busy16 -o p -- python $R/bench.py $ARGS > $R/$OUT/busy16.log 2>&1
+  cd $R
+  python tools/pmc_step.py --fetch $OUT/fetch16 --write $OUT/write16 --busy $OUT/busy16 --out $OUT/traffic.json --key step_cfg4_bf16 > $OUT/pmc_step_bf16.txt
+  head -12 $OUT/pmc_step_bf16.txt
+  cp $OUT/traffic.json profiles/traffic.json
+  exit 0
+fi
 R=$GRAFT_REPO_ROOT
 cp profiles/traffic.json $OUT/traffic.json
 cd /tmp && export TMPDIR=/tmp
