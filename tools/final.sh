@@ -36,3 +36,10 @@ for cfg in cfg4 cfg2 cfg5; do
   bash tools/bench_kstats.sh $1/kst $cfg $L > /dev/null 2>&1; cp $OUT/kst/${L}_bench_kernel_stats_$cfg.txt $OUT/
 done
 timeout 600 python tools/time_gridify.py > $OUT/${L}_gridify_times.txt 2> $OUT/gridify_times.err; tail -12 $OUT/${L}_gridify_times.txt
+# round 5: the bf16 step's own PMC pass (traffic.json: step_cfg4_bf16), the bf16 cfg4 line again with it, Gridify
+# instruction counters, A/B of the two round-5 kernels
+bash tools/pmc_step.sh $1/pmc bf16 > $OUT/pmc_step_bf16.log 2>&1; cp $OUT/pmc/pmc_step_bf16.txt $OUT/${L}_pmc_step_bf16.txt; cp $OUT/pmc/traffic.json $OUT/traffic.json
+timeout 900 python bench.py --config cfg4 --dtype bf16 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${L}_bench_cfg4_bf16.json 2> $OUT/bench_cfg4_bf16b.err
+bash tools/gridify_insts.sh $1/ginsts > /dev/null 2>&1; cp $OUT/ginsts/gridify_insts.txt $OUT/${L}_gridify_insts.txt
+{ timeout 300 python tools/time_nz.py; timeout 300 python tools/time_bwdfused.py; } > $OUT/${L}_ab_kernels.txt 2>&1; tail -12 $OUT/${L}_ab_kernels.txt
+timeout 300 python tools/graph_branch_probe.py > $OUT/${L}_graph_branch_probe.txt 2>&1; tail -2 $OUT/${L}_graph_branch_probe.txt
