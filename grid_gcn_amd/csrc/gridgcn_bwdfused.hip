@@ -4,14 +4,16 @@
 // The register-direct pair (gridgcn_direct.hip) reads Z and dY twice -- gg_k_linear_dx_direct forms dZ for
 // dX = dZ W, gg_k_linear_dw_direct forms it again for dW = dZ^T act(X) -- 0.67 GB of the 1.34 + 1.0 GB the two
 // move at fc1 of the 81 920-point net, and neither is bound by its MFMAs (51 % of the matrix pipe together).
-// Here a workgroup of 8 waves (two per SIMD, one workgroup per CU: 142 KB of LDS) owns 128-row blocks, and every
-// dZ and every act(X) value is formed exactly ONCE per block:
+// Here a workgroup of 8 waves (two per SIMD, one workgroup per CU: 142 KB of LDS) holds the dX operand W once and
+// runs two independent HALVES of four waves, each owning 64-row blocks, a transposed dZ tile and a barrier of its own
+// (an LDS counter: gfx950 has no named barriers), and every dZ and every act(X) value is formed exactly ONCE per block:
 //
+//   (w4 = wave & 3 inside a half; tw = w4 & 1 row tile of the block, hw = w4 >> 1, ct = w4)
 //   phase 1   wave (tw, hw): dZ of row tile tw for the channel half hw (lane = row, gg_dz4v as everywhere): A operand
 //             of a PARTIAL dX[32 rows, all four column tiles] over those 64 channels (32 steps x 4 MFMAs, W from LDS:
 //             one formed value feeds four MFMAs), and parked TRANSPOSED in the block's LDS tile T[tile][channel][row]
 //   barrier
-//   phase 2   wave (ct = tw, rg = hw) owns dW[all 128 channels, column tile ct] for the row tiles 2rg, 2rg + 1:
+//   phase 2   wave ct owns dW[all 128 channels, column tile ct] for the block's two row tiles:
 //             B = act(X) read straight from memory in the C/D row order (lane = column; a coalesced 128-byte row piece
 //             per half-wave and load) -- one formed value feeds the four channel slices' MFMAs -- A = dZ^T from T
 //             (lane = channel, 16 rows: four ds_read_b128)
@@ -49,13 +51,19 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
-    const int tw = wave & 3, hw = wave >> 2;
+    // Two independent HALVES of four waves (waves 0-3, 4-7) share the workgroup's LDS operand but own separate 64-row
+    // blocks, transposed tiles and barriers (gg_half_barrier: an LDS counter), so that one half's barrier / epilogue
+    // stalls overlap the other half's MFMAs -- with one 8-wave team both waves of every SIMD sat at the same barrier.
+    // Inside a half: w4 = wave & 3;  phase 1 / epilogue: row tile tw = w4 & 1, channel half hw = w4 >> 1;
+    // phase 2: column tile ct = w4, both row tiles of the block.
+    const int half = wave >> 2, w4 = wave & 3;
+    const int tw = w4 & 1, hw = w4 >> 1, ct = w4;
     // (the per-channel constants FIRST: a ds_read reaches 64 KB from its base register by immediate offset -- behind
     //  the 64-KB operand every constant array of every quad got an address register of its own, 33 of them spilled,
     //  and a scratch reload waits for ALL outstanding loads: vmcnt(0) in front of every MFMA group)
     float *cst = lds;                             // scale, shift, mean, bz, cz  [5][C]
     float *pcs = cst + 5 * C;                     // layer in front: scale, shift, mean, rstd  [4][128]
-    float *T = pcs + 4 * 128;                     // [4 row tiles][C][TS]; after phase 2: the dX exchange [8 waves][32][64]
+    float *T = pcs + 4 * 128;                     // [2 halves][2 row tiles][C][TS]; after phase 2: the dX exchange [4 waves][32][64]
     float *Wl = T + 4 * C * GG_BF_TS;             // [64 steps][64 lanes][4 column tiles]
     const int ldx = p.cin, col0 = p.dx_col0;
     const int ldz = p.ldz ? p.ldz : C;
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
             pcs[384 + c] = pb ? p.prstd[col] : 0.f;
         }
     }
+    if (tid < 2) ((int *)(Wl + 64 * 64 * 4))[tid] = 0;
     __syncthreads();
     const bool prevbn = p.pscale != nullptr;
     const float lo = prevbn ? 0.f : -__builtin_inff();
@@ -95,13 +104,26 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
         // lane part of an address in a 32-row x 128-column block of [.][ldx] floats, C/D order: row 4h, column of tile
         lcd[t] = (unsigned)(4 * h * ldx + (2 * hw + t) * 32 + l31) * 4u;
     }
-    const unsigned lcb = (unsigned)(4 * h * ldx + tw * 32 + l31) * 4u;
+    const unsigned lcb = (unsigned)(4 * h * ldx + ct * 32 + l31) * 4u;
     float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
     ggm_f32x16 accw[4];
     ggm_zero<4>(accw);
-    const long long nblk = p.E >> 7;
-    float *Tw = T + (size_t)tw * (C * GG_BF_TS);
-    float *Xw = T + (size_t)wave * 2048, *Xp = T + (size_t)(wave ^ 4) * 2048;   // dX exchange: mine, my partner's
+    const long long nblk = p.E >> 6;              // 64-row blocks: half h takes blocks 2 * blockIdx.x + h, + 2 * gridDim.x, ..
+    float *Th = T + (size_t)half * (2 * C * GG_BF_TS);
+    float *Tw = Th + (size_t)tw * (C * GG_BF_TS);
+    float *Xw = Th + (size_t)w4 * 2048, *Xp = Th + (size_t)(w4 ^ 2) * 2048;   // dX exchange: mine, my partner's
+    // barrier of the four waves of a half: arrivals counted in LDS (the writes in front of it drained first), then a
+    // poll with s_sleep; `bar_target` advances by 4 per barrier
+    int *bar = (int *)(Wl + 64 * 64 * 4) + half;
+    int bar_target = 0;
+    auto half_barrier = [&]() {
+        bar_target += 4;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < bar_target)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
     // Phase 1's (Z, dY) stream as a ring of four QUADS (4 channels of Z and of dY per lane each: 8 registers): quad
     // q + 4 is requested when quad q has been consumed, i.e. three quads = 48 MFMAs ahead of its use; the first four
     // of a block are requested during the block in front.  (Whole 32-channel chunks, two of them resident, did not
@@ -114,12 +136,15 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
         q_.z = gg_ld_f4(p.Z + (row0 + l31) * ldz + k);
         q_.g = gg_ld_f4(p.dY + (row0 + l31) * p.ldy + k);
     };
-    if ((long long)blockIdx.x < nblk) {
+    const long long blk0 = 2 * (long long)blockIdx.x + half, bstep = 2 * (long long)gridDim.x;
+    if (blk0 < nblk) {
 #pragma unroll
-        for (int qi = 0; qi < 4; qi++) ldq(Q[qi], ((long long)blockIdx.x << 7) + tw * 32, qi);
+        for (int qi = 0; qi < 4; qi++) ldq(Q[qi], (blk0 << 6) + tw * 32, qi);
     }
-    for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const long long b0 = blk << 7, r0 = b0 + tw * 32;
+    // (a start offset of half a block between the halves -- s_sleep in front of the second one's loop -- measured: no
+    //  change; the halves drift apart by themselves)
+    for (long long blk = blk0; blk < nblk; blk += bstep) {
+        const long long b0 = blk << 6, r0 = b0 + tw * 32;
         // 16 rows (C/D order) of one column tile of a 32-row tile of X
         auto ldx16 = [&](float (&x)[16], long long row0, unsigned lanepart) {
             const gg_rsrc rx = gg_make_rsrc(p.Aprev + (row0 * ldx + col0));
@@ -152,18 +177,18 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
             mmq(Q[qi & 3], qi);
             __builtin_amdgcn_sched_barrier(0);
             if (qi < 4) ldq(Q[qi & 3], r0, qi + 4);
-            else if (qi == 4) ldx16(xb[0], b0 + (2 * hw) * 32, lcb);       // (phase 2's tiles, into registers the
-            else if (qi == 6) ldx16(xb[1], b0 + (2 * hw + 1) * 32, lcb);   //  ring no longer needs)
+            else if (qi == 4) ldx16(xb[0], b0, lcb);                       // (phase 2's tiles, into registers the
+            else if (qi == 6) ldx16(xb[1], b0 + 32, lcb);                  //  ring no longer needs)
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        // ---- phase 2: dW[all 128 channels, column tile tw] += dZ^T act(X) over row tiles 2hw, 2hw + 1: one formed
+        half_barrier();
+        // ---- phase 2: dW[all 128 channels, column tile ct] += dZ^T act(X) over row tiles 2hw, 2hw + 1: one formed
         //      act(X) value feeds four MFMAs (the four channel slices) ----
         float xo[2][16];
-        const float bps = pcs[tw * 32 + l31], bpsh = pcs[128 + tw * 32 + l31];
+        const float bps = pcs[ct * 32 + l31], bpsh = pcs[128 + ct * 32 + l31];
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
-            const int j = 2 * hw + jj;
+            const int j = jj;
             float xa[16];
 #pragma unroll
             for (int s = 0; s < 16; s++) xa[s] = fmaxf(__builtin_fmaf(xb[jj][s], bps, bpsh), lo);
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
 #pragma unroll
             for (int cs = 0; cs < 4; cs++) {
                 gg_f32x4 t4[4];
-                const float *tp = T + ((size_t)j * C + 32 * cs + l31) * GG_BF_TS + 4 * h;
+                const float *tp = Th + ((size_t)j * C + 32 * cs + l31) * GG_BF_TS + 4 * h;
 #pragma unroll
                 for (int jg = 0; jg < 4; jg++) t4[jg] = gg_ld_f4(tp + 8 * jg);
 #pragma unroll
@@ -185,7 +210,7 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        half_barrier();
         // ---- dX exchange: the partner (same row tile, other channel half) gets my partial of ITS two column tiles ----
         // (two copies of the code under a wave-uniform branch: with `hw ? a : b` on the accumulator arrays the compiler
         //  selects register by register into copies, 64 more live registers)
@@ -203,12 +228,12 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
         {
             // the next block's two chunks (past the end: this block's again, a harmless re-read) -- requested here, where
             // the half of the dX accumulators that went to the partner is dead: in phase 2 they did not fit
-            const long long nb = blk + gridDim.x < nblk ? blk + gridDim.x : blk;
-            nrow0 = (nb << 7) + tw * 32;
+            const long long nb = blk + bstep < nblk ? blk + bstep : blk;
+            nrow0 = (nb << 6) + tw * 32;
 #pragma unroll
             for (int qi = 0; qi < 4; qi++) ldq(Q[qi], nrow0, qi);
         }
-        __syncthreads();
+        half_barrier();
         // ---- epilogue: dX of row tile tw, column tiles 2hw, 2hw+1 (channel halves added in the order 0, 1) + the
         //      BatchNorm-backward sums of the layer in front (xo = its raw output there) ----
         const gg_rsrc xs = gg_make_rsrc(p.dX + (r0 * ldx + col0));
@@ -247,9 +272,9 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
         };
         if (hw == 0) { finish(accx[0], 0, true); finish(accx[1], 1, true); }
         else { finish(accx[2], 0, false); finish(accx[3], 1, false); }
-        __syncthreads();               // (the exchange area is the next block's transposed tile)
+        half_barrier();                // (the exchange area is the next block's transposed tile)
     }
-    // dW partial of this workgroup: [wave][channel slice cs][reg][lane]; wave = column tile tw, row group hw
+    // dW partial of this workgroup: [wave][channel slice cs][reg][lane]; wave = 4 * half + column tile ct
     {
         float *out = part + ((size_t)blockIdx.x * 8 + wave) * 4096 + lane;
 #pragma unroll
@@ -276,7 +301,8 @@ __global__ __launch_bounds__(512) void gg_k_linear_bwd_fused128(GGLinBwd p, floa
         const int lim = p.nbn ? p.nbn : p.ndx;
         if (col0 + c < lim) {
             float v = 0.f;
-            for (int w = 0; w < 4; w++) v += red[((w + 4 * hq) * 2 + which) * 64 + t * 32 + l];
+            for (int w = 0; w < 4; w++)      // the four waves that finish column half hq: (half, row tile) = (w >> 1, w & 1)
+                v += red[(((w >> 1) * 4 + (w & 1) + 2 * hq) * 2 + which) * 64 + t * 32 + l];
             atomicAdd(&p.psums[which * (p.nbn ? p.nbn : p.cin) + col0 + c], (double)v);
         }
     }
@@ -325,8 +351,8 @@ __global__ __launch_bounds__(1024) void gg_k_bwd_fused128_reduce(const float *__
 
 static int gg_bwd_fused128_grid(long long E)
 {
-    const long long nblk = E >> 7;
-    return (int)(nblk < 256 ? nblk : 256);       // one 8-wave workgroup per CU (LDS: 140 KB)
+    const long long nblk = (E >> 6) / 2;         // (two 64-row blocks per workgroup and round: one per half)
+    return (int)(nblk < 256 ? (nblk < 1 ? 1 : nblk) : 256);       // one 8-wave workgroup per CU (LDS: 140 KB)
 }
 
 bool gg_linear_bwd_fused128_ok(const GGLinBwd &p)
@@ -347,7 +373,7 @@ int gg_linear_bwd_fused128(const GGLinBwd &pin, hipStream_t st)
 {
     if (!gg_linear_bwd_fused128_ok(pin)) return 1;
     static bool attr_done = false;
-    const size_t lds = (size_t)(64 * 64 * 4 + 5 * GG_BF_C + 4 * 128 + 4 * GG_BF_C * GG_BF_TS) * sizeof(float);
+    const size_t lds = (size_t)(64 * 64 * 4 + 5 * GG_BF_C + 4 * 128 + 4 * GG_BF_C * GG_BF_TS + 4) * sizeof(float);
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_linear_bwd_fused128, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return 3;
