@@ -251,3 +251,43 @@ def test_dp_step_wiring_gloo_world2():
     stable = np.abs(g_first) > 1e-3 * gmax
     np.testing.assert_allclose(res[0][1][stable], want[stable], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(res[0][1], want, rtol=0, atol=2.1e-3 * nsteps)
+
+
+def _agree_worker(rank, world, port, q, values):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out = []
+    for what, vals in values:
+        try:
+            bench.ranks_agree(what, vals[rank], world, torch.device("cpu"))
+            out.append("ok")
+        except RuntimeError as e:
+            out.append("raised:" + str(e)[:40])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_refuses_a_job_whose_ranks_disagree_on_the_step_mode():
+    """bench.ranks_agree (round 5): with N > 1 every rank must time the same kind of step; a rank
+    that fell back to the eager step (or whose RCCL capture probe said something else) makes ALL ranks raise instead
+    of producing a line that would read as a scaling loss.  Two gloo ranks: equal values pass, unequal ones raise on
+    both ranks, None == None passes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 1000
+    values = [("step_mode", ("hipgraph", "hipgraph")), ("step_mode", ("hipgraph", "eager")),
+              ("rccl_capture_probe", (None, None)), ("rccl_capture_probe", ("ok", "failed"))]
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q, values)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r][0] == "ok" and res[r][2] == "ok", res
+        assert res[r][1].startswith("raised:") and res[r][3].startswith("raised:"), res
