@@ -576,17 +576,21 @@ def main():
         ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=mi, device=dev)
         ms_f_step = instep[kf_] or ms_f
         tf_f = 2.0 * e_f * cin_f * c_f / (ms_f_step * 1e-3) / 1e12
+        # (bf16 mode: this layer sits behind a BatchNorm + ReLU and runs on v_mfma_f32_32x32x16_bf16 -- priced against
+        #  THAT pipe's dense peak; against the fp32 peak the line read 1.16)
+        peak_f = MFMA_F32_PEAK_TF if a.dtype == "f32" else 2500.0
         out["roofline_mfma"] = {"bound": "mfma", "kernel": "gg_k_linear_fwd_direct (%d->%d conv + "
                                 "BN/ReLU prologue + statistics over %d rows)" % (cin_f, c_f, e_f),
-                                "achieved": tf_f, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": tf_f / MFMA_F32_PEAK_TF,
+                                "achieved": tf_f, "peak": peak_f, "unit": "TFLOP/s",
+                                "frac": tf_f / peak_f,
                                 "traffic": traffic.get("linear_fwd_E%d_%dto%d" % (e_f, cin_f, c_f)),
                                 "traffic_key": "linear_fwd_E%d_%dto%d" % (e_f, cin_f, c_f),
                                 "algorithmic_flops_per_launch": 2.0 * e_f * cin_f * c_f,
                                 "ms_per_launch": ms_f, "ms_in_step": instep[kf_],
                                 "launches_per_step": per_step[kf_],
-                                "frac_micro": 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                                "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+                                "frac_micro": 2.0 * e_f * cin_f * c_f / (ms_f * 1e-3) / 1e12 / peak_f,
+                                "dtype": "f32 (v_mfma_f32_32x32x2_f32)" if a.dtype == "f32"
+                                else "bf16 operands, fp32 storage (v_mfma_f32_32x32x16_bf16; HBM bound: 1.0 GB per launch)"}
         # ---- the materialising neighbour gather as an operator (SURVEY §8(d) algorithmic bytes):
         #      batch_take_g forward + its sorted backward at the shape of layer up2 ----
         with torch.no_grad():
