@@ -37,7 +37,7 @@
 #define GG_BF_C 128
 
 static int g_bwd_fused128 = 1;          // GRIDGCN_OPT_BWD_FUSED128
-void gg_set_bwd_fused128(int v) { g_bwd_fused128 = v ? 1 : 0; }
+void gg_set_bwd_fused128(int v) { g_bwd_fused128 = v < 0 ? 0 : (v > 2 ? 2 : v); }   // 0 off, 1 all shapes, 2 cin = 128 only
 int gg_get_bwd_fused128() { return g_bwd_fused128; }
 
 __device__ __forceinline__ float gg_bf_f4(const gg_f32x4 &v, int i)
@@ -357,7 +357,8 @@ static int gg_bwd_fused128_grid(long long E)
 
 bool gg_linear_bwd_fused128_ok(const GGLinBwd &p)
 {
-    return g_bwd_fused128 && p.dX && p.Wdx && !p.amax && p.dY && p.C == GG_BF_C && (p.cin == 128 || p.cin == 256) &&
+    return g_bwd_fused128 && p.dX && p.Wdx && !p.amax && p.dY && p.C == GG_BF_C &&
+           (p.cin == 128 || (p.cin == 256 && g_bwd_fused128 == 1)) &&
            p.ndx == p.cin && p.cin_w == p.cin && p.rot == 0 && (p.E & 127) == 0 && p.E >= 32768 && !p.zfmt &&
            !p.drop_thr && !gg_get_mlp_bf16() && p.dx_col0 == 0 && p.dx_wstride == 1 && (p.nbn == 0 || p.nbn == 128) &&
            p.dWpart && p.dW && (!p.pscale || p.psums);

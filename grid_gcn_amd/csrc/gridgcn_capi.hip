@@ -169,7 +169,7 @@ int gridgcn_set_option(int option, int value)
         return GRIDGCN_OK;
     }
     if (option == GRIDGCN_OPT_BWD_FUSED128) {
-        if (value != 0 && value != 1) return GRIDGCN_EINVAL;
+        if (value < 0 || value > 2) return GRIDGCN_EINVAL;
         gg_set_bwd_fused128(value);
         return GRIDGCN_OK;
     }

@@ -107,8 +107,9 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
 #define GRIDGCN_OPT_BWD_FUSED128 7     /* [1] gridgcn_linear_bwd of a 128-output layer with 128 / 256 inputs, dense
                                         *     gradient, E % 128 == 0, E >= 32768: dX, dW and the sums of the layer
                                         *     in front from ONE pass over Z and dY (csrc/gridgcn_bwdfused.hip);
-                                        *     0 = the separate dX and dW kernels.  dX identical; dW and the sums
-                                        *     differ by summation order. */
+                                        *     0 = the separate dX and dW kernels; 2 = only layers of 128 inputs (the
+                                        *     256-input update conv takes two launches of it: worth 0.03 ms of a cfg4
+                                        *     step, the 128-input fc1 0.1 ms).  Same terms, other summation orders. */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 
