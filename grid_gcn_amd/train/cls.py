@@ -1,12 +1,10 @@
 """The classification GridConv edge block (classification/models/gcn_module_g.py:64-223) in training mode."""
 import ctypes
-import weakref
 
 import torch
 
 from .. import _lib
 from ..ops import _ptr, _stream
-from .options import OPT
 from .common import (  # noqa: F401
     _chain_backward, _chain_forward, _dw_direct_ok, _gemm_small, _mm_nn, _mm_nt, _momentum, _small_ok,
     _stats_written, _tn_matmul, _zeros, packed_sizes, supported,)

@@ -1,7 +1,6 @@
 """The GridConv edge block of the segmentation nets in training mode (gcn_module_g_att.py:120-287):
 source-side first conv, attention chain, product + max, and the fused backward."""
 import ctypes
-import weakref
 
 import torch
 

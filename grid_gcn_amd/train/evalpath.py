@@ -1,6 +1,5 @@
 """Evaluation-mode paths through the training kernels (running statistics applied on the fly) and their
 caches of folded constants / packed weights."""
-import ctypes
 import weakref
 
 import torch

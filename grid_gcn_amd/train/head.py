@@ -1,7 +1,6 @@
 """Segmentation / classification heads in training mode: class scores, fc1 + Dropout + fc2 as one op,
 SoftmaxOutput(use_ignore, normalization='valid') (segmentation/models/ggcn_models_g.py:30-43)."""
 import ctypes
-import weakref
 
 import torch
 

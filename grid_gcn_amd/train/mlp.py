@@ -1,7 +1,6 @@
 """Per-point conv + BatchNorm + ReLU stacks in training mode (centre / update MLPs, fc1; wide layers in
 256-column slices): autograd Functions over train/common.py's chain kernels."""
 import ctypes
-import weakref
 
 import torch
 

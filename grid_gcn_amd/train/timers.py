@@ -1,6 +1,5 @@
 """Micro-benchmarks of single library calls on synthetic tensors (bench.py's roofline lines)."""
 import ctypes
-import weakref
 
 import torch
 
