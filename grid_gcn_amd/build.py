@@ -19,7 +19,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libgridgcn_hip.so")
 SOURCES = ["gridgcn_index.hip", "gridgcn_index_legacy.hip", "gridgcn_query.hip",
            "gridgcn_query_knn.hip", "gridgcn_knn.hip", "gridgcn_conv.hip", "gridgcn_train.hip",
-           "gridgcn_direct.hip", "gridgcn_bwdfused.hip", "gridgcn_attbwd.hip", "gridgcn_attbwd_nz.hip", "gridgcn_atteval.hip",
+           "gridgcn_direct.hip", "gridgcn_bwdfused.hip", "gridgcn_attbwd.hip", "gridgcn_attbwd_nz.hip", "gridgcn_attfwd.hip", "gridgcn_atteval.hip",
            "gridgcn_pairmax.hip", "gridgcn_head.hip", "gridgcn_scatter.hip",
            "gridgcn_edgelin.hip", "gridgcn_ballgrid.hip", "gridgcn_clsblock.hip", "gridgcn_cas.hip", "gridgcn_fastrand.hip",
            "gridgcn_gemm.hip", "gridgcn_optim.hip",

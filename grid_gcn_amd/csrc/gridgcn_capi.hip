@@ -133,7 +133,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 7; }
+int gridgcn_abi_version(void) { return 8; }
 
 int gridgcn_set_option(int option, int value)
 {
@@ -699,6 +699,42 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
     const int rc = gg_att_bwd_noz(Z1, pscale, pshift, pmean, prstd, W2, b2, scale, mean, rstd, sums, amax, gval,
                                   P, E, dX, dW, m1, m2, dgamma, dbeta, psums, s1, workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes)
+{
+    if (!bytes || E < 1 || cin != 32 || C != 128) return GRIDGCN_EINVAL;
+    *bytes = gg_att_moments_workspace(E);
+    return GRIDGCN_OK;
+}
+
+int gridgcn_att_bn2_moments(const float *Z1, const float *scale1, const float *shift1, const float *W2,
+                            const float *b2, const float *gamma, const float *beta, long long E, int cin, int C,
+                            float eps, float momentum, float *scale, float *shift, float *mean, float *rstd,
+                            float *running_mean, float *running_var, int64_t *num_batches_tracked, double *sums,
+                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!Z1 || !scale1 || !shift1 || !W2 || !b2 || !gamma || !beta || !scale || !shift || !mean || !rstd ||
+        E < 1 || cin != 32 || C != 128 || (!running_mean) != (!running_var))
+        return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_att_moments_workspace(E)) return GRIDGCN_EWORKSPACE;
+    return gg_att_bn2_moments(Z1, scale1, shift1, W2, b2, gamma, beta, E, eps, momentum, scale, shift, mean, rstd,
+                              running_mean, running_var, (long long *)num_batches_tracked, sums, workspace,
+                              (hipStream_t)stream);
+}
+
+int gridgcn_att_pairmax_fwd(const float *Ysrc, const int32_t *nebidx, const float *att16, const float *Wg,
+                            const float *b, int B, int Nsrc, int O, const float *Z1, const float *scale1,
+                            const float *shift1, const float *W2, const float *b2, const float *scale_p,
+                            const float *shift_p, const float *scale_a, const float *shift_a, long long ncent,
+                            int P, int cin, int C, float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream)
+{
+    if (!Ysrc || !nebidx || !att16 || !b || !Z1 || !scale1 || !shift1 || !W2 || !b2 || !scale_p || !shift_p ||
+        !scale_a || !shift_a || !agg || !amax || !zsel || B < 1 || Nsrc < 1 || O < 1 || ncent != (long long)B * O)
+        return GRIDGCN_EINVAL;
+    if (!gg_att_fwd_ok(ncent, P, cin, C, ld_agg, (long long)B * Nsrc)) return GRIDGCN_EINVAL;
+    return gg_att_pairmax_args(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Z1, scale1, shift1, W2, b2, scale_p, shift_p,
+                               scale_a, shift_a, ncent, agg, ld_agg, amax, zsel, (hipStream_t)stream);
 }
 
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,

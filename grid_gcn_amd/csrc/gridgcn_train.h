@@ -157,6 +157,17 @@ int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st);   // gridgcn_direct
 int gg_linear_dx_direct(const GGLinBwd &p, hipStream_t st);    // 1 = shape not supported
 int gg_linear_dw_direct(const GGLinBwd &p, hipStream_t st);
 size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shape not supported
+// gridgcn_attfwd.hip: the forward of the attention pair product / max without the second conv's pre-activation
+bool gg_att_fwd_ok(long long ncent, int P, int cin, int C, int lda, long long rows);
+size_t gg_att_moments_workspace(long long E);
+int gg_att_bn2_moments(const float *Z1, const float *s1, const float *h1, const float *W2, const float *b2,
+                       const float *gamma, const float *beta, long long E, float eps, float momentum, float *scale,
+                       float *shift, float *mean, float *rstd, float *run_mean, float *run_var, long long *nbt,
+                       double *sums, void *ws, hipStream_t st);
+int gg_att_pairmax_args(const float *Ysrc, const int *nebidx, const float *att16, const float *Wg, const float *b,
+                        int B, int Nsrc, int O, const float *Z1, const float *s1, const float *h1, const float *W2,
+                        const float *b2, const float *scp, const float *shp, const float *sca, const float *sha,
+                        long long ncent, float *agg, int lda, unsigned char *amax, float *zsel, hipStream_t st);
 int gg_att_bwd_fused(const GGLinBwd &p, hipStream_t st);       // gridgcn_attbwd.hip; 1 = other shape
 int gg_linear_bwd_fused128(const GGLinBwd &p, hipStream_t st); // gridgcn_bwdfused.hip; 1 = other shape
 size_t gg_linear_bwd_fused128_workspace(long long E);

@@ -107,6 +107,36 @@ def _att_bwd_noz(lib, att16, Z1, aS, aH, aM, aR, aWb, aWg, aWx, ndxs, W2, b2, su
     return list(g0) + [dW2, db2, v[2], v[3]]
 
 
+def _att_fwd_noz(lib, att16, pa, bns_a, eps, st):
+    """forward of the attention chain (10 -> 32 -> 128) of an up layer without the second conv's [E, 128] output:
+    the first conv as ever, the second BatchNorm's vectors from the moments of the 32-wide activation
+    (gridgcn_att_bn2_moments; csrc/gridgcn_attfwd.hip).  Returns the chain record with an EMPTY second Z."""
+    sa = _chain_forward(lib, att16, pa[:4], bns_a[:1], eps)
+    E, dev = att16.shape[0], att16.device
+    W2, b2, g2, be2 = pa[4:8]
+    C, cin = W2.shape
+    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.gridgcn_att_fwd_noz_workspace_bytes(E, cin, C, ctypes.byref(nbytes)), "att_fwd_noz_workspace")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    bn = bns_a[1]
+    track = bn is not None and bn.track_running_stats
+    rc = lib.gridgcn_att_bn2_moments(
+        _ptr(sa.Z[0]), _ptr(sa.scale[0]), _ptr(sa.shift[0]), _ptr(W2.detach()), _ptr(b2.detach()),
+        _ptr(g2.detach()), _ptr(be2.detach()), E, cin, C, eps, _momentum(bn) if track else 0.0,
+        _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]), _ptr(vec[3]),
+        _ptr(bn.running_mean) if track else None, _ptr(bn.running_var) if track else None,
+        _ptr(bn.num_batches_tracked) if track else None, None, _ptr(ws), nbytes.value, st)
+    _lib.check(rc, "gridgcn_att_bn2_moments")
+    if track:
+        _stats_written(bn)
+    none = torch.empty(0, dtype=torch.float32, device=dev)
+    sa.Z.append(none); sa.scale.append(vec[0]); sa.shift.append(vec[1])
+    sa.mean.append(vec[2]); sa.rstd.append(vec[3])
+    sa.Wb.append(none); sa.Wg.append(none); sa.Wdx.append(none); sa.ndx.append(0)
+    return sa
+
+
 class _EdgeBlockSrcTrain(torch.autograd.Function):
     """The whole GridConv edge block from (src, nebidx, cent): the first conv of the point MLP is
     applied to the SOURCE points (Ysrc = features * Wf^T, [B*Nsrc, C0]) and gathered, instead of
@@ -201,8 +231,21 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             # the tensor is then not saved ...
             nz = (OPT.NOZ_ATT_BWD and noz and La == 2 and not z16 and lib.gridgcn_get_mlp_precision() == 0
                   and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16)
-            sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)
-            if noz:
+            # ... and neither does the forward (gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd): the [E, 128]
+            # tensor is then never written at all
+            nzf = nz and OPT.NOZ_ATT_FWD and P == 5 and ncent >= 7 and R < (1 << 23) and lda >= C
+            if nzf:
+                sa = _att_fwd_noz(lib, att16, pa, bns_a, eps, st)
+                rc = lib.gridgcn_att_pairmax_fwd(
+                    _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]), B, Nsrc, O,
+                    _ptr(sa.Z[0]), _ptr(sa.scale[0]), _ptr(sa.shift[0]), _ptr(pa[4].detach()), _ptr(pa[5].detach()),
+                    _ptr(scl), _ptr(shl), _ptr(sa.scale[1]), _ptr(sa.shift[1]), ncent, P, A0, C, _ptr(agg), lda,
+                    _ptr(amax), _ptr(zsel), st)
+            else:
+                sa = _chain_forward(lib, att16, pa, bns_a, eps, z16_last=z16)
+            if nzf:
+                pass
+            elif noz:
                 rc = lib.gridgcn_pairmax_fwd_src_z(
                     _ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg) if geo else None, _ptr(wgb[3]),
                     B, Nsrc, O, _ptr(sa.Z[-1]), 1 if z16 else 0, _ptr(scl), _ptr(shl),

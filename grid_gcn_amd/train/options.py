@@ -33,6 +33,9 @@ class PathOptions:
     # fp32 mode, up layers: backward of the second attention conv without its [E, 128] pre-activation
     # (csrc/gridgcn_attbwd_nz.hip): the tensor is not kept for the backward at all
     NOZ_ATT_BWD: bool = True
+    # ... and the forward: its BatchNorm from the moments of the 32-wide activation, the conv recomputed inside the
+    # pair product / max kernel (csrc/gridgcn_attfwd.hip): the tensor is never written (needs NOZ_ATT_BWD)
+    NOZ_ATT_FWD: bool = True
     # the source-point products on csrc/gridgcn_gemm.hip instead of the framework's GEMM
     SMALL_GEMM: bool = True
     # small zero-filled accumulators carved from 4 MB zero chunks (one fill per chunk instead of ~70 per step)

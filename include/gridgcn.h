@@ -77,7 +77,8 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  *    nbn > 0 is [2][nbn]
                                  * 7: GRIDGCN_OPT_ATT_NZ_V2, GRIDGCN_OPT_BWD_FUSED128 (gridgcn_linear_bwd may take the one-pass
                                  *    kernel: dX / dW / sums in other summation orders); gridgcn_gemm_small_workspace_bytes is
-                                 *    bounded (~16 MB) whatever the row count */
+                                 *    bounded (~16 MB) whatever the row count
+                                 * 8: gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd (+ _workspace_bytes) */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -665,6 +666,30 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
                         const float *gval, int P, long long E, int cin, int C, float *dX, float *dW, float *m1,
                         float *m2, float *dgamma, float *dbeta, double *psums, double *s1, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* ---- FORWARD of the same pair of layers without that pre-activation (csrc/gridgcn_attfwd.hip) -------------------
+ * Training needed Z2 = W2 a1 + b2 [E, 128] for two things: its BatchNorm batch statistics and the pair product /
+ * neighbour max (gcn_module_g_att.py:152-167, :57-59).  Both are obtained from Z1 [E, 32]:
+ * gridgcn_att_bn2_moments: S1 = sum_e a1, S2 = sum_e a1 a1^T (a1 = relu(Z1 * scale1 + shift1); fp32 MFMA products,
+ *   fp64 accumulation from 256 rows up, fixed summation order), then for every output channel
+ *     sum z2 = W2[c,:].S1 + E b2[c],   sum z2^2 = W2[c,:] S2 W2[c,:]^T + 2 b2[c] W2[c,:].S1 + E b2[c]^2   (fp64)
+ *   and from those exactly what gridgcn_bn_finalize writes (scale, shift, mean, rstd [128]; the running estimates
+ *   and num_batches_tracked when given; sums [2][128] fp64 when not NULL).  cin = 32, C = 128.
+ * gridgcn_att_pairmax_fwd: what gridgcn_pairmax_fwd_src writes (agg, amax, zsel -- zsel REQUIRED: the backward has
+ *   nothing else to take the arg-max pre-activations from), the second conv recomputed per 30-edge tile on the MFMA
+ *   unit.  P = 5, cin = 32, C = 128, ncent >= 7, B*Nsrc < 2^23; GRIDGCN_EINVAL otherwise (callers keep the Z2 path).
+ *   The attention value of an edge is W2 a1 + b2 in the MFMA unit's summation order with the bias FIRST: the same
+ *   terms as gridgcn_linear_fwd_direct, last-bit differences possible; the point branch is bit-identical. */
+int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes);
+int gridgcn_att_bn2_moments(const float *Z1, const float *scale1, const float *shift1, const float *W2,
+                            const float *b2, const float *gamma, const float *beta, long long E, int cin, int C,
+                            float eps, float momentum, float *scale, float *shift, float *mean, float *rstd,
+                            float *running_mean, float *running_var, int64_t *num_batches_tracked, double *sums,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int gridgcn_att_pairmax_fwd(const float *Ysrc, const int32_t *nebidx, const float *att16, const float *Wg,
+                            const float *b, int B, int Nsrc, int O, const float *Z1, const float *scale1,
+                            const float *shift1, const float *W2, const float *b2, const float *scale_p,
+                            const float *shift_p, const float *scale_a, const float *shift_a, long long ncent,
+                            int P, int cin, int C, float *agg, int ld_agg, uint8_t *amax, float *zsel, void *stream);
 int gridgcn_bn_relu_apply(const float *Z, const float *scale, const float *shift, float *Y,
                           long long E, int C, int ldy, void *stream);
 /* Head of the segmentation net: fc1 (conv+BN+ReLU) -> Dropout(p) -> fc2

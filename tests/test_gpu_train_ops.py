@@ -370,6 +370,152 @@ def test_att_bwd_noz_round5_tile_loop_is_word_identical(ncent, P):
     assert float(x0[:E].abs().max()) > 0 and bool(torch.isfinite(x1[:E]).all())
 
 
+def _att_fwd_inputs(B, Nsrc, O, seed, geo=True):
+    P, cin, C = 5, 32, 128
+    ncent, E, R = B * O, B * O * 5, B * Nsrc
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    d = dict(P=P, cin=cin, C=C, ncent=ncent, E=E, R=R)
+    d["Ysrc"] = rnd(R, C)
+    # (indices one past either end: take mode 'clip')
+    d["nebidx"] = torch.randint(-1, Nsrc + 1, (B, O, P), device=DEV, dtype=torch.int32, generator=g)
+    d["att16"] = rnd(E, 16)
+    d["Wg"] = rnd(3, C) * 0.3 if geo else None
+    d["b"] = rnd(C) * 0.1
+    d["Z1"] = rnd(E, cin)
+    d["s1"], d["h1"] = rnd(cin).abs() + 0.5, rnd(cin) * 0.3
+    d["W2"], d["b2"] = rnd(C, cin) * 0.2, rnd(C) * 0.1
+    d["scp"], d["shp"] = rnd(C).abs() + 0.5, rnd(C) * 0.3
+    d["gamma"], d["beta"] = rnd(C).abs() + 0.5, rnd(C) * 0.3
+    return d
+
+
+@pytest.mark.parametrize("E", [32, 33, 511, 512, 8191, 70001, 1300000])
+def test_att_bn2_moments_match_the_statistics_of_the_materialised_conv(E):
+    """gridgcn_att_bn2_moments (csrc/gridgcn_attfwd.hip): the BatchNorm of z2 = W2 a1 + b2 from S1 = sum a1 and
+    S2 = sum a1 a1^T, against float64 statistics of the materialised z2.  Bars: mean 2e-6 of the largest |mean| (or
+    of the spread), rstd 5e-6 relative -- the S2 products are fp32 MFMA terms, folded into fp64 every 256 rows;
+    measured 3e-7 / 8e-7 at E = 1.3 M.  Running estimates and the step counter as gridgcn_bn_finalize writes them;
+    bit-reproducible (fixed summation order)."""
+    import ctypes
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    cin, C, eps, mom = 32, 128, 1e-5, 0.1
+    g = torch.Generator(device=DEV).manual_seed(E)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    Z1 = rnd(E, cin)
+    s1, h1 = rnd(cin).abs() + 0.5, rnd(cin) * 0.3
+    W2, b2 = rnd(C, cin) * 0.2, rnd(C) * 0.5
+    gamma, beta = rnd(C).abs() + 0.5, rnd(C) * 0.3
+    nbytes = ctypes.c_size_t(0)
+    assert lib.gridgcn_att_fwd_noz_workspace_bytes(E, cin, C, ctypes.byref(nbytes)) == 0
+    assert lib.gridgcn_att_fwd_noz_workspace_bytes(E, 16, C, ctypes.byref(nbytes)) != 0
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
+    outs = []
+    for rep in range(2):
+        vec = torch.empty(4, C, device=DEV)
+        rm, rv = torch.full((C,), 0.25, device=DEV), torch.full((C,), 2.0, device=DEV)
+        nbt = torch.full((1,), 41, dtype=torch.int64, device=DEV)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+        rc = lib.gridgcn_att_bn2_moments(_ptr(Z1), _ptr(s1), _ptr(h1), _ptr(W2), _ptr(b2), _ptr(gamma), _ptr(beta), E,
+                                         cin, C, eps, mom, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]), _ptr(vec[3]),
+                                         _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(sums), _ptr(ws), nbytes.value, _stream(Z1))
+        assert rc == 0
+        outs.append((vec, rm, rv, nbt, sums))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    vec, rm, rv, nbt, sums = outs[0]
+    a1 = torch.clamp_min(Z1 * s1 + h1, 0).double()
+    z2 = a1 @ W2.double().t() + b2.double()
+    mean, var = z2.mean(0), z2.var(0, unbiased=False)
+    rstd = (var.float() + eps).rsqrt().double()
+    spread = float(var.sqrt().max())
+    assert float((vec[2].double() - mean).abs().max()) <= 2e-6 * max(float(mean.abs().max()), spread)
+    assert float((vec[3].double() / rstd - 1).abs().max()) <= 5e-6
+    sc = gamma.double() * rstd
+    assert float((vec[0].double() - sc).abs().max()) <= 5e-6 * float(sc.abs().max())
+    sh = beta.double() - mean * sc
+    assert float((vec[1].double() - sh).abs().max()) <= 1e-5 * max(1.0, float(sh.abs().max()))
+    assert float((sums[:C] - z2.sum(0)).abs().max()) <= 2e-6 * float(z2.abs().sum(0).max())
+    assert float((sums[C:] / (z2 * z2).sum(0) - 1).abs().max()) <= 5e-6
+    assert int(nbt) == 42
+    unb = var * (E / max(E - 1, 1))
+    assert float((rm.double() - (0.9 * 0.25 + 0.1 * mean)).abs().max()) <= 1e-5
+    assert float((rv.double() - (0.9 * 2.0 + 0.1 * unb)).abs().max()) <= 1e-5 * max(1.0, float(unb.max()))
+
+
+@pytest.mark.parametrize("B,Nsrc,O,geo", [(1, 40, 7, True), (2, 150, 33, True), (3, 150, 700, False), (1, 5000, 4099, True),
+                                          (2, 20000, 65536, True)])
+def test_att_pairmax_fwd_matches_the_materialised_path(B, Nsrc, O, geo):
+    """gridgcn_att_pairmax_fwd (the second attention conv recomputed per 30-edge MFMA tile, csrc/gridgcn_attfwd.hip)
+    against gridgcn_linear_fwd-style materialisation + gridgcn_pairmax_fwd_src on the same inputs and the SAME
+    BatchNorm vectors.  The point branch is bit-identical; an attention value may differ in its last bits (bias first,
+    MFMA order), so: agg to 2e-6 of its largest entry, the arg max equal except at near ties (an entry whose arg max
+    differs must have a runner-up within 1e-5), zsel at equal arg max: point row bit-equal, attention row 2e-6.
+    Against a float64 restatement as well.  Cases: one tile + one centre, tiles ending mid-way (ncent % 6 = 3, 0,
+    1, 4), out-of-range neighbour indices (clipped), no geo_vec weights, an agg that is the left half of a wider
+    buffer."""
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    d = _att_fwd_inputs(B, Nsrc, O, B * 1000 + O, geo)
+    P, cin, C, ncent, E = d["P"], d["cin"], d["C"], d["ncent"], d["E"]
+    st = _stream(d["Z1"])
+    a1 = torch.clamp_min(d["Z1"] * d["s1"] + d["h1"], 0)
+    z2 = a1.double() @ d["W2"].double().t() + d["b2"].double()
+    mean, var = z2.mean(0), z2.var(0, unbiased=False)
+    sca = (d["gamma"].double() * (var + 1e-5).rsqrt()).float()
+    sha = (d["beta"].double() - mean * sca.double()).float()
+    Z2 = z2.float().contiguous()
+    lda = 256
+    wide = [torch.full((ncent + 3, lda), 7.0, device=DEV) for _ in range(2)]
+    amax = [torch.full((ncent + 3, C), 99, dtype=torch.uint8, device=DEV) for _ in range(2)]
+    zsel = [torch.full((2, ncent, C), 7.0, device=DEV) for _ in range(2)]
+    wg = _ptr(d["Wg"]) if geo else None
+    rc = lib.gridgcn_att_pairmax_fwd(_ptr(d["Ysrc"]), _ptr(d["nebidx"]), _ptr(d["att16"]), wg, _ptr(d["b"]), B, Nsrc, O,
+                                     _ptr(d["Z1"]), _ptr(d["s1"]), _ptr(d["h1"]), _ptr(d["W2"]), _ptr(d["b2"]),
+                                     _ptr(d["scp"]), _ptr(d["shp"]), _ptr(sca), _ptr(sha), ncent, P, cin, C,
+                                     _ptr(wide[0]), lda, _ptr(amax[0]), _ptr(zsel[0]), st)
+    assert rc == 0
+    rc = lib.gridgcn_pairmax_fwd_src_z(_ptr(d["Ysrc"]), _ptr(d["nebidx"]), _ptr(d["att16"]), wg, _ptr(d["b"]), B, Nsrc,
+                                       O, _ptr(Z2), 0, _ptr(d["scp"]), _ptr(d["shp"]), _ptr(sca), _ptr(sha), ncent, P,
+                                       C, _ptr(wide[1]), lda, _ptr(amax[1]), _ptr(zsel[1]), st)
+    assert rc == 0
+    for w, am in zip(wide, amax):
+        assert bool((w[:, C:] == 7.0).all()) and bool((w[ncent:] == 7.0).all()) and bool((am[ncent:] == 99).all())
+    agg1, agg0 = wide[0][:ncent, :C], wide[1][:ncent, :C]
+    top = float(agg0.abs().max())
+    assert float((agg1 - agg0).abs().max()) <= 2e-6 * top
+    # float64 restatement of the whole thing
+    flat = (d["nebidx"].long() + (torch.arange(B, device=DEV) * Nsrc)[:, None, None]).clamp(0, B * Nsrc - 1)
+    zp = d["Ysrc"].double()[flat.reshape(-1)]
+    if geo:
+        zp = zp + d["att16"][:, 1:4].double() @ d["Wg"].double()
+    zp = zp + d["b"].double()
+    v = (torch.clamp_min(zp * d["scp"].double() + d["shp"].double(), 0)
+         * torch.clamp_min(z2 * sca.double() + sha.double(), 0)).reshape(ncent, P, C)
+    ref = v.max(1).values
+    assert float((agg1.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    same = amax[0][:ncent] == amax[1][:ncent]
+    if not bool(same.all()):
+        srt = v.sort(1, descending=True).values
+        gap = (srt[:, 0] - srt[:, 1])[~same]
+        assert float(gap.max()) <= 1e-5 * float(ref.abs().max())
+        assert float((~same).float().mean()) < 1e-3
+    assert torch.equal(zsel[0][0][same], zsel[1][0][same])
+    assert float((zsel[0][1][same] - zsel[1][1][same]).abs().max()) <= 2e-6 * float(z2.abs().max())
+    # shapes the kernel declines: the callers keep the Z2 path
+    args = [_ptr(d["Ysrc"]), _ptr(d["nebidx"]), _ptr(d["att16"]), wg, _ptr(d["b"]), B, Nsrc, O, _ptr(d["Z1"]),
+            _ptr(d["s1"]), _ptr(d["h1"]), _ptr(d["W2"]), _ptr(d["b2"]), _ptr(d["scp"]), _ptr(d["shp"]), _ptr(sca),
+            _ptr(sha), ncent]
+    tail = [_ptr(wide[0]), lda, _ptr(amax[0]), _ptr(zsel[0]), st]
+    assert lib.gridgcn_att_pairmax_fwd(*args, 7, cin, C, *tail) != 0
+    assert lib.gridgcn_att_pairmax_fwd(*args, P, 16, C, *tail) != 0
+    assert lib.gridgcn_att_pairmax_fwd(*args, P, cin, 64, *tail) != 0
+    assert lib.gridgcn_att_pairmax_fwd(*args, P, cin, C, _ptr(wide[0]), lda, _ptr(amax[0]), None, st) != 0
+
+
 @pytest.mark.parametrize("E,cin,prev_bn,nbn", [(32768, 128, True, 0), (65536, 256, True, 128), (40960, 128, False, 0),
                                                (131072, 256, True, 0)])
 def test_linear_bwd_fused128_matches_separate_kernels(E, cin, prev_bn, nbn):
