@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ gg_f32x4 act[2][2][4];       // [scale | shift][k half][4 x float4]
     // per wave, per lane half: gx / gy / gz / byte offset of the source row of the half's 15 edges (slot 15: a dummy),
     // slot-major so that one 16-byte read delivers four slots of a component
-    __shared__ gg_f32x4 geo[4][2][4][4];
+    __shared__ gg_f32x4 geo[4][2][2][4][4];  // [wave][buffer][lane half][gx gy gz row][four slots each]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     if (threadIdx.x < 128) {
@@ -94,8 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ((float *)act)[k] = p.s1[k];
         ((float *)act)[32 + k] = p.h1[k];
     }
-    ((float *)geo)[threadIdx.x] = 0.f;
-    ((float *)geo)[256 + threadIdx.x] = 0.f;
+    for (int i = threadIdx.x; i < 4 * 2 * 2 * 4 * 4 * 4; i += 256) ((float *)geo)[i] = 0.f;
     // B operand: W2^T, step m contracts k = m (lane half 0) and k = 16 + m (lane half 1)
     float wb[4][16];
 #pragma unroll
@@ -108,55 +107,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();
-    const long long ntile = (p.ncent + 5) / 6;
-    const long long E = p.ncent * 5;
-    const long long rows = (long long)p.B * p.Nsrc;
+    // (32-bit indices throughout: gg_att_fwd_ok bounds the edge count and every byte offset below 2^32)
+    const unsigned ncent = (unsigned)p.ncent, ntile = (ncent + 5) / 6, E = ncent * 5;
+    const int rows = p.B * p.Nsrc;
     const gg_rsrc ry = gg_make_rsrc(p.Ysrc);
-    const gg_rsrc ragg = gg_make_rsrc_bytes(p.agg, (unsigned)(p.ncent * p.lda * 4));
-    const gg_rsrc rzp = gg_make_rsrc_bytes(p.zsel, (unsigned)(p.ncent * 512));
-    const gg_rsrc rza = gg_make_rsrc_bytes(p.zsel + p.ncent * 128, (unsigned)(p.ncent * 512));
-    const gg_rsrc ram = gg_make_rsrc_bytes(p.amax, (unsigned)(p.ncent * 128));
+    const gg_rsrc rz1 = gg_make_rsrc(p.Z1), ratt = gg_make_rsrc(p.att16), rnb = gg_make_rsrc(p.nebidx);
+    const gg_rsrc ragg = gg_make_rsrc_bytes(p.agg, ncent * (unsigned)p.lda * 4u);
+    const gg_rsrc rzp = gg_make_rsrc_bytes(p.zsel, ncent * 512u);
+    const gg_rsrc rza = gg_make_rsrc_bytes(p.zsel + p.ncent * 128, ncent * 512u);
+    const gg_rsrc ram = gg_make_rsrc_bytes(p.amax, ncent * 128u);
     // the A row of this lane: slot s_i of lane half h_i
     const int si = (j & 3) + 4 * (j >> 3), hi = (j >> 2) & 1;
-    const int arow = hi * 15 + (si < 15 ? si : 14);
+    const unsigned arow = hi * 15 + (si < 15 ? si : 14);
     // the staging lanes (0..29): edge `lane` of the tile -> half lane / 15, slot lane % 15
     const int sh_ = lane >= 15 ? 1 : 0, ss_ = lane - 15 * sh_;
-    float *gst = (float *)&geo[wave][sh_][0][0] + (ss_ & 15);
-    const int slane = lane < 30 ? lane : 29;
+    const int gso = sh_ * 64 + (ss_ & 15);
+    const unsigned slane = lane < 30 ? lane : 29;
     const float NEG = -__builtin_inff();
     const unsigned jb = (unsigned)j * 4;
     typedef gg_f32x2 f2;
     struct In { gg_f32x4 z[4], g; int nb; };
-    auto load = [&](long long t, In &in) {
-        const long long eb = t * 30;
-        long long ea = eb + arow;
+    auto load = [&](unsigned t, In &in) {
+        const unsigned eb = t * 30;
+        unsigned ea = eb + arow;
         ea = ea < E ? ea : E - 1;
-        const float *zr = p.Z1 + ea * 32 + h * 16;
+        const unsigned zo = ea * 128u + h * 64u;
 #pragma unroll
-        for (int q = 0; q < 4; q++) in.z[q] = gg_ld_f4(zr + 4 * q);
-        long long e = eb + slane;
+        for (int q = 0; q < 4; q++) in.z[q] = gg_buf_ld4(rz1, zo + 16u * q, 0);
+        unsigned e = eb + slane;
         e = e < E ? e : E - 1;
-        in.g = gg_ld_f4(p.att16 + e * 16);
-        in.nb = p.nebidx[e];
+        in.g = gg_buf_ld4(ratt, e * 64u, 0);
+        in.nb = (int)gg_buf_ld_u32(rnb, e * 4u, 0);
     };
-    In cur;
-    const long long tstep = (long long)gridDim.x * 4;
-    long long t = (long long)blockIdx.x * 4 + wave;
-    if (t < ntile) load(t, cur);
-    for (; t < ntile; t += tstep) {
-        In nxt;
-        load(t + tstep < ntile ? t + tstep : t, nxt);
+    // the staging lanes' part of a tile: (gx, gy, gz, byte offset of the source row) of edge `lane` into buffer gb
+    auto stage = [&](unsigned t, const In &in, float *gb) {
+        // cloud of the tile's first centre (scalar), then at most one step up inside the tile
+        const unsigned oc0 = t * 6, bt = oc0 / (unsigned)p.O;
+        unsigned e = t * 30 + slane;
+        e = e < E ? e : E - 1;
+        const unsigned o = e / 5;
+        const int bi = (int)bt + (o >= (bt + 1) * (unsigned)p.O ? 1 : 0);
+        int flat = in.nb + bi * p.Nsrc;
+        flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
         if (lane < 30) {
-            long long e = t * 30 + lane;
-            e = e < E ? e : E - 1;
-            const long long o = e / 5;
-            long long flat = (long long)cur.nb + (o / p.O) * p.Nsrc;
-            flat = flat < 0 ? 0 : (flat > rows - 1 ? rows - 1 : flat);
-            gst[0] = cur.g.y; gst[16] = cur.g.z; gst[32] = cur.g.w; gst[48] = __uint_as_float((unsigned)flat * 512u);
+            float *g = gb + gso;
+            g[0] = in.g.y; g[16] = in.g.z; g[32] = in.g.w; g[48] = __uint_as_float((unsigned)flat * 512u);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // the sixteen slots of this lane half, one channel each (column tile ct)
+    auto gather = [&](const float *gb, int ct, f2 (&y)[8]) {
+        const gg_f32x4 *gq = (const gg_f32x4 *)gb + (h * 4 + 3) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const gg_f32x4 gr = gq[k];
+            y[2 * k].x = gg_buf_ld(ry, __float_as_uint(gr.x) + jb + 128u * ct, 0);
+            y[2 * k].y = gg_buf_ld(ry, __float_as_uint(gr.y) + jb + 128u * ct, 0);
+            y[2 * k + 1].x = gg_buf_ld(ry, __float_as_uint(gr.z) + jb + 128u * ct, 0);
+            y[2 * k + 1].y = gg_buf_ld(ry, __float_as_uint(gr.w) + jb + 128u * ct, 0);
+        }
+    };
+    // Software pipeline over the wave's tiles: while tile t is folded, the rows and edge records of t + 1 are in
+    // flight, its edge records are staged half-way through (into the other LDS buffer), and the gathers of ITS first
+    // column tile are issued before the last MFMAs of t; inside a tile the gathers of column tile ct + 1 go out before
+    // the MFMAs of ct.  Nothing the fold needs is requested less than ~1000 cycles before it is used.
+    In cur;
+    const unsigned tstep = gridDim.x * 4;
+    unsigned t = blockIdx.x * 4 + wave;
+    float *gcur = (float *)&geo[wave][0][0][0][0], *gnxt = (float *)&geo[wave][1][0][0][0];
+    f2 yb[2][8];
+    if (t < ntile) {
+        load(t, cur);
+        stage(t, cur, gcur);
+        gather(gcur, 0, yb[0]);
+    }
+    for (; t < ntile; t += tstep) {
+        In nxt;
+        const unsigned tn = t + tstep < ntile ? t + tstep : t;
+        load(tn, nxt);
         float a[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -164,19 +194,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         }
         // byte offsets of this lane's outputs: centre 6 t + 3 h + cs, channel j (+ 32 ct)
-        const unsigned o0 = (unsigned)(t * 6 + h * 3);
+        const unsigned o0 = t * 6 + h * 3;
+        const gg_f32x4 *gx = (const gg_f32x4 *)gcur + h * 16;
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) {
-            // the sixteen slots of this lane half, one channel each: the gathers in flight together, under the MFMAs
-            f2 y[8];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const gg_f32x4 gr = geo[wave][h][3][k];
-                y[2 * k].x = gg_buf_ld(ry, __float_as_uint(gr.x) + jb + 128u * ct, 0);
-                y[2 * k].y = gg_buf_ld(ry, __float_as_uint(gr.y) + jb + 128u * ct, 0);
-                y[2 * k + 1].x = gg_buf_ld(ry, __float_as_uint(gr.z) + jb + 128u * ct, 0);
-                y[2 * k + 1].y = gg_buf_ld(ry, __float_as_uint(gr.w) + jb + 128u * ct, 0);
-            }
+            if (ct < 3) gather(gcur, ct + 1, yb[(ct + 1) & 1]);
+            else gather(gnxt, 0, yb[0]);
+            const f2 (&y)[8] = yb[ct & 1];
             ggm_f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; r++) d[r] = 0.f;
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f2 z1[8], vv[8];
 #pragma unroll
             for (int k4 = 0; k4 < 4; k4++) {
-                const gg_f32x4 X = geo[wave][h][0][k4], Y = geo[wave][h][1][k4], Z = geo[wave][h][2][k4];
+                const gg_f32x4 X = gx[k4], Y = gx[4 + k4], Z = gx[8 + k4];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int k = 2 * k4 + u;
@@ -211,16 +235,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #pragma unroll
             for (int cs = 0; cs < 3; cs++) {
-                float best = NEG, zps = 0.f, zas = 0.f;
-                int bi = 0;
+                // the FIRST neighbour that attains the maximum (what `v > best` in neighbour order selects): the
+                // maximum of the five products, then the equality masks of neighbours 3 .. 0, the lowest last
+                float v[5], zp[5];
 #pragma unroll
                 for (int q = 0; q < 5; q++) {
                     const int r = cs * 5 + q;
-                    const float v = (r & 1) ? vv[r >> 1].y : vv[r >> 1].x;
-                    const float zp = (r & 1) ? z1[r >> 1].y : z1[r >> 1].x;
-                    const bool upd = v > best;
-                    if (upd || q == 0) { zps = zp; zas = d[r]; }
-                    if (upd) { best = v; bi = q; }
+                    v[q] = (r & 1) ? vv[r >> 1].y : vv[r >> 1].x;
+                    zp[q] = (r & 1) ? z1[r >> 1].y : z1[r >> 1].x;
+                }
+                const float best = fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]),
+                                         __builtin_fmaxf(v[3], v[4]));
+                int bi = 4;
+                float zps = zp[4], zas = d[cs * 5 + 4];
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+                    const bool m = v[q] == best;
+                    bi = m ? q : bi; zps = m ? zp[q] : zps; zas = m ? d[cs * 5 + q] : zas;
                 }
                 const unsigned oc = o0 + cs;
                 gg_buf_st(best, ragg, oc * (unsigned)(p.lda * 4) + jb + 128u * ct, 0);
@@ -228,11 +259,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 gg_buf_st(zps, rzp, oc * 512u + jb + 128u * ct, 0);
                 gg_buf_st(zas + b2c, rza, oc * 512u + jb + 128u * ct, 0);
             }
+            if (ct == 1) stage(tn, nxt, gnxt);
         }
-        // (the next tile's geo[] writes come after this tile's reads: LDS operations of a wave execute in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        cur = nxt;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur.z[q] = nxt.z[q];
+        float *sw = gcur; gcur = gnxt; gnxt = sw;
     }
 }
 
@@ -240,60 +271,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // part [workgroups][17][64] fp64: rows 0..15 the C/D registers of S2 (lane l: column l&31, row (r&3)+8(r>>2)+4(l>>5)),
 // row 16 the lane's share of S1[l&31].
 #define GG_MOM_FLUSH 8           // batches of 16 row pairs between two fp64 folds (256 rows)
-__global__ __launch_bounds__(256) void gg_k_att_moments(const float *__restrict__ Z1, const float *__restrict__ s1,
-                                                        const float *__restrict__ h1, long long E,
-                                                        double *__restrict__ part)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gg_k_att_moments(
+    const float *__restrict__ Z1, const float *__restrict__ s1, const float *__restrict__ h1, unsigned E,
+    double *__restrict__ part)
 {
     __shared__ double sl[4][17][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+    const unsigned gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
     const float sc = s1[lane & 31], sh = h1[lane & 31];
-    const long long npair = (E + 1) / 2;
-    long long per = (npair + nw - 1) / nw;
-    per = (per + 15) & ~15ll;
-    const long long lo = gw * per;
-    const long long hi = lo + per < npair ? lo + per : npair;
+    const unsigned npair = (E + 1) / 2;
+    unsigned per = (npair + nw - 1) / nw;
+    per = (per + 15) & ~15u;
+    const unsigned lo = gw * per < npair ? gw * per : npair;
+    const unsigned hi = lo + per < npair ? lo + per : npair;
+    // whole batches of 16 pairs whose 32 rows all exist; what is left (at most one batch) takes the predicated path
+    const unsigned nfull = (hi - lo) / 16 - ((hi - lo) % 16 == 0 && hi == npair && (E & 1) && hi > lo ? 1 : 0);
+    const gg_rsrc rz = gg_make_rsrc(Z1);
     ggm_f32x16 acc;
     double accd[16], s1d = 0.0;
     float s1f = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc[r] = 0.f; accd[r] = 0.0; }
     // lane l reads element l of each 64-float row pair: one coalesced 256-byte load per MFMA step
-    auto ld = [&](long long q, float (&v)[16]) {
+    auto ld = [&](unsigned q, float (&v)[16]) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const long long row = 2 * (q + i) + (lane >> 5);
-            v[i] = Z1[(row < E ? row : E - 1) * 32 + (lane & 31)];
-        }
+        for (int i = 0; i < 16; i++) v[i] = gg_buf_ld(rz, q * 256u + lane * 4u + 256u * i, 0);
+    };
+    auto fold = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
+        s1d += (double)s1f;
+        s1f = 0.f;
     };
     float v[16];
-    if (lo < hi) ld(lo, v);
-    int nb = 0;
-    for (long long q = lo; q < hi; q += 16) {
+    if (nfull) ld(lo, v);
+    unsigned nb = 0;
+    for (unsigned b = 0; b < nfull; b++) {
+        const unsigned q = lo + 16 * b;
         float vn[16];
-        if (q + 16 < hi) ld(q + 16, vn);
+        if (b + 1 < nfull) ld(q + 16, vn);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const bool ok = 2 * (q + i) + (lane >> 5) < E;
-            const float a = ok ? fmaxf(v[i] * sc + sh, 0.f) : 0.f;
+            // (two alternating accumulators: no faster -- the chain of dependent MFMAs is not what bounds this)
+            const float a = fmaxf(fmaf(v[i], sc, sh), 0.f);
             s1f += a;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
         }
-        if (++nb == GG_MOM_FLUSH) {
-            nb = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
-            s1d += (double)s1f;
-            s1f = 0.f;
-        }
-        if (q + 16 < hi) {
+        if (++nb == GG_MOM_FLUSH) { nb = 0; fold(); }
+        if (b + 1 < nfull) {
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = vn[i];
         }
     }
+    for (unsigned q = lo + 16 * nfull; q < hi; q++) {         // the ragged end: pair by pair
+        const unsigned row = 2 * q + (lane >> 5);
+        const float z = gg_buf_ld(rz, (row < E ? row : E - 1) * 128u + (lane & 31) * 4u, 0);
+        const float a = row < E ? fmaxf(fmaf(z, sc, sh), 0.f) : 0.f;
+        s1f += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc, 0, 0, 0);
+    }
+    fold();
 #pragma unroll
-    for (int r = 0; r < 16; r++) sl[wave][r][lane] = accd[r] + (double)acc[r];
-    sl[wave][16][lane] = s1d + (double)s1f;
+    for (int r = 0; r < 16; r++) sl[wave][r][lane] = accd[r];
+    sl[wave][16][lane] = s1d;
     __syncthreads();
     for (int i = threadIdx.x; i < 17 * 64; i += 256) {
         const double *s = &sl[0][0][0] + i;
@@ -357,13 +397,14 @@ __global__ __launch_bounds__(64) void gg_k_att_bn2_from_moments(const double *__
 
 static int gg_att_moments_grid(long long E)
 {
-    long long nb = (E + 256 * 4 - 1) / (256 * 4);       // >= 256 rows per wave, two waves per SIMD
+    // >= 256 rows per wave, two workgroups per CU (four: 108 us against 93)
+    long long nb = (E + 256 * 4 - 1) / (256 * 4);
     return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
 }
 
-bool gg_att_fwd_ok(long long ncent, int P, int cin, int C, int lda, long long rows)
+bool gg_att_fwd_ok(long long ncent, int O, int P, int cin, int C, int lda, long long rows)
 {
-    return P == 5 && cin == 32 && C == 128 && ncent >= 7 && lda >= 128 && rows >= 1 &&
+    return P == 5 && cin == 32 && C == 128 && ncent >= 7 && ncent < (1ll << 22) && O >= 6 && lda >= 128 && rows >= 1 &&
            rows < (1ll << 23) && ncent * (long long)lda * 4 < (1ll << 32);
 }
 
@@ -379,7 +420,7 @@ int gg_att_bn2_moments(const float *Z1, const float *s1, const float *h1, const 
 {
     const int grid = gg_att_moments_grid(E);
     double *part = (double *)ws, *mom = part + (size_t)grid * 17 * 64;
-    gg_k_att_moments<<<grid, 256, 0, st>>>(Z1, s1, h1, E, part);
+    gg_k_att_moments<<<grid, 256, 0, st>>>(Z1, s1, h1, (unsigned)E, part);
     gg_k_att_moments_reduce<<<17, 1024, 0, st>>>(part, grid, mom);
     gg_k_att_bn2_from_moments<<<128, 64, 0, st>>>(mom, W2, b2, gamma, beta, E, eps, momentum, scale, shift, mean, rstd,
                                                  run_mean, run_var, nbt, sums);

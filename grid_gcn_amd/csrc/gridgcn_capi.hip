@@ -703,7 +703,7 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
 
 int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes)
 {
-    if (!bytes || E < 1 || cin != 32 || C != 128) return GRIDGCN_EINVAL;
+    if (!bytes || E < 1 || E >= (1ll << 25) || cin != 32 || C != 128) return GRIDGCN_EINVAL;
     *bytes = gg_att_moments_workspace(E);
     return GRIDGCN_OK;
 }
@@ -715,7 +715,7 @@ int gridgcn_att_bn2_moments(const float *Z1, const float *scale1, const float *s
                             void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!Z1 || !scale1 || !shift1 || !W2 || !b2 || !gamma || !beta || !scale || !shift || !mean || !rstd ||
-        E < 1 || cin != 32 || C != 128 || (!running_mean) != (!running_var))
+        E < 1 || E >= (1ll << 25) || cin != 32 || C != 128 || (!running_mean) != (!running_var))
         return GRIDGCN_EINVAL;
     if (!workspace || workspace_bytes < gg_att_moments_workspace(E)) return GRIDGCN_EWORKSPACE;
     return gg_att_bn2_moments(Z1, scale1, shift1, W2, b2, gamma, beta, E, eps, momentum, scale, shift, mean, rstd,
@@ -732,7 +732,7 @@ int gridgcn_att_pairmax_fwd(const float *Ysrc, const int32_t *nebidx, const floa
     if (!Ysrc || !nebidx || !att16 || !b || !Z1 || !scale1 || !shift1 || !W2 || !b2 || !scale_p || !shift_p ||
         !scale_a || !shift_a || !agg || !amax || !zsel || B < 1 || Nsrc < 1 || O < 1 || ncent != (long long)B * O)
         return GRIDGCN_EINVAL;
-    if (!gg_att_fwd_ok(ncent, P, cin, C, ld_agg, (long long)B * Nsrc)) return GRIDGCN_EINVAL;
+    if (!gg_att_fwd_ok(ncent, O, P, cin, C, ld_agg, (long long)B * Nsrc)) return GRIDGCN_EINVAL;
     return gg_att_pairmax_args(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Z1, scale1, shift1, W2, b2, scale_p, shift_p,
                                scale_a, shift_a, ncent, agg, ld_agg, amax, zsel, (hipStream_t)stream);
 }

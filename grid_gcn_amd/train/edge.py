@@ -233,7 +233,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                   and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16)
             # ... and neither does the forward (gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd): the [E, 128]
             # tensor is then never written at all
-            nzf = nz and OPT.NOZ_ATT_FWD and P == 5 and ncent >= 7 and R < (1 << 23) and lda >= C
+            nzf = (nz and OPT.NOZ_ATT_FWD and P == 5 and O >= 6 and ncent >= 7 and R < (1 << 23) and lda >= C
+                   and ncent * lda < (1 << 30))
             if nzf:
                 sa = _att_fwd_noz(lib, att16, pa, bns_a, eps, st)
                 rc = lib.gridgcn_att_pairmax_fwd(

@@ -676,7 +676,7 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
  *   and num_batches_tracked when given; sums [2][128] fp64 when not NULL).  cin = 32, C = 128.
  * gridgcn_att_pairmax_fwd: what gridgcn_pairmax_fwd_src writes (agg, amax, zsel -- zsel REQUIRED: the backward has
  *   nothing else to take the arg-max pre-activations from), the second conv recomputed per 30-edge tile on the MFMA
- *   unit.  P = 5, cin = 32, C = 128, ncent >= 7, B*Nsrc < 2^23; GRIDGCN_EINVAL otherwise (callers keep the Z2 path).
+ *   unit.  P = 5, cin = 32, C = 128, O >= 6, ncent >= 7, B*Nsrc < 2^23, ncent*ld_agg < 2^30; GRIDGCN_EINVAL otherwise (callers keep the Z2 path).
  *   The attention value of an edge is W2 a1 + b2 in the MFMA unit's summation order with the bias FIRST: the same
  *   terms as gridgcn_linear_fwd_direct, last-bit differences possible; the point branch is bit-identical. */
 int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes);
