@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the MFMAs of ct.  Nothing the fold needs is requested less than ~1000 cycles before it is used.
     In cur;
     const unsigned tstep = gridDim.x * 4;
+    // (an XCD-contiguous renumbering of the workgroups -- neighbouring tiles in one L2 -- measured neutral)
     unsigned t = blockIdx.x * 4 + wave;
     float *gcur = (float *)&geo[wave][0][0][0][0], *gnxt = (float *)&geo[wave][1][0][0][0];
     f2 yb[2][8];
