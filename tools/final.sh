@@ -41,5 +41,7 @@ timeout 600 python tools/time_gridify.py > $OUT/${L}_gridify_times.txt 2> $OUT/g
 bash tools/pmc_step.sh $1/pmc bf16 > $OUT/pmc_step_bf16.log 2>&1; cp $OUT/pmc/pmc_step_bf16.txt $OUT/${L}_pmc_step_bf16.txt; cp $OUT/pmc/traffic.json $OUT/traffic.json
 timeout 900 python bench.py --config cfg4 --dtype bf16 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${L}_bench_cfg4_bf16.json 2> $OUT/bench_cfg4_bf16b.err
 bash tools/gridify_insts.sh $1/ginsts > /dev/null 2>&1; cp $OUT/ginsts/gridify_insts.txt $OUT/${L}_gridify_insts.txt
-{ timeout 300 python tools/time_nz.py; timeout 300 python tools/time_bwdfused.py; } > $OUT/${L}_ab_kernels.txt 2>&1; tail -12 $OUT/${L}_ab_kernels.txt
+{ timeout 300 python tools/time_nz.py; timeout 300 python tools/time_bwdfused.py; timeout 300 python tools/time_attfwd.py; } > $OUT/${L}_ab_kernels.txt 2>&1; tail -12 $OUT/${L}_ab_kernels.txt
+# the Z2-free attention forward, in the step (OPT.NOZ_ATT_FWD)
+bash tools/ab_lib.sh $1/abfwd NOZ_ATT_FWD 2 > $OUT/${L}_ab_noz_att_fwd.txt 2>&1; cat $OUT/${L}_ab_noz_att_fwd.txt
 timeout 300 python tools/graph_branch_probe.py > $OUT/${L}_graph_branch_probe.txt 2>&1; tail -2 $OUT/${L}_graph_branch_probe.txt

@@ -62,7 +62,9 @@ def short(name):
 
 # kernels whose reads are PARTLY dwordx4 row streams: factor = 1 + (share of the fetched bytes that are wide)
 # gg_k_linear_bwd_fused128: Z and dY as 16-byte row reads (2/3 of its HBM reads), X as coalesced dword rows
-PARTLY = {"gg_k_linear_bwd_fused128": 1.5}
+# gg_k_att_pairmax: Z1 rows and edge records as 16-byte reads (630 of its ~730 MB), the gathered source rows and the
+#   neighbour indices as dword reads: (630 + 97) / (315 + 97)
+PARTLY = {"gg_k_linear_bwd_fused128": 1.5, "gg_k_att_pairmax": 1.75}
 
 
 def is_wide(name):
