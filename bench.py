@@ -508,7 +508,9 @@ def main():
         c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
         e_b = float(ncent_b * p_b)
-        noz = (train_ops.OPT.NOZ_ATT_BWD and a.dtype == "f32" and cin_b == 32 and c_b == 128)
+        # (bf16 mode takes the same fp32 pair of Z2-free kernels for this layer: OPT.NOZ_IN_BF16)
+        noz = (train_ops.OPT.NOZ_ATT_BWD and cin_b == 32 and c_b == 128 and p_b == 5
+               and (a.dtype == "f32" or (train_ops.OPT.NOZ_IN_BF16 and train_ops.OPT.NOZ_ATT_FWD)))
         if noz:
             ms_b = train_ops.time_att_bwd_noz(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev)
             # read Z1 [E,cin], the sparse upstream gradient (one-byte amax + fp32 value) [ncent,C]; write dA1

@@ -224,13 +224,17 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             # accumulators are rounded once; BatchNorm statistics from the fp32 values).  Only where
             # both readers take it: the source-side max kernel and the fused attention backward.
             # (E >= 32: below that the fused backward declines and nothing else reads a bf16 Z)
+            nz_shape = noz and La == 2 and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16
+            # (bf16 mode, OPT.NOZ_IN_BF16: where the Z2-free pair of kernels applies it is taken in bf16 mode too -- it is
+            #  fp32-exact and moves fewer bytes than the bf16-stored tensor does)
+            nz16 = (OPT.NOZ_IN_BF16 and OPT.NOZ_ATT_BWD and OPT.NOZ_ATT_FWD and nz_shape and P == 5 and O >= 6
+                    and lib.gridgcn_get_mlp_precision() == 1)
             z16 = (OPT.Z16_STORAGE and noz and La == 2 and A0 in (16, 32) and C in (64, 128) and E >= 32
-                   and lib.gridgcn_get_mlp_precision() == 1
+                   and lib.gridgcn_get_mlp_precision() == 1 and not nz16
                    and lib.gridgcn_get_option(_lib.OPT_ATT_BWD_FUSED) == 1)
             # the backward of the second attention conv needs no Z2 (gridgcn_att_bwd_noz): decided HERE, because
             # the tensor is then not saved ...
-            nz = (OPT.NOZ_ATT_BWD and noz and La == 2 and not z16 and lib.gridgcn_get_mlp_precision() == 0
-                  and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16)
+            nz = (OPT.NOZ_ATT_BWD and nz_shape and not z16 and (lib.gridgcn_get_mlp_precision() == 0 or nz16))
             # ... and neither does the forward (gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd): the [E, 128]
             # tensor is then never written at all
             nzf = (nz and OPT.NOZ_ATT_FWD and P == 5 and O >= 6 and ncent >= 7 and R < (1 << 23) and lda >= C

@@ -36,6 +36,8 @@ class PathOptions:
     # ... and the forward: its BatchNorm from the moments of the 32-wide activation, the conv recomputed inside the
     # pair product / max kernel (csrc/gridgcn_attfwd.hip): the tensor is never written (needs NOZ_ATT_BWD)
     NOZ_ATT_FWD: bool = True
+    # bf16 mode: the same pair of (fp32) kernels instead of the bf16-stored tensor, where the shape allows
+    NOZ_IN_BF16: bool = True
     # the source-point products on csrc/gridgcn_gemm.hip instead of the framework's GEMM
     SMALL_GEMM: bool = True
     # small zero-filled accumulators carved from 4 MB zero chunks (one fill per chunk instead of ~70 per step)

@@ -1118,6 +1118,7 @@ def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
     g = torch.randn(B, O, 128, generator=gen).to(DEV)
     outs = []
+    monkeypatch.setattr(train_ops.OPT, "NOZ_IN_BF16", False)        # (this shape would take the Z2-free pair: next test)
     try:
         train_ops.set_mlp_precision("bf16")
         for net, src, z16 in ((ref, src1, False), (new, src2, True)):
@@ -1134,6 +1135,48 @@ def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     assert rel(s1[..., 4:], s0[..., 4:]) <= 5e-2
     for a, b in zip(p1, p0):
         assert rel(a, b) <= 5e-2, (rel(a, b), a.shape)
+
+
+def test_bf16_mode_takes_the_z2_free_attention_pair_where_it_applies(monkeypatch):
+    """bf16 mode, up-layer shape (P = 5, attention 10 -> 32 -> 128): OPT.NOZ_IN_BF16 runs the second attention conv's
+    forward and backward on the fp32 Z2-free kernels (csrc/gridgcn_attfwd.hip, gridgcn_attbwd_nz.hip) instead of the
+    bf16-stored tensor: one conv of the block in exact fp32 instead of bf16 operands.  So, against the fp32 mode on the
+    same inputs, the variant must be no farther away than plain bf16 mode is (output: 1.2 x in max norm; gradients:
+    1.5 x in relative L2 norm -- single arg-max flips move entries either way), and no [E, 128] tensor is saved."""
+    import copy
+    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.gridconv import SubGUpdate
+    torch.manual_seed(22)
+    gen = torch.Generator().manual_seed(6)
+    B, Nsrc, O, P, cin = 2, 300, 4000, 5, 128
+    net0 = SubGUpdate(cin, [128], localfdim=3).to(DEV).train()
+    src0 = (torch.rand(B, Nsrc, 4 + cin, generator=gen) * 2 - 1).to(DEV)
+    nebidx = torch.randint(0, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
+    cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
+    g = torch.randn(B, O, 128, generator=gen).to(DEV)
+    outs = []
+    monkeypatch.setattr(train_ops.OPT, "Z16_STORAGE", False)
+    try:
+        for mode, nzb in (("fp32", True), ("bf16", False), ("bf16", True)):
+            train_ops.set_mlp_precision(mode)
+            monkeypatch.setattr(train_ops.OPT, "NOZ_IN_BF16", nzb)
+            net, src = copy.deepcopy(net0), src0.clone().requires_grad_(True)
+            saved = []
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(tuple(t.shape)), t)[1], lambda t: t):
+                y = net.forward_src(cent, src, nebidx, None)
+            assert ((B * O * P, 128) in saved) == (mode == "bf16" and not nzb)
+            y.backward(g)
+            outs.append((y.detach(), src.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+    finally:
+        train_ops.set_mlp_precision("fp32")
+    (yf, sf, pf), (yb, sb, pb), (yn, sn, pn) = outs
+    assert float((yb - yn).abs().max()) > 0.0
+    assert float((yn - yf).abs().max()) <= 1.2 * float((yb - yf).abs().max())
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))   # noqa: E731
+    assert rel(sn[..., 4:], sf[..., 4:]) <= 1.5 * rel(sb[..., 4:], sf[..., 4:]) + 1e-3
+    for a, b, f in zip(pn, pb, pf):
+        if float(f.norm()) > 0:
+            assert rel(a, f) <= 1.5 * rel(b, f) + 1e-3, (rel(a, f), rel(b, f), a.shape)
 
 
 @pytest.mark.parametrize("B,N,O,P,C,outlier", [(2, 50, 300, 5, 40, False), (2, 50, 300, 5, 40, True),
