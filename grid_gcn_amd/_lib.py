@@ -18,6 +18,7 @@ OPT_COL_SPLIT = 4               # GRIDGCN_OPT_COL_SPLIT
 OPT_PAIRMAX_SPLIT = 5           # GRIDGCN_OPT_PAIRMAX_SPLIT
 OPT_ATT_NZ_V2 = 6               # GRIDGCN_OPT_ATT_NZ_V2
 OPT_BWD_FUSED128 = 7            # GRIDGCN_OPT_BWD_FUSED128
+OPT_ATT_EVAL_TILE = 8           # GRIDGCN_OPT_ATT_EVAL_TILE
 
 EXPORTS = [
     "gridgcn_strerror", "gridgcn_abi_version", "gridgcn_set_mlp_precision",

@@ -68,6 +68,9 @@ __device__ __forceinline__ gg_rsrc gg_make_rsrc_bytes(const void *uniform_base, 
 // Measured on the way (profiles/r5_attfwd_variants.txt): the gathers as STRUCTURED buffer loads (row index as
 // vindex, stride 512 -- one instruction, no address arithmetic) cost +0.24 ms: raw loads with the byte offset
 // computed by a multiply-add it is.
+// TRAIN = false: the evaluation forward (every BatchNorm a fixed affine map; csrc/gridgcn_atteval.hip is the general
+// form): only the maximum is kept -- no arg max, no saved pre-activations.
+template <bool TRAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gg_k_att_pairmax(GGAttFwd p)
 {
     // per channel, every value twice (the two halves of a packed operand): a1 b1 | a2 b2' | w0 w1 | w2 b   (b2' = b2 + b2c a2)
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const f2 w0 = {c2.x, c2.y}, w1 = {c2.z, c2.w}, w2 = {c3.x, c3.y}, wbias = {c3.z, c3.w};
             const float b2c = cb2c[32 * ct + j];
             // pairs of slots on the packed fp32 instructions
-            f2 z1[8], vv[8];
+            f2 z1[TRAIN ? 8 : 1], vv[8];
 #pragma unroll
             for (int k4 = 0; k4 < 4; k4++) {
                 const gg_f32x4 X = gx[k4], Y = gx[4 + k4], Z = gx[8 + k4];
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     zz = __builtin_elementwise_fma(py, w1, zz);
                     zz = __builtin_elementwise_fma(pz, w2, zz);
                     zz = zz + wbias;
-                    z1[k] = zz;
+                    if (TRAIN) z1[TRAIN ? k : 0] = zz;
                     const f2 y1 = __builtin_elementwise_max(__builtin_elementwise_fma(zz, a1, b1), (f2)(0.f));
                     const f2 y2 = __builtin_elementwise_max(__builtin_elementwise_fma(dd, a2, b2), (f2)(0.f));
                     vv[k] = y1 * y2;
@@ -238,27 +241,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int cs = 0; cs < 3; cs++) {
                 // the FIRST neighbour that attains the maximum (what `v > best` in neighbour order selects): the
                 // maximum of the five products, then the equality masks of neighbours 3 .. 0, the lowest last
-                float v[5], zp[5];
+                float v[5];
 #pragma unroll
                 for (int q = 0; q < 5; q++) {
                     const int r = cs * 5 + q;
                     v[q] = (r & 1) ? vv[r >> 1].y : vv[r >> 1].x;
-                    zp[q] = (r & 1) ? z1[r >> 1].y : z1[r >> 1].x;
                 }
                 const float best = fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]),
                                          __builtin_fmaxf(v[3], v[4]));
-                int bi = 4;
-                float zps = zp[4], zas = d[cs * 5 + 4];
-#pragma unroll
-                for (int q = 3; q >= 0; q--) {
-                    const bool m = v[q] == best;
-                    bi = m ? q : bi; zps = m ? zp[q] : zps; zas = m ? d[cs * 5 + q] : zas;
-                }
                 const unsigned oc = o0 + cs;
                 gg_buf_st(best, ragg, oc * (unsigned)(p.lda * 4) + jb + 128u * ct, 0);
-                gg_buf_st_u8((unsigned char)bi, ram, oc * 128u + j + 32u * ct, 0);
-                gg_buf_st(zps, rzp, oc * 512u + jb + 128u * ct, 0);
-                gg_buf_st(zas + b2c, rza, oc * 512u + jb + 128u * ct, 0);
+                if constexpr (TRAIN) {
+                    int bi = 4;
+                    float zps = z1[(cs * 5 + 4) >> 1].x, zas = d[cs * 5 + 4];
+                    if ((cs * 5 + 4) & 1) zps = z1[(cs * 5 + 4) >> 1].y;
+#pragma unroll
+                    for (int q = 3; q >= 0; q--) {
+                        const int r = cs * 5 + q;
+                        const bool m = v[q] == best;
+                        const float zp = (r & 1) ? z1[r >> 1].y : z1[r >> 1].x;
+                        bi = m ? q : bi; zps = m ? zp : zps; zas = m ? d[r] : zas;
+                    }
+                    gg_buf_st_u8((unsigned char)bi, ram, oc * 128u + j + 32u * ct, 0);
+                    gg_buf_st(zps, rzp, oc * 512u + jb + 128u * ct, 0);
+                    gg_buf_st(zas + b2c, rza, oc * 512u + jb + 128u * ct, 0);
+                }
             }
             if (ct == 1) stage(tn, nxt, gnxt);
         }
@@ -396,6 +403,10 @@ __global__ __launch_bounds__(64) void gg_k_att_bn2_from_moments(const double *__
     }
 }
 
+static int g_att_eval_tile = 1;         // GRIDGCN_OPT_ATT_EVAL_TILE
+void gg_set_att_eval_tile(int v) { g_att_eval_tile = v ? 1 : 0; }
+int gg_get_att_eval_tile() { return g_att_eval_tile; }
+
 static int gg_att_moments_grid(long long E)
 {
     // >= 256 rows per wave, two workgroups per CU (four: 108 us against 93)
@@ -433,7 +444,8 @@ int gg_att_pairmax(const GGAttFwd &p, hipStream_t st)
     const long long ntile = (p.ncent + 5) / 6;
     long long nb = (ntile + 3) / 4;
     nb = nb > 512 ? 512 : nb;                                // two workgroups (of four waves) per CU
-    gg_k_att_pairmax<<<(int)nb, 256, 0, st>>>(p);
+    if (p.amax) gg_k_att_pairmax<true><<<(int)nb, 256, 0, st>>>(p);
+    else gg_k_att_pairmax<false><<<(int)nb, 256, 0, st>>>(p);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

@@ -173,6 +173,11 @@ int gridgcn_set_option(int option, int value)
         gg_set_bwd_fused128(value);
         return GRIDGCN_OK;
     }
+    if (option == GRIDGCN_OPT_ATT_EVAL_TILE) {
+        if (value != 0 && value != 1) return GRIDGCN_EINVAL;
+        gg_set_att_eval_tile(value);
+        return GRIDGCN_OK;
+    }
     return GRIDGCN_EINVAL;
 }
 
@@ -186,6 +191,7 @@ int gridgcn_get_option(int option)
     if (option == GRIDGCN_OPT_PAIRMAX_SPLIT) return gg_pairmax_split;
     if (option == GRIDGCN_OPT_ATT_NZ_V2) return gg_get_att_nz_v2();
     if (option == GRIDGCN_OPT_BWD_FUSED128) return gg_get_bwd_fused128();
+    if (option == GRIDGCN_OPT_ATT_EVAL_TILE) return gg_get_att_eval_tile();
     return -1;
 }
 
@@ -1179,6 +1185,11 @@ int gridgcn_att_max_eval(const float *Z1, const float *scale1, const float *shif
         !att16 || !b || !scale_p || !shift_p || !agg || B < 1 || Nsrc < 1 || O < 1 || P < 1 ||
         ld_agg < C)
         return GRIDGCN_EINVAL;
+    // the up layers' shape: the tile kernel of the training forward, without its arg max and saved pre-activations
+    if (gg_get_att_eval_tile() && gg_att_fwd_ok((long long)B * O, O, P, 32, C, ld_agg, (long long)B * Nsrc))
+        return gg_att_pairmax_args(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Z1, scale1, shift1, W2, b2, scale_p, shift_p,
+                                   scale_a, shift_a, (long long)B * O, agg, ld_agg, nullptr, nullptr,
+                                   (hipStream_t)stream);
     GGAttEval p;
     p.Z1 = Z1; p.s1 = scale1; p.h1 = shift1; p.W2 = W2; p.b2 = b2; p.sa = scale_a; p.ha = shift_a;
     p.Ysrc = Ysrc; p.nebidx = nebidx; p.att16 = att16; p.Wg = Wg; p.bp = b; p.sp = scale_p;

@@ -160,6 +160,8 @@ size_t gg_linear_dw_direct_workspace(long long E, int cin, int C);   // 0 = shap
 // gridgcn_attfwd.hip: the forward of the attention pair product / max without the second conv's pre-activation
 bool gg_att_fwd_ok(long long ncent, int O, int P, int cin, int C, int lda, long long rows);
 size_t gg_att_moments_workspace(long long E);
+void gg_set_att_eval_tile(int v);
+int gg_get_att_eval_tile();
 int gg_att_bn2_moments(const float *Z1, const float *s1, const float *h1, const float *W2, const float *b2,
                        const float *gamma, const float *beta, long long E, float eps, float momentum, float *scale,
                        float *shift, float *mean, float *rstd, float *run_mean, float *run_var, long long *nbt,

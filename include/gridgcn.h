@@ -78,7 +78,7 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  * 7: GRIDGCN_OPT_ATT_NZ_V2, GRIDGCN_OPT_BWD_FUSED128 (gridgcn_linear_bwd may take the one-pass
                                  *    kernel: dX / dW / sums in other summation orders); gridgcn_gemm_small_workspace_bytes is
                                  *    bounded (~16 MB) whatever the row count
-                                 * 8: gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd (+ _workspace_bytes) */
+                                 * 8: gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd (+ _workspace_bytes), GRIDGCN_OPT_ATT_EVAL_TILE */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -111,6 +111,10 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                         *     0 = the separate dX and dW kernels; 2 = only layers of 128 inputs (the
                                         *     256-input update conv takes two launches of it: worth 0.03 ms of a cfg4
                                         *     step, the 128-input fc1 0.1 ms).  Same terms, other summation orders. */
+#define GRIDGCN_OPT_ATT_EVAL_TILE 8     /* [1] gridgcn_att_max_eval at the up layers' shape (P = 5, 32 -> 128 and the limits of
+                                        *     gridgcn_att_pairmax_fwd): the tile kernel of the training forward without
+                                        *     its arg max and saved pre-activations (0.41 ms against 1.1 at cfg4 up2);
+                                        *     0 = the general kernel for every shape.  Same terms, last-bit differences. */
 int gridgcn_set_option(int option, int value);
 int gridgcn_get_option(int option);
 

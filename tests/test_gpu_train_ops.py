@@ -1137,6 +1137,50 @@ def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
         assert rel(a, b) <= 5e-2, (rel(a, b), a.shape)
 
 
+@pytest.mark.parametrize("B,Nsrc,O,geo", [(2, 150, 33, True), (3, 150, 700, False), (1, 5000, 4099, True)])
+def test_att_max_eval_tile_kernel_matches_the_general_kernel(B, Nsrc, O, geo):
+    """gridgcn_att_max_eval at the up layers' shape runs the tile kernel of the training forward without its arg max and
+    saved pre-activations (GRIDGCN_OPT_ATT_EVAL_TILE, csrc/gridgcn_attfwd.hip <false>); against the general evaluation
+    kernel (csrc/gridgcn_atteval.hip, option 0) on the same inputs: 2e-6 of the largest entry (the attention value in
+    another summation order, the BatchNorm maps as fused multiply-adds), and against float64 1e-5; an agg that is the
+    left half of a wider buffer, untouched elsewhere."""
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    d = _att_fwd_inputs(B, Nsrc, O, B * 77 + O, geo)
+    P, cin, C, ncent = d["P"], d["cin"], d["C"], d["ncent"]
+    sca, sha = d["gamma"], d["beta"]
+    lda = 256
+    outs = []
+    try:
+        for tile in (1, 0):
+            assert lib.gridgcn_set_option(_lib.OPT_ATT_EVAL_TILE, tile) == 0
+            assert lib.gridgcn_get_option(_lib.OPT_ATT_EVAL_TILE) == tile
+            wide = torch.full((ncent + 3, lda), 7.0, device=DEV)
+            rc = lib.gridgcn_att_max_eval(_ptr(d["Z1"]), _ptr(d["s1"]), _ptr(d["h1"]), _ptr(d["W2"]), _ptr(d["b2"]),
+                                          _ptr(sca), _ptr(sha), _ptr(d["Ysrc"]), _ptr(d["nebidx"]), _ptr(d["att16"]),
+                                          _ptr(d["Wg"]) if geo else None, _ptr(d["b"]), _ptr(d["scp"]), _ptr(d["shp"]),
+                                          B, Nsrc, O, P, C, _ptr(wide), lda, _stream(wide))
+            assert rc == 0
+            assert bool((wide[:, C:] == 7.0).all()) and bool((wide[ncent:] == 7.0).all())
+            outs.append(wide[:ncent, :C].clone())
+    finally:
+        lib.gridgcn_set_option(_lib.OPT_ATT_EVAL_TILE, 1)
+    a1 = torch.clamp_min(d["Z1"] * d["s1"] + d["h1"], 0)
+    z2 = a1.double() @ d["W2"].double().t() + d["b2"].double()
+    flat = (d["nebidx"].long() + (torch.arange(B, device=DEV) * Nsrc)[:, None, None]).clamp(0, B * Nsrc - 1)
+    zp = d["Ysrc"].double()[flat.reshape(-1)]
+    if geo:
+        zp = zp + d["att16"][:, 1:4].double() @ d["Wg"].double()
+    zp = zp + d["b"].double()
+    ref = (torch.clamp_min(zp * d["scp"].double() + d["shp"].double(), 0)
+           * torch.clamp_min(z2 * sca.double() + sha.double(), 0)).reshape(ncent, P, C).max(1).values
+    top = float(ref.abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * top
+    assert float((outs[0].double() - ref).abs().max()) <= 1e-5 * top
+    assert float((outs[1].double() - ref).abs().max()) <= 1e-5 * top
+
+
 def test_bf16_mode_takes_the_z2_free_attention_pair_where_it_applies(monkeypatch):
     """bf16 mode, up-layer shape (P = 5, attention 10 -> 32 -> 128): OPT.NOZ_IN_BF16 runs the second attention conv's
     forward and backward on the fp32 Z2-free kernels (csrc/gridgcn_attfwd.hip, gridgcn_attbwd_nz.hip) instead of the

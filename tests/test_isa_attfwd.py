@@ -44,7 +44,11 @@ def _loops(body):
 
 def test_att_pairmax_tile_loop():
     ks = isa.kernels("gridgcn_attfwd.hip")
-    body = ks["gg_k_att_pairmax"]
+    body = ks["gg_k_att_pairmax<true>"]
+    # (the evaluation form <false>: the same loop without arg max and saved pre-activations)
+    ev = _loops(ks["gg_k_att_pairmax<false>"])[0]
+    assert sum(1 for o in ev if o.startswith("v_mfma_f32_32x32x2")) == 64 and len(ev) <= 900, len(ev)
+    assert not any(o.startswith(("scratch_", "v_accvgpr", "buffer_store_byte")) for o in ev)
     ops = _ops(body)
     assert not any(o.startswith("scratch_") for o in ops)
     assert not any(o.startswith("v_accvgpr") for o in ops)
