@@ -318,13 +318,6 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
 // Needs 32-bit byte offsets: E < 2^24 rows, E / P < 2^22 centres (gg_att_nz2_ok); otherwise the first form runs.
 __device__ gg_i32x4 gg_buf_ld4i(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
-__device__ __forceinline__ gg_rsrc gg_make_rsrc_n(const void *uniform_base, unsigned bytes)
-{
-    gg_rsrc r = gg_make_rsrc(uniform_base);
-    r.z = (int)bytes;                    // raw buffer, stride 0: num_records in bytes; beyond it loads return 0
-    return r;
-}
-
 __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
 {
     constexpr int C = GG_NZ_C, NJ = 4;

@@ -52,14 +52,6 @@ struct GGAttFwd {
 };
 
 __device__ void gg_buf_st_u8(unsigned char v, gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.store.i8");
-// raw buffer of `bytes` bytes: stores past the end are dropped (the partial last tile needs no predicate)
-__device__ __forceinline__ gg_rsrc gg_make_rsrc_bytes(const void *uniform_base, unsigned bytes)
-{
-    gg_rsrc r = gg_make_rsrc(uniform_base);
-    r.z = (int)bytes;
-    return r;
-}
-
 // One wave per tile, all four 32-channel column tiles (the activation of the tile's rows, the edge records and the
 // row indices are paid once per tile, not once per column tile); two waves per SIMD: 256 registers a lane, and
 // (amdgpu_waves_per_eu) the accumulators stay in ordinary VGPRs -- with the default bound the compiler keeps MFMA
@@ -115,10 +107,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rows = p.B * p.Nsrc;
     const gg_rsrc ry = gg_make_rsrc(p.Ysrc);
     const gg_rsrc rz1 = gg_make_rsrc(p.Z1), ratt = gg_make_rsrc(p.att16), rnb = gg_make_rsrc(p.nebidx);
-    const gg_rsrc ragg = gg_make_rsrc_bytes(p.agg, ncent * (unsigned)p.lda * 4u);
-    const gg_rsrc rzp = gg_make_rsrc_bytes(p.zsel, ncent * 512u);
-    const gg_rsrc rza = gg_make_rsrc_bytes(p.zsel + p.ncent * 128, ncent * 512u);
-    const gg_rsrc ram = gg_make_rsrc_bytes(p.amax, ncent * 128u);
+    const gg_rsrc ragg = gg_make_rsrc_n(p.agg, ncent * (unsigned)p.lda * 4u);
+    const gg_rsrc rzp = gg_make_rsrc_n(p.zsel, ncent * 512u);
+    const gg_rsrc rza = gg_make_rsrc_n(p.zsel + p.ncent * 128, ncent * 512u);
+    const gg_rsrc ram = gg_make_rsrc_n(p.amax, ncent * 128u);
     // the A row of this lane: slot s_i of lane half h_i
     const int si = (j & 3) + 4 * (j >> 3), hi = (j >> 2) & 1;
     const unsigned arow = hi * 15 + (si < 15 ? si : 14);

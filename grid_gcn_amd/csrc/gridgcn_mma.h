@@ -133,6 +133,15 @@ __device__ __forceinline__ gg_rsrc gg_make_rsrc(const void *uniform_base)
     return r;
 }
 
+// the same with a range check: raw buffer, stride 0, num_records in bytes -- loads beyond it return 0, stores beyond it
+// are dropped (the partial last tile of a loop needs no predicate)
+__device__ __forceinline__ gg_rsrc gg_make_rsrc_n(const void *uniform_base, unsigned bytes)
+{
+    gg_rsrc r = gg_make_rsrc(uniform_base);
+    r.z = (int)bytes;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // Operand formulas of the training kernels, written for instruction count (every VALU instruction
 // costs the SIMD ~5 cycles of MFMA time): explicit FMAs on float4 values, which the compiler issues
