@@ -187,7 +187,9 @@ __device__ __forceinline__ void gg_final(const float *Aw, const float *Tw, const
 }
 
 // blockDim = 64 * WPC (WPC = waves per centre = ceil(P/32) when P > 32, else 1)
-__global__ __launch_bounds__(256) void gg_k_gridconv(GGConvParams p)
+// (amdgpu_waves_per_eu(2): 256 registers a lane -- and the MFMA accumulators in ordinary VGPRs; with the default bound the
+//  compiler kept them in AGPRs: 1344 v_accvgpr copies in the loop, found at the end of round 5)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gg_k_gridconv(GGConvParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;

@@ -148,7 +148,9 @@ __device__ __forceinline__ float4 gg_bnrelu4(float4 a, const float4 sc, const fl
 #define GG_FWD4_THREADS 512    // fp32 forward at four column tiles: 8 waves = two per SIMD (768 = three per SIMD at 168 registers: 25 spilled, 372 -> 418 us at 256 -> 128)
 #endif
 template <int NT, bool WLDS, bool EXACT, bool BF16 = false, bool CS = false, bool DROP = false>
-__global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT == 8 ? 512 : (NT == 4 ? GG_FWD4_THREADS : (NT == 2 ? 768 : 1024))))) void gg_k_linear_fwd_direct(GGLinFwd p)
+// (amdgpu_waves_per_eu(2): for the 256-thread column-split form -- at one wave per SIMD the compiler keeps MFMA results in
+//  AGPRs and copies every value the epilogue touches; the larger workgroups are bound to <= 256 registers anyway)
+__global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 : 1024)) : (NT == 8 ? 512 : (NT == 4 ? GG_FWD4_THREADS : (NT == 2 ? 768 : 1024))))) __attribute__((amdgpu_waves_per_eu(2))) void gg_k_linear_fwd_direct(GGLinFwd p)
 {
     static_assert(!DROP || (NT == 1 && !BF16 && !CS), "Dropout prologue: one column tile, fp32");
     unsigned drop_lo = p.drop_lo, drop_hi = p.drop_hi;
@@ -605,7 +607,7 @@ int gg_linear_fwd_direct(const GGLinFwd &p, hipStream_t st)
 // CS (column split, few row tiles): as in the forward kernel -- gridDim.y column groups of NT tiles, each
 // forming dZ itself; p.dx_wstride = vector width of the packed operand (1/2/4/8).
 template <int NT, bool BF16 = false, bool CS = false>
-__global__ __launch_bounds__(CS ? 256 : 512) void gg_k_linear_dx_direct(GGLinBwd p)
+__global__ __launch_bounds__(CS ? 256 : 512) __attribute__((amdgpu_waves_per_eu(2))) void gg_k_linear_dx_direct(GGLinBwd p)
 {
     constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
     extern __shared__ __attribute__((aligned(16))) float lds[];

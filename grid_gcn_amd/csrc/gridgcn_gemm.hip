@@ -31,7 +31,7 @@ struct GGGemm {
 
 // mode 0: C[m][n] = sum_k A[m][k] B[n][k]      mode 1: C[m][n] = sum_k A[m][k] B[k][n]
 template <int MODE>
-__global__ __launch_bounds__(256) void gg_k_gemm_rows(GGGemm p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gg_k_gemm_rows(GGGemm p)
 {
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int ntn = (p.N + 31) >> 5;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gg_k_gemm_rows(GGGemm p)
                             // a [512 x 320] product over 10^6 rows would otherwise ask for 2.6 GB of workspace
 
 // C[m][n] = sum_k A[k][m] B[k][n]
-__global__ __launch_bounds__(256) void gg_k_gemm_tn(GGGemm p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gg_k_gemm_tn(GGGemm p)
 {
     __shared__ float red[3][16 * 64];
     __shared__ int s_last;
