@@ -145,8 +145,9 @@ def rccl_capture_probe(world, rank, local, dev):
 def make_opt(net, eager):
     """Adam(lr 1e-3, wd 1e-5): the one-launch kernel of grid_gcn_amd.optim (torch.optim.Adam's update to
     within rounding; tests/test_gpu_glue.py), or -- --switch OWN_ADAM=0 -- the framework's multi-tensor one"""
-    from grid_gcn_amd import optim, train_ops
-    if train_ops.OPT.OWN_ADAM:
+    from grid_gcn_amd import optim
+    from grid_gcn_amd.train.options import OPT
+    if OPT.OWN_ADAM:
         return optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)
     return torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=not eager)
 
@@ -279,20 +280,21 @@ def param_sync_spread(net, world, dev):
 
 def in_step_ms(net, loss_fn, inputs, target, keys, steps=4):
     """Device time of selected library calls inside EAGER training steps (forward + loss + backward; the
-    kernels behind their real predecessors, real tensors, cold L2): train_ops.LaunchTimers.  The first step
+    kernels behind their real predecessors, real tensors, cold L2): tcommon.LaunchTimers.  The first step
     is dropped."""
-    from grid_gcn_amd import train_ops
-    train_ops.OPT.TIMERS = train_ops.LaunchTimers(keys)
+    from grid_gcn_amd.train import common as tcommon
+    from grid_gcn_amd.train.options import OPT
+    OPT.TIMERS = tcommon.LaunchTimers(keys)
     try:
         for _ in range(steps):
             for prm in net.parameters():
                 prm.grad = None
             loss_fn(net(*inputs), target).backward()
         torch.cuda.synchronize()
-        per_step = {k: len(v) // steps for k, v in train_ops.OPT.TIMERS.ev.items()}
-        return {k: train_ops.OPT.TIMERS.median(k, skip=per_step[k]) for k in keys}, per_step
+        per_step = {k: len(v) // steps for k, v in OPT.TIMERS.ev.items()}
+        return {k: OPT.TIMERS.median(k, skip=per_step[k]) for k in keys}, per_step
     finally:
-        train_ops.OPT.TIMERS = None
+        OPT.TIMERS = None
 
 
 def cagq_roofline(d4, n, kw, B, N, traffic, key, iters=100):
@@ -331,7 +333,7 @@ def main():
                          "(parity path, the headline), bf16 = bf16 MFMA operands with fp32 storage, "
                          "accumulation and statistics (BASELINE configs[2] 'bf16 MLP / fp32 indices')")
     ap.add_argument("--switch", action="append", default=[],
-                    help="NAME=0|1: a path switch of grid_gcn_amd.train_ops (e.g. NOZ_ATT_BWD=0) or a "
+                    help="NAME=0|1: a path switch of grid_gcn_amd.train.options.OPT (e.g. NOZ_ATT_BWD=0) or a "
                          "gridgcn_set_option name (COL_SPLIT, INDEX_SMALL, ATT_BWD_FUSED) for A/B measurements; "
                          "the defaults are what is shipped and reported")
     a = ap.parse_args()
@@ -349,15 +351,16 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     traffic = load_traffic()
-    from grid_gcn_amd import train_ops as _tops
-    _tops.set_mlp_precision("bf16" if a.dtype == "bf16" else "fp32")
+    from grid_gcn_amd.train import common as tcommon, evalpath as teval, timers as ttimers
+    from grid_gcn_amd.train.options import OPT
+    tcommon.set_mlp_precision("bf16" if a.dtype == "bf16" else "fp32")
     for sw in a.switch:
         name, val = sw.split("=")
         from grid_gcn_amd import _lib as _glib
         if hasattr(_glib, "OPT_" + name):       # a kernel-selection option of the library (gridgcn_set_option)
             _glib.check(_glib.load().gridgcn_set_option(getattr(_glib, "OPT_" + name), int(val)), "set_option")
             continue
-        _tops.OPT.set(name, val)               # (KeyError on an unknown name)
+        OPT.set(name, val)               # (KeyError on an unknown name)
 
     if a.config != "cfg4":
         import bench_configs
@@ -441,8 +444,15 @@ def main():
         out["roofline_step"]["traffic"] = traffic.get(skey)
         out["roofline_step"]["mfma_busy"] = traffic.get(skey + "_mfma_busy")
         out["roofline_step"]["traffic_key"] = skey
+        # the step's three roofs in one place: `frac` = algorithmic flops of the REFERENCE's graph
+        # / time / matrix peak (a speed figure, not a utilisation), `mfma_busy` = the counter, `hbm_frac` = looked-up
+        # PMC bytes of one step / THIS run's ms_per_step / 8 TB/s
+        if traffic.get(skey):
+            out["roofline_step"]["hbm_frac"] = traffic[skey] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline_step"]["hbm_frac_note"] = ("traffic is a look-up in profiles/traffic.json (PMC pass of "
+                                                     "another session), the time is this run's")
     if rank == 0 and world == 1 and not a.no_micro:
-        from grid_gcn_amd.train_ops import median_ms
+        from grid_gcn_amd.train.timers import median_ms
         # ---- ms per CAGQ layer: Gridify of down layer 0 on the same batch ----
         kw = synth.gridify_kwargs(cfg["grid"], 0)
         d4 = torch.from_numpy(data).to(dev)
@@ -469,10 +479,11 @@ def main():
             ms_k = median_ms(call, mi, 5, dev)
             # the path evaluation actually takes for this layer (one point conv: source-side)
             ms_src = None
-            from grid_gcn_amd import train_ops as _to
+            from grid_gcn_amd.train import common as tcommon, evalpath as teval, timers as ttimers
+            from grid_gcn_amd.train.options import OPT
             attl, ptl = [layer.att1[0], layer.att2[0]], list(layer.pt_mlp)
-            if _to.edge_block_src_eval_supported(ptl, attl, src_, layer.has_feats):
-                call2 = lambda: _to.edge_block_src_eval(src_, idx_, cent_.contiguous(), ptl[0],  # noqa: E731
+            if teval.edge_block_src_eval_supported(ptl, attl, src_, layer.has_feats):
+                call2 = lambda: teval.edge_block_src_eval(src_, idx_, cent_.contiguous(), ptl[0],  # noqa: E731
                                                         attl, layer.localfdim)
                 ms_src = median_ms(call2, mi, 5, dev)
         macs = sum(l.lin.in_features * l.lin.out_features
@@ -503,27 +514,28 @@ def main():
         #      single launch of the step.  Its algorithmic traffic (Z1 in, dA1 out, the [ncent, C] sparse
         #      gradient) is 1.3 GB -- 0.2 ms at HBM peak -- so the roof that binds it is the fp32 MFMA pipe,
         #      which its VALU work shares. ----
-        from grid_gcn_amd import train_ops
+        from grid_gcn_amd.train import common as tcommon, evalpath as teval, timers as ttimers
+        from grid_gcn_amd.train.options import OPT
         cin_b = layer.att2[0].lin.in_features
         c_b = layer.att2[0].lin.out_features
         ncent_b, p_b = idx_.shape[0] * idx_.shape[1], idx_.shape[2]
         e_b = float(ncent_b * p_b)
         # (bf16 mode takes the same fp32 pair of Z2-free kernels for this layer: OPT.NOZ_IN_BF16)
-        noz = (train_ops.OPT.NOZ_ATT_BWD and cin_b == 32 and c_b == 128 and p_b == 5
-               and (a.dtype == "f32" or (train_ops.OPT.NOZ_IN_BF16 and train_ops.OPT.NOZ_ATT_FWD)))
+        noz = (OPT.NOZ_ATT_BWD and cin_b == 32 and c_b == 128 and p_b == 5
+               and (a.dtype == "f32" or (OPT.NOZ_IN_BF16 and OPT.NOZ_ATT_FWD)))
         if noz:
-            ms_b = train_ops.time_att_bwd_noz(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev)
+            ms_b = ttimers.time_att_bwd_noz(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev)
             # read Z1 [E,cin], the sparse upstream gradient (one-byte amax + fp32 value) [ncent,C]; write dA1
             bytes_b = 4.0 * e_b * 2 * cin_b + 5.0 * ncent_b * c_b
         else:
-            ms_b = train_ops.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev,
+            ms_b = ttimers.time_linear_bwd(ncent_b, p_b, cin_b, c_b, iters=mi, device=dev,
                                              ndx=cin_b, prev_bn=True)
             # read Z [E,C] once, the sparse upstream gradient [ncent,C], the previous layer's raw output
             # [E,cin]; write dX [E,cin].  The micro-benchmark reads an fp32 Z; inside a bf16-mode step this
             # tensor is STORED as bf16 (OPT.Z16_STORAGE): the in-step figure counts it at that width (VERDICT r4:
             # counted at 4 bytes the line claimed 6.9 TB/s, above what the part delivers)
             bytes_b = 4.0 * e_b * (c_b + 2 * cin_b) + 5.0 * ncent_b * c_b
-            z16 = a.dtype == "bf16" and train_ops.OPT.Z16_STORAGE and c_b in (64, 128)
+            z16 = a.dtype == "bf16" and OPT.Z16_STORAGE and c_b in (64, 128)
             bytes_b_step = bytes_b - (2.0 * e_b * c_b if z16 else 0.0)
         flops_b = 4.0 * e_b * cin_b * c_b            # dX + dW products
         # ... and the same calls timed INSIDE eager training steps (their real predecessors and tensors):
@@ -575,7 +587,7 @@ def main():
                                "dtype": "f32 (v_mfma_f32_32x32x2_f32)" if a.dtype == "f32" else "bf16 MFMA operands"}
         # the largest MFMA-bound kernel of the step: forward of the 256->128 update conv over
         # all B*N points (previous BatchNorm+ReLU applied while loading, statistics epilogue)
-        ms_f = train_ops.time_linear_fwd(e_f, cin_f, c_f, iters=mi, device=dev)
+        ms_f = ttimers.time_linear_fwd(e_f, cin_f, c_f, iters=mi, device=dev)
         ms_f_step = instep[kf_] or ms_f
         tf_f = 2.0 * e_f * cin_f * c_f / (ms_f_step * 1e-3) / 1e12
         # (bf16 mode: this layer sits behind a BatchNorm + ReLU and runs on v_mfma_f32_32x32x16_bf16 -- priced against
@@ -604,8 +616,9 @@ def main():
             ms_gb = median_ms(tb, mi, 5, dev)
         alg_g = 4.0 * gsrc.numel() + 4.0 * idx_.numel() + 4.0 * idx_.numel() * gsrc.shape[2]
         out["roofline_gather"] = {
-            "bound": "hbm", "kernel": "gridgcn_batch_take (batch_take_g of GridConv %s: src %s, "
-            "index %s)" % (name, list(gsrc.shape), list(idx_.shape)),
+            "bound": "hbm", "kernel": "gridgcn_batch_take -- OPERATOR-BOUNDARY MICRO-BENCHMARK, not launched by the "
+            "timed step (the step's edge kernels gather inside themselves): the reference's batch_take_g of GridConv "
+            "%s, src %s, index %s" % (name, list(gsrc.shape), list(idx_.shape)),
             "achieved": alg_g / (ms_g * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_g / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic.get("batch_take_%s_E%d" % (name, idx_.numel())),

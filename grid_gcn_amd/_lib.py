@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GG_HIP_LIB: profiling variant of the same library (lib/libgridgcn_hip_prof.so, tools/prof_phases.py)
 LIB_PATH = os.environ.get("GG_HIP_LIB") or os.path.join(_HERE, "lib", "libgridgcn_hip.so")
 
-ABI_VERSION = 8                 # include/gridgcn.h: gridgcn_abi_version()
+ABI_VERSION = 9                 # include/gridgcn.h: gridgcn_abi_version()
 OPT_ATT_BWD_FUSED = 0           # GRIDGCN_OPT_ATT_BWD_FUSED
 OPT_INDEX_SLAB_SHIFT = 1        # GRIDGCN_OPT_INDEX_SLAB_SHIFT
 OPT_INDEX_CHUNK = 2             # GRIDGCN_OPT_INDEX_CHUNK
@@ -45,6 +45,7 @@ EXPORTS = [
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd", "gridgcn_pairmax_bwd_masked",
     "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz", "gridgcn_gemm_bias",
     "gridgcn_att_fwd_noz_workspace_bytes", "gridgcn_att_bn2_moments", "gridgcn_att_pairmax_fwd",
+    "gridgcn_att_pairmax_fwd_supported",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
@@ -219,6 +220,8 @@ def load():
     lib.gridgcn_att_bn2_moments.restype = ci
     lib.gridgcn_att_bn2_moments.argtypes = ([vp] * 7 + [ll, ci, ci, ctypes.c_float, ctypes.c_float] + [vp] * 8
                                             + [vp, cs, vp])
+    lib.gridgcn_att_pairmax_fwd_supported.restype = ci
+    lib.gridgcn_att_pairmax_fwd_supported.argtypes = [ll, ci, ci, ci, ci, ci, ll]
     lib.gridgcn_att_pairmax_fwd.restype = ci
     lib.gridgcn_att_pairmax_fwd.argtypes = [vp] * 5 + [ci, ci, ci] + [vp] * 9 + [ll, ci, ci, ci, vp, ci, vp, vp, vp]
     lib.gridgcn_att_bwd_noz.restype = ci

@@ -12,6 +12,7 @@
 //      C/D row order, i.e. exactly the 16 values per lane the dX epilogue needs anyway.
 // Z is read once, Aprev once; algorithmic bytes per edge 4(C + 2*32) instead of 4(2C + 3*32).
 #include "gridgcn_mma.h"
+#include "gridgcn_once.h"
 #include "gridgcn_train.h"
 
 // LDS operand layouts (round 4): every MFMA run reads its B operands with four ds_read_b128 IN FRONT of the run.
@@ -418,7 +419,7 @@ size_t gg_att_bwd_fused_workspace(long long E, int cin, int C)
 template <int NJ>
 static int launch_att_fused(const GGLinBwd &p, hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_att_bwd_fused<NJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
         if (hipFuncSetAttribute((const void *)gg_k_att_bwd_fused<NJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;

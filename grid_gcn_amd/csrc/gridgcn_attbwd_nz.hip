@@ -21,6 +21,7 @@
 //   gg_k_att_nz_reduce     partial dW^T / S2 tiles of the workgroups -> dW (sparse part), S2
 //   gg_k_att_nz_finish     dW += dense part; dgamma, dbeta, m1, m2 of this layer from its sums
 #include "gridgcn_mma.h"
+#include "gridgcn_once.h"
 #include "gridgcn_train.h"
 
 #define GG_NZ_TS 36    // LDS stride (floats) of one CHANNEL of a wave's transposed dZ half tile: 32 rows + 4
@@ -631,7 +632,7 @@ int gg_att_bwd_noz(const float *Z1, const float *ps, const float *psh, const flo
                    double *s1, void *ws, hipStream_t st)
 {
     if (E < 32 || P < 1 || (E % P)) return 1;
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
         if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;

@@ -31,6 +31,7 @@
 // largest entry; both against float64).  128 input columns per launch ([dx_col0, +128) of a layer with cin = 128 or
 // 256: the 256-wide update conv takes two launches, forming dZ twice); E % 128 == 0, dense dY, fp32.
 #include "gridgcn_mma.h"
+#include "gridgcn_once.h"
 #include "gridgcn_train.h"
 
 #define GG_BF_TS 36          // LDS stride (floats) of one channel's 32 rows of a dZ tile: 32 + 4
@@ -373,7 +374,7 @@ size_t gg_linear_bwd_fused128_workspace(long long E)
 int gg_linear_bwd_fused128(const GGLinBwd &pin, hipStream_t st)
 {
     if (!gg_linear_bwd_fused128_ok(pin)) return 1;
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     const size_t lds = (size_t)(64 * 64 * 4 + 5 * GG_BF_C + 4 * 128 + 4 * GG_BF_C * GG_BF_TS + 4) * sizeof(float);
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_linear_bwd_fused128, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -133,7 +133,7 @@ const char *gridgcn_strerror(int code)
     }
 }
 
-int gridgcn_abi_version(void) { return 8; }
+int gridgcn_abi_version(void) { return 9; }
 
 int gridgcn_set_option(int option, int value)
 {
@@ -712,6 +712,11 @@ int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *byt
     if (!bytes || E < 1 || E >= (1ll << 25) || cin != 32 || C != 128) return GRIDGCN_EINVAL;
     *bytes = gg_att_moments_workspace(E);
     return GRIDGCN_OK;
+}
+
+int gridgcn_att_pairmax_fwd_supported(long long ncent, int O, int P, int cin, int C, int ld_agg, long long rows)
+{
+    return gg_att_fwd_ok(ncent, O, P, cin, C, ld_agg, rows) ? 1 : 0;
 }
 
 int gridgcn_att_bn2_moments(const float *Z1, const float *scale1, const float *shift1, const float *W2,

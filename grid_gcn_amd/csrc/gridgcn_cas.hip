@@ -26,6 +26,7 @@
 // that no earlier unresolved challenger can still affect go to the 16 waves together (see "phase B"
 // below).  Same verdicts as the one-by-one walk (tests/test_cas.py, bit for bit), 7x its speed.
 #include "gridgcn_index.h"
+#include "gridgcn_once.h"
 
 #define GG_CAS_NT 1024
 
@@ -513,7 +514,7 @@ int gg_cas_refine(const float *data, const int *np, int B, int N, const GGGrid &
                   int *slotfirst1, const int *centnum, const int2 *vtab, const int *sorted, char *ws,
                   hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_cas_refine<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void *)gg_k_cas_refine<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)

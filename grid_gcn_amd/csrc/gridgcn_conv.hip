@@ -21,6 +21,7 @@
 //     (C/D layout: lane = column, regs = rows) -- only [B,O,C] leaves the CU.
 // Waves never synchronise with each other unless a centre spans several waves (P > 32).
 #include "gridgcn_dev.h"
+#include "gridgcn_once.h"
 #include "gridgcn_conv.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 int gg_gridconv_forward(const GGConvParams &p, hipStream_t st)
 {
     const long long ncent = (long long)p.B * p.O;
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_gridconv,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,

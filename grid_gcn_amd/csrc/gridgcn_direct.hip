@@ -14,6 +14,7 @@
 // and stores -- the LDS-staged kernels of gridgcn_train.hip ran one wave per SIMD with the three
 // phases serialised (measured), at 25-40 TFLOP/s.
 #include "gridgcn_mma.h"
+#include "gridgcn_once.h"
 #include "gridgcn_train.h"
 
 template <int NT> struct GGBVec { float v[NT]; };
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(CS ? 256 : (BF16 ? (NT == 8 ? 512 : (NT == 4 ? 768 
 template <int NTS>
 static int launch_fwd_direct_cs(const GGLinFwd &q, hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NTS, true, false, false, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -507,7 +508,7 @@ static int launch_fwd_direct_cs(const GGLinFwd &q, hipStream_t st)
 template <int NT>
 static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         const void *fs[4] = {(const void *)gg_k_linear_fwd_direct<NT, true, true>,
                              (const void *)gg_k_linear_fwd_direct<NT, true, false>,
@@ -535,7 +536,7 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
         // Dropout prologue: the class-score conv (one column tile, fp32, K a multiple of 32, weights in LDS)
         if constexpr (NT == 1) {
             if (g_mlp_bf16 || (q.K & 31) || wbytes + sbytes > 156 * 1024 || !q.scale || q.X2 || q.zfmt) return 1;
-            static bool attr_d = false;
+            static GGDevOnce attr_d;
             if (!attr_d) {
                 if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<1, true, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                     hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<1, true, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -554,7 +555,7 @@ static int launch_fwd_direct(const GGLinFwd &q, hipStream_t st)
     // bf16 only behind a BatchNorm+ReLU (q.scale): the FIRST conv of a stack sees raw coordinates /
     // geometric features (|mean| / sigma ~ 30 for the attention inputs), which 8 mantissa bits destroy
     if (g_mlp_bf16 && q.scale && w16 + sbytes <= 156 * 1024) {
-        static bool attr16 = false;
+        static GGDevOnce attr16;
         if (!attr16) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute((const void *)gg_k_linear_fwd_direct<NT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -974,7 +975,7 @@ template <int NT>
 static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
 {
     constexpr int NTV = NT <= 1 ? 1 : (NT <= 2 ? 2 : (NT <= 4 ? 4 : 8));
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -995,7 +996,7 @@ static int launch_dx_direct(const GGLinBwd &p, hipStream_t st)
     // few row tiles, several column tiles: the column tiles go to separate workgroups (a row tile is one
     // serial chain of NT * C / 2 MFMAs per wave)
     if (NT >= 2 && ntile <= GG_CS_TILES && !bf16 && p.dx_wstride == 1 && p.dx_col0 == 0 && g_opt_col_split) {
-        static bool cs_attr = false;
+        static GGDevOnce cs_attr;
         if (!cs_attr) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute((const void *)gg_k_linear_dx_direct<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -1637,7 +1638,7 @@ static int launch_dw_direct(const GGLinBwd &p, const GGDwCfg &c, hipStream_t st)
     const bool bf = g_mlp_bf16 && p.pscale;   // the B operand is the layer's INPUT: bf16 only behind a BatchNorm+ReLU
     const size_t ldsb = c.lds_red ? (size_t)c.MG * MT * (4 * NQ + 2 * NP + NS) * 4096 : 0;
     if (ldsb > 64 * 1024) {
-        static bool attr_done[4] = {false, false, false, false};
+        static GGDevOnce attr_done[4];
         const int vi = (bf ? 2 : 0) + (sp ? 1 : 0);
         if (!attr_done[vi]) {
             const void *f = bf ? (sp ? (const void *)gg_k_linear_dw_direct<MT, NQ, NP, NS, true, true>

@@ -16,6 +16,7 @@
 // The two small GEMMs on [B*Nsrc] rows (Ysrc; dfeat = dYsrc * Wf, dWf = dYsrc^T * feat) run on the
 // ordinary linear kernels.  Same fp32 math as the conv on the gathered tensor up to summation order.
 #include "gridgcn_csr.h"
+#include "gridgcn_once.h"
 #include "gridgcn_edgelin.h"
 #include "gridgcn_fixpt.h"
 
@@ -542,7 +543,7 @@ int gg_edge_geo_fwd(const float *Ysrc, const float *src, const int *nebidx, cons
 {
     const size_t lds = (size_t)(N + 1) * 28;
     if (lds > 150 * 1024 || C < 1 || C > 1024 || (long long)B * O * P >= (1ll << 31)) return 1;
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_edge_geo_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) return 3;
         attr_done = true;
@@ -910,7 +911,7 @@ int gg_edge_lin0_bwd_sparse(const int *nebidx, const float *att16, const unsigne
     size_t lds = (size_t)(N + 1) * 16 * 8;          // acc[(N+1)][16] int64 (the geo sums alias its start)
     if (lds > 150 * 1024 || C < 1 || (C & 3) || (long long)B * O * P >= (1ll << 31)) return 1;
     if (lds < 3 * 64 * 16 * 4) lds = 3 * 64 * 16 * 4;
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         // (the kernel also has 1 KB of static LDS: dynamic + static must stay within 160 KB)
         if (hipFuncSetAttribute((const void *)gg_k_edge_lin0_bwd_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) return 3;

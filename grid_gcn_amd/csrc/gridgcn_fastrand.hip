@@ -15,6 +15,7 @@
 // of its id in the other runs (runs staged in LDS when they fit) -- and plays the reservoir with
 // an LDS atomicMax on the rank.
 #include "gridgcn_index.h"
+#include "gridgcn_once.h"
 
 #define GG_FR_NT 1024
 #define GG_FR_QW 4          // waves per workgroup of the query
@@ -247,7 +248,7 @@ int gg_fastrand_query(const float *data, const int *np, int B, int N, const GGGr
                       const GGIndexWs &w, char *scratch, int *nebidx, float *nebmsk, float *cent,
                       float *centmsk, int *centnum, hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_query_fastrand, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
             return 3;

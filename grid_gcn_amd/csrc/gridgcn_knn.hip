@@ -7,6 +7,7 @@
 // top-k kept in registers with a branch-free stable insertion.
 // Arithmetic is pinned: d = ((dx*dx + dy*dy) + dz*dz), fp32, no FMA.
 #include "gridgcn_dev.h"
+#include "gridgcn_once.h"
 #include <float.h>
 
 #define GG_KNN_TILE 1024
@@ -223,7 +224,7 @@ int gg_batch_take_backward(const float *gout, const int *index, int B, int N, in
     while (cs < 128 && cs < C) cs <<= 1;
     while (cs > 1 && (size_t)(N + 1) * cs * 4 > 144 * 1024) cs >>= 1;
     if (cs >= 8 && (size_t)(N + 1) * cs * 4 <= 144 * 1024 && (long long)M >= 4LL * N) {
-        static bool attr_done = false;
+        static GGDevOnce attr_done;
         if (!attr_done) {
             if (hipFuncSetAttribute((const void *)gg_k_take_bwd_lds,
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

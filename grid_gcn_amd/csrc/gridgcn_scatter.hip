@@ -19,6 +19,7 @@
 // The order of the edges inside a run depends on the LDS atomics of the sort: sums are reproducible
 // to fp32 round-off, not bit for bit (as the framework's own scatter-add backward).
 #include "gridgcn_csr.h"
+#include "gridgcn_once.h"
 
 __device__ __forceinline__ int gg_csr_key(int idx, int b, int N, long long rows)
 {
@@ -235,7 +236,7 @@ int gg_csr_build(const int *index, int B, int N, int M, void *workspace, int **p
     int *keys = perm + (size_t)B * M;
     int *rowptr = keys + (size_t)B * M;
     int *hist = rowptr + (size_t)B * (N + 3);
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_csr_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         if (hipFuncSetAttribute((const void *)gg_k_csr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;

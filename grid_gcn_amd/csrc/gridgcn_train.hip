@@ -19,6 +19,7 @@
 // and then walks row tiles, so the B operand never waits on L2 (with 4-byte-per-lane global B
 // loads the backward GEMM was latency bound: 10.7 ms for the 3.3 M-edge layer of cfg4).
 #include "gridgcn_mma.h"
+#include "gridgcn_once.h"
 #include "gridgcn_train.h"
 
 // kernel-selection option (include/gridgcn.h: gridgcn_set_option): the one-pass backward of the
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void gg_k_linear_fwd(GGLinFwd p)
 template <int NT, int NV>
 static int launch_fwd_nv(const GGLinFwd &q, hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_linear_fwd<NT, true, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         if (hipFuncSetAttribute((const void *)gg_k_linear_fwd<NT, false, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -933,7 +934,7 @@ int gg_linear_bwd_workspace(long long E, int cin, int C, size_t *bytes, int *nwg
 template <int PAIRS>
 static int launch_bwd(const GGLinBwd &p, bool wlds, size_t lds, int nwg, hipStream_t st)
 {
-    static bool attr_done = false;
+    static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_linear_bwd<PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
         if (hipFuncSetAttribute((const void *)gg_k_linear_bwd<PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
@@ -985,7 +986,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
     // ---- split mode: dX by the light one-wave-per-tile kernel, then dW by the kernel below ----
     if (p.dX && p.Wg && p.C >= 4 && (p.C & (p.C - 1)) == 0) {
         if (finalize_now()) return 3;
-        static bool attr_dx = false;
+        static GGDevOnce attr_dx;
         if (!attr_dx) {
             if (hipFuncSetAttribute((const void *)gg_k_linear_dx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 3;
             attr_dx = true;
@@ -1075,7 +1076,7 @@ int gg_linear_bwd(const GGLinBwd &pin, hipStream_t st)
             if (nw2 > nwg) nw2 = nwg;             // workspace was sized for nwg partials
 #define GG_DW(PP)                                                                               \
     do {                                                                                        \
-        static bool done_##PP = false;                                                          \
+        static GGDevOnce done_##PP;                                                                  \
         if (!done_##PP) {                                                                       \
             if (hipFuncSetAttribute((const void *)gg_k_linear_dw<PP>,                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize,                 \

@@ -27,7 +27,7 @@ import os
 
 import torch
 
-from . import train_ops
+from .train import common as tcommon
 
 _GOLDEN = 0x9E3779B97F4A7C15 - (1 << 64)   # as a signed int64 increment
 
@@ -81,7 +81,7 @@ class GraphedTrainStep:
 
         self.g1 = torch.cuda.CUDAGraph()
         # scratch carved out of a shared zero chunk must not cross a capture boundary
-        train_ops.reset_zero_arena()
+        tcommon.reset_zero_arena()
         # capture_error_mode "thread_local": the RCCL watchdog thread polls its events with
         # hipEventQuery while this thread captures; under the default "global" mode such a call from
         # ANY thread invalidates the capture ("operation not permitted when stream is capturing": seen
@@ -96,7 +96,7 @@ class GraphedTrainStep:
                 assert all(g is not None for g in self.static_grads)
                 self._allreduce()                  # p.grad become views of the flat bucket
             opt.step()
-        train_ops.reset_zero_arena()
+        tcommon.reset_zero_arena()
         torch.cuda.synchronize(dev)
 
     def _sync_eager(self):
@@ -127,5 +127,5 @@ class GraphedTrainStep:
         # Tensor._version (folded evaluation constants, gridconv.SubGUpdate.packed_layers) must see it
         with torch.no_grad():
             torch.autograd.graph.increment_version(self._state)
-        train_ops.params_changed()
+        tcommon.params_changed()
         return self.loss

@@ -66,7 +66,7 @@ def _warn_stock_fallback(layers, x):
     """The MFMA training kernels take stacks of <= 256 output / <= 384 input channels (fp32,
     contiguous rows); wider conv+BN+ReLU stacks run on 256-column slices of those kernels or on
     csrc/gridgcn_gemm.hip + this library's BatchNorm kernels
-    (train_ops.mlp_wide_train); anything else (no BatchNorm, no ReLU, other dtypes) on the stock
+    (tmlp.mlp_wide_train); anything else (no BatchNorm, no ReLU, other dtypes) on the stock
     PyTorch modules -- several times slower.  Say so once per shape instead of silently."""
     key = (tuple((l.lin.in_features, l.lin.out_features) for l in layers), str(x.dtype))
     if key not in _warned_shapes:
@@ -79,19 +79,19 @@ def _warn_stock_fallback(layers, x):
 
 def run_mlp(layers, x, mfma=True):
     """A stack of ConvBNReLU layers.  Training on the GPU: one autograd op over the hand-written
-    kernels (train_ops.mlp_bn_relu_train); otherwise the stock PyTorch modules."""
+    kernels (tmlp.mlp_bn_relu_train); otherwise the stock PyTorch modules."""
     if mfma and x.is_cuda and layers and layers[0].training and torch.is_grad_enabled():
-        from . import train_ops
-        if train_ops.supported(layers, x):
-            return train_ops.mlp_bn_relu_train(x, layers)
-        if train_ops.wide_supported(layers, x):
+        from .train import common as tcommon, evalpath as teval, mlp as tmlp
+        if tcommon.supported(layers, x):
+            return tmlp.mlp_bn_relu_train(x, layers)
+        if tmlp.wide_supported(layers, x):
             # beyond the MFMA kernels' widths: 256-column slices / gridgcn_gemm + this library's BatchNorm kernels
-            return train_ops.mlp_wide_train(x, layers)
+            return tmlp.mlp_wide_train(x, layers)
         _warn_stock_fallback(layers, x)
     if mfma and x.is_cuda and layers and not layers[0].training and not torch.is_grad_enabled():
-        from . import train_ops
-        if train_ops.supported(layers, x) and all(l.lin.in_features <= 1024 for l in layers):
-            return train_ops.mlp_bn_relu_eval(x, layers)      # same MFMA kernel, running stats
+        from .train import common as tcommon, evalpath as teval, mlp as tmlp
+        if tcommon.supported(layers, x) and all(l.lin.in_features <= 1024 for l in layers):
+            return teval.mlp_bn_relu_eval(x, layers)      # same MFMA kernel, running stats
     for l in layers:
         x = l(x)
     return x
@@ -216,44 +216,44 @@ class SubGUpdate(nn.Module):
         """Training path on the GPU: the edge inputs (gather + geo features + concat) come from
         one HIP kernel (ops.edge_inputs, scatter-add backward); the MLPs with batch-statistics
         BatchNorm are stock PyTorch ops.  defer_mask: the caller multiplies by center_masks itself
-        (train_ops.cat_mask: the mask and the concat with the centres in one launch)."""
+        (tcommon.cat_mask: the mask and the concat with the centres in one launch)."""
         from . import ops
         if defer_mask:
             center_masks = None
         att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
         src = src.contiguous()
         if self.mfma_train and self.training and torch.is_grad_enabled():
-            from . import train_ops
-            if train_ops.edge_block_src_supported(pt_layers, att_layers, src, self.has_feats,
+            from .train import common as tcommon, edge as tedge
+            if tedge.edge_block_src_supported(pt_layers, att_layers, src, self.has_feats,
                                                   nebidx.shape[2]):
                 # first conv on the source points, gathered afterwards: no [E, 3+Cf] tensor at all
                 buf, out = None, None
                 if center_ori_feats is not None and self.center_mlp is not None and \
-                        train_ops.supported(list(self.center_mlp), src):
+                        tcommon.supported(list(self.center_mlp), src):
                     # update_func concatenates (centre MLP output, aggregate): both producers
                     # write their half of one buffer instead of a concat pass
                     B, O = nebidx.shape[0], nebidx.shape[1]
                     ccf = self.center_mlp[-1].lin.out_features
                     C = pt_layers[-1].lin.out_features
                     buf = torch.empty((B * O, ccf + C), dtype=torch.float32, device=src.device)
-                    out = train_ops.alias_columns(buf, ccf, C)
-                agg = train_ops.edge_block_src_train(src, nebidx, cent.contiguous(), pt_layers,
+                    out = tcommon.alias_columns(buf, ccf, C)
+                agg = tedge.edge_block_src_train(src, nebidx, cent.contiguous(), pt_layers,
                                                      att_layers, self.localfdim, out=out)
                 return self.finish(agg, center_masks, center_ori_feats, buf=buf, tail=tail)
-            if train_ops.edge_block_supported(pt_layers, att_layers, src, nebidx.shape[2]) and \
+            if tedge.edge_block_supported(pt_layers, att_layers, src, nebidx.shape[2]) and \
                     ops.edge_inputs_rows_supported(src, self.has_feats):
                 # rows laid out for the MFMA kernels (features | geo_vec | zero padding)
                 nf, att16, rot = ops.edge_inputs_rows(src, nebidx, cent.contiguous(),
                                                       has_feats=self.has_feats,
                                                       localfdim=self.localfdim)
-                agg = train_ops.edge_block_train(nf, att16, pt_layers, att_layers, rot)
+                agg = tedge.edge_block_train(nf, att16, pt_layers, att_layers, rot)
                 return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         nf, att_vec = ops.edge_inputs(src, nebidx, cent.contiguous(),
                                       has_feats=self.has_feats, localfdim=self.localfdim)
         if self.mfma_train and self.training and torch.is_grad_enabled():
-            from . import train_ops
-            if train_ops.edge_block_supported(pt_layers, att_layers, nf, nebidx.shape[2]):
-                agg = train_ops.edge_block_train(nf, att_vec, pt_layers, att_layers)
+            from .train import common as tcommon, edge as tedge
+            if tedge.edge_block_supported(pt_layers, att_layers, nf, nebidx.shape[2]):
+                agg = tedge.edge_block_train(nf, att_vec, pt_layers, att_layers)
                 return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         pair = run_mlp(att_layers, att_vec, self.mfma_train) * \
             run_mlp(pt_layers, nf, self.mfma_train)
@@ -262,9 +262,10 @@ class SubGUpdate(nn.Module):
 
     def packed_layers(self):
         """BatchNorm-folded, padded weights for the fused kernel (cached; eval mode only)."""
-        from . import ops, train_ops
+        from . import ops
+        from .train import common as tcommon
         # (the parameter generation: fused optimizers rewrite weights without moving Tensor._version)
-        key = (train_ops._PARAM_GEN[0],) + tuple(p._version for p in self.parameters()) + tuple(
+        key = (tcommon._PARAM_GEN[0],) + tuple(p._version for p in self.parameters()) + tuple(
             b._version for b in self.buffers())
         if getattr(self, "_packed_key", None) != key:
             # LDS row of the first pt layer = the gathered source row (x,y,z,w,features) with
@@ -292,25 +293,25 @@ class SubGUpdate(nn.Module):
         src [B,Nsrc,4+C] (NOT gathered), nebidx [B,O,P], cent [B,O,>=3]."""
         from . import ops
         assert not self.training, "the fused kernel folds BatchNorm: eval() mode only"
-        from . import train_ops
+        from .train import common as tcommon, evalpath as teval
         att_layers, pt_layers = [self.att1[0], self.att2[0]], list(self.pt_mlp)
-        if train_ops.edge_block_src_eval_supported(pt_layers, att_layers, src, self.has_feats):
+        if teval.edge_block_src_eval_supported(pt_layers, att_layers, src, self.has_feats):
             # up layers (one point conv): that conv on the source points, gathered by the max kernel
             if center_ori_feats is not None and self.center_mlp is not None and \
-                    train_ops.supported(list(self.center_mlp), src) and \
+                    tcommon.supported(list(self.center_mlp), src) and \
                     all(l.lin.in_features <= 1024 for l in self.center_mlp):
                 # update_func's concat: centre MLP and aggregate write the two halves of one buffer
                 B, O = nebidx.shape[0], nebidx.shape[1]
                 ccf = self.center_mlp[-1].lin.out_features
                 C = pt_layers[-1].lin.out_features
                 buf = torch.empty((B * O, ccf + C), dtype=torch.float32, device=src.device)
-                train_ops.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
+                teval.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
                                               att_layers, self.localfdim,
-                                              out=train_ops.alias_columns(buf, ccf, C))
-                train_ops.mlp_bn_relu_eval(center_ori_feats, list(self.center_mlp),
-                                           out=train_ops.alias_columns(buf, 0, ccf))
+                                              out=tcommon.alias_columns(buf, ccf, C))
+                teval.mlp_bn_relu_eval(center_ori_feats, list(self.center_mlp),
+                                           out=tcommon.alias_columns(buf, 0, ccf))
                 return self.finish(buf.view(B, O, ccf + C), center_masks, None, tail=tail)
-            agg = train_ops.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
+            agg = teval.edge_block_src_eval(src, nebidx, cent.contiguous(), pt_layers[0],
                                                 att_layers, self.localfdim)
             return self.finish(agg, center_masks, center_ori_feats, tail=tail)
         pt, att = self.packed_layers()
@@ -323,19 +324,19 @@ class SubGUpdate(nn.Module):
         nonneg = False   # both halves of the concat are >= 0: update_func's ReLU is the identity
         if center_ori_feats is not None and buf is not None:
             # `agg` already sits in the right half of buf; the centre MLP writes the left half
-            from . import train_ops
+            from .train import common as tcommon, evalpath as teval, head as thead, mlp as tmlp
             B, O = center_ori_feats.shape[0], center_ori_feats.shape[1]
             ccf = self.center_mlp[-1].lin.out_features
             nonneg = True
             if self._raw_link_ok(center_ori_feats, buf, tail, center_masks):
                 # ... as the RAW output of its last conv: the update MLP applies that layer's
                 # BatchNorm+ReLU while it loads the concat, and its input-gradient kernel accumulates
-                # the layer's BatchNorm-backward sums (train_ops.RawLink): one activation pass and one
+                # the layer's BatchNorm-backward sums (tcommon.RawLink): one activation pass and one
                 # reduce pass over [B*O, ccf] less
-                link = train_ops.RawLink(ccf, buf.shape[1], buf.device)
-            cf = train_ops.mlp_bn_relu_train(center_ori_feats, list(self.center_mlp),
-                                             out=train_ops.alias_columns(buf, 0, ccf), link=link)
-            agg = train_ops._Cat2.apply(cf, agg, buf).reshape(B, O, buf.shape[1])
+                link = tcommon.RawLink(ccf, buf.shape[1], buf.device)
+            cf = tmlp.mlp_bn_relu_train(center_ori_feats, list(self.center_mlp),
+                                             out=tcommon.alias_columns(buf, 0, ccf), link=link)
+            agg = tcommon._Cat2.apply(cf, agg, buf).reshape(B, O, buf.shape[1])
         elif center_ori_feats is not None:
             cf = (run_mlp(list(self.center_mlp), center_ori_feats, self.mfma_train)
                   if self.center_mlp is not None else center_ori_feats)
@@ -351,38 +352,38 @@ class SubGUpdate(nn.Module):
                 tail.done = 1
                 if tail.head is not None and self.mfma_train and agg.is_cuda and \
                         self.training and torch.is_grad_enabled():
-                    from . import train_ops
+                    from .train import common as tcommon, evalpath as teval, head as thead, mlp as tmlp
                     p, lin = tail.head[:2]
-                    if train_ops.head_supported(agg, layers, lin):
-                        # ... and the Dropout + class-score Linear behind them (train_ops._HeadTrain)
+                    if thead.head_supported(agg, layers, lin):
+                        # ... and the Dropout + class-score Linear behind them (thead._HeadTrain)
                         tail.done = 2
                         seed_dev = tail.head[2] if len(tail.head) > 2 else None
                         seed = tail.head[3] if len(tail.head) > 3 else None
-                        return train_ops.head_train(agg, layers, p, lin, seed=seed,
+                        return thead.head_train(agg, layers, p, lin, seed=seed,
                                                     seed_dev=seed_dev, prev=link)
                 if tail.head is not None and self.mfma_train and agg.is_cuda and \
                         not self.training and not torch.is_grad_enabled():
-                    from . import train_ops
+                    from .train import common as tcommon, evalpath as teval, head as thead, mlp as tmlp
                     p, lin = tail.head[:2]
-                    if train_ops.head_supported(agg, layers, lin) and \
+                    if thead.head_supported(agg, layers, lin) and \
                             all(l.lin.in_features <= 1024 for l in layers):
                         tail.done = 2                   # evaluation: dropout is the identity
-                        return train_ops.head_eval(agg, layers, lin)
+                        return teval.head_eval(agg, layers, lin)
             if link is not None:
-                from . import train_ops
-                agg = train_ops.mlp_bn_relu_train(agg, layers, prev=link)
+                from .train import common as tcommon, evalpath as teval, head as thead, mlp as tmlp
+                agg = tmlp.mlp_bn_relu_train(agg, layers, prev=link)
             else:
                 agg = run_mlp(layers, agg, self.mfma_train)
         if center_masks is not None:
             agg = agg * center_masks[..., None]                            # :284-285
         return agg
 
-    raw_link = True   # training: centre MLP output handed to the update MLP raw (train_ops.RawLink)
+    raw_link = True   # training: centre MLP output handed to the update MLP raw (tcommon.RawLink)
 
     def _raw_link_ok(self, center_ori_feats, buf, tail, center_masks):
         """the update MLP (with the tail layers it absorbs) and the centre MLP's last layer are all
         shapes of the register-direct kernels, which alone read a row-strided Z"""
-        from . import train_ops
+        from .train import common as tcommon
         if not (self.raw_link and self.mfma_train and self.training and torch.is_grad_enabled()
                 and self.update_mlp is not None and buf.is_cuda):
             return False
@@ -394,6 +395,6 @@ class SubGUpdate(nn.Module):
         cin_last = cm[-2].lin.out_features if len(cm) > 1 else center_ori_feats.shape[-1]
         cin_last = (cin_last + 3) & ~3
         need_dx = len(cm) > 1 or center_ori_feats.requires_grad
-        return (train_ops.supported(layers, buf) and buf.shape[1] % 8 == 0 and buf.shape[1] <= 256
-                and train_ops._dw_direct_ok(C, cin_last) and C % 8 == 0
+        return (tcommon.supported(layers, buf) and buf.shape[1] % 8 == 0 and buf.shape[1] <= 256
+                and tcommon._dw_direct_ok(C, cin_last) and C % 8 == 0
                 and (not need_dx or cin_last <= 256))

@@ -97,7 +97,7 @@ class GGCNSeg(nn.Module):
         self.fc2 = nn.Linear(128, cfg["num_classes"])
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
-        # ... and so do fc1/dropout + fc2 (:36-38): train_ops._HeadTrain
+        # ... and so do fc1/dropout + fc2 (:36-38): thead._HeadTrain
         self.fused_head = HEAD_KERNELS and FUSED_HEAD and _is_hip(index_ops)
         # indices from the index operators lie in [-1, N-1]: sorted segmented-sum gather backward
         self._take_kw = dict(neighbour_index=True) if _is_hip(index_ops) else {}
@@ -130,14 +130,15 @@ class GGCNSeg(nn.Module):
         B, N, _ = data_xyz.shape
         nd = len(self.down)
         # training on the HIP path: concat / centre mask / zero padding of the layer boundaries in one
-        # launch each (train_ops.cat_mask) instead of 2-4 framework ops
+        # launch each (tcommon.cat_mask) instead of 2-4 framework ops
         glue = (self.glue_kernels and _is_hip(ix) and self.edge_kernel and data_xyz.is_cuda
                 and data_xyz.dtype == torch.float32 and self.training and torch.is_grad_enabled())
         if glue:
-            from . import train_ops
-            glue = train_ops.OPT.GLUE_KERNELS
+            from .train import common as tcommon, head as thead
+            from .train.options import OPT
+            glue = OPT.GLUE_KERNELS
         if glue:
-            data, data_pad = train_ops.cat_mask(data_xyz.detach(), None, None, pad=True)  # :137
+            data, data_pad = tcommon.cat_mask(data_xyz.detach(), None, None, pad=True)  # :137
         else:
             data = torch.cat([data_xyz, torch.ones_like(data_xyz[..., :1])], dim=2)     # :137
             data_pad = data
@@ -150,8 +151,9 @@ class GGCNSeg(nn.Module):
         if self.training:
             self.forward_no += 1
             if data_xyz.is_cuda and torch.is_grad_enabled():
-                from . import train_ops
-                train_ops.PACKS.prepack(self)   # all weight layouts of the step, one launch
+                from .train import common as tcommon, head as thead
+                from .train.options import OPT
+                tcommon.PACKS.prepack(self)   # all weight layouts of the step, one launch
         seed_dev = self._seed_dev()
         sd = dict(seed_dev=seed_dev) if (seed_dev is not None and _is_hip(ix)) else {}
         for i, layer in enumerate(self.down):
@@ -169,7 +171,7 @@ class GGCNSeg(nn.Module):
                 neighbors = ix.batch_take_g(data_layer.contiguous(), nebidx, **self._take_kw)  # :172-173
                 cf = layer(cent[..., 0:3], neighbors, centmsk)                      # :185
             if glue:
-                data_layer, dl_pad = train_ops.cat_mask(cent, cf, centmsk, pad=i != nd - 1)   # :186
+                data_layer, dl_pad = tcommon.cat_mask(cent, cf, centmsk, pad=i != nd - 1)   # :186
             else:
                 data_layer = dl_pad = torch.cat([cent, cf], dim=2)                  # :186
             locs.append(cent); feats.append(data_layer); masks.append(centmsk); nums.append(centnum)
@@ -200,7 +202,7 @@ class GGCNSeg(nn.Module):
                                          **sd)  # :206-210
             f_this = feats[-i - 2]
             if glue and layer.center_mlp is not None and layer.mfma_train and \
-                    train_ops.supported(list(layer.center_mlp), f_this):
+                    tcommon.supported(list(layer.center_mlp), f_this):
                 f_this = feats_pad[-i - 2]        # (the MFMA kernels take the zero-padded rows as they are)
             cmask = masks[-i - 2] if i != nup - 1 else None                         # :224
             if self.use_fused():
@@ -217,7 +219,7 @@ class GGCNSeg(nn.Module):
                            tail=tail if i == nup - 1 else None)                       # :229
             if i != nup - 1:                      # (the last layer's features go to the head only)
                 if glue:
-                    f_last = train_ops.cat_mask(upl, cf, cmask)[0]                  # :231
+                    f_last = tcommon.cat_mask(upl, cf, cmask)[0]                  # :231
                 else:
                     f_last = torch.cat([upl, cf], dim=2)                            # :231
         self.last_tail_done = tail.done           # (introspection only: which head path ran)
@@ -226,9 +228,10 @@ class GGCNSeg(nn.Module):
         net = cf if tail.done else run_mlp([self.fc1], cf)
         net = F.dropout(net, self.cfg["dropout"], self.training)
         if HEAD_KERNELS and self.training and torch.is_grad_enabled() and _is_hip(self.ix):
-            from . import train_ops
-            if train_ops.linear_plain_supported(net, self.fc2):
-                return train_ops.linear_plain_train(net, self.fc2)
+            from .train import common as tcommon, head as thead
+            from .train.options import OPT
+            if thead.linear_plain_supported(net, self.fc2):
+                return thead.linear_plain_train(net, self.fc2)
         return self.fc2(net)
 
 
@@ -260,9 +263,9 @@ def seg_forward_flops(net, B, N):
 
 
 def release_packs(module, _inputs, _output):
-    """forward hook of the three nets: see train_ops._PackCache.release"""
-    from . import train_ops
-    train_ops.PACKS.release(module)
+    """forward hook of the three nets: see tcommon._PackCache.release"""
+    from .train import common as tcommon
+    tcommon.PACKS.release(module)
 
 
 class WeightedGradient(torch.autograd.Function):
@@ -287,8 +290,8 @@ def seg_loss(logits, label, weights=None):
     weights: optional per-class gradient weights (the 'weighted_gradient' op of :39-40)."""
     lg, lb = logits.reshape(-1, logits.shape[-1]), label.reshape(-1).long()
     if lg.is_cuda and lg.dtype == torch.float32 and lg.shape[1] <= 32 and HEAD_KERNELS:
-        from . import train_ops
-        return train_ops.softmax_ce(lg, lb, 0, weights)       # csrc/gridgcn_head.hip
+        from .train import head as thead
+        return thead.softmax_ce(lg, lb, 0, weights)       # csrc/gridgcn_head.hip
     if weights is not None:
         lg = WeightedGradient.apply(lg, torch.as_tensor(weights, dtype=lg.dtype, device=lg.device))
     return F.cross_entropy(lg, lb, ignore_index=0, reduction="mean")

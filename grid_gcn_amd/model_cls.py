@@ -52,10 +52,10 @@ class SubGUpdateCls(nn.Module):
 
     def forward_src(self, cent, src, nebidx, center_masks=None):
         """On the GPU from the un-gathered source points: the whole edge block on the hand-written
-        kernels (train_ops._EdgeBlockClsTrain; evaluation under no_grad: edge_block_cls_eval with
+        kernels (tcls._EdgeBlockClsTrain; evaluation under no_grad: edge_block_cls_eval with
         the running statistics) -- no gathered [E, 4+C] tensor, no concat, no tiled context.  None when the shapes are outside the kernels' domain (the caller
         then gathers and uses forward())."""
-        from . import train_ops
+        from .train import cls as tcls, evalpath as teval
         train = self.training and torch.is_grad_enabled()
         infer = not self.training and not torch.is_grad_enabled()
         if not (self.mfma_train and src.is_cuda and (train or infer)):
@@ -63,12 +63,12 @@ class SubGUpdateCls(nn.Module):
         if self.has_feats and self.localfdim == 0:
             return None
         pt, a1, a2 = list(self.pt_mlp), list(self.att1), list(self.att2)
-        if not train_ops.edge_block_cls_supported(pt, a1, a2, src, nebidx.shape[2]):
+        if not tcls.edge_block_cls_supported(pt, a1, a2, src, nebidx.shape[2]):
             return None
         if train:
-            agg = train_ops.edge_block_cls_train(src, nebidx, cent, pt, a1, a2)
+            agg = tcls.edge_block_cls_train(src, nebidx, cent, pt, a1, a2)
         else:
-            agg = train_ops.edge_block_cls_eval(src, nebidx, cent, pt, a1, a2)
+            agg = teval.edge_block_cls_eval(src, nebidx, cent, pt, a1, a2)
         # (relu of a product of two relu outputs is the identity: gcn_module_g.py's relu=True)
         if center_masks is not None:
             agg = agg * center_masks[..., None]
@@ -143,8 +143,8 @@ class GGCNCls(nn.Module):
         if self.training:
             self.forward_no += 1
             if data_xyz.is_cuda and torch.is_grad_enabled():
-                from . import train_ops
-                train_ops.PACKS.prepack(self)   # all weight layouts of the step, one launch
+                from .train import common as tcommon, head as thead
+                tcommon.PACKS.prepack(self)   # all weight layouts of the step, one launch
         for i, layer in enumerate(self.layers):
             seed = self.seed if (self.fixed_seed or not self.training) else \
                 call_seed(self.seed, fwd_no, i)
@@ -161,8 +161,8 @@ class GGCNCls(nn.Module):
         net = cf.reshape(cf.shape[0], -1)                                         # flatten=True
         h = self.fc2(self.fc1(net))
         if h.is_cuda and self._take_kw:
-            from . import train_ops
-            return train_ops.linear_mm(h, self.fc3)
+            from .train import common as tcommon, head as thead
+            return thead.linear_mm(h, self.fc3)
         return self.fc3(h)
 
 

@@ -47,8 +47,8 @@ class GGCNSynth(nn.Module):
         if self.training:
             self.forward_no += 1
             if data_xyz.is_cuda and torch.is_grad_enabled():
-                from . import train_ops
-                train_ops.PACKS.prepack(self)   # all weight layouts of the step, one launch
+                from .train import common as tcommon, head as thead
+                tcommon.PACKS.prepack(self)   # all weight layouts of the step, one launch
         data_loc, data_layer, num = data, data, actual_centnum
         outs = []
         for i, layer in enumerate(self.down):
@@ -71,8 +71,8 @@ class GGCNSynth(nn.Module):
         neg = torch.finfo(cf.dtype).min
         pooled = torch.where(centmsk[..., None] > 0, cf, torch.full_like(cf, neg)).max(dim=1).values
         if pooled.is_cuda and _is_hip(ix):
-            from . import train_ops
-            logits = train_ops.linear_mm(pooled, self.fc)
+            from .train import common as tcommon, head as thead
+            logits = thead.linear_mm(pooled, self.fc)
         else:
             logits = self.fc(pooled)
         return (logits, outs) if return_layers else logits

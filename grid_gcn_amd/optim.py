@@ -75,9 +75,10 @@ class Adam(torch.optim.Optimizer):
         device-side counter; a checkpoint carries an independent float32 scalar per parameter instead (what
         torch.optim.Adam stores), so that loading it there does not advance one shared element once per parameter."""
         sd = super().state_dict()
-        for s in sd["state"].values():
-            if "step" in s:
-                s["step"] = s["step"].detach().to(torch.float32).reshape(()).clone()
+        # (torch hands out the optimizer's OWN per-parameter dicts: the replacement goes into copies, never into
+        #  self.state[p], whose `step` must stay a view of the live counter)
+        sd["state"] = {k: ({**s, "step": s["step"].detach().to(torch.float32).reshape(()).clone()}
+                           if "step" in s else dict(s)) for k, s in sd["state"].items()}
         return sd
 
     def load_state_dict(self, state_dict):

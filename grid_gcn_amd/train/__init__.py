@@ -1,5 +1,6 @@
 """Host side of the training / evaluation path on the hand-written kernels, by block (round 5: was one
-2 570-line module).  grid_gcn_amd.train_ops re-exports everything under its old names.
+2 570-line module; the re-export shim `grid_gcn_amd/train_ops.py` that bridged the split was deleted in round 6 -- callers
+import the block they use: `from grid_gcn_amd.train import edge`, `from grid_gcn_amd.train.options import OPT`).
 
     options    the path switches: one object, OPT
     common     operand packing cache, conv + BatchNorm + ReLU chains (forward / backward), small GEMMs, glue

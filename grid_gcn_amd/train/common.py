@@ -1,5 +1,5 @@
 """Shared state and helpers of the training path: operand packing cache, chain forward / backward
-(one conv + BatchNorm + ReLU stack), the small GEMMs, the zero arena, concat glue.  See grid_gcn_amd/train_ops.py
+(one conv + BatchNorm + ReLU stack), the small GEMMs, the zero arena, concat glue.  See grid_gcn_amd/train/__init__.py
 for the overview; everything goes through the C ABI of include/gridgcn.h."""
 import ctypes
 import weakref
@@ -264,7 +264,7 @@ class LaunchTimers:
     """Device time of selected library calls INSIDE a running training step (bench.py: `ms_in_step`).  A
     micro-benchmark launches a kernel back to back on random tensors with warm caches; the step pays for it
     behind other kernels' traffic (0.717 ms in the micro-benchmark, 0.823 ms in the traced step).
-    With `train_ops.OPT.TIMERS = LaunchTimers({key, ...})` set, the chain code brackets every matching call --
+    With `OPT.TIMERS = LaunchTimers({key, ...})` set, the chain code brackets every matching call --
     key = ("linear_fwd" | "linear_bwd", rows, cin, cout) -- by a pair of events on the launch stream (eager
     steps only: events cannot be read back from a graph replay).  median(key) -> ms."""
 

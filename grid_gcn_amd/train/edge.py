@@ -225,9 +225,12 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             # both readers take it: the source-side max kernel and the fused attention backward.
             # (E >= 32: below that the fused backward declines and nothing else reads a bf16 Z)
             nz_shape = noz and La == 2 and A0 == 32 and C == 128 and E >= 32 and att16.shape[1] == 16
-            # (bf16 mode, OPT.NOZ_IN_BF16: where the Z2-free pair of kernels applies it is taken in bf16 mode too -- it is
-            #  fp32-exact and moves fewer bytes than the bf16-stored tensor does)
-            nz16 = (OPT.NOZ_IN_BF16 and OPT.NOZ_ATT_BWD and OPT.NOZ_ATT_FWD and nz_shape and P == 5 and O >= 6
+            # the limits of the Z2-free FORWARD kernel, asked of the library (ONE statement of them: gg_att_fwd_ok)
+            nzf_shape = nz_shape and lib.gridgcn_att_pairmax_fwd_supported(ncent, O, P, A0, C, lda, R) == 1
+            # (bf16 mode, OPT.NOZ_IN_BF16: where the Z2-free PAIR of kernels applies -- both of them, or the step would
+            #  write an fp32 Z2 from the bf16 chain and run the fp32 recompute backward on it -- it is taken in bf16 mode
+            #  too: it is fp32-exact and moves fewer bytes than the bf16-stored tensor does)
+            nz16 = (OPT.NOZ_IN_BF16 and OPT.NOZ_ATT_BWD and OPT.NOZ_ATT_FWD and nzf_shape
                     and lib.gridgcn_get_mlp_precision() == 1)
             z16 = (OPT.Z16_STORAGE and noz and La == 2 and A0 in (16, 32) and C in (64, 128) and E >= 32
                    and lib.gridgcn_get_mlp_precision() == 1 and not nz16
@@ -237,8 +240,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             nz = (OPT.NOZ_ATT_BWD and nz_shape and not z16 and (lib.gridgcn_get_mlp_precision() == 0 or nz16))
             # ... and neither does the forward (gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd): the [E, 128]
             # tensor is then never written at all
-            nzf = (nz and OPT.NOZ_ATT_FWD and P == 5 and O >= 6 and ncent >= 7 and R < (1 << 23) and lda >= C
-                   and ncent * lda < (1 << 30))
+            nzf = nz and OPT.NOZ_ATT_FWD and nzf_shape
             if nzf:
                 sa = _att_fwd_noz(lib, att16, pa, bns_a, eps, st)
                 rc = lib.gridgcn_att_pairmax_fwd(

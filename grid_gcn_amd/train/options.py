@@ -4,10 +4,10 @@ Every switch selects between two implementations of the same step that compute t
 what is measured and shipped); they exist for A/B measurements (`bench.py --switch NAME=0`) and for the tests that
 run one input through both paths.  Nothing here, and nothing in the C library, reads the process environment.
 
-    from grid_gcn_amd import train_ops
-    with train_ops.OPT.override(NOZ_ATT_BWD=False):      # scoped (tests)
+    from grid_gcn_amd.train.options import OPT
+    with OPT.override(NOZ_ATT_BWD=False):      # scoped (tests)
         ...
-    train_ops.OPT.set("FOLD_FINALIZE", False)            # process-wide (bench.py --switch)
+    OPT.set("FOLD_FINALIZE", False)            # process-wide (bench.py --switch)
 
 Kernel-selection options of the C library itself (gridgcn_set_option: COL_SPLIT, ATT_NZ_V2, BWD_FUSED128, ...) are a
 separate, process-wide table inside the library; bench.py's --switch takes both kinds of name.

@@ -78,7 +78,8 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  * 7: GRIDGCN_OPT_ATT_NZ_V2, GRIDGCN_OPT_BWD_FUSED128 (gridgcn_linear_bwd may take the one-pass
                                  *    kernel: dX / dW / sums in other summation orders); gridgcn_gemm_small_workspace_bytes is
                                  *    bounded (~16 MB) whatever the row count
-                                 * 8: gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd (+ _workspace_bytes), GRIDGCN_OPT_ATT_EVAL_TILE */
+                                 * 8: gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd (+ _workspace_bytes), GRIDGCN_OPT_ATT_EVAL_TILE
+                                 * 9: gridgcn_att_pairmax_fwd_supported */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -684,6 +685,9 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
  *   The attention value of an edge is W2 a1 + b2 in the MFMA unit's summation order with the bias FIRST: the same
  *   terms as gridgcn_linear_fwd_direct, last-bit differences possible; the point branch is bit-identical. */
 int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes);
+/* 1 when gridgcn_att_pairmax_fwd takes this shape (rows = B*Nsrc), 0 when it would return GRIDGCN_EINVAL: the ONE
+ * statement of its limits -- callers decide between the Z2-free pair and the Z2 path with it, before anything runs. */
+int gridgcn_att_pairmax_fwd_supported(long long ncent, int O, int P, int cin, int C, int ld_agg, long long rows);
 int gridgcn_att_bn2_moments(const float *Z1, const float *scale1, const float *shift1, const float *W2,
                             const float *b2, const float *gamma, const float *beta, long long E, int cin, int C,
                             float eps, float momentum, float *scale, float *shift, float *mean, float *rstd,

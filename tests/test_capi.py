@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_strerror(lib):
     from grid_gcn_amd import _lib
-    assert lib.gridgcn_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.gridgcn_abi_version() == _lib.ABI_VERSION == 9
     for opt in (_lib.OPT_INDEX_SMALL, _lib.OPT_COL_SPLIT):          # round 4: both on by default, 0 / 1 only
         assert lib.gridgcn_get_option(opt) == 1
         assert lib.gridgcn_set_option(opt, 2) == 1 and lib.gridgcn_set_option(opt, 0) == 0

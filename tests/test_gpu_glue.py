@@ -106,13 +106,13 @@ def test_adam_state_dict_round_trip_and_tensor_lr():
                                             (4, 4, True, True), (3, 5, True, True), (4, 6, False, False),
                                             (5, 64, True, True)])
 def test_cat_mask_matches_torch(ca, cb, mask, pad):
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import common as tcommon
     torch.manual_seed(ca * 100 + (cb or 0))
     B, O = 3, 37
     a = torch.randn(B, O, ca, device=DEV)
     b = torch.randn(B, O, cb, device=DEV, requires_grad=True) if cb else None
     mk = (torch.rand(B, O, device=DEV) > 0.3).float() if mask else None
-    out, outp = train_ops.cat_mask(a, b, mk, pad=pad)
+    out, outp = tcommon.cat_mask(a, b, mk, pad=pad)
     bb = b if b is not None else torch.ones(B, O, 1, device=DEV)
     ref = torch.cat([a, bb * mk[..., None] if mk is not None else bb], dim=-1)
     assert torch.equal(out, ref)
@@ -207,7 +207,8 @@ def test_eval_constants_cache_follows_training():
     """the cached evaluation constants (folded BatchNorm, packed weights) are rebuilt after eager training steps
     (optim.Adam and the kernels' running-statistics updates move the version counters by hand) and after
     replays of a captured step: evaluation == evaluation with the cache switched off"""
-    from grid_gcn_amd import graph, model, optim, synth, train_ops
+    from grid_gcn_amd import graph, model, optim, synth
+    from grid_gcn_amd.train.options import OPT
     torch.manual_seed(1)
     net = model.GGCNSeg(model.SEG_8192, seed=3).to(DEV)
     data, npn = synth.make_batch(2, 8192, "planes", first_id=5)
@@ -220,11 +221,11 @@ def test_eval_constants_cache_follows_training():
         net.eval()
         with torch.no_grad():
             a = net(x, n).clone()
-            train_ops.OPT.EVAL_CACHE = False
+            OPT.EVAL_CACHE = False
             try:
                 b = net(x, n).clone()
             finally:
-                train_ops.OPT.EVAL_CACHE = True
+                OPT.EVAL_CACHE = True
         net.train()
         return a, b
 
@@ -289,12 +290,49 @@ def test_adam_checkpoints_travel_to_and_from_torch_adam():
         assert torch.allclose(a, b, rtol=0, atol=5e-7)
 
 
+def test_adam_second_checkpoint_carries_the_advanced_step():
+    """Optimizer.state_dict() returns the optimizer's own per-parameter dicts; writing the frozen scalar
+    into them cut self.state[p]['step'] loose from the device counter, so every later checkpoint repeated the
+    first one's count.  step, checkpoint, step, checkpoint: the second says 2 more, and the live entry is still
+    the counter's view (a resumed optimizer continues at the right bias correction)."""
+    from grid_gcn_amd import optim
+    ps = _params(SIZES[:4], 11)
+    own = optim.Adam(ps, lr=1e-3)
+    g = torch.Generator().manual_seed(3)
+
+    def step(n):
+        for _ in range(n):
+            for p in ps:
+                p.grad = torch.randn(p.shape, generator=g).to(DEV)
+            own.step()
+
+    step(5)
+    sd1 = own.state_dict()
+    assert all(float(s["step"]) == 5.0 for s in sd1["state"].values())
+    live = own.state[ps[0]]["step"]
+    assert live.dtype == torch.int32 and int(live) == 5          # still the counter's view, not the frozen copy
+    step(4)
+    assert int(own.state[ps[0]]["step"]) == 9
+    sd2 = own.state_dict()
+    assert all(float(s["step"]) == 9.0 for s in sd2["state"].values())
+    assert all(float(s["step"]) == 5.0 for s in sd1["state"].values())       # the first checkpoint is its own copy
+    # resume from the second checkpoint: the counter continues at 9
+    o2 = optim.Adam(ps, lr=1e-3)
+    o2.load_state_dict(copy.deepcopy(sd2))
+    for p in ps:
+        p.grad = torch.zeros_like(p)
+    o2.step()
+    assert int(o2.state[ps[0]]["step"]) == 10
+
+
 def test_eval_cache_sees_torch_fused_adam():
     """torch's fused Adam rewrites the weights without moving Tensor._version; the evaluation caches
     (folded BatchNorm vectors, packed weights, the wgb table, SubGUpdate.packed_layers) are keyed on the
     parameter generation that the global optimizer-step hook advances -- evaluation after eager training with
     that optimizer == evaluation with the cache off."""
-    from grid_gcn_amd import model, synth, train_ops
+    from grid_gcn_amd import model, synth
+    from grid_gcn_amd.train import common as tcommon
+    from grid_gcn_amd.train.options import OPT
     torch.manual_seed(2)
     net = model.GGCNSeg(model.SEG_8192, seed=3).to(DEV)
     data, npn = synth.make_batch(2, 8192, "planes", first_id=9)
@@ -305,12 +343,12 @@ def test_eval_cache_sees_torch_fused_adam():
 
     def evaluate(cache):
         net.eval()
-        train_ops.OPT.EVAL_CACHE = cache
+        OPT.EVAL_CACHE = cache
         try:
             with torch.no_grad():
                 return net(x, n).clone()
         finally:
-            train_ops.OPT.EVAL_CACHE = True
+            OPT.EVAL_CACHE = True
             net.train()
 
     net.train()
@@ -323,8 +361,8 @@ def test_eval_cache_sees_torch_fused_adam():
         v0 = net.fc2.weight._version
         opt.zero_grad(set_to_none=True)
         model.seg_loss(net(x, n), lab).backward()
-        g0 = train_ops._PARAM_GEN[0]
+        g0 = tcommon._PARAM_GEN[0]
         opt.step()
-        assert train_ops._PARAM_GEN[0] > g0
+        assert tcommon._PARAM_GEN[0] > g0
     a = evaluate(True)
     assert torch.equal(a, evaluate(False)) and float((a - prev).abs().max()) > 0

@@ -140,9 +140,9 @@ def test_edge_inputs_rows_layout(cin, lfd):
                                               (128, 0, [128], 2000, 5)])
 def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P):
     """GridConv training forward/backward with the first pt conv applied to the SOURCE points and
-    gathered (train_ops.edge_block_src_train) == the stock modules on the gathered tensor."""
+    gathered (tedge.edge_block_src_train) == the stock modules on the gathered tensor."""
     import copy
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import edge as tedge
     torch.manual_seed(cin + lfd + O)
     gen = torch.Generator().manual_seed(cin + P)
     B, Nsrc = 3, 150
@@ -156,7 +156,7 @@ def test_edge_block_source_side_first_conv(cin, lfd, dims, O, P):
     src2 = src1.detach().clone().requires_grad_(True)
     nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
-    assert train_ops.edge_block_src_supported(list(new.pt_mlp), [new.att1[0], new.att2[0]], src2, True)
+    assert tedge.edge_block_src_supported(list(new.pt_mlp), [new.att1[0], new.att2[0]], src2, True)
     y1 = ref(cent[..., 0:3], ops.batch_take_g(src1, nebidx), None)
     y2 = new.forward_src(cent, src2, nebidx, None)
     assert y1.shape == y2.shape
@@ -189,7 +189,7 @@ def test_att_bwd_noz_equals_direct_form(O, P, B, monkeypatch):
     reads Z2 (gg_k_att_bwd_fused): every gradient agrees to fp32 association (the stock-module / float64
     bars are the other tests')."""
     import copy
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train.options import OPT
     torch.manual_seed(O + P)
     gen = torch.Generator().manual_seed(O * 7 + P)
     cin, Nsrc = 128, 150
@@ -203,9 +203,9 @@ def test_att_bwd_noz_equals_direct_form(O, P, B, monkeypatch):
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
     g = torch.randn((B, O, 128), generator=gen).to(DEV)
     res = []
-    monkeypatch.setattr(train_ops.OPT, "NOZ_ATT_FWD", False)       # (its own test below)
+    monkeypatch.setattr(OPT, "NOZ_ATT_FWD", False)       # (its own test below)
     for bwd in (True, False):
-        monkeypatch.setattr(train_ops.OPT, "NOZ_ATT_BWD", bwd)
+        monkeypatch.setattr(OPT, "NOZ_ATT_BWD", bwd)
         m = copy.deepcopy(net)
         s_ = src.clone().requires_grad_(True)
         y = m.forward_src(cent, s_, nebidx, None)
@@ -235,7 +235,7 @@ def test_att_fwd_noz_equals_the_materialised_form(O, B, monkeypatch):
     the two forwards may order a near-tied neighbour maximum differently, which moves single gradient entries
     (test_gpu_fuzz.py), so: 99.9 % of every gradient within 1e-4 of its largest entry, all of it within 2e-2."""
     import copy
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train.options import OPT
     P = 5
     torch.manual_seed(O + P)
     gen = torch.Generator().manual_seed(O * 7 + P)
@@ -251,7 +251,7 @@ def test_att_fwd_noz_equals_the_materialised_form(O, B, monkeypatch):
     g = torch.randn((B, O, 128), generator=gen).to(DEV)
     res = []
     for fwd in (True, False):
-        monkeypatch.setattr(train_ops.OPT, "NOZ_ATT_FWD", fwd)
+        monkeypatch.setattr(OPT, "NOZ_ATT_FWD", fwd)
         m = copy.deepcopy(net)
         s_ = src.clone().requires_grad_(True)
         y = m.forward_src(cent, s_, nebidx, None)
@@ -484,7 +484,8 @@ def test_att_max_eval_kernel_equals_two_kernel_path(cin, C, O, P):
     transposed MFMA product, a lane owns a centre) against the path that materialises the [E, C]
     attention tensor (forward MFMA kernel + gg_k_pairmax_fwd4_src), and both against the stock
     modules."""
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import evalpath as teval
+    from grid_gcn_amd.train.options import OPT
     torch.manual_seed(cin + C + P)
     gen = torch.Generator().manual_seed(O + P)
     B, Nsrc = 3, 150
@@ -495,14 +496,14 @@ def test_att_max_eval_kernel_equals_two_kernel_path(cin, C, O, P):
     nebidx = torch.randint(-1, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
     att_layers, pt = [layer.att1[0], layer.att2[0]], layer.pt_mlp[0]
-    assert train_ops.edge_block_src_eval_supported([pt], att_layers, src, True)
+    assert teval.edge_block_src_eval_supported([pt], att_layers, src, True)
     outs = []
     for flag in (True, False):
-        train_ops.OPT.ATT_MAX_EVAL = flag
+        OPT.ATT_MAX_EVAL = flag
         try:
-            outs.append(train_ops.edge_block_src_eval(src, nebidx, cent, pt, att_layers, 3))
+            outs.append(teval.edge_block_src_eval(src, nebidx, cent, pt, att_layers, 3))
         finally:
-            train_ops.OPT.ATT_MAX_EVAL = True
+            OPT.ATT_MAX_EVAL = True
     with torch.no_grad():
         ref = layer(cent[..., 0:3], ops.batch_take_g(src, nebidx), None)
     scale = max(1.0, float(ref.abs().max()))

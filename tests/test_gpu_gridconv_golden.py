@@ -50,7 +50,7 @@ def run_hip(case, m, train):
             return m.forward_src(cent, src, idx, cm, center_ori_feats=cof)
         with torch.no_grad():
             return m.forward_fused(cent, src, idx, cm, center_ori_feats=cof)
-    # classification block: the kernels of train_ops._EdgeBlockClsTrain / edge_block_cls_eval
+    # classification block: the kernels of tcls._EdgeBlockClsTrain / edge_block_cls_eval
     with (torch.enable_grad() if train else torch.no_grad()):
         out = m.forward_src(cent, src, idx, cm)
     assert out is not None, "classification edge block fell back to the stock modules"

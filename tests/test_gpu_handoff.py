@@ -67,7 +67,8 @@ def _mismatch(flag, a, b):
 def test_folded_batchnorm_finalisation_under_load(E, cin, C):
     """gridgcn_linear_fwd_direct_fin: scale / shift / mean / rstd and the running statistics written by the LAST
     workgroup == gridgcn_bn_finalize_tail run afterwards on the sums the kernel left in memory."""
-    from grid_gcn_amd import _lib, train_ops
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.train import common as tcommon
     lib = _lib.load()
     st = torch.cuda.current_stream(DEV).cuda_stream
     g = torch.Generator(device=DEV).manual_seed(E + C)
@@ -75,7 +76,7 @@ def test_folded_batchnorm_finalisation_under_load(E, cin, C):
     W = torch.randn(C, cin, device=DEV, generator=g) * 0.1
     b = torch.randn(C, device=DEV, generator=g)
     gamma, beta = torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g)
-    K, ldw, nwp, nwb = train_ops.packed_sizes(C, cin)
+    K, ldw, nwp, nwb = tcommon.packed_sizes(C, cin)
     Bp, Wq = torch.empty(ldw, device=DEV), torch.empty(cin * ldw, device=DEV)
     assert lib.gridgcn_pack_linear(_p(W), _p(b), C, cin, 0, cin, 0, None, _p(Bp), None, None, _p(Wq), None, st) == 0
     Z = torch.empty(E, C, device=DEV)
@@ -174,11 +175,11 @@ def test_loss_and_colsum_finish_under_load(E):
 def test_gemm_tn_ticket_under_load(R, m, n):
     """gg_k_gemm_tn (slice partials -> ticket -> last arriver; release / acquire): bit-identical to a quiet run
     in every round -- the summation order is fixed, so any difference is a stale or missing slice."""
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import common as tcommon
     g = torch.Generator(device=DEV).manual_seed(R)
     As = [torch.randn(R, m, device=DEV, generator=g) for _ in range(2)]
     Bs = [torch.randn(R, n, device=DEV, generator=g) for _ in range(2)]
-    quiet = [train_ops._tn_matmul(a, b).clone() for a, b in zip(As, Bs)]
+    quiet = [tcommon._tn_matmul(a, b).clone() for a, b in zip(As, Bs)]
     ref64 = As[0].double().t() @ Bs[0].double()
     assert float((quiet[0] - ref64).abs().max()) <= 1e-5 * float(ref64.abs().max()) * R ** 0.5
     torch.cuda.synchronize()
@@ -190,7 +191,7 @@ def test_gemm_tn_ticket_under_load(R, m, n):
         if r % 8 == 0:
             load.kick()
         o = outs[r % 4]
-        train_ops._tn_matmul(As[r % 2], Bs[r % 2], out=o)
+        tcommon._tn_matmul(As[r % 2], Bs[r % 2], out=o)
         _mismatch(flag, o, quiet[r % 2])
     load.done()
     torch.cuda.synchronize()
@@ -203,7 +204,8 @@ def test_dw_reduce_and_att_nz_chain_under_load(ncent, P, cin, C, dense):
     """gridgcn_linear_bwd (dX, dW partials, gg_k_dw_reduce_direct's slice ticket) and gridgcn_att_bwd_noz (partial
     tiles -> gg_k_att_nz_reduce -> gg_k_att_nz_finish): dW of every round == dW of a quiet run, bit for bit
     (both reduce in a fixed order)."""
-    from grid_gcn_amd import _lib, train_ops
+    from grid_gcn_amd import _lib
+    from grid_gcn_amd.train import common as tcommon
     lib = _lib.load()
     E = ncent * P
     st = torch.cuda.current_stream(DEV).cuda_stream
@@ -216,7 +218,7 @@ def test_dw_reduce_and_att_nz_chain_under_load(ncent, P, cin, C, dense):
     gval = rnd(ncent, C)
     dY = rnd(E, C) if dense else None
     Wt = rnd(C, cin)
-    Wb, Wg = train_ops.pack_tiles(Wt), train_ops.pack_groups(Wt)
+    Wb, Wg = tcommon.pack_tiles(Wt), tcommon.pack_groups(Wt)
     ndx = min(cin, 256)
     Wdx = torch.empty(C * 32 * 8, device=DEV)
     assert lib.gridgcn_pack_linear(_p(Wt), None, C, cin, 0, cin, ndx, None, None, None, None, None, _p(Wdx), st) == 0

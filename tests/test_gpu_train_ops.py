@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 import torch  # noqa: E402
 
-from grid_gcn_amd import train_ops  # noqa: E402
+from grid_gcn_amd.train import common as tcommon, edge as tedge, evalpath as teval, head as thead, mlp as tmlp
+from grid_gcn_amd.train.options import OPT  # noqa: E402
 from grid_gcn_amd.gridconv import mlp  # noqa: E402
 
 DEV = "cuda:0"
@@ -47,9 +48,9 @@ def test_mlp_train_matches_torch(E, cin, dims):
     new = copy.deepcopy(ref)
     x1 = (torch.randn(E, cin, device=DEV) * 1.5).requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
-    assert train_ops.supported(list(new), x2)
+    assert tcommon.supported(list(new), x2)
     y1 = ref(x1)
-    y2 = train_ops.mlp_bn_relu_train(x2, list(new))
+    y2 = tmlp.mlp_bn_relu_train(x2, list(new))
     scale = float(y1.abs().max())
     assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, scale)
     g = torch.randn_like(y1)
@@ -113,7 +114,7 @@ def test_col_split_equals_whole_rows(E, cin, dims):
         try:
             m = copy.deepcopy(net)
             xi = x.clone().requires_grad_(True)
-            y = train_ops.mlp_bn_relu_train(xi, list(m))
+            y = tmlp.mlp_bn_relu_train(xi, list(m))
             y.backward(g)
             res.append((y.detach(), xi.grad, [p.grad for p in m.parameters()]))
         finally:
@@ -151,9 +152,9 @@ def test_wide_layers_without_rocblas_match_torch(E, cin, dims):
     new = copy.deepcopy(ref)
     x1 = torch.randn(E, cin, device=DEV).requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
-    assert not train_ops.supported(list(new), x2) and train_ops.wide_supported(list(new), x2)
+    assert not tcommon.supported(list(new), x2) and tmlp.wide_supported(list(new), x2)
     y1 = ref(x1)
-    y2 = train_ops.mlp_wide_train(x2, list(new))
+    y2 = tmlp.mlp_wide_train(x2, list(new))
     assert float((y1 - y2).abs().max()) <= 3e-5 * max(1.0, float(y1.abs().max()))
     g = torch.randn_like(y1)
     y1.backward(g)
@@ -188,15 +189,15 @@ def test_gemm_any_k_and_bias():
         b = torch.randn(N, K + 3, device=DEV)[:, :K]
         bias = torch.randn(N, device=DEV)
         want = a.double() @ b.double().t() + bias.double()
-        got = train_ops._mm_nt(a, b, bias=bias)
+        got = tcommon._mm_nt(a, b, bias=bias)
         assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * K ** 0.5
         b2 = torch.randn(K, N + 2, device=DEV)[:, :N]
         want = a.double() @ b2.double()
-        got = train_ops._mm_nn(a, b2)
+        got = tcommon._mm_nn(a, b2)
         assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * K ** 0.5
         c = torch.randn(M, N, device=DEV)
         want = a.double().t() @ c.double()
-        got = train_ops._tn_matmul(a, c)
+        got = tcommon._tn_matmul(a, c)
         assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) * M ** 0.5
 
 
@@ -226,8 +227,8 @@ def test_edge_block_train_matches_torch(B, O, P, cin, dims):
     nf2 = nf1.detach().clone().requires_grad_(True)
     av = torch.randn(B, O, P, 10, device=DEV)
     y1 = (a2_ref(a1_ref(av)) * pt_ref(nf1)).max(dim=2).values
-    assert train_ops.edge_block_supported(list(pt_new), [a1_new[0], a2_new[0]], nf2)
-    y2 = train_ops.edge_block_train(nf2, av, list(pt_new), [a1_new[0], a2_new[0]])
+    assert tedge.edge_block_supported(list(pt_new), [a1_new[0], a2_new[0]], nf2)
+    y2 = tedge.edge_block_train(nf2, av, list(pt_new), [a1_new[0], a2_new[0]])
     s = max(1.0, float(y1.detach().abs().max()))
     assert float((y1 - y2).abs().max()) <= 3e-5 * s
     g = torch.randn_like(y1)
@@ -257,7 +258,7 @@ def test_pack_linear_layouts(C, cin):
     torch.manual_seed(C * 1000 + cin)
     W = torch.randn(C, cin, device=DEV)
     b = torch.randn(C, device=DEV)
-    K, ldw, nwp, nwb = train_ops.packed_sizes(C, cin)
+    K, ldw, nwp, nwb = tcommon.packed_sizes(C, cin)
     Wp, Bp = torch.full((nwp,), 7.0, device=DEV), torch.full((ldw,), 7.0, device=DEV)
     Wb, Wg = torch.full((nwb,), 7.0, device=DEV), torch.full((nwb,), 7.0, device=DEV)
     rc = lib.gridgcn_pack_linear(_ptr(W), _ptr(b), C, cin, 0, cin, 0, _ptr(Wp), _ptr(Bp), _ptr(Wb),
@@ -266,15 +267,15 @@ def test_pack_linear_layouts(C, cin):
     rWp, rBp, rK, rldw, _ = pack_conv_layer(W.t(), b)
     assert (rK, rldw) == (K, ldw)
     assert torch.equal(Wp, rWp.reshape(-1)) and torch.equal(Bp, rBp)
-    assert torch.equal(Wb, train_ops.pack_tiles(W).reshape(-1))
-    assert torch.equal(Wg, train_ops.pack_groups(W))
+    assert torch.equal(Wb, tcommon.pack_tiles(W).reshape(-1))
+    assert torch.equal(Wg, tcommon.pack_groups(W))
     # rotated + zero padded columns == packing the explicitly permuted matrix
     if cin > 3:
         cinp = (cin + 7) & ~7
         Wperm = torch.zeros(C, cinp, device=DEV)
         Wperm[:, :cin - 3] = W[:, 3:]
         Wperm[:, cin - 3:cin] = W[:, :3]
-        K2, ldw2, nwp2, nwb2 = train_ops.packed_sizes(C, cinp)
+        K2, ldw2, nwp2, nwb2 = tcommon.packed_sizes(C, cinp)
         outs = [torch.full((n,), 7.0, device=DEV) for n in (nwp2, nwb2, nwb2, cinp * ldw2)]
         refs = [torch.full((n,), 7.0, device=DEV) for n in (nwp2, nwb2, nwb2, cinp * ldw2)]
         for src, rot, cw, dst in ((W, 3, cin, outs), (Wperm, 0, cinp, refs)):
@@ -296,29 +297,29 @@ def test_gemm_small_matches_torch(R, Cf, C0, rot):
     src = torch.randn(R, 4 + Cf, device=DEV)
     W0 = torch.randn(C0, rot + Cf, device=DEV)
     feat, Wf = src[:, 4:], W0[:, rot:]
-    Y = train_ops._gemm_small(0, feat, Wf, torch.empty(R, C0, device=DEV), R, C0, Cf)
+    Y = tcommon._gemm_small(0, feat, Wf, torch.empty(R, C0, device=DEV), R, C0, Cf)
     ref = feat.double() @ Wf.double().t()
     assert float((Y - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * Cf ** 0.5
     if C0 % 8 == 0:
         dY = torch.randn(R, C0, device=DEV)
         g = torch.full((R, 4 + Cf), 7.0, device=DEV)
-        train_ops._gemm_small(1, dY, Wf, g[:, 4:], R, Cf, C0, zero_left=4)
+        tcommon._gemm_small(1, dY, Wf, g[:, 4:], R, Cf, C0, zero_left=4)
         ref = dY.double() @ Wf.double()
         assert float((g[:, 4:] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * C0 ** 0.5
         assert float(g[:, :4].abs().max()) == 0.0
     dY = torch.randn(R, C0, device=DEV)
     dW = torch.full((C0, rot + Cf), 7.0, device=DEV)
-    train_ops._tn_matmul(dY, feat, out=dW[:, rot:])
+    tcommon._tn_matmul(dY, feat, out=dW[:, rot:])
     ref = dY.double().t() @ feat.double()
     assert float((dW[:, rot:] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * R ** 0.5
     assert rot == 0 or bool((dW[:, :rot] == 7.0).all())
     G = torch.randn(R, 4, device=DEV)
-    t = train_ops._tn_matmul(Y, G)
+    t = tcommon._tn_matmul(Y, G)
     ref = Y.double().t() @ G.double()
     assert t.shape == (C0, 4) and float((t - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * R ** 0.5
     # bit-reproducible (fixed summation order), and the workspace's tickets are back at zero
     for _ in range(3):
-        assert torch.equal(t, train_ops._tn_matmul(Y, G))
+        assert torch.equal(t, tcommon._tn_matmul(Y, G))
 
 
 @pytest.mark.parametrize("ncent,P", [(655, 5), (64, 7), (2000, 5), (33, 1), (4096, 5), (70000, 5), (13, 3)])
@@ -537,7 +538,7 @@ def test_linear_bwd_fused128_matches_separate_kernels(E, cin, prev_bn, nbn):
     mean, rstd = rnd(C) * 0.1, rnd(C).abs() + 0.5
     sums = (rnd(2 * C) * 1e-3 * E).double()
     Wt = rnd(C, cin) * 0.1
-    Wb, Wg = train_ops.pack_tiles(Wt), train_ops.pack_groups(Wt)
+    Wb, Wg = tcommon.pack_tiles(Wt), tcommon.pack_groups(Wt)
     Wdx = torch.empty(C * 32 * (4 if cin == 128 else 8), device=DEV)
     st = _stream(Z)
     assert lib.gridgcn_pack_linear(_ptr(Wt), None, C, cin, 0, cin, cin, None, None, None, None, None, _ptr(Wdx), st) == 0
@@ -602,21 +603,21 @@ def test_tn_matmul_tall_product_bounded_workspace():
     a, b = torch.randn(R, m, device=DEV), torch.randn(R, k, device=DEV)
     lib.gridgcn_gemm_small_workspace_bytes(m, k, R, ctypes.byref(n))
     assert n.value <= (17 << 20)
-    t = train_ops._tn_matmul(a, b)
+    t = tcommon._tn_matmul(a, b)
     ref = a.double().t() @ b.double()
     assert float((t - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * R ** 0.5
-    assert torch.equal(t, train_ops._tn_matmul(a, b))
+    assert torch.equal(t, tcommon._tn_matmul(a, b))
 
 
 def test_pack_cache_batch_launch_equals_single_packs():
-    """train_ops.PACKS: the one-launch rebuild of every layout of a module
+    """tcommon.PACKS: the one-launch rebuild of every layout of a module
     (gridgcn_pack_linear_batch) writes, bit for bit, what the per-layer gridgcn_pack_linear writes;
     after it each entry serves ONE lookup without a launch, every other lookup packs on its own."""
     from grid_gcn_amd import _lib
     from grid_gcn_amd.ops import _stream
     lib = _lib.load()
     torch.manual_seed(5)
-    cache = train_ops._PackCache()
+    cache = tcommon._PackCache()
     shapes = [(32, 11, 3, 16, 0), (64, 32, 0, 32, 32), (128, 131, 3, 136, 131),
               (256, 128, 0, 128, 128), (13, 128, 0, 128, 128), (128, 256, 0, 256, 256)]
     holder = torch.nn.Module()
@@ -626,7 +627,7 @@ def test_pack_cache_batch_launch_equals_single_packs():
         b = torch.nn.Parameter(torch.randn(C, device=DEV))
         holder.register_parameter("w%d" % i, W)
         holder.register_parameter("b%d" % i, b)
-        K, ldw, nwp, nwb = train_ops.packed_sizes(C, cin)
+        K, ldw, nwp, nwb = tcommon.packed_sizes(C, cin)
         Cp = (C + 7) & ~7
         nt = (ndx + 31) // 32
         ntv = 1 if nt <= 1 else 2 if nt <= 2 else 4 if nt <= 4 else 8
@@ -691,7 +692,7 @@ def test_softmax_ce_matches_torch(E, C):
     x2 = x1.detach().clone().requires_grad_(True)
     lab = torch.randint(0, C, (E,), device=DEV)
     l1 = F.cross_entropy(x1, lab, ignore_index=0, reduction="mean")
-    l2 = train_ops.softmax_ce(x2, lab, 0)
+    l2 = thead.softmax_ce(x2, lab, 0)
     assert abs(float(l1) - float(l2)) <= 2e-6 * max(1.0, abs(float(l1)))
     (l1 * 1.7).backward()
     (l2 * 1.7).backward()
@@ -710,13 +711,13 @@ def test_linear_plain_and_loss_match_torch(E, cin, C):
     x1 = torch.randn(E, cin, device=DEV).requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
     lab = torch.randint(0, C, (E,), device=DEV)
-    assert train_ops.linear_plain_supported(x2, lin2)
+    assert thead.linear_plain_supported(x2, lin2)
     y1 = lin1(x1)
-    y2 = train_ops.linear_plain_train(x2, lin2)
+    y2 = thead.linear_plain_train(x2, lin2)
     assert y2.shape == y1.shape
     assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))
     l1 = F.cross_entropy(y1, lab, ignore_index=0, reduction="mean")
-    l2 = train_ops.softmax_ce(y2, lab, 0)
+    l2 = thead.softmax_ce(y2, lab, 0)
     assert abs(float(l1) - float(l2)) <= 1e-5
     l1.backward()
     l2.backward()
@@ -732,7 +733,7 @@ def test_linear_plain_and_loss_match_torch(E, cin, C):
     lin3 = copy.deepcopy(lin1)
     lin3.zero_grad()
     g = torch.randn(E, C, device=DEV)
-    train_ops.linear_plain_train(x3, lin3).backward(g)
+    thead.linear_plain_train(x3, lin3).backward(g)
     x4 = x1.detach().clone().requires_grad_(True)
     lin1.zero_grad()
     lin1(x4).backward(g)
@@ -757,7 +758,7 @@ def test_mlp_eval_matches_modules(E, cin, dims):
     x = torch.randn(E, cin, device=DEV) * 1.5
     with torch.no_grad():
         y1 = ref(x)
-        y2 = train_ops.mlp_bn_relu_eval(x, list(ref))
+        y2 = teval.mlp_bn_relu_eval(x, list(ref))
     assert y1.shape == y2.shape
     assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))
 
@@ -769,7 +770,7 @@ def test_unsupported_width_falls_to_modules():
     x = torch.randn(10, 8, device=DEV)
     for m in (torch.nn.Sequential(ConvBNReLU(8, 64, use_bn=False)), mlp(8, [48])):
         m = m.to(DEV).train()
-        assert not train_ops.supported(list(m), x) and not train_ops.wide_supported(list(m), x)
+        assert not tcommon.supported(list(m), x) and not tmlp.wide_supported(list(m), x)
         import grid_gcn_amd.gridconv as gcv
         gcv._warned_shapes.clear()
         with pytest.warns(RuntimeWarning):
@@ -780,7 +781,7 @@ def test_unsupported_width_falls_to_modules():
                                         (700, 8, [768]), (2000, 128, [512])])
 def test_wide_stack_rocblas_plus_bn_kernels_matches_stock(E, cin, dims):
     """stacks beyond the MFMA kernels' widths (the 512-wide last layer of the classifier and of the
-    200k-point workload): rocBLAS GEMMs + this library's BatchNorm kernels (train_ops.mlp_wide_train,
+    200k-point workload): rocBLAS GEMMs + this library's BatchNorm kernels (tmlp.mlp_wide_train,
     with the supported sub-runs still on the MFMA chain) == the stock modules: forward, input and
     parameter gradients, running statistics."""
     import copy
@@ -792,7 +793,7 @@ def test_wide_stack_rocblas_plus_bn_kernels_matches_stock(E, cin, dims):
             m.weight.data.uniform_(0.5, 1.5)
             m.bias.data.normal_(0, 0.3)
     new = copy.deepcopy(ref)
-    assert not train_ops.supported(list(new), torch.empty(1, cin, device=DEV))
+    assert not tcommon.supported(list(new), torch.empty(1, cin, device=DEV))
     x1 = (torch.randn(E, cin, device=DEV) * 1.5).requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
     y1 = ref(x1)
@@ -819,7 +820,7 @@ def test_wide_stack_rocblas_plus_bn_kernels_matches_stock(E, cin, dims):
                                              (333, 64, [64], 13, 0.3), (4097, 256, [128, 128], 21, 0.0)])
 def test_head_train_matches_torch(E, cin, dims, C2, p):
     """fc1 chain -> Dropout(p) -> fc2 as one op (dropout folded into the neighbouring kernels)
-    against the stock modules with the SAME mask (train_ops.dropout_mask regenerates it)."""
+    against the stock modules with the SAME mask (thead.dropout_mask regenerates it)."""
     torch.manual_seed(E + cin + C2)
     ref = mlp(cin, dims).to(DEV).train()
     for m in ref.modules():
@@ -831,8 +832,8 @@ def test_head_train_matches_torch(E, cin, dims, C2, p):
     x1 = (torch.randn(E, cin, device=DEV) * 1.5).requires_grad_(True)
     x2 = x1.detach().clone().requires_grad_(True)
     seed = 987654321012345 + E
-    assert train_ops.head_supported(x2, list(new), lin2)
-    mask = train_ops.dropout_mask(E, dims[-1], p, seed, DEV)
+    assert thead.head_supported(x2, list(new), lin2)
+    mask = thead.dropout_mask(E, dims[-1], p, seed, DEV)
     keep = float((mask > 0).float().mean())
     assert abs(keep - (1.0 - p)) < 0.01, keep                  # the hash drops a fraction p
     import numpy as np
@@ -841,9 +842,9 @@ def test_head_train_matches_torch(E, cin, dims, C2, p):
         m01 = (mask > 0).float()
         assert abs(float((m01[:, 1:] * m01[:, :-1]).mean()) - (1 - p) ** 2) < 0.01
         assert abs(float((m01[1:] * m01[:-1]).mean()) - (1 - p) ** 2) < 0.01
-        assert not torch.equal(mask, train_ops.dropout_mask(E, dims[-1], p, seed + 1, DEV))
+        assert not torch.equal(mask, thead.dropout_mask(E, dims[-1], p, seed + 1, DEV))
     y1 = lin1(ref(x1) * mask)
-    y2 = train_ops.head_train(x2, list(new), p, lin2, seed)
+    y2 = thead.head_train(x2, list(new), p, lin2, seed)
     assert y1.shape == y2.shape
     assert float((y1 - y2).abs().max()) <= 2e-5 * max(1.0, float(y1.abs().max()))
     g = torch.randn_like(y1)
@@ -870,7 +871,7 @@ def test_head_train_matches_torch(E, cin, dims, C2, p):
 
 
 def test_head_fused_dropout_equals_stored_dropout(monkeypatch):
-    """Dropout evaluated inside fc2's forward / dW kernels (train_ops.OPT.FUSE_DROPOUT) against the path that
+    """Dropout evaluated inside fc2's forward / dW kernels (OPT.FUSE_DROPOUT) against the path that
     stores the dropped activation: the same mask bit for bit, so outputs and gradients agree to rounding."""
     torch.manual_seed(11)
     E, C, C2, p, seed = 40003, 128, 21, 0.5, 1234567890123
@@ -880,10 +881,10 @@ def test_head_fused_dropout_equals_stored_dropout(monkeypatch):
     g = torch.randn(E, C2, device=DEV)
     out = []
     for fuse in (True, False):
-        monkeypatch.setattr(train_ops.OPT, "FUSE_DROPOUT", fuse)
+        monkeypatch.setattr(OPT, "FUSE_DROPOUT", fuse)
         n2, l2 = copy.deepcopy(net), copy.deepcopy(lin)
         xi = x.clone().requires_grad_(True)
-        y = train_ops.head_train(xi, list(n2), p, l2, seed)
+        y = thead.head_train(xi, list(n2), p, l2, seed)
         y.backward(g)
         out.append((y.detach(), xi.grad, l2.weight.grad, l2.bias.grad, [q.grad for q in n2.parameters()]))
     (ya, xa, wa, ba, pa), (yb, xb, wb, bb, pb) = out
@@ -967,7 +968,7 @@ def test_att_bwd_fused_equals_separate_kernels(ncent, P, cin, C, sparse):
     gval = rnd(ncent, C)
     dY = rnd(E, C)
     W = rnd(C, cin)
-    Wb = train_ops.pack_tiles(W)
+    Wb = tcommon.pack_tiles(W)
     Wdx = torch.empty(C * 32, device=DEV)
     _lib.check(lib.gridgcn_pack_linear(_ptr(W), None, C, cin, 0, cin, cin, None, None, None, None,
                                        None, _ptr(Wdx), _stream(W)), "pack")
@@ -1004,7 +1005,7 @@ def test_bf16_mlp_precision_mode_close_to_fp32():
     Tolerance of the variant (NOT the parity path, which stays fp32): output of a 3-layer
     conv+BN+ReLU stack within 2e-2 * max|y| of the fp32 kernels, input and weight gradients within
     1e-1 in relative L2 norm (measured: 6e-2 on the input gradient); and the switch really changes the arithmetic (the outputs differ)."""
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import common as tcommon, mlp as tmlp
     from grid_gcn_amd.gridconv import mlp
     torch.manual_seed(11)
     layers = mlp(136, [128, 128, 256]).to(DEV).train()
@@ -1012,17 +1013,17 @@ def test_bf16_mlp_precision_mode_close_to_fp32():
     res = {}
     try:
         for mode in ("fp32", "bf16"):
-            train_ops.set_mlp_precision(mode)
-            assert train_ops.get_mlp_precision() == mode
+            tcommon.set_mlp_precision(mode)
+            assert tcommon.get_mlp_precision() == mode
             for l in layers:
                 l.zero_grad()
             xi = x.clone().requires_grad_(True)
-            y = train_ops.mlp_bn_relu_train(xi, list(layers))
+            y = tmlp.mlp_bn_relu_train(xi, list(layers))
             (y * y).sum().backward()
             res[mode] = (y.detach().clone(), xi.grad.clone(),
                          [l.lin.weight.grad.clone() for l in layers])
     finally:
-        train_ops.set_mlp_precision("fp32")
+        tcommon.set_mlp_precision("fp32")
     y32, y16 = res["fp32"][0], res["bf16"][0]
     assert float((y32 - y16).abs().max()) > 0.0
     assert float((y32 - y16).abs().max()) <= 2e-2 * float(y32.abs().max())
@@ -1038,7 +1039,7 @@ def test_bf16_mode_wide_layer_close_to_fp32():
     """a 512-wide layer (256-column slices of the register-direct kernels) in the bf16 contraction mode:
     same stated tolerance as the narrow stacks above (cfg5's last layer; in fp32-only form it fell to the
     small-GEMM kernels in this mode: 27 instead of 20 ms per cfg5 step)"""
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import common as tcommon, mlp as tmlp
     from grid_gcn_amd.gridconv import mlp
     torch.manual_seed(3)
     net = mlp(128, [512, 256]).to(DEV).train()
@@ -1046,15 +1047,15 @@ def test_bf16_mode_wide_layer_close_to_fp32():
     res = {}
     try:
         for mode in ("fp32", "bf16"):
-            train_ops.set_mlp_precision(mode)
+            tcommon.set_mlp_precision(mode)
             n2 = copy.deepcopy(net)
             xx = x.clone().requires_grad_(True)
-            assert train_ops.wide_supported(list(n2), xx)
-            y = train_ops.mlp_wide_train(xx, list(n2))
+            assert tmlp.wide_supported(list(n2), xx)
+            y = tmlp.mlp_wide_train(xx, list(n2))
             y.square().mean().backward()
             res[mode] = (y.detach(), xx.grad, [p.grad for p in n2.parameters()])
     finally:
-        train_ops.set_mlp_precision("fp32")
+        tcommon.set_mlp_precision("fp32")
     rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
     assert rel(res["bf16"][0], res["fp32"][0]) <= 2e-2
     assert rel(res["bf16"][1], res["fp32"][1]) <= 1e-1
@@ -1070,7 +1071,8 @@ def test_bf16_mode_whole_model_loss_and_gradient_direction():
     0.4 % perturbation of the pair features flips the arg-max of the neighbour max-pool in a fraction
     of the (centre, channel) pairs, which re-routes their gradient to another edge."""
     import copy
-    from grid_gcn_amd import model, synth, train_ops
+    from grid_gcn_amd import model, synth
+    from grid_gcn_amd.train import common as tcommon
     torch.manual_seed(3)
     cfg = dict(model.SEG_81920, dropout=0.0)
     net = model.GGCNSeg(cfg, fixed_seed=True).to(DEV).train()
@@ -1082,14 +1084,14 @@ def test_bf16_mode_whole_model_loss_and_gradient_direction():
     res = {}
     try:
         for mode in ("fp32", "bf16"):
-            train_ops.set_mlp_precision(mode)
+            tcommon.set_mlp_precision(mode)
             net.load_state_dict(state)
             net.zero_grad()
             loss = model.seg_loss(net(x, n), lab)
             loss.backward()
             res[mode] = (float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double())
     finally:
-        train_ops.set_mlp_precision("fp32")
+        tcommon.set_mlp_precision("fp32")
     a, b = res["fp32"], res["bf16"]
     assert a[0] != b[0]
     assert abs(a[0] - b[0]) < 1e-3 * abs(a[0])
@@ -1099,13 +1101,15 @@ def test_bf16_mode_whole_model_loss_and_gradient_direction():
 
 def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     """bf16 mode with the [E, C] pre-activation of the second attention conv STORED as bf16
-    (train_ops.OPT.Z16_STORAGE: written by gridgcn_linear_fwd_direct_ld zfmt 1, read by
+    (OPT.Z16_STORAGE: written by gridgcn_linear_fwd_direct_ld zfmt 1, read by
     gridgcn_pairmax_fwd_src_z and the fused attention backward) against the same mode with fp32
     storage.  Stated tolerance of the variant: aggregate within 1e-2 * max|y| (one bf16 rounding of a
     pre-activation whose BatchNorm+ReLU+product follow), every gradient within 5e-2 in relative L2
     norm (a few arg-max flips re-route single entries)."""
     import copy
-    from grid_gcn_amd import ops, train_ops
+    from grid_gcn_amd import ops
+    from grid_gcn_amd.train import common as tcommon
+    from grid_gcn_amd.train.options import OPT
     from grid_gcn_amd.gridconv import SubGUpdate
     torch.manual_seed(21)
     gen = torch.Generator().manual_seed(5)
@@ -1118,16 +1122,16 @@ def test_bf16_storage_of_attention_tensor_close_to_fp32_storage(monkeypatch):
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
     g = torch.randn(B, O, 128, generator=gen).to(DEV)
     outs = []
-    monkeypatch.setattr(train_ops.OPT, "NOZ_IN_BF16", False)        # (this shape would take the Z2-free pair: next test)
+    monkeypatch.setattr(OPT, "NOZ_IN_BF16", False)        # (this shape would take the Z2-free pair: next test)
     try:
-        train_ops.set_mlp_precision("bf16")
+        tcommon.set_mlp_precision("bf16")
         for net, src, z16 in ((ref, src1, False), (new, src2, True)):
-            monkeypatch.setattr(train_ops.OPT, "Z16_STORAGE", z16)
+            monkeypatch.setattr(OPT, "Z16_STORAGE", z16)
             y = net.forward_src(cent, src, nebidx, None)
             y.backward(g)
             outs.append((y.detach(), src.grad.clone(), [p.grad.clone() for p in net.parameters()]))
     finally:
-        train_ops.set_mlp_precision("fp32")
+        tcommon.set_mlp_precision("fp32")
     (y0, s0, p0), (y1, s1, p1) = outs
     assert float((y0 - y1).abs().max()) > 0.0                       # the storage really changed
     assert float((y0 - y1).abs().max()) <= 1e-2 * float(y0.abs().max())
@@ -1188,7 +1192,8 @@ def test_bf16_mode_takes_the_z2_free_attention_pair_where_it_applies(monkeypatch
     same inputs, the variant must be no farther away than plain bf16 mode is (output: 1.2 x in max norm; gradients:
     1.5 x in relative L2 norm -- single arg-max flips move entries either way), and no [E, 128] tensor is saved."""
     import copy
-    from grid_gcn_amd import train_ops
+    from grid_gcn_amd.train import common as tcommon
+    from grid_gcn_amd.train.options import OPT
     from grid_gcn_amd.gridconv import SubGUpdate
     torch.manual_seed(22)
     gen = torch.Generator().manual_seed(6)
@@ -1199,11 +1204,11 @@ def test_bf16_mode_takes_the_z2_free_attention_pair_where_it_applies(monkeypatch
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
     g = torch.randn(B, O, 128, generator=gen).to(DEV)
     outs = []
-    monkeypatch.setattr(train_ops.OPT, "Z16_STORAGE", False)
+    monkeypatch.setattr(OPT, "Z16_STORAGE", False)
     try:
         for mode, nzb in (("fp32", True), ("bf16", False), ("bf16", True)):
-            train_ops.set_mlp_precision(mode)
-            monkeypatch.setattr(train_ops.OPT, "NOZ_IN_BF16", nzb)
+            tcommon.set_mlp_precision(mode)
+            monkeypatch.setattr(OPT, "NOZ_IN_BF16", nzb)
             net, src = copy.deepcopy(net0), src0.clone().requires_grad_(True)
             saved = []
             with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(tuple(t.shape)), t)[1], lambda t: t):
@@ -1212,7 +1217,7 @@ def test_bf16_mode_takes_the_z2_free_attention_pair_where_it_applies(monkeypatch
             y.backward(g)
             outs.append((y.detach(), src.grad.clone(), [p.grad.clone() for p in net.parameters()]))
     finally:
-        train_ops.set_mlp_precision("fp32")
+        tcommon.set_mlp_precision("fp32")
     (yf, sf, pf), (yb, sb, pb), (yn, sn, pn) = outs
     assert float((yb - yn).abs().max()) > 0.0
     assert float((yn - yf).abs().max()) <= 1.2 * float((yb - yf).abs().max())

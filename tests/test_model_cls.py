@@ -41,8 +41,91 @@ def test_cls_model_hip_index_ops_match_oracle_path():
         net_gpu.load_state_dict(net.state_dict())
         net_gpu = net_gpu.to("cuda:0")
         got = net_gpu(x.to("cuda:0"), n.to("cuda:0")).cpu()
-    # identical neighbour sets (bit-exact index ops) -> only fp32 GEMM order differs
-    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-3, atol=2e-3)
+    # identical neighbour sets (bit-exact index ops) -> only fp32 GEMM order differs: the distance is MEASURED
+    # (GG_PARITY_REPORT -> profiles/r6_float_parity.txt) and the bar is 3 x that, relative to max(1, max|logit|)
+    scale = max(1.0, float(want.abs().max()))
+    dist = float((got - want).abs().max()) / scale
+    from conftest import parity_report
+    parity_report("model cls eval (4 x 1024) HIP path vs CPU model on oracle index ops: max|dlogit| = %.3e * "
+                  "max(1, max|logit| = %.3g)" % (dist, float(want.abs().max())))
+    assert dist <= CLS_EVAL_BAR, dist
+
+
+# TODO(r6, after the first GPU session): 3 x the distances the two eval tests print into GG_PARITY_REPORT
+# (relative to max(1, max|logit|)); until then the round-5 bar
+CLS_EVAL_BAR = 2e-3
+
+
+@pytest.mark.gpu
+def test_cls_cfg2_batch32_gridify_bit_exact_and_eval_logits():
+    """BASELINE configs[1] at its REAL batch: 32 clouds x 1024 points (VERDICT r5 10a -- the index kernels are
+    parameterised by B: one workgroup per cloud in gg_k_small_build, XCD placement b mod 8).  The three Gridify
+    layers of the classifier, chained as the model chains them, byte for byte against the C oracle; then the
+    evaluation logits of the whole net against the CPU model on the oracle's index ops."""
+    from grid_gcn_amd import ops
+    from oracle import oracle as orc
+    cfg = synth.CLS_MODELNET40
+    data, npn = synth.make_batch(32, 1024, "ball")
+    npn = npn.copy()
+    npn[5, 0], npn[17, 0], npn[31, 0] = 1000, 513, 1          # ragged clouds inside the batch
+    d, n = data, npn
+    for l in range(3):
+        kw = synth.gridify_kwargs(cfg, l, seed=3 + l)
+        want = orc.gridify(d, n, **kw)
+        got = [t.cpu().numpy() for t in ops.Gridify(torch.from_numpy(d).to("cuda:0"),
+                                                     torch.from_numpy(n).to("cuda:0"), **kw)]
+        for j, (g, w) in enumerate(zip(got, want)):
+            assert g.tobytes() == w.tobytes(), "layer %d output %d" % (l, j)
+        d, n = want[2], want[4]
+    torch.manual_seed(1)
+    net = model_cls.GGCNCls(index_ops=OracleIndexOps).eval()
+    x, nn_ = _inputs(32, 1024)
+    with torch.no_grad():
+        want = net(x, nn_)
+        net_gpu = model_cls.GGCNCls().eval()
+        net_gpu.load_state_dict(net.state_dict())
+        net_gpu = net_gpu.to("cuda:0")
+        got = net_gpu(x.to("cuda:0"), nn_.to("cuda:0")).cpu()
+    scale = max(1.0, float(want.abs().max()))
+    dist = float((got - want).abs().max()) / scale
+    from conftest import parity_report
+    parity_report("model cls eval (32 x 1024, cfg2's batch) HIP path vs CPU model on oracle index ops: "
+                  "max|dlogit| = %.3e * max(1, max|logit| = %.3g)" % (dist, float(want.abs().max())))
+    assert dist <= CLS_EVAL_BAR, dist
+
+
+@pytest.mark.gpu
+def test_cls_cfg2_batch32_training_step_matches_stock_modules():
+    """one fwd + bwd of GGCNCls at cfg2's batch of 32 (the size bench.py --config cfg2 times): the hand-written
+    training kernels against the stock PyTorch modules on the same HIP index outputs."""
+    torch.manual_seed(0)
+    cfg = dict(model_cls.CLS_MN40, dropout=0.0)
+    net = model_cls.GGCNCls(cfg, fixed_seed=True).to("cuda:0").train()
+    x, n = _inputs(32, 1024)
+    x, n = x.to("cuda:0"), n.to("cuda:0")
+    lab = torch.randint(0, 40, (32,), device="cuda:0")
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = []
+    for mfma in (True, False):
+        net.load_state_dict(state)
+        net.zero_grad(set_to_none=True)
+        for l in net.layers:
+            l.mfma_train = mfma
+        loss = model_cls.cls_loss(net(x, n), lab)
+        loss.backward()
+        res.append((float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()])))
+    dl = abs(res[0][0] - res[1][0]) / max(1.0, abs(res[1][0]))
+    a, b = res[0][1].double(), res[1][1].double()
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    rel = float((a - b).norm() / b.norm())
+    from conftest import parity_report
+    parity_report("model cls (32 x 1024, cfg2's batch) HIP kernels vs stock fp32 modules: |dloss|/loss %.3e  "
+                  "1-cos(grad) %.3e  rel-L2(grad) %.3e" % (dl, 1.0 - cos, rel))
+    assert torch.isfinite(res[0][1]).all()
+    # bars as the 8-cloud test below until measured (this net is discretely sensitive at fp32 round-off: see there)
+    assert dl < 2e-6, dl
+    assert 1.0 - cos < 3.6e-5, cos
+    assert rel < 1.5e-2, rel
 
 
 @pytest.mark.gpu
@@ -91,7 +174,8 @@ def test_cls_edge_block_kernels_match_stock_modules(cin, pt, att, O, P):
     per-centre bias -- against the stock modules on the gathered / concatenated tensors:
     forward, every parameter gradient, the source gradient, the running statistics."""
     import copy
-    from grid_gcn_amd import ops, train_ops
+    from grid_gcn_amd import ops
+    from grid_gcn_amd.train import cls as tcls
     DEV = "cuda:0"
     torch.manual_seed(cin + O)
     gen = torch.Generator().manual_seed(cin + P)
@@ -110,7 +194,7 @@ def test_cls_edge_block_kernels_match_stock_modules(cin, pt, att, O, P):
     nebidx = torch.randint(0, Nsrc, (B, O, P), generator=gen, dtype=torch.int32).to(DEV)
     cent = (torch.rand(B, O, 4, generator=gen) * 2 - 1).to(DEV)
     msk = (torch.rand(B, O, generator=gen) > 0.2).float().to(DEV)
-    assert train_ops.edge_block_cls_supported(list(new.pt_mlp), list(new.att1), list(new.att2),
+    assert tcls.edge_block_cls_supported(list(new.pt_mlp), list(new.att1), list(new.att2),
                                               src2, P)
     y1 = ref(cent[..., 0:3], ops.batch_take_g(src1, nebidx), msk)
     y2 = new.forward_src(cent, src2, nebidx, msk)

@@ -1,19 +1,20 @@
-"""train_ops._PackCache bookkeeping (CPU tier: the pack launch itself is replaced by a counter; the
+"""tcommon._PackCache bookkeeping (CPU tier: the pack launch itself is replaced by a counter; the
 descriptor fill is host code of the C library).  ADVICE r3: (1) a Parameter that got new storage must
 not leave its old entry -- dead pointers -- in the cache or in a device table; (2) a re-pack between
 a forward and its backward must not pass silently."""
 import pytest
 import torch
 
-from grid_gcn_amd import _lib, train_ops
+from grid_gcn_amd import _lib
+from grid_gcn_amd.train import common as tcommon
 
 
 @pytest.fixture
 def cache(monkeypatch):
     packs = []
-    monkeypatch.setattr(train_ops._PackCache, "_pack_one",
+    monkeypatch.setattr(tcommon._PackCache, "_pack_one",
                         staticmethod(lambda lib, W, b, *a: packs.append((W.data_ptr(), b.data_ptr()))))
-    c = train_ops._PackCache()
+    c = tcommon._PackCache()
     c.packs = packs
     return c
 
@@ -21,7 +22,7 @@ def cache(monkeypatch):
 def _layer(cout=32, cin=16):
     W = torch.nn.Parameter(torch.randn(cout, cin))
     b = torch.nn.Parameter(torch.randn(cout))
-    sizes = train_ops.packed_sizes(cout, cin)
+    sizes = tcommon.packed_sizes(cout, cin)
     return W, b, (sizes[2], sizes[1], sizes[3], cin * sizes[1], cout * 32)
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of a train_ops switch on the timed cfg4 step: ab.sh <outdir> NAME [reps]
+# A/B of a train/options.py switch on the timed cfg4 step: ab.sh <outdir> NAME [reps]
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/${1:-ab}; NAME=$2; REPS=${3:-2}
 mkdir -p $OUT

@@ -5,23 +5,24 @@ dW, reduce = three launches on 16-64 workgroups), one stream against fork / join
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from grid_gcn_amd import train_ops
+from grid_gcn_amd import _lib
+from grid_gcn_amd.train import common as tcommon
 
 dev = "cuda:0"
 E, cin, C = 2048, 128, 128
 
 
 def make_call(seed):
-    # one gridgcn_linear_bwd call on its own tensors (dense gradient), as train_ops.time_linear_bwd builds it
+    # one gridgcn_linear_bwd call on its own tensors (dense gradient), as ttimers.time_linear_bwd builds it
     import types
-    lib = train_ops._lib.load()
+    lib = _lib.load()
     g = torch.Generator(device=dev).manual_seed(seed)
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
     from grid_gcn_amd.ops import _ptr
     Z, X, dY = rnd(E, C), rnd(E, cin), rnd(E, C)
     v = [rnd(C).abs() + 0.5, rnd(C) * 0.1, rnd(C) * 0.1, rnd(C).abs() + 0.5, rnd(C) * 1e-3, rnd(C) * 1e-3]
     Wt = rnd(C, cin)
-    Wb, Wg = train_ops.pack_tiles(Wt), train_ops.pack_groups(Wt)
+    Wb, Wg = tcommon.pack_tiles(Wt), tcommon.pack_groups(Wt)
     Wdx = torch.empty(C * 32 * 8, device=dev)
     lib.gridgcn_pack_linear(_ptr(Wt), None, C, cin, 0, cin, cin, None, None, None, None, None, _ptr(Wdx),
                             torch.cuda.current_stream().cuda_stream)

@@ -6,10 +6,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from grid_gcn_amd import model, synth, train_ops  # noqa: E402
+from grid_gcn_amd import model, synth  # noqa: E402
+from grid_gcn_amd.train import common as tcommon
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-orig = train_ops._chain_forward
+orig = tcommon._chain_forward
 
 
 def logged(lib, x, params, bns, eps, rot=0, ndx0=0, **kw):
@@ -20,7 +21,7 @@ def logged(lib, x, params, bns, eps, rot=0, ndx0=0, **kw):
     return orig(lib, x, params, bns, eps, rot, ndx0, **kw)
 
 
-train_ops._chain_forward = logged
+tcommon._chain_forward = logged
 dev = torch.device("cuda", 0)
 net = model.GGCNSeg(model.SEG_81920).to(dev).train()
 data, npn = synth.make_batch(B, 81920, "planes")

@@ -26,9 +26,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--summarise":
                     print("%-50s %-11s n=%3d avg=%12.1f KB" % (k, c, v[0], v[1] / v[0]))
     sys.exit(0)
 
-from grid_gcn_amd import train_ops  # noqa: E402
+from grid_gcn_amd.train import timers as ttimers  # noqa: E402
 
-ms = train_ops.time_linear_bwd(655360, 5, 32, 128, iters=3, device="cuda:0", ndx=32, prev_bn=True)   # bench.py's call
+ms = ttimers.time_linear_bwd(655360, 5, 32, 128, iters=3, device="cuda:0", ndx=32, prev_bn=True)   # bench.py's call
 print("ms per call", ms)
-ms = train_ops.time_linear_fwd(655360, 256, 128, iters=3, device="cuda:0")
+ms = ttimers.time_linear_fwd(655360, 256, 128, iters=3, device="cuda:0")
 print("fwd ms per call", ms)

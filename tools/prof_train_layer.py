@@ -8,7 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from grid_gcn_amd import train_ops  # noqa: E402
+from grid_gcn_amd.train import mlp as tmlp  # noqa: E402
 from grid_gcn_amd.gridconv import mlp  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -54,7 +54,7 @@ def run(fn):
 
 nb = 3.0 if not a.nograd_x else 2.0 + (len(dims) - 1) / len(dims)
 if a.only in ("both", "mfma"):
-    tf, tb = run(lambda t: train_ops.mlp_bn_relu_train(t, list(new)))
+    tf, tb = run(lambda t: tmlp.mlp_bn_relu_train(t, list(new)))
     print("mfma : fwd %7.3f ms (%5.1f TF/s)  bwd %7.3f ms (%5.1f TF/s)" % (
         tf, flops_f / tf / 1e9, tb, 2 * flops_f / tb / 1e9))
 if a.only in ("both", "torch"):

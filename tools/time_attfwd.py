@@ -6,7 +6,8 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from grid_gcn_amd import _lib, train_ops
+from grid_gcn_amd import _lib
+from grid_gcn_amd.train import common as tcommon
 from grid_gcn_amd.ops import _ptr, _stream
 from grid_gcn_amd.train.edge import _att_fwd_noz
 
@@ -37,7 +38,7 @@ st = _stream(att16)
 
 
 def old():
-    sa = train_ops._chain_forward(lib, att16, pa, [bn1, bn2], 1e-5)
+    sa = tcommon._chain_forward(lib, att16, pa, [bn1, bn2], 1e-5)
     rc = lib.gridgcn_pairmax_fwd_src_z(_ptr(Ysrc), _ptr(nebidx), _ptr(att16), _ptr(Wg), _ptr(b), B, Nsrc, O,
                                        _ptr(sa.Z[-1]), 0, _ptr(scp), _ptr(shp), _ptr(sa.scale[-1]), _ptr(sa.shift[-1]),
                                        ncent, P, C, _ptr(agg), C, _ptr(amax), _ptr(zsel), st)
@@ -54,7 +55,7 @@ def new():
 
 
 def first_layer():
-    train_ops._chain_forward(lib, att16, pa[:4], [bn1], 1e-5)
+    tcommon._chain_forward(lib, att16, pa[:4], [bn1], 1e-5)
 
 
 def timeit(f, iters=20):

@@ -6,7 +6,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from grid_gcn_amd import _lib, train_ops  # noqa: E402
+from grid_gcn_amd import _lib  # noqa: E402
+from grid_gcn_amd.train import common as tcommon
 from grid_gcn_amd.ops import _ptr, _stream  # noqa: E402
 
 lib = _lib.load()
@@ -20,7 +21,7 @@ for E, cin, C, act in SHAPES:
     X = torch.randn(E, cin, device=dev)
     sc = torch.rand(cin, device=dev) + 0.5 if act else None
     sh = torch.randn(cin, device=dev) * 0.1 if act else None
-    K, ldw, nwp, nwb = train_ops.packed_sizes(C, cin)
+    K, ldw, nwp, nwb = tcommon.packed_sizes(C, cin)
     Wp, Bp = torch.empty(nwp, device=dev), torch.empty(ldw, device=dev)
     Wq = torch.empty(cin * ldw, device=dev)
     lib.gridgcn_pack_linear(_ptr(W), _ptr(b), C, cin, 0, cin, 0, _ptr(Wp), _ptr(Bp), None, None,

@@ -7,7 +7,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from grid_gcn_amd import _lib, train_ops  # noqa: E402
+from grid_gcn_amd import _lib  # noqa: E402
+from grid_gcn_amd.train import timers as ttimers
 
 lib = _lib.load()
 dev = "cuda:0"
@@ -29,6 +30,6 @@ for ncent, P, C in [(8192, 128, 64), (2048, 32, 128), (192, 32, 256), (16384, 64
         call = lambda: lib.gridgcn_pairmax_fwd(p(Zp), p(Za), p(sc[0]), p(sh[0]), p(sc[1]), p(sh[1]), ncent, P, C,  # noqa: E731
                                                p(agg), C, p(amax), p(zsel), st)
         assert call() == 0
-        row.append("%s:%7.1f us" % (ps or "auto", train_ops.median_ms(call, 30, device=dev) * 1e3))
+        row.append("%s:%7.1f us" % (ps or "auto", ttimers.median_ms(call, 30, device=dev) * 1e3))
     lib.gridgcn_set_option(_lib.OPT_PAIRMAX_SPLIT, 0)
     print("ncent %7d P %3d C %3d (%.0f MB)  " % (ncent, P, C, 2 * E * C * 4 / 1e6) + "  ".join(row))
