@@ -45,7 +45,8 @@ EXPORTS = [
     "gridgcn_pairmax_fwd", "gridgcn_pairmax_bwd", "gridgcn_pairmax_bwd_masked",
     "gridgcn_att_bwd_noz_workspace_bytes", "gridgcn_att_bwd_noz", "gridgcn_gemm_bias",
     "gridgcn_att_fwd_noz_workspace_bytes", "gridgcn_att_bn2_moments", "gridgcn_att_pairmax_fwd",
-    "gridgcn_att_pairmax_fwd_supported",
+    "gridgcn_att_pairmax_fwd_supported", "gridgcn_att_bwd_noz_mom_supported", "gridgcn_att_moments_offset",
+    "gridgcn_att_bwd_noz_mom",
     "gridgcn_bn_relu_apply", "gridgcn_bn_relu_bwd_reduce",
     "gridgcn_bn_relu_dropout_apply", "gridgcn_linear_dx",
     "gridgcn_bn_relu_bwd_elemt",
@@ -217,6 +218,12 @@ def load():
     lib.gridgcn_gemm_bias.argtypes = [ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.gridgcn_att_fwd_noz_workspace_bytes.restype = ci
     lib.gridgcn_att_fwd_noz_workspace_bytes.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_att_bwd_noz_mom_supported.restype = ci
+    lib.gridgcn_att_bwd_noz_mom_supported.argtypes = [ll, ci, ci, ci]
+    lib.gridgcn_att_moments_offset.restype = ci
+    lib.gridgcn_att_moments_offset.argtypes = [ll, ci, ci, ctypes.POINTER(cs)]
+    lib.gridgcn_att_bwd_noz_mom.restype = ci
+    lib.gridgcn_att_bwd_noz_mom.argtypes = [vp] * 13 + [ci, ll, ci, ci] + [vp] * 8 + [vp, cs, vp]
     lib.gridgcn_att_bn2_moments.restype = ci
     lib.gridgcn_att_bn2_moments.argtypes = ([vp] * 7 + [ll, ci, ci, ctypes.c_float, ctypes.c_float] + [vp] * 8
                                             + [vp, cs, vp])

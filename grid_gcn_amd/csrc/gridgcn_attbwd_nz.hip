@@ -319,6 +319,13 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz(GGAttNz p)
 // Needs 32-bit byte offsets: E < 2^24 rows, E / P < 2^22 centres (gg_att_nz2_ok); otherwise the first form runs.
 __device__ gg_i32x4 gg_buf_ld4i(gg_rsrc r, unsigned lane_bytes, unsigned uniform_bytes, int aux = 0) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
+//
+// S2IN (round 6): the moments S1 = sum_e a1, S2 = sum_e a1 a1^T are NOT accumulated here -- the Z2-free FORWARD of the
+// same layer has already formed them, in fp64, for the BatchNorm statistics of this conv (gg_k_att_moments,
+// gridgcn_attfwd.hip), and the dense part of dW2 takes them from there (gg_k_att_nz_reduce_fin): 144 MFMAs per tile
+// instead of 160, sixteen accumulator registers and the S1 column sums gone from the loop.  Every other word of the
+// kernel is the <false> form.
+template <bool S2IN>
 __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
 {
     constexpr int C = GG_NZ_C, NJ = 4;
@@ -373,8 +380,10 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
     float a1 = 0.f, a2 = 0.f, a3 = 0.f;
     ggm_f32x16 accw[NJ], accS;
     ggm_zero<NJ>(accw);
+    if constexpr (!S2IN) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) accS[r] = 0.f;
+        for (int r = 0; r < 16; r++) accS[r] = 0.f;
+    }
 
     const int E = (int)p.E, P = p.P;
     const int ntile = (E + 31) >> 5;
@@ -493,8 +502,10 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
 #pragma unroll
             for (int i = 0; i < 4; i++) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(yv[i], mv[i], accx, 0, 0, 0);
         }
+        if constexpr (!S2IN) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) accS = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[r], avr[r], accS, 0, 0, 0);
+            for (int r = 0; r < 16; r++) accS = __builtin_amdgcn_mfma_f32_32x32x2f32(avr[r], avr[r], accS, 0, 0, 0);
+        }
         // dX tile + BatchNorm-backward sums of the layer in front + S1 (rows past the end: a1 = 0, store dropped)
         float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -504,22 +515,24 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
             const float d = avr[r] > 0.f ? dx : 0.f;
             s1 += d;
             s2 = __builtin_fmaf(d, __builtin_fmaf(zpv[r], pr, pc), s2);
-            s3 += avr[r];
+            if constexpr (!S2IN) s3 += avr[r];
         }
         a1 += s1;
         a2 += s2;
-        a3 += s3;
+        if constexpr (!S2IN) a3 += s3;
         cen = cenN;
         pp = ppN;
     }
     // partial tiles: the four waves add up in LDS (fixed order), one [tile][reg][lane] block per workgroup
+    // (S2IN: the four dW^T tiles only; the block stride of `part` stays five tiles)
     {
+        constexpr int NPT = S2IN ? NJ : NJ + 1;
         float *blk = pcs + 64;                         // 5 * 1024 floats over the tile area (4 * 64 * 36)
         __syncthreads();
         for (int w = 0; w < 4; w++) {
             if (wave == w) {
 #pragma unroll
-                for (int j = 0; j < NJ + 1; j++)
+                for (int j = 0; j < NPT; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int idx = (j * 16 + r) * 64 + lane;
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
             __syncthreads();
         }
         float *part = p.part + (size_t)blockIdx.x * (NJ + 1) * 1024;
-        for (int i = tid; i < (NJ + 1) * 1024; i += 256) part[i] = blk[i];
+        for (int i = tid; i < NPT * 1024; i += 256) part[i] = blk[i];
     }
     __syncthreads();
     float *red = lds;                                  // [4 waves][3][32]
@@ -544,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void gg_k_att_bwd_nz2(GGAttNz p)
         }
     }
     __syncthreads();
-    if (tid < 96) {
+    if (tid < (S2IN ? 64 : 96)) {
         const int which = tid >> 5, col = tid & 31;
         float v = 0.f;
         for (int w = 0; w < 4; w++) v += red[(w * 3 + which) * 32 + col];
@@ -602,6 +615,51 @@ __global__ __launch_bounds__(256) void gg_k_att_nz_finish(GGAttNz p, const float
     if (i == 0 && fm1) gg_bn_bwd_fin_write(p.bsums, p.E, C, c, fm1, fm2, fdg, fdb);
 }
 
+// S2IN form: reduce + finish in ONE launch.  Block (j < 4, r) sums the workgroups' partial dW^T values of tile j,
+// register r exactly as gg_k_att_nz_reduce does, and its 64 finishing threads add the dense part of their own element
+//   dW[c][i] += (cz_c + bz_c (b2_c - mu_c)) S1[i] + bz_c sum_k W2[c][k] S2[k][i]
+// from the forward's moments (fp64; mom[r][l] = S2[ggm_row(r, l)][l & 31], mom[1024 + l] = lane l's share of
+// S1[l & 31]: gg_k_att_moments_reduce); block 0 also writes the layer's BatchNorm-backward vectors.
+__global__ __launch_bounds__(1024) void gg_k_att_nz_reduce_fin(GGAttNz p, int nwg, const double *__restrict__ mom,
+                                                               float *__restrict__ dW, float *__restrict__ fm1,
+                                                               float *__restrict__ fm2, float *__restrict__ fdg,
+                                                               float *__restrict__ fdb)
+{
+    constexpr int C = GG_NZ_C;
+    __shared__ float sh[16][64];
+    const int j = blockIdx.x >> 4, r = blockIdx.x & 15;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float v = 0.f;
+    int w = grp;
+    for (; w + 7 * 16 < nwg; w += 8 * 16) {             // (the summation order of gg_k_att_nz_reduce)
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = p.part[((size_t)(w + 16 * u) * 5 + j) * 1024 + r * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (; w < nwg; w += 16) v += p.part[((size_t)w * 5 + j) * 1024 + r * 64 + lane];
+    sh[grp][lane] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int g = 0; g < 16; g++) t += sh[g][lane];
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int c = 32 * j + (lane & 31);
+        const float sc = p.sc[c];
+        const float m1 = (float)(p.bsums[c] / (double)p.E), m2 = (float)(p.bsums[C + c] / (double)p.E);
+        const float bz = -(sc * p.rs[c]) * m2, cz = -(sc * m1);
+        // S2[k][i]: lane i + 32 ((k >> 2) & 1), register (k & 3) + 4 (k >> 3)
+        double acc = 0.0;
+        for (int k = 0; k < GG_NZ_K; k++)
+            acc += (double)p.W2[c * GG_NZ_K + k] * mom[((k & 3) + 4 * (k >> 3)) * 64 + i + 32 * ((k >> 2) & 1)];
+        const double s1i = mom[1024 + i] + mom[1024 + 32 + i];
+        dW[c * GG_NZ_K + i] = t + (float)((double)(cz + bz * (p.b2[c] - p.mu[c])) * s1i + (double)bz * acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + C && fm1)
+        gg_bn_bwd_fin_write(p.bsums, p.E, C, (int)threadIdx.x - 64, fm1, fm2, fdg, fdb);
+}
+
 // GRIDGCN_OPT_ATT_NZ_V2 [1]: the stripped tile loop (identical results); 0 = the round-4 kernel
 static int g_att_nz_v2 = 1;
 void gg_set_att_nz_v2(int v) { g_att_nz_v2 = v ? 1 : 0; }
@@ -618,6 +676,11 @@ static int gg_att_nz_grid(long long E)
 }
 
 bool gg_att_bwd_noz_ok(long long E, int cin, int C) { return cin == GG_NZ_K && C == GG_NZ_C && E >= 32; }
+// the form that takes S1 / S2 from the forward's moments exists for the stripped tile loop only
+bool gg_att_bwd_noz_mom_ok(long long E, int cin, int C, int P)
+{
+    return gg_att_bwd_noz_ok(E, cin, C) && P >= 1 && (E % P) == 0 && gg_att_nz2_ok(E, P);
+}
 
 size_t gg_att_bwd_noz_workspace(long long E)
 {
@@ -629,13 +692,14 @@ int gg_att_bwd_noz(const float *Z1, const float *ps, const float *psh, const flo
                    const float *W2, const float *b2, const float *sc, const float *mu, const float *rs,
                    const double *bsums, const unsigned char *amax, const float *gval, int P, long long E,
                    float *dX, float *dW, float *m1, float *m2, float *dgamma, float *dbeta, double *psums,
-                   double *s1, void *ws, hipStream_t st)
+                   double *s1, void *ws, hipStream_t st, const double *mom)
 {
     if (E < 32 || P < 1 || (E % P)) return 1;
     static GGDevOnce attr_done;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
-        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz2, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
+        if (hipFuncSetAttribute((const void *)gg_k_att_bwd_nz2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 3;
         attr_done = true;
     }
     GGAttNz p;
@@ -645,7 +709,15 @@ int gg_att_bwd_noz(const float *Z1, const float *ps, const float *psh, const flo
     const int nwg = gg_att_nz_grid(E);
     float *S2 = p.part + (size_t)nwg * 5 * 1024;
     const size_t lds = (size_t)(5 * 64 * GG_NZ_WS + 3 * GG_NZ_C + 32 + 64 + 4 * 64 * GG_NZ_TS) * sizeof(float);
-    if (g_att_nz_v2 && gg_att_nz2_ok(E, P)) gg_k_att_bwd_nz2<<<nwg, 256, lds, st>>>(p);
+    if (mom) {
+        // the forward's moments stand in for S1 / S2: no accumulation of them in the tile loop, reduce + finish in one
+        // launch (the stripped tile loop only: callers check gg_att_bwd_noz_mom_ok)
+        if (!gg_att_nz2_ok(E, P)) return 1;
+        gg_k_att_bwd_nz2<true><<<nwg, 256, lds, st>>>(p);
+        gg_k_att_nz_reduce_fin<<<4 * 16, 1024, 0, st>>>(p, nwg, mom, dW, m1, m2, dgamma, dbeta);
+        return hipGetLastError() == hipSuccess ? 0 : 3;
+    }
+    if (g_att_nz_v2 && gg_att_nz2_ok(E, P)) gg_k_att_bwd_nz2<false><<<nwg, 256, lds, st>>>(p);
     else gg_k_att_bwd_nz<<<nwg, 256, lds, st>>>(p);
     gg_k_att_nz_reduce<<<5 * 16, 1024, 0, st>>>(p.part, nwg, dW, S2);
     gg_k_att_nz_finish<<<(GG_NZ_C * GG_NZ_K + 255) / 256, 256, 0, st>>>(p, S2, dW, m1, m2, dgamma, dbeta);

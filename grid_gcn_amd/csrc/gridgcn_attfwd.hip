@@ -406,6 +406,8 @@ static int gg_att_moments_grid(long long E)
     return (int)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
 }
 
+int gg_att_moments_grid_of(long long E) { return gg_att_moments_grid(E); }
+
 bool gg_att_fwd_ok(long long ncent, int O, int P, int cin, int C, int lda, long long rows)
 {
     return P == 5 && cin == 32 && C == 128 && ncent >= 7 && ncent < (1ll << 22) && O >= 6 && lda >= 128 && rows >= 1 &&

@@ -77,7 +77,9 @@ size_t gg_att_bwd_noz_workspace(long long E);
 int gg_att_bwd_noz(const float *, const float *, const float *, const float *, const float *, const float *,
                    const float *, const float *, const float *, const float *, const double *,
                    const unsigned char *, const float *, int, long long, float *, float *, float *, float *,
-                   float *, float *, double *, double *, void *, hipStream_t);
+                   float *, float *, double *, double *, void *, hipStream_t, const double *mom = nullptr);
+bool gg_att_bwd_noz_mom_ok(long long E, int cin, int C, int P);
+int gg_att_moments_grid_of(long long E);                           // gridgcn_attfwd.hip
 int gg_pack_desc_fill(gridgcn_pack_desc *e);
 int gg_pack_linear_batch(const gridgcn_pack_desc *dev, int nlayers, int max_n, hipStream_t st);
 
@@ -705,6 +707,36 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
     const int rc = gg_att_bwd_noz(Z1, pscale, pshift, pmean, prstd, W2, b2, scale, mean, rstd, sums, amax, gval,
                                   P, E, dX, dW, m1, m2, dgamma, dbeta, psums, s1, workspace, (hipStream_t)stream);
     return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_att_bwd_noz_mom_supported(long long E, int cin, int C, int P)
+{
+    return gg_att_bwd_noz_mom_ok(E, cin, C, P) ? 1 : 0;
+}
+
+int gridgcn_att_bwd_noz_mom(const float *Z1, const float *pscale, const float *pshift, const float *pmean,
+                            const float *prstd, const float *W2, const float *b2, const float *scale,
+                            const float *mean, const float *rstd, const double *sums, const uint8_t *amax,
+                            const float *gval, int P, long long E, int cin, int C, const double *moments, float *dX,
+                            float *dW, float *m1, float *m2, float *dgamma, float *dbeta, double *psums,
+                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!Z1 || !pscale || !pshift || !pmean || !prstd || !W2 || !b2 || !scale || !mean || !rstd || !sums ||
+        !amax || !gval || !moments || !dX || !dW || !m1 || !m2 || !dgamma || !dbeta || !psums)
+        return GRIDGCN_EINVAL;
+    if (P < 1 || P > 256 || !gg_att_bwd_noz_mom_ok(E, cin, C, P)) return GRIDGCN_EINVAL;
+    if (!workspace || workspace_bytes < gg_att_bwd_noz_workspace(E)) return GRIDGCN_EWORKSPACE;
+    const int rc = gg_att_bwd_noz(Z1, pscale, pshift, pmean, prstd, W2, b2, scale, mean, rstd, sums, amax, gval,
+                                  P, E, dX, dW, m1, m2, dgamma, dbeta, psums, nullptr, workspace, (hipStream_t)stream,
+                                  moments);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int gridgcn_att_moments_offset(long long E, int cin, int C, size_t *offset_bytes)
+{
+    if (!offset_bytes || E < 1 || E >= (1ll << 25) || cin != 32 || C != 128) return GRIDGCN_EINVAL;
+    *offset_bytes = (size_t)gg_att_moments_grid_of(E) * 17 * 64 * sizeof(double);
+    return GRIDGCN_OK;
 }
 
 int gridgcn_att_fwd_noz_workspace_bytes(long long E, int cin, int C, size_t *bytes)

@@ -58,6 +58,68 @@ def call_seed(seed, forward_no, call_no):
     return (x ^ (x >> 31)) & (2 ** 63 - 1)
 
 
+_SIDE_STREAMS = {}      # device -> the stream of the index operators (OPT.INDEX_SIDE_STREAM), one per process
+
+
+class _IndexAhead:
+    """OPT.INDEX_SIDE_STREAM (round 6; OFF until a GPU session has run tests/test_zz_r6_unverified.py): every index
+    operator of a step -- the Gridify of each down layer, the BallKNN / GridifyUp of each up layer -- depends on point
+    COORDINATES only (ggcn_models_g.py:154-159, :204-210: `data_loc <- cent`), never on features.  They are ~0.2 ms of
+    latency-bound launches on a handful of workgroups each; here everything behind the first Gridify runs on a side
+    stream, in the shadow of the first layer's GridConv kernels, and the main stream waits on an event per result
+    where the reference's graph consumes it.  Inside a captured step the fork and the joins are graph edges.
+    Memory: the results are allocated on the side stream and read on the main one; they stay referenced by the
+    autograd graph until the backward is through, and the next step's fork (side waits for main) orders any reuse
+    of their blocks behind every reader."""
+
+    def __init__(self, net, data, num, fwd_no, sd):
+        cfg, g, ix = net.cfg, net.cfg["grid"], net.ix
+        dev = data.device
+        main = torch.cuda.current_stream(dev)
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        self.main, self.down_res, self.up_res = main, [], []
+        kw = dict(synth.gridify_kwargs(g, 0, net._seed(fwd_no, 0)), **sd)
+        first = ix.Gridify(data.detach().contiguous(), num, **kw)          # (needed at once: on the main stream)
+        self.down_res.append((first, None))
+        side.wait_stream(main)
+        locs, nums = [data, first[2]], [num, first[4]]
+        with torch.cuda.stream(side):
+            for i in range(1, len(net.down)):
+                kw = dict(synth.gridify_kwargs(g, i, net._seed(fwd_no, i)), **sd)
+                r = ix.Gridify(locs[-1].detach().contiguous(), nums[-1], **kw)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.down_res.append((r, ev))
+                locs.append(r[2]); nums.append(r[4])
+            for i in range(len(net.up)):
+                down, upl = locs[-i - 1], locs[-i - 2]
+                downnum, upnum = nums[-i - 1], nums[-i - 2]
+                U = g["up"][i]
+                if cfg["up_neigh_fetch"]:
+                    radius = U["voxel_size"][0] * U["kernel_size"] * 1.7 / 2
+                    nb = ix.BallKNN(upl[..., 0:3].detach(), down[..., 0:3].detach(), downnum, upnum,
+                                    k=U["max_p_grid"], radius=radius)
+                else:
+                    nb, _ = ix.GridifyUp(down.detach().contiguous(), upl.detach().contiguous(), downnum, upnum,
+                                         **synth.gridify_up_kwargs(g, i, net._seed(fwd_no, 16 + i)), **sd)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.up_res.append((nb, ev))
+
+    def down(self, i):
+        r, ev = self.down_res[i]
+        if ev is not None:
+            self.main.wait_event(ev)
+        return r
+
+    def up(self, i):
+        nb, ev = self.up_res[i]
+        self.main.wait_event(ev)
+        return nb
+
+
 class GGCNSeg(nn.Module):
     def __init__(self, cfg=SEG_8192, index_ops=HipIndexOps, seed=0, fixed_seed=False):
         """seed: base of the per-call sampling seeds (training mode redraws the random voxel
@@ -97,7 +159,7 @@ class GGCNSeg(nn.Module):
         self.fc2 = nn.Linear(128, cfg["num_classes"])
         nn.init.xavier_uniform_(self.fc2.weight)
         nn.init.zeros_(self.fc2.bias)
-        # ... and so do fc1/dropout + fc2 (:36-38): thead._HeadTrain
+        # ... and so do fc1/dropout + fc2 (:36-38): train/head.py: _HeadTrain
         self.fused_head = HEAD_KERNELS and FUSED_HEAD and _is_hip(index_ops)
         # indices from the index operators lie in [-1, N-1]: sorted segmented-sum gather backward
         self._take_kw = dict(neighbour_index=True) if _is_hip(index_ops) else {}
@@ -130,7 +192,7 @@ class GGCNSeg(nn.Module):
         B, N, _ = data_xyz.shape
         nd = len(self.down)
         # training on the HIP path: concat / centre mask / zero padding of the layer boundaries in one
-        # launch each (tcommon.cat_mask) instead of 2-4 framework ops
+        # launch each (train/common.py: cat_mask) instead of 2-4 framework ops
         glue = (self.glue_kernels and _is_hip(ix) and self.edge_kernel and data_xyz.is_cuda
                 and data_xyz.dtype == torch.float32 and self.training and torch.is_grad_enabled())
         if glue:
@@ -156,10 +218,16 @@ class GGCNSeg(nn.Module):
                 tcommon.PACKS.prepack(self)   # all weight layouts of the step, one launch
         seed_dev = self._seed_dev()
         sd = dict(seed_dev=seed_dev) if (seed_dev is not None and _is_hip(ix)) else {}
+        ahead = None
+        if glue and OPT.INDEX_SIDE_STREAM and ix is HipIndexOps:
+            ahead = _IndexAhead(self, data, actual_centnum, fwd_no, sd)
         for i, layer in enumerate(self.down):
-            kw = dict(synth.gridify_kwargs(g, i, self._seed(fwd_no, i)), **sd)
-            nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
-                data_loc.detach().contiguous(), nums[-1], **kw)                     # :154-159
+            if ahead is not None:
+                nebidx, nebidxmsk, cent, centmsk, centnum = ahead.down(i)
+            else:
+                kw = dict(synth.gridify_kwargs(g, i, self._seed(fwd_no, i)), **sd)
+                nebidx, nebidxmsk, cent, centmsk, centnum = ix.Gridify(
+                    data_loc.detach().contiguous(), nums[-1], **kw)                 # :154-159
             data_loc = cent
             if self.use_fused():
                 if self.jobs is not None:
@@ -189,7 +257,9 @@ class GGCNSeg(nn.Module):
             down, upl = locs[-i - 1], locs[-i - 2]
             downnum, upnum = nums[-i - 1], nums[-i - 2]
             U = g["up"][i]
-            if cfg["up_neigh_fetch"]:
+            if ahead is not None:
+                nebidx = ahead.up(i)
+            elif cfg["up_neigh_fetch"]:
                 radius = U["voxel_size"][0] * U["kernel_size"] * 1.7 / 2            # :204
                 # (the HIP operator reads the xyz columns of the [B,n,4] rows in place)
                 cont = (lambda t: t) if _is_hip(ix) else (lambda t: t.contiguous())
@@ -263,7 +333,7 @@ def seg_forward_flops(net, B, N):
 
 
 def release_packs(module, _inputs, _output):
-    """forward hook of the three nets: see tcommon._PackCache.release"""
+    """forward hook of the three nets: see train/common.py: _PackCache.release"""
     from .train import common as tcommon
     tcommon.PACKS.release(module)
 

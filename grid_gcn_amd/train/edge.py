@@ -77,11 +77,12 @@ class _EdgeBlockTrain(torch.autograd.Function):
         return (dnf, None, None) + tuple(grads_p) + tuple(grads_a)
 
 
-def _att_bwd_noz(lib, att16, Z1, aS, aH, aM, aR, aWb, aWg, aWx, ndxs, W2, b2, sums_a, amax, ga, P, cwa, st):
+def _att_bwd_noz(lib, att16, Z1, aS, aH, aM, aR, aWb, aWg, aWx, ndxs, W2, b2, sums_a, amax, ga, P, cwa, st, mom=None):
     """backward of the attention chain (10 -> 32 -> 128) of an up layer without the second conv's [E, 128]
     pre-activation: gridgcn_att_bwd_noz for the second conv (dA1, dW2, its BatchNorm vectors, the BatchNorm-
     backward sums of the first layer), then the ordinary chain backward for the first conv.  Returns the
-    chain's gradient list [dW, db, dgamma, dbeta] * 2."""
+    chain's gradient list [dW, db, dgamma, dbeta] * 2.
+    mom: the [17 * 64] fp64 moments (S2, S1) of the forward (_att_fwd_noz), or None: accumulated here."""
     E, dev = att16.shape[0], att16.device
     C, cin = W2.shape
     dA1 = torch.empty((E, cin), dtype=torch.float32, device=dev)
@@ -93,11 +94,18 @@ def _att_bwd_noz(lib, att16, Z1, aS, aH, aM, aR, aWb, aWg, aWx, ndxs, W2, b2, su
     _lib.check(lib.gridgcn_att_bwd_noz_workspace_bytes(E, cin, C, ctypes.byref(nbytes)), "att_bwd_noz_workspace")
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     t_end = OPT.TIMERS.bracket(("linear_bwd", E, cin, C)) if OPT.TIMERS is not None else None
-    rc = lib.gridgcn_att_bwd_noz(_ptr(Z1), _ptr(aS[0]), _ptr(aH[0]), _ptr(aM[0]), _ptr(aR[0]),
-                                 _ptr(W2.detach()), _ptr(b2.detach()), _ptr(aS[1]), _ptr(aM[1]), _ptr(aR[1]),
-                                 _ptr(sums_a), _ptr(amax), _ptr(ga), int(P), E, cin, C, _ptr(dA1), _ptr(dW2),
-                                 _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(psums), _ptr(s1),
-                                 _ptr(ws), nbytes.value, st)
+    if mom is not None:
+        rc = lib.gridgcn_att_bwd_noz_mom(_ptr(Z1), _ptr(aS[0]), _ptr(aH[0]), _ptr(aM[0]), _ptr(aR[0]),
+                                         _ptr(W2.detach()), _ptr(b2.detach()), _ptr(aS[1]), _ptr(aM[1]), _ptr(aR[1]),
+                                         _ptr(sums_a), _ptr(amax), _ptr(ga), int(P), E, cin, C, _ptr(mom), _ptr(dA1),
+                                         _ptr(dW2), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(psums),
+                                         _ptr(ws), nbytes.value, st)
+    else:
+        rc = lib.gridgcn_att_bwd_noz(_ptr(Z1), _ptr(aS[0]), _ptr(aH[0]), _ptr(aM[0]), _ptr(aR[0]),
+                                     _ptr(W2.detach()), _ptr(b2.detach()), _ptr(aS[1]), _ptr(aM[1]), _ptr(aR[1]),
+                                     _ptr(sums_a), _ptr(amax), _ptr(ga), int(P), E, cin, C, _ptr(dA1), _ptr(dW2),
+                                     _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(psums), _ptr(s1),
+                                     _ptr(ws), nbytes.value, st)
     if t_end is not None:
         t_end.record()
     _lib.check(rc, "gridgcn_att_bwd_noz")
@@ -134,6 +142,13 @@ def _att_fwd_noz(lib, att16, pa, bns_a, eps, st):
     sa.Z.append(none); sa.scale.append(vec[0]); sa.shift.append(vec[1])
     sa.mean.append(vec[2]); sa.rstd.append(vec[3])
     sa.Wb.append(none); sa.Wg.append(none); sa.Wdx.append(none); sa.ndx.append(0)
+    # the moments S2 / S1 of the 32-wide activation (fp64, [17 * 64]) stay in the workspace: the backward takes them
+    # from there instead of accumulating them again (OPT.NOZ_BWD_MOMENTS; a view: it keeps the workspace alive)
+    sa.mom = None
+    if OPT.NOZ_BWD_MOMENTS and lib.gridgcn_att_bwd_noz_mom_supported(E, cin, C, 5) == 1:
+        off = ctypes.c_size_t(0)
+        _lib.check(lib.gridgcn_att_moments_offset(E, cin, C, ctypes.byref(off)), "att_moments_offset")
+        sa.mom = ws[off.value:off.value + 17 * 64 * 8].view(torch.float64)
     return sa
 
 
@@ -266,6 +281,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         ctx.dims = (Lp, La, B, Nsrc, Cs, O, P, C0, rot, params[4 * Lp].shape[1], noz)
         ctx.ndx = (sp.ndx, sa.ndx)
         ctx.nz = nz
+        mom = getattr(sa, "mom", None) if nzf else None
+        ctx.mom = mom is not None
         ctx.geo = gsum is not None      # (per-source geo sums of the forward: the backward's geo pass is skipped)
         saZ = list(sa.Z)
         if nz:
@@ -274,7 +291,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             src, nebidx, att16, amax, Ysrc if noz else Z0, vec0, W0, zsel, wgb,
             *sp.Z, *sp.scale, *sp.shift, *sp.mean, *sp.rstd, *sp.Wb, *sp.Wg, *sp.Wdx,
             *saZ, *sa.scale, *sa.shift, *sa.mean, *sa.rstd, *sa.Wb, *sa.Wg, *sa.Wdx,
-            *((pa[4], pa[5]) if nz else ()), *((gsum, gg) if gsum is not None else ()))
+            *((pa[4], pa[5]) if nz else ()), *((gsum, gg) if gsum is not None else ()),
+            *((mom,) if mom is not None else ()))
         ctx.mark_non_differentiable(amax)
         return agg if out is not None else agg.reshape(B, O, C)
 
@@ -297,6 +315,8 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
         W2, b2 = (t[o], t[o + 1]) if nz else (None, None)
         o += 2 if nz else 0
         gsum_f, gg_f = (t[o], t[o + 1]) if ctx.geo else (None, None)
+        o += 2 if ctx.geo else 0
+        mom = t[o] if ctx.mom else None
         dev = src.device
         E, R, Cf, ncent = B * O * P, B * Nsrc, Cs - 4, B * O
         Zl = pZ[-1] if L1 else Z0
@@ -331,7 +351,7 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
             _lib.check(rc, "gridgcn_pairmax_bwd")
             if nz:
                 grads_a = _att_bwd_noz(lib, att16, aZ[0], aS, aH, aM, aR, aWb, aWg, aWx, ctx.ndx[1], W2, b2,
-                                       sums_a, amax, ga, P, cwa, st)
+                                       sums_a, amax, ga, P, cwa, st, mom=mom)
             else:
                 _, grads_a = _chain_backward(lib, att16, aZ, aS, aH, aM, aR, aWb, aWg, aWx,
                                              ctx.ndx[1], sums_a, None, (amax, ga, P), False, cwa, 0)

@@ -36,6 +36,10 @@ class PathOptions:
     # ... and the forward: its BatchNorm from the moments of the 32-wide activation, the conv recomputed inside the
     # pair product / max kernel (csrc/gridgcn_attfwd.hip): the tensor is never written (needs NOZ_ATT_BWD)
     NOZ_ATT_FWD: bool = True
+    # ... and the backward takes S1 = sum a1, S2 = sum a1 a1^T from the moments that forward left behind instead of
+    # accumulating them again (gridgcn_att_bwd_noz_mom: 144 MFMAs per tile instead of 160, one launch fewer).
+    # ROUND 6, WRITTEN WHILE THE GPU POOL WAS CLOSED: off until a GPU session has run tests/test_zz_r6_unverified.py
+    NOZ_BWD_MOMENTS: bool = False
     # bf16 mode: the same pair of (fp32) kernels instead of the bf16-stored tensor, where the shape allows
     NOZ_IN_BF16: bool = True
     # the source-point products on csrc/gridgcn_gemm.hip instead of the framework's GEMM
@@ -56,6 +60,9 @@ class PathOptions:
     WGB_PREPACK: bool = True
     # concat + centre mask + zero padding of a layer boundary in one launch (model.GGCNSeg.forward)
     GLUE_KERNELS: bool = True
+    # training: the index operators behind the first Gridify on a side stream (model._IndexAhead).  ROUND 6, WRITTEN
+    # WHILE THE GPU POOL WAS CLOSED: off until a GPU session has run tests/test_zz_r6_unverified.py and an A/B
+    INDEX_SIDE_STREAM: bool = False
     # evaluation of single-layer-pt edge blocks (the up layers) through the source-side kernels ...
     SRC_EVAL: bool = True
     # ... with the second attention conv + product + max in one kernel (csrc/gridgcn_atteval.hip)

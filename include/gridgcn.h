@@ -79,7 +79,7 @@ int gridgcn_abi_version(void);  /* 2: seed_dev / drop_seed_dev; 3: one-byte arg-
                                  *    kernel: dX / dW / sums in other summation orders); gridgcn_gemm_small_workspace_bytes is
                                  *    bounded (~16 MB) whatever the row count
                                  * 8: gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd (+ _workspace_bytes), GRIDGCN_OPT_ATT_EVAL_TILE
-                                 * 9: gridgcn_att_pairmax_fwd_supported */
+                                 * 9: gridgcn_att_pairmax_fwd_supported, gridgcn_att_bwd_noz_mom (+ _supported), gridgcn_att_moments_offset */
 
 /* Kernel-selection options (process-wide, read at launch time; for A/B tests -- the defaults are
  * what is measured and shipped).  set: 0 ok / GRIDGCN_EINVAL for an unknown option; get: -1. */
@@ -671,6 +671,22 @@ int gridgcn_att_bwd_noz(const float *Z1, const float *pscale, const float *pshif
                         const float *gval, int P, long long E, int cin, int C, float *dX, float *dW, float *m1,
                         float *m2, float *dgamma, float *dbeta, double *psums, double *s1, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* gridgcn_att_bwd_noz_mom (round 6): the same backward with S1 = sum_e a1 and S2 = sum_e a1 a1^T TAKEN from the
+ * moments the Z2-free forward of the layer left behind (gridgcn_att_bn2_moments: fp64, at byte
+ * gridgcn_att_moments_offset(E, ..) of ITS workspace -- 17 x 64 doubles: rows 0..15 the C/D registers of S2, lane l =
+ * column l & 31, row (r & 3) + 8 (r >> 2) + 4 (l >> 5); row 16 lane l's share of S1[l & 31]) instead of being
+ * accumulated again: 144 MFMAs per 32-row tile instead of 160, reduce + finish in one launch.  Same outputs as
+ * gridgcn_att_bwd_noz except `s1` (not produced); dW's dense part is evaluated in fp64 from the fp64 moments.  The
+ * caller keeps the forward's workspace alive until here.  _supported: 1 when the shape is taken (the limits of
+ * gridgcn_att_bwd_noz and E < 2^24, E / P < 2^22), else 0 and the call returns GRIDGCN_EINVAL. */
+int gridgcn_att_bwd_noz_mom_supported(long long E, int cin, int C, int P);
+int gridgcn_att_moments_offset(long long E, int cin, int C, size_t *offset_bytes);
+int gridgcn_att_bwd_noz_mom(const float *Z1, const float *pscale, const float *pshift, const float *pmean,
+                            const float *prstd, const float *W2, const float *b2, const float *scale,
+                            const float *mean, const float *rstd, const double *sums, const uint8_t *amax,
+                            const float *gval, int P, long long E, int cin, int C, const double *moments, float *dX,
+                            float *dW, float *m1, float *m2, float *dgamma, float *dbeta, double *psums,
+                            void *workspace, size_t workspace_bytes, void *stream);
 /* ---- FORWARD of the same pair of layers without that pre-activation (csrc/gridgcn_attfwd.hip) -------------------
  * Training needed Z2 = W2 a1 + b2 [E, 128] for two things: its BatchNorm batch statistics and the pair product /
  * neighbour max (gcn_module_g_att.py:152-167, :57-59).  Both are obtained from Z1 [E, 32]:

@@ -122,10 +122,12 @@ def test_cls_cfg2_batch32_training_step_matches_stock_modules():
     parity_report("model cls (32 x 1024, cfg2's batch) HIP kernels vs stock fp32 modules: |dloss|/loss %.3e  "
                   "1-cos(grad) %.3e  rel-L2(grad) %.3e" % (dl, 1.0 - cos, rel))
     assert torch.isfinite(res[0][1]).all()
-    # bars as the 8-cloud test below until measured (this net is discretely sensitive at fp32 round-off: see there)
-    assert dl < 2e-6, dl
-    assert 1.0 - cos < 3.6e-5, cos
-    assert rel < 1.5e-2, rel
+    # NOT YET MEASURED at this batch (the GPU pool was closed when the test was written): sanity bars an order of
+    # magnitude above the 8-cloud test's measured distances (1.3e-7 / 1.2e-5 / 4.9e-3; this net is discretely
+    # sensitive at fp32 round-off: see there); the measured values go to GG_PARITY_REPORT
+    assert dl < 2e-5, dl
+    assert 1.0 - cos < 4e-4, cos
+    assert rel < 5e-2, rel
 
 
 @pytest.mark.gpu
