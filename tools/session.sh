@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU session: session.sh <outdir> [what...]   what = tests micro bench trace pmc configs (default: all but pmc/configs)
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+export GG_R6_UNVERIFIED=1   # tests/test_zz_r6_unverified.py: the round-6 opt-in paths
 OUT=gpurun_out/${1:-session}; shift
 WHAT="${@:-tests micro bench trace}"
 mkdir -p $OUT
