@@ -1,0 +1,151 @@
+"""numpy front end of the host-side emulation of the index operators (tests/simt/): the signatures of
+grid_gcn_amd.ops (Gridify, GridifyKNN, Gridify_occaware, Gridify_fast_rand, GridifyUp, BallKNN, KNN) on numpy arrays.
+TEST INFRASTRUCTURE -- the product never imports this."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from grid_gcn_amd._lib import GridParams  # noqa: E402  (the ctypes mirror of gridgcn_grid_params: a plain struct)
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        sys.path.insert(0, HERE)
+        import build as simt_build
+        _LIB = ctypes.CDLL(simt_build.build())
+        _LIB.simt_ball_grid_workspace.restype = ctypes.c_size_t
+    return _LIB
+
+
+def counters():
+    """(launches, rendezvous, shuffles that read a lane outside their group, rendezvous in divergent control flow)"""
+    out = (ctypes.c_longlong * 4)()
+    load().simt_counters(out)
+    return tuple(out)
+
+
+def set_option(which, value):
+    """0: slab shift, 1: chunk, 2: one-launch build for small clouds (gg_index_set_tuning)"""
+    load().simt_set_option(int(which), int(value))
+
+
+def _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed):
+    p = GridParams()
+    p.max_p_grid, p.max_o_grid, p.kernel_size = int(max_p_grid), int(max_o_grid), int(kernel_size)
+    p.stride, p.loc = int(stride), int(loc)
+    for j in range(3):
+        p.coord_shift[j] = float(coord_shift[j])
+        p.voxel_size[j] = float(voxel_size[j])
+        p.grid_size[j] = int(grid_size[j])
+    p.seed = int(seed) & (2 ** 64 - 1)
+    p.seed_dev = None
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _gridify(mode, data, npn, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0, coord_shift, voxel_size,
+             grid_size, seed=0, beta=0.0):
+    lib = load()
+    data = np.ascontiguousarray(data, np.float32)
+    npn = np.ascontiguousarray(npn, np.int32)
+    B, N, _ = data.shape
+    p = _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed)
+    nb = ctypes.c_size_t(0)
+    rc = lib.simt_gridify_workspace_bytes(mode, B, N, ctypes.byref(p), ctypes.byref(nb))
+    assert rc == 0, rc
+    ws = np.full(nb.value + 64, 0xA5, np.uint8)           # (garbage on entry, as a caller's workspace is)
+    O, P = int(max_o_grid), int(max_p_grid)
+    nebidx = np.full((B, O, P), -7, np.int32)
+    nebmsk = np.full((B, O, P), np.nan, np.float32)
+    cent = np.full((B, O, 4), np.nan, np.float32)
+    centmsk = np.full((B, O), np.nan, np.float32)
+    centnum = np.full((B, 1), -7, np.int32)
+    rc = lib.simt_gridify(mode, _ptr(data), _ptr(npn), B, N, ctypes.byref(p), ctypes.c_float(beta), _ptr(nebidx),
+                          _ptr(nebmsk), _ptr(cent), _ptr(centmsk), _ptr(centnum), _ptr(ws), ctypes.c_size_t(nb.value))
+    assert rc == 0, rc
+    return nebidx, nebmsk, cent, centmsk, centnum
+
+
+def Gridify(data, npn, **kw):
+    return _gridify(0, data, npn, **kw)
+
+
+def GridifyKNN(data, npn, **kw):
+    return _gridify(1, data, npn, **kw)
+
+
+def Gridify_occaware(data, npn, beta=1.0, **kw):
+    return _gridify(2, data, npn, beta=beta, **kw)
+
+
+def Gridify_fast_rand(data, npn, **kw):
+    return _gridify(3, data, npn, **kw)
+
+
+def GridifyUp(down, up, down_np, up_np, *, max_p_grid, max_o_grid, kernel_size, coord_shift, voxel_size, grid_size,
+              seed=0):
+    lib = load()
+    down = np.ascontiguousarray(down, np.float32)
+    up = np.ascontiguousarray(up, np.float32)
+    down_np = np.ascontiguousarray(down_np, np.int32)
+    up_np = np.ascontiguousarray(up_np, np.int32)
+    B, Nd, _ = down.shape
+    assert up.shape == (B, max_o_grid, 4)
+    p = _params(max_p_grid, max_o_grid, kernel_size, 1, 0, coord_shift, voxel_size, grid_size, seed)
+    nb = ctypes.c_size_t(0)
+    rc = lib.simt_gridify_up_workspace_bytes(B, Nd, ctypes.byref(p), ctypes.byref(nb))
+    assert rc == 0, rc
+    ws = np.full(nb.value + 64, 0xA5, np.uint8)
+    nebidx = np.full((B, max_o_grid, max_p_grid), -7, np.int32)
+    nebmsk = np.full((B, max_o_grid, max_p_grid), np.nan, np.float32)
+    rc = lib.simt_gridify_up(_ptr(down), _ptr(up), _ptr(down_np), _ptr(up_np), B, Nd, ctypes.byref(p), _ptr(nebidx),
+                             _ptr(nebmsk), _ptr(ws), ctypes.c_size_t(nb.value))
+    assert rc == 0, rc
+    return nebidx, nebmsk
+
+
+def BallKNN(unknown, known, downnum, upnum, k=3, radius=0.1, grid=False):
+    lib = load()
+    unknown = np.ascontiguousarray(unknown, np.float32)
+    known = np.ascontiguousarray(known, np.float32)
+    downnum = np.ascontiguousarray(downnum, np.int32)
+    upnum = np.ascontiguousarray(upnum, np.int32)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    idx = np.zeros((B, n, k), np.int32)                   # (rows >= upnum stay untouched: zeros here, as ops.BallKNN)
+    if grid:
+        ws = np.full(lib.simt_ball_grid_workspace(B, m) + 64, 0xA5, np.uint8)
+        rc = lib.simt_ball_knn_grid(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k),
+                                    ctypes.c_float(radius), _ptr(idx), _ptr(ws))
+    else:
+        rc = lib.simt_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k),
+                               ctypes.c_float(radius), _ptr(idx))
+    assert rc == 0, rc
+    return idx
+
+
+def KNN(unknown, known, downnum, upnum, k=3):
+    lib = load()
+    unknown = np.ascontiguousarray(unknown, np.float32)
+    known = np.ascontiguousarray(known, np.float32)
+    downnum = np.ascontiguousarray(downnum, np.int32)
+    upnum = np.ascontiguousarray(upnum, np.int32)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    idx = np.zeros((B, n, k), np.int32)
+    rc = lib.simt_knn_all(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k), _ptr(idx))
+    assert rc == 0, rc
+    return idx

@@ -1,0 +1,346 @@
+// simt_hip.h -- a wave64 SIMT emulator for the HOST: the HIP kernels of grid_gcn_amd/csrc, compiled by g++ and run on
+// the CPU, one fibre per work-item.  TEST INFRASTRUCTURE (tests/test_simt_index.py): it lets the CPU-tier suite execute
+// the PRODUCT's kernel source -- not a restatement of it -- against the oracle when no GPU is at hand, and lets a
+// kernel change be checked bit for bit before a GPU session is spent on it.  It proves the arithmetic and the
+// data flow of a kernel; it says nothing about its speed, its occupancy or the memory model of the real machine.
+//
+// Execution model
+//   * a launch runs its workgroups one after the other; a workgroup is blockDim fibres (ucontext), scheduled wave
+//     by wave, lane by lane, each until it blocks;
+//   * every cross-lane operation (__ballot, __shfl*, readlane / readfirstlane, __builtin_amdgcn_wave_barrier) is a
+//     RENDEZVOUS of the wave: a lane deposits its operand and waits; when no lane of the wave can run any more, the
+//     waiting lanes -- all at the same operation in wave-uniform control flow: the lanes the EXEC mask would hold
+//     there -- are resolved together (simt_resolve_wave).  Lanes run one after the other BETWEEN rendezvous points, so LDS traffic between the lanes
+//     of a wave must be ordered by one -- exactly where the GPU code needs its wave_barrier for the compiler;
+//   * __syncthreads is the rendezvous of every live fibre of the workgroup;
+//   * atomics are plain read-modify-writes (one fibre runs at a time); fences and s_waitcnt are nothing;
+//   * `__shared__` is a function-local static (workgroups are sequential), `extern __shared__` is rewritten by
+//     tests/simt/build.py into a pointer to the launch's dynamic LDS block, `k<<<g, b, lds, s>>>(args)` into
+//     simt_launch(g, b, lds, [&] { k(args); }).
+//   * a shuffle that reads a lane outside its group is counted (simt_foreign_reads): a kernel relying on it would
+//     read a stale register on the GPU as well.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+// ---- vector types -----------------------------------------------------------------------------------------------
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---- qualifiers -------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_SYMBOL(x) x
+
+// ---- the host runtime calls the launchers make ------------------------------------------------------------------
+typedef void *hipStream_t;
+enum hipError_t { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+
+// ---- scheduler --------------------------------------------------------------------------------------------------
+enum { SIMT_RUN = 0, SIMT_WAVE = 1, SIMT_BLOCK = 2, SIMT_DONE = 3 };
+enum { SIMT_OP_BALLOT, SIMT_OP_SHFL, SIMT_OP_UP, SIMT_OP_DOWN, SIMT_OP_XOR, SIMT_OP_BAR, SIMT_OP_FIRST };
+
+struct SimtFiber {
+    ucontext_t ctx;
+    int state;
+    dim3 tidx;
+    int op, arg, width;
+    const void *site;
+    long long seq;          // cross-lane operations executed so far in this launch
+    uint64_t val, res;
+};
+
+inline SimtFiber *simt_cur = nullptr;
+inline ucontext_t simt_sched;
+inline dim3 simt_blockIdx, simt_blockDim, simt_gridDim;
+inline char *simt_dyn_lds = nullptr;
+inline long long simt_foreign_reads = 0, simt_launches = 0, simt_rendezvous = 0, simt_divergent_rendezvous = 0;
+inline const std::function<void()> *simt_body = nullptr;
+
+#define threadIdx (simt_cur->tidx)
+#define blockIdx simt_blockIdx
+#define blockDim simt_blockDim
+#define gridDim simt_gridDim
+
+static inline void simt_yield(int st)
+{
+    SimtFiber *f = simt_cur;
+    f->state = st;
+    swapcontext(&f->ctx, &simt_sched);
+}
+
+static void simt_entry()
+{
+    (*simt_body)();
+    simt_cur->state = SIMT_DONE;
+    swapcontext(&simt_cur->ctx, &simt_sched);
+}
+
+__attribute__((noinline)) static uint64_t simt_collective(int op, uint64_t val, int arg, int width)
+{
+    SimtFiber *f = simt_cur;
+    f->op = op; f->val = val; f->arg = arg; f->width = width;
+    f->site = __builtin_return_address(0);
+    f->seq++;
+    simt_yield(SIMT_WAVE);
+    return f->res;
+}
+
+// Resolve ONE group of waiting lanes of a wave (lanes[0..n): the wave's fibres).  Called when no lane of the wave can
+// run.  Every lane counts the cross-lane operations it has executed in this launch; in wave-uniform control flow --
+// the only place the kernels under test put such an operation -- the k-th operation of one lane IS the k-th of every
+// other, so the waiting lanes all carry the same count and the same opcode and form one group: the lanes the EXEC
+// mask would hold there.  (The call SITE is not the identity of an operation: g++ duplicates a call into both arms
+// of an `if (lane == 0)` in front of it.)  If the waiting lanes disagree -- a cross-lane operation inside divergent
+// control flow: the hardware would run the branches one after the other and reconverge -- the group that is furthest
+// behind (lowest count, then lowest code address) goes on alone, the others wait for it, and the event is counted:
+// simt_divergent_rendezvous.  The tests assert that the count is 0, i.e. that no guess was ever made.
+static inline void simt_resolve_wave(SimtFiber *lanes, int n)
+{
+    int lead = -1, nkeys = 0;
+    for (int i = 0; i < n; i++) {
+        if (lanes[i].state != SIMT_WAVE) continue;
+        bool seen = false;
+        for (int j = 0; j < i; j++)
+            seen |= lanes[j].state == SIMT_WAVE && lanes[j].seq == lanes[i].seq && lanes[j].op == lanes[i].op;
+        if (seen) continue;
+        nkeys++;
+        if (lead < 0 || lanes[i].seq < lanes[lead].seq ||
+            (lanes[i].seq == lanes[lead].seq && (uintptr_t)lanes[i].site < (uintptr_t)lanes[lead].site))
+            lead = i;
+    }
+    const long long seq = lanes[lead].seq;
+    const int op = lanes[lead].op;
+    if (nkeys > 1) {
+        if (simt_divergent_rendezvous < 4 && getenv("SIMT_DEBUG")) {
+            fprintf(stderr, "simt: wave blocked at %d different operations:", nkeys);
+            for (int i = 0; i < n; i++)
+                if (lanes[i].state == SIMT_WAVE)
+                    fprintf(stderr, " %d:#%lld/%d@%p", i, lanes[i].seq, lanes[i].op, lanes[i].site);
+            fprintf(stderr, "\n");
+        }
+        simt_divergent_rendezvous++;
+    }
+    bool in[64] = {false};
+    uint64_t ballot = 0;
+    int first = -1;
+    for (int j = 0; j < n; j++)
+        if (lanes[j].state == SIMT_WAVE && lanes[j].seq == seq && lanes[j].op == op) {
+            in[j] = true;
+            if (first < 0) first = j;
+            if (op == SIMT_OP_BALLOT && lanes[j].val) ballot |= 1ull << j;
+        }
+    simt_rendezvous++;
+    for (int j = 0; j < n; j++) {
+        if (!in[j]) continue;
+        SimtFiber &f = lanes[j];
+        const int w = f.width > 0 ? f.width : 64, base = j - (j % w);
+        int src = j;
+        switch (op) {
+        case SIMT_OP_BALLOT: f.res = ballot; break;
+        case SIMT_OP_BAR: f.res = 0; break;
+        case SIMT_OP_FIRST: f.res = lanes[first].val; break;
+        case SIMT_OP_SHFL: src = base + (((f.arg % w) + w) % w); break;
+        case SIMT_OP_UP: src = (j % w) >= f.arg ? j - f.arg : j; break;
+        case SIMT_OP_DOWN: src = (j % w) + f.arg < w ? j + f.arg : j; break;
+        case SIMT_OP_XOR: src = base + ((j % w) ^ f.arg); if (src - base >= w) src = j; break;
+        }
+        if (op == SIMT_OP_SHFL || op == SIMT_OP_UP || op == SIMT_OP_DOWN || op == SIMT_OP_XOR) {
+            if (src < 0 || src >= n) src = j;
+            if (!in[src]) simt_foreign_reads++;
+            f.res = lanes[src].val;
+        }
+    }
+    for (int j = 0; j < n; j++)
+        if (in[j]) lanes[j].state = SIMT_RUN;
+}
+
+inline std::vector<char> simt_stacks;
+inline std::vector<SimtFiber> simt_fibers;
+inline std::vector<char> simt_lds_buf;
+#ifndef SIMT_STACK
+#define SIMT_STACK (96 * 1024)
+#endif
+
+static inline void simt_run_block(int nthreads, const dim3 &bd)
+{
+    if ((int)simt_fibers.size() < nthreads) simt_fibers.resize(nthreads);
+    if (simt_stacks.size() < (size_t)nthreads * SIMT_STACK) simt_stacks.resize((size_t)nthreads * SIMT_STACK);
+    for (int t = 0; t < nthreads; t++) {
+        SimtFiber &f = simt_fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = simt_stacks.data() + (size_t)t * SIMT_STACK;
+        f.ctx.uc_stack.ss_size = SIMT_STACK;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, simt_entry, 0);
+        f.state = SIMT_RUN;
+        f.tidx = dim3(t % bd.x, (t / bd.x) % bd.y, t / (bd.x * bd.y));
+        f.val = f.res = 0;
+        f.seq = 0;
+    }
+    const int nwave = (nthreads + 63) / 64;
+    for (;;) {
+        bool progress = false;
+        for (int w = 0; w < nwave; w++) {
+            SimtFiber *lanes = &simt_fibers[w * 64];
+            const int n = std::min(64, nthreads - w * 64);
+            for (;;) {
+                bool ran = false;
+                for (int l = 0; l < n; l++)
+                    if (lanes[l].state == SIMT_RUN) {
+                        simt_cur = &lanes[l];
+                        swapcontext(&simt_sched, &lanes[l].ctx);
+                        ran = true;
+                    }
+                bool waiting = false;
+                for (int l = 0; l < n; l++) waiting |= lanes[l].state == SIMT_WAVE;
+                if (ran) progress = true;
+                if (!waiting) break;
+                simt_resolve_wave(lanes, n);
+                progress = true;
+            }
+        }
+        int nblock = 0, ndone = 0;
+        for (int t = 0; t < nthreads; t++) {
+            nblock += simt_fibers[t].state == SIMT_BLOCK;
+            ndone += simt_fibers[t].state == SIMT_DONE;
+        }
+        if (ndone == nthreads) break;
+        if (nblock + ndone == nthreads) {
+            for (int t = 0; t < nthreads; t++)
+                if (simt_fibers[t].state == SIMT_BLOCK) simt_fibers[t].state = SIMT_RUN;
+            continue;
+        }
+        if (!progress) {
+            fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d at the barrier, %d done of %d\n", simt_blockIdx.x,
+                    simt_blockIdx.y, simt_blockIdx.z, nblock, ndone, nthreads);
+            abort();
+        }
+    }
+    simt_cur = nullptr;
+}
+
+static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body)
+{
+    simt_launches++;
+    if (simt_lds_buf.size() < lds_bytes + 64) simt_lds_buf.resize(lds_bytes + 64);
+    simt_dyn_lds = (char *)(((uintptr_t)simt_lds_buf.data() + 63) & ~(uintptr_t)63);
+    simt_gridDim = grid;
+    simt_blockDim = block;
+    simt_body = &body;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++)
+            for (unsigned x = 0; x < grid.x; x++) {
+                simt_blockIdx = dim3(x, y, z);
+                simt_run_block(nthreads, block);
+            }
+    simt_body = nullptr;
+}
+
+// ---- device intrinsics ------------------------------------------------------------------------------------------
+static inline void __syncthreads() { simt_yield(SIMT_BLOCK); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+
+template <class T> static inline uint64_t simt_pack(T v)
+{
+    static_assert(sizeof(T) <= 8, "operand wider than 64 bits");
+    uint64_t u = 0;
+    memcpy(&u, &v, sizeof(T));
+    return u;
+}
+template <class T> static inline T simt_unpack(uint64_t u)
+{
+    T v;
+    memcpy(&v, &u, sizeof(T));
+    return v;
+}
+#define SIMT_INL inline __attribute__((always_inline))
+static SIMT_INL unsigned long long __ballot(int pred) { return simt_collective(SIMT_OP_BALLOT, pred ? 1 : 0, 0, 64); }
+static SIMT_INL int __any(int pred) { return simt_collective(SIMT_OP_BALLOT, pred ? 1 : 0, 0, 64) != 0; }
+static SIMT_INL int __all(int pred) { return simt_collective(SIMT_OP_BALLOT, pred ? 0 : 1, 0, 64) == 0; }
+template <class T> static SIMT_INL T __shfl(T v, int src, int width = 64)
+{
+    return simt_unpack<T>(simt_collective(SIMT_OP_SHFL, simt_pack(v), src, width));
+}
+template <class T> static SIMT_INL T __shfl_up(T v, unsigned d, int width = 64)
+{
+    return simt_unpack<T>(simt_collective(SIMT_OP_UP, simt_pack(v), (int)d, width));
+}
+template <class T> static SIMT_INL T __shfl_down(T v, unsigned d, int width = 64)
+{
+    return simt_unpack<T>(simt_collective(SIMT_OP_DOWN, simt_pack(v), (int)d, width));
+}
+template <class T> static SIMT_INL T __shfl_xor(T v, int m, int width = 64)
+{
+    return simt_unpack<T>(simt_collective(SIMT_OP_XOR, simt_pack(v), m, width));
+}
+static SIMT_INL void __builtin_amdgcn_wave_barrier() { (void)simt_collective(SIMT_OP_BAR, 0, 0, 64); }
+static SIMT_INL int __builtin_amdgcn_readfirstlane(int v)
+{
+    return simt_unpack<int>(simt_collective(SIMT_OP_FIRST, simt_pack(v), 0, 64));
+}
+static SIMT_INL int __builtin_amdgcn_readlane(int v, int lane)
+{
+    return simt_unpack<int>(simt_collective(SIMT_OP_SHFL, simt_pack(v), lane, 64));
+}
+
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __mul24(int a, int b) { return (int)((long long)a * b); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __int_as_float(int x) { return simt_unpack<float>((uint64_t)(uint32_t)x); }
+static inline int __float_as_int(float x) { return (int)(uint32_t)simt_pack(x); }
+static inline float __uint_as_float(unsigned x) { return simt_unpack<float>((uint64_t)x); }
+static inline unsigned __float_as_uint(float x) { return (unsigned)simt_pack(x); }
+static inline long long wall_clock64() { return 0; }
+static inline long long clock64() { return 0; }
+
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned v) { unsigned long long o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T *p, T v) { T o = *p; *p = o > v ? o : v; return o; }
+template <class T> static inline T atomicMin(T *p, T v) { T o = *p; *p = o < v ? o : v; return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
+template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <class T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
