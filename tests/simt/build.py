@@ -1,7 +1,7 @@
 """Build the HOST emulation of the index kernels: tests/simt/_build/libsimt_index.so.
 
 The kernel sources are taken from grid_gcn_amd/csrc AS THEY ARE, passed through three textual rewrites that only
-concern launch syntax and GPU-only spellings (what they compute is untouched), and compiled by g++ against
+concern launch syntax and GPU-only spellings (what they compute is untouched), and compiled for the HOST (clang++, x86) against
 tests/simt/simt_hip.h:
 
     k<<<grid, block, lds, stream>>>(args);            ->  simt_launch(grid, block, lds, [&]() { k(args); });
@@ -23,7 +23,10 @@ CSRC = os.path.join(ROOT, "grid_gcn_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsimt_index.so")
 SOURCES = ["gridgcn_index.hip", "gridgcn_index_legacy.hip", "gridgcn_query.hip", "gridgcn_query_knn.hip",
-           "gridgcn_knn.hip", "gridgcn_ballgrid.hip", "gridgcn_fastrand.hip", "gridgcn_cas.hip"]
+           "gridgcn_knn.hip", "gridgcn_ballgrid.hip", "gridgcn_fastrand.hip", "gridgcn_cas.hip",
+           # training kernels (fp32 MFMA as a wave rendezvous, raw buffer loads / stores as checked host accesses)
+           "gridgcn_attbwd_nz.hip", "gridgcn_attfwd.hip"]
+CXX = "/opt/rocm/lib/llvm/bin/clang++"      # host compile: the kernels use clang's ext_vector_type / elementwise builtins
 
 
 def _balanced(s, i, open_ch, close_ch):
@@ -97,7 +100,13 @@ def rewrite(text):
     text = re.sub(r'asm volatile\("s_waitcnt [^"]*\\n\\ts_barrier"[^;]*;', "__syncthreads();", text)
     text = re.sub(r'asm volatile\("s_waitcnt [^"]*"[^;]*;', ";", text)
     text = re.sub(r"__attribute__\(\(amdgpu_\w+\([^)]*\)\)\)", "", text)
-    return rewrite_launches(text)
+    return rewrite_launches(rewrite_header(text))
+
+
+def rewrite_header(text):
+    """the raw buffer intrinsics are declared by their LLVM names (`... __asm("llvm.amdgcn.raw.buffer.load.f32")`):
+    the label goes, the emulator defines the functions under their C++ names (tests/simt/simt_buf.cpp)"""
+    return re.sub(r'\s*__asm\("llvm\.amdgcn\.raw\.buffer\.[^"]+"\)', "", text)
 
 
 def _stamp():
@@ -105,32 +114,55 @@ def _stamp():
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".h") or f in SOURCES:
             h.update(open(os.path.join(CSRC, f), "rb").read())
-    for f in ("simt_hip.h", "driver.cpp", "build.py"):
+    for f in ("simt_hip.h", "driver.cpp", "simt_buf.cpp", "build.py"):
         h.update(open(os.path.join(HERE, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "gridgcn.h"), "rb").read())
     return h.hexdigest()
 
 
 def build(force=False, verbose=False):
+    """one translation unit per kernel source, as the product's own build (grid_gcn_amd/build.py), plus the driver"""
+    import concurrent.futures
     os.makedirs(OUT, exist_ok=True)
     stamp_file = os.path.join(OUT, "stamp")
     stamp = _stamp()
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
+    flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-attributes",
+             "-Wno-unused-variable", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-int-to-pointer-cast",
+             "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-pass-failed", "-Wno-unused-value",
+             "-include", os.path.join(HERE, "simt_hip.h"), "-D__HIPCC__=1",
+             "-I" + HERE, "-I" + OUT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
+    units = []
+    for h in sorted(os.listdir(CSRC)):          # headers: found in _build first (-I order)
+        if h.endswith(".h"):
+            with open(os.path.join(OUT, h), "w") as f:
+                f.write(rewrite_header(open(os.path.join(CSRC, h)).read()))
     for src in SOURCES:
         text = rewrite(open(os.path.join(CSRC, src)).read())
-        with open(os.path.join(OUT, src.replace(".hip", ".simt.inc")), "w") as f:
+        cpp = os.path.join(OUT, src.replace(".hip", ".simt.cpp"))
+        with open(cpp, "w") as f:
             f.write("// generated by tests/simt/build.py from grid_gcn_amd/csrc/%s -- do not edit\n" % src)
             f.write(text)
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing",
-           "-Wno-attributes", "-Wno-unused-variable", "-Wno-unused-function", "-Wno-unknown-pragmas",
-           "-Wno-int-to-pointer-cast", "-I" + HERE, "-I" + OUT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
-           os.path.join(HERE, "driver.cpp"), "-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
+        units.append(cpp)
+    units += [os.path.join(HERE, "driver.cpp"), os.path.join(HERE, "simt_buf.cpp")]
+
+    def compile_one(cpp):
+        obj = os.path.join(OUT, os.path.basename(cpp) + ".o")
+        cmd = [CXX] + flags + ["-c", cpp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("simt build failed (%s):\n%s" % (os.path.basename(cpp), r.stderr[-6000:]))
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, units))
+    cmd = [CXX, "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("simt build failed:\n" + r.stderr[-6000:])
+        raise RuntimeError("simt link failed:\n" + r.stderr[-6000:])
     os.replace(LIB + ".tmp", LIB)
     with open(stamp_file, "w") as f:
         f.write(stamp)

@@ -1,25 +1,37 @@
 // driver.cpp -- extern "C" entries of the host-side emulation of the index operators (tests/simt/simt_hip.h).
-// One translation unit: the emulator header, then the kernel sources of grid_gcn_amd/csrc as rewritten by
-// tests/simt/build.py (launch syntax only), then the same orchestration as grid_gcn_amd/csrc/gridgcn_capi.hip
+// Linked with the kernel sources of grid_gcn_amd/csrc as rewritten by tests/simt/build.py (launch syntax only), one
+// translation unit each as in the product's build; here: the same orchestration as grid_gcn_amd/csrc/gridgcn_capi.hip
 // (gridify_common / gridgcn_gridify_up / gridgcn_ball_knn*), statement for statement, so that what runs here is the
 // product's code path minus the GPU.  TEST INFRASTRUCTURE: nothing under grid_gcn_amd/ knows this file.
 #include "simt_hip.h"
 
 #include "gridgcn_fillgrid.h"
 #include "gridgcn_index.h"
+#include "gridgcn_train.h"
 
-#include "gridgcn_index.simt.inc"
-#include "gridgcn_index_legacy.simt.inc"
-#include "gridgcn_query.simt.inc"
-#include "gridgcn_query_knn.simt.inc"
-#include "gridgcn_fastrand.simt.inc"
-#include "gridgcn_cas.simt.inc"
-namespace simt_knn {
-#include "gridgcn_knn.simt.inc"
-}
-namespace simt_ballgrid {
-#include "gridgcn_ballgrid.simt.inc"
-}
+// the launchers of the kernel translation units (declared as gridgcn_capi.hip declares them)
+int gg_launch_query_gridify(const float *data, int B, int N, const GGGrid &gp, char *wsbase, const GGIndexWs &w,
+                            int *nebidx, float *nebmsk, float *cent, float *centmsk, const int *centnum, hipStream_t st);
+int gg_launch_query_knn(const float *data, int B, int N, const GGGrid &gp, char *wsbase, const GGIndexWs &w, int *nebidx,
+                        float *nebmsk, float *cent, float *centmsk, const int *centnum, hipStream_t st);
+int gg_launch_query_up(const float *updata, const int *up_np, int B, int Nd, const GGGrid &gp, char *wsbase,
+                       const GGIndexWs &w, int *nebidx, float *nebmsk, hipStream_t st);
+int gg_ball_knn(const float *, const float *, const int *, const int *, int, int, int, int, float, int *, hipStream_t,
+                int su = 3, int sk = 3, int ztail = 0);
+int gg_knn(const float *, const float *, const int *, const int *, int, int, int, int, int *, hipStream_t);
+size_t gg_ball_grid_workspace(int B, int m);
+int gg_ball_knn_grid(const float *, const float *, const int *, const int *, int, int, int, int, float, int *, void *,
+                     hipStream_t, int su = 3, int sk = 3, int ztail = 0);
+bool gg_att_bwd_noz_ok(long long E, int cin, int C);
+bool gg_att_bwd_noz_mom_ok(long long E, int cin, int C, int P);
+size_t gg_att_bwd_noz_workspace(long long E);
+int gg_att_bwd_noz(const float *, const float *, const float *, const float *, const float *, const float *,
+                   const float *, const float *, const float *, const float *, const double *, const unsigned char *,
+                   const float *, int, long long, float *, float *, float *, float *, float *, float *, double *,
+                   double *, void *, hipStream_t, const double *mom = nullptr);
+void gg_set_att_nz_v2(int v);
+int gg_att_moments_grid_of(long long E);
+extern long long simt_buf_oob;
 
 static size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -31,6 +43,7 @@ void simt_counters(long long *out)
     out[1] = simt_rendezvous;
     out[2] = simt_foreign_reads;
     out[3] = simt_divergent_rendezvous;
+    out[4] = simt_buf_oob;
 }
 
 void simt_set_option(int which, int value) { gg_index_set_tuning(which, value); }
@@ -105,24 +118,63 @@ int simt_ball_knn(const float *unknown, const float *known, const int32_t *downn
                   int n, int m, int k, float radius, int32_t *idx)
 {
     if (B < 1 || n < 1 || m < 1 || k < 1 || k > 6) return GRIDGCN_EINVAL;
-    return simt_knn::gg_ball_knn(unknown, known, downnum, upnum, B, n, m, k, radius, idx, nullptr, 3, 3, 0);
+    return gg_ball_knn(unknown, known, downnum, upnum, B, n, m, k, radius, idx, nullptr, 3, 3, 0);
 }
 
 int simt_knn_all(const float *unknown, const float *known, const int32_t *downnum, const int32_t *upnum, int B, int n,
                  int m, int k, int32_t *idx)
 {
     if (B < 1 || n < 1 || m < 1 || k < 1 || k > 6) return GRIDGCN_EINVAL;
-    return simt_knn::gg_knn(unknown, known, downnum, upnum, B, n, m, k, idx, nullptr);
+    return gg_knn(unknown, known, downnum, upnum, B, n, m, k, idx, nullptr);
 }
 
-size_t simt_ball_grid_workspace(int B, int m) { return simt_ballgrid::gg_ball_grid_workspace(B, m); }
+size_t simt_ball_grid_workspace(int B, int m) { return gg_ball_grid_workspace(B, m); }
 
 int simt_ball_knn_grid(const float *unknown, const float *known, const int32_t *downnum, const int32_t *upnum,
                        int B, int n, int m, int k, float radius, int32_t *idx, void *ws)
 {
     if (B < 1 || n < 1 || m < 1 || k < 1 || k > 6) return GRIDGCN_EINVAL;
-    return simt_ballgrid::gg_ball_knn_grid(unknown, known, downnum, upnum, B, n, m, k, radius, idx, ws, nullptr, 3, 3,
+    return gg_ball_knn_grid(unknown, known, downnum, upnum, B, n, m, k, radius, idx, ws, nullptr, 3, 3,
                                            0);
+}
+
+// ---- training kernels (the entries of gridgcn_capi.hip, argument checks included) --------------------------------
+size_t simt_att_bwd_noz_workspace(long long E) { return gg_att_bwd_noz_workspace(E); }
+size_t simt_att_moments_workspace(long long E) { return gg_att_moments_workspace(E); }
+size_t simt_att_moments_offset(long long E) { return (size_t)gg_att_moments_grid_of(E) * 17 * 64 * sizeof(double); }
+void simt_set_att_nz_v2(int v) { gg_set_att_nz_v2(v); }
+
+int simt_att_bn2_moments(const float *Z1, const float *scale1, const float *shift1, const float *W2, const float *b2,
+                         const float *gamma, const float *beta, long long E, float eps, float momentum, float *scale,
+                         float *shift, float *mean, float *rstd, double *sums, void *ws)
+{
+    return gg_att_bn2_moments(Z1, scale1, shift1, W2, b2, gamma, beta, E, eps, momentum, scale, shift, mean, rstd,
+                              nullptr, nullptr, nullptr, sums, ws, nullptr);
+}
+
+// moments == NULL: gridgcn_att_bwd_noz; else gridgcn_att_bwd_noz_mom
+int simt_att_bwd_noz(const float *Z1, const float *pscale, const float *pshift, const float *pmean, const float *prstd,
+                     const float *W2, const float *b2, const float *scale, const float *mean, const float *rstd,
+                     const double *sums, const uint8_t *amax, const float *gval, int P, long long E,
+                     const double *moments, float *dX, float *dW, float *m1, float *m2, float *dgamma, float *dbeta,
+                     double *psums, double *s1, void *ws)
+{
+    if (!gg_att_bwd_noz_ok(E, 32, 128) || P < 1 || P > 256 || (E % P)) return GRIDGCN_EINVAL;
+    if (moments && !gg_att_bwd_noz_mom_ok(E, 32, 128, P)) return GRIDGCN_EINVAL;
+    const int rc = gg_att_bwd_noz(Z1, pscale, pshift, pmean, prstd, W2, b2, scale, mean, rstd, sums, amax, gval, P, E,
+                                  dX, dW, m1, m2, dgamma, dbeta, psums, s1, ws, nullptr, moments);
+    return rc == 1 ? GRIDGCN_EINVAL : rc;
+}
+
+int simt_att_pairmax_fwd(const float *Ysrc, const int32_t *nebidx, const float *att16, const float *Wg, const float *b,
+                         int B, int Nsrc, int O, const float *Z1, const float *scale1, const float *shift1,
+                         const float *W2, const float *b2, const float *scale_p, const float *shift_p,
+                         const float *scale_a, const float *shift_a, long long ncent, float *agg, int ld_agg,
+                         uint8_t *amax, float *zsel)
+{
+    if (!gg_att_fwd_ok(ncent, O, 5, 32, 128, ld_agg, (long long)B * Nsrc)) return GRIDGCN_EINVAL;
+    return gg_att_pairmax_args(Ysrc, nebidx, att16, Wg, b, B, Nsrc, O, Z1, scale1, shift1, W2, b2, scale_p, shift_p,
+                               scale_a, shift_a, ncent, agg, ld_agg, amax, zsel, nullptr);
 }
 
 }  // extern "C"

@@ -29,7 +29,7 @@ def load():
 
 def counters():
     """(launches, rendezvous, shuffles that read a lane outside their group, rendezvous in divergent control flow)"""
-    out = (ctypes.c_longlong * 4)()
+    out = (ctypes.c_longlong * 5)()
     load().simt_counters(out)
     return tuple(out)
 
@@ -149,3 +149,55 @@ def KNN(unknown, known, downnum, upnum, k=3):
     rc = lib.simt_knn_all(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k), _ptr(idx))
     assert rc == 0, rc
     return idx
+
+
+# ---- training kernels ---------------------------------------------------------------------------------------------
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def att_bn2_moments(Z1, s1, h1, W2, b2, gamma, beta, eps=1e-3):
+    """gridgcn_att_bn2_moments: (scale, shift, mean, rstd [128], sums [2][128] fp64, moments [17 * 64] fp64)"""
+    lib = load()
+    lib.simt_att_moments_workspace.restype = ctypes.c_size_t
+    lib.simt_att_moments_offset.restype = ctypes.c_size_t
+    Z1, s1, h1, W2, b2, gamma, beta = map(_f32, (Z1, s1, h1, W2, b2, gamma, beta))
+    E = Z1.shape[0]
+    ws = np.full(lib.simt_att_moments_workspace(ctypes.c_longlong(E)) + 64, 0xA5, np.uint8)
+    vec = np.full((4, 128), np.nan, np.float32)
+    sums = np.full((2, 128), np.nan, np.float64)
+    rc = lib.simt_att_bn2_moments(_ptr(Z1), _ptr(s1), _ptr(h1), _ptr(W2), _ptr(b2), _ptr(gamma), _ptr(beta),
+                                  ctypes.c_longlong(E), ctypes.c_float(eps), ctypes.c_float(0.0), _ptr(vec[0]),
+                                  _ptr(vec[1]), _ptr(vec[2]), _ptr(vec[3]), _ptr(sums), _ptr(ws))
+    assert rc == 0, rc
+    off = lib.simt_att_moments_offset(ctypes.c_longlong(E))
+    mom = ws[off:off + 17 * 64 * 8].view(np.float64).copy()
+    return vec, sums, mom
+
+
+def att_bwd_noz(Z1, ps, psh, pm, pr, W2, b2, sc, mu, rs, bsums, amax, gval, P, mom=None, v2=1):
+    """gridgcn_att_bwd_noz (mom None) / gridgcn_att_bwd_noz_mom: dict(dX, dW, v [4][128], psums [2][32], s1 [32])"""
+    lib = load()
+    lib.simt_att_bwd_noz_workspace.restype = ctypes.c_size_t
+    Z1, ps, psh, pm, pr, W2, b2, sc, mu, rs, gval = map(_f32, (Z1, ps, psh, pm, pr, W2, b2, sc, mu, rs, gval))
+    bsums = np.ascontiguousarray(bsums, np.float64)
+    amax = np.ascontiguousarray(amax, np.uint8)
+    E = Z1.shape[0]
+    ws = np.full(lib.simt_att_bwd_noz_workspace(ctypes.c_longlong(E)) + 64, 0xA5, np.uint8)
+    dX = np.full((E + 8, 32), 7.0, np.float32)          # (guard rows: nothing may be written past E)
+    dW = np.full((128, 32), np.nan, np.float32)
+    v = np.full((4, 128), np.nan, np.float32)
+    psums = np.zeros((2, 32), np.float64)
+    s1 = np.zeros(32, np.float64)
+    lib.simt_set_att_nz_v2(int(v2))
+    try:
+        rc = lib.simt_att_bwd_noz(_ptr(Z1), _ptr(ps), _ptr(psh), _ptr(pm), _ptr(pr), _ptr(W2), _ptr(b2), _ptr(sc),
+                                  _ptr(mu), _ptr(rs), _ptr(bsums), _ptr(amax), _ptr(gval), int(P), ctypes.c_longlong(E),
+                                  _ptr(np.ascontiguousarray(mom, np.float64)) if mom is not None else None, _ptr(dX),
+                                  _ptr(dW), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(psums), _ptr(s1),
+                                  _ptr(ws))
+    finally:
+        lib.simt_set_att_nz_v2(1)
+    assert rc == 0, rc
+    assert np.all(dX[E:] == 7.0), "rows past E were written"
+    return dict(dX=dX[:E], dW=dW, v=v, psums=psums, s1=s1)

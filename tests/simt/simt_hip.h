@@ -31,6 +31,10 @@
 #include <functional>
 #include <vector>
 
+using std::isfinite;
+using std::isnan;
+using std::isinf;
+
 // ---- vector types -----------------------------------------------------------------------------------------------
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
@@ -67,8 +71,8 @@ static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 
 // ---- scheduler --------------------------------------------------------------------------------------------------
-enum { SIMT_RUN = 0, SIMT_WAVE = 1, SIMT_BLOCK = 2, SIMT_DONE = 3 };
-enum { SIMT_OP_BALLOT, SIMT_OP_SHFL, SIMT_OP_UP, SIMT_OP_DOWN, SIMT_OP_XOR, SIMT_OP_BAR, SIMT_OP_FIRST };
+enum { SIMT_RUN = 0, SIMT_WAVE = 1, SIMT_BLOCK = 2, SIMT_DONE = 3, SIMT_SPIN = 4 };
+enum { SIMT_OP_BALLOT, SIMT_OP_SHFL, SIMT_OP_UP, SIMT_OP_DOWN, SIMT_OP_XOR, SIMT_OP_BAR, SIMT_OP_FIRST, SIMT_OP_XCHG };
 
 struct SimtFiber {
     ucontext_t ctx;
@@ -76,6 +80,7 @@ struct SimtFiber {
     dim3 tidx;
     int op, arg, width;
     const void *site;
+    int lane;               // lane of the wave (flat work-item number & 63)
     long long seq;          // cross-lane operations executed so far in this launch
     uint64_t val, res;
 };
@@ -86,6 +91,11 @@ inline dim3 simt_blockIdx, simt_blockDim, simt_gridDim;
 inline char *simt_dyn_lds = nullptr;
 inline long long simt_foreign_reads = 0, simt_launches = 0, simt_rendezvous = 0, simt_divergent_rendezvous = 0;
 inline const std::function<void()> *simt_body = nullptr;
+// operands of the wave's last rendezvous, as deposited (SIMT_OP_XCHG: matrix instructions read them lane by lane; it
+// stays valid until the wave's next rendezvous, i.e. until every lane has consumed it) and who took part
+inline uint64_t simt_xchg[64];
+inline bool simt_xchg_in[64];
+inline const void *simt_kernarg = nullptr;      // __builtin_amdgcn_kernarg_segment_ptr(): first argument of the launch
 
 #define threadIdx (simt_cur->tidx)
 #define blockIdx simt_blockIdx
@@ -181,6 +191,10 @@ static inline void simt_resolve_wave(SimtFiber *lanes, int n)
             f.res = lanes[src].val;
         }
     }
+    for (int j = 0; j < 64; j++) {
+        simt_xchg_in[j] = j < n && in[j];
+        simt_xchg[j] = j < n ? lanes[j].val : 0;
+    }
     for (int j = 0; j < n; j++)
         if (in[j]) lanes[j].state = SIMT_RUN;
 }
@@ -192,8 +206,10 @@ inline std::vector<char> simt_lds_buf;
 #define SIMT_STACK (96 * 1024)
 #endif
 
+inline long long simt_spin_rounds = 0;
 static inline void simt_run_block(int nthreads, const dim3 &bd)
 {
+    simt_spin_rounds = 0;
     if ((int)simt_fibers.size() < nthreads) simt_fibers.resize(nthreads);
     if (simt_stacks.size() < (size_t)nthreads * SIMT_STACK) simt_stacks.resize((size_t)nthreads * SIMT_STACK);
     for (int t = 0; t < nthreads; t++) {
@@ -207,6 +223,7 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
         f.tidx = dim3(t % bd.x, (t / bd.x) % bd.y, t / (bd.x * bd.y));
         f.val = f.res = 0;
         f.seq = 0;
+        f.lane = t & 63;
     }
     const int nwave = (nthreads + 63) / 64;
     for (;;) {
@@ -222,10 +239,14 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
                         swapcontext(&simt_sched, &lanes[l].ctx);
                         ran = true;
                     }
-                bool waiting = false;
-                for (int l = 0; l < n; l++) waiting |= lanes[l].state == SIMT_WAVE;
+                bool waiting = false, spinning = false;
+                for (int l = 0; l < n; l++) {
+                    waiting |= lanes[l].state == SIMT_WAVE;
+                    if (lanes[l].state == SIMT_SPIN) { lanes[l].state = SIMT_RUN; spinning = true; }
+                }
                 if (ran) progress = true;
-                if (!waiting) break;
+                // (a lane polling memory -- s_sleep -- gives the other waves a turn: whatever it waits for is theirs)
+                if (!waiting || spinning) break;
                 simt_resolve_wave(lanes, n);
                 progress = true;
             }
@@ -240,6 +261,10 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
             for (int t = 0; t < nthreads; t++)
                 if (simt_fibers[t].state == SIMT_BLOCK) simt_fibers[t].state = SIMT_RUN;
             continue;
+        }
+        if (++simt_spin_rounds > (1ll << 26)) {
+            fprintf(stderr, "simt: livelock (a lane polls for something nobody writes)\n");
+            abort();
         }
         if (!progress) {
             fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d at the barrier, %d done of %d\n", simt_blockIdx.x,
@@ -268,6 +293,7 @@ static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const st
     simt_body = nullptr;
 }
 
+#define SIMT_INL inline __attribute__((always_inline))
 // ---- device intrinsics ------------------------------------------------------------------------------------------
 static inline void __syncthreads() { simt_yield(SIMT_BLOCK); }
 static inline void __threadfence() {}
@@ -289,7 +315,6 @@ template <class T> static inline T simt_unpack(uint64_t u)
     memcpy(&v, &u, sizeof(T));
     return v;
 }
-#define SIMT_INL inline __attribute__((always_inline))
 static SIMT_INL unsigned long long __ballot(int pred) { return simt_collective(SIMT_OP_BALLOT, pred ? 1 : 0, 0, 64); }
 static SIMT_INL int __any(int pred) { return simt_collective(SIMT_OP_BALLOT, pred ? 1 : 0, 0, 64) != 0; }
 static SIMT_INL int __all(int pred) { return simt_collective(SIMT_OP_BALLOT, pred ? 0 : 1, 0, 64) == 0; }
@@ -319,6 +344,46 @@ static SIMT_INL int __builtin_amdgcn_readlane(int v, int lane)
     return simt_unpack<int>(simt_collective(SIMT_OP_SHFL, simt_pack(v), lane, 64));
 }
 
+static inline void simt_sleep() { simt_yield(SIMT_SPIN); }
+#define __builtin_amdgcn_s_sleep(n) simt_sleep()
+#define __builtin_amdgcn_kernarg_segment_ptr() ((void *)simt_kernarg)
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+#define __hip_atomic_fetch_add(p, v, order, scope) simt_fetch_add((p), (v))
+template <class T, class V> static inline T simt_fetch_add(T *p, V v) { T o = *p; *p = (T)(o + (T)v); return o; }
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] B[2x32].  Lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31] and owns
+// D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r = 0..15.  The guide (cdna_hip_programming.md, "FP32-input MFMA"):
+// bit for bit a k-ordered chain of fused multiply-adds, one rounding per product.
+typedef float simt_f32x16 __attribute__((ext_vector_type(16)));
+static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x16 c, int, int, int)
+{
+    uint64_t v = 0;
+    memcpy(&v, &a, 4);
+    memcpy((char *)&v + 4, &b, 4);
+    (void)simt_collective(SIMT_OP_XCHG, v, 0, 64);
+    const int l = simt_cur->lane, col = l & 31, h = l >> 5;
+    float b0, b1;
+    memcpy(&b0, (const char *)&simt_xchg[col] + 4, 4);
+    memcpy(&b1, (const char *)&simt_xchg[col + 32] + 4, 4);
+    if (!simt_xchg_in[col] || !simt_xchg_in[col + 32]) simt_foreign_reads++;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float a0, a1;
+        memcpy(&a0, &simt_xchg[row], 4);
+        memcpy(&a1, &simt_xchg[row + 32], 4);
+        if (!simt_xchg_in[row] || !simt_xchg_in[row + 32]) simt_foreign_reads++;
+        c[r] = __builtin_fmaf(a1, b1, __builtin_fmaf(a0, b0, c[r]));
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 simt_mfma_f32_32x32x2f32
+
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }   // (the GPU's is an approximation within 1 ulp)
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
