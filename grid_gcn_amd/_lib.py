@@ -107,6 +107,15 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError("cannot load %s: %s (grid_gcn_amd has no CPU fallback)" % (LIB_PATH, e))
+    _lib = declare(lib, LIB_PATH)
+    return _lib
+
+
+def declare(lib, path="<library>"):
+    """Attach the prototypes of include/gridgcn.h to an already opened library object and check its ABI version.
+    load() applies it to the HIP library, the one library the package ever opens; the CPU-tier tests apply it to the
+    host-side emulation of the same sources (tests/simt/) to call the same entries on numpy buffers."""
+    LIB_PATH = path
     vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     pp = ctypes.POINTER(GridParams)
     lib.gridgcn_strerror.restype = ctypes.c_char_p
@@ -315,7 +324,6 @@ def load():
     lib.gridgcn_gridconv_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci,
                                              ctypes.POINTER(ConvLayer), ctypes.POINTER(ConvLayer),
                                              vp, vp]
-    _lib = lib
     return lib
 
 

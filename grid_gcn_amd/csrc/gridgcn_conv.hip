@@ -56,6 +56,7 @@ __device__ __forceinline__ void gg_mma(const float *A, int lda, const float *__r
     const int lane = threadIdx.x & 63;
     const float *ap = A + (lane & 31) * lda + (lane >> 5);
     const V *wp = (const V *)Wg + ((lane >> 5) * 32 + (lane & 31));
+    GG_LOCKSTEP();      // (the rows of A were written by other lanes of this wave: the gather, the layer in front)
     // k-step s covers k = 2s, 2s+1 (lane half selects which); packed row stride = 32 V per k
     float a0 = ap[0], a1 = ap[2];
     V b0 = wp[0], b1 = wp[2 * 32];

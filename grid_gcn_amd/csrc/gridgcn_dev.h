@@ -94,6 +94,18 @@ static __device__ unsigned long long *gg_prof_buf = nullptr;
 #define GG_PROF_SETTER(name)
 #endif
 
+// Lanes of a wave execute in lockstep and their LDS operations complete in order: what one lane has stored is there
+// for another lane's next load without any instruction in between.  The host-side emulation of the kernels
+// (tests/simt/) runs the lanes of a wave one after the other between cross-lane operations and needs a rendezvous at
+// such a point; GG_LOCKSTEP() marks it -- a wave barrier there (GG_SIMT), NOTHING in the GPU build.
+#ifndef GG_LOCKSTEP
+#ifdef GG_SIMT
+#define GG_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+#else
+#define GG_LOCKSTEP() ((void)0)
+#endif
+#endif
+
 __device__ __forceinline__ int gg_lane() { return (int)(threadIdx.x & 63); }
 
 // Workgroup number -> (cloud, item of the cloud) for a 1-D launch of B * per_cloud workgroups.

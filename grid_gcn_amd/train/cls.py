@@ -111,7 +111,8 @@ class _EdgeBlockClsTrain(torch.autograd.Function):
             rowb = _mm_nt(ctxv, W2d[:, K12:], bias=b2)                              # [ncent, N0]
             _, ldw, _, _ = packed_sizes(N0, K12)
             Wq = torch.empty(K12 * ldw, dtype=torch.float32, device=dev)
-            _lib.check(lib.gridgcn_pack_linear(_ptr(W2d[:, :K12].contiguous()), None, N0, K12, 0,
+            W12 = W2d[:, :K12].contiguous()       # (a name: the copy must outlive the call that reads it)
+            _lib.check(lib.gridgcn_pack_linear(_ptr(W12), None, N0, K12, 0,
                                                K12, 0, None, None, None, None, _ptr(Wq), None, st),
                        "gridgcn_pack_linear")
             part1 = _pack_bwd_part(lib, W2d[:, :A0].contiguous(), st)

@@ -396,8 +396,9 @@ class _EdgeBlockSrcTrain(torch.autograd.Function):
                 if rot:
                     # geo_vec columns of dW0, written in place by one kernel
                     dW0 = torch.empty((C0, rot + Cf), dtype=torch.float32, device=dev)
+                    ytg = _tn_matmul(Ysrc, Gsum)          # (a name: the product must outlive the call that reads it)
                     rc = lib.gridgcn_edge_lin0_dwg(
-                        _ptr(wgs), _ptr(gg), _ptr(_tn_matmul(Ysrc, Gsum)), _ptr(wgb),
+                        _ptr(wgs), _ptr(gg), _ptr(ytg), _ptr(wgb),
                         _ptr(vec0[0]), _ptr(vec0[2]), _ptr(vec0[3]), _ptr(v[0]), _ptr(v[1]), C0,
                         _ptr(dW0), rot + Cf, st)
                     _lib.check(rc, "gridgcn_edge_lin0_dwg")

@@ -247,7 +247,8 @@ def edge_block_cls_eval(src, nebidx, cent, pt_layers, att1_layers, att2_layers):
         rowb = _mm_nt(ctxv, W2[:, K12:], bias=a20.lin.bias)
         _, ldw, _, _ = packed_sizes(N0, K12)
         Wq = torch.empty(K12 * ldw, dtype=torch.float32, device=dev)
-        _lib.check(lib.gridgcn_pack_linear(_ptr(W2[:, :K12].contiguous()), None, N0, K12, 0, K12, 0,
+        W12 = W2[:, :K12].contiguous()            # (a name: the copy must outlive the call that reads it)
+        _lib.check(lib.gridgcn_pack_linear(_ptr(W12), None, N0, K12, 0, K12, 0,
                                            None, None, None, None, _ptr(Wq), None, st),
                    "gridgcn_pack_linear")
         Z20 = torch.empty((E, N0), dtype=torch.float32, device=dev)

@@ -4,9 +4,14 @@ The kernel sources are taken from grid_gcn_amd/csrc AS THEY ARE, passed through 
 concern launch syntax and GPU-only spellings (what they compute is untouched), and compiled for the HOST (clang++, x86) against
 tests/simt/simt_hip.h:
 
-    k<<<grid, block, lds, stream>>>(args);            ->  simt_launch(grid, block, lds, [&]() { k(args); });
+    k<<<grid, block, lds, stream>>>(args);            ->  simt_launch(grid, block, lds, [&]() { k(args); }, &first arg);
     extern __shared__ [attrs] T name[];               ->  T *name = (T *)simt_dyn_lds;
-    asm volatile("s_waitcnt ..." / "s_barrier")       ->  (nothing / __syncthreads())
+    asm volatile("s_waitcnt ...")                     ->  simt_waitcnt(): a rendezvous of the wave -- the instruction is
+                                                          executed by the WAVE, so every lane's earlier memory
+                                                          operations have been issued when it returns (the last-
+                                                          arriver hand-offs drain a neighbour lane's atomic with it)
+    asm volatile("s_waitcnt ...\n\ts_barrier")        ->  __syncthreads()
+    asm volatile("" : "+s"(x)) and the like           ->  (nothing: register-class pins, scheduling fences)
     __attribute__((amdgpu_...(..)))                   ->  (nothing)
 
     python tests/simt/build.py [--force]
@@ -21,11 +26,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "grid_gcn_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-LIB = os.path.join(OUT, "libsimt_index.so")
-SOURCES = ["gridgcn_index.hip", "gridgcn_index_legacy.hip", "gridgcn_query.hip", "gridgcn_query_knn.hip",
-           "gridgcn_knn.hip", "gridgcn_ballgrid.hip", "gridgcn_fastrand.hip", "gridgcn_cas.hip",
-           # training kernels (fp32 MFMA as a wave rendezvous, raw buffer loads / stores as checked host accesses)
-           "gridgcn_attbwd_nz.hip", "gridgcn_attfwd.hip"]
+LIB = os.path.join(OUT, "libgridgcn_simt.so")
+def _product_sources():
+    """every kernel source of the product's own build (grid_gcn_amd/build.py: SOURCES)"""
+    sys.path.insert(0, ROOT)
+    from grid_gcn_amd import build as product_build
+    return list(product_build.SOURCES)
+
+
+SOURCES = _product_sources()
 CXX = "/opt/rocm/lib/llvm/bin/clang++"      # host compile: the kernels use clang's ext_vector_type / elementwise builtins
 
 
@@ -90,7 +99,8 @@ def rewrite_launches(s):
         a1 = _balanced(s, a0, "(", ")")
         args = s[a0:a1]
         out.append(s[pos:k])
-        out.append("simt_launch(%s, %s, %s, [&]() { %s%s; })" % (grid, block, lds, kern, args))
+        out.append("simt_launch(%s, %s, %s, [&]() { %s%s; }, simt_first_arg%s, \"%s\")" % (
+            grid, block, lds, kern, args, args, kern.replace('"', "")))
         pos = a1
 
 
@@ -98,8 +108,10 @@ def rewrite(text):
     text = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([\w ]+?)\s+(\w+)\[\];",
                   lambda m: "%s *%s = (%s *)simt_dyn_lds;" % (m.group(1), m.group(2), m.group(1)), text)
     text = re.sub(r'asm volatile\("s_waitcnt [^"]*\\n\\ts_barrier"[^;]*;', "__syncthreads();", text)
-    text = re.sub(r'asm volatile\("s_waitcnt [^"]*"[^;]*;', ";", text)
+    text = re.sub(r'asm volatile\("s_waitcnt [^"]*"[^;]*;', "simt_waitcnt();", text)
     text = re.sub(r"__attribute__\(\(amdgpu_\w+\([^)]*\)\)\)", "", text)
+    # empty asm statements that only pin a value to a GPU register class ("+s" / "v": scheduling fences)
+    text = re.sub(r'asm volatile\(""\s*:[^;]*\);', ";", text)
     return rewrite_launches(rewrite_header(text))
 
 
@@ -131,7 +143,7 @@ def build(force=False, verbose=False):
     flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-attributes",
              "-Wno-unused-variable", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-int-to-pointer-cast",
              "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-pass-failed", "-Wno-unused-value",
-             "-include", os.path.join(HERE, "simt_hip.h"), "-D__HIPCC__=1",
+             "-include", os.path.join(HERE, "simt_hip.h"), "-D__HIPCC__=1", "-DGG_SIMT=1",
              "-I" + HERE, "-I" + OUT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
     units = []
     for h in sorted(os.listdir(CSRC)):          # headers: found in _build first (-I order)

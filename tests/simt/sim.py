@@ -1,6 +1,7 @@
-"""numpy front end of the host-side emulation of the index operators (tests/simt/): the signatures of
-grid_gcn_amd.ops (Gridify, GridifyKNN, Gridify_occaware, Gridify_fast_rand, GridifyUp, BallKNN, KNN) on numpy arrays.
-TEST INFRASTRUCTURE -- the product never imports this."""
+"""numpy front end of the host-side emulation of the library (tests/simt/): the operator signatures of
+grid_gcn_amd.ops on numpy arrays, each a call of the SAME C-ABI entry the product binds (include/gridgcn.h:
+gridgcn_gridify, gridgcn_gridify_up, gridgcn_ball_knn, ... -- gridgcn_capi.hip compiled for the host with the rest),
+plus a few of the training entries.  TEST INFRASTRUCTURE -- the product never imports this."""
 import ctypes
 import os
 import sys
@@ -9,34 +10,21 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
 
-from grid_gcn_amd._lib import GridParams  # noqa: E402  (the ctypes mirror of gridgcn_grid_params: a plain struct)
+from grid_gcn_amd import _lib  # noqa: E402
+from grid_gcn_amd._lib import GridParams  # noqa: E402  (the ctypes mirror of gridgcn_grid_params)
+import emu  # noqa: E402
 
-_LIB = None
-
-
-def load():
-    global _LIB
-    if _LIB is None:
-        sys.path.insert(0, HERE)
-        import build as simt_build
-        _LIB = ctypes.CDLL(simt_build.build())
-        _LIB.simt_ball_grid_workspace.restype = ctypes.c_size_t
-    return _LIB
-
-
-def counters():
-    """(launches, rendezvous, shuffles that read a lane outside their group, rendezvous in divergent control flow)"""
-    out = (ctypes.c_longlong * 5)()
-    load().simt_counters(out)
-    return tuple(out)
+load = emu.library
+counters = emu.counters
 
 
 def set_option(which, value):
-    """0: slab shift, 1: chunk, 2: one-launch build for small clouds (gg_index_set_tuning)"""
-    load().simt_set_option(int(which), int(value))
+    """gridgcn_set_option (e.g. _lib.OPT_INDEX_SMALL)"""
+    assert load().gridgcn_set_option(int(which), int(value)) == 0
 
 
 def _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed):
@@ -56,43 +44,50 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def _gridify(mode, data, npn, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0, coord_shift, voxel_size,
-             grid_size, seed=0, beta=0.0):
+def _ws(nbytes):
+    """a caller's workspace: garbage on entry, 64-byte aligned"""
+    raw = np.full(int(nbytes) + 128, 0xA5, np.uint8)
+    off = (-raw.ctypes.data) % 64
+    return raw[off:off + int(nbytes) + 64]
+
+
+def _gridify(fn, data, npn, *, max_p_grid, max_o_grid, kernel_size, stride=1, loc=0, coord_shift, voxel_size,
+             grid_size, seed=0, extra=()):
     lib = load()
     data = np.ascontiguousarray(data, np.float32)
     npn = np.ascontiguousarray(npn, np.int32)
     B, N, _ = data.shape
     p = _params(max_p_grid, max_o_grid, kernel_size, stride, loc, coord_shift, voxel_size, grid_size, seed)
     nb = ctypes.c_size_t(0)
-    rc = lib.simt_gridify_workspace_bytes(mode, B, N, ctypes.byref(p), ctypes.byref(nb))
+    rc = getattr(lib, fn + "_workspace_bytes")(B, N, ctypes.byref(p), ctypes.byref(nb))
     assert rc == 0, rc
-    ws = np.full(nb.value + 64, 0xA5, np.uint8)           # (garbage on entry, as a caller's workspace is)
+    ws = _ws(nb.value)
     O, P = int(max_o_grid), int(max_p_grid)
     nebidx = np.full((B, O, P), -7, np.int32)
     nebmsk = np.full((B, O, P), np.nan, np.float32)
     cent = np.full((B, O, 4), np.nan, np.float32)
     centmsk = np.full((B, O), np.nan, np.float32)
     centnum = np.full((B, 1), -7, np.int32)
-    rc = lib.simt_gridify(mode, _ptr(data), _ptr(npn), B, N, ctypes.byref(p), ctypes.c_float(beta), _ptr(nebidx),
-                          _ptr(nebmsk), _ptr(cent), _ptr(centmsk), _ptr(centnum), _ptr(ws), ctypes.c_size_t(nb.value))
-    assert rc == 0, rc
+    rc = getattr(lib, fn)(_ptr(data), _ptr(npn), B, N, ctypes.byref(p), *extra, _ptr(nebidx), _ptr(nebmsk), _ptr(cent),
+                          _ptr(centmsk), _ptr(centnum), _ptr(ws), nb.value, None)
+    assert rc == 0, (fn, rc)
     return nebidx, nebmsk, cent, centmsk, centnum
 
 
 def Gridify(data, npn, **kw):
-    return _gridify(0, data, npn, **kw)
+    return _gridify("gridgcn_gridify", data, npn, **kw)
 
 
 def GridifyKNN(data, npn, **kw):
-    return _gridify(1, data, npn, **kw)
+    return _gridify("gridgcn_gridify_knn", data, npn, **kw)
 
 
 def Gridify_occaware(data, npn, beta=1.0, **kw):
-    return _gridify(2, data, npn, beta=beta, **kw)
+    return _gridify("gridgcn_gridify_occaware", data, npn, extra=(ctypes.c_float(float(beta)),), **kw)
 
 
 def Gridify_fast_rand(data, npn, **kw):
-    return _gridify(3, data, npn, **kw)
+    return _gridify("gridgcn_gridify_fast_rand", data, npn, **kw)
 
 
 def GridifyUp(down, up, down_np, up_np, *, max_p_grid, max_o_grid, kernel_size, coord_shift, voxel_size, grid_size,
@@ -106,13 +101,12 @@ def GridifyUp(down, up, down_np, up_np, *, max_p_grid, max_o_grid, kernel_size, 
     assert up.shape == (B, max_o_grid, 4)
     p = _params(max_p_grid, max_o_grid, kernel_size, 1, 0, coord_shift, voxel_size, grid_size, seed)
     nb = ctypes.c_size_t(0)
-    rc = lib.simt_gridify_up_workspace_bytes(B, Nd, ctypes.byref(p), ctypes.byref(nb))
-    assert rc == 0, rc
-    ws = np.full(nb.value + 64, 0xA5, np.uint8)
+    assert lib.gridgcn_gridify_up_workspace_bytes(B, Nd, ctypes.byref(p), ctypes.byref(nb)) == 0
+    ws = _ws(nb.value)
     nebidx = np.full((B, max_o_grid, max_p_grid), -7, np.int32)
     nebmsk = np.full((B, max_o_grid, max_p_grid), np.nan, np.float32)
-    rc = lib.simt_gridify_up(_ptr(down), _ptr(up), _ptr(down_np), _ptr(up_np), B, Nd, ctypes.byref(p), _ptr(nebidx),
-                             _ptr(nebmsk), _ptr(ws), ctypes.c_size_t(nb.value))
+    rc = lib.gridgcn_gridify_up(_ptr(down), _ptr(up), _ptr(down_np), _ptr(up_np), B, Nd, ctypes.byref(p), _ptr(nebidx),
+                                _ptr(nebmsk), _ptr(ws), nb.value, None)
     assert rc == 0, rc
     return nebidx, nebmsk
 
@@ -127,12 +121,14 @@ def BallKNN(unknown, known, downnum, upnum, k=3, radius=0.1, grid=False):
     m = known.shape[1]
     idx = np.zeros((B, n, k), np.int32)                   # (rows >= upnum stay untouched: zeros here, as ops.BallKNN)
     if grid:
-        ws = np.full(lib.simt_ball_grid_workspace(B, m) + 64, 0xA5, np.uint8)
-        rc = lib.simt_ball_knn_grid(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k),
-                                    ctypes.c_float(radius), _ptr(idx), _ptr(ws))
+        nb = ctypes.c_size_t(0)
+        assert lib.gridgcn_ball_knn_grid_workspace_bytes(B, m, ctypes.byref(nb)) == 0
+        ws = _ws(nb.value)
+        rc = lib.gridgcn_ball_knn_grid(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k),
+                                       float(radius), _ptr(idx), _ptr(ws), nb.value, None)
     else:
-        rc = lib.simt_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k),
-                               ctypes.c_float(radius), _ptr(idx))
+        rc = lib.gridgcn_ball_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k),
+                                  float(radius), _ptr(idx), None)
     assert rc == 0, rc
     return idx
 
@@ -146,7 +142,7 @@ def KNN(unknown, known, downnum, upnum, k=3):
     B, n, _ = unknown.shape
     m = known.shape[1]
     idx = np.zeros((B, n, k), np.int32)
-    rc = lib.simt_knn_all(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k), _ptr(idx))
+    rc = lib.gridgcn_knn(_ptr(unknown), _ptr(known), _ptr(downnum), _ptr(upnum), B, n, m, int(k), _ptr(idx), None)
     assert rc == 0, rc
     return idx
 
@@ -159,45 +155,54 @@ def _f32(a):
 def att_bn2_moments(Z1, s1, h1, W2, b2, gamma, beta, eps=1e-3):
     """gridgcn_att_bn2_moments: (scale, shift, mean, rstd [128], sums [2][128] fp64, moments [17 * 64] fp64)"""
     lib = load()
-    lib.simt_att_moments_workspace.restype = ctypes.c_size_t
-    lib.simt_att_moments_offset.restype = ctypes.c_size_t
     Z1, s1, h1, W2, b2, gamma, beta = map(_f32, (Z1, s1, h1, W2, b2, gamma, beta))
     E = Z1.shape[0]
-    ws = np.full(lib.simt_att_moments_workspace(ctypes.c_longlong(E)) + 64, 0xA5, np.uint8)
+    nb = ctypes.c_size_t(0)
+    assert lib.gridgcn_att_fwd_noz_workspace_bytes(E, 32, 128, ctypes.byref(nb)) == 0
+    ws = _ws(nb.value)
     vec = np.full((4, 128), np.nan, np.float32)
     sums = np.full((2, 128), np.nan, np.float64)
-    rc = lib.simt_att_bn2_moments(_ptr(Z1), _ptr(s1), _ptr(h1), _ptr(W2), _ptr(b2), _ptr(gamma), _ptr(beta),
-                                  ctypes.c_longlong(E), ctypes.c_float(eps), ctypes.c_float(0.0), _ptr(vec[0]),
-                                  _ptr(vec[1]), _ptr(vec[2]), _ptr(vec[3]), _ptr(sums), _ptr(ws))
+    rc = lib.gridgcn_att_bn2_moments(_ptr(Z1), _ptr(s1), _ptr(h1), _ptr(W2), _ptr(b2), _ptr(gamma), _ptr(beta), E, 32,
+                                     128, float(eps), 0.0, _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]), _ptr(vec[3]), None,
+                                     None, None, _ptr(sums), _ptr(ws), nb.value, None)
     assert rc == 0, rc
-    off = lib.simt_att_moments_offset(ctypes.c_longlong(E))
-    mom = ws[off:off + 17 * 64 * 8].view(np.float64).copy()
+    off = ctypes.c_size_t(0)
+    assert lib.gridgcn_att_moments_offset(E, 32, 128, ctypes.byref(off)) == 0
+    assert off.value + 17 * 64 * 8 == nb.value
+    mom = ws[off.value:off.value + 17 * 64 * 8].view(np.float64).copy()
     return vec, sums, mom
 
 
 def att_bwd_noz(Z1, ps, psh, pm, pr, W2, b2, sc, mu, rs, bsums, amax, gval, P, mom=None, v2=1):
     """gridgcn_att_bwd_noz (mom None) / gridgcn_att_bwd_noz_mom: dict(dX, dW, v [4][128], psums [2][32], s1 [32])"""
     lib = load()
-    lib.simt_att_bwd_noz_workspace.restype = ctypes.c_size_t
     Z1, ps, psh, pm, pr, W2, b2, sc, mu, rs, gval = map(_f32, (Z1, ps, psh, pm, pr, W2, b2, sc, mu, rs, gval))
     bsums = np.ascontiguousarray(bsums, np.float64)
     amax = np.ascontiguousarray(amax, np.uint8)
     E = Z1.shape[0]
-    ws = np.full(lib.simt_att_bwd_noz_workspace(ctypes.c_longlong(E)) + 64, 0xA5, np.uint8)
+    nb = ctypes.c_size_t(0)
+    assert lib.gridgcn_att_bwd_noz_workspace_bytes(E, 32, 128, ctypes.byref(nb)) == 0
+    ws = _ws(nb.value)
     dX = np.full((E + 8, 32), 7.0, np.float32)          # (guard rows: nothing may be written past E)
     dW = np.full((128, 32), np.nan, np.float32)
     v = np.full((4, 128), np.nan, np.float32)
     psums = np.zeros((2, 32), np.float64)
     s1 = np.zeros(32, np.float64)
-    lib.simt_set_att_nz_v2(int(v2))
+    set_option(_lib.OPT_ATT_NZ_V2, v2)
     try:
-        rc = lib.simt_att_bwd_noz(_ptr(Z1), _ptr(ps), _ptr(psh), _ptr(pm), _ptr(pr), _ptr(W2), _ptr(b2), _ptr(sc),
-                                  _ptr(mu), _ptr(rs), _ptr(bsums), _ptr(amax), _ptr(gval), int(P), ctypes.c_longlong(E),
-                                  _ptr(np.ascontiguousarray(mom, np.float64)) if mom is not None else None, _ptr(dX),
-                                  _ptr(dW), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]), _ptr(psums), _ptr(s1),
-                                  _ptr(ws))
+        if mom is not None:
+            mom = np.ascontiguousarray(mom, np.float64)
+            rc = lib.gridgcn_att_bwd_noz_mom(_ptr(Z1), _ptr(ps), _ptr(psh), _ptr(pm), _ptr(pr), _ptr(W2), _ptr(b2),
+                                             _ptr(sc), _ptr(mu), _ptr(rs), _ptr(bsums), _ptr(amax), _ptr(gval), int(P),
+                                             E, 32, 128, _ptr(mom), _ptr(dX), _ptr(dW), _ptr(v[0]), _ptr(v[1]),
+                                             _ptr(v[2]), _ptr(v[3]), _ptr(psums), _ptr(ws), nb.value, None)
+        else:
+            rc = lib.gridgcn_att_bwd_noz(_ptr(Z1), _ptr(ps), _ptr(psh), _ptr(pm), _ptr(pr), _ptr(W2), _ptr(b2),
+                                         _ptr(sc), _ptr(mu), _ptr(rs), _ptr(bsums), _ptr(amax), _ptr(gval), int(P), E,
+                                         32, 128, _ptr(dX), _ptr(dW), _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), _ptr(v[3]),
+                                         _ptr(psums), _ptr(s1), _ptr(ws), nb.value, None)
     finally:
-        lib.simt_set_att_nz_v2(1)
+        set_option(_lib.OPT_ATT_NZ_V2, 1)
     assert rc == 0, rc
     assert np.all(dX[E:] == 7.0), "rows past E were written"
     return dict(dX=dX[:E], dW=dW, v=v, psums=psums, s1=s1)

@@ -13,7 +13,8 @@
 //     there -- are resolved together (simt_resolve_wave).  Lanes run one after the other BETWEEN rendezvous points, so LDS traffic between the lanes
 //     of a wave must be ordered by one -- exactly where the GPU code needs its wave_barrier for the compiler;
 //   * __syncthreads is the rendezvous of every live fibre of the workgroup;
-//   * atomics are plain read-modify-writes (one fibre runs at a time); fences and s_waitcnt are nothing;
+//   * atomics are plain read-modify-writes (one fibre runs at a time); fences are nothing; s_waitcnt is a rendezvous of
+//     the wave (the hardware executes it per wave: what the other lanes issued before it has been issued);
 //   * `__shared__` is a function-local static (workgroups are sequential), `extern __shared__` is rewritten by
 //     tests/simt/build.py into a pointer to the launch's dynamic LDS block, `k<<<g, b, lds, s>>>(args)` into
 //     simt_launch(g, b, lds, [&] { k(args); }).
@@ -69,6 +70,13 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+typedef void *hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 // ---- scheduler --------------------------------------------------------------------------------------------------
 enum { SIMT_RUN = 0, SIMT_WAVE = 1, SIMT_BLOCK = 2, SIMT_DONE = 3, SIMT_SPIN = 4 };
@@ -83,6 +91,7 @@ struct SimtFiber {
     int lane;               // lane of the wave (flat work-item number & 63)
     long long seq;          // cross-lane operations executed so far in this launch
     uint64_t val, res;
+    uint64_t wide[4];       // 32-byte operand of the bf16 matrix instruction
 };
 
 inline SimtFiber *simt_cur = nullptr;
@@ -94,6 +103,7 @@ inline const std::function<void()> *simt_body = nullptr;
 // operands of the wave's last rendezvous, as deposited (SIMT_OP_XCHG: matrix instructions read them lane by lane; it
 // stays valid until the wave's next rendezvous, i.e. until every lane has consumed it) and who took part
 inline uint64_t simt_xchg[64];
+inline uint64_t simt_xchg_wide[64][4];
 inline bool simt_xchg_in[64];
 inline const void *simt_kernarg = nullptr;      // __builtin_amdgcn_kernarg_segment_ptr(): first argument of the launch
 
@@ -194,6 +204,7 @@ static inline void simt_resolve_wave(SimtFiber *lanes, int n)
     for (int j = 0; j < 64; j++) {
         simt_xchg_in[j] = j < n && in[j];
         simt_xchg[j] = j < n ? lanes[j].val : 0;
+        if (op == SIMT_OP_XCHG && j < n) memcpy(simt_xchg_wide[j], lanes[j].wide, 32);
     }
     for (int j = 0; j < n; j++)
         if (in[j]) lanes[j].state = SIMT_RUN;
@@ -275,8 +286,19 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
     simt_cur = nullptr;
 }
 
-static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body)
+// (the kernel-argument segment: the address of the launch's first argument -- one kernel reads its own argument
+//  struct through __builtin_amdgcn_kernarg_segment_ptr())
+template <class A, class... R> static inline const void *simt_first_arg(const A &a, const R &...) { return &a; }
+static inline const void *simt_first_arg() { return nullptr; }
+
+static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body,
+                               const void *kernarg = nullptr, const char *name = "?")
 {
+    simt_kernarg = kernarg;
+    static const bool trace = getenv("SIMT_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "simt: %s <<<(%u,%u,%u), (%u,%u,%u), %zu>>>\n", name, grid.x, grid.y, grid.z, block.x, block.y,
+                block.z, lds_bytes);
     simt_launches++;
     if (simt_lds_buf.size() < lds_bytes + 64) simt_lds_buf.resize(lds_bytes + 64);
     simt_dyn_lds = (char *)(((uintptr_t)simt_lds_buf.data() + 63) & ~(uintptr_t)63);
@@ -294,6 +316,9 @@ static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const st
 }
 
 #define SIMT_INL inline __attribute__((always_inline))
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    simt_launch((grid), (block), (lds), [&]() { kernel(__VA_ARGS__); }, simt_first_arg(__VA_ARGS__), #kernel)
+
 // ---- device intrinsics ------------------------------------------------------------------------------------------
 static inline void __syncthreads() { simt_yield(SIMT_BLOCK); }
 static inline void __threadfence() {}
@@ -335,6 +360,7 @@ template <class T> static SIMT_INL T __shfl_xor(T v, int m, int width = 64)
     return simt_unpack<T>(simt_collective(SIMT_OP_XOR, simt_pack(v), m, width));
 }
 static SIMT_INL void __builtin_amdgcn_wave_barrier() { (void)simt_collective(SIMT_OP_BAR, 0, 0, 64); }
+static SIMT_INL void simt_waitcnt() { (void)simt_collective(SIMT_OP_BAR, 0, 0, 64); }
 static SIMT_INL int __builtin_amdgcn_readfirstlane(int v)
 {
     return simt_unpack<int>(simt_collective(SIMT_OP_FIRST, simt_pack(v), 0, 64));
@@ -382,6 +408,35 @@ static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 simt_mfma_f32_32x32x2f32
+
+// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] B[16x32], bf16 operands, fp32 accumulate.  Lane l supplies
+// A[l & 31][8 (l >> 5) + j] and B[8 (l >> 5) + j][l & 31], j = 0..7.  The products are exact in fp32; the hardware's
+// order of adding the sixteen of them is not documented -- ascending k with one rounding per addition here.
+static inline float simt_bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+template <class V> static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x16_bf16(V a, V b, simt_f32x16 c, int, int, int)
+{
+    static_assert(sizeof(V) == 16, "bf16x8 operands");
+    memcpy(simt_cur->wide, &a, 16);
+    memcpy(simt_cur->wide + 2, &b, 16);
+    (void)simt_collective(SIMT_OP_XCHG, 0, 0, 64);
+    const int l = simt_cur->lane, col = l & 31, h = l >> 5;
+    uint16_t bk[16];
+    memcpy(bk, &simt_xchg_wide[col][2], 16);
+    memcpy(bk + 8, &simt_xchg_wide[col + 32][2], 16);
+    if (!simt_xchg_in[col] || !simt_xchg_in[col + 32]) simt_foreign_reads++;
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        uint16_t ak[16];
+        memcpy(ak, &simt_xchg_wide[row][0], 16);
+        memcpy(ak + 8, &simt_xchg_wide[row + 32][0], 16);
+        if (!simt_xchg_in[row] || !simt_xchg_in[row + 32]) simt_foreign_reads++;
+        float acc = c[r];
+        for (int k = 0; k < 16; k++) acc = __builtin_fmaf(simt_bf16_to_f32(ak[k]), simt_bf16_to_f32(bk[k]), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 simt_mfma_f32_32x32x16_bf16
 
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }   // (the GPU's is an approximation within 1 ulp)
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -1,6 +1,6 @@
 """CPU tier: the PRODUCT's index kernels (grid_gcn_amd/csrc/gridgcn_index*.hip, _query*.hip, _knn.hip, _ballgrid.hip,
-_cas.hip, _fastrand.hip), compiled for the host by g++ under the wave64 SIMT emulator of tests/simt/ and run on
-numpy arrays, against the C oracle and the committed golden fixtures -- bit for bit, every output, every golden
+_cas.hip, _fastrand.hip) behind their C-ABI entries (gridgcn_capi.hip), compiled for the host under the wave64 SIMT
+emulator of tests/simt/ and run on numpy arrays, against the C oracle and the committed golden fixtures -- bit for bit, every output, every golden
 case (the one 4.5 M-voxel case of the legacy build is left to the GPU tier: its kernels launch a work-item per voxel).
 
 This is not the parity proof (that is the `-m gpu` tier: the same comparison on the real machine); it is what
@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import oracle as orc  # noqa: E402
 from golden import make_golden  # noqa: E402
 from test_oracle import check_against_golden  # noqa: E402
-from grid_gcn_amd import synth  # noqa: E402
+from grid_gcn_amd import _lib, synth  # noqa: E402
 from simt import sim  # noqa: E402
 
 ALL = [c for c in make_golden.all_cases() if c[0] != "gridify_legacy_4m_voxels"]
@@ -80,10 +80,10 @@ def test_emulated_split_build_equals_small_build(name, build, run):
     args, kw = build()
     want = run(args, kw)
     try:
-        sim.set_option(2, 0)
+        sim.set_option(_lib.OPT_INDEX_SMALL, 0)
         got = run_sim(name, args, kw)
     finally:
-        sim.set_option(2, 1)
+        sim.set_option(_lib.OPT_INDEX_SMALL, 1)
     _same(got, want, name + " (split build)")
 
 

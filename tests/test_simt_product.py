@@ -1,0 +1,195 @@
+"""CPU tier: the product's HOST code driving the product's KERNELS with no GPU in the machine.
+
+`emulated_gpu()` (tests/simt/emu.py) points grid_gcn_amd._lib at the host-side emulation of the library and lets CPU
+tensors pass for device tensors; the functions below are then the GPU tier's own test bodies (imported from the
+tests/test_gpu_*.py modules, DEV switched to "cpu") at sizes the emulator finishes in seconds: operand packing,
+forward / backward chains with their BatchNorm hand-offs, the segmentation and classification edge blocks against the
+stock PyTorch modules and the float64 fixtures, the round-6 opt-in paths.  Every allocation is poisoned with NaN.
+
+What this proves and what it does not: tests/simt/simt_hip.h.  GG_SIMT_FULL=1 adds the slow cases (all four float64
+fixtures with their gradients, a whole training step of the segmentation net against the CPU model on the oracle's
+index operators: ~10 minutes)."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from simt import emu  # noqa: E402
+
+FULL = os.environ.get("GG_SIMT_FULL") == "1"
+slow = pytest.mark.skipif(not FULL, reason="slow under emulation: set GG_SIMT_FULL=1")
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    c0 = emu.counters()
+    with emu.emulated_gpu():
+        yield
+    c1 = emu.counters()
+    assert c1[2] == c0[2], "a cross-lane read took a lane outside the set executing the operation"
+    assert c1[3] == c0[3], "a cross-lane operation was reached in divergent control flow"
+
+
+def _gpu_module(name):
+    """a tests/test_gpu_*.py module with its device constant pointed at the emulator's tensors"""
+    import importlib
+    m = importlib.import_module(name)
+    if hasattr(m, "DEV"):
+        m.DEV = "cpu"
+    return m
+
+
+@pytest.mark.parametrize("E,cin,dims", [(500, 8, [32, 32, 64]), (300, 3, [32, 64]), (77, 132, [128]),
+                                        (1000, 264, [128, 256]), (31, 24, [8, 128]), (2100, 64, [256, 32])])
+def test_mlp_chain_forward_backward(E, cin, dims):
+    """gridgcn_pack_linear, gridgcn_linear_fwd_direct_fin (BatchNorm finalisation by the last workgroup), the LDS-staged
+    forward for odd widths, gridgcn_linear_bwd_fin (dX / dW / reduce, the column-split forms): against nn.Linear ->
+    BatchNorm1d -> ReLU stacks, outputs, input and parameter gradients, running statistics"""
+    _gpu_module("test_gpu_train_ops").test_mlp_train_matches_torch(E, cin, dims)
+
+
+@pytest.mark.parametrize("E,cin,dims", [(1500, 72, [64, 256, 32]), (95, 64, [256])])
+def test_col_split_equals_whole_rows(E, cin, dims):
+    _gpu_module("test_gpu_train_ops").test_col_split_equals_whole_rows(E, cin, dims)
+
+
+def _to_cpu(fn):
+    """a GPU test body that spells its device "cuda:0": .to("cuda:0") lands on the emulator's (CPU) tensors"""
+    def run(*a, **k):
+        t_to, m_to = torch.Tensor.to, torch.nn.Module.to
+        fix = lambda args: tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in args)  # noqa: E731
+        torch.Tensor.to = lambda self, *aa, **kk: t_to(self, *fix(aa), **kk)
+        torch.nn.Module.to = lambda self, *aa, **kk: m_to(self, *fix(aa), **kk)
+        try:
+            return fn(*a, **k)
+        finally:
+            torch.Tensor.to, torch.nn.Module.to = t_to, m_to
+    return run
+
+
+@pytest.mark.parametrize("cin,pt,att,O,P", [(32, [32, 64], [32, 64, 64], 9, 32),
+                                            pytest.param(0, [64, 64, 128], [64, 128, 128], 40, 64, marks=slow)])
+def test_cls_edge_block(cin, pt, att, O, P):
+    """the classification GridConv edge block (two-source first attention conv, context as a per-centre bias): forward,
+    every gradient, running statistics, evaluation -- against the stock modules"""
+    m = _gpu_module("test_model_cls")
+    _to_cpu(m.test_cls_edge_block_kernels_match_stock_modules)(cin, pt, att, O, P)
+
+
+@pytest.mark.parametrize("name", ["gridconv_seg_L1", pytest.param("gridconv_seg_L0", marks=slow),
+                                  pytest.param("gridconv_up2", marks=slow),
+                                  pytest.param("gridconv_cls_L0", marks=slow)])
+def test_gridconv_float64_fixtures(name):
+    """the GPU tier's fixture tests (north_star's 1e-5 bar, relative to max(1, max|x|)): evaluation kernel and
+    training kernels of one GridConv layer against tests/golden/gridconv_*.npz"""
+    m = _gpu_module("test_gpu_gridconv_golden")
+    m.test_hip_eval_matches_fixture(name)
+    m.test_hip_train_not_worse_than_stock_fp32(name)
+
+
+@slow
+@pytest.mark.parametrize("name", ["gridconv_seg_L1", "gridconv_up2", "gridconv_cls_L0"])
+def test_gridconv_gradients_against_float64(name):
+    _gpu_module("test_gpu_gridconv_golden").test_hip_gradients_bounded_by_stock_fp32(name)
+
+
+def _up_layer_case(seed, B=1, Nsrc=96, O=640):
+    """an up layer of the segmentation net at toy size: [B, Nsrc] source points with 128 features, O up points with
+    5 neighbours each (P = 5: the Z2-free attention pair), centre MLP + update MLP"""
+    from grid_gcn_amd.gridconv import SubGUpdate
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    layer = SubGUpdate(128, [128], 3, False, center_in=4, center_dim=[128], out_dim=[128], bn_decay=0.9).train()
+    for mod in layer.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.3)
+    src = torch.cat([torch.rand(B, Nsrc, 3, generator=g) * 2 - 1, torch.ones(B, Nsrc, 1),
+                     torch.randn(B, Nsrc, 128, generator=g).clamp_(min=0)], 2)
+    upl = torch.cat([torch.rand(B, O, 3, generator=g) * 2 - 1, torch.ones(B, O, 1)], 2)
+    nebidx = torch.randint(-1, Nsrc, (B, O, 5), generator=g, dtype=torch.int32)
+    return layer, src, upl, nebidx
+
+
+def test_up_layer_z2_free_pair_and_round6_moments():
+    """An up layer through the Z2-free attention forward / backward (gridgcn_att_bn2_moments, gridgcn_att_pairmax_fwd,
+    gridgcn_att_bwd_noz) against the stock modules; then the same step with OPT.NOZ_BWD_MOMENTS -- the backward
+    takes S1 / S2 from the forward's moments (round 6) -- against the shipped form: same output, gradients within
+    fp32 round-off of each other."""
+    from grid_gcn_amd import ops
+    from grid_gcn_amd.train.options import OPT
+    layer, src, upl, nebidx = _up_layer_case(5)
+    ref = copy.deepcopy(layer)
+    ref.mfma_train = False
+    state = copy.deepcopy(layer.state_dict())
+    cot = torch.randn(src.shape[0], nebidx.shape[1], 128)
+
+    def step(m, mom, stock=False):
+        m.load_state_dict(state)
+        m.zero_grad(set_to_none=True)
+        s = src.clone().requires_grad_(True)
+        with OPT.override(NOZ_BWD_MOMENTS=mom):
+            if stock:
+                y = m(upl[..., 0:3], ops.batch_take_g(s, nebidx), None, center_ori_feats=upl)
+            else:
+                y = m.forward_src(upl, s, nebidx, None, center_ori_feats=upl)
+            (y * cot).sum().backward()
+        return y.detach(), s.grad.detach(), [p.grad.detach().clone() for p in m.parameters()]
+
+    y0, gs0, gp0 = step(ref, False, stock=True)
+    y1, gs1, gp1 = step(layer, False)
+    y2, gs2, gp2 = step(layer, True)
+    scale = max(1.0, float(y0.abs().max()))
+    assert float((y1 - y0).abs().max()) <= 1e-5 * scale
+    assert torch.equal(y2, y1)                                   # the forward is the same code
+    # (feature columns: the kernels treat the coordinates as data -- the model feeds them detached)
+    gs0, gs1, gs2 = gs0[..., 4:], gs1[..., 4:], gs2[..., 4:]
+    gscale = max(1e-6, float(gs0.abs().max()))
+    assert float((gs1 - gs0).abs().max()) <= 2e-4 * gscale
+    assert float((gs2 - gs1).abs().max()) <= 1e-6 * gscale       # dX path: same arithmetic, same order
+    for (n, _), a, b, c in zip(layer.named_parameters(), gp0, gp1, gp2):
+        if n.endswith("lin.bias"):
+            continue                                             # (a bias in front of a BatchNorm: exact 0 vs noise)
+        s_ = max(1e-6, float(a.abs().max()))
+        assert float((b - a).abs().max()) <= 5e-4 * s_, n
+        assert float((c - b).abs().max()) <= 5e-6 * s_, n
+
+
+@slow
+def test_segmentation_training_step_against_the_cpu_model():
+    """one forward + backward of GGCNSeg (1 x 1024 points) through every kernel of the training path against the same
+    net on the oracle's index operators and the stock modules: the loss to fp32 round-off; the gradient as a vector
+    (a 24-row BatchNorm in the coarsest layer makes single entries discretely sensitive at this size)"""
+    from grid_gcn_amd import model, synth
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(0)
+    data, npn = synth.make_batch(1, 1024, "planes")
+    cfg = dict(model.SEG_8192, dropout=0.0)
+    with emu.emulated_gpu(poison=False):      # (plain CPU reference: no emulated kernel in it)
+        pass
+    net_cpu = model.GGCNSeg(cfg, index_ops=OracleIndexOps).train()
+    net_emu = model.GGCNSeg(cfg)
+    net_emu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    net_emu.train()
+    x, n = torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn)
+    lab = torch.randint(1, 21, (1, 1024))
+    loss = model.seg_loss(net_emu(x, n), lab)
+    loss.backward()
+    torch.Tensor.is_cuda_saved = None
+    # the reference outside the emulation: plain CPU tensors on the stock path
+    del torch.Tensor.is_cuda
+    try:
+        loss_cpu = model.seg_loss(net_cpu(x, n), lab)
+        loss_cpu.backward()
+    finally:
+        torch.Tensor.is_cuda = property(lambda self: True)
+    assert abs(float(loss) - float(loss_cpu)) <= 5e-6 * max(1.0, abs(float(loss_cpu)))
+    ga = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    gb = torch.cat([p.grad.reshape(-1) for p in net_emu.parameters()]).double()
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert 1.0 - cos < 2e-3, cos
