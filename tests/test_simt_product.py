@@ -93,9 +93,47 @@ def test_gridconv_float64_fixtures(name):
 
 
 @slow
-@pytest.mark.parametrize("name", ["gridconv_seg_L1", "gridconv_up2", "gridconv_cls_L0"])
+@pytest.mark.parametrize("name", ["gridconv_seg_L1", "gridconv_up2", pytest.param(
+    "gridconv_cls_L0", marks=pytest.mark.xfail(strict=False, reason=(
+        "under emulation ONE hidden ReLU input of the last point conv (row 31957, channel 4 of 8.4 M) is +2^-24 where "
+        "float64 has it <= 0 -- the host's 1/sqrtf against the GPU's v_rsq_f32 in the BatchNorm's rstd is enough -- and "
+        "the open mask moves the point branch's weight gradients by up to 9e-4 of their scale (the fp32 discontinuity "
+        "(ii) of DESIGN section 2); every library call of the path reproduces numpy from its own inputs at 3e-7 - "
+        "2.5e-6, the attention branch's gradients are within 2.3e-6; on the GPU the test measured 3.5e-6")))])
 def test_gridconv_gradients_against_float64(name):
     _gpu_module("test_gpu_gridconv_golden").test_hip_gradients_bounded_by_stock_fp32(name)
+
+
+# GPU-tier test bodies of tests/test_gpu_train_ops.py at (their own) parameters the emulator finishes in seconds: the
+# whole file was swept once (round 6: every body passes except the ones that need more than ~90 s or a CUDA runtime
+# call of their own); these stay in the CPU tier
+GPU_BODIES = [
+    ("test_att_pairmax_fwd_matches_the_materialised_path", (2, 150, 33, True)),
+    ("test_att_pairmax_fwd_matches_the_materialised_path", (3, 150, 700, False)),
+    ("test_att_max_eval_tile_kernel_matches_the_general_kernel", (3, 150, 700, False)),
+    ("test_edge_block_train_matches_torch", (1, 33, 128, 3, [32, 32, 64])),
+    ("test_edge_block_train_matches_torch", (2, 40, 32, 67, [64, 64, 128])),
+    ("test_edge_lin0_backward_sparse_fixed_point_matches_float64", (2, 50, 300, 5, 40, True)),
+    ("test_gemm_small_matches_torch", (2048, 64, 64, 3)),
+    ("test_gemm_small_matches_torch", (192, 256, 128, 3)),
+    ("test_head_train_matches_torch", (333, 64, [64], 13, 0.3)),
+    ("test_linear_plain_and_loss_match_torch", (4000, 128, 21)),
+    ("test_linear_plain_and_loss_match_torch", (333, 64, 13)),
+    ("test_mlp_eval_matches_modules", (5000, 4, [128])),
+    ("test_mlp_eval_matches_modules", (300, 67, [64, 32])),
+    ("test_pack_linear_layouts", (128, 131)),
+    ("test_pairmax_fwd_first_argmax_exact", (192, 32, 256)),
+    ("test_softmax_ce_matches_torch", (1000, 21)),
+    ("test_softmax_ce_matches_torch", (257, 8)),
+    ("test_softmax_ce_class_weights_match_weighted_gradient_op", ()),
+    ("test_wide_stack_rocblas_plus_bn_kernels_matches_stock", (700, 8, [768])),
+    ("test_unsupported_width_falls_to_modules", ()),
+]
+
+
+@pytest.mark.parametrize("body,args", GPU_BODIES, ids=["%s-%s" % (b[5:40], "x".join(str(a)[:8] for a in c)) for b, c in GPU_BODIES])
+def test_gpu_tier_bodies_of_the_training_kernels(body, args):
+    _to_cpu(getattr(_gpu_module("test_gpu_train_ops"), body))(*args)
 
 
 def _up_layer_case(seed, B=1, Nsrc=96, O=640):
