@@ -132,8 +132,24 @@ def _stamp():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    """one translation unit per kernel source, as the product's own build (grid_gcn_amd/build.py), plus the driver"""
+def build(force=False, verbose=False, asan=False):
+    """one translation unit per kernel source, as the product's own build (grid_gcn_amd/build.py), plus the driver.
+    asan=True: libgridgcn_simt_asan.so, every unit with -fsanitize=address (run the python process with the runtime
+    preloaded: tests/simt/asan.sh)"""
+    import concurrent.futures
+    global OUT, LIB
+    if asan:
+        saved = (OUT, LIB)
+        OUT = os.path.join(HERE, "_build", "asan")
+        LIB = os.path.join(OUT, "libgridgcn_simt_asan.so")
+        try:
+            return _build(force, verbose, ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"])
+        finally:
+            OUT, LIB = saved
+    return _build(force, verbose, [])
+
+
+def _build(force, verbose, extra):
     import concurrent.futures
     os.makedirs(OUT, exist_ok=True)
     stamp_file = os.path.join(OUT, "stamp")
@@ -144,7 +160,7 @@ def build(force=False, verbose=False):
              "-Wno-unused-variable", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-int-to-pointer-cast",
              "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-pass-failed", "-Wno-unused-value",
              "-include", os.path.join(HERE, "simt_hip.h"), "-D__HIPCC__=1", "-DGG_SIMT=1",
-             "-I" + HERE, "-I" + OUT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
+             "-I" + HERE, "-I" + OUT, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")] + extra
     units = []
     for h in sorted(os.listdir(CSRC)):          # headers: found in _build first (-I order)
         if h.endswith(".h"):
@@ -171,7 +187,7 @@ def build(force=False, verbose=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, units))
-    cmd = [CXX, "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
+    cmd = [CXX, "-shared", "-fPIC"] + extra + objs + ["-o", LIB + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("simt link failed:\n" + r.stderr[-6000:])
@@ -182,4 +198,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))

@@ -37,7 +37,9 @@ def library():
     global _EMU
     if _EMU is None:
         import build as simt_build
-        lib = ctypes.CDLL(simt_build.build())
+        # GG_SIMT_ASAN=1: the AddressSanitizer build (the process must have been started with the runtime preloaded:
+        # tests/simt/asan.sh)
+        lib = ctypes.CDLL(simt_build.build(asan=os.environ.get("GG_SIMT_ASAN") == "1"))
         _EMU = _lib.declare(lib, "tests/simt emulation")
         _EMU.simt_counters.argtypes = [ctypes.c_void_p]
     return _EMU

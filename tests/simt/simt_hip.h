@@ -112,18 +112,52 @@ inline const void *simt_kernarg = nullptr;      // __builtin_amdgcn_kernarg_segm
 #define blockDim simt_blockDim
 #define gridDim simt_gridDim
 
+// AddressSanitizer build (tests/simt/build.py --asan: the CPU build is where a sanitizer can look at these kernels):
+// the fibre switches are announced, so that ASan knows which stack it is on
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SIMT_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+inline const void *simt_sched_stack = nullptr;
+inline size_t simt_sched_stack_size = 0;
+
 static inline void simt_yield(int st)
 {
     SimtFiber *f = simt_cur;
     f->state = st;
+#ifdef SIMT_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(st == SIMT_DONE ? nullptr : &fake, simt_sched_stack, simt_sched_stack_size);
+#endif
     swapcontext(&f->ctx, &simt_sched);
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(fake, &simt_sched_stack, &simt_sched_stack_size);
+#endif
 }
 
 static void simt_entry()
 {
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &simt_sched_stack, &simt_sched_stack_size);
+#endif
     (*simt_body)();
-    simt_cur->state = SIMT_DONE;
-    swapcontext(&simt_cur->ctx, &simt_sched);
+    simt_yield(SIMT_DONE);
+}
+
+// scheduler -> fibre
+static inline void simt_resume(SimtFiber *f, char *stack, size_t size)
+{
+    simt_cur = f;
+#ifdef SIMT_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, stack, size);
+#endif
+    swapcontext(&simt_sched, &f->ctx);
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
 }
 
 __attribute__((noinline)) static uint64_t simt_collective(int op, uint64_t val, int arg, int width)
@@ -246,8 +280,7 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
                 bool ran = false;
                 for (int l = 0; l < n; l++)
                     if (lanes[l].state == SIMT_RUN) {
-                        simt_cur = &lanes[l];
-                        swapcontext(&simt_sched, &lanes[l].ctx);
+                        simt_resume(&lanes[l], simt_stacks.data() + (size_t)(w * 64 + l) * SIMT_STACK, SIMT_STACK);
                         ran = true;
                     }
                 bool waiting = false, spinning = false;
