@@ -45,24 +45,40 @@
 
 /* ---- cuRAND XORWOW, curand_init(seed, 0, 0) then first curand_uniform ------- */
 /* call sites: gridify.cu:149-150, 182-183, 260-261; gridify_up.cu:162-163        */
-float gridgcn_oracle_xorwow_uniform(uint64_t seed)
+/* The generator with its four seed-scramble constants as parameters: n-th raw 32-bit output (n >= 1)
+ * of the state seeded with (seed, subsequence 0, offset 0).  Marsaglia's xorwow (state words, shifts 2 / 1 / 4,
+ * Weyl increment 362437) + the seeding pattern x0 += t0, x1 ^= t0, x2 += t1, x3 ^= t1, x4 += t0, d += t1 + t0.
+ * tests/test_oracle.py::test_xorwow_skeleton_is_rocrands runs this skeleton with rocRAND's constants against
+ * rocRAND's own host-callable engine (/opt/rocm/include/rocrand/rocrand_xorwow.h, in the image): everything
+ * but cuRAND's four scramble constants and the 2^-33 offset of _curand_uniform is checked there against a
+ * vendor implementation of the same published generator. */
+uint32_t gridgcn_oracle_xorwow_raw(uint64_t seed, uint32_t xs0, uint32_t xs1, uint32_t m0, uint32_t m1, int n)
 {
-    uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
-    uint32_t s1 = ((uint32_t)(seed >> 32)) ^ 0xf7dcefddu;
-    uint32_t t0 = 1099087573u * s0;
-    uint32_t t1 = 2591861531u * s1;
+    uint32_t s0 = ((uint32_t)seed) ^ xs0;
+    uint32_t s1 = ((uint32_t)(seed >> 32)) ^ xs1;
+    uint32_t t0 = m0 * s0;
+    uint32_t t1 = m1 * s1;
     uint32_t d = 6615241u + t1 + t0;
     uint32_t v0 = 123456789u + t0;
     uint32_t v1 = 362436069u ^ t0;
     uint32_t v2 = 521288629u + t1;
     uint32_t v3 = 88675123u ^ t1;
     uint32_t v4 = 5783321u + t0;
-    /* one XORWOW step */
-    uint32_t t = v0 ^ (v0 >> 2);
-    (void)v1; (void)v2; (void)v3;
-    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
-    d += 362437u;
-    uint32_t x = v4 + d;
+    uint32_t x = 0;
+    for (int i = 0; i < n; i++) {   /* one XORWOW step */
+        uint32_t t = v0 ^ (v0 >> 2);
+        v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+        v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
+        d += 362437u;
+        x = v4 + d;
+    }
+    return x;
+}
+
+float gridgcn_oracle_xorwow_uniform(uint64_t seed)
+{
+    /* cuRAND's scramble constants (curand_kernel.h, _curand_init_scratch): recalled, unverifiable here */
+    uint32_t x = gridgcn_oracle_xorwow_raw(seed, 0xaad26b49u, 0xf7dcefddu, 1099087573u, 2591861531u, 1);
     /* _curand_uniform: x * 2^-32 + 2^-33, one rounding (product is exact) */
     return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
 }

@@ -37,6 +37,28 @@ def _load():
     return _lib
 
 
+def xorwow_raw(seed, xs0, xs1, m0, m1, n=1):
+    """n-th raw 32-bit output of the oracle's XORWOW skeleton under the four seed-scramble constants given."""
+    lib = _load()
+    lib.gridgcn_oracle_xorwow_raw.restype = ctypes.c_uint32
+    lib.gridgcn_oracle_xorwow_raw.argtypes = [ctypes.c_uint64] + [ctypes.c_uint32] * 4 + [ctypes.c_int]
+    return int(lib.gridgcn_oracle_xorwow_raw(ctypes.c_uint64(seed & (2**64 - 1)), xs0, xs1, m0, m1, n))
+
+
+def rocrand_xorwow_raw(seed, n=1):
+    """n-th raw output of rocRAND's own XORWOW engine (oracle/xorwow_rocrand.cpp); None when the image has no rocRAND
+    headers."""
+    so = os.path.join(_HERE, "_build", "libxorwow_rocrand.so")
+    if not os.path.exists(so):
+        subprocess.call(["make", "-C", _HERE, "-s"])
+    if not os.path.exists(so):
+        return None
+    lib = ctypes.CDLL(so)
+    lib.gridgcn_rocrand_xorwow_raw.restype = ctypes.c_uint32
+    lib.gridgcn_rocrand_xorwow_raw.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    return int(lib.gridgcn_rocrand_xorwow_raw(ctypes.c_uint64(seed & (2**64 - 1)), n))
+
+
 def threads_for(work):
     """OpenMP team size the oracle uses for a loop of `work` independent clouds / queries."""
     lib = _load()

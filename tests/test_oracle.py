@@ -41,6 +41,28 @@ def test_xorwow_restatements_agree():
     assert abs(np.mean(u) - 0.5) < 0.01
 
 
+def test_xorwow_skeleton_is_rocrands():
+    """The oracle's XORWOW -- Marsaglia's state words and shifts, the Weyl increment, the seeding pattern, output =
+    x4 + d -- against a vendor implementation of the same published generator that IS in the image: rocRAND's
+    host-callable xorwow_engine (/opt/rocm/include/rocrand/rocrand_xorwow.h).  rocRAND scrambles the seed with four
+    constants of its own, so the oracle's skeleton is run with those; what this does NOT check is cuRAND's four
+    scramble constants and the 2^-33 offset of curand_uniform (no CUDA toolkit here: they stay recalled)."""
+    if orc.rocrand_xorwow_raw(0) is None:
+        pytest.skip("no rocRAND headers in this image")
+    rr = (0x2c7f967f, 0xa03697cb, 1228688033, 2073658381)      # rocrand_xorwow.h: xorwow_engine(seed, 0, 0)
+    rng = np.random.default_rng(5)
+    seeds = [0, 1, 2, 12345, 2 ** 31 - 1, 2 ** 32, 2 ** 33 + 7, 2 ** 64 - 5] + [int(x) for x in
+                                                                                 rng.integers(0, 2 ** 63, 200)]
+    for s in seeds:
+        for n in (1, 2, 3, 7):
+            assert orc.xorwow_raw(s, *rr, n) == orc.rocrand_xorwow_raw(s, n), (s, n)
+    # and the uniform the operators draw is the first output of the same skeleton under cuRAND's constants
+    for s in seeds[:40]:
+        x = orc.xorwow_raw(s, 0xaad26b49, 0xf7dcefdd, 1099087573, 2591861531, 1)
+        u = np.float32(np.float32(x) * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2.0))
+        assert np.float32(orc.xorwow_uniform(s)) == u
+
+
 @pytest.mark.parametrize("seed", [0, 7, 123456])
 def test_oracle_equals_order_independent_form_gridify(seed):
     """S0 (sequential simulation) == "largest index wins" formulation used by the kernels."""
