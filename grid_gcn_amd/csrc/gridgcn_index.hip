@@ -421,9 +421,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_num_sgpr(80))) void 
             const unsigned vl = valid ? (unsigned)mylvl[i] : 0u;
             const int id = valid ? mylid[i] : 0;
             const unsigned long long peers = gg_wave_peers(valid, vl, sp.SB);
+            const int rank = __popcll(peers & lt), npeer = __popcll(peers);
+            // (every peer reads the voxel's counter, THEN the last peer advances it: one load instruction, one later
+            //  store of the wave -- lockstep; the store depends on the load's value)
+            const int base = valid ? wc[wave * S + vl] : 0;
+            GG_LOCKSTEP();
             if (valid) {
-                const int rank = __popcll(peers & lt), npeer = __popcll(peers);
-                const int base = wc[wave * S + vl];
                 const int pos = base + rank;
                 if (rank == npeer - 1) wc[wave * S + vl] = base + npeer;
                 a.sorted[gbase + pos] = id;
@@ -705,9 +708,10 @@ __global__ __launch_bounds__(1024) void gg_k_small_build(GGSmallArgs a, GGGrid g
 #pragma unroll
         for (int j = 0; j < IPT; j++) {
             const unsigned long long peers = gg_wave_peers(val[j], (unsigned)dig[j], rb);
+            const int rank = __popcll(peers & lt), npeer = __popcll(peers);
+            const int base = val[j] ? wc[wave * nb + dig[j]] : 0;     // (all peers read, then the last one advances)
+            GG_LOCKSTEP();
             if (val[j]) {
-                const int rank = __popcll(peers & lt), npeer = __popcll(peers);
-                const int base = wc[wave * nb + dig[j]];
                 nv[base + rank] = v[j];
                 ni[base + rank] = idv[j];
                 if (IPT > 1 && rank == npeer - 1) wc[wave * nb + dig[j]] = base + npeer;

@@ -126,13 +126,17 @@ def _stamp():
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".h") or f in SOURCES:
             h.update(open(os.path.join(CSRC, f), "rb").read())
-    for f in ("simt_hip.h", "driver.cpp", "simt_buf.cpp", "build.py"):
+    for f in ("simt_hip.h", "driver.cpp", "simt_buf.cpp", "simt_race.cpp", "build.py"):
         h.update(open(os.path.join(HERE, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "gridgcn.h"), "rb").read())
     return h.hexdigest()
 
 
-def build(force=False, verbose=False, asan=False):
+RACE_FLAGS = ["-DSIMT_RACE=1", "-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0", "-mllvm",
+              "-tsan-instrument-memintrinsics=0", "-mllvm", "-tsan-instrument-atomics=0"]
+
+
+def build(force=False, verbose=False, asan=False, race=False):
     """one translation unit per kernel source, as the product's own build (grid_gcn_amd/build.py), plus the driver.
     asan=True: libgridgcn_simt_asan.so, every unit with -fsanitize=address (run the python process with the runtime
     preloaded: tests/simt/asan.sh)"""
@@ -146,10 +150,19 @@ def build(force=False, verbose=False, asan=False):
             return _build(force, verbose, ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"])
         finally:
             OUT, LIB = saved
+    if race:
+        # clang's ThreadSanitizer INSTRUMENTATION of the kernel units, tests/simt/simt_race.cpp as its runtime
+        saved = (OUT, LIB)
+        OUT = os.path.join(HERE, "_build", "race")
+        LIB = os.path.join(OUT, "libgridgcn_simt_race.so")
+        try:
+            return _build(force, verbose, RACE_FLAGS, race=True)
+        finally:
+            OUT, LIB = saved
     return _build(force, verbose, [])
 
 
-def _build(force, verbose, extra):
+def _build(force, verbose, extra, race=False):
     import concurrent.futures
     os.makedirs(OUT, exist_ok=True)
     stamp_file = os.path.join(OUT, "stamp")
@@ -174,10 +187,16 @@ def _build(force, verbose, extra):
             f.write(text)
         units.append(cpp)
     units += [os.path.join(HERE, "driver.cpp"), os.path.join(HERE, "simt_buf.cpp")]
+    plain = set()         # units of the race build that are NOT instrumented: the detector and the buffer intrinsics
+    if race:
+        plain = {os.path.join(HERE, "simt_buf.cpp"), os.path.join(HERE, "simt_race.cpp")}
+        units.append(os.path.join(HERE, "simt_race.cpp"))
 
     def compile_one(cpp):
         obj = os.path.join(OUT, os.path.basename(cpp) + ".o")
-        cmd = [CXX] + flags + ["-c", cpp, "-o", obj]
+        fl = [f for f in flags if not (cpp in plain and (f.startswith("-fsanitize") or f.startswith("-tsan") or
+                                                          f == "-mllvm"))]
+        cmd = [CXX] + fl + ["-c", cpp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -187,7 +206,7 @@ def _build(force, verbose, extra):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, units))
-    cmd = [CXX, "-shared", "-fPIC"] + extra + objs + ["-o", LIB + ".tmp"]
+    cmd = [CXX, "-shared", "-fPIC"] + ([] if race else extra) + objs + (["-ldl"] if race else []) + ["-o", LIB + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("simt link failed:\n" + r.stderr[-6000:])
@@ -197,5 +216,32 @@ def _build(force, verbose, extra):
     return LIB
 
 
+def build_selftest():
+    """tests/simt/race_selftest.hip through the same rewrites and the same instrumentation -> a library of its own
+    with the detector linked in (tests/test_simt_race.py)"""
+    out = os.path.join(HERE, "_build", "race_selftest")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "librace_selftest.so")
+    srcs = [os.path.join(HERE, f) for f in ("race_selftest.hip", "simt_race.cpp", "simt_hip.h", "build.py")]
+    if os.path.exists(lib) and all(os.path.getmtime(lib) > os.path.getmtime(f) for f in srcs):
+        return lib
+    cpp = os.path.join(out, "race_selftest.simt.cpp")
+    with open(cpp, "w") as f:
+        f.write("// generated by tests/simt/build.py from tests/simt/race_selftest.hip -- do not edit\n")
+        f.write(rewrite(open(srcs[0]).read()))
+    base = ["-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-attributes",
+            "-include", os.path.join(HERE, "simt_hip.h"), "-DGG_SIMT=1", "-DSIMT_RACE=1", "-I" + HERE]
+    for unit, extra in ((cpp, RACE_FLAGS), (srcs[1], ["-DSIMT_RACE=1"])):
+        r = subprocess.run([CXX] + base + extra + ["-c", unit, "-o", unit + ".o" if unit == cpp else
+                            os.path.join(out, "simt_race.o")], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("race selftest build failed:\n" + r.stderr[-4000:])
+    r = subprocess.run([CXX, "-shared", "-fPIC", cpp + ".o", os.path.join(out, "simt_race.o"), "-ldl", "-o", lib],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("race selftest link failed:\n" + r.stderr[-4000:])
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv, race="--race" in sys.argv))

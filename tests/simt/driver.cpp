@@ -12,3 +12,12 @@ extern "C" void simt_counters(long long *out)
     out[3] = simt_divergent_rendezvous;    // ... reached in divergent control flow (the emulator had to guess)
     out[4] = simt_buf_oob;                 // buffer dwords outside their descriptor's range (partial tiles: legitimate)
 }
+
+// schedule of the launches that follow (simt_hip.h: simt_order, a bit mask): 0 ascending; 1 / 2 / 4 workgroups / waves /
+// lanes descending; 8 workgroups permuted
+extern "C" void simt_set_order(int order) { simt_order = order; }
+// ... restricted to launches whose kernel expression contains `substr` ("" = all): which kernel is it that depends on order?
+extern "C" void simt_set_order_filter(const char *substr)
+{
+    strncpy(simt_order_filter, substr ? substr : "", sizeof simt_order_filter - 1);
+}

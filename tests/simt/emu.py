@@ -39,10 +39,75 @@ def library():
         import build as simt_build
         # GG_SIMT_ASAN=1: the AddressSanitizer build (the process must have been started with the runtime preloaded:
         # tests/simt/asan.sh)
-        lib = ctypes.CDLL(simt_build.build(asan=os.environ.get("GG_SIMT_ASAN") == "1"))
+        # GG_SIMT_RACE=1: the data-race detector (tests/simt/simt_race.cpp); its report goes to the file named by
+        # GG_SIMT_RACE_REPORT when the process ends (tests/simt/race.sh)
+        race = os.environ.get("GG_SIMT_RACE") == "1"
+        lib = ctypes.CDLL(simt_build.build(asan=os.environ.get("GG_SIMT_ASAN") == "1", race=race))
         _EMU = _lib.declare(lib, "tests/simt emulation")
         _EMU.simt_counters.argtypes = [ctypes.c_void_p]
+        if race:
+            import atexit
+            atexit.register(_write_race_report)
     return _EMU
+
+
+def race_report(lib=None):
+    """[(kind, kernel, file:line of the earlier access, file:line of the later one, count, example)] of the race build
+    (or of another library with the detector linked in)"""
+    import subprocess
+    lib = lib or library()
+    lib.simt_race_report.restype = ctypes.c_int
+    lib.simt_race_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(1 << 22)
+    lib.simt_race_report(buf, len(buf))
+    rows = [ln.split("\t") for ln in buf.value.decode().splitlines() if ln]
+    if not rows:
+        return []
+    so = rows[0][2]
+    addrs = [a for r in rows for a in (r[3], r[4])]
+    # (the address of the call's return: one byte back is inside the access's own line)
+    sym = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "--obj=" + so, "--functions=none", "--no-inlines"] +
+                         [hex(int(a, 16) - 1) for a in addrs], capture_output=True, text=True).stdout
+    locs = [ln.strip() for ln in sym.splitlines() if ln.strip()]
+
+    def hip_line(l):
+        # generated unit -> the product's source: one header line was added in front (tests/simt/build.py)
+        f, _, rest = os.path.basename(l).partition(":")
+        if f.endswith(".simt.cpp") and rest.split(":")[0].isdigit():
+            return "%s:%d" % (f.replace(".simt.cpp", ".hip"), int(rest.split(":")[0]) - 1)
+        if rest.split(":")[0].isdigit():
+            return "%s:%s" % (f, rest.split(":")[0])
+        return os.path.basename(l)
+
+    locs = [hip_line(l) for l in locs]
+    agg = {}        # template instantiations and inlined copies of one source line: one row
+    for i, r in enumerate(rows):
+        a, b = (locs[2 * i], locs[2 * i + 1]) if len(locs) >= 2 * i + 2 else (r[3], r[4])
+        same = r[6].startswith("same-value stores: ")
+        k = (r[0], r[1], a, b)
+        if k in agg:
+            n, ex, sm = agg[k]
+            agg[k] = (n + int(r[5]), ex if sm or not same else r[6], sm and same)
+        else:
+            agg[k] = (int(r[5]), r[6], same)
+    return [(k[0], k[1], k[2], k[3], v[0], v[1] if v[2] or not v[1].startswith("same-value") else
+             v[1][len("same-value stores: "):]) for k, v in sorted(agg.items())]
+
+
+def race_counters():
+    """(instrumented accesses checked, conflicts seen, distinct reports)"""
+    out = (ctypes.c_longlong * 3)()
+    library().simt_race_counters(out)
+    return tuple(out)
+
+
+def _write_race_report():
+    path = os.environ.get("GG_SIMT_RACE_REPORT", "/tmp/simt_race_report.txt")
+    rows = race_report()
+    with open(path, "w") as f:
+        f.write("# accesses checked %d, conflicts %d, distinct %d\n" % race_counters())
+        for r in rows:
+            f.write("%s\t%s\t%s\t%s\t%d\t%s\n" % r)
 
 
 def counters():

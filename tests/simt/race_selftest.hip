@@ -1,0 +1,123 @@
+// race_selftest.hip -- kernels with KNOWN races (and their repaired forms) for the detector of tests/simt/simt_race.cpp.
+// TEST INFRASTRUCTURE: compiled only for the host, by tests/simt/build.py: build_selftest(), through the same rewrites
+// and the same instrumentation as the product's sources; tests/test_simt_race.py says which reports must appear.
+
+// LDS written by one wave and read by another: with / without the barrier
+__global__ void rk_barrier(int *out, int fix)
+{
+    __shared__ int buf[128];
+    const int t = threadIdx.x;
+    buf[t] = t + 1;
+    if (fix) __syncthreads();
+    out[blockIdx.x * 128 + t] = buf[(t + 64) & 127];
+}
+
+// LDS exchanged between the lanes of ONE wave: with / without a wave-level ordering point
+__global__ void rk_lockstep(int *out, int fix)
+{
+    __shared__ int buf[64];
+    const int t = threadIdx.x;
+    buf[t] = t + 1;
+    if (fix) __builtin_amdgcn_wave_barrier();
+    out[t] = buf[t ^ 1];
+}
+
+// write-after-read: the second phase overwrites what another wave may still be reading
+__global__ void rk_war(int *out, int fix)
+{
+    __shared__ int buf[128];
+    const int t = threadIdx.x;
+    buf[t] = t;
+    __syncthreads();
+    const int v = buf[(t + 64) & 127];
+    if (fix) __syncthreads();
+    buf[t] = v + 1;
+    __syncthreads();
+    out[t] = buf[t];
+}
+
+// partial results of every workgroup summed by the last arriver.
+//   mode 1: the hand-off as the product writes it (stores, barrier, fence, ticket; ticket, barrier, loads)
+//   mode 0: no ticket at all -- every workgroup reads workgroup 0's slice
+//   mode 2: the ticket is taken BEFORE the slice is written
+//   mode 3: ticket in place, but the last arriver's other waves do not wait for the work-item that took it
+__global__ void rk_ticket(int *part, int *ticket, int *out, int mode)
+{
+    __shared__ int last;
+    const int t = threadIdx.x, nb = gridDim.x;
+    if (mode == 2 && t == 0) last = atomicAdd(ticket, 1) == nb - 1;
+    part[blockIdx.x * 128 + t] = t + (int)blockIdx.x;
+    if (mode == 0) {
+        out[blockIdx.x * 128 + t] = part[t];
+        return;
+    }
+    __syncthreads();
+    if (mode != 2 && t == 0) {
+        __threadfence();
+        last = atomicAdd(ticket, 1) == nb - 1;
+    }
+    if (mode == 3) {
+        if (blockIdx.x == nb - 1 && t >= 64) {        // (the emulator runs the workgroups in order: this IS the last)
+            int s = 0;
+            for (int b = 0; b < nb; b++) s += part[b * 128 + t];
+            out[t] = s;
+        }
+        return;
+    }
+    __syncthreads();
+    if (last) {
+        int s = 0;
+        for (int b = 0; b < nb; b++) s += part[b * 128 + t];
+        out[t] = s;
+    }
+}
+
+// the idiom "whoever sees it raises the flag": conflicting stores of one value
+__global__ void rk_flag(int *out)
+{
+    __shared__ int flag;
+    if (threadIdx.x == 0) flag = 0;
+    __syncthreads();
+    if (threadIdx.x & 1) flag = 1;
+    __syncthreads();
+    out[threadIdx.x] = flag;
+}
+
+// accumulation by atomics, read back in the same launch without a hand-off: unordered
+__global__ void rk_atomic_then_plain(int *acc, int *out)
+{
+    // (a work-item that took part in no atomic on the location and is not ordered behind one that did)
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x == 63) out[0] = *acc;
+    } else if (threadIdx.x < 32) {
+        atomicAdd(acc, 1);
+    }
+}
+
+// a per-wave counter every lane reads and ONE lane then advances (the shape of a ballot-ranked placement): in lockstep the
+// loads are one instruction and the store a later one; lane by lane the store of one lane meets the loads of the others
+__global__ void rk_counter(int *out, int fix)
+{
+    __shared__ int ctr;
+    const int t = threadIdx.x;
+    if (t == 0) ctr = 5;
+    __syncthreads();
+    const int base = ctr;
+    if (fix) __builtin_amdgcn_wave_barrier();
+    if (t == 63) ctr = base + 64;
+    out[t] = base + t;
+}
+
+extern "C" void rk_run(int which, int arg, int *a, int *b, int *c)
+{
+    hipStream_t st = nullptr;
+    switch (which) {
+    case 0: rk_barrier<<<4, 128, 0, st>>>(a, arg); break;
+    case 1: rk_lockstep<<<1, 64, 0, st>>>(a, arg); break;
+    case 2: rk_war<<<1, 128, 0, st>>>(a, arg); break;
+    case 3: rk_ticket<<<6, 128, 0, st>>>(a, b, c, arg); break;
+    case 4: rk_flag<<<1, 128, 0, st>>>(a); break;
+    case 5: rk_atomic_then_plain<<<3, 64, 0, st>>>(a, b); break;
+    case 6: rk_counter<<<1, 64, 0, st>>>(a, arg); break;
+    }
+}

@@ -22,6 +22,12 @@ load = emu.library
 counters = emu.counters
 
 
+def set_order(order):
+    """schedule of the launches that follow (tests/simt/simt_hip.h: simt_order, a bit mask): 0 workgroups / waves / lanes
+    ascending, 1 / 2 / 4 workgroups / waves / lanes descending, 8 workgroups in a pseudo-random permutation"""
+    load().simt_set_order(int(order))
+
+
 def set_option(which, value):
     """gridgcn_set_option (e.g. _lib.OPT_INDEX_SMALL)"""
     assert load().gridgcn_set_option(int(which), int(value)) == 0

@@ -59,7 +59,23 @@ struct dim3 {
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+// tests/simt/build.py --race (-DSIMT_RACE, -fsanitize=thread instrumentation, tests/simt/simt_race.cpp as its runtime):
+// the emulator's own code is not instrumented, `__shared__` variables sit in one section (their addresses are LDS)
+#ifdef SIMT_RACE
+#define SIMT_NOSAN __attribute__((no_sanitize("thread")))
+#define __shared__ static __attribute__((section("simt_lds")))
+extern "C" void simt_race_atomic(const void *p, int size, int kind, const void *pc);   // 1 read-modify-write, 2 load, 3 store
+extern "C" void simt_race_access(const void *p, int size, int write, const void *pc);
+extern "C" void simt_race_launch_end();
+// (the atomics are calls there: the address they return to is the kernel's line)
+#define SIMT_ATOMIC_FN __attribute__((no_sanitize("thread"), noinline))
+#define SIMT_RACE_ATOMIC(p, kind) simt_race_atomic((const void *)(p), (int)sizeof(*(p)), (kind), __builtin_return_address(0))
+#else
+#define SIMT_NOSAN
+#define SIMT_ATOMIC_FN
 #define __shared__ static
+#define SIMT_RACE_ATOMIC(p, kind) ((void)0)
+#endif
 #define HIP_SYMBOL(x) x
 
 // ---- the host runtime calls the launchers make ------------------------------------------------------------------
@@ -90,6 +106,7 @@ struct SimtFiber {
     const void *site;
     int lane;               // lane of the wave (flat work-item number & 63)
     long long seq;          // cross-lane operations executed so far in this launch
+    int bar;                // workgroup barriers passed so far
     uint64_t val, res;
     uint64_t wide[4];       // 32-byte operand of the bf16 matrix instruction
 };
@@ -105,6 +122,15 @@ inline const std::function<void()> *simt_body = nullptr;
 inline uint64_t simt_xchg[64];
 inline uint64_t simt_xchg_wide[64][4];
 inline bool simt_xchg_in[64];
+// Schedule of a launch (simt_set_order, tests only), a bit mask.  0: workgroups, waves and lanes in ascending order.
+// 1: workgroups descending; 2: the waves of a workgroup descending; 4: the lanes of a wave descending; 8: workgroups in
+// a pseudo-random permutation (seeded by the launch number).  A kernel whose result is meant to be independent of
+// arrival order gives the same bytes under all of them.
+inline int simt_order = 0;
+inline char simt_order_filter[128] = "";       // ... only for launches whose kernel expression contains this
+inline long long simt_wg_serial = 0;            // workgroups run so far (all launches)
+inline size_t simt_lds_bytes = 0;               // size of the running launch's dynamic LDS block
+inline const char *simt_kernel_name = nullptr;  // ... its kernel expression
 inline const void *simt_kernarg = nullptr;      // __builtin_amdgcn_kernarg_segment_ptr(): first argument of the launch
 
 #define threadIdx (simt_cur->tidx)
@@ -123,7 +149,7 @@ inline const void *simt_kernarg = nullptr;      // __builtin_amdgcn_kernarg_segm
 inline const void *simt_sched_stack = nullptr;
 inline size_t simt_sched_stack_size = 0;
 
-static inline void simt_yield(int st)
+SIMT_NOSAN static inline void simt_yield(int st)
 {
     SimtFiber *f = simt_cur;
     f->state = st;
@@ -137,7 +163,7 @@ static inline void simt_yield(int st)
 #endif
 }
 
-static void simt_entry()
+SIMT_NOSAN static void simt_entry()
 {
 #ifdef SIMT_ASAN
     __sanitizer_finish_switch_fiber(nullptr, &simt_sched_stack, &simt_sched_stack_size);
@@ -147,7 +173,7 @@ static void simt_entry()
 }
 
 // scheduler -> fibre
-static inline void simt_resume(SimtFiber *f, char *stack, size_t size)
+SIMT_NOSAN static inline void simt_resume(SimtFiber *f, char *stack, size_t size)
 {
     simt_cur = f;
 #ifdef SIMT_ASAN
@@ -160,7 +186,7 @@ static inline void simt_resume(SimtFiber *f, char *stack, size_t size)
 #endif
 }
 
-__attribute__((noinline)) static uint64_t simt_collective(int op, uint64_t val, int arg, int width)
+SIMT_NOSAN __attribute__((noinline)) static uint64_t simt_collective(int op, uint64_t val, int arg, int width)
 {
     SimtFiber *f = simt_cur;
     f->op = op; f->val = val; f->arg = arg; f->width = width;
@@ -179,7 +205,7 @@ __attribute__((noinline)) static uint64_t simt_collective(int op, uint64_t val, 
 // control flow: the hardware would run the branches one after the other and reconverge -- the group that is furthest
 // behind (lowest count, then lowest code address) goes on alone, the others wait for it, and the event is counted:
 // simt_divergent_rendezvous.  The tests assert that the count is 0, i.e. that no guess was ever made.
-static inline void simt_resolve_wave(SimtFiber *lanes, int n)
+SIMT_NOSAN static inline void simt_resolve_wave(SimtFiber *lanes, int n)
 {
     int lead = -1, nkeys = 0;
     for (int i = 0; i < n; i++) {
@@ -252,9 +278,10 @@ inline std::vector<char> simt_lds_buf;
 #endif
 
 inline long long simt_spin_rounds = 0;
-static inline void simt_run_block(int nthreads, const dim3 &bd)
+SIMT_NOSAN static inline void simt_run_block(int nthreads, const dim3 &bd)
 {
     simt_spin_rounds = 0;
+    simt_wg_serial++;
     if ((int)simt_fibers.size() < nthreads) simt_fibers.resize(nthreads);
     if (simt_stacks.size() < (size_t)nthreads * SIMT_STACK) simt_stacks.resize((size_t)nthreads * SIMT_STACK);
     for (int t = 0; t < nthreads; t++) {
@@ -268,21 +295,25 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
         f.tidx = dim3(t % bd.x, (t / bd.x) % bd.y, t / (bd.x * bd.y));
         f.val = f.res = 0;
         f.seq = 0;
+        f.bar = 0;
         f.lane = t & 63;
     }
     const int nwave = (nthreads + 63) / 64;
     for (;;) {
         bool progress = false;
-        for (int w = 0; w < nwave; w++) {
+        for (int wi = 0; wi < nwave; wi++) {
+            const int w = (simt_order & 2) ? nwave - 1 - wi : wi;
             SimtFiber *lanes = &simt_fibers[w * 64];
             const int n = std::min(64, nthreads - w * 64);
             for (;;) {
                 bool ran = false;
-                for (int l = 0; l < n; l++)
+                for (int li = 0; li < n; li++) {
+                    const int l = (simt_order & 4) ? n - 1 - li : li;
                     if (lanes[l].state == SIMT_RUN) {
                         simt_resume(&lanes[l], simt_stacks.data() + (size_t)(w * 64 + l) * SIMT_STACK, SIMT_STACK);
                         ran = true;
                     }
+                }
                 bool waiting = false, spinning = false;
                 for (int l = 0; l < n; l++) {
                     waiting |= lanes[l].state == SIMT_WAVE;
@@ -324,7 +355,7 @@ static inline void simt_run_block(int nthreads, const dim3 &bd)
 template <class A, class... R> static inline const void *simt_first_arg(const A &a, const R &...) { return &a; }
 static inline const void *simt_first_arg() { return nullptr; }
 
-static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body,
+SIMT_NOSAN static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body,
                                const void *kernarg = nullptr, const char *name = "?")
 {
     simt_kernarg = kernarg;
@@ -333,19 +364,37 @@ static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const st
         fprintf(stderr, "simt: %s <<<(%u,%u,%u), (%u,%u,%u), %zu>>>\n", name, grid.x, grid.y, grid.z, block.x, block.y,
                 block.z, lds_bytes);
     simt_launches++;
+    const int order_asked = simt_order;
+    if (simt_order_filter[0] && !strstr(name, simt_order_filter)) simt_order = 0;
+    simt_kernel_name = name;
+    simt_lds_bytes = lds_bytes;
     if (simt_lds_buf.size() < lds_bytes + 64) simt_lds_buf.resize(lds_bytes + 64);
     simt_dyn_lds = (char *)(((uintptr_t)simt_lds_buf.data() + 63) & ~(uintptr_t)63);
     simt_gridDim = grid;
     simt_blockDim = block;
     simt_body = &body;
     const int nthreads = (int)(block.x * block.y * block.z);
-    for (unsigned z = 0; z < grid.z; z++)
-        for (unsigned y = 0; y < grid.y; y++)
-            for (unsigned x = 0; x < grid.x; x++) {
-                simt_blockIdx = dim3(x, y, z);
-                simt_run_block(nthreads, block);
-            }
+    const unsigned long long nwg = (unsigned long long)grid.x * grid.y * grid.z;
+    // order 2: i -> (a i + c) mod nwg with a odd multiplier coprime to nwg (a bijection), seeded by the launch number
+    unsigned long long mul = 1, add = 0;
+    if ((simt_order & 8) && nwg > 1) {
+        mul = (0x9E3779B97F4A7C15ull * (unsigned long long)simt_launches) % nwg | 1;
+        auto gcd = [](unsigned long long a, unsigned long long b) { while (b) { const unsigned long long t = a % b; a = b; b = t; } return a; };
+        while (gcd(mul, nwg) != 1) mul += 2;
+        add = (0xD1B54A32D192ED03ull * (unsigned long long)simt_launches) % nwg;
+    }
+    for (unsigned long long i = 0; i < nwg; i++) {
+        unsigned long long k = i;
+        if (simt_order & 8) k = (unsigned long long)(((unsigned __int128)mul * i + add) % nwg);
+        if (simt_order & 1) k = nwg - 1 - k;
+        simt_blockIdx = dim3((unsigned)(k % grid.x), (unsigned)((k / grid.x) % grid.y), (unsigned)(k / ((unsigned long long)grid.x * grid.y)));
+        simt_run_block(nthreads, block);
+    }
     simt_body = nullptr;
+    simt_order = order_asked;
+#ifdef SIMT_RACE
+    simt_race_launch_end();
+#endif
 }
 
 #define SIMT_INL inline __attribute__((always_inline))
@@ -353,7 +402,7 @@ static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const st
     simt_launch((grid), (block), (lds), [&]() { kernel(__VA_ARGS__); }, simt_first_arg(__VA_ARGS__), #kernel)
 
 // ---- device intrinsics ------------------------------------------------------------------------------------------
-static inline void __syncthreads() { simt_yield(SIMT_BLOCK); }
+SIMT_NOSAN static inline void __syncthreads() { simt_cur->bar++; simt_yield(SIMT_BLOCK); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 #define __builtin_amdgcn_fence(...) ((void)0)
@@ -403,23 +452,25 @@ static SIMT_INL int __builtin_amdgcn_readlane(int v, int lane)
     return simt_unpack<int>(simt_collective(SIMT_OP_SHFL, simt_pack(v), lane, 64));
 }
 
-static inline void simt_sleep() { simt_yield(SIMT_SPIN); }
+SIMT_NOSAN static inline void simt_sleep() { simt_yield(SIMT_SPIN); }
 #define __builtin_amdgcn_s_sleep(n) simt_sleep()
 #define __builtin_amdgcn_kernarg_segment_ptr() ((void *)simt_kernarg)
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+#define __hip_atomic_load(p, order, scope) simt_atomic_load((p))
+#define __hip_atomic_store(p, v, order, scope) simt_atomic_store((p), (v))
 #define __hip_atomic_fetch_add(p, v, order, scope) simt_fetch_add((p), (v))
-template <class T, class V> static inline T simt_fetch_add(T *p, V v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T> SIMT_ATOMIC_FN static inline T simt_atomic_load(T *p) { SIMT_RACE_ATOMIC(p, 2); return *p; }
+template <class T, class V> SIMT_ATOMIC_FN static inline void simt_atomic_store(T *p, V v) { SIMT_RACE_ATOMIC(p, 3); *p = (T)v; }
+template <class T, class V> SIMT_ATOMIC_FN static inline T simt_fetch_add(T *p, V v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = (T)(o + (T)v); return o; }
 
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] B[2x32].  Lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31] and owns
 // D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31], r = 0..15.  The guide (cdna_hip_programming.md, "FP32-input MFMA"):
 // bit for bit a k-ordered chain of fused multiply-adds, one rounding per product.
 typedef float simt_f32x16 __attribute__((ext_vector_type(16)));
-static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x16 c, int, int, int)
+SIMT_NOSAN static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x16 c, int, int, int)
 {
     uint64_t v = 0;
     memcpy(&v, &a, 4);
@@ -446,7 +497,7 @@ static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x
 // A[l & 31][8 (l >> 5) + j] and B[8 (l >> 5) + j][l & 31], j = 0..7.  The products are exact in fp32; the hardware's
 // order of adding the sixteen of them is not documented -- ascending k with one rounding per addition here.
 static inline float simt_bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
-template <class V> static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x16_bf16(V a, V b, simt_f32x16 c, int, int, int)
+template <class V> SIMT_NOSAN static SIMT_INL simt_f32x16 simt_mfma_f32_32x32x16_bf16(V a, V b, simt_f32x16 c, int, int, int)
 {
     static_assert(sizeof(V) == 16, "bf16x8 operands");
     memcpy(simt_cur->wide, &a, 16);
@@ -489,11 +540,11 @@ static inline unsigned __float_as_uint(float x) { return (unsigned)simt_pack(x);
 static inline long long wall_clock64() { return 0; }
 static inline long long clock64() { return 0; }
 
-template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
-static inline unsigned long long atomicAdd(unsigned long long *p, unsigned v) { unsigned long long o = *p; *p = o + v; return o; }
-template <class T> static inline T atomicMax(T *p, T v) { T o = *p; *p = o > v ? o : v; return o; }
-template <class T> static inline T atomicMin(T *p, T v) { T o = *p; *p = o < v ? o : v; return o; }
-template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
-template <class T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
-template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
-template <class T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicAdd(T *p, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = o + v; return o; }
+SIMT_ATOMIC_FN static inline unsigned long long atomicAdd(unsigned long long *p, unsigned v) { SIMT_RACE_ATOMIC(p, 1); unsigned long long o = *p; *p = o + v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicMax(T *p, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = o > v ? o : v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicMin(T *p, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = o < v ? o : v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicOr(T *p, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = o | v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicAnd(T *p, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = o & v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicExch(T *p, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; *p = v; return o; }
+template <class T> SIMT_ATOMIC_FN static inline T atomicCAS(T *p, T c, T v) { SIMT_RACE_ATOMIC(p, 1); T o = *p; if (o == c) *p = v; return o; }

@@ -1,0 +1,370 @@
+// simt_race.cpp -- a data-race detector for the product's kernels on the CPU build.  TEST INFRASTRUCTURE.
+//
+// tests/simt/build.py --race compiles every kernel source with clang's ThreadSanitizer INSTRUMENTATION
+// (-fsanitize=thread: a call to __tsan_read<N> / __tsan_write<N> in front of every load and store that is not a private
+// stack slot) but links THIS file instead of the ThreadSanitizer runtime.  ThreadSanitizer's own runtime models
+// threads and mutexes; what orders two accesses on the GPU is something else, and the emulator knows it exactly:
+//
+//   two accesses to the same location, at least one a store, not both atomic, are ORDERED iff
+//     * they belong to different launches (a kernel boundary orders everything), or
+//     * same work-item, or
+//     * same workgroup and a __syncthreads lies between them (the first was made before the k-th barrier of its
+//       work-item, the second after the k-th barrier of its own: barrier counts differ), or
+//     * same wave and a cross-lane operation of the wave (ballot, shuffle, readlane, wave_barrier, s_waitcnt, a matrix
+//       instruction) lies between them (the lanes' counts of such operations differ) -- what the hardware's in-order
+//       LDS / memory pipeline gives a wave once the compiler is told not to move the accesses across that point, or
+//     * different workgroups, and the first workgroup RELEASED (an atomic read-modify-write or atomic store executed
+//       after the access: a barrier, or a wave operation of the same wave, or the same work-item in between) on a
+//       location on which the second ACQUIRED (an atomic read-modify-write or atomic load executed before its access)
+//       -- the ticket / last-arriver hand-offs; transitive through a third workgroup.
+//   Everything else is reported, once per (kernel, kind, pair of code addresses):
+//     INTRA  same workgroup, different waves, no barrier between       -- a missing __syncthreads
+//     WAVE   same wave, different lanes, no wave operation between      -- the kernel leans on lockstep there
+//     INTER  different workgroups of one launch                         -- unordered global traffic
+//
+// LDS (the launch's dynamic block and every `__shared__` variable: section "simt_lds") belongs to one workgroup: an
+// entry left by an earlier workgroup is stale, not a conflict.  The fibres' stacks are private.
+//
+// What it cannot see: accesses the compiler kept in registers or removed (it is the -O1 host build that runs), the
+// hardware's memory model beyond "atomics synchronise" (a relaxed ticket counts as release + acquire here: the fences
+// that make it so on the GPU are checked by tests/test_isa_handoff.py on the GPU ISA), and anything the tests do not
+// execute.
+#include "simt_hip.h"
+
+#include <dlfcn.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+
+extern "C" {
+extern char __start_simt_lds[] __attribute__((weak));
+extern char __stop_simt_lds[] __attribute__((weak));
+}
+
+namespace {
+
+struct Acc {                 // one recorded access: 16 bytes
+    uint32_t gen;            // launch serial (0 = empty)
+    uint32_t wg_tid;         // workgroup serial of the launch << 10 | work-item
+    uint32_t seq;            // the work-item's count of cross-lane operations
+    uint16_t bar;            // ... of workgroup barriers
+    uint16_t pc_fl;          // code address index << 2 | atomic << 1 | write
+};
+struct Cell { Acc w, r0, r1, r2; };   // last store; latest load, latest load of another lane of r0's wave, of another wave
+
+enum { PAGE_SHIFT = 12, GRAN = 1024 };
+struct Shadow {
+    std::unordered_map<uintptr_t, Cell *> pages;
+    uintptr_t last_page = ~(uintptr_t)0;
+    Cell *last = nullptr;
+    int shift;               // log2 of the granule in bytes (2: words, 0: bytes)
+    explicit Shadow(int s) : shift(s) {}
+    Cell *cell(uintptr_t a)
+    {
+        const uintptr_t g = a >> shift, page = g / GRAN;
+        if (page != last_page) {
+            auto it = pages.find(page);
+            if (it == pages.end()) it = pages.emplace(page, (Cell *)calloc(GRAN, sizeof(Cell))).first;
+            last_page = page;
+            last = it->second;
+        }
+        return last + (g % GRAN);
+    }
+    void clear()
+    {
+        for (auto &p : pages) free(p.second);
+        pages.clear();
+        last_page = ~(uintptr_t)0;
+        last = nullptr;
+    }
+};
+Shadow sh_word(2), sh_byte(0);
+
+struct Rel { uint32_t wg, tid, seq; uint16_t bar; };                  // a release: who, and where in its program
+struct Edge { Rel rel; uint32_t acq_tid, acq_seq; uint16_t acq_bar; };  // ... acquired by the current workgroup
+std::unordered_map<uintptr_t, std::map<uint32_t, Rel>> released;       // atomic location -> latest release per workgroup
+std::map<uint32_t, Edge> acquired;                                     // of the workgroup that is running
+uint32_t acquired_wg = ~0u, acquired_gen = 0;
+
+std::vector<const void *> pcs(1, nullptr);
+std::unordered_map<const void *, uint16_t> pc_index;
+uint16_t pc_of(const void *pc)
+{
+    auto it = pc_index.find(pc);
+    if (it != pc_index.end()) return it->second;
+    if (pcs.size() >= (1u << 14)) return 0;
+    pc_index[pc] = (uint16_t)pcs.size();
+    pcs.push_back(pc);
+    return (uint16_t)(pcs.size() - 1);
+}
+
+struct Report {
+    long long count = 0;
+    long long same = 0;      // store/store conflicts in which the second store wrote the value that was there
+    uintptr_t addr = 0;
+    uint32_t wg0 = 0, tid0 = 0, wg1 = 0, tid1 = 0;
+    bool w0 = false, w1 = false, lds = false;
+};
+struct Key {
+    std::string kernel;
+    int kind;
+    const void *pc0, *pc1;
+    bool operator<(const Key &o) const
+    {
+        if (kernel != o.kernel) return kernel < o.kernel;
+        if (kind != o.kind) return kind < o.kind;
+        if (pc0 != o.pc0) return pc0 < o.pc0;
+        return pc1 < o.pc1;
+    }
+};
+std::map<Key, Report> reports;
+long long n_access = 0, n_conflict = 0;
+bool enabled = true;
+uint32_t cur_gen = 0;
+const char *KIND[] = {"INTRA", "WAVE", "INTER"};
+
+inline bool is_stack(uintptr_t a)
+{
+    const uintptr_t s = (uintptr_t)simt_stacks.data();
+    return a - s < simt_stacks.size();
+}
+inline bool is_lds(uintptr_t a)
+{
+    if (a - (uintptr_t)simt_dyn_lds < simt_lds_bytes) return true;
+    return a - (uintptr_t)__start_simt_lds < (uintptr_t)(__stop_simt_lds - __start_simt_lds);
+}
+
+inline void start_wg_if_new(uint32_t wg)
+{
+    if (acquired_wg != wg || acquired_gen != cur_gen) {
+        acquired.clear();
+        acquired_wg = wg;
+        acquired_gen = cur_gen;
+    }
+}
+
+// was access A (of another workgroup) released to the current workgroup before the access at (tid, bar, seq)?
+bool ordered_by_atomics(const Acc &A, uint32_t tid, uint16_t bar, uint32_t seq)
+{
+    auto it = acquired.find(A.wg_tid >> 10);
+    if (it == acquired.end()) return false;
+    const Edge &e = it->second;
+    const uint32_t atid = A.wg_tid & 1023;
+    const bool before_rel = A.bar < e.rel.bar || atid == e.rel.tid || ((atid >> 6) == (e.rel.tid >> 6) && A.seq < e.rel.seq);
+    const bool after_acq = bar > e.acq_bar || tid == e.acq_tid || ((tid >> 6) == (e.acq_tid >> 6) && seq > e.acq_seq);
+    return before_rel && after_acq;
+}
+
+// a store that conflicts with an earlier store: what does it write?  The hook runs BEFORE the store, so the location is
+// looked at again when the next hook runs (nothing but the store lies between): the same bytes = the idiom "every
+// work-item stores the same value" (flags, clamped staging stores), counted apart.
+struct Pending { Report *r; uintptr_t addr; unsigned size; uint32_t old; };
+std::vector<Pending> pending;
+inline void flush_pending()
+{
+    for (const Pending &p : pending) {
+        uint32_t now = 0;
+        memcpy(&now, (const void *)p.addr, p.size);
+        if (now == p.old) p.r->same++;
+    }
+    pending.clear();
+}
+
+void report(int kind, const Acc &A, const Acc &B, uintptr_t addr, bool lds, unsigned gran)
+{
+    n_conflict++;
+    Key k{simt_kernel_name ? simt_kernel_name : "?", kind, pcs[A.pc_fl >> 2], pcs[B.pc_fl >> 2]};
+    Report &r = reports[k];
+    if (r.count++ == 0) {
+        r.addr = addr;
+        r.wg0 = A.wg_tid >> 10; r.tid0 = A.wg_tid & 1023; r.w0 = A.pc_fl & 1;
+        r.wg1 = B.wg_tid >> 10; r.tid1 = B.wg_tid & 1023; r.w1 = B.pc_fl & 1;
+        r.lds = lds;
+    }
+    if ((A.pc_fl & 1) && (B.pc_fl & 1)) {
+        Pending p{&r, addr, gran, 0};
+        memcpy(&p.old, (const void *)addr, gran);
+        pending.push_back(p);
+    }
+}
+
+inline void check(const Acc &A, const Acc &B, uintptr_t addr, bool lds, unsigned gran)
+{
+    if (A.gen != B.gen) return;
+    const uint32_t wgA = A.wg_tid >> 10, wgB = B.wg_tid >> 10;
+    if ((A.pc_fl & 2) && (B.pc_fl & 2)) return;            // both atomic
+    if (wgA == wgB) {
+        const uint32_t ta = A.wg_tid & 1023, tb = B.wg_tid & 1023;
+        if (ta == tb || A.bar != B.bar) return;            // (B runs later in emulator time: its count is the larger)
+        if ((ta >> 6) == (tb >> 6)) {
+            if (A.seq != B.seq) return;
+            report(1, A, B, addr, lds, gran);
+        } else {
+            report(0, A, B, addr, lds, gran);
+        }
+        return;
+    }
+    if (lds) return;                                       // another workgroup's LDS contents: stale
+    if (ordered_by_atomics(A, B.wg_tid & 1023, B.bar, B.seq)) return;
+    report(2, A, B, addr, lds, gran);
+}
+
+inline void touch(Cell *c, const Acc &cur, uintptr_t addr, bool lds, unsigned gran)
+{
+    if (cur.pc_fl & 1) {
+        check(c->w, cur, addr, lds, gran);
+        check(c->r0, cur, addr, lds, gran);
+        check(c->r1, cur, addr, lds, gran);
+        check(c->r2, cur, addr, lds, gran);
+        c->w = cur;
+        c->r0.gen = c->r1.gen = c->r2.gen = 0;   // (accesses ordered after this store are ordered after those loads: a
+                                                 //  load that is NOT ordered before this store has just been reported)
+    } else {
+        check(c->w, cur, addr, lds, gran);
+        // r0 = the latest reader; when it is replaced it moves to r1 (replaced by another lane of its wave: a wave that
+        // reads a word lane by lane and then lets ONE lane store it) or to r2 (replaced by another wave / workgroup)
+        if (c->r0.gen == cur.gen && c->r0.wg_tid != cur.wg_tid) {
+            if ((c->r0.wg_tid >> 6) == (cur.wg_tid >> 6)) c->r1 = c->r0;
+            else c->r2 = c->r0;
+        }
+        c->r0 = cur;
+    }
+}
+
+void access(const void *p, unsigned size, bool write, bool atomic, const void *pc)
+{
+    SimtFiber *f = simt_cur;
+    if (!pending.empty()) flush_pending();
+    if (!enabled || !f || f->state != SIMT_RUN) return;    // host code, the scheduler
+    const uintptr_t a = (uintptr_t)p;
+    if (is_stack(a)) return;
+    n_access++;
+    cur_gen = (uint32_t)simt_launches;
+    const uint32_t wg = (uint32_t)simt_wg_serial & 0x3fffff, tid = (uint32_t)(f - simt_fibers.data());
+    start_wg_if_new(wg);
+    Acc cur{cur_gen, wg << 10 | tid, (uint32_t)f->seq, (uint16_t)f->bar,
+            (uint16_t)(pc_of(pc) << 2 | (atomic ? 2 : 0) | (write ? 1 : 0))};
+    const bool lds = is_lds(a);
+    if (size >= 4 && (a & 3) == 0) {
+        for (unsigned o = 0; o < size; o += 4) touch(sh_word.cell(a + o), cur, a + o, lds, 4);
+    } else {
+        for (unsigned o = 0; o < size; o++) touch(sh_byte.cell(a + o), cur, a + o, lds, 1);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// kind: 1 read-modify-write (acquire + release), 2 load (acquire), 3 store (release)
+__attribute__((noinline)) void simt_race_atomic(const void *p, int size, int kind, const void *pc)
+{
+    SimtFiber *f = simt_cur;
+    if (!enabled || !f || f->state != SIMT_RUN) return;
+    if (kind != 3) access(p, size, false, true, pc);
+    if (kind != 2) access(p, size, true, true, pc);
+    if (is_lds((uintptr_t)p)) return;
+    const uint32_t wg = (uint32_t)simt_wg_serial & 0x3fffff, tid = (uint32_t)(f - simt_fibers.data());
+    start_wg_if_new(wg);
+    auto &rel = released[(uintptr_t)p];
+    if (kind != 3)
+        for (auto &kv : rel) {
+            if (kv.first == wg) continue;
+            Edge e{kv.second, tid, (uint32_t)f->seq, (uint16_t)f->bar};
+            auto it = acquired.find(kv.first);
+            // (keep the edge that covers more: the later release; of equal ones the earlier acquire)
+            if (it == acquired.end() || it->second.rel.bar < e.rel.bar) acquired[kv.first] = e;
+        }
+    if (kind != 2) {
+        rel[wg] = Rel{wg, tid, (uint32_t)f->seq, (uint16_t)f->bar};
+        for (auto &kv : acquired)                          // transitive: what this workgroup had acquired travels on,
+            if (!rel.count(kv.first)) rel[kv.first] = kv.second.rel;   // as released where ITS releaser said
+    }
+}
+
+__attribute__((noinline)) void simt_race_access(const void *p, int size, int write, const void *pc)
+{
+    access(p, (unsigned)size, write != 0, false, pc);
+}
+
+// a launch is over: nothing recorded in it can conflict with anything later
+void simt_race_launch_end()
+{
+    flush_pending();
+    released.clear();
+    acquired.clear();
+    acquired_wg = ~0u;
+    if (sh_word.pages.size() + sh_byte.pages.size() > 16384) {   // ~ 0.8 GB of shadow: start afresh
+        sh_word.clear();
+        sh_byte.clear();
+    }
+}
+
+void simt_race_enable(int on) { enabled = on != 0; }
+void simt_race_reset()
+{
+    reports.clear();
+    n_access = n_conflict = 0;
+}
+void simt_race_counters(long long *out)
+{
+    out[0] = n_access;
+    out[1] = n_conflict;
+    out[2] = (long long)reports.size();
+}
+
+// text report: one line per distinct (kernel, kind, code pair); returns the number of lines
+int simt_race_report(char *buf, size_t n)
+{
+    flush_pending();
+    std::string s;
+    char line[1024];
+    for (auto &kv : reports) {
+        const Key &k = kv.first;
+        const Report &r = kv.second;
+        Dl_info i0{}, i1{};
+        dladdr(k.pc0, &i0);
+        dladdr(k.pc1, &i1);
+        snprintf(line, sizeof line, "%s\t%s\t%s\t0x%zx\t0x%zx\t%lld\t%s%s %s wg %u item %u -> %s wg %u item %u\n",
+                 KIND[k.kind], k.kernel.c_str(), i0.dli_fname ? i0.dli_fname : "?",
+                 (size_t)((const char *)k.pc0 - (const char *)i0.dli_fbase),
+                 (size_t)((const char *)k.pc1 - (const char *)i1.dli_fbase), r.count, r.same == r.count ? "same-value stores: " : "", r.lds ? "lds" : "global",
+                 r.w0 ? "store" : "load", r.wg0, r.tid0, r.w1 ? "store" : "load", r.wg1, r.tid1);
+        s += line;
+    }
+    if (buf && n) {
+        const size_t m = std::min(n - 1, s.size());
+        memcpy(buf, s.data(), m);
+        buf[m] = 0;
+    }
+    return (int)reports.size();
+}
+
+// ---- the instrumentation's entry points (clang -fsanitize=thread) ------------------------------------------------
+#define RD(N)                                                                                                   \
+    void __tsan_read##N(void *p) { access(p, N, false, false, __builtin_return_address(0)); }                   \
+    void __tsan_unaligned_read##N(void *p) { access(p, N, false, false, __builtin_return_address(0)); }         \
+    void __tsan_write##N(void *p) { access(p, N, true, false, __builtin_return_address(0)); }                   \
+    void __tsan_unaligned_write##N(void *p) { access(p, N, true, false, __builtin_return_address(0)); }         \
+    void __tsan_read_write##N(void *p)                                                                          \
+    {                                                                                                           \
+        access(p, N, false, false, __builtin_return_address(0));                                                \
+        access(p, N, true, false, __builtin_return_address(0));                                                 \
+    }                                                                                                           \
+    void __tsan_unaligned_read_write##N(void *p)                                                                \
+    {                                                                                                           \
+        access(p, N, false, false, __builtin_return_address(0));                                                \
+        access(p, N, true, false, __builtin_return_address(0));                                                 \
+    }
+RD(1) RD(2) RD(4) RD(8) RD(16)
+void __tsan_read_range(void *p, unsigned long n) { access(p, (unsigned)n, false, false, __builtin_return_address(0)); }
+void __tsan_write_range(void *p, unsigned long n) { access(p, (unsigned)n, true, false, __builtin_return_address(0)); }
+void __tsan_init() {}
+void __tsan_func_entry(void *) {}
+void __tsan_func_exit() {}
+void __tsan_vptr_update(void **, void *) {}
+void __tsan_vptr_read(void **) {}
+void __tsan_ignore_thread_begin() {}
+void __tsan_ignore_thread_end() {}
+}

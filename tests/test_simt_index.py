@@ -69,6 +69,27 @@ def test_emulated_kernels_match_oracle_and_golden(name, build, run):
     check_against_golden(name, got)
 
 
+# Arrival order: the operators' outputs are DEFINED to be independent of it (the reservoir keeps the largest item
+# number, ranks come from ballots and prefix sums) -- so the emulator runs the launch in other orders:
+# every workgroup, wave and lane descending (7); workgroups in a pseudo-random permutation, waves descending (10).  The
+# last-arriver hand-offs of the build then fall to other workgroups; the bytes must not move.
+ORDERED = [c for c in ALL if not c[0].startswith(("gridify_seg80k", "gridify_synth200k", "gridify_cfg"))]
+
+
+@pytest.mark.parametrize("order", [7, 10])
+@pytest.mark.parametrize("name,build,run", ORDERED, ids=[c[0] for c in ORDERED])
+def test_emulated_kernels_do_not_depend_on_arrival_order(name, build, run, order):
+    if order == 10 and os.environ.get("GG_SIMT_FULL") != "1" and [c[0] for c in ORDERED].index(name) % 3:
+        pytest.skip("permuted workgroups: every third case unless GG_SIMT_FULL=1")
+    args, kw = build()
+    try:
+        sim.set_order(order)
+        got = run_sim(name, args, kw)
+    finally:
+        sim.set_order(0)
+    check_against_golden(name, got)
+
+
 SMALL = [c for c in ALL if c[0].startswith(("gridify_mn40", "gridify_scan8k_L1", "gridify_oob", "gridify_weights",
                                             "gridify_ragged", "gridify_up_overflow", "fastrand_scan8k_overfull"))]
 

@@ -1,0 +1,102 @@
+"""The data-race detector of the CPU build (tests/simt/simt_race.cpp: clang's ThreadSanitizer instrumentation of the
+kernel sources, the emulator's own notion of what orders two accesses as the runtime) on kernels with KNOWN races:
+every broken form must be reported under the right kind and source line, every repaired form must be silent.
+TEST INFRASTRUCTURE about test infrastructure -- the product's kernels go through the same detector in
+tests/simt/race.sh (profiles/r6_race_report.txt)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "simt"))
+
+SRC = open(os.path.join(HERE, "simt", "race_selftest.hip")).read().splitlines()
+
+
+def line_of(pattern, nth=0):
+    hits = [i + 1 for i, l in enumerate(SRC) if re.search(pattern, l)]
+    return "race_selftest.hip:%d" % hits[nth]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import build as simt_build
+    so = ctypes.CDLL(simt_build.build_selftest())
+    so.rk_run.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+    so.rk_run.restype = None
+    return so
+
+
+def run(lib, which, arg=0):
+    import emu
+    a, b, c = (np.zeros(4096, np.int32) for _ in range(3))
+    lib.simt_race_reset()
+    lib.rk_run(which, arg, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+    return emu.race_report(lib), (a, b, c)
+
+
+def test_missing_barrier_between_waves(lib):
+    rep, (out, _, _) = run(lib, 0, 0)
+    st, ld = line_of(r"buf\[t\] = t \+ 1;"), line_of(r"out\[blockIdx.x \* 128 \+ t\] = buf")
+    # (wave 0 runs first here: its loads meet wave 1's later stores, wave 1's loads meet wave 0's earlier stores)
+    assert {(r[0], r[2], r[3]) for r in rep} == {("INTRA", st, ld), ("INTRA", ld, st)}, rep
+    assert all("lds " in r[5] for r in rep)
+    rep, (out, _, _) = run(lib, 0, 1)
+    assert rep == []
+    assert (out[:128] == (np.arange(128) + 64) % 128 + 1).all()
+
+
+def test_lane_exchange_without_a_wave_ordering_point(lib):
+    rep, _ = run(lib, 1, 0)
+    assert {(r[0], r[1]) for r in rep} == {("WAVE", "rk_lockstep")} and len(rep) == 2, rep   # both directions
+    rep, _ = run(lib, 1, 1)
+    assert rep == []
+
+
+def test_write_after_read(lib):
+    rep, _ = run(lib, 2, 0)
+    assert {(r[0], r[3]) for r in rep if "-> store" in r[5]} == {("INTRA", line_of(r"buf\[t\] = v \+ 1;"))}, rep
+    assert any(r[5].split("->")[0].strip().startswith("lds load") for r in rep)
+    rep, _ = run(lib, 2, 1)
+    assert rep == []
+
+
+def test_ticket_hand_off_between_workgroups(lib):
+    # the hand-off as the product writes it: silent, and the sum is right
+    rep, (_, _, out) = run(lib, 3, 1)
+    assert rep == [], rep
+    assert (out[:128] == 6 * np.arange(128) + 15).all()
+    # no ticket: the other workgroups' loads of workgroup 0's slice are unordered
+    rep, _ = run(lib, 3, 0)
+    assert {r[0] for r in rep} == {"INTER"} and all("global store" in r[5] for r in rep), rep
+    # ticket taken before the slice is written: nothing was released
+    rep, _ = run(lib, 3, 2)
+    assert {r[0] for r in rep} == {"INTER"}, rep
+    # ticket in place, but the reading waves do not wait for the work-item that took it
+    rep, _ = run(lib, 3, 3)
+    assert {r[0] for r in rep} == {"INTER"}, rep
+
+
+def test_same_value_stores_are_told_apart(lib):
+    rep, (out, _, _) = run(lib, 4)
+    assert rep and all(r[5].startswith("same-value stores: ") for r in rep), rep
+    assert {r[0] for r in rep} <= {"INTRA", "WAVE"}
+    assert (out[:128] == 1).all()
+
+
+def test_plain_load_of_an_accumulator_other_workgroups_add_to(lib):
+    rep, _ = run(lib, 5)
+    assert [(r[0], r[1]) for r in rep] == [("INTER", "rk_atomic_then_plain")], rep
+
+
+def test_counter_read_by_every_lane_and_advanced_by_one(lib):
+    """the latest reader of a word is not the only one that matters: lanes 0..62 read, lane 63 reads and stores"""
+    rep, (out, _, _) = run(lib, 6, 0)
+    assert [(r[0], r[1]) for r in rep] == [("WAVE", "rk_counter")] and "load" in rep[0][5].split("->")[0], rep
+    assert (out[:64] == 5 + np.arange(64)).all()
+    rep, _ = run(lib, 6, 1)
+    assert rep == []
