@@ -21,3 +21,17 @@ extern "C" void simt_set_order_filter(const char *substr)
 {
     strncpy(simt_order_filter, substr ? substr : "", sizeof simt_order_filter - 1);
 }
+
+// which kernels have run: "kernel expression\tlaunches\n" per kernel (the expression as the launcher spells it, template
+// arguments by name); returns the number of kernels
+extern "C" int simt_kernel_coverage(char *buf, size_t n)
+{
+    std::string s;
+    for (auto &kv : simt_kernel_launches) s += kv.first + "\t" + std::to_string(kv.second) + "\n";
+    if (buf && n) {
+        const size_t m = std::min(n - 1, s.size());
+        memcpy(buf, s.data(), m);
+        buf[m] = 0;
+    }
+    return (int)simt_kernel_launches.size();
+}

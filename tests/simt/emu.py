@@ -45,10 +45,35 @@ def library():
         lib = ctypes.CDLL(simt_build.build(asan=os.environ.get("GG_SIMT_ASAN") == "1", race=race))
         _EMU = _lib.declare(lib, "tests/simt emulation")
         _EMU.simt_counters.argtypes = [ctypes.c_void_p]
+        _EMU.simt_set_order_filter.argtypes = [ctypes.c_char_p]
+        # GG_SIMT_ORDER=<bit mask>: every launch of the process in another schedule (tests/simt/simt_hip.h: simt_order)
+        if os.environ.get("GG_SIMT_ORDER"):
+            _EMU.simt_set_order(int(os.environ["GG_SIMT_ORDER"]))
         if race:
             import atexit
             atexit.register(_write_race_report)
+        # GG_SIMT_COVERAGE=<file>: the kernels this process launched are appended there when it ends
+        if os.environ.get("GG_SIMT_COVERAGE"):
+            import atexit
+            atexit.register(_write_coverage)
     return _EMU
+
+
+def kernel_coverage():
+    """{kernel expression: launches} of this process"""
+    lib = library()
+    lib.simt_kernel_coverage.restype = ctypes.c_int
+    lib.simt_kernel_coverage.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(1 << 20)
+    lib.simt_kernel_coverage(buf, len(buf))
+    return {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().splitlines() if ln}
+
+
+def _write_coverage():
+    path = os.environ["GG_SIMT_COVERAGE"]
+    with open(path, "a") as f:
+        for k, v in sorted(kernel_coverage().items()):
+            f.write("%s\t%d\n" % (k, v))
 
 
 def race_report(lib=None):
@@ -146,7 +171,7 @@ class _Event:
         pass
 
 
-_PATCHED = ("current_stream", "device", "synchronize", "Stream", "Event", "stream")
+_PATCHED = ("current_stream", "device", "synchronize", "Stream", "Event", "stream", "is_current_stream_capturing")
 
 
 @contextlib.contextmanager
@@ -179,6 +204,7 @@ def emulated_gpu(poison=True):
         torch.cuda.Stream = _Stream
         torch.cuda.Event = _Event
         torch.cuda.stream = lambda s: contextlib.nullcontext()
+        torch.cuda.is_current_stream_capturing = lambda: False
         torch.Tensor.is_cuda = property(lambda self: True)
         if poison:
             torch.empty = empty

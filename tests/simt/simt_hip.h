@@ -30,6 +30,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <string>
 #include <vector>
 
 using std::isfinite;
@@ -127,7 +129,8 @@ inline bool simt_xchg_in[64];
 // a pseudo-random permutation (seeded by the launch number).  A kernel whose result is meant to be independent of
 // arrival order gives the same bytes under all of them.
 inline int simt_order = 0;
-inline char simt_order_filter[128] = "";       // ... only for launches whose kernel expression contains this
+inline char simt_order_filter[128] = "";
+inline std::map<std::string, long long> simt_kernel_launches;   // kernel expression -> launches (coverage: driver.cpp)       // ... only for launches whose kernel expression contains this
 inline long long simt_wg_serial = 0;            // workgroups run so far (all launches)
 inline size_t simt_lds_bytes = 0;               // size of the running launch's dynamic LDS block
 inline const char *simt_kernel_name = nullptr;  // ... its kernel expression
@@ -367,6 +370,7 @@ SIMT_NOSAN static inline void simt_launch(dim3 grid, dim3 block, size_t lds_byte
     const int order_asked = simt_order;
     if (simt_order_filter[0] && !strstr(name, simt_order_filter)) simt_order = 0;
     simt_kernel_name = name;
+    simt_kernel_launches[name]++;
     simt_lds_bytes = lds_bytes;
     if (simt_lds_buf.size() < lds_bytes + 64) simt_lds_buf.resize(lds_bytes + 64);
     simt_dyn_lds = (char *)(((uintptr_t)simt_lds_buf.data() + 63) & ~(uintptr_t)63);

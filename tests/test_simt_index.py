@@ -131,6 +131,57 @@ def test_emulated_build_edge_shapes(N, G, P, O, k):
     _same(sim.GridifyUp(data, up, npn, upn, **ukw), orc.gridify_up(data, up, npn, upn, **ukw), "gridify_up")
 
 
+def test_emulated_legacy_build_matches_oracle():
+    """the first-generation build (gridgcn_index_legacy.hip: the fallback for grids beyond 1024 slabs x 4096 voxels; its one
+    golden case has 4.5 M voxels) at a size the emulator runs: a 64^3 grid whose slab plan is pushed out of range by
+    GRIDGCN_OPT_INDEX_SLAB_SHIFT = -4 -- Gridify, GridifyKNN and GridifyUp through it, over-full voxels, ragged counts"""
+    rng = np.random.default_rng(11)
+    B, N, G = 2, 3000, 64
+    xyz = rng.uniform(-0.33, 0.33, (B, N, 3)).astype(np.float32)
+    xyz[1, :40] = 0.7                                        # one voxel far beyond P
+    w = rng.integers(1, 4, (B, N, 1)).astype(np.float32)
+    data = np.concatenate([xyz, w], 2)
+    npn = np.array([[N], [N - 77]], np.int32)
+    kw = dict(max_p_grid=2, max_o_grid=300, kernel_size=3, stride=1, loc=1, coord_shift=[1.0] * 3,
+              voxel_size=[2.0 / G] * 3, grid_size=[G] * 3, seed=5)
+    up = rng.uniform(-0.4, 0.4, (B, 200, 4)).astype(np.float32)
+    upn = np.array([[200], [123]], np.int32)
+    ukw = dict(kw, max_o_grid=200)
+    ukw.pop("stride"); ukw.pop("loc")
+    k0 = set(sim.emu.kernel_coverage())
+    try:
+        sim.set_option(_lib.OPT_INDEX_SMALL, 0)
+        sim.set_option(_lib.OPT_INDEX_SLAB_SHIFT, -4)
+        got = sim.Gridify(data, npn, **kw)
+        got_knn = sim.GridifyKNN(data, npn, **kw)
+        got_up = sim.GridifyUp(data, up, npn, upn, **ukw)
+    finally:
+        sim.set_option(_lib.OPT_INDEX_SMALL, 1)
+        sim.set_option(_lib.OPT_INDEX_SLAB_SHIFT, 0)
+    ran = set(sim.emu.kernel_coverage()) - k0 | k0
+    assert {"gg_k_voxelize", "gg_k_slab_count", "gg_k_scatter", "gg_k_centres", "gg_k_legacy_pack_vtab"} <= ran, ran
+    _same(got, orc.gridify(data, npn, **kw), "gridify (legacy build)")
+    _same(got_knn, orc.gridify_knn(data, npn, **kw), "gridify_knn (legacy build)")
+    _same(got_up, orc.gridify_up(data, up, npn, upn, **ukw), "gridify_up (legacy build)")
+
+
+def test_emulated_ball_knn_grid_thread_per_query_form():
+    """more than 32768 queries: the cell-grid BallKNN with a THREAD per query (gg_k_ball_grid_query; below that the
+    eight-lanes-per-query form runs) -- both k ranges, against the oracle"""
+    rng = np.random.default_rng(3)
+    B, n, m = 2, 16500, 300
+    un = rng.uniform(-1.0, 1.0, (B, n, 3)).astype(np.float32)
+    kn = rng.uniform(-1.0, 1.0, (B, m, 3)).astype(np.float32)
+    dn = np.array([[m], [m - 31]], np.int32)
+    upn = np.array([[n], [n - 1000]], np.int32)
+    for k, radius in ((3, 0.2), (5, 0.35)):
+        want = orc.ball_knn(un, kn, dn, upn, k=k, radius=radius)
+        got = sim.BallKNN(un, kn, dn, upn, k=k, radius=radius, grid=True)
+        for b in range(B):
+            assert np.array_equal(got[b, :upn[b, 0]], want[b, :upn[b, 0]])
+    assert any(k.startswith("gg_k_ball_grid_query<") for k in sim.emu.kernel_coverage())
+
+
 @pytest.mark.parametrize("n,m,k,radius,kind", [(700, 128, 5, 0.1275, "ball"), (600, 100, 3, 0.05, "planes"),
                                                (500, 128, 5, 5.0, "ball"), (500, 64, 4, 0.0, "ball"),
                                                (900, 300, 6, 0.02, "lattice"), (400, 200, 5, 0.3, "special")])

@@ -136,6 +136,49 @@ def test_gpu_tier_bodies_of_the_training_kernels(body, args):
     _to_cpu(getattr(_gpu_module("test_gpu_train_ops"), body))(*args)
 
 
+# ... and of the other GPU-tier files: the glue kernels (Adam, concat + mask, edge inputs), the statistics of the
+# source-side first conv, batch_take with its three backward forms, the inference edge kernels
+MORE_BODIES = [
+    ("test_gpu_glue", "test_adam_matches_torch", (1e-2,)),
+    ("test_gpu_glue", "test_adam_many_tensors_none_grads_and_mxnet_form", ()),
+    ("test_gpu_glue", "test_cat_mask_matches_torch", (4, 64, True, True)),
+    ("test_gpu_glue", "test_cat_mask_matches_torch", (3, None, False, True)),
+    ("test_gpu_glue", "test_cat_mask_matches_torch", (3, 5, True, True)),
+    ("test_gpu_glue", "test_cat_mask_matches_torch", (4, 6, False, False)),
+    ("test_gpu_glue", "test_ball_knn_reads_wider_rows_in_place", ()),
+    ("test_gpu_glue", "test_edge_geo_forward_statistics_match_the_edge_pass", (2, 24, 256, 8, 64, True)),
+    ("test_gpu_glue", "test_edge_geo_forward_statistics_match_the_edge_pass", (1, 300, 77, 5, 32, False)),
+    ("test_gpu_parity", "test_batch_take_matches_oracle_and_grad", ()),
+    ("test_gpu_parity", "test_error_behaviour", ()),
+    ("test_gpu_gridconv", "test_edge_inputs_forward_backward", (64, 3)),
+    ("test_gpu_gridconv", "test_edge_inputs_forward_backward", (33, 3)),
+    ("test_gpu_gridconv", "test_edge_inputs_rows_layout", (36, 3)),
+    ("test_gpu_gridconv", "test_edge_inputs_rows_layout", (0, 3)),
+    ("test_gpu_gridconv", "test_edge_block_source_side_first_conv", (64, 3, [64, 64, 128], 90, 12)),
+    ("test_gpu_gridconv", "test_att_max_eval_kernel_equals_two_kernel_path", (64, 64, 90, 7)),
+    ("test_gpu_gridconv", "test_att_max_eval_kernel_equals_two_kernel_path", (32, 128, 41, 33)),
+    ("test_gpu_train_ops", "test_wide_layers_without_rocblas_match_torch", (300, 64, [512])),
+    ("test_gpu_train_ops", "test_pairmax_fwd_first_argmax_exact", (300, 5, 64)),     # one thread per (centre, quad)
+    ("test_gpu_train_ops", "test_pairmax_fwd_first_argmax_exact", (77, 5, 30)),      # ... per (centre, channel)
+    ("test_gpu_train_ops", "test_mlp_train_matches_torch", (200, 13, [32])),         # padded input rows
+    ("test_gpu_train_ops", "test_mlp_train_matches_torch", (300, 100, [64, 16])),    # LDS-staged dW
+    ("test_gpu_train_ops", "test_mlp_train_matches_torch", (150, 7, [4, 2])),        # the first-generation GEMM family
+    ("test_gpu_train_ops", "test_pack_cache_batch_launch_equals_single_packs", ()),
+    pytest.param("test_gpu_train_ops", "test_linear_bwd_fused128_matches_separate_kernels", (32768, 128, True, 0),
+                 marks=slow),
+    pytest.param("test_gpu_gridconv", "test_full_model_eval_fused_vs_torch", (), marks=slow),
+]
+
+
+def _body_id(v):
+    return v if isinstance(v, str) and v.startswith("test_") else None
+
+
+@pytest.mark.parametrize("module,body,args", MORE_BODIES)
+def test_gpu_tier_bodies_of_the_other_files(module, body, args):
+    _to_cpu(getattr(_gpu_module(module), body))(*args)
+
+
 def _up_layer_case(seed, B=1, Nsrc=96, O=640):
     """an up layer of the segmentation net at toy size: [B, Nsrc] source points with 128 features, O up points with
     5 neighbours each (P = 5: the Z2-free attention pair), centre MLP + update MLP"""
