@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const gg_rsrc rz1 = gg_make_rsrc(p.Z1), ratt = gg_make_rsrc(p.att16), rnb = gg_make_rsrc(p.nebidx);
     const gg_rsrc ragg = gg_make_rsrc_n(p.agg, ncent * (unsigned)p.lda * 4u);
     const gg_rsrc rzp = gg_make_rsrc_n(p.zsel, ncent * 512u);
-    const gg_rsrc rza = gg_make_rsrc_n(p.zsel + p.ncent * 128, ncent * 512u);
+    const gg_rsrc rza = gg_make_rsrc_n(TRAIN ? p.zsel + p.ncent * 128 : p.zsel, ncent * 512u);   // (evaluation: no zsel at all)
     const gg_rsrc ram = gg_make_rsrc_n(p.amax, ncent * 128u);
     // the A row of this lane: slot s_i of lane half h_i
     const int si = (j & 3) + 4 * (j >> 3), hi = (j >> 2) & 1;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rr = (r & 3) + 8 * (r >> 2);
-            if (tm * 32 + 4 * h + rr < p.M) p.C[(size_t)(tm * 32 + 4 * h + rr) * p.ldc - p.zero_left + l31] = 0.f;
+            if (tm * 32 + 4 * h + rr < p.M) p.C[(long long)(tm * 32 + 4 * h + rr) * p.ldc - p.zero_left + l31] = 0.f;   // (columns LEFT of C: a signed offset)
         }
     }
 }

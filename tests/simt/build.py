@@ -133,10 +133,19 @@ def _stamp():
 
 
 RACE_FLAGS = ["-DSIMT_RACE=1", "-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0", "-mllvm",
-              "-tsan-instrument-memintrinsics=0", "-mllvm", "-tsan-instrument-atomics=0"]
+              "-tsan-instrument-atomics=0"]
 
 
-def build(force=False, verbose=False, asan=False, race=False):
+UBSAN_CHECKS = ("signed-integer-overflow,shift,bounds,alignment,integer-divide-by-zero,float-cast-overflow,null,"
+                "vla-bound,unreachable,return,pointer-overflow,bool")
+
+
+def _ubsan_runtime():
+    import glob
+    return sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so"))[0]
+
+
+def build(force=False, verbose=False, asan=False, race=False, ubsan=False):
     """one translation unit per kernel source, as the product's own build (grid_gcn_amd/build.py), plus the driver.
     asan=True: libgridgcn_simt_asan.so, every unit with -fsanitize=address (run the python process with the runtime
     preloaded: tests/simt/asan.sh)"""
@@ -148,6 +157,18 @@ def build(force=False, verbose=False, asan=False, race=False):
         LIB = os.path.join(OUT, "libgridgcn_simt_asan.so")
         try:
             return _build(force, verbose, ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan"])
+        finally:
+            OUT, LIB = saved
+    if ubsan:
+        # UndefinedBehaviorSanitizer over the kernel units (tests/simt/ubsan.sh): index arithmetic that overflows, shifts
+        # out of range, register arrays indexed past their end, misaligned vector accesses, float -> int conversions
+        # out of range; the runtime (a shared library of the toolchain) is linked in, reports go to stderr / log_path
+        saved = (OUT, LIB)
+        OUT = os.path.join(HERE, "_build", "ubsan")
+        LIB = os.path.join(OUT, "libgridgcn_simt_ubsan.so")
+        try:
+            return _build(force, verbose, ["-fsanitize=" + UBSAN_CHECKS, "-fno-sanitize-recover=unreachable,return"],
+                          link_extra=[_ubsan_runtime(), "-Wl,-rpath," + os.path.dirname(_ubsan_runtime())])
         finally:
             OUT, LIB = saved
     if race:
@@ -162,7 +183,7 @@ def build(force=False, verbose=False, asan=False, race=False):
     return _build(force, verbose, [])
 
 
-def _build(force, verbose, extra, race=False):
+def _build(force, verbose, extra, race=False, link_extra=None):
     import concurrent.futures
     os.makedirs(OUT, exist_ok=True)
     stamp_file = os.path.join(OUT, "stamp")
@@ -206,7 +227,8 @@ def _build(force, verbose, extra, race=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, units))
-    cmd = [CXX, "-shared", "-fPIC"] + ([] if race else extra) + objs + (["-ldl"] if race else []) + ["-o", LIB + ".tmp"]
+    cmd = [CXX, "-shared", "-fPIC"] + ([] if (race or link_extra) else extra) + objs + (["-ldl"] if race else []) + \
+        (link_extra or []) + ["-o", LIB + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("simt link failed:\n" + r.stderr[-6000:])
@@ -244,4 +266,5 @@ def build_selftest():
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv, race="--race" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv, race="--race" in sys.argv,
+                ubsan="--ubsan" in sys.argv))

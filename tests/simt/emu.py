@@ -42,7 +42,9 @@ def library():
         # GG_SIMT_RACE=1: the data-race detector (tests/simt/simt_race.cpp); its report goes to the file named by
         # GG_SIMT_RACE_REPORT when the process ends (tests/simt/race.sh)
         race = os.environ.get("GG_SIMT_RACE") == "1"
-        lib = ctypes.CDLL(simt_build.build(asan=os.environ.get("GG_SIMT_ASAN") == "1", race=race))
+        # GG_SIMT_UBSAN=1: the UndefinedBehaviorSanitizer build (tests/simt/ubsan.sh)
+        lib = ctypes.CDLL(simt_build.build(asan=os.environ.get("GG_SIMT_ASAN") == "1", race=race,
+                                           ubsan=os.environ.get("GG_SIMT_UBSAN") == "1"))
         _EMU = _lib.declare(lib, "tests/simt emulation")
         _EMU.simt_counters.argtypes = [ctypes.c_void_p]
         _EMU.simt_set_order_filter.argtypes = [ctypes.c_char_p]
@@ -88,7 +90,7 @@ def race_report(lib=None):
     rows = [ln.split("\t") for ln in buf.value.decode().splitlines() if ln]
     if not rows:
         return []
-    so = rows[0][2]
+    so = next((r[2] for r in rows if r[2] != "?"), rows[0][2])
     addrs = [a for r in rows for a in (r[3], r[4])]
     # (the address of the call's return: one byte back is inside the access's own line)
     sym = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-symbolizer", "--obj=" + so, "--functions=none", "--no-inlines"] +

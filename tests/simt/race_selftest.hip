@@ -108,6 +108,27 @@ __global__ void rk_counter(int *out, int fix)
     out[t] = base + t;
 }
 
+// LDS nobody of this workgroup has written (the GPU hands over the last tenant's bytes), and a store beyond the launch's
+// dynamic LDS block (dropped silently by the GPU); a float4 stored as a whole is a memory intrinsic to the compiler
+struct rk_f4 { float x, y, z, w; };
+__global__ void rk_lds(int *out, int mode)
+{
+    extern __shared__ int dyn[];
+    __shared__ rk_f4 quad[64];
+    const int t = threadIdx.x;
+    if (mode == 0) {                       // read what nobody wrote
+        out[blockIdx.x * 64 + t] = dyn[t];
+    } else if (mode == 1) {                // 64 ints were asked for at the launch
+        dyn[64 + t] = t;
+        out[blockIdx.x * 64 + t] = t;
+    } else {                               // whole-struct store, element loads: initialised, and ordered by the barrier
+        const rk_f4 v = {1.f * t, 2.f, 3.f, 4.f};
+        quad[t] = v;
+        __syncthreads();
+        out[blockIdx.x * 64 + t] = (int)(quad[63 - t].x + quad[63 - t].w);
+    }
+}
+
 extern "C" void rk_run(int which, int arg, int *a, int *b, int *c)
 {
     hipStream_t st = nullptr;
@@ -119,5 +140,11 @@ extern "C" void rk_run(int which, int arg, int *a, int *b, int *c)
     case 4: rk_flag<<<1, 128, 0, st>>>(a); break;
     case 5: rk_atomic_then_plain<<<3, 64, 0, st>>>(a, b); break;
     case 6: rk_counter<<<1, 64, 0, st>>>(a, arg); break;
+    case 7:
+        // (the emulator's LDS buffer only grows: a first launch with a large block, so that the out-of-block store of
+        //  mode 1 lands inside the buffer, as it lands inside the CU's LDS on the GPU)
+        rk_lds<<<1, 64, 4096, st>>>(b, 2);
+        rk_lds<<<2, 64, 64 * sizeof(int), st>>>(a, arg);
+        break;
     }
 }

@@ -21,6 +21,10 @@
 //     INTRA  same workgroup, different waves, no barrier between       -- a missing __syncthreads
 //     WAVE   same wave, different lanes, no wave operation between      -- the kernel leans on lockstep there
 //     INTER  different workgroups of one launch                         -- unordered global traffic
+//   Two more things the same shadow state shows, reported in the same table:
+//     UNINIT a load of an LDS word no work-item of THIS workgroup has stored (LDS is not cleared between workgroups: the
+//            GPU hands over whatever the last tenant left)
+//     LDSOOB an access beyond the launch's dynamic LDS block (the GPU drops such a store and reads 0: silently)
 //
 // LDS (the launch's dynamic block and every `__shared__` variable: section "simt_lds") belongs to one workgroup: an
 // entry left by an earlier workgroup is stale, not a conflict.  The fibres' stacks are private.
@@ -44,12 +48,12 @@ extern char __stop_simt_lds[] __attribute__((weak));
 
 namespace {
 
-struct Acc {                 // one recorded access: 16 bytes
+struct Acc {                 // one recorded access: 20 bytes
     uint32_t gen;            // launch serial (0 = empty)
     uint32_t wg_tid;         // workgroup serial of the launch << 10 | work-item
     uint32_t seq;            // the work-item's count of cross-lane operations
+    uint32_t pc_fl;          // code address index << 2 | atomic << 1 | write
     uint16_t bar;            // ... of workgroup barriers
-    uint16_t pc_fl;          // code address index << 2 | atomic << 1 | write
 };
 struct Cell { Acc w, r0, r1, r2; };   // last store; latest load, latest load of another lane of r0's wave, of another wave
 
@@ -88,15 +92,15 @@ std::map<uint32_t, Edge> acquired;                                     // of the
 uint32_t acquired_wg = ~0u, acquired_gen = 0;
 
 std::vector<const void *> pcs(1, nullptr);
-std::unordered_map<const void *, uint16_t> pc_index;
-uint16_t pc_of(const void *pc)
+std::unordered_map<const void *, uint32_t> pc_index;
+uint32_t pc_of(const void *pc)
 {
     auto it = pc_index.find(pc);
     if (it != pc_index.end()) return it->second;
-    if (pcs.size() >= (1u << 14)) return 0;
-    pc_index[pc] = (uint16_t)pcs.size();
+    if (pcs.size() >= (1u << 29)) return 0;
+    pc_index[pc] = (uint32_t)pcs.size();
     pcs.push_back(pc);
-    return (uint16_t)(pcs.size() - 1);
+    return (uint32_t)(pcs.size() - 1);
 }
 
 struct Report {
@@ -122,7 +126,7 @@ std::map<Key, Report> reports;
 long long n_access = 0, n_conflict = 0;
 bool enabled = true;
 uint32_t cur_gen = 0;
-const char *KIND[] = {"INTRA", "WAVE", "INTER"};
+const char *KIND[] = {"INTRA", "WAVE", "INTER", "UNINIT", "LDSOOB"};
 
 inline bool is_stack(uintptr_t a)
 {
@@ -189,6 +193,18 @@ void report(int kind, const Acc &A, const Acc &B, uintptr_t addr, bool lds, unsi
     }
 }
 
+void report_one(int kind, const Acc &B, uintptr_t addr)
+{
+    n_conflict++;
+    Key k{simt_kernel_name ? simt_kernel_name : "?", kind, pcs[B.pc_fl >> 2], pcs[B.pc_fl >> 2]};
+    Report &r = reports[k];
+    if (r.count++ == 0) {
+        r.addr = addr;
+        r.wg0 = r.wg1 = B.wg_tid >> 10; r.tid0 = r.tid1 = B.wg_tid & 1023; r.w0 = r.w1 = B.pc_fl & 1;
+        r.lds = true;
+    }
+}
+
 inline void check(const Acc &A, const Acc &B, uintptr_t addr, bool lds, unsigned gran)
 {
     if (A.gen != B.gen) return;
@@ -210,6 +226,20 @@ inline void check(const Acc &A, const Acc &B, uintptr_t addr, bool lds, unsigned
     report(2, A, B, addr, lds, gran);
 }
 
+inline bool written_by_wg(const Acc &w, const Acc &cur)
+{
+    return w.gen == cur.gen && (w.wg_tid >> 10) == (cur.wg_tid >> 10);
+}
+// the word shadow and the byte shadow are separate tables: a word stored as a word and loaded as two halves (or the
+// other way round) is initialised all the same
+inline bool written_other_granule(uintptr_t addr, unsigned gran, const Acc &cur)
+{
+    if (gran == 1) return written_by_wg(sh_word.cell(addr & ~(uintptr_t)3)->w, cur);
+    for (unsigned o = 0; o < 4; o++)
+        if (!written_by_wg(sh_byte.cell(addr + o)->w, cur)) return false;
+    return true;
+}
+
 inline void touch(Cell *c, const Acc &cur, uintptr_t addr, bool lds, unsigned gran)
 {
     if (cur.pc_fl & 1) {
@@ -221,6 +251,7 @@ inline void touch(Cell *c, const Acc &cur, uintptr_t addr, bool lds, unsigned gr
         c->r0.gen = c->r1.gen = c->r2.gen = 0;   // (accesses ordered after this store are ordered after those loads: a
                                                  //  load that is NOT ordered before this store has just been reported)
     } else {
+        if (lds && !written_by_wg(c->w, cur) && !written_other_granule(addr, gran, cur)) report_one(3, cur, addr);
         check(c->w, cur, addr, lds, gran);
         // r0 = the latest reader; when it is replaced it moves to r1 (replaced by another lane of its wave: a wave that
         // reads a word lane by lane and then lets ONE lane store it) or to r2 (replaced by another wave / workgroup)
@@ -243,14 +274,17 @@ void access(const void *p, unsigned size, bool write, bool atomic, const void *p
     cur_gen = (uint32_t)simt_launches;
     const uint32_t wg = (uint32_t)simt_wg_serial & 0x3fffff, tid = (uint32_t)(f - simt_fibers.data());
     start_wg_if_new(wg);
-    Acc cur{cur_gen, wg << 10 | tid, (uint32_t)f->seq, (uint16_t)f->bar,
-            (uint16_t)(pc_of(pc) << 2 | (atomic ? 2 : 0) | (write ? 1 : 0))};
+    Acc cur{cur_gen, wg << 10 | tid, (uint32_t)f->seq, pc_of(pc) << 2 | (atomic ? 2u : 0u) | (write ? 1u : 0u),
+            (uint16_t)f->bar};
     const bool lds = is_lds(a);
-    if (size >= 4 && (a & 3) == 0) {
-        for (unsigned o = 0; o < size; o += 4) touch(sh_word.cell(a + o), cur, a + o, lds, 4);
-    } else {
-        for (unsigned o = 0; o < size; o++) touch(sh_byte.cell(a + o), cur, a + o, lds, 1);
+    if (!lds && a - (uintptr_t)simt_dyn_lds < simt_lds_buf.size() - (size_t)(simt_dyn_lds - simt_lds_buf.data())) {
+        report_one(4, cur, a);
+        return;
     }
+    unsigned o = 0;
+    if ((a & 3) == 0)
+        for (; o + 4 <= size; o += 4) touch(sh_word.cell(a + o), cur, a + o, lds, 4);
+    for (; o < size; o++) touch(sh_byte.cell(a + o), cur, a + o, lds, 1);
 }
 
 }  // namespace
@@ -360,6 +394,26 @@ int simt_race_report(char *buf, size_t n)
 RD(1) RD(2) RD(4) RD(8) RD(16)
 void __tsan_read_range(void *p, unsigned long n) { access(p, (unsigned)n, false, false, __builtin_return_address(0)); }
 void __tsan_write_range(void *p, unsigned long n) { access(p, (unsigned)n, true, false, __builtin_return_address(0)); }
+// struct copies and fills the compiler lowers to the memory intrinsics (a float4 assigned as a whole)
+void *__tsan_memcpy(void *d, const void *s, unsigned long n)
+{
+    const void *pc = __builtin_return_address(0);
+    access(s, (unsigned)n, false, false, pc);
+    access(d, (unsigned)n, true, false, pc);
+    return memcpy(d, s, n);
+}
+void *__tsan_memmove(void *d, const void *s, unsigned long n)
+{
+    const void *pc = __builtin_return_address(0);
+    access(s, (unsigned)n, false, false, pc);
+    access(d, (unsigned)n, true, false, pc);
+    return memmove(d, s, n);
+}
+void *__tsan_memset(void *d, int v, unsigned long n)
+{
+    access(d, (unsigned)n, true, false, __builtin_return_address(0));
+    return memset(d, v, n);
+}
 void __tsan_init() {}
 void __tsan_func_entry(void *) {}
 void __tsan_func_exit() {}

@@ -31,12 +31,15 @@ def lib():
     return so
 
 
-def run(lib, which, arg=0):
+def run(lib, which, arg=0, uninit=False):
+    """the report of one launch; UNINIT rows (a load that meets no store of its workgroup: every load that runs ahead of
+    the store it races with is one, too) only on request"""
     import emu
     a, b, c = (np.zeros(4096, np.int32) for _ in range(3))
     lib.simt_race_reset()
     lib.rk_run(which, arg, a.ctypes.data, b.ctypes.data, c.ctypes.data)
-    return emu.race_report(lib), (a, b, c)
+    rep = emu.race_report(lib)
+    return [r for r in rep if uninit or r[0] != "UNINIT"], (a, b, c)
 
 
 def test_missing_barrier_between_waves(lib):
@@ -100,3 +103,14 @@ def test_counter_read_by_every_lane_and_advanced_by_one(lib):
     assert (out[:64] == 5 + np.arange(64)).all()
     rep, _ = run(lib, 6, 1)
     assert rep == []
+
+
+def test_uninitialised_lds_and_lds_beyond_the_block(lib):
+    rep, _ = run(lib, 7, 0, uninit=True)
+    assert [(r[0], r[2]) for r in rep] == [("UNINIT", line_of(r"= dyn\[t\];"))], rep
+    rep, _ = run(lib, 7, 1, uninit=True)
+    assert [(r[0], r[2]) for r in rep] == [("LDSOOB", line_of(r"dyn\[64 \+ t\] = t;"))], rep
+    # a struct stored as a whole reaches the detector as a memory intrinsic: seen as a store (no UNINIT, no race)
+    rep, (out, _, _) = run(lib, 7, 2, uninit=True)
+    assert rep == [], rep
+    assert (out[:64] == (63 - np.arange(64)) + 4).all()
