@@ -33,9 +33,25 @@
 // hardware's memory model beyond "atomics synchronise" (a relaxed ticket counts as release + acquire here: the fences
 // that make it so on the GPU are checked by tests/test_isa_handoff.py on the GPU ISA), and anything the tests do not
 // execute.
+//
+// TRAFFIC ACCOUNTING (simt_traffic_enable(1); tools/simt_traffic.py).  The same hooks see every global load and store
+// with its address, so a launch's memory footprint can be COUNTED instead of estimated.  Per launch, with workgroup
+// (x, y, z) placed on XCD  linear index mod 8  (the dispatch order of MI355X: cdna_hip_programming.md):
+//   requested   bytes the work-items asked for (sum of access sizes): what an L1-less, L2-less machine would move
+//   fetched     128-byte lines x 128 that an XCD reads WITHOUT having read or written them earlier in the launch, summed
+//               over the eight XCDs: the L2-miss traffic of eight private, unbounded L2s that start the launch cold --
+//               what TCC_EA_RDREQ (FETCH_SIZE) counts when nothing of a launch's working set is evicted inside the
+//               launch and nothing is inherited from the launch in front
+//   written     distinct 32-byte sectors x 32 stored to: the write-back of an L2 that merges all stores to a sector
+// Exact for what they define, hardware-independent, and a bracket for the counters: PMC fetch <= `fetched` when a
+// launch inherits lines from its predecessor in the same XCD's L2 (the index build relies on it), PMC fetch >= `fetched`
+// when the working set of the workgroups in flight exceeds 4 MB per XCD.  Checked against the round-5 counter tables
+// (profiles/traffic.json) in profiles/r6_emulated_traffic.txt.
 #include "simt_hip.h"
 
 #include <dlfcn.h>
+#include <link.h>
+#include <pthread.h>
 
 #include <map>
 #include <string>
@@ -127,6 +143,86 @@ long long n_access = 0, n_conflict = 0;
 bool enabled = true;
 uint32_t cur_gen = 0;
 const char *KIND[] = {"INTRA", "WAVE", "INTER", "UNINIT", "LDSOOB"};
+
+// ---- traffic accounting ----------------------------------------------------------------------------------------------
+bool traffic_on = false;
+struct TLine { uint8_t touched_xcd = 0, wsect = 0; };      // per 128-byte line of the current launch
+std::unordered_map<uintptr_t, TLine> t_lines;
+struct TPc { long long fetched = 0, written = 0, req_ld = 0, req_st = 0; };
+struct TStat {
+    long long launches = 0, wgs = 0, req_ld = 0, req_st = 0, fetched = 0, written = 0;
+    std::unordered_map<const void *, TPc> by_pc;
+};
+std::map<std::string, TStat> t_stats;
+TStat *t_cur = nullptr;
+uint32_t t_cur_gen = 0;
+
+// the emulator's own state is not device memory: the library's data segments (threadIdx & co., option flags) and the
+// fibre records
+uintptr_t t_obj_lo = 0, t_obj_hi = 0;
+int t_find_obj(struct dl_phdr_info *info, size_t, void *)
+{
+    const uintptr_t me = (uintptr_t)&t_obj_lo;
+    for (int i = 0; i < info->dlpi_phnum; i++) {
+        const ElfW(Phdr) &ph = info->dlpi_phdr[i];
+        if (ph.p_type != PT_LOAD) continue;
+        const uintptr_t lo = info->dlpi_addr + ph.p_vaddr, hi = lo + ph.p_memsz;
+        if (me >= lo && me < hi) {
+            for (int j = 0; j < info->dlpi_phnum; j++) {
+                const ElfW(Phdr) &q = info->dlpi_phdr[j];
+                if (q.p_type != PT_LOAD) continue;
+                const uintptr_t l2 = info->dlpi_addr + q.p_vaddr, h2 = l2 + q.p_memsz;
+                if (!t_obj_lo || l2 < t_obj_lo) t_obj_lo = l2;
+                if (h2 > t_obj_hi) t_obj_hi = h2;
+            }
+            return 1;
+        }
+    }
+    return 0;
+}
+uintptr_t t_host_lo = 0, t_host_hi = 0;      // stack of the launching thread: kernel arguments (SGPRs on the GPU)
+inline bool is_emulator_state(uintptr_t a)
+{
+    if (!t_obj_hi) {
+        dl_iterate_phdr(t_find_obj, nullptr);
+        pthread_attr_t at;
+        void *sa = nullptr;
+        size_t sz = 0;
+        if (pthread_getattr_np(pthread_self(), &at) == 0) {
+            pthread_attr_getstack(&at, &sa, &sz);
+            pthread_attr_destroy(&at);
+            t_host_lo = (uintptr_t)sa;
+            t_host_hi = t_host_lo + sz;
+        }
+    }
+    if (a >= t_obj_lo && a < t_obj_hi) return true;
+    if (a >= t_host_lo && a < t_host_hi) return true;
+    return a - (uintptr_t)simt_fibers.data() < simt_fibers.size() * sizeof(SimtFiber);
+}
+
+inline void traffic(uintptr_t a, unsigned size, bool write, const void *pc)
+{
+    if (is_emulator_state(a)) return;
+    if (t_cur_gen != (uint32_t)simt_launches || !t_cur) {
+        t_cur = &t_stats[simt_kernel_name ? simt_kernel_name : "?"];
+        t_cur_gen = (uint32_t)simt_launches;
+    }
+    const unsigned lin = simt_blockIdx.x + simt_gridDim.x * (simt_blockIdx.y + simt_gridDim.y * simt_blockIdx.z);
+    const uint8_t xbit = (uint8_t)(1u << (lin & 7));
+    TPc &P = t_cur->by_pc[pc];
+    (write ? t_cur->req_st : t_cur->req_ld) += size;
+    (write ? P.req_st : P.req_ld) += size;
+    for (uintptr_t s = a >> 5; s <= (a + size - 1) >> 5; s++) {       // 32-byte sectors
+        TLine &L = t_lines[s >> 2];
+        if (write) {
+            const uint8_t sb = (uint8_t)(1u << (s & 3));
+            if (!(L.wsect & sb)) { L.wsect |= sb; t_cur->written += 32; P.written += 32; }
+        } else if (!(L.touched_xcd & xbit)) {
+            t_cur->fetched += 128; P.fetched += 128;
+        }
+        L.touched_xcd |= xbit;
+    }
+}
 
 inline bool is_stack(uintptr_t a)
 {
@@ -267,9 +363,13 @@ void access(const void *p, unsigned size, bool write, bool atomic, const void *p
 {
     SimtFiber *f = simt_cur;
     if (!pending.empty()) flush_pending();
-    if (!enabled || !f || f->state != SIMT_RUN) return;    // host code, the scheduler
+    if (!(enabled || traffic_on) || !f || f->state != SIMT_RUN) return;    // host code, the scheduler
     const uintptr_t a = (uintptr_t)p;
     if (is_stack(a)) return;
+    if (traffic_on && size && !is_lds(a) &&
+        !(a - (uintptr_t)simt_dyn_lds < simt_lds_buf.size() - (size_t)(simt_dyn_lds - simt_lds_buf.data())))
+        traffic(a, size, write, pc);
+    if (!enabled) return;
     n_access++;
     cur_gen = (uint32_t)simt_launches;
     const uint32_t wg = (uint32_t)simt_wg_serial & 0x3fffff, tid = (uint32_t)(f - simt_fibers.data());
@@ -295,7 +395,12 @@ extern "C" {
 __attribute__((noinline)) void simt_race_atomic(const void *p, int size, int kind, const void *pc)
 {
     SimtFiber *f = simt_cur;
-    if (!enabled || !f || f->state != SIMT_RUN) return;
+    if (!(enabled || traffic_on) || !f || f->state != SIMT_RUN) return;
+    if (!enabled) {                                         // traffic only
+        if (kind != 3) access(p, size, false, true, pc);
+        if (kind != 2) access(p, size, true, true, pc);
+        return;
+    }
     if (kind != 3) access(p, size, false, true, pc);
     if (kind != 2) access(p, size, true, true, pc);
     if (is_lds((uintptr_t)p)) return;
@@ -325,6 +430,13 @@ __attribute__((noinline)) void simt_race_access(const void *p, int size, int wri
 // a launch is over: nothing recorded in it can conflict with anything later
 void simt_race_launch_end()
 {
+    if (traffic_on) {
+        TStat &k = t_stats[simt_kernel_name ? simt_kernel_name : "?"];
+        k.launches++;
+        k.wgs += (long long)simt_gridDim.x * simt_gridDim.y * simt_gridDim.z;
+        t_lines.clear();
+        t_cur = nullptr;
+    }
     flush_pending();
     released.clear();
     acquired.clear();
@@ -336,6 +448,41 @@ void simt_race_launch_end()
 }
 
 void simt_race_enable(int on) { enabled = on != 0; }
+void simt_traffic_enable(int on) { traffic_on = on != 0; }
+void simt_traffic_reset()
+{
+    t_stats.clear();
+    t_lines.clear();
+    t_cur = nullptr;
+}
+// one line per kernel:  K <tab> kernel <tab> launches <tab> workgroups <tab> requested load / store <tab> fetched <tab> written
+// and, with per_pc != 0, one line per code address of that kernel:  P <tab> kernel <tab> library <tab> offset <tab> the same four
+int simt_traffic_report(char *buf, size_t n, int per_pc)
+{
+    std::string s;
+    char line[1024];
+    for (auto &kv : t_stats) {
+        const TStat &k = kv.second;
+        snprintf(line, sizeof line, "K\t%s\t%lld\t%lld\t%lld\t%lld\t%lld\t%lld\n", kv.first.c_str(), k.launches, k.wgs,
+                 k.req_ld, k.req_st, k.fetched, k.written);
+        s += line;
+        if (!per_pc) continue;
+        for (auto &pv : k.by_pc) {
+            Dl_info i0{};
+            dladdr(pv.first, &i0);
+            snprintf(line, sizeof line, "P\t%s\t%s\t0x%zx\t%lld\t%lld\t%lld\t%lld\n", kv.first.c_str(),
+                     i0.dli_fname ? i0.dli_fname : "?", (size_t)((const char *)pv.first - (const char *)i0.dli_fbase),
+                     pv.second.req_ld, pv.second.req_st, pv.second.fetched, pv.second.written);
+            s += line;
+        }
+    }
+    if (buf && n) {
+        const size_t m = std::min(n - 1, s.size());
+        memcpy(buf, s.data(), m);
+        buf[m] = 0;
+    }
+    return (int)s.size();
+}
 void simt_race_reset()
 {
     reports.clear();

@@ -210,3 +210,28 @@ def test_emulated_ball_knn_grid_equals_scan_and_oracle(n, m, k, radius, kind):
     for b in range(B):          # rows >= upnum are left untouched by the operator
         assert np.array_equal(scan[b, :upn[b, 0]], want[b, :upn[b, 0]])
         assert np.array_equal(grid[b, :upn[b, 0]], want[b, :upn[b, 0]])
+
+
+@pytest.mark.parametrize("order", [0, pytest.param(10, marks=pytest.mark.skipif(
+    os.environ.get("GG_SIMT_FULL") != "1", reason="permuted workgroups: with GG_SIMT_FULL=1"))])
+def test_emulated_cfg2_batch32_gridify_chain(order):
+    """BASELINE configs[1] at its real batch -- 32 clouds x 1024 points, ragged counts inside the batch -- through the
+    three Gridify layers of the classifier, chained as the model chains them: the index half of the GPU tier's
+    test_cls_cfg2_batch32_gridify_bit_exact_and_eval_logits (written in round 6 with the GPU pool closed: this is its
+    first execution).  One workgroup per cloud in gg_k_small_build, cloud b on XCD b mod 8 -- B = 32 is four clouds per
+    XCD, which no golden case has."""
+    cfg = synth.CLS_MODELNET40
+    data, npn = synth.make_batch(32, 1024, "ball")
+    npn = npn.copy()
+    npn[5, 0], npn[17, 0], npn[31, 0] = 1000, 513, 1
+    d, n = data, npn
+    try:
+        sim.set_order(order)
+        for l in range(3):
+            kw = synth.gridify_kwargs(cfg, l, seed=3 + l)
+            want = orc.gridify(d, n, **kw)
+            got = sim.Gridify(d, n, **kw)
+            _same(got, want, "cfg2 b32 layer %d" % l)
+            d, n = want[2], want[4]
+    finally:
+        sim.set_order(0)
