@@ -38,7 +38,25 @@ __global__ __launch_bounds__(256) void gg_k_ctx_max(const float *__restrict__ sr
         const float c0 = j < 3 ? cent[(size_t)ci * cent_stride + j] : 0.f;
         float best = -INFINITY;
         int bi_ = 0;
-        for (int p = 0; p < P; p++) {
+        // eight gathered rows in flight, compared in neighbour order (the first maximum wins, as one by one: a load per
+        // iteration behind a data-dependent branch was P memory round trips in a row -- tools/isa_chains.py)
+        int p = 0;
+        for (; p + 8 <= P; p += 8) {
+            int ri[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ri[u] = sidx[p + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)ri[u] * Cs + col];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float d = v[u] - c0;
+                const bool gt = d > best;
+                best = gt ? d : best;
+                bi_ = gt ? ri[u] : bi_;
+            }
+        }
+        for (; p < P; p++) {
             const float v = src[(size_t)sidx[p] * Cs + col] - c0;
             if (v > best) { best = v; bi_ = sidx[p]; }
         }
@@ -89,7 +107,22 @@ __global__ __launch_bounds__(256) void gg_k_dz_segsum(const float *__restrict__ 
     if (ok) {
         sc = scale[c]; sh = shift[c];
         const float *zr = Z + (size_t)ci * P * C + c, *gr = dY + (size_t)ci * P * C + c;
-        for (int p = r; p < P; p += rs) {
+        // eight rows of Z and of dY in flight, added in row order (the sums of the one-by-one loop, bit for bit)
+        int p = r;
+        for (; p + 7 * rs < P; p += 8 * rs) {
+            float z[8], g[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                z[u] = zr[(size_t)(p + u * rs) * C];
+                g[u] = gr[(size_t)(p + u * rs) * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                s1 += (z[u] * sc + sh > 0.f) ? g[u] : 0.f;
+                sz += z[u];
+            }
+        }
+        for (; p < P; p += rs) {
             const float z = zr[(size_t)p * C];
             const float g = gr[(size_t)p * C];
             s1 += (z * sc + sh > 0.f) ? g : 0.f;

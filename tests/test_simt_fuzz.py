@@ -2,7 +2,7 @@
 P / O, ragged counts, duplicate and out-of-grid points, integer weights) through the host-side emulation of the
 index kernels -- and, instance by instance, through ANOTHER ARRIVAL ORDER of workgroups, waves and lanes
 (tests/simt/simt_hip.h: simt_order), which the GPU tier cannot choose.  Every output bit for bit against the oracle.
-GG_SIMT_FUZZ_N instances (4 by default: half a minute; a hunt of 300 ran clean in round 6, profiles/r6_simt_fuzz.txt)."""
+GG_SIMT_FUZZ_N instances (4 by default: half a minute; GG_SIMT_FUZZ_N=200 -- 300 test instances -- ran clean in round 6: profiles/r6_simt_fuzz.txt)."""
 import os
 import sys
 
