@@ -129,6 +129,20 @@ __global__ void rk_lds(int *out, int mode)
     }
 }
 
+// traffic accounting (simt_traffic_enable): 16 workgroups (two per XCD: workgroup w on XCD w mod 8) of 64 work-items.
+//   every work-item reads ONE table of 64 ints (256 bytes = 2 lines) -> fetched once per XCD, not per workgroup: 8 x 256
+//   work-item t of workgroup w reads a[w * 64 + t] (streamed: 16 x 256 bytes, each line by one XCD)
+//   and stores b[(w * 64 + t) * 16]: 4 bytes per 64-byte stride -> 1024 distinct 32-byte sectors
+//   workgroup w >= 8 also reads c[(w - 8) * 64 + t], which workgroup w - 8 (same XCD) has WRITTEN: no fetch
+__global__ void rk_traffic(const int *a, int *b, int *c, const int *table)
+{
+    const int w = blockIdx.x, t = threadIdx.x;
+    int v = table[t] + a[w * 64 + t];
+    if (w < 8) c[w * 64 + t] = v;
+    else v += c[(w - 8) * 64 + t];
+    b[(w * 64 + t) * 16] = v;
+}
+
 extern "C" void rk_run(int which, int arg, int *a, int *b, int *c)
 {
     hipStream_t st = nullptr;
@@ -146,5 +160,6 @@ extern "C" void rk_run(int which, int arg, int *a, int *b, int *c)
         rk_lds<<<1, 64, 4096, st>>>(b, 2);
         rk_lds<<<2, 64, 64 * sizeof(int), st>>>(a, arg);
         break;
+    case 8: rk_traffic<<<16, 64, 0, st>>>(a, b, c, a + 2048); break;
     }
 }

@@ -358,8 +358,8 @@ SIMT_NOSAN static inline void simt_run_block(int nthreads, const dim3 &bd)
 template <class A, class... R> static inline const void *simt_first_arg(const A &a, const R &...) { return &a; }
 static inline const void *simt_first_arg() { return nullptr; }
 
-SIMT_NOSAN static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body,
-                               const void *kernarg = nullptr, const char *name = "?")
+SIMT_NOSAN static inline void simt_launch_impl(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body,
+                                    const void *kernarg, const char *name)
 {
     simt_kernarg = kernarg;
     static const bool trace = getenv("SIMT_TRACE") != nullptr;
@@ -399,6 +399,18 @@ SIMT_NOSAN static inline void simt_launch(dim3 grid, dim3 block, size_t lds_byte
 #ifdef SIMT_RACE
     simt_race_launch_end();
 #endif
+}
+
+// (the launch statement's closure stays where the compiler put it -- the launching function's frame -- and the
+//  std::function holds one reference to it: a closure of more than 16 bytes would otherwise be copied to the heap, and the
+//  traffic accounting of the race build would take the work-items' reads of the by-value kernel arguments for device
+//  memory traffic; the launching thread's stack it knows)
+template <class F>
+SIMT_NOSAN static inline void simt_launch(dim3 grid, dim3 block, size_t lds_bytes, const F &fn, const void *kernarg = nullptr,
+                               const char *name = "?")
+{
+    const std::function<void()> body = [&fn]() { fn(); };
+    simt_launch_impl(grid, block, lds_bytes, body, kernarg, name);
 }
 
 #define SIMT_INL inline __attribute__((always_inline))

@@ -114,3 +114,42 @@ def test_uninitialised_lds_and_lds_beyond_the_block(lib):
     rep, (out, _, _) = run(lib, 7, 2, uninit=True)
     assert rep == [], rep
     assert (out[:64] == (63 - np.arange(64)) + 4).all()
+
+
+def test_traffic_accounting_on_a_kernel_with_known_footprint(lib):
+    """simt_traffic_enable: requested bytes, 128-byte lines fetched per XCD (workgroup w on XCD w mod 8; a line an XCD has
+    written or read earlier in the launch is not fetched again), distinct 32-byte sectors written -- on a kernel whose
+    numbers can be counted by hand (tests/simt/race_selftest.hip: rk_traffic).  The race build of the product reports
+    the same quantities per kernel: tools/simt_traffic.py, profiles/r6_emulated_traffic.txt."""
+    a = np.zeros(4096, np.int32)
+    b = np.zeros(16 * 64 * 16, np.int32)
+    c = np.zeros(4096, np.int32)
+    # (128-byte aligned views: the line counts below assume it)
+    def aligned(x, n):
+        off = (-x.ctypes.data % 128) // 4
+        return x[off:off + n]
+    a, b, c = aligned(np.zeros(4096 + 32, np.int32), 4096), aligned(np.zeros(16 * 64 * 16 + 32, np.int32), 16 * 64 * 16), \
+        aligned(np.zeros(4096 + 32, np.int32), 4096)
+    a[:] = np.arange(4096)
+    lib.simt_traffic_report.restype = ctypes.c_int
+    lib.simt_traffic_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    lib.simt_race_enable(0)
+    lib.simt_traffic_reset()
+    lib.simt_traffic_enable(1)
+    try:
+        lib.rk_run(8, 0, a.ctypes.data, b.ctypes.data, c.ctypes.data)
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.simt_traffic_report(buf, len(buf), 0)
+    finally:
+        lib.simt_traffic_enable(0)
+        lib.simt_race_enable(1)
+    rows = [ln.split("\t") for ln in buf.value.decode().splitlines() if ln.startswith("K")]
+    assert len(rows) == 1 and rows[0][1] == "rk_traffic", rows
+    launches, wgs, req_ld, req_st, fetched, written = map(int, rows[0][2:8])
+    assert (launches, wgs) == (1, 16)
+    assert req_ld == 16 * 64 * 4 * 2 + 8 * 64 * 4            # table + a by everyone, c by the upper eight workgroups
+    assert req_st == 16 * 64 * 4 + 8 * 64 * 4                # b by everyone, c by the lower eight
+    assert fetched == 8 * 256 + 16 * 256                     # the table once per XCD; a streamed; c never (written there)
+    assert written == 16 * 64 * 32 + 8 * 64 * 4              # b: a sector per work-item; c: 8 x 256 contiguous bytes
+    v = np.arange(2048, 2048 + 64)
+    assert (b[::16][:64] == a[:64] + v).all() and (b[::16][8 * 64:9 * 64] == a[8 * 64:9 * 64] + v + a[:64] + v).all()
