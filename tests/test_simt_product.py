@@ -274,3 +274,94 @@ def test_segmentation_training_step_against_the_cpu_model():
     gb = torch.cat([p.grad.reshape(-1) for p in net_emu.parameters()]).double()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     assert 1.0 - cos < 2e-3, cos
+
+
+def _tiny_cls_cfg():
+    """the classifier of BASELINE configs[1] with its layer WIDTHS (what the kernels are specialised on) on a grid small
+    enough for the emulator: 3 Gridify layers 8^3 / 4^3 / 1 voxel, k = 3 / 3 / 1, P = 32 (the edge kernels want whole
+    32-row tiles per centre), O = 16 / 4 / 1"""
+    from grid_gcn_amd import model_cls
+    grid = dict(num_points=160, coord_shift=[1.0, 1.0, 1.0], loc=1, down=[
+        dict(voxel_size=[0.25] * 3, grid_size=[8] * 3, kernel_size=3, max_p_grid=32, max_o_grid=16),
+        dict(voxel_size=[0.5] * 3, grid_size=[4] * 3, kernel_size=3, max_p_grid=32, max_o_grid=4),
+        dict(voxel_size=[2.0] * 3, grid_size=[1] * 3, kernel_size=1, max_p_grid=32, max_o_grid=1)])
+    return dict(model_cls.CLS_MN40, grid=grid, dropout=0.0)
+
+
+def test_classifier_training_step_against_the_cpu_model():
+    """GGCNCls, forward + backward, through model_cls.py's own host code and every kernel of the classification path
+    (Gridify x 3, the context max / scatter, the two-source attention GEMMs with a bias per centre, the dZ segment sums,
+    the FC head) against the same net on the oracle's index operators and the stock modules.  The full-size GPU tests of
+    this net (tests/test_model_cls.py) cannot run here (144 GMAC per step); this is the whole graph at 3 x 160 points."""
+    from grid_gcn_amd import model_cls, synth
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(0)
+    cfg = _tiny_cls_cfg()
+    data, npn = synth.make_batch(3, 160, "ball")
+    npn = npn.copy()
+    npn[1, 0] = 131
+    net_cpu = model_cls.GGCNCls(cfg, index_ops=OracleIndexOps, fixed_seed=True).train()
+    net_emu = model_cls.GGCNCls(cfg, fixed_seed=True)
+    net_emu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    net_emu.train()
+    x, n = torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn)
+    lab = torch.tensor([3, 17, 39])
+    cov0 = emu.kernel_coverage()
+    loss = model_cls.cls_loss(net_emu(x, n), lab)
+    loss.backward()
+    cov1 = emu.kernel_coverage()
+    ran = {k.split("<")[0].strip() for k, v in cov1.items() if v > cov0.get(k, 0)}
+    assert {"gg_k_ctx_max", "gg_k_ctx_scatter", "gg_k_dz_segsum", "gg_k_small_build"} <= ran, sorted(ran)
+    del torch.Tensor.is_cuda                  # the reference outside the emulation: plain CPU tensors, stock path
+    try:
+        loss_cpu = model_cls.cls_loss(net_cpu(x, n), lab)
+        loss_cpu.backward()
+    finally:
+        torch.Tensor.is_cuda = property(lambda self: True)
+    assert abs(float(loss.detach()) - float(loss_cpu.detach())) <= 2e-5 * max(1.0, abs(float(loss_cpu.detach())))
+    ga = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    gb = torch.cat([p.grad.reshape(-1) for p in net_emu.parameters()]).double()
+    assert torch.isfinite(gb).all()
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert 1.0 - cos < 2e-3, cos
+
+
+def test_synth200k_net_training_step_against_the_cpu_model():
+    """GGCNSynth (BASELINE configs[4]: four GridConv down layers, K = P = 64, widths 64 / 128 / 256 / 512) on a grid the
+    emulator can afford -- 2 x 600 points, 8^3 / 4^3 / 2^3 / 1 voxels, O = 12 / 6 / 3 / 1 -- through model_synth.py's host code
+    and the down layers' attention kernels at P = 64 (the materialised-pre-activation backward `gg_k_att_bwd_fused`, which
+    the segmentation step of the test above only meets at P = 32) against the CPU model on the oracle's index operators"""
+    from grid_gcn_amd import model_synth, synth
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(0)
+    grid = dict(num_points=600, coord_shift=[1.0, 1.0, 1.0], loc=1, down=[
+        dict(voxel_size=[0.25] * 3, grid_size=[8] * 3, kernel_size=3, max_p_grid=64, max_o_grid=12),
+        dict(voxel_size=[0.5] * 3, grid_size=[4] * 3, kernel_size=3, max_p_grid=64, max_o_grid=6),
+        dict(voxel_size=[1.0] * 3, grid_size=[2] * 3, kernel_size=3, max_p_grid=64, max_o_grid=3),
+        dict(voxel_size=[2.0] * 3, grid_size=[1] * 3, kernel_size=1, max_p_grid=64, max_o_grid=1)])
+    cfg = dict(model_synth.SYNTH_200K, grid=grid)
+    data, npn = synth.make_batch(2, 600, "planes")
+    net_cpu = model_synth.GGCNSynth(cfg, index_ops=OracleIndexOps, fixed_seed=True).train()
+    net_emu = model_synth.GGCNSynth(cfg, fixed_seed=True)
+    net_emu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    net_emu.train()
+    x, n = torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn)
+    lab = torch.tensor([5, 33])
+    cov0 = emu.kernel_coverage()
+    loss = model_synth.synth_loss(net_emu(x, n), lab)
+    loss.backward()
+    cov1 = emu.kernel_coverage()
+    ran = {k.split("<")[0].strip() for k, v in cov1.items() if v > cov0.get(k, 0)}
+    assert {"gg_k_att_bwd_fused", "gg_k_small_build", "gg_k_query_gridify"} <= ran, sorted(ran)
+    del torch.Tensor.is_cuda
+    try:
+        loss_cpu = model_synth.synth_loss(net_cpu(x, n), lab)
+        loss_cpu.backward()
+    finally:
+        torch.Tensor.is_cuda = property(lambda self: True)
+    assert abs(float(loss.detach()) - float(loss_cpu.detach())) <= 2e-5 * max(1.0, abs(float(loss_cpu.detach())))
+    ga = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    gb = torch.cat([p.grad.reshape(-1) for p in net_emu.parameters()]).double()
+    assert torch.isfinite(gb).all()
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert 1.0 - cos < 2e-3, cos
