@@ -365,3 +365,96 @@ def test_synth200k_net_training_step_against_the_cpu_model():
     assert torch.isfinite(gb).all()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     assert 1.0 - cos < 2e-3, cos
+
+
+def _tiny_seg_cfg(base, **over):
+    """a segmentation config on a grid of 1024 points: down O = 128 / 32 / 8 (P = 32), up M = 32 / 128 / 1024 (P = 5) --
+    the layer widths and branch options of `base` (model.SEG_8192 / SEG_81920) untouched"""
+    grid = dict(num_points=1024, coord_shift=[1.0, 1.0, 1.0], loc=1,
+                down=[dict(voxel_size=[0.125] * 3, grid_size=[16] * 3, kernel_size=3, max_p_grid=32, max_o_grid=128),
+                      dict(voxel_size=[0.25] * 3, grid_size=[8] * 3, kernel_size=3, max_p_grid=32, max_o_grid=32),
+                      dict(voxel_size=[0.5] * 3, grid_size=[4] * 3, kernel_size=3, max_p_grid=32, max_o_grid=8)],
+                up=[dict(voxel_size=[0.5] * 3, grid_size=[4] * 3, kernel_size=3, max_p_grid=5, max_o_grid=32),
+                    dict(voxel_size=[0.25] * 3, grid_size=[8] * 3, kernel_size=3, max_p_grid=5, max_o_grid=128),
+                    dict(voxel_size=[0.125] * 3, grid_size=[16] * 3, kernel_size=3, max_p_grid=5, max_o_grid=1024)])
+    return dict(base, grid=grid, dropout=0.0, **over)
+
+
+SEG_VARIANTS = {
+    # name: (base config, config overrides, index operators (emulated, oracle), mode, loss bar, 1 - cos bar)
+    "seg81920_layers_train": ("SEG_81920", {}, ("HipIndexOps", "OracleIndexOps"), "train", 5e-6, 2e-3),
+    "gridify_up_variant_train": ("SEG_8192", dict(up_neigh_fetch=False), ("HipIndexOps", "OracleIndexOps"), "train", 5e-6, 2e-3),
+    "gridify_knn_variant_train": ("SEG_8192", {}, ("HipIndexOpsKNN", "OracleIndexOpsKNN"), "train", 5e-6, 2e-3),
+    "seg81920_layers_eval": ("SEG_81920", {}, ("HipIndexOps", "OracleIndexOps"), "eval", 2e-4, None),
+    "seg8192_layers_eval": ("SEG_8192", {}, ("HipIndexOps", "OracleIndexOps"), "eval", 2e-4, None),
+    # (bf16 operands: the gradient keeps its DIRECTION, cos > 0.9 -- the GPU tier's own bar for this mode,
+    #  test_bf16_mode_whole_model_loss_and_gradient_direction: a 0.4 % perturbation flips arg-maxima of the neighbour max)
+    "seg81920_layers_bf16_train": ("SEG_81920", {}, ("HipIndexOps", "OracleIndexOps"), "bf16", 3e-2, 1e-1),
+}
+
+
+@slow
+@pytest.mark.parametrize("name", list(SEG_VARIANTS))
+def test_segmentation_variants_against_the_cpu_model(name):
+    """the paths of GGCNSeg the fp32 training step above does not take, each against the CPU model on the oracle's index
+    operators: the 81 920-point net's layer family (localfdim = 3, no ReLU behind the max: the source-side first conv,
+    the Z2-free attention pair), the GridifyUp and GridifyKNN variants, the EVALUATION forward (BatchNorm folded, the
+    fused inference kernels, train/evalpath.py), bf16 operands (stated tolerance: the emulator adds a bf16 MFMA's sixteen
+    products in ascending k, the hardware's order is undocumented)"""
+    from grid_gcn_amd import model, synth
+    from grid_gcn_amd.train import common as tcommon
+    import oracle.torch_index_ops as oix
+    base, over, (hip_ix, orc_ix), mode, loss_bar, cos_bar = SEG_VARIANTS[name]
+    torch.manual_seed(0)
+    cfg = _tiny_seg_cfg(getattr(model, base), **over)
+    data, npn = synth.make_batch(2, 1024, "planes")
+    npn = npn.copy()
+    npn[1, 0] = 900
+    net_cpu = model.GGCNSeg(cfg, index_ops=getattr(oix, orc_ix), fixed_seed=True)
+    net_emu = model.GGCNSeg(cfg, index_ops=getattr(model, hip_ix), fixed_seed=True)
+    g = torch.Generator().manual_seed(3)
+    for m in net_cpu.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):          # (evaluation: running statistics that are not the identity)
+            m.weight.data.uniform_(0.5, 1.5, generator=g); m.bias.data.normal_(0, 0.3, generator=g)
+            m.running_mean.normal_(0, 0.2, generator=g); m.running_var.uniform_(0.5, 1.5, generator=g)
+    net_emu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    x, n = torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn)
+    lab = torch.randint(1, 21, (2, 1024))
+
+    def reference(fn):
+        del torch.Tensor.is_cuda
+        try:
+            return fn()
+        finally:
+            torch.Tensor.is_cuda = property(lambda self: True)
+
+    if mode == "eval":
+        net_cpu.eval(); net_emu.eval()
+        with torch.no_grad():
+            got = net_emu(x, n)
+            want = reference(lambda: net_cpu(x, n))
+        assert net_emu.last_tail_done == 2                  # the fused inference kernels ran, head included
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) <= loss_bar * scale
+        return
+    net_cpu.train(); net_emu.train()
+    if mode == "bf16":
+        tcommon.set_mlp_precision("bf16")
+    try:
+        loss = model.seg_loss(net_emu(x, n), lab)
+        loss.backward()
+    finally:
+        tcommon.set_mlp_precision("fp32")
+    assert net_emu.last_tail_done == 2                      # the training kernels ran, head included
+
+    def ref_step():
+        l = model.seg_loss(net_cpu(x, n), lab)
+        l.backward()
+        return l
+    loss_cpu = reference(ref_step)
+    assert abs(float(loss.detach()) - float(loss_cpu.detach())) <= loss_bar * max(1.0, abs(float(loss_cpu.detach())))
+    ga = torch.cat([p.grad.reshape(-1) for p in net_cpu.parameters()]).double()
+    gb = torch.cat([p.grad.reshape(-1) for p in net_emu.parameters()]).double()
+    assert torch.isfinite(gb).all()
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert 1.0 - cos < cos_bar, cos
