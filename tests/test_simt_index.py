@@ -219,7 +219,9 @@ def test_emulated_cfg2_batch32_gridify_chain(order):
     three Gridify layers of the classifier, chained as the model chains them: the index half of the GPU tier's
     test_cls_cfg2_batch32_gridify_bit_exact_and_eval_logits (written in round 6 with the GPU pool closed: this is its
     first execution).  One workgroup per cloud in gg_k_small_build, cloud b on XCD b mod 8 -- B = 32 is four clouds per
-    XCD, which no golden case has."""
+    XCD, which no golden case has.  Layer 0 (k = 7: 343 voxels per centre, a minute under emulation) with
+    GG_SIMT_FULL=1 only; the default tier runs layers 1 and 2 on the oracle's layer-0 centres."""
+    full = os.environ.get("GG_SIMT_FULL") == "1"
     cfg = synth.CLS_MODELNET40
     data, npn = synth.make_batch(32, 1024, "ball")
     npn = npn.copy()
@@ -230,8 +232,9 @@ def test_emulated_cfg2_batch32_gridify_chain(order):
         for l in range(3):
             kw = synth.gridify_kwargs(cfg, l, seed=3 + l)
             want = orc.gridify(d, n, **kw)
-            got = sim.Gridify(d, n, **kw)
-            _same(got, want, "cfg2 b32 layer %d" % l)
+            if l > 0 or full:
+                got = sim.Gridify(d, n, **kw)
+                _same(got, want, "cfg2 b32 layer %d" % l)
             d, n = want[2], want[4]
     finally:
         sim.set_order(0)

@@ -458,3 +458,35 @@ def test_segmentation_variants_against_the_cpu_model(name):
     assert torch.isfinite(gb).all()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
     assert 1.0 - cos < cos_bar, cos
+
+
+def test_classifier_evaluation_forward_against_the_cpu_model():
+    """GGCNCls in evaluation mode (running statistics folded, train/evalpath.py: edge_block_cls_eval, the FC head through
+    the plain GEMM) at the reduced grid of the training-step test, against the CPU model on the oracle's index operators"""
+    from grid_gcn_amd import model_cls, synth
+    from oracle.torch_index_ops import OracleIndexOps
+    torch.manual_seed(1)
+    cfg = _tiny_cls_cfg()
+    data, npn = synth.make_batch(3, 160, "ball")
+    net_cpu = model_cls.GGCNCls(cfg, index_ops=OracleIndexOps).eval()
+    g = torch.Generator().manual_seed(5)
+    for m in net_cpu.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5, generator=g); m.bias.data.normal_(0, 0.3, generator=g)
+            m.running_mean.normal_(0, 0.2, generator=g); m.running_var.uniform_(0.5, 1.5, generator=g)
+    net_emu = model_cls.GGCNCls(cfg).eval()
+    net_emu.load_state_dict(copy.deepcopy(net_cpu.state_dict()))
+    x, n = torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn)
+    cov0 = emu.kernel_coverage()
+    with torch.no_grad():
+        got = net_emu(x, n)
+        cov1 = emu.kernel_coverage()
+        del torch.Tensor.is_cuda
+        try:
+            want = net_cpu(x, n)
+        finally:
+            torch.Tensor.is_cuda = property(lambda self: True)
+    ran = {k.split("<")[0].strip() for k, v in cov1.items() if v > cov0.get(k, 0)}
+    assert "gg_k_ctx_max" in ran, sorted(ran)              # (the classification edge block's own kernels ran)
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= 2e-4 * scale, float((got - want).abs().max()) / scale
