@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64) void gg_k_query_up(const float4 *__restrict__ u
 // corners) fall to the wave-per-point routine above, one after the other, inside the same launch.
 #define GG_UP_MAXC 16
 template <int K>
-__global__ __launch_bounds__(256) void gg_k_query_up_lanes(const float4 *__restrict__ updata,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gg_k_query_up_lanes(const float4 *__restrict__ updata,
                                                            const int *__restrict__ up_np, int Nd,
                                                            GGGrid gp, GGQueryPtrs q, int total,
                                                            int *__restrict__ nebidx,
@@ -611,13 +611,26 @@ __global__ __launch_bounds__(256) void gg_k_query_up_lanes(const float4 *__restr
             } else {
                 int *cand = s_cand + tid * GG_UP_MAXC;
                 unsigned char *cnei = s_cnei + tid * GG_UP_MAXC;
+                // positions first (LDS only), then all M <= 16 ids in ONE round of loads: a load per (neighbour, item)
+                // iteration was up to sixteen memory round trips in a row for a lane (tools/isa_chains.py: 55 loops)
                 int pos = 0;
 #pragma unroll
                 for (int nei = 0; nei < K3; nei++)
                     for (int j = 0; j < vt[nei].y; j++) {
-                        cand[pos] = q.sorted[vt[nei].x + j];
+                        cand[pos] = vt[nei].x + j;
                         cnei[pos] = (unsigned char)nei;
                         pos++;
+                    }
+                // (two rounds of eight: sixteen at once cost 20 registers and a wave per SIMD; most points have M <= 8)
+#pragma unroll
+                for (int h8 = 0; h8 < GG_UP_MAXC; h8 += 8)
+                    if (M > h8) {
+                        int ids[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) ids[i] = q.sorted[cand[h8 + i < M ? h8 + i : 0]];   // (beyond M: a valid address)
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            if (h8 + i < M) cand[h8 + i] = ids[i];
                     }
                 int slot[8];
 #pragma unroll
