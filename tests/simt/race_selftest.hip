@@ -129,6 +129,29 @@ __global__ void rk_lds(int *out, int mode)
     }
 }
 
+// a barrier of PART of a workgroup built from an LDS counter (the shape of gridgcn_bwdfused.hip: half_barrier): waves 0 and
+// 1 exchange a buffer, waves 2 and 3 do not take part.  mode 0: no synchronisation at all (a race); mode 1: arrivals
+// counted by an atomic add after the wave's LDS stores have drained, then a poll -- ordered; mode 2: the poll without the
+// drain in front of the arrival is still a release in the emulator's model (documented blind spot: s_waitcnt is what makes
+// it one on the GPU), so it is not part of the test
+__global__ void rk_ldsbar(int *out, int mode)
+{
+    __shared__ int buf[128];
+    __shared__ int cnt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) cnt = 0;
+    __syncthreads();
+    if (wave < 2) {
+        buf[t] = t + 1;
+        if (mode == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2) __builtin_amdgcn_s_sleep(1);
+        }
+        out[blockIdx.x * 128 + t] = buf[(t + 64) % 128];
+    }
+}
+
 // traffic accounting (simt_traffic_enable): 16 workgroups (two per XCD: workgroup w on XCD w mod 8) of 64 work-items.
 //   every work-item reads ONE table of 64 ints (256 bytes = 2 lines) -> fetched once per XCD, not per workgroup: 8 x 256
 //   work-item t of workgroup w reads a[w * 64 + t] (streamed: 16 x 256 bytes, each line by one XCD)
@@ -161,5 +184,6 @@ extern "C" void rk_run(int which, int arg, int *a, int *b, int *c)
         rk_lds<<<2, 64, 64 * sizeof(int), st>>>(a, arg);
         break;
     case 8: rk_traffic<<<16, 64, 0, st>>>(a, b, c, a + 2048); break;
+    case 9: rk_ldsbar<<<2, 256, 0, st>>>(a, arg); break;
     }
 }

@@ -13,6 +13,10 @@
 //     * same wave and a cross-lane operation of the wave (ballot, shuffle, readlane, wave_barrier, s_waitcnt, a matrix
 //       instruction) lies between them (the lanes' counts of such operations differ) -- what the hardware's in-order
 //       LDS / memory pipeline gives a wave once the compiler is told not to move the accesses across that point, or
+//     * same workgroup, different waves, and the first wave RELEASED (an atomic read-modify-write or atomic store on an LDS
+//       location, executed after the access in the sense above) where the second ACQUIRED (an atomic load or read-modify-
+//       write of that location executed before its access): barriers of PART of a workgroup built from an LDS counter
+//       (gridgcn_bwdfused.hip: the four waves of a half count their arrivals and poll), or
 //     * different workgroups, and the first workgroup RELEASED (an atomic read-modify-write or atomic store executed
 //       after the access: a barrier, or a wave operation of the same wave, or the same work-item in between) on a
 //       location on which the second ACQUIRED (an atomic read-modify-write or atomic load executed before its access)
@@ -106,6 +110,13 @@ struct Edge { Rel rel; uint32_t acq_tid, acq_seq; uint16_t acq_bar; };  // ... a
 std::unordered_map<uintptr_t, std::map<uint32_t, Rel>> released;       // atomic location -> latest release per workgroup
 std::map<uint32_t, Edge> acquired;                                     // of the workgroup that is running
 uint32_t acquired_wg = ~0u, acquired_gen = 0;
+// ... and inside the running workgroup, through LDS atomics: location -> latest release per wave; per acquiring work-item
+// the latest edge from every releasing wave (checks are made when the later access happens, so the latest edge is the one
+// that covers the most)
+struct RelW { uint32_t tid, seq; uint16_t bar; };
+struct EdgeW { RelW rel; uint32_t acq_seq; uint16_t acq_bar; };
+std::unordered_map<uintptr_t, std::unordered_map<uint32_t, RelW>> lds_released;
+std::unordered_map<uint32_t, std::unordered_map<uint32_t, EdgeW>> lds_acquired;    // [work-item][releasing wave]
 
 std::vector<const void *> pcs(1, nullptr);
 std::unordered_map<const void *, uint32_t> pc_index;
@@ -239,6 +250,8 @@ inline void start_wg_if_new(uint32_t wg)
 {
     if (acquired_wg != wg || acquired_gen != cur_gen) {
         acquired.clear();
+        lds_released.clear();
+        lds_acquired.clear();
         acquired_wg = wg;
         acquired_gen = cur_gen;
     }
@@ -254,6 +267,29 @@ bool ordered_by_atomics(const Acc &A, uint32_t tid, uint16_t bar, uint32_t seq)
     const bool before_rel = A.bar < e.rel.bar || atid == e.rel.tid || ((atid >> 6) == (e.rel.tid >> 6) && A.seq < e.rel.seq);
     const bool after_acq = bar > e.acq_bar || tid == e.acq_tid || ((tid >> 6) == (e.acq_tid >> 6) && seq > e.acq_seq);
     return before_rel && after_acq;
+}
+
+// same workgroup, different waves: was access A released through an LDS atomic that work-item `tid` (or, in front of a
+// wave operation, another lane of its wave) has acquired?
+bool ordered_by_lds_atomics(const Acc &A, uint32_t tid, uint32_t seq)
+{
+    const uint32_t atid = A.wg_tid & 1023, aw = atid >> 6;
+    auto covers = [&](const EdgeW &e) {
+        return A.bar < e.rel.bar || atid == e.rel.tid || A.seq < e.rel.seq;       // (A's wave is the releasing wave)
+    };
+    auto it = lds_acquired.find(tid);
+    if (it != lds_acquired.end()) {
+        auto jt = it->second.find(aw);
+        if (jt != it->second.end() && covers(jt->second)) return true;
+    }
+    for (uint32_t l = (tid & ~63u); l < (tid & ~63u) + 64; l++) {                  // a lane of my wave, then a wave operation
+        if (l == tid) continue;
+        auto lt = lds_acquired.find(l);
+        if (lt == lds_acquired.end()) continue;
+        auto jt = lt->second.find(aw);
+        if (jt != lt->second.end() && seq > jt->second.acq_seq && covers(jt->second)) return true;
+    }
+    return false;
 }
 
 // a store that conflicts with an earlier store: what does it write?  The hook runs BEFORE the store, so the location is
@@ -313,6 +349,7 @@ inline void check(const Acc &A, const Acc &B, uintptr_t addr, bool lds, unsigned
             if (A.seq != B.seq) return;
             report(1, A, B, addr, lds, gran);
         } else {
+            if (ordered_by_lds_atomics(A, tb, B.seq)) return;
             report(0, A, B, addr, lds, gran);
         }
         return;
@@ -403,9 +440,27 @@ __attribute__((noinline)) void simt_race_atomic(const void *p, int size, int kin
     }
     if (kind != 3) access(p, size, false, true, pc);
     if (kind != 2) access(p, size, true, true, pc);
-    if (is_lds((uintptr_t)p)) return;
     const uint32_t wg = (uint32_t)simt_wg_serial & 0x3fffff, tid = (uint32_t)(f - simt_fibers.data());
     start_wg_if_new(wg);
+    if (is_lds((uintptr_t)p)) {
+        auto &relw = lds_released[(uintptr_t)p];
+        const uint32_t w = tid >> 6;
+        if (kind != 3) {
+            auto &mine = lds_acquired[tid];
+            for (auto &kv : relw)
+                if (kv.first != w) mine[kv.first] = EdgeW{kv.second, (uint32_t)f->seq, (uint16_t)f->bar};
+            // transitive: what the releasing work-items had acquired themselves travels with their release
+            for (auto &kv : relw) {
+                if (kv.first == w) continue;
+                auto rt = lds_acquired.find(kv.second.tid);
+                if (rt == lds_acquired.end() || rt->first == tid) continue;
+                for (auto &e : rt->second)
+                    if (e.first != w && !mine.count(e.first)) mine[e.first] = EdgeW{e.second.rel, (uint32_t)f->seq, (uint16_t)f->bar};
+            }
+        }
+        if (kind != 2) relw[w] = RelW{tid, (uint32_t)f->seq, (uint16_t)f->bar};
+        return;
+    }
     auto &rel = released[(uintptr_t)p];
     if (kind != 3)
         for (auto &kv : rel) {
@@ -440,6 +495,8 @@ void simt_race_launch_end()
     flush_pending();
     released.clear();
     acquired.clear();
+    lds_released.clear();
+    lds_acquired.clear();
     acquired_wg = ~0u;
     if (sh_word.pages.size() + sh_byte.pages.size() > 16384) {   // ~ 0.8 GB of shadow: start afresh
         sh_word.clear();

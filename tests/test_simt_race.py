@@ -116,6 +116,19 @@ def test_uninitialised_lds_and_lds_beyond_the_block(lib):
     assert (out[:64] == (63 - np.arange(64)) + 4).all()
 
 
+def test_partial_barrier_from_an_lds_counter(lib):
+    """two of a workgroup's four waves exchange a buffer behind a barrier of their own -- arrivals counted by an LDS atomic,
+    then a poll (gridgcn_bwdfused.hip: half_barrier).  Without it: INTRA, both directions; with it: ordered, silent, and
+    the exchanged values are the partner's."""
+    rep, (out, _, _) = run(lib, 9, 0)
+    st, ld = line_of(r"buf\[t\] = t \+ 1;", 2), line_of(r"= buf\[\(t \+ 64\) % 128\];")
+    assert {(r[0], r[1]) for r in rep} == {("INTRA", "rk_ldsbar")}, rep
+    assert {(r[2], r[3]) for r in rep} <= {(st, ld), (ld, st)}, rep
+    rep, (out, _, _) = run(lib, 9, 1)
+    assert rep == [], rep
+    assert (out[:128] == (np.arange(128) + 64) % 128 + 1).all()
+
+
 def test_traffic_accounting_on_a_kernel_with_known_footprint(lib):
     """simt_traffic_enable: requested bytes, 128-byte lines fetched per XCD (workgroup w on XCD w mod 8; a line an XCD has
     written or read earlier in the launch is not fetched again), distinct 32-byte sectors written -- on a kernel whose
