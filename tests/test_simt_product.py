@@ -490,3 +490,17 @@ def test_classifier_evaluation_forward_against_the_cpu_model():
     assert "gg_k_ctx_max" in ran, sorted(ran)              # (the classification edge block's own kernels ran)
     scale = max(1.0, float(want.abs().max()))
     assert float((got - want).abs().max()) <= 2e-4 * scale, float((got - want).abs().max()) / scale
+
+
+@slow
+def test_smoke_entry_point_body(monkeypatch):
+    """__graft_entry__.smoke() as the driver runs it at round end -- Gridify and BallKNN against the oracle, one training
+    step of the segmentation net against the CPU model -- with the emulator in place of cuda:0 (270 s)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("graft_entry_emu", os.path.join(root, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    _to_cpu(mod.smoke)()
