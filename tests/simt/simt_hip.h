@@ -21,6 +21,7 @@
 //   * a shuffle that reads a lane outside its group is counted (simt_foreign_reads): a kernel relying on it would
 //     read a stale register on the GPU as well.
 #pragma once
+#include <time.h>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -88,12 +89,25 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// events hold the host's clock (launches are synchronous): an elapsed time is the emulation's wall time -- never zero, so
+// that the library's *_timed entries and bench.py's arithmetic on them can be executed here (tools/simt_bench.py)
 typedef void *hipEvent_t;
-static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (void *)1; return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new double(0.0); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete (double *)e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t)
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    *(double *)e = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    return hipSuccess;
+}
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
+{
+    *ms = (float)(*(double *)b - *(double *)a);
+    if (!(*ms > 0.f)) *ms = 1e-6f;
+    return hipSuccess;
+}
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 // ---- scheduler --------------------------------------------------------------------------------------------------

@@ -504,3 +504,16 @@ def test_smoke_entry_point_body(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     _to_cpu(mod.smoke)()
+
+
+@slow
+def test_bench_main_on_the_emulator():
+    """bench.py's main() -- the program the driver runs at round end -- executed with the emulator in place of cuda:0 at
+    1 x 1024 points (tools/simt_bench.py): the line it prints carries the contract's fields"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import simt_bench
+    line = simt_bench.run(["--config", "cfg3", "--batch", "1", "--points", "1024", "--no-micro"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_step", "ms_per_cagq_layer"):
+        assert k in line, k
+    assert line["step_mode"] == "eager" and line["value"] > 0 and line["config"]["points_per_cloud"] == 1024

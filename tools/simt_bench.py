@@ -1,0 +1,83 @@
+"""bench.py's main() with the emulator in place of cuda:0 (no GPU needed): the whole driver-facing program -- argument
+handling, the training step, the timing brackets, the micro-benchmarks, the JSON line -- EXECUTED at a batch / cloud size
+the emulator can afford.  Nothing it prints is a measurement (a "millisecond" here is the emulation's wall clock); what it
+shows is that the program runs to its last line and that the line has every field.  TEST INFRASTRUCTURE.
+
+    python tools/simt_bench.py cfg3 --batch 1 --points 1024 --no-micro           # bench_configs.py's path, ~4 minutes
+    python tools/simt_bench.py cfg4 --batch 1 --points 1024 --micro-iters 1      # the headline path with its micro-benchmarks
+
+Always eager (a hipGraph cannot be captured here), never the CPU baseline."""
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from simt import emu  # noqa: E402
+
+
+class _Event(emu._Event):
+    t = 0.0
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return max((other.t - self.t) * 1e3, 1e-6)
+
+
+class _TorchProxy(types.ModuleType):
+    """`torch` as bench.py sees it: every device is the CPU"""
+
+    def __init__(self):
+        super().__init__("torch_proxy")
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    @staticmethod
+    def device(*a, **k):
+        return torch.device("cpu")
+
+
+def run(argv):
+    """bench.main() under emulated_gpu(); returns the JSON line it printed"""
+    import contextlib
+    import io
+    import json
+    import bench
+    import bench_configs
+    import test_simt_product as P
+    px = _TorchProxy()
+    saved = (bench.torch, bench_configs.torch, torch.cuda.is_available, torch.cuda.set_device, torch.cuda.device_count,
+             sys.argv)
+    bench.torch = bench_configs.torch = px
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.device_count = lambda: 1
+    sys.argv = ["bench.py"] + list(argv) + ["--steps", "1", "--warmup", "0", "--eager", "--no-cpu-baseline"]
+    buf = io.StringIO()
+    try:
+        with emu.emulated_gpu(poison=False):
+            torch.cuda.Event = _Event
+            with contextlib.redirect_stdout(buf):
+                P._to_cpu(bench.main)()
+    finally:
+        (bench.torch, bench_configs.torch, torch.cuda.is_available, torch.cuda.set_device, torch.cuda.device_count,
+         sys.argv) = saved
+    return json.loads(buf.getvalue().strip().splitlines()[-1])
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    args = sys.argv[1:]
+    if args and not args[0].startswith("-"):
+        args = ["--config", args[0]] + args[1:]
+    line = run(args)
+    import json
+    print(json.dumps(line))
+    print("bench.main() on the emulator: ran to its last line in %.0f s; keys: %s" % (time.time() - t0, sorted(line)),
+          file=sys.stderr)
