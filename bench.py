@@ -301,10 +301,13 @@ def cagq_roofline(d4, n, kw, B, N, traffic, key, iters=100):
     ms, _ = ops.gridify_timed(d4, n, iters, **kw)
     alg = B * synth.gridify_algorithmic_bytes(N, kw["max_o_grid"], kw["max_p_grid"])
     ach = alg / (ms * 1e-3) / 1e9
+    # (clouds of <= 4096 points take the one-launch build: csrc/gridgcn_index.hip, GRIDGCN_OPT_INDEX_SMALL)
+    from grid_gcn_amd import _lib as _glib
+    small = N <= 4096 and kw["max_o_grid"] <= 4096 and _glib.load().gridgcn_get_option(_glib.OPT_INDEX_SMALL) != 0
+    build = "gg_k_small_build" if small else "gg_k_chunk_split + gg_k_slab_build + gg_k_centre_slots"
     return ms, {"bound": "hbm",
-                "kernel": "gridgcn_gridify (gg_k_chunk_split + gg_k_slab_build + gg_k_centre_slots "
-                          "+ gg_k_query_gridify; %d back-to-back calls between two HIP events on "
-                          "the launch stream)" % iters,
+                "kernel": "gridgcn_gridify (%s + gg_k_query_gridify; %d back-to-back calls between two HIP events on "
+                          "the launch stream)" % (build, iters),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic.get(key), "traffic_key": key,
                 "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms}
