@@ -6,6 +6,9 @@ shows is that the program runs to its last line and that the line has every fiel
     python tools/simt_bench.py cfg3 --batch 1 --points 1024 --no-micro           # bench_configs.py's path, ~4 minutes
     python tools/simt_bench.py cfg4 --batch 1 --points 1024 --micro-iters 1      # the headline path with its micro-benchmarks
 
+Two ranks over gloo (the N > 1 path: FlatGradAllReduce, ranks_agree, the max over ranks, param_sync_spread):
+    for r in 0 1; do MASTER_ADDR=127.0.0.1 MASTER_PORT=29731 WORLD_SIZE=2 RANK=$r LOCAL_RANK=$r GG_DIST_BACKEND=gloo \
+        python tools/simt_bench.py cfg3 --gpus 2 --batch 1 --points 1024 --no-micro & done; wait
 Always eager (a hipGraph cannot be captured here), never the CPU baseline."""
 import os
 import sys
@@ -68,7 +71,8 @@ def run(argv):
     finally:
         (bench.torch, bench_configs.torch, torch.cuda.is_available, torch.cuda.set_device, torch.cuda.device_count,
          sys.argv) = saved
-    return json.loads(buf.getvalue().strip().splitlines()[-1])
+    out = buf.getvalue().strip().splitlines()
+    return json.loads(out[-1]) if out else None       # (a rank other than 0 prints nothing)
 
 
 if __name__ == "__main__":
@@ -78,6 +82,7 @@ if __name__ == "__main__":
         args = ["--config", args[0]] + args[1:]
     line = run(args)
     import json
-    print(json.dumps(line))
-    print("bench.main() on the emulator: ran to its last line in %.0f s; keys: %s" % (time.time() - t0, sorted(line)),
-          file=sys.stderr)
+    if line is not None:
+        print(json.dumps(line))
+    print("bench.main() on the emulator: ran to its last line in %.0f s; keys: %s" % (
+        time.time() - t0, sorted(line) if line else "(no line: not rank 0)"), file=sys.stderr)
