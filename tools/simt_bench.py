@@ -9,7 +9,9 @@ shows is that the program runs to its last line and that the line has every fiel
 Two ranks over gloo (the N > 1 path: FlatGradAllReduce, ranks_agree, the max over ranks, param_sync_spread):
     for r in 0 1; do MASTER_ADDR=127.0.0.1 MASTER_PORT=29731 WORLD_SIZE=2 RANK=$r LOCAL_RANK=$r GG_DIST_BACKEND=gloo \
         python tools/simt_bench.py cfg3 --gpus 2 --batch 1 --points 1024 --no-micro & done; wait
-Always eager (a hipGraph cannot be captured here), never the CPU baseline."""
+Eager unless --graph (a stand-in for torch.cuda.CUDAGraph whose capture runs its body once and whose replay does
+nothing: graph.py's GraphedTrainStep and bench.py's graph branch then execute -- four training steps); never the CPU
+baseline."""
 import os
 import sys
 import time
@@ -46,7 +48,17 @@ class _TorchProxy(types.ModuleType):
         return torch.device("cpu")
 
 
-def run(argv):
+class _FakeGraph:
+    """--graph: stands in for torch.cuda.CUDAGraph so that graph.py's GraphedTrainStep and bench.py's graph branch EXECUTE:
+    the "capture" runs its body once, eagerly (as a capture does on the host side); a replay does nothing -- the step a
+    replay would repeat has been run by the capture, which is all that can be checked without a GPU"""
+    replays = 0
+
+    def replay(self):
+        _FakeGraph.replays += 1
+
+
+def run(argv, graph=False):
     """bench.main() under emulated_gpu(); returns the JSON line it printed"""
     import contextlib
     import io
@@ -61,7 +73,11 @@ def run(argv):
     torch.cuda.is_available = lambda: True
     torch.cuda.set_device = lambda *a, **k: None
     torch.cuda.device_count = lambda: 1
-    sys.argv = ["bench.py"] + list(argv) + ["--steps", "1", "--warmup", "0", "--eager", "--no-cpu-baseline"]
+    sys.argv = ["bench.py"] + list(argv) + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + ([] if graph else ["--eager"])
+    saved_graph = (torch.cuda.CUDAGraph, torch.cuda.graph)
+    if graph:
+        torch.cuda.CUDAGraph = _FakeGraph
+        torch.cuda.graph = lambda g, **kw: contextlib.nullcontext()
     buf = io.StringIO()
     try:
         with emu.emulated_gpu(poison=False):
@@ -71,6 +87,7 @@ def run(argv):
     finally:
         (bench.torch, bench_configs.torch, torch.cuda.is_available, torch.cuda.set_device, torch.cuda.device_count,
          sys.argv) = saved
+        torch.cuda.CUDAGraph, torch.cuda.graph = saved_graph
     out = buf.getvalue().strip().splitlines()
     return json.loads(out[-1]) if out else None       # (a rank other than 0 prints nothing)
 
@@ -78,9 +95,11 @@ def run(argv):
 if __name__ == "__main__":
     t0 = time.time()
     args = sys.argv[1:]
+    use_graph = "--graph" in args
+    args = [x for x in args if x != "--graph"]
     if args and not args[0].startswith("-"):
         args = ["--config", args[0]] + args[1:]
-    line = run(args)
+    line = run(args, graph=use_graph)
     import json
     if line is not None:
         print(json.dumps(line))
