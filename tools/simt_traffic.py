@@ -1,6 +1,8 @@
 """Memory traffic of the kernels, COUNTED on the emulator (no GPU needed):
 
-    python tools/simt_traffic.py gridify [cfg4|cfg5|cfg3|cfg1] [--batch B] [--lines]   ->  profiles/r6_emulated_traffic.txt
+    python tools/simt_traffic.py gridify [cfg4|cfg5|cfg3] [--batch B] [--lines N]   ->  profiles/r6_emulated_traffic.txt
+    python tools/simt_traffic.py att_bwd [--ncent N]                               (the Z2-free attention backward, per edge)
+    python tools/simt_traffic.py step                                              ->  profiles/r6_emulated_step_lines.txt
 
 The race build of the emulated library (tests/simt/simt_race.cpp) sees every global load and store of every work-item
 with its address.  With the race checks off and `simt_traffic_enable(1)` it keeps, per launch, which 128-byte lines each
@@ -67,12 +69,6 @@ def report(per_pc=False):
         pairs = [ln.strip() for ln in sym.splitlines() if ln.strip()]
         funcs, locs = pairs[0::2], pairs[1::2]
         for r, fn, l in zip(prow, funcs, locs):
-            if "$_" in fn or "_ZNSt" in fn or "_ZSt" in fn:
-                # the launch statement's closure (`[&] { k(args); }`: by-value kernel arguments copied per work-item --
-                # SGPRs on the GPU) and the std:: plumbing of the emulator's scheduler: not device memory traffic
-                k = ker[r[1]]
-                k["req_ld"] -= int(r[4]); k["req_st"] -= int(r[5]); k["fetched"] -= int(r[6]); k["written"] -= int(r[7])
-                continue
             f, _, rest = os.path.basename(l).partition(":")
             ln = rest.split(":")[0]
             if f.endswith(".simt.cpp") and ln.isdigit():
@@ -175,9 +171,41 @@ def att_bwd(ncent, top):
         print("%-24s %5s | %14.1f %14.3f | %14.1f %14.3f |" % ("total", "", tf, ff, tw, fw))
 
 
+def step():
+    """one training step (forward + backward) of the segmentation net's 81 920-point layer family on the reduced grid of
+    tests/test_simt_product.py (2 x 1024 points): every kernel of the step with the bytes it requests, fetches and
+    writes.  At this size the per-launch constants (operand staging, partial tiles) dominate, so the table says nothing
+    about the step's traffic at BASELINE size; what it is for is LINE UTILISATION -- a kernel that fetches much more than
+    it requests reads 4-byte items out of 128-byte lines or re-reads the same lines from several XCDs"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import test_simt_product as P
+    from grid_gcn_amd import model
+    torch.manual_seed(0)
+    cfg = P._tiny_seg_cfg(model.SEG_81920)
+    data, npn = synth.make_batch(2, 1024, "planes")
+    with emu.emulated_gpu(poison=False):
+        net = model.GGCNSeg(cfg, fixed_seed=True).train()
+        x, n = torch.from_numpy(data[..., :3].copy()), torch.from_numpy(npn)
+        lab = torch.randint(1, 21, (2, 1024))
+        start()
+        model.seg_loss(net(x, n), lab).backward()
+        ker, _ = report()
+    agg = collections.OrderedDict()
+    for k, v in ker.items():
+        agg.setdefault(short(k), collections.Counter()).update(v)
+    print("# one training step of GGCNSeg (81 920-point layer family) at 2 x 1024 points on the emulator: MB per step, per kernel;")
+    print("# f/r = fetched / requested loads, w/r = written / requested stores.  Line utilisation only -- see tools/simt_traffic.py: step")
+    print("%-30s %5s | %9s %9s | %9s %9s | %6s %6s" % ("kernel", "n", "req ld", "req st", "fetched", "written", "f/r", "w/r"))
+    for k, a in sorted(agg.items(), key=lambda kv: -(kv[1]["fetched"] + kv[1]["written"])):
+        print("%-30s %5d | %9.3f %9.3f | %9.3f %9.3f | %6.2f %6.2f" % (
+            k, a["launches"], a["req_ld"] / 1e6, a["req_st"] / 1e6, a["fetched"] / 1e6, a["written"] / 1e6,
+            a["fetched"] / max(a["req_ld"], 1), a["written"] / max(a["req_st"], 1)))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gridify", "att_bwd"])
+    ap.add_argument("what", choices=["gridify", "att_bwd", "step"])
     ap.add_argument("cfg", nargs="?", default="cfg4")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--layer", type=int, default=0)
@@ -187,6 +215,8 @@ def main():
     a = ap.parse_args()
     if a.what == "att_bwd":
         return att_bwd(a.ncent, a.lines)
+    if a.what == "step":
+        return step()
     grids = {"cfg4": (synth.SEG_SCANNET_81920, 81920, 8, "planes", "gridify_N81920_B8"),
              "cfg3": (synth.SEG_SCANNET_8192, 8192, 16, "planes", None),
              "cfg5": (synth.SYNTH_200K, 200000, 8, "planes", "gridify_N200000_B8")}
