@@ -51,9 +51,11 @@ def test_cls_model_hip_index_ops_match_oracle_path():
     assert dist <= CLS_EVAL_BAR, dist
 
 
-# TODO(r6, after the first GPU session): 3 x the distances the two eval tests print into GG_PARITY_REPORT
-# (relative to max(1, max|logit|)); until then the round-5 bar
-CLS_EVAL_BAR = 2e-3
+# Measured on the EMULATOR (no GPU in round 6; profiles/r6_float_parity.txt): 2.8e-9 relative to max(1, max|logit|) at cfg2's
+# batch of 32 -- the evaluation forward has no atomics and the emulated fp32 MFMA is the hardware's k-ordered chain, so the
+# GPU's figure is expected to be the same to within a few ulp.  The bar is that x 350 until a GPU session prints its own
+# figure into GG_PARITY_REPORT (then: 3 x it).  It was 2e-3 with no measurement behind it.
+CLS_EVAL_BAR = 1e-6
 
 
 @pytest.mark.gpu
