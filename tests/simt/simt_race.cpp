@@ -407,6 +407,10 @@ void access(const void *p, unsigned size, bool write, bool atomic, const void *p
         !(a - (uintptr_t)simt_dyn_lds < simt_lds_buf.size() - (size_t)(simt_dyn_lds - simt_lds_buf.data())))
         traffic(a, size, write, pc);
     if (!enabled) return;
+    // the emulator's own state (the exchange buffers of the emulated cross-lane and matrix operations, threadIdx & co.,
+    // the fibre records) is not device memory: the bf16 matrix instruction's operand exchange showed as INTER rows of
+    // every bf16 kernel.  (The product has no __device__ globals; static __shared__ variables are recognised first.)
+    if (!is_lds(a) && is_emulator_state(a)) return;
     n_access++;
     cur_gen = (uint32_t)simt_launches;
     const uint32_t wg = (uint32_t)simt_wg_serial & 0x3fffff, tid = (uint32_t)(f - simt_fibers.data());
