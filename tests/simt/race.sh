@@ -8,6 +8,7 @@ OUT=${1:-profiles/r6_race_report.txt}; shift
 COV=${OUT%/*}/r6_simt_kernel_coverage.txt
 python tests/simt/build.py --race > /dev/null || exit 1
 export GG_SIMT_RACE=1 GG_SIMT_FULL=${GG_SIMT_FULL:-1} GG_SIMT_COVERAGE=/tmp/simt_cov_raw.txt
+FINAL=$OUT; OUT=/tmp/simt_race_report.$$.txt      # (an hour of runs: the report appears under profiles/ when it is whole)
 : > "$OUT"; : > $GG_SIMT_COVERAGE
 for t in ${@:-tests/test_simt_index.py tests/test_simt_train.py tests/test_simt_product.py}; do
   GG_SIMT_RACE_REPORT=/tmp/simt_race_part.txt python -m pytest -q -p no:cacheprovider "$t" | tail -1 > /tmp/simt_race_pytest.txt
@@ -28,4 +29,5 @@ print("# kernels of grid_gcn_amd/csrc launched by the emulator suites (tests/sim
 for k in sorted(allk, key=lambda k: (allk[k], k)):
     print("%-26s %-34s %d" % (allk[k], k, cov.get(k, 0)))
 PY
-cat "$OUT"; head -1 "$COV"
+mv "$OUT" "$FINAL"
+cat "$FINAL"; head -1 "$COV"
