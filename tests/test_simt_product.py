@@ -164,6 +164,13 @@ MORE_BODIES = [
     ("test_gpu_train_ops", "test_mlp_train_matches_torch", (300, 100, [64, 16])),    # LDS-staged dW
     ("test_gpu_train_ops", "test_mlp_train_matches_torch", (150, 7, [4, 2])),        # the first-generation GEMM family
     ("test_gpu_train_ops", "test_pack_cache_batch_launch_equals_single_packs", ()),
+    ("test_gpu_glue", "test_adam_state_dict_round_trip_and_tensor_lr", ()),
+    ("test_gpu_glue", "test_adam_second_checkpoint_carries_the_advanced_step", ()),     # (round 6: never ran on a GPU)
+    ("test_gpu_glue", "test_adam_checkpoints_travel_to_and_from_torch_adam", ()),
+    ("test_gpu_fuzz", "test_gridconv_training_block_random_shapes", (0,)),              # random (O, P, widths) blocks
+    ("test_gpu_fuzz", "test_gridconv_training_block_random_shapes", (1,)),
+    ("test_gpu_fuzz", "test_gridconv_training_block_random_shapes", (2,)),
+    ("test_gpu_fuzz", "test_gridconv_training_block_random_shapes", (3,)),
     pytest.param("test_gpu_train_ops", "test_linear_bwd_fused128_matches_separate_kernels", (32768, 128, True, 0),
                  marks=slow),
     pytest.param("test_gpu_gridconv", "test_full_model_eval_fused_vs_torch", (), marks=slow),
