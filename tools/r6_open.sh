@@ -25,3 +25,13 @@ import json
 d=json.loads(open('$OUT/bench_cfg4_driver_cmd.json').read().strip().splitlines()[-1])
 print({k:d[k] for k in ('value','ms_per_step','step_mode','ms_per_cagq_layer') if k in d})
 PY
+# the other BASELINE configs at HEAD (round 6 touched gg_k_ctx_max / gg_k_dz_segsum of the classifier and gg_k_query_up_lanes of
+# the GridifyUp path: round-5 figures cfg2 16.44 ms, cfg3up 4.25 ms, cfg3 4.24 ms, cfg5 21.02 ms)
+for cfg in cfg2 cfg3up cfg3 cfg5; do
+  st=30; [ $cfg = cfg5 ] && st=10
+  timeout 600 python bench.py --config $cfg --steps $st --warmup 5 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+  echo "== $cfg rc=$?"; python -c "
+import json
+d=json.loads(open('$OUT/bench_$cfg.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','step_mode','ms_per_cagq_layer') if k in d})"
+done
