@@ -622,12 +622,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
                         pos++;
                     }
                 // (two rounds of eight: sixteen at once cost 20 registers and a wave per SIMD; most points have M <= 8)
+                const int pos0 = M > 0 ? cand[0] : 0;          // (beyond M: a valid position, its value unused)
 #pragma unroll
                 for (int h8 = 0; h8 < GG_UP_MAXC; h8 += 8)
                     if (M > h8) {
                         int ids[8];
 #pragma unroll
-                        for (int i = 0; i < 8; i++) ids[i] = q.sorted[cand[h8 + i < M ? h8 + i : 0]];   // (beyond M: a valid address)
+                        for (int i = 0; i < 8; i++) ids[i] = q.sorted[h8 + i < M ? cand[h8 + i] : pos0];
 #pragma unroll
                         for (int i = 0; i < 8; i++)
                             if (h8 + i < M) cand[h8 + i] = ids[i];
