@@ -203,9 +203,37 @@ def step():
             a["fetched"] / max(a["req_ld"], 1), a["written"] / max(a["req_st"], 1)))
 
 
+def linear_fwd(E):
+    """the 256 -> 128 forward conv of the per-point update layer (gridgcn_linear_fwd_direct: the BatchNorm + ReLU of the
+    layer in front applied while loading, statistics epilogue) at E and 2 E rows: bytes per ROW next to the round-5
+    counters at cfg4's 655 360 rows (profiles/traffic.json: linear_fwd_E655360_256to128).  Algorithmic: 1024 B read
+    (256 fp32 inputs) + 512 B written (128 outputs) per row."""
+    import torch
+    from grid_gcn_amd.train import timers as ttimers
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["linear_fwd_E655360_256to128_detail"]
+    res = {}
+    with emu.emulated_gpu(poison=False):
+        torch.cuda.Event = type("E", (emu._Event,), {"elapsed_time": lambda self, o: 1.0})
+        for rows in (E, 2 * E):
+            start()
+            ttimers.time_linear_fwd(rows, 256, 128, iters=1, device="cpu")
+            ker, _ = report()
+            k = next(v for kk, v in ker.items() if kk.startswith("gg_k_linear_fwd_direct"))
+            res[rows] = k
+    a, b = res[E], res[2 * E]
+    print("# gridgcn_linear_fwd_direct 256 -> 128, emulated at %d and %d rows (%d / %d launches of the kernel: warm-up + timed):"
+          " bytes per ROW and launch" % (E, 2 * E, a["launches"], b["launches"]))
+    for name, key in (("fetched", "fetched"), ("written", "written"), ("requested loads", "req_ld")):
+        pa, pb = a[key] / a["launches"], b[key] / b["launches"]
+        slope = (pb - pa) / E
+        print("%-16s %8.1f B per row + %.3f MB per launch" % (name, slope, (pa - slope * E) / 1e6))
+    m = next(iter(pmc.values()))
+    print("round-5 PMC at 655 360 rows: fetch %.1f B per row, write %.1f B per row" % (m["fetch_bytes"] / 655360, m["write_bytes"] / 655360))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gridify", "att_bwd", "step"])
+    ap.add_argument("what", choices=["gridify", "att_bwd", "step", "linear_fwd"])
     ap.add_argument("cfg", nargs="?", default="cfg4")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--layer", type=int, default=0)
@@ -217,6 +245,8 @@ def main():
         return att_bwd(a.ncent, a.lines)
     if a.what == "step":
         return step()
+    if a.what == "linear_fwd":
+        return linear_fwd(a.ncent)
     grids = {"cfg4": (synth.SEG_SCANNET_81920, 81920, 8, "planes", "gridify_N81920_B8"),
              "cfg3": (synth.SEG_SCANNET_8192, 8192, 16, "planes", None),
              "cfg5": (synth.SYNTH_200K, 200000, 8, "planes", "gridify_N200000_B8")}
