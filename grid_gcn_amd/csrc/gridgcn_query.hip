@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void g
             } else {
                 int *cand = s_cand + tid * GG_UP_MAXC;
                 unsigned char *cnei = s_cnei + tid * GG_UP_MAXC;
-                // positions first (LDS only), then all M <= 16 ids in ONE round of loads: a load per (neighbour, item)
+                // positions first (LDS only), then the M <= 16 ids in rounds of eight loads: a load per (neighbour, item)
                 // iteration was up to sixteen memory round trips in a row for a lane (tools/isa_chains.py: 55 loops)
                 int pos = 0;
 #pragma unroll
